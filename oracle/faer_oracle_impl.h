@@ -1,0 +1,770 @@
+/*
+ * CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ *
+ * Type-generic body of the oracle; included twice by faer_oracle.c with
+ *   T    = double / float
+ *   FN() = name##_f64 / name##_f32
+ *
+ * Every routine restates, in plain C, the algorithm that faer 0.24.4 runs on
+ * the CPU for the hot path.  Citations are
+ * file:line under /root/reference/faer/src/linalg unless stated otherwise.
+ *
+ * Parity status: the GEMM arithmetic of the reference lives in unvendored
+ * crates (private-gemm-x86 0.1.20 / gemm 0.19.0 / nano-gemm 0.2.2), so no
+ * golden vector pins its summation order => bitwise parity is UNPINNED and
+ * everything here is pinned at tolerance level only: against the reference's
+ * known-answer test (qr/mod.rs:116-191), its 2x2 matmul doctests
+ * (matmul/mod.rs:1595-1614) and LAPACK (scipy) residual checks.
+ */
+
+typedef struct {
+	T *p;
+	long nrows, ncols, rs, cs;
+} FN(mat);
+
+#define AT(M, i, j) ((M).p[(long)(i) * (M).rs + (long)(j) * (M).cs])
+
+static inline FN(mat) FN(sub)(FN(mat) a, long r0, long c0, long nr, long nc)
+{
+	FN(mat) r;
+	r.p = a.p + r0 * a.rs + c0 * a.cs;
+	r.nrows = nr;
+	r.ncols = nc;
+	r.rs = a.rs;
+	r.cs = a.cs;
+	return r;
+}
+static inline FN(mat) FN(tr)(FN(mat) a)
+{
+	FN(mat) r = a;
+	r.nrows = a.ncols;
+	r.ncols = a.nrows;
+	r.rs = a.cs;
+	r.cs = a.rs;
+	return r;
+}
+static inline FN(mat) FN(rev_rows)(FN(mat) a)
+{
+	FN(mat) r = a;
+	if (a.nrows > 0)
+		r.p = a.p + (a.nrows - 1) * a.rs;
+	r.rs = -a.rs;
+	return r;
+}
+static inline FN(mat) FN(rev_rows_cols)(FN(mat) a)
+{
+	FN(mat) r = FN(rev_rows)(a);
+	if (a.ncols > 0)
+		r.p = r.p + (a.ncols - 1) * a.cs;
+	r.cs = -a.cs;
+	return r;
+}
+
+/* ------------------------------------------------------------------ GEMM */
+/* matmul/mod.rs:1176-1560 (contract) + :58-329 (in-tree micro-kernel):
+ * dst <- [dst +] alpha * lhs * rhs.  Replace never reads dst (K==0 => zero
+ * fill, :1194-1196).  Accumulation is a k-ordered FMA chain starting at 0,
+ * combined once as alpha*acc [+ dst] (single K chunk). */
+static void FN(gemm)(FN(mat) dst, int accum_add, FN(mat) lhs, FN(mat) rhs, T alpha)
+{
+	long m = dst.nrows, n = dst.ncols, k = lhs.ncols;
+	if (m == 0 || n == 0)
+		return;
+#pragma omp parallel for schedule(static) if ((double)m * n * k > 1e6)
+	for (long j = 0; j < n; j++) {
+		T *tmp = (T *)malloc(sizeof(T) * (size_t)m);
+		for (long i = 0; i < m; i++)
+			tmp[i] = 0;
+		for (long p = 0; p < k; p++) {
+			T b = AT(rhs, p, j);
+			if (lhs.rs == 1) {
+				const T *a = lhs.p + p * lhs.cs;
+				for (long i = 0; i < m; i++)
+					tmp[i] = FMA(a[i], b, tmp[i]);
+			} else {
+				for (long i = 0; i < m; i++)
+					tmp[i] = FMA(AT(lhs, i, p), b, tmp[i]);
+			}
+		}
+		for (long i = 0; i < m; i++) {
+			if (accum_add)
+				AT(dst, i, j) = FMA(alpha, tmp[i], AT(dst, i, j));
+			else
+				AT(dst, i, j) = alpha * tmp[i];
+		}
+		free(tmp);
+	}
+}
+
+/* -------------------------------------------------- triangular product */
+/* triangular.rs:906-977 (BlockStructure), :1246-1495 (semantics).
+ * structure codes follow faer-ffi/src/lib.rs:84-93:
+ * 0 Rect, 1 TriLower, 2 TriUpper, 3 StrictLower, 4 StrictUpper, 5 UnitLower,
+ * 6 UnitUpper.  Only the structured part of each operand is ACCESSED; only
+ * the structured part of dst is WRITTEN (strict/unit => diagonal untouched). */
+static inline int FN(in_struct)(int s, long i, long j)
+{
+	switch (s) {
+	case 0: return 1;
+	case 1: return i >= j;
+	case 2: return i <= j;
+	case 3: case 5: return i > j;
+	case 4: case 6: return i < j;
+	}
+	return 0;
+}
+static inline T FN(sval)(FN(mat) a, int s, long i, long j)
+{
+	if ((s == 5 || s == 6) && i == j)
+		return (T)1;
+	if (!FN(in_struct)(s, i, j))
+		return (T)0;
+	return AT(a, i, j);
+}
+static void FN(matmul_triangular)(FN(mat) dst, int dst_s, int accum_add, FN(mat) lhs, int lhs_s,
+				  FN(mat) rhs, int rhs_s, T alpha)
+{
+	long m = dst.nrows, n = dst.ncols, k = lhs.ncols;
+	for (long j = 0; j < n; j++)
+		for (long i = 0; i < m; i++) {
+			if (!FN(in_struct)(dst_s, i, j))
+				continue;
+			T acc = 0;
+			for (long p = 0; p < k; p++) {
+				T a = FN(sval)(lhs, lhs_s, i, p);
+				T b = FN(sval)(rhs, rhs_s, p, j);
+				if (a != 0 && b != 0)
+					acc = FMA(a, b, acc);
+			}
+			if (accum_add)
+				AT(dst, i, j) = FMA(alpha, acc, AT(dst, i, j));
+			else
+				AT(dst, i, j) = alpha * acc;
+		}
+}
+
+/* ------------------------------------------------------------------ TRSM */
+/* triangular_solve.rs:200-215 block_size(), :16-198 base cases n<=4,
+ * :420-604 recursion.  Solves tril * X = rhs in place (left side). */
+static long FN(trsm_block_size)(long n)
+{
+	long base_rem = n / 2, r;
+	if (n >= 32)
+		r = (base_rem + 15) / 16 * 16;
+	else if (n >= 16)
+		r = (base_rem + 7) / 8 * 8;
+	else if (n >= 8)
+		r = (base_rem + 3) / 4 * 4;
+	else
+		r = base_rem;
+	return n - r;
+}
+static void FN(trsm_lower)(FN(mat) tril, int unit, FN(mat) rhs)
+{
+	long n = tril.nrows, k = rhs.ncols;
+	if (n == 0 || k == 0)
+		return;
+	if (k > 64 && n <= 128) { /* :430-449 */
+		FN(trsm_lower)(tril, unit, FN(sub)(rhs, 0, 0, n, k / 2));
+		FN(trsm_lower)(tril, unit, FN(sub)(rhs, 0, k / 2, n, k - k / 2));
+		return;
+	}
+	if (n <= 4) {
+		/* :98-198 : x_i <- x_i*(1/l_ii) + sum_j (-l_ij/l_ii) x_j  (non-unit)
+		 * :16-96  : x_i <- x_i - sum_j l_ij x_j                   (unit)   */
+		T inv[4], c[4][4];
+		for (long i = 0; i < n; i++) {
+			inv[i] = unit ? (T)1 : (T)1 / AT(tril, i, i);
+			for (long j = 0; j < i; j++)
+				c[i][j] = unit ? -AT(tril, i, j) : (-AT(tril, i, j)) * inv[i];
+		}
+		for (long col = 0; col < k; col++) {
+			T y[4];
+			for (long i = 0; i < n; i++) {
+				T v = AT(rhs, i, col);
+				if (!unit)
+					v = v * inv[i];
+				for (long j = 0; j < i; j++)
+					v = v + c[i][j] * y[j];
+				y[i] = v;
+			}
+			for (long i = 0; i < n; i++)
+				AT(rhs, i, col) = y[i];
+		}
+		return;
+	}
+	long bs = FN(trsm_block_size)(n);
+	FN(mat) tl = FN(sub)(tril, 0, 0, bs, bs);
+	FN(mat) bl = FN(sub)(tril, bs, 0, n - bs, bs);
+	FN(mat) br = FN(sub)(tril, bs, bs, n - bs, n - bs);
+	FN(mat) top = FN(sub)(rhs, 0, 0, bs, k);
+	FN(mat) bot = FN(sub)(rhs, bs, 0, n - bs, k);
+	FN(trsm_lower)(tl, unit, top);
+	FN(gemm)(bot, 1, bl, top, (T)-1);
+	FN(trsm_lower)(br, unit, bot);
+}
+/* :578-604 upper = lower on the row/col reversed views */
+static void FN(trsm_upper)(FN(mat) triu, int unit, FN(mat) rhs)
+{
+	FN(trsm_lower)(FN(rev_rows_cols)(triu), unit, FN(rev_rows)(rhs));
+}
+
+/* --------------------------------------------------------------- Cholesky */
+/* cholesky/ldlt/factor.rs:299-366 (fallback == simd base semantics, :7-177):
+ * left-looking; d = a_jj - sum; regularise; !(d>0) => Err(j); column
+ * (including the diagonal) is multiplied by 1/sqrt(d). Returns count or
+ * -(j+1) on failure. */
+static long FN(chol_base)(FN(mat) A, T *D, int regularize, T eps, T delta)
+{
+	long n = A.nrows, count = 0;
+	for (long j = 0; j < n; j++) {
+		for (long i = j; i < n; i++) {
+			T sum = 0;
+			for (long k = 0; k < j; k++)
+				sum = sum + AT(A, j, k) * AT(A, i, k);
+			AT(A, i, j) = AT(A, i, j) - sum;
+		}
+		T diag = AT(A, j, j);
+		if (regularize) {
+			int small_or_negative = diag <= eps;
+			if (small_or_negative) { /* sign == 1 for llt, :122-131 */
+				diag = delta;
+				count += 1;
+			}
+		}
+		if (!(diag > 0)) {
+			D[j] = diag;
+			return -(j + 1);
+		}
+		diag = SQRT(diag);
+		D[j] = diag;
+		if (diag == 0 || !isfinite(diag))
+			return -(j + 1);
+		T inv = (T)1 / diag;
+		for (long i = j; i < n; i++)
+			AT(A, i, j) = AT(A, i, j) * inv;
+	}
+	return count;
+}
+static long FN(next_pow2)(long n)
+{
+	long p = 1;
+	while (p < n)
+		p <<= 1;
+	return p;
+}
+/* cholesky/ldlt/factor.rs:367-498 (is_llt branch) */
+static long FN(chol_rec)(FN(mat) A, T *D, long rec_threshold, long block_size, int regularize, T eps,
+			 T delta)
+{
+	long n = A.ncols;
+	if (n <= rec_threshold)
+		return FN(chol_base)(A, D, regularize, eps, delta);
+	long count = 0;
+	long bs0 = FN(next_pow2)(n) / 2;
+	if (bs0 > block_size)
+		bs0 = block_size;
+	long j = 0;
+	while (j < n) {
+		long bs = bs0 < n - j ? bs0 : n - j;
+		FN(mat) A00 = FN(sub)(A, j, j, bs, bs);
+		FN(mat) A10 = FN(sub)(A, j + bs, j, n - j - bs, bs);
+		FN(mat) A11 = FN(sub)(A, j + bs, j + bs, n - j - bs, n - j - bs);
+		long r = FN(chol_rec)(A00, D + j, rec_threshold, bs, regularize, eps, delta);
+		if (r < 0)
+			return -(j + (-r - 1) + 1);
+		count += r;
+		/* :422-426  A10^T <- L00^-1 A10^T  (i.e. A10 <- A10 L00^-T) */
+		FN(trsm_lower)(A00, 0, FN(tr)(A10));
+		/* :436-446  lower(A11) -= A10 A10^T */
+		FN(matmul_triangular)(A11, 1, 1, A10, 0, FN(tr)(A10), 0, (T)-1);
+		j += bs;
+	}
+	return count;
+}
+/* cholesky/llt/factor.rs:67-97.  Returns dynamic_regularization_count (>=0)
+ * or -(index+1) for NonPositivePivot{index}. */
+long FN(oracle_llt_in_place)(T *a, long n, long rs, long cs, T reg_delta, T reg_eps, long rec_threshold,
+			     long block_size)
+{
+	FN(mat) A = {a, n, n, rs, cs};
+	T *D = (T *)malloc(sizeof(T) * (size_t)(n > 0 ? n : 1));
+	int regularize = (reg_delta > 0 && reg_eps > 0);
+	long r = FN(chol_rec)(A, D, rec_threshold, block_size, regularize, reg_eps, reg_delta);
+	free(D);
+	return r;
+}
+
+/* --------------------------------------------------------------------- LU */
+/* lu/partial_pivoting/factor.rs:19-67 */
+static long FN(lu_unblocked)(FN(mat) M, long start, long end, long *trans)
+{
+	long m = M.nrows;
+	long n_trans = 0;
+	for (long j = start; j < end; j++) {
+		long col = j, row = j - start;
+		long imax = row;
+		T max = 0;
+		for (long i = imax; i < m; i++) {
+			T a = FABS(AT(M, i, col));
+			if (a > max) {
+				max = a;
+				imax = i;
+			}
+		}
+		trans[row] = imax - row;
+		if (imax != row) {
+			for (long c = 0; c < M.ncols; c++) { /* perm/mod.rs:98-107 full rows */
+				T t = AT(M, row, c);
+				AT(M, row, c) = AT(M, imax, c);
+				AT(M, imax, c) = t;
+			}
+			n_trans += 1;
+		}
+		FN(mat) S = FN(sub)(M, 0, start, m, end - start);
+		T inv = (T)1 / AT(S, row, row);
+		for (long i = row + 1; i < m; i++)
+			AT(S, i, row) = AT(S, i, row) * inv;
+		/* rank-1 update via matmul K=1 (:54-64) -> rank_update_imp
+		 * (matmul/mod.rs:1038-1136): dst = fma(x_i, alpha*y_j, dst) */
+		for (long c = row + 1; c < end - start; c++) {
+			T y = (T)-1 * AT(S, row, c);
+			for (long i = row + 1; i < m; i++)
+				AT(S, i, c) = FMA(AT(S, i, row), y, AT(S, i, c));
+		}
+	}
+	return n_trans;
+}
+/* lu/partial_pivoting/factor.rs:68-187 */
+static long FN(lu_rec)(FN(mat) A, long start, long end, long *trans, long rec_threshold)
+{
+	long m = A.nrows, ncols = A.ncols, n = end - start;
+	if (n <= rec_threshold)
+		return FN(lu_unblocked)(A, start, end, trans);
+	long half = n / 2;
+	long pow = FN(next_pow2)(half);
+	if (pow > 16)
+		pow = 16;
+	long bs = (half + pow - 1) / pow * pow;
+	long n_trans = 0;
+	FN(mat) P = FN(sub)(A, 0, start, m, n);
+	n_trans += FN(lu_rec)(P, 0, bs, trans, rec_threshold);
+	{
+		FN(mat) A00 = FN(sub)(P, 0, 0, bs, bs);
+		FN(mat) A01 = FN(sub)(P, 0, bs, bs, n - bs);
+		FN(mat) A10 = FN(sub)(P, bs, 0, m - bs, bs);
+		FN(mat) A11 = FN(sub)(P, bs, bs, m - bs, n - bs);
+		FN(trsm_lower)(A00, 1, A01);
+		FN(gemm)(A11, 1, A10, A01, (T)-1);
+		n_trans += FN(lu_rec)(FN(sub)(P, bs, 0, m - bs, n), bs, n, trans + bs, rec_threshold);
+	}
+	/* :127-185 deferred swaps on the columns outside [start,end) */
+	for (long c = 0; c < ncols; c++) {
+		if (c >= start && c < end)
+			continue;
+		for (long j = 0; j < n; j++) {
+			long t = trans[j] + j;
+			T tmp = AT(A, j, c);
+			AT(A, j, c) = AT(A, t, c);
+			AT(A, t, c) = tmp;
+		}
+	}
+	return n_trans;
+}
+/* lu/partial_pivoting/factor.rs:234-295.  perm[i] = source row of row i of
+ * P*A; returns transposition_count. */
+long FN(oracle_lu_in_place)(T *a, long m, long n, long rs, long cs, long *perm, long *perm_inv,
+			    long rec_threshold)
+{
+	FN(mat) A = {a, m, n, rs, cs};
+	long size = m < n ? m : n;
+	for (long i = 0; i < m; i++)
+		perm[i] = i;
+	long *trans = (long *)calloc((size_t)(size > 0 ? size : 1), sizeof(long));
+	long nt = FN(lu_rec)(A, 0, size, trans, rec_threshold);
+	for (long idx = 0; idx < size; idx++) {
+		long t = trans[idx];
+		long tmp = perm[idx];
+		perm[idx] = perm[idx + t];
+		perm[idx + t] = tmp;
+	}
+	if (m < n)
+		FN(trsm_lower)(FN(sub)(A, 0, 0, size, size), 1, FN(sub)(A, 0, size, size, n - size));
+	for (long i = 0; i < m; i++)
+		perm_inv[perm[i]] = i;
+	free(trans);
+	return nt;
+}
+
+/* ---------------------------------------------------------------- norm_l2 */
+/* reductions/norm_l2.rs:6-45,173-184: three scaled accumulators; the
+ * pairwise splitting (:46-82) only changes rounding, not semantics. */
+T FN(oracle_norm_l2)(const T *x, long n, long stride)
+{
+	T sml = SQRT(TMIN), big = SQRT(TMAX);
+	T a_sml = 0, a_med = 0, a_big = 0;
+	for (long i = 0; i < n; i++) {
+		T v = x[i * stride];
+		a_sml = FMA(v * sml, v * sml, a_sml);
+		a_med = FMA(v, v, a_med);
+		a_big = FMA(v * big, v * big, a_big);
+	}
+	if (a_sml >= 1)
+		return SQRT(a_sml) * big;
+	else if (a_med >= 1)
+		return SQRT(a_med);
+	else
+		return SQRT(a_big) * sml;
+}
+
+/* ------------------------------------------------------------ Householder */
+/* householder.rs:59-107.  tail is read from `in` (stride is) and v is written
+ * to `out` (stride os); in==out for the in-place variant. */
+typedef struct {
+	T tau, norm;
+} FN(hinfo);
+static FN(hinfo) FN(make_householder)(T *head, T *out, long os, const T *in, long is, long len)
+{
+	FN(hinfo) r;
+	T tail_norm = FN(oracle_norm_l2)(in, len, is);
+	T head_norm = FABS(*head);
+	if (head_norm < TMIN) {
+		*head = 0;
+		head_norm = 0;
+	}
+	if (tail_norm < TMIN) {
+		r.tau = (T)INFINITY;
+		r.norm = head_norm;
+		return r;
+	}
+	T norm = HYPOT(head_norm, tail_norm);
+	T sign = head_norm != 0 ? (*head) * ((T)1 / head_norm) : (T)1;
+	T signed_norm = sign * norm;
+	T head_with_beta = *head + signed_norm;
+	T hinv = (T)1 / head_with_beta;
+	for (long i = 0; i < len; i++)
+		out[i * os] = in[i * is] * hinv;
+	*head = -signed_norm;
+	T t = tail_norm * FABS(hinv);
+	r.tau = (T)0.5 * ((T)1 + t * t);
+	r.norm = norm;
+	return r;
+}
+
+/* 4-accumulator dot (matmul/mod.rs:692-726 semantics up to rounding) */
+static T FN(dot)(const T *a, long as, const T *b, long bs, long n)
+{
+	T acc = 0;
+	for (long i = 0; i < n; i++)
+		acc = FMA(a[i * as], b[i * bs], acc);
+	return acc;
+}
+
+/* qr/no_pivoting/factor.rs:11-86 */
+static long FN(qr_unblocked)(FN(mat) A, T *H, long hs, long hsize, long row_start, long col_start)
+{
+	long m = A.nrows, n = A.ncols;
+	long size = hsize;
+	long col = col_start, row = row_start;
+	long lim = size < m ? size : m;
+	while (row < lim && col < n) {
+		T norm_above = FN(oracle_norm_l2)(&AT(A, 0, col), row, A.rs);
+		T *head = &AT(A, row, col);
+		long tail_len = m - row - 1;
+		T *tail_in = &AT(A, row + 1, col);
+		FN(hinfo) info;
+		const T *v;
+		if (row == col) {
+			info = FN(make_householder)(head, tail_in, A.rs, tail_in, A.rs, tail_len);
+			v = tail_in;
+		} else {
+			T *out = &AT(A, row + 1, row);
+			info = FN(make_householder)(head, out, A.rs, tail_in, A.rs, tail_len);
+			long z = tail_len < col - row ? tail_len : col - row;
+			for (long i = 0; i < z; i++)
+				tail_in[i * A.rs] = 0;
+			v = out;
+		}
+		/* NOTE: when row != col the head lives at (row,col) and stays there */
+		T norm = HYPOT(info.norm, norm_above);
+		T threshold = TEPS * (T)((double)(m - row) * 16.0) * norm;
+		T tau_inv = (T)1 / info.tau;
+		H[row * hs] = info.tau;
+		if (tau_inv < TMIN) {
+			if (info.norm > 0)
+				row += 1;
+		} else if (info.norm > threshold) {
+			for (long c = col + 1; c < n; c++) {
+				T *hd = &AT(A, row, c);
+				T *tl = &AT(A, row + 1, c);
+				T dot = *hd + FN(dot)(v, A.rs, tl, A.rs, tail_len);
+				T k = -(dot * tau_inv);
+				*hd += k;
+				for (long i = 0; i < tail_len; i++)
+					tl[i * A.rs] += k * v[i * A.rs];
+			}
+			row += 1;
+		}
+		col += 1;
+	}
+	return row;
+}
+
+/* householder.rs:132-272.  Fills the off-diagonal blocks of the upper
+ * triangular factor T given the diagonal blocks of size prev_block_size:
+ * T_ij = v_i^H v_j for i<j (V unit lower trapezoidal).  The recursion of the
+ * reference only decides WHICH products are formed together; the values are
+ * the strict upper triangle of V^H V outside the prev-size diagonal blocks
+ * (or, when prev_block_size < 8, the whole strict upper triangle). */
+static void FN(upgrade_householder_factor)(FN(mat) Tf, FN(mat) V, long block_size, long prev_block_size)
+{
+	long n = V.ncols, m = V.nrows;
+	if (block_size == prev_block_size || Tf.nrows <= prev_block_size)
+		return;
+	long block_count = (Tf.nrows + block_size - 1) / block_size;
+	if (block_count > 1) { /* :153-185 */
+		long mid = block_count / 2; /* NB: reference splits at `mid` (a block count) */
+		FN(upgrade_householder_factor)(FN(sub)(Tf, 0, 0, mid, mid), FN(sub)(V, 0, 0, m, mid), block_size,
+					       prev_block_size);
+		FN(upgrade_householder_factor)(FN(sub)(Tf, mid, mid, Tf.nrows - mid, Tf.ncols - mid),
+					       FN(sub)(V, mid, mid, m - mid, n - mid), block_size,
+					       prev_block_size);
+		return;
+	}
+	for (long i = 0; i < n; i++)
+		for (long j = i + 1; j < n; j++) {
+			if (prev_block_size >= 8 && (i / prev_block_size) == (j / prev_block_size))
+				continue; /* diagonal block already built by the child */
+			/* v_i^H v_j : v_i has implicit 1 at row i, v_j implicit 1 at row j */
+			T acc = AT(V, j, i); /* v_i[j] * 1 */
+			for (long r = j + 1; r < m; r++)
+				acc = FMA(AT(V, r, i), AT(V, r, j), acc);
+			AT(Tf, i, j) = acc;
+		}
+}
+
+/* householder.rs:370-620 (generic path).  forward != 0  => apply
+ * (I - V T^-H V^H) (the "transpose" apply), else (I - V T^-1 V^H). */
+static void FN(apply_block_householder)(FN(mat) V, FN(mat) Tf, FN(mat) M, int forward)
+{
+	long m = V.nrows, n = V.ncols, k = M.ncols;
+	if (n == 0 || k == 0)
+		return;
+	T *tmpb = (T *)calloc((size_t)(n * k), sizeof(T));
+	FN(mat) tmp = {tmpb, n, k, 1, n};
+	/* tmp = V^H M with V unit lower trapezoidal */
+	for (long c = 0; c < k; c++)
+		for (long i = 0; i < n; i++) {
+			T acc = AT(M, i, c);
+			for (long r = i + 1; r < m; r++)
+				acc = FMA(AT(V, r, i), AT(M, r, c), acc);
+			AT(tmp, i, c) = acc;
+		}
+	if (forward)
+		FN(trsm_lower)(FN(tr)(Tf), 0, tmp); /* T^-H tmp */
+	else
+		FN(trsm_upper)(Tf, 0, tmp); /* T^-1 tmp */
+	/* M -= V tmp */
+	for (long c = 0; c < k; c++)
+		for (long r = 0; r < m; r++) {
+			T acc = 0;
+			long lim = r < n ? r : n; /* strictly-lower part of V */
+			for (long i = 0; i < lim; i++)
+				acc = FMA(AT(V, r, i), AT(tmp, i, c), acc);
+			if (r < n)
+				acc = acc + AT(tmp, r, c);
+			AT(M, r, c) = AT(M, r, c) - acc;
+		}
+	free(tmpb);
+}
+
+/* qr/no_pivoting/factor.rs:137-256 */
+static long FN(qr_blocked)(FN(mat) A, FN(mat) H, long row_start, long col_start, long blocking_threshold)
+{
+	long m = A.nrows, n = A.ncols;
+	long size = m < n ? m : n;
+	long block_size = H.nrows;
+	if (block_size == 1)
+		return FN(qr_unblocked)(A, H.p, H.cs, H.ncols, row_start, col_start);
+	long sub_block_size0 = (m * n < blocking_threshold) ? 1 : block_size / 2;
+	long col = col_start, row = row_start;
+	while (row < size && col < n) {
+		long bs = block_size;
+		if (size - row < bs)
+			bs = size - row;
+		if (n - col < bs)
+			bs = n - col;
+		long sbs = bs < sub_block_size0 ? bs : sub_block_size0;
+		long start = row;
+		long offset = 0;
+		while (offset < bs && col < n) {
+			long bs2 = (n - col) < (bs - offset) ? (n - col) : (bs - offset);
+			long sbs2 = bs2 < sbs ? bs2 : sbs;
+			long new_row = FN(qr_blocked)(FN(sub)(A, 0, 0, m, col + bs2),
+						      FN(sub)(H, offset, 0, sbs2, H.ncols), row, col,
+						      blocking_threshold);
+			long local = new_row - row;
+			if (local > 0) {
+				long k = 0;
+				while (k < local) {
+					long s = sbs2 < local - k ? sbs2 : local - k;
+					if (k > 0) {
+						/* :184-198 move the child's T block onto the diagonal */
+						for (long jj = 0; jj < s; jj++)
+							for (long ii = 0; ii <= jj; ii++)
+								AT(H, offset + k + ii, row + k + jj) =
+									AT(H, offset + ii, row + k + jj);
+					}
+					k += sbs2;
+				}
+				FN(upgrade_householder_factor)(FN(sub)(H, offset, row, local, local),
+							       FN(sub)(A, row, row, m - row, local), local, sbs2);
+				if (offset > 0) {
+					/* :207-239 rebuild the whole strict upper triangle of the
+					 * (offset+local) block as V^H V */
+					long w = offset + local;
+					FN(mat) Hb = FN(sub)(H, 0, start, w, w);
+					FN(mat) Vb = FN(sub)(A, start, start, m - start, w);
+					for (long i = 0; i < w; i++)
+						for (long j = i + 1; j < w; j++) {
+							T acc = AT(Vb, j, i);
+							for (long r = j + 1; r < m - start; r++)
+								acc = FMA(AT(Vb, r, i), AT(Vb, r, j), acc);
+							AT(Hb, i, j) = acc;
+						}
+				}
+			}
+			long nright = n - (col + bs2);
+			if (nright > 0 && local > 0)
+				FN(apply_block_householder)(FN(sub)(A, row, row, m - row, local),
+							    FN(sub)(H, offset, row, local, local),
+							    FN(sub)(A, row, col + bs2, m - row, nright), 1);
+			offset += local;
+			row += local;
+			col += bs2;
+		}
+	}
+	return row;
+}
+
+/* qr/no_pivoting/factor.rs:91-116 */
+long FN(oracle_qr_recommended_block_size)(long nrows, long ncols)
+{
+	long prod = nrows * ncols;
+	long size = nrows < ncols ? nrows : ncols;
+	long r;
+	if (prod > 8192L * 8192)
+		r = 256;
+	else if (prod > 2048L * 2048)
+		r = 128;
+	else if (prod > 1024L * 1024)
+		r = 64;
+	else if (prod > 512L * 512)
+		r = 48;
+	else if (prod > 128L * 128)
+		r = 32;
+	else if (prod > 32L * 32)
+		r = 8;
+	else if (prod > 16L * 16)
+		r = 4;
+	else
+		r = 1;
+	if (r > size)
+		r = size;
+	if (r < 1)
+		r = 1;
+	return r;
+}
+
+/* qr/no_pivoting/factor.rs:258-301.  H is block_size x min(m,n). Returns rank. */
+long FN(oracle_qr_in_place)(T *a, long m, long n, long rs, long cs, T *h, long block_size, long hrs, long hcs,
+			    long blocking_threshold)
+{
+	FN(mat) A = {a, m, n, rs, cs};
+	long size = m < n ? m : n;
+	FN(mat) H = {h, block_size, size, hrs, hcs};
+	long rank = FN(qr_blocked)(A, H, 0, 0, blocking_threshold);
+	for (long j = rank; j < size; j++)
+		for (long i = 0; i < block_size; i++)
+			AT(H, i, j) = 0;
+	long col = rank / block_size * block_size;
+	while (col < size) {
+		long bs = block_size < size - col ? block_size : size - col;
+		long start = rank > col ? rank : col;
+		for (long d = start; d < col + bs; d++)
+			AT(H, d - col, d) = (T)INFINITY;
+		col += bs;
+	}
+	return rank;
+}
+
+/* householder.rs:724-808 : sequence apply on the left.
+ * transpose != 0 => Q^H * M (blocks first to last), else Q * M (last to first). */
+void FN(oracle_apply_householder_sequence_left)(const T *v, long m, long n, long vrs, long vcs, const T *h,
+						long block_size, long hrs, long hcs, T *mat, long k, long mrs,
+						long mcs, int transpose)
+{
+	FN(mat) V = {(T *)v, m, n, vrs, vcs};
+	long size = m < n ? m : n;
+	FN(mat) H = {(T *)h, block_size, size, hrs, hcs};
+	FN(mat) M = {mat, m, k, mrs, mcs};
+	if (transpose) {
+		long j = 0;
+		while (j < size) {
+			long bs = block_size < size - j ? block_size : size - j;
+			FN(apply_block_householder)(FN(sub)(V, j, j, m - j, bs), FN(sub)(H, 0, j, bs, bs),
+						    FN(sub)(M, j, 0, m - j, k), 1);
+			j += bs;
+		}
+	} else {
+		long j = size;
+		long bs = size % block_size;
+		if (bs == 0)
+			bs = block_size;
+		while (j > 0) {
+			long jp = j - bs;
+			bs = block_size;
+			FN(apply_block_householder)(FN(sub)(V, jp, jp, m - jp, j - jp),
+						    FN(sub)(H, 0, jp, j - jp, j - jp),
+						    FN(sub)(M, jp, 0, m - jp, k), 0);
+			j = jp;
+		}
+	}
+}
+
+/* --------------------------------------------------------- exported shims */
+void FN(oracle_matmul)(T *c, long m, long n, long crs, long ccs, int accum_add, const T *a, long k, long ars,
+		       long acs, const T *b, long brs, long bcs, T alpha)
+{
+	FN(mat) C = {c, m, n, crs, ccs};
+	FN(mat) A = {(T *)a, m, k, ars, acs};
+	FN(mat) B = {(T *)b, k, n, brs, bcs};
+	if (k == 0) { /* matmul/mod.rs:1194-1196 */
+		if (!accum_add)
+			for (long j = 0; j < n; j++)
+				for (long i = 0; i < m; i++)
+					AT(C, i, j) = 0;
+		return;
+	}
+	FN(gemm)(C, accum_add, A, B, alpha);
+}
+void FN(oracle_matmul_triangular)(T *c, long m, long n, long crs, long ccs, int c_s, int accum_add, const T *a,
+				  long k, long ars, long acs, int a_s, const T *b, long brs, long bcs, int b_s,
+				  T alpha)
+{
+	FN(mat) C = {c, m, n, crs, ccs};
+	FN(mat) A = {(T *)a, m, k, ars, acs};
+	FN(mat) B = {(T *)b, k, n, brs, bcs};
+	FN(matmul_triangular)(C, c_s, accum_add, A, a_s, B, b_s, alpha);
+}
+/* side: 0 lower, 1 upper */
+void FN(oracle_trsm)(const T *t, long n, long trs, long tcs, int upper, int unit, T *x, long k, long xrs,
+		     long xcs)
+{
+	FN(mat) Tm = {(T *)t, n, n, trs, tcs};
+	FN(mat) X = {x, n, k, xrs, xcs};
+	if (upper)
+		FN(trsm_upper)(Tm, unit, X);
+	else
+		FN(trsm_lower)(Tm, unit, X);
+}
