@@ -1,0 +1,385 @@
+"""faer_rs_amd -- thin host-side mirror of faer's low-level API over libfaer_hip.so.
+
+Everything here is plumbing: it builds the repr(C) structs of include/faer_hip.h from numpy arrays
+(host memory) or torch tensors (device memory) and calls the C-ABI through ctypes.  The compute lives in
+the shared library (hand-written HIP for gfx950); there is no Python or CPU compute path, and importing
+`lib()` raises if the library has not been built (run `python -c "import __graft_entry__ as g; g.build()"`).
+
+Function names, argument order and error behaviour follow the reference:
+  matmul                      faer/src/linalg/matmul/mod.rs:1617
+  matmul_triangular           faer/src/linalg/matmul/triangular.rs:1193
+  solve_*_triangular_in_place faer/src/linalg/triangular_solve.rs:220-419
+  llt_factor_in_place         faer/src/linalg/cholesky/llt/factor.rs:67   (Result<LltInfo, LltError>)
+  partial_piv_lu_factor_in_place  faer/src/linalg/lu/partial_pivoting/factor.rs:234
+  qr_factor_in_place          faer/src/linalg/qr/no_pivoting/factor.rs:258
+  Llt / PartialPivLu / Qr     faer/src/linalg/solvers.rs:770-1204 (high level owners)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfaer_hip.so")
+_LIB = None
+
+# ------------------------------------------------------------------ repr(C) structs (include/faer_hip.h)
+
+
+class MatRef(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("nrows", C.c_size_t), ("ncols", C.c_size_t), ("row_stride", C.c_ssize_t),
+                ("col_stride", C.c_ssize_t)]
+
+
+class MatMut(MatRef):
+    pass
+
+
+class SliceMut(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("len", C.c_size_t)]
+
+
+class Par(C.Structure):
+    _fields_ = [("tag", C.c_int), ("nthreads", C.c_size_t)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("len_bytes", C.c_size_t), ("align_bytes", C.c_size_t)]
+
+
+class MemAlloc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("len_bytes", C.c_size_t)]
+
+
+class LltStatus(C.Structure):
+    _fields_ = [("tag", C.c_int), ("value", C.c_size_t)]
+
+
+class PartialPivLuStatus(C.Structure):
+    _fields_ = [("tag", C.c_int), ("transposition_count", C.c_size_t)]
+
+
+class QrStatus(C.Structure):
+    _fields_ = [("tag", C.c_int), ("rank", C.c_size_t)]
+
+
+class LltParams(C.Structure):
+    _fields_ = [("recursion_threshold", C.c_size_t), ("block_size", C.c_size_t)]
+
+
+class PartialPivLuParams(C.Structure):
+    _fields_ = [("recursion_threshold", C.c_size_t), ("block_size", C.c_size_t), ("par_threshold", C.c_size_t)]
+
+
+class QrParams(C.Structure):
+    _fields_ = [("blocking_threshold", C.c_size_t), ("par_threshold", C.c_size_t)]
+
+
+class LltRegularization(C.Structure):
+    _fields_ = [("dynamic_regularization_delta", C.c_void_p), ("dynamic_regularization_epsilon", C.c_void_p)]
+
+
+BCAST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+
+
+class Comm(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("bcast", BCAST_FN), ("user", C.c_void_p)]
+
+
+ACCUM_REPLACE, ACCUM_ADD = 0, 1
+CONJ_NO = 0
+BLOCK = {"rect": 0, "lower": 1, "upper": 2, "strict_lower": 3, "strict_upper": 4, "unit_lower": 5, "unit_upper": 6}
+DST_FULL, DST_LOWER, DST_UPPER = 0, 1, 2
+DTYPE_F32, DTYPE_F64 = 0, 1
+PAR_SEQ = Par(0, 1)
+
+
+class LltError(Exception):
+    """faer::linalg::cholesky::llt::factor::LltError::NonPositivePivot { index }"""
+
+    def __init__(self, index):
+        super().__init__(f"NonPositivePivot {{ index: {index} }}")
+        self.index = index
+
+
+def lib():
+    """Loads libfaer_hip.so.  Fails loudly when it is missing: there is no fallback path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc, gfx950). "
+                           "faer_rs_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for suf in ("f64", "f32"):
+        getattr(L, f"libfaer_v0_23_llt_factor_in_place_{suf}").restype = LltStatus
+        getattr(L, f"libfaer_v0_23_qr_factor_in_place_{suf}").restype = QrStatus
+        getattr(L, f"libfaer_v0_23_qr_recommended_block_size_{suf}").restype = C.c_size_t
+        getattr(L, f"libfaer_v0_23_LltParams_{suf}").restype = LltParams
+        getattr(L, f"libfaer_v0_23_PartialPivLuParams_{suf}").restype = PartialPivLuParams
+        getattr(L, f"libfaer_v0_23_QrParams_{suf}").restype = QrParams
+        for it in ("u32", "u64"):
+            getattr(L, f"libfaer_v0_23_partial_piv_lu_factor_in_place_{it}_{suf}").restype = PartialPivLuStatus
+            getattr(L, f"libfaer_v0_23_partial_piv_lu_factor_in_place_scratch_{it}_{suf}").restype = Layout
+        for name in ("llt_factor_in_place_scratch", "llt_solve_in_place_scratch", "qr_factor_in_place_scratch",
+                     "apply_householder_on_the_left_scratch", "apply_householder_transpose_on_the_left_scratch"):
+            getattr(L, f"libfaer_v0_23_{name}_{suf}").restype = Layout
+        getattr(L, f"faer_hip_dist_partial_piv_lu_{suf}").restype = PartialPivLuStatus
+    L.libfaer_v0_23_get_global_par.restype = Par
+    L.faer_hip_version.restype = C.c_char_p
+    L.faer_hip_device_count.restype = C.c_int
+    L.faer_hip_get_stream.restype = C.c_void_p
+    L.faer_hip_malloc.restype = C.c_void_p
+    L.faer_hip_time_gemm_ms.restype = C.c_double
+    L.faer_hip_mfma_peak_tflops.restype = C.c_double
+    L.faer_hip_dist_local_ncols.restype = C.c_size_t
+    _LIB = L
+    return L
+
+
+# ------------------------------------------------------------------ operand marshalling
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _dtype_suffix(x):
+    if _is_torch(x):
+        import torch
+
+        if x.dtype == torch.float64:
+            return "f64", C.c_double, 8
+        if x.dtype == torch.float32:
+            return "f32", C.c_float, 4
+    else:
+        if x.dtype == np.float64:
+            return "f64", C.c_double, 8
+        if x.dtype == np.float32:
+            return "f32", C.c_float, 4
+    raise TypeError(f"faer_rs_amd supports f32/f64 only, got {x.dtype}")
+
+
+def _mat(x, cls=MatRef):
+    """2-D numpy array / torch tensor -> MatRef/MatMut (strides in elements)."""
+    if _is_torch(x):
+        assert x.dim() == 2
+        return cls(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), x.stride(1))
+    assert x.ndim == 2
+    it = x.itemsize
+    return cls(x.ctypes.data, x.shape[0], x.shape[1], x.strides[0] // it, x.strides[1] // it)
+
+
+def use_torch_stream():
+    """Enqueue on torch's current HIP stream (torch is plumbing here: memory + streams)."""
+    import torch
+
+    lib().faer_hip_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
+def synchronize():
+    lib().faer_hip_synchronize()
+
+
+# ------------------------------------------------------------------ low level API (faer::linalg)
+def matmul(c, accum, a, b, alpha=1.0, par=PAR_SEQ):
+    suf, ct, _ = _dtype_suffix(c)
+    al = ct(alpha)
+    getattr(lib(), f"libfaer_v0_23_matmul_{suf}")(_mat(c, MatMut), C.c_int(accum), _mat(a), _mat(b), C.byref(al), par)
+    return c
+
+
+def matmul_triangular(c, c_block, accum, a, a_block, b, b_block, alpha=1.0, par=PAR_SEQ):
+    suf, ct, _ = _dtype_suffix(c)
+    al = ct(alpha)
+    getattr(lib(), f"libfaer_v0_23_matmul_triangular_{suf}")(_mat(c, MatMut), C.c_int(BLOCK[c_block]), C.c_int(accum),
+                                                           _mat(a), C.c_int(BLOCK[a_block]), _mat(b),
+                                                           C.c_int(BLOCK[b_block]), C.byref(al), par)
+    return c
+
+
+def gemm(dst, dst_kind, accum, lhs, rhs, alpha=1.0, row_idx=None, col_idx=None, diag=None):
+    """inner boundary: the private_gemm_x86::gemm call of faer (include/faer_hip.h section 1)."""
+    suf, ct, _ = _dtype_suffix(dst)
+    al = ct(alpha)
+    m, k = lhs.shape
+    n = rhs.shape[1]
+    d = _mat(dst, MatMut)
+    a, b = _mat(lhs), _mat(rhs)
+
+    def idx(v):
+        if v is None:
+            return None, 1
+        assert v.dtype in (np.uint32, np.uint64)
+        return C.c_void_p(v.ctypes.data), (1 if v.dtype == np.uint64 else 0)
+
+    ri, it1 = idx(row_idx)
+    ci, it2 = idx(col_idx)
+    itype = it1 if row_idx is not None else it2
+    dg, dgs = (None, 0)
+    if diag is not None:
+        dg = C.c_void_p(diag.data_ptr() if _is_torch(diag) else diag.ctypes.data)
+        dgs = diag.stride(0) if _is_torch(diag) else diag.strides[0] // diag.itemsize
+    lib().faer_hip_gemm(C.c_int(DTYPE_F64 if suf == "f64" else DTYPE_F32), C.c_int(itype), C.c_size_t(m), C.c_size_t(n),
+                        C.c_size_t(k), C.c_void_p(d.ptr), C.c_ssize_t(d.row_stride), C.c_ssize_t(d.col_stride), ri, ci,
+                        C.c_int(dst_kind), C.c_int(accum), C.c_void_p(a.ptr), C.c_ssize_t(a.row_stride),
+                        C.c_ssize_t(a.col_stride), C.c_bool(False), dg, C.c_ssize_t(dgs), C.c_void_p(b.ptr),
+                        C.c_ssize_t(b.row_stride), C.c_ssize_t(b.col_stride), C.c_bool(False), C.byref(al), C.c_size_t(0))
+    return dst
+
+
+def _trsm(name, t, rhs, par):
+    suf, _, _ = _dtype_suffix(rhs)
+    getattr(lib(), f"libfaer_v0_23_{name}_{suf}")(_mat(t), C.c_int(CONJ_NO), _mat(rhs, MatMut), par)
+    return rhs
+
+
+def solve_lower_triangular_in_place(l, rhs, par=PAR_SEQ):
+    return _trsm("solve_triangular_lower_in_place", l, rhs, par)
+
+
+def solve_upper_triangular_in_place(u, rhs, par=PAR_SEQ):
+    return _trsm("solve_triangular_upper_in_place", u, rhs, par)
+
+
+def solve_unit_lower_triangular_in_place(l, rhs, par=PAR_SEQ):
+    return _trsm("solve_unit_triangular_lower_in_place", l, rhs, par)
+
+
+def solve_unit_upper_triangular_in_place(u, rhs, par=PAR_SEQ):
+    return _trsm("solve_unit_triangular_upper_in_place", u, rhs, par)
+
+
+def llt_factor_in_place(a, regularization=(0.0, 0.0), par=PAR_SEQ):
+    """returns dynamic_regularization_count; raises LltError(index) like Err(NonPositivePivot{index})"""
+    suf, ct, _ = _dtype_suffix(a)
+    delta, eps = ct(regularization[0]), ct(regularization[1])
+    reg = LltRegularization(C.cast(C.pointer(delta), C.c_void_p), C.cast(C.pointer(eps), C.c_void_p))
+    L = lib()
+    params = getattr(L, f"libfaer_v0_23_LltParams_{suf}")()
+    st = getattr(L, f"libfaer_v0_23_llt_factor_in_place_{suf}")(_mat(a, MatMut), reg, par, MemAlloc(None, 0), params)
+    if st.tag == 0:
+        return st.value
+    if st.tag == 1:
+        raise LltError(st.value)
+    raise RuntimeError("LltStatus::Unknown")
+
+
+def llt_solve_in_place(l, rhs, par=PAR_SEQ):
+    suf, _, _ = _dtype_suffix(rhs)
+    getattr(lib(), f"libfaer_v0_23_llt_solve_in_place_{suf}")(_mat(l), C.c_int(CONJ_NO), _mat(rhs, MatMut), par,
+                                                            MemAlloc(None, 0))
+    return rhs
+
+
+def partial_piv_lu_factor_in_place(a, index_dtype=np.uint64, par=PAR_SEQ):
+    """returns (perm_fwd, perm_bwd, transposition_count); perm_fwd[i] = source row of row i of P*A"""
+    suf, _, _ = _dtype_suffix(a)
+    m = a.shape[0]
+    it = "u64" if np.dtype(index_dtype) == np.uint64 else "u32"
+    fwd = np.zeros(m, dtype=index_dtype)
+    bwd = np.zeros(m, dtype=index_dtype)
+    L = lib()
+    params = getattr(L, f"libfaer_v0_23_PartialPivLuParams_{suf}")()
+    st = getattr(L, f"libfaer_v0_23_partial_piv_lu_factor_in_place_{it}_{suf}")(
+        _mat(a, MatMut), SliceMut(fwd.ctypes.data, m), SliceMut(bwd.ctypes.data, m), par, MemAlloc(None, 0), params)
+    if st.tag != 0:
+        raise RuntimeError("PartialPivLuStatus::Unknown")
+    return fwd, bwd, st.transposition_count
+
+
+def qr_recommended_block_size(nrows, ncols, dtype=np.float64):
+    suf = "f64" if np.dtype(dtype) == np.float64 else "f32"
+    return getattr(lib(), f"libfaer_v0_23_qr_recommended_block_size_{suf}")(C.c_size_t(nrows), C.c_size_t(ncols))
+
+
+def qr_factor_in_place(a, q_coeff, par=PAR_SEQ):
+    """q_coeff: block_size x min(m, n).  returns rank (QrInfo.rank)"""
+    suf, _, _ = _dtype_suffix(a)
+    L = lib()
+    params = getattr(L, f"libfaer_v0_23_QrParams_{suf}")()
+    st = getattr(L, f"libfaer_v0_23_qr_factor_in_place_{suf}")(_mat(a, MatMut), _mat(q_coeff, MatMut), par,
+                                                             MemAlloc(None, 0), params)
+    if st.tag != 0:
+        raise RuntimeError("QrStatus::Unknown")
+    return st.rank
+
+
+def apply_block_householder_sequence_on_the_left_in_place(basis, factor, rhs, transpose=False, par=PAR_SEQ):
+    suf, _, _ = _dtype_suffix(rhs)
+    name = "apply_householder_transpose_on_the_left" if transpose else "apply_householder_on_the_left"
+    getattr(lib(), f"libfaer_v0_23_{name}_{suf}")(_mat(basis), _mat(factor), C.c_int(CONJ_NO), _mat(rhs, MatMut), par,
+                                                MemAlloc(None, 0))
+    return rhs
+
+
+# ------------------------------------------------------------------ high level owners (faer/src/linalg/solvers.rs)
+def _empty_like_f(a, shape):
+    if _is_torch(a):
+        import torch
+
+        return torch.zeros(shape[::-1], dtype=a.dtype, device=a.device).t()  # column major
+    return np.zeros(shape, dtype=a.dtype, order="F")
+
+
+def _copy_f(a):
+    if _is_torch(a):
+        return a.t().contiguous().t()
+    return np.array(a, order="F", copy=True)
+
+
+class Llt:
+    """solvers.rs:770-817: copies the lower triangle, factors, zeroes the strict upper triangle."""
+
+    def __init__(self, a):
+        self.l = _copy_f(a)
+        llt_factor_in_place(self.l)
+        if _is_torch(self.l):
+            self.l.copy_(self.l.tril())
+        else:
+            self.l[:] = np.tril(self.l)
+
+    def L(self):
+        return self.l
+
+    def solve_in_place(self, rhs):
+        return llt_solve_in_place(self.l, rhs)
+
+
+class PartialPivLu:
+    """solvers.rs:955-1035"""
+
+    def __init__(self, a):
+        self.lu = _copy_f(a)
+        self.perm, self.perm_inv, self.transposition_count = partial_piv_lu_factor_in_place(self.lu)
+
+    def solve_in_place(self, rhs):
+        # lu/partial_pivoting/solve.rs: x = U^-1 L^-1 P b
+        p = self.perm.astype(np.int64)
+        if _is_torch(rhs):
+            import torch
+
+            rhs.copy_(rhs[torch.as_tensor(p, device=rhs.device)])
+        else:
+            rhs[:] = rhs[p]
+        n = self.lu.shape[1]
+        solve_unit_lower_triangular_in_place(self.lu[:n, :n], rhs)
+        solve_upper_triangular_in_place(self.lu[:n, :n], rhs)
+        return rhs
+
+
+class Qr:
+    """solvers.rs:1106-1204"""
+
+    def __init__(self, a):
+        m, n = a.shape
+        self.qr = _copy_f(a)
+        bs = qr_recommended_block_size(m, n, np.float64 if _dtype_suffix(a)[0] == "f64" else np.float32)
+        self.q_coeff = _empty_like_f(a, (bs, min(m, n)))
+        self.rank = qr_factor_in_place(self.qr, self.q_coeff)
+
+    def Q_basis(self):
+        return self.qr
+
+    def Q_coeff(self):
+        return self.q_coeff

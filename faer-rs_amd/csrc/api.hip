@@ -1,0 +1,479 @@
+// extern "C" surface of libfaer_hip.so (see include/faer_hip.h for the contract and the reference
+// citations of every entry point).  This file only validates shapes, stages host operands and forwards
+// to the device drivers; there is deliberately no CPU compute path here.
+#include <atomic>
+
+#include "common.h"
+
+using namespace fh;
+
+namespace {
+
+template <typename T> MatV<const T> view(FaerMatRef m)
+{
+	return MatV<const T>{static_cast<const T *>(m.ptr), (idx_t) m.nrows, (idx_t) m.ncols, (idx_t) m.row_stride,
+			     (idx_t) m.col_stride};
+}
+template <typename T> MatV<T> view(FaerMatMut m)
+{
+	return MatV<T>{static_cast<T *>(m.ptr), (idx_t) m.nrows, (idx_t) m.ncols, (idx_t) m.row_stride,
+		       (idx_t) m.col_stride};
+}
+
+std::atomic<int> g_par_tag{(int) FaerParTag_Rayon};
+std::atomic<size_t> g_par_threads{0};
+
+// ---- matmul ---------------------------------------------------------------------------------------
+template <typename T> void matmul_api(FaerMatMut C, FaerAccum accum, FaerMatRef A, FaerMatRef B, const void *alpha)
+{
+	// faer/src/linalg/matmul/mod.rs:1562-1575 `precondition`
+	FH_CHECK(C.nrows == A.nrows && C.ncols == B.ncols && A.ncols == B.nrows, "matmul: dimension mismatch");
+	FH_CHECK(alpha != nullptr, "matmul: alpha is NULL");
+	const bool add = accum == FaerAccum_Add;
+	Staged<const T> a(view<T>(A), true, false), b(view<T>(B), true, false);
+	Staged<T> c(view<T>(C), add, true); // Replace never reads dst
+	gemm_dev<T>(c.dev, DST_FULL, add, a.dev, b.dev, *static_cast<const T *>(alpha));
+}
+
+template <typename T>
+void matmul_triangular_api(FaerMatMut C, FaerBlock cb, FaerAccum accum, FaerMatRef A, FaerBlock ab, FaerMatRef B, FaerBlock bb,
+			   const void *alpha)
+{
+	FH_CHECK(C.nrows == A.nrows && C.ncols == B.ncols && A.ncols == B.nrows, "matmul_triangular: dimension mismatch");
+	// triangular operands must be square (faer/src/linalg/matmul/triangular.rs:1246-1262)
+	FH_CHECK(cb == FaerBlock_Rectangular || C.nrows == C.ncols, "matmul_triangular: triangular dst must be square");
+	FH_CHECK(ab == FaerBlock_Rectangular || A.nrows == A.ncols, "matmul_triangular: triangular lhs must be square");
+	FH_CHECK(bb == FaerBlock_Rectangular || B.nrows == B.ncols, "matmul_triangular: triangular rhs must be square");
+	const bool add = accum == FaerAccum_Add;
+	Staged<const T> a(view<T>(A), true, false), b(view<T>(B), true, false);
+	// a triangular dst keeps its other triangle => always copy in
+	Staged<T> c(view<T>(C), add || cb != FaerBlock_Rectangular, true);
+	matmul_triangular_dev<T>(c.dev, (int) cb, add, a.dev, (int) ab, b.dev, (int) bb, *static_cast<const T *>(alpha));
+}
+
+template <typename T> void trsm_api(FaerMatRef Tm, FaerMatMut rhs, bool upper, bool unit)
+{
+	FH_CHECK(Tm.nrows == Tm.ncols && rhs.nrows == Tm.ncols, "triangular solve: dimension mismatch");
+	Staged<const T> t(view<T>(Tm), true, false);
+	Staged<T> x(view<T>(rhs), true, true);
+	if (upper)
+		trsm_upper_dev<T>(t.dev, unit, x.dev);
+	else
+		trsm_lower_dev<T>(t.dev, unit, x.dev);
+}
+
+template <typename T> FaerLltStatus llt_api(FaerMatMut A, FaerLltRegularization reg)
+{
+	FH_CHECK(A.nrows == A.ncols, "llt: matrix must be square");
+	T delta = reg.dynamic_regularization_delta ? *static_cast<const T *>(reg.dynamic_regularization_delta) : (T) 0;
+	T eps = reg.dynamic_regularization_epsilon ? *static_cast<const T *>(reg.dynamic_regularization_epsilon) : (T) 0;
+	long r;
+	{
+		Staged<T> a(view<T>(A), true, true);
+		r = potrf_lower_dev<T>(a.dev, delta, eps);
+	}
+	FaerLltStatus st;
+	memset(&st, 0, sizeof(st));
+	if (r >= 0) {
+		st.tag = FaerLltStatus_Ok;
+		st.ok.dynamic_regularization_count = (size_t) r;
+	} else {
+		st.tag = FaerLltStatus_NonPositivePivot;
+		st.non_positive_pivot.index = (size_t) (-r - 1);
+	}
+	return st;
+}
+
+template <typename T> void llt_solve_api(FaerMatRef L, FaerMatMut rhs)
+{
+	// cholesky/llt/solve.rs:12-35: L y = b ; L^H x = y
+	FH_CHECK(L.nrows == L.ncols && rhs.nrows == L.nrows, "llt solve: dimension mismatch");
+	Staged<const T> l(view<T>(L), true, false);
+	Staged<T> x(view<T>(rhs), true, true);
+	trsm_lower_dev<T>(l.dev, false, x.dev);
+	trsm_upper_dev<T>(l.dev.t(), false, x.dev);
+}
+
+template <typename T, typename I> FaerPartialPivLuStatus lu_api(FaerMatMut A, FaerSliceMut pf, FaerSliceMut pb)
+{
+	const idx_t m = (idx_t) A.nrows;
+	FH_CHECK((idx_t) pf.len == m && (idx_t) pb.len == m, "partial_piv_lu: perm slices must have nrows entries");
+	FH_CHECK(!is_device_ptr(pf.ptr) && !is_device_ptr(pb.ptr), "partial_piv_lu: perm slices must be host memory");
+	std::vector<idx_t> perm((size_t) m), perm_inv((size_t) m);
+	long nt;
+	{
+		Staged<T> a(view<T>(A), true, true);
+		nt = getrf_dev<T>(a.dev, perm.data(), perm_inv.data());
+	}
+	I *f = static_cast<I *>(pf.ptr), *b = static_cast<I *>(pb.ptr);
+	for (idx_t i = 0; i < m; ++i) {
+		f[i] = (I) perm[(size_t) i];
+		b[i] = (I) perm_inv[(size_t) i];
+	}
+	FaerPartialPivLuStatus st;
+	memset(&st, 0, sizeof(st));
+	st.tag = FaerPartialPivLuStatus_Ok;
+	st.ok.transposition_count = (size_t) nt;
+	return st;
+}
+
+size_t qr_block_size(size_t nrows, size_t ncols)
+{
+	// qr/no_pivoting/factor.rs:91-116
+	const size_t prod = nrows * ncols;
+	const size_t size = nrows < ncols ? nrows : ncols;
+	size_t r;
+	if (prod > 8192UL * 8192)
+		r = 256;
+	else if (prod > 2048UL * 2048)
+		r = 128;
+	else if (prod > 1024UL * 1024)
+		r = 64;
+	else if (prod > 512UL * 512)
+		r = 48;
+	else if (prod > 128UL * 128)
+		r = 32;
+	else if (prod > 32UL * 32)
+		r = 8;
+	else if (prod > 16UL * 16)
+		r = 4;
+	else
+		r = 1;
+	if (r > size)
+		r = size;
+	return r < 1 ? 1 : r;
+}
+
+template <typename T> FaerQrStatus qr_api(FaerMatMut A, FaerMatMut Q, FaerQrParams params)
+{
+	const size_t size = A.nrows < A.ncols ? A.nrows : A.ncols;
+	FH_CHECK(Q.nrows > 0 && Q.ncols == size, "qr: Q_coeff must be block_size x min(nrows, ncols)");
+	long rank;
+	{
+		Staged<T> a(view<T>(A), true, true);
+		Staged<T> q(view<T>(Q), false, true);
+		rank = geqrf_dev<T>(a.dev, q.dev, (idx_t) params.blocking_threshold);
+	}
+	FaerQrStatus st;
+	memset(&st, 0, sizeof(st));
+	st.tag = FaerQrStatus_Ok;
+	st.ok.rank = (size_t) rank;
+	return st;
+}
+
+template <typename T> void apply_hh_api(FaerMatRef V, FaerMatRef H, FaerMatMut rhs, bool transpose)
+{
+	const size_t size = V.nrows < V.ncols ? V.nrows : V.ncols;
+	FH_CHECK(H.nrows > 0 && H.ncols == size && rhs.nrows == V.nrows, "apply_householder: dimension mismatch");
+	Staged<const T> v(view<T>(V), true, false), h(view<T>(H), true, false);
+	Staged<T> x(view<T>(rhs), true, true);
+	apply_householder_sequence_left_dev<T>(v.dev, h.dev, x.dev, transpose);
+}
+
+FaerLayout layout(size_t bytes, size_t align) { return FaerLayout{bytes, align}; }
+
+} // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------- inner boundary
+void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m, size_t n, size_t k, void *dst, ptrdiff_t dst_rs,
+		   ptrdiff_t dst_cs, const void *row_idx, const void *col_idx, FaerHipDstKind dst_kind, FaerAccum accum,
+		   const void *lhs, ptrdiff_t lhs_rs, ptrdiff_t lhs_cs, bool conj_lhs, const void *diag, ptrdiff_t diag_stride,
+		   const void *rhs, ptrdiff_t rhs_rs, ptrdiff_t rhs_cs, bool conj_rhs, const void *alpha, size_t n_threads)
+{
+	(void) conj_lhs; // conjugation is the identity for real scalars
+	(void) conj_rhs;
+	(void) n_threads;
+	FH_CHECK(dtype == FaerHipDType_F32 || dtype == FaerHipDType_F64, "faer_hip_gemm: only f32/f64 are supported");
+	FH_CHECK(alpha != nullptr, "faer_hip_gemm: alpha is NULL");
+	if (m == 0 || n == 0)
+		return;
+	const bool add = accum == FaerAccum_Add;
+	auto run = [&](auto tag) {
+		typedef decltype(tag) T;
+		const size_t isz = itype == FaerHipIType_U64 ? 8 : 4;
+		// extent of dst in rows / cols when scattered through the index arrays
+		idx_t drows = (idx_t) m, dcols = (idx_t) n;
+		std::vector<unsigned char> hri, hci;
+		auto max_idx = [&](const void *p, size_t cnt) {
+			idx_t mx = 0;
+			for (size_t i = 0; i < cnt; ++i) {
+				idx_t v = isz == 8 ? (idx_t) static_cast<const uint64_t *>(p)[i]
+						   : (idx_t) static_cast<const uint32_t *>(p)[i];
+				if (v > mx)
+					mx = v;
+			}
+			return mx;
+		};
+		const bool ri_host = row_idx && !is_device_ptr(row_idx), ci_host = col_idx && !is_device_ptr(col_idx);
+		FH_CHECK((!row_idx || ri_host || is_device_ptr(dst)) && (!col_idx || ci_host || is_device_ptr(dst)),
+			 "faer_hip_gemm: device index arrays require a device dst");
+		if (ri_host)
+			drows = max_idx(row_idx, m) + 1;
+		if (ci_host)
+			dcols = max_idx(col_idx, n) + 1;
+		MatV<T> D{static_cast<T *>(dst), drows, dcols, (idx_t) dst_rs, (idx_t) dst_cs};
+		MatV<const T> A{static_cast<const T *>(lhs), (idx_t) m, (idx_t) k, (idx_t) lhs_rs, (idx_t) lhs_cs};
+		MatV<const T> B{static_cast<const T *>(rhs), (idx_t) k, (idx_t) n, (idx_t) rhs_rs, (idx_t) rhs_cs};
+		MatV<const T> Dg{static_cast<const T *>(diag), diag ? (idx_t) k : 0, 1, (idx_t) diag_stride, 0};
+		Staged<const T> a(A, true, false), b(B, true, false), dg(Dg, true, false);
+		// a non-Full or scattered dst keeps untouched entries => copy in
+		Staged<T> c(D, add || dst_kind != FaerHipDstKind_Full || row_idx || col_idx, true);
+		Staged<const unsigned char> ri(MatV<const unsigned char>{static_cast<const unsigned char *>(row_idx),
+									  row_idx ? (idx_t) (m * isz) : 0, 1, 1, 0},
+					       true, false);
+		Staged<const unsigned char> ci(MatV<const unsigned char>{static_cast<const unsigned char *>(col_idx),
+									  col_idx ? (idx_t) (n * isz) : 0, 1, 1, 0},
+					       true, false);
+		GemmExtra<T> ex;
+		ex.row_idx = row_idx ? ri.dev.p : nullptr;
+		ex.col_idx = col_idx ? ci.dev.p : nullptr;
+		ex.idx64 = isz == 8;
+		ex.diag = diag ? dg.dev.p : nullptr;
+		ex.diag_stride = (idx_t) diag_stride;
+		MatV<T> Cv{c.dev.p, (idx_t) m, (idx_t) n, c.dev.rs, c.dev.cs};
+		gemm_dev<T>(Cv, (DstKind) dst_kind, add, a.dev, b.dev, *static_cast<const T *>(alpha), &ex);
+	};
+	if (dtype == FaerHipDType_F64)
+		run(double());
+	else
+		run(float());
+}
+
+// ---------------------------------------------------------------------------------------- outer boundary
+#define FH_FOR_DTYPES(X) X(f64, double) X(f32, float)
+
+#define X(suf, T)                                                                                                      \
+	void libfaer_v0_23_matmul_##suf(FaerMatMut C, FaerAccum accum, FaerMatRef A, FaerMatRef B, const void *alpha,    \
+					FaerPar par)                                                                        \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		matmul_api<T>(C, accum, A, B, alpha);                                                                  \
+	}                                                                                                              \
+	void libfaer_v0_23_matmul_triangular_##suf(FaerMatMut C, FaerBlock C_block, FaerAccum accum, FaerMatRef A,      \
+						   FaerBlock A_block, FaerMatRef B, FaerBlock B_block, const void *alpha,    \
+						   FaerPar par)                                                             \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		matmul_triangular_api<T>(C, C_block, accum, A, A_block, B, B_block, alpha);                             \
+	}                                                                                                              \
+	void libfaer_v0_23_solve_triangular_lower_in_place_##suf(FaerMatRef L, FaerConj cj, FaerMatMut rhs, FaerPar par) \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		trsm_api<T>(L, rhs, false, false);                                                                     \
+	}                                                                                                              \
+	void libfaer_v0_23_solve_triangular_upper_in_place_##suf(FaerMatRef U, FaerConj cj, FaerMatMut rhs, FaerPar par) \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		trsm_api<T>(U, rhs, true, false);                                                                      \
+	}                                                                                                              \
+	void libfaer_v0_23_solve_unit_triangular_lower_in_place_##suf(FaerMatRef L, FaerConj cj, FaerMatMut rhs,        \
+								      FaerPar par)                                          \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		trsm_api<T>(L, rhs, false, true);                                                                      \
+	}                                                                                                              \
+	void libfaer_v0_23_solve_unit_triangular_upper_in_place_##suf(FaerMatRef U, FaerConj cj, FaerMatMut rhs,        \
+								      FaerPar par)                                          \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		trsm_api<T>(U, rhs, true, true);                                                                       \
+	}                                                                                                              \
+	FaerLltParams libfaer_v0_23_LltParams_##suf(void) { return FaerLltParams{64, 128}; }                            \
+	FaerLayout libfaer_v0_23_llt_factor_in_place_scratch_##suf(size_t dim, FaerPar par, FaerLltParams params)       \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		(void) params;                                                                                         \
+		return layout(dim * sizeof(T), 64);                                                                    \
+	}                                                                                                              \
+	FaerLltStatus libfaer_v0_23_llt_factor_in_place_##suf(FaerMatMut A, FaerLltRegularization reg, FaerPar par,     \
+							      FaerMemAlloc mem, FaerLltParams params)                        \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		(void) params;                                                                                         \
+		return llt_api<T>(A, reg);                                                                             \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_llt_solve_in_place_scratch_##suf(size_t dim, size_t rhs_ncols, FaerPar par)            \
+	{                                                                                                              \
+		(void) dim;                                                                                            \
+		(void) rhs_ncols;                                                                                      \
+		(void) par;                                                                                            \
+		return layout(0, 1);                                                                                   \
+	}                                                                                                              \
+	void libfaer_v0_23_llt_solve_in_place_##suf(FaerMatRef L, FaerConj cj, FaerMatMut rhs, FaerPar par,             \
+						    FaerMemAlloc mem)                                                       \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		llt_solve_api<T>(L, rhs);                                                                              \
+	}                                                                                                              \
+	FaerPartialPivLuParams libfaer_v0_23_PartialPivLuParams_##suf(void)                                             \
+	{                                                                                                              \
+		return FaerPartialPivLuParams{16, 64, 128 * 128};                                                      \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_partial_piv_lu_factor_in_place_scratch_u32_##suf(size_t dim, size_t bs, FaerPar par,   \
+										  FaerPartialPivLuParams params)            \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		(void) params;                                                                                         \
+		return layout((dim < bs ? dim : bs) * 4, 4);                                                           \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_partial_piv_lu_factor_in_place_scratch_u64_##suf(size_t dim, size_t bs, FaerPar par,   \
+										  FaerPartialPivLuParams params)            \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		(void) params;                                                                                         \
+		return layout((dim < bs ? dim : bs) * 8, 8);                                                           \
+	}                                                                                                              \
+	FaerPartialPivLuStatus libfaer_v0_23_partial_piv_lu_factor_in_place_u32_##suf(                                  \
+		FaerMatMut A, FaerSliceMut pf, FaerSliceMut pb, FaerPar par, FaerMemAlloc mem, FaerPartialPivLuParams params) \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		(void) params;                                                                                         \
+		return lu_api<T, uint32_t>(A, pf, pb);                                                                 \
+	}                                                                                                              \
+	FaerPartialPivLuStatus libfaer_v0_23_partial_piv_lu_factor_in_place_u64_##suf(                                  \
+		FaerMatMut A, FaerSliceMut pf, FaerSliceMut pb, FaerPar par, FaerMemAlloc mem, FaerPartialPivLuParams params) \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		(void) params;                                                                                         \
+		return lu_api<T, uint64_t>(A, pf, pb);                                                                 \
+	}                                                                                                              \
+	FaerQrParams libfaer_v0_23_QrParams_##suf(void) { return FaerQrParams{48 * 48, 192 * 256}; }                    \
+	size_t libfaer_v0_23_qr_recommended_block_size_##suf(size_t nrows, size_t ncols)                                \
+	{                                                                                                              \
+		return qr_block_size(nrows, ncols);                                                                    \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_qr_factor_in_place_scratch_##suf(size_t nrows, size_t ncols, size_t bs, FaerPar par,   \
+								  FaerQrParams params)                                      \
+	{                                                                                                              \
+		(void) nrows;                                                                                          \
+		(void) par;                                                                                            \
+		(void) params;                                                                                         \
+		return layout(bs * ncols * sizeof(T), 64);                                                             \
+	}                                                                                                              \
+	FaerQrStatus libfaer_v0_23_qr_factor_in_place_##suf(FaerMatMut A, FaerMatMut Q, FaerPar par, FaerMemAlloc mem,  \
+							    FaerQrParams params)                                            \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		return qr_api<T>(A, Q, params);                                                                        \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_apply_householder_on_the_left_scratch_##suf(size_t dim, size_t bs, size_t k)           \
+	{                                                                                                              \
+		(void) dim;                                                                                            \
+		return layout(bs * k * sizeof(T), 64);                                                                 \
+	}                                                                                                              \
+	void libfaer_v0_23_apply_householder_on_the_left_##suf(FaerMatRef V, FaerMatRef H, FaerConj cj, FaerMatMut rhs, \
+							       FaerPar par, FaerMemAlloc mem)                               \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		apply_hh_api<T>(V, H, rhs, false);                                                                     \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_apply_householder_transpose_on_the_left_scratch_##suf(size_t dim, size_t bs, size_t k) \
+	{                                                                                                              \
+		(void) dim;                                                                                            \
+		return layout(bs * k * sizeof(T), 64);                                                                 \
+	}                                                                                                              \
+	void libfaer_v0_23_apply_householder_transpose_on_the_left_##suf(FaerMatRef V, FaerMatRef H, FaerConj cj,       \
+									 FaerMatMut rhs, FaerPar par, FaerMemAlloc mem)     \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		apply_hh_api<T>(V, H, rhs, true);                                                                      \
+	}
+FH_FOR_DTYPES(X)
+#undef X
+
+FaerPar libfaer_v0_23_get_global_par(void)
+{
+	FaerPar p;
+	p.tag = (FaerParTag) g_par_tag.load();
+	p.nthreads = p.tag == FaerParTag_Seq ? 1 : g_par_threads.load();
+	return p;
+}
+void libfaer_v0_23_set_global_par(FaerPar par)
+{
+	g_par_tag.store((int) par.tag);
+	g_par_threads.store(par.nthreads);
+}
+
+// ---------------------------------------------------------------------------------------- runtime control
+const char *faer_hip_version(void) { return "faer_hip 0.1 gfx950"; }
+
+int faer_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		(void) hipGetLastError();
+		return 0;
+	}
+	int ok = 0;
+	for (int d = 0; d < n; ++d) {
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+			++ok;
+	}
+	return ok;
+}
+void faer_hip_set_device(int device)
+{
+	FH_HIP(hipSetDevice(device));
+	Ctx &c = ctx();
+	c.device = device;
+}
+void faer_hip_set_stream(void *s) { ctx().stream = static_cast<hipStream_t>(s); }
+void *faer_hip_get_stream(void) { return ctx().stream; }
+void faer_hip_synchronize(void) { ctx().sync(); }
+void *faer_hip_malloc(size_t bytes)
+{
+	ctx();
+	void *p = nullptr;
+	FH_HIP(hipMalloc(&p, bytes ? bytes : 1));
+	return p;
+}
+void faer_hip_free(void *p)
+{
+	if (p)
+		FH_HIP(hipFree(p));
+}
+void faer_hip_memcpy_h2d(void *d, const void *s, size_t bytes)
+{
+	FH_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, ctx().stream));
+	ctx().sync();
+}
+void faer_hip_memcpy_d2h(void *d, const void *s, size_t bytes)
+{
+	FH_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, ctx().stream));
+	ctx().sync();
+}
+void faer_hip_set_gemm_variant(int v) { ctx().gemm_variant = v; }
+
+double faer_hip_time_gemm_ms(FaerHipDType dtype, size_t m, size_t n, size_t k, void *dst, ptrdiff_t dst_cs, const void *lhs,
+			     ptrdiff_t lhs_cs, const void *rhs, ptrdiff_t rhs_cs, int iters)
+{
+	FH_CHECK(is_device_ptr(dst) && is_device_ptr(lhs) && is_device_ptr(rhs), "time_gemm: operands must be device memory");
+	if (dtype == FaerHipDType_F64)
+		return gemm_time_ms<double>(MatV<double>{(double *) dst, (idx_t) m, (idx_t) n, 1, (idx_t) dst_cs},
+					    MatV<const double>{(const double *) lhs, (idx_t) m, (idx_t) k, 1, (idx_t) lhs_cs},
+					    MatV<const double>{(const double *) rhs, (idx_t) k, (idx_t) n, 1, (idx_t) rhs_cs}, iters);
+	FH_CHECK(dtype == FaerHipDType_F32, "time_gemm: f32/f64 only");
+	return gemm_time_ms<float>(MatV<float>{(float *) dst, (idx_t) m, (idx_t) n, 1, (idx_t) dst_cs},
+				   MatV<const float>{(const float *) lhs, (idx_t) m, (idx_t) k, 1, (idx_t) lhs_cs},
+				   MatV<const float>{(const float *) rhs, (idx_t) k, (idx_t) n, 1, (idx_t) rhs_cs}, iters);
+}
+double faer_hip_mfma_peak_tflops(FaerHipDType dtype, int iters) { return mfma_peak_tflops(dtype == FaerHipDType_F64, iters); }
+
+} // extern "C"

@@ -1,0 +1,187 @@
+// Shared host-side infrastructure of libfaer_hip.so (gfx950 only, no compatibility layers).
+//
+//  * MatV<T>: the strided view every driver works on.  It is faer's MatView
+//    {ptr, nrows, ncols, row_stride, col_stride} (faer/src/mat/mod.rs:7-13) with strides in elements.
+//  * Ctx: per-thread device / stream / scratch state.  faer's entry points may be called from any
+//    rayon worker => everything mutable is thread_local.
+//  * Staged<T>: host<->device staging so that a host-resident faer::Mat works unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/faer_hip.h"
+
+namespace fh {
+
+[[noreturn]] inline void die(const char *msg, const char *file, int line)
+{
+	fprintf(stderr, "faer_hip: fatal: %s (%s:%d)\n", msg, file, line);
+	fflush(stderr);
+	abort();
+}
+#define FH_CHECK(cond, msg)                                                                                             \
+	do {                                                                                                            \
+		if (!(cond))                                                                                            \
+			::fh::die(msg, __FILE__, __LINE__);                                                             \
+	} while (0)
+#define FH_HIP(expr)                                                                                                    \
+	do {                                                                                                            \
+		hipError_t e_ = (expr);                                                                                 \
+		if (e_ != hipSuccess)                                                                                   \
+			::fh::die(hipGetErrorString(e_), __FILE__, __LINE__);                                           \
+	} while (0)
+
+typedef long idx_t;
+
+template <typename T> struct MatV {
+	T *p;
+	idx_t nrows, ncols, rs, cs;
+
+	MatV sub(idx_t r0, idx_t c0, idx_t nr, idx_t nc) const { return MatV{p + r0 * rs + c0 * cs, nr, nc, rs, cs}; }
+	MatV t() const { return MatV{p, ncols, nrows, cs, rs}; }
+	MatV rev_rows() const { return MatV{nrows > 0 ? p + (nrows - 1) * rs : p, nrows, ncols, -rs, cs}; }
+	MatV rev_cols() const { return MatV{ncols > 0 ? p + (ncols - 1) * cs : p, nrows, ncols, rs, -cs}; }
+	MatV<const T> c() const { return MatV<const T>{p, nrows, ncols, rs, cs}; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// per-thread context
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	int gemm_variant = 0;
+	// scratch pool: simple stack of device buffers reused across calls of this thread
+	struct Buf {
+		void *p;
+		size_t bytes;
+		bool used;
+	};
+	std::vector<Buf> pool;
+	int *status = nullptr; // 16 ints of device status words (pinned-host readable copy below)
+	int *status_host = nullptr;
+
+	void ensure_device();
+	void *alloc(size_t bytes); // returns a device buffer valid until release()
+	void release(void *p);
+	void sync() { FH_HIP(hipStreamSynchronize(stream)); }
+};
+Ctx &ctx();
+
+// RAII scratch
+struct Scratch {
+	void *p;
+	explicit Scratch(size_t bytes) : p(ctx().alloc(bytes)) {}
+	~Scratch() { ctx().release(p); }
+	Scratch(const Scratch &) = delete;
+	Scratch &operator=(const Scratch &) = delete;
+	template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+bool is_device_ptr(const void *p);
+
+// Span of memory (in elements, relative to .p) touched by a strided view.
+template <typename T> inline void view_span(const MatV<T> &v, idx_t &lo, idx_t &hi)
+{
+	lo = 0;
+	hi = 0;
+	if (v.nrows == 0 || v.ncols == 0)
+		return;
+	idx_t r = (v.nrows - 1) * v.rs, c = (v.ncols - 1) * v.cs;
+	lo = (r < 0 ? r : 0) + (c < 0 ? c : 0);
+	hi = (r > 0 ? r : 0) + (c > 0 ? c : 0);
+}
+
+// Host->device staging of one operand.  If the view already lives in device memory it is used in
+// place; otherwise the (contiguous span of the) view is copied to a scratch buffer keeping the strides,
+// and copied back on destruction when `writeback` is set.
+template <typename T> struct Staged {
+	MatV<T> dev;
+	T *host_base = nullptr;
+	void *buf = nullptr;
+	size_t bytes = 0;
+	bool writeback = false;
+
+	Staged(MatV<T> v, bool copy_in, bool writeback_)
+	{
+		typedef typename std::remove_const<T>::type U;
+		dev = v;
+		if (v.nrows == 0 || v.ncols == 0 || is_device_ptr(v.p))
+			return;
+		idx_t lo, hi;
+		view_span(v, lo, hi);
+		bytes = (size_t)(hi - lo + 1) * sizeof(T);
+		buf = ctx().alloc(bytes);
+		host_base = const_cast<T *>(v.p) + lo;
+		if (copy_in)
+			FH_HIP(hipMemcpyAsync(buf, (const void *)host_base, bytes, hipMemcpyHostToDevice, ctx().stream));
+		dev.p = reinterpret_cast<T *>(static_cast<U *>(buf) - lo);
+		writeback = writeback_;
+	}
+	~Staged()
+	{
+		if (!buf)
+			return;
+		if (writeback) {
+			FH_HIP(hipMemcpyAsync((void *)host_base, buf, bytes, hipMemcpyDeviceToHost, ctx().stream));
+			FH_HIP(hipStreamSynchronize(ctx().stream));
+		}
+		ctx().release(buf);
+	}
+	Staged(const Staged &) = delete;
+	Staged &operator=(const Staged &) = delete;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device-level drivers (operands are device memory); defined in the .hip files
+// ------------------------------------------------------------------------------------------------
+enum DstKind { DST_FULL = 0, DST_LOWER = 1, DST_UPPER = 2 };
+
+template <typename T> struct GemmExtra {
+	const void *row_idx = nullptr; // device memory, itype-wide indices
+	const void *col_idx = nullptr;
+	int idx64 = 1;
+	const T *diag = nullptr; // device memory
+	idx_t diag_stride = 0;
+	int a_struct = 0, b_struct = 0; // FaerBlock codes of the operands (triangular products)
+	bool dst_strict = false;	// with DST_LOWER / DST_UPPER: leave the diagonal untouched
+};
+
+// dst(kind) <- [dst +] alpha * A * diag * B        (gemm.hip)
+template <typename T>
+void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> B, T alpha,
+	      const GemmExtra<T> *extra = nullptr);
+// average ms per launch of the dense kernel (hipEvents on the ctx stream)
+template <typename T> double gemm_time_ms(MatV<T> C, MatV<const T> A, MatV<const T> B, int iters);
+double mfma_peak_tflops(bool f64, int iters);
+
+// dst(structure) <- [dst +] alpha * A(structure) * B(structure)   (trmm.hip)
+template <typename T>
+void matmul_triangular_dev(MatV<T> C, int c_s, bool add, MatV<const T> A, int a_s, MatV<const T> B, int b_s, T alpha);
+
+// X <- op(T)^-1 X, T lower triangular n x n, X n x k (trsm.hip); upper handled by reversal
+template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X);
+template <typename T> void trsm_upper_dev(MatV<const T> U, bool unit, MatV<T> X);
+
+// in-place lower Cholesky; returns >=0 regularization count or -(index+1)   (potrf.hip)
+template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps);
+
+// partial pivot LU; perm/perm_inv are HOST arrays of idx_t (m entries)   (getrf.hip)
+template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv);
+
+// Householder QR without pivoting (qr.hip); H is block_size x min(m,n) (device). returns rank
+template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold);
+template <typename T>
+void apply_householder_sequence_left_dev(MatV<const T> V, MatV<const T> H, MatV<T> M, bool transpose);
+
+// small utility kernels (util.hip)
+template <typename T> void fill_dev(MatV<T> A, DstKind kind, T value);
+template <typename T> void copy_dev(MatV<T> dst, MatV<const T> src);
+
+} // namespace fh

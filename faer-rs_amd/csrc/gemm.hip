@@ -1,0 +1,629 @@
+// fp64 / fp32 GEMM for gfx950 on the MFMA pipe.
+//
+// Replaces the kernel behind faer's `gemm_call!` (faer/src/linalg/matmul/mod.rs:1312-1453, i.e.
+// private_gemm_x86::gemm with DstKind::{Full,Lower,Upper}) -- SURVEY.md section 8a rows a6 / a12 / a14.
+//
+// Design (CDNA4-first, not a port of a CPU packing GEMM):
+//   * one workgroup = WM x WN waves, block tile BM x BN, K step BK = 16;
+//   * each wave owns a (BM/WM) x (BN/WN) sub-tile as TM x TN accumulators of v_mfma_{f64,f32}_16x16x4
+//     (one VGPR pair / one VGPR per operand per lane, 64 / 32 cycles per instruction): the pipe is fed
+//     with 8 LDS reads per 16 MFMAs, so LDS bandwidth is irrelevant and the kernel is MFMA-issue bound;
+//   * A and B tiles are staged through LDS with a register prefetch of the next K tile (global loads
+//     for tile t+1 are in flight while tile t is multiplied) and two LDS buffers => ONE barrier per K tile;
+//   * operands may have ANY signed element strides.  Two loader shapes per operand pick the coalesced
+//     direction: "MN-major" (unit stride along the m / n index, LDS image [k][mn], row pitch == 16 mod 32
+//     elements) and "K-major" (unit stride along k, LDS image [mn][k], pitch BK+2): both images are
+//     bank-conflict free for the ds_read_b64 / ds_read_b32 fragment reads (MI355X_MICROARCH.md, LDS table);
+//   * the MFMA is issued with the operands swapped (D' = tile^T) so that a lane's 16 neighbours hold 16
+//     consecutive rows of C: 128-byte contiguous stores into a column-major dst;
+//   * blockIdx is remapped XCD-aware (each XCD's private L2 gets a contiguous run of tiles) and then
+//     rastered in groups of 8 tile rows; DstKind::Lower enumerates only the tiles that touch the lower
+//     triangle;
+//   * tall-skinny products (K >> M,N: the Householder T = V^H V products of QR) use split-K with fp64/fp32
+//     hardware atomics.
+#include <type_traits>
+
+#include "common.h"
+
+namespace fh {
+
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+	typedef double acc_t __attribute__((ext_vector_type(4)));
+	static __device__ __forceinline__ acc_t run(double a, double b, acc_t c)
+	{
+		return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+	}
+	// f64 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+	static __device__ __forceinline__ int row(int r, int lhi) { return lhi + 4 * r; }
+};
+template <> struct Mfma<float> {
+	typedef float acc_t __attribute__((ext_vector_type(4)));
+	static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
+	{
+		return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+	}
+	// f32 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
+	static __device__ __forceinline__ int row(int r, int lhi) { return lhi * 4 + r; }
+};
+
+template <typename T> struct GemmArgs {
+	int M, N, K;
+	T *dst;
+	idx_t drs, dcs;
+	const T *a;
+	idx_t ars, acs; // element (m,k) at a[m*ars + k*acs]
+	const T *b;
+	idx_t brs, bcs; // element (k,n) at b[k*brs + n*bcs]
+	T alpha;
+	int add;    // 1: dst += ; 0: dst =
+	int lower;  // 1: only i >= j written
+	int atomic; // split-K: atomicAdd(alpha * partial)
+	int k_per_split;
+	int ntm, ntn;
+	int tri_enum; // lower && square tiles: grid enumerates the lower triangle of tiles only
+	const void *row_idx;
+	const void *col_idx;
+	int idx64;
+	const T *diag;
+	idx_t diag_stride;
+	int a_struct, b_struct; // FaerBlock codes of lhs (m x k) and rhs (k x n); EXTRA kernels only
+	int dst_strict;		// lower && strict: only i > j written
+};
+
+// FaerBlock membership test (faer/src/linalg/matmul/triangular.rs:906-977)
+static __device__ __forceinline__ bool in_block(int s, int i, int j)
+{
+	return s == 0 || ((s == 1) & (i >= j)) || ((s == 2) & (i <= j)) || (((s == 3) | (s == 5)) & (i > j)) ||
+	       (((s == 4) | (s == 6)) & (i < j));
+}
+
+static __device__ __forceinline__ idx_t load_idx(const void *p, int idx64, int i)
+{
+	return idx64 ? (idx_t) reinterpret_cast<const unsigned long long *>(p)[i]
+		     : (idx_t) reinterpret_cast<const unsigned int *>(p)[i];
+}
+
+// blockIdx.x -> tile coordinates.  (1) XCD remap: hardware deals block b to XCD b % 8, so give XCD x
+// the contiguous range of logical ids [start_x, start_x + count_x) (bijective for any grid size);
+// (2) logical id -> (tm, tn) in groups of 8 tile rows, column fastest inside the group's rows.
+static __device__ __forceinline__ int xcd_remap(int b, int nblocks)
+{
+	const int q = nblocks >> 3, r = nblocks & 7;
+	const int xcd = b & 7, idx = b >> 3;
+	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool AKM, bool BKM, bool EXTRA>
+__global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kernel(const GemmArgs<T> g)
+{
+	constexpr int NT = WM * WN * 64;
+	constexpr int WTM = BM / WM, WTN = BN / WN; // wave tile
+	constexpr int TM = WTM / 16, TN = WTN / 16;
+	constexpr int SA = AKM ? BK + 2 : BM + 16; // LDS pitch (elements)
+	constexpr int SB = BKM ? BK + 2 : BN + 16;
+	constexpr int A_SZ = AKM ? BM * SA : BK * SA;
+	constexpr int B_SZ = BKM ? BN * SB : BK * SB;
+	constexpr int A_CNT = BM * BK / NT, B_CNT = BN * BK / NT; // elements per thread per tile
+	static_assert(BM * BK % NT == 0 && BN * BK % NT == 0, "tile/threads");
+	static_assert(NT % BM == 0 || AKM, "MN loader needs NT % BM == 0");
+	static_assert(NT % BN == 0 || BKM, "MN loader needs NT % BN == 0");
+	static_assert(NT % BK == 0, "K loader needs NT % BK == 0");
+	typedef typename Mfma<T>::acc_t acc_t;
+
+	__shared__ T smem[2 * (A_SZ + B_SZ)];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int wm = wave % WM, wn = wave / WM;
+	const int l15 = lane & 15, lhi = lane >> 4;
+
+	// ---- tile coordinates
+	int tm, tn;
+	{
+		const int nblocks = gridDim.x;
+		const int pid = xcd_remap(blockIdx.x, nblocks);
+		if (g.tri_enum) {
+			// pid enumerates (i, j), j <= i, row by row
+			int i = (int) ((sqrtf(8.0f * (float) pid + 1.0f) - 1.0f) * 0.5f);
+			while ((i + 1) * (i + 2) / 2 <= pid)
+				++i;
+			while (i * (i + 1) / 2 > pid)
+				--i;
+			tm = i;
+			tn = pid - i * (i + 1) / 2;
+		} else {
+			constexpr int G = 8;
+			const int per_group = G * g.ntn;
+			const int grp = pid / per_group;
+			const int first_m = grp * G;
+			const int gsz = min(g.ntm - first_m, G);
+			const int rem = pid - grp * per_group;
+			tm = first_m + rem % gsz;
+			tn = rem / gsz;
+		}
+	}
+	const int m_off = tm * BM, n_off = tn * BN;
+	if (g.lower && m_off + BM - 1 < n_off)
+		return; // tile entirely above the diagonal
+
+	int k_begin = blockIdx.z * g.k_per_split;
+	int k_end = min(g.K, k_begin + g.k_per_split);
+	if (EXTRA) {
+		// skip the K range where a triangular operand is identically zero for this tile
+		const int as = g.a_struct, bs = g.b_struct;
+		if (as == 1 || as == 3 || as == 5) // lhs lower: k <= m
+			k_end = min(k_end, m_off + BM);
+		if (as == 2 || as == 4 || as == 6) // lhs upper: k >= m
+			k_begin = max(k_begin, m_off / BK * BK);
+		if (bs == 1 || bs == 3 || bs == 5) // rhs lower: k >= n
+			k_begin = max(k_begin, n_off / BK * BK);
+		if (bs == 2 || bs == 4 || bs == 6) // rhs upper: k <= n
+			k_end = min(k_end, n_off + BN);
+	}
+	const bool k_empty = k_begin >= k_end;
+	if (k_empty && (g.add || g.atomic))
+		return; // nothing to accumulate (Replace still has to write zeros)
+
+	// ---- loader state.  MN-major: thread owns one mn index and A_CNT k's (stride KSTEP);
+	//      K-major: thread owns one k and A_CNT mn's (stride MSTEP).
+	constexpr int A_KSTEP = AKM ? 0 : NT / BM, A_MSTEP = AKM ? NT / BK : 0;
+	constexpr int B_KSTEP = BKM ? 0 : NT / BN, B_NSTEP = BKM ? NT / BK : 0;
+	const int a_mn = AKM ? tid / BK : tid % BM; // first mn (tile local)
+	const int a_k = AKM ? tid % BK : tid / BM;  // first k (tile local)
+	const int b_mn = BKM ? tid / BK : tid % BN;
+	const int b_k = BKM ? tid % BK : tid / BN;
+
+	T ra[A_CNT], rb[B_CNT];
+	unsigned amask = 0, bmask = 0; // validity of ra[] / rb[]; applied at LDS-store time so that the
+				       // global loads stay in flight across the MFMA section
+
+	// per-thread base pointers (64-bit math once); per-load offsets are wave-uniform
+	const int a_mn0 = m_off + a_mn, b_mn0 = n_off + b_mn;
+	const T *a_base = g.a + (AKM ? (idx_t) 0 : (idx_t) min(a_mn0, g.M - 1) * g.ars) + (idx_t) a_k * g.acs;
+	const T *b_base = g.b + (BKM ? (idx_t) 0 : (idx_t) min(b_mn0, g.N - 1) * g.bcs) + (idx_t) b_k * g.brs;
+	unsigned a_mnmask = 0, b_mnmask = 0;
+#pragma unroll
+	for (int i = 0; i < A_CNT; ++i)
+		a_mnmask |= (unsigned) (a_mn0 + (AKM ? i * A_MSTEP : 0) < g.M) << i;
+#pragma unroll
+	for (int i = 0; i < B_CNT; ++i)
+		b_mnmask |= (unsigned) (b_mn0 + (BKM ? i * B_NSTEP : 0) < g.N) << i;
+
+	auto load_a = [&](int k0, bool kcheck) {
+		amask = a_mnmask;
+#pragma unroll
+		for (int i = 0; i < A_CNT; ++i) {
+			const int mn = a_mn0 + (AKM ? i * A_MSTEP : 0);
+			const int k = k0 + a_k + (AKM ? 0 : i * A_KSTEP);
+			int kc = k;
+			if (kcheck) {
+				kc = min(k, k_end - 1);
+				if (k >= k_end)
+					amask &= ~(1u << i);
+			}
+			const T *p = a_base + (idx_t) (kc - a_k) * g.acs;
+			if (AKM)
+				p += (idx_t) min(mn, g.M - 1) * g.ars;
+			T v = *p;
+			if (EXTRA) {
+				const int as = g.a_struct;
+				if (!in_block(as, mn, k))
+					v = ((((as == 5) | (as == 6)) & (mn == k)) != 0) ? (T) 1 : (T) 0;
+			}
+			ra[i] = v;
+		}
+	};
+	auto load_b = [&](int k0, bool kcheck) {
+		bmask = b_mnmask;
+#pragma unroll
+		for (int i = 0; i < B_CNT; ++i) {
+			const int mn = b_mn0 + (BKM ? i * B_NSTEP : 0);
+			const int k = k0 + b_k + (BKM ? 0 : i * B_KSTEP);
+			int kc = k;
+			if (kcheck) {
+				kc = min(k, k_end - 1);
+				if (k >= k_end)
+					bmask &= ~(1u << i);
+			}
+			const T *p = b_base + (idx_t) (kc - b_k) * g.brs;
+			if (BKM)
+				p += (idx_t) min(mn, g.N - 1) * g.bcs;
+			T v = *p;
+			if (EXTRA) {
+				const int bs = g.b_struct;
+				if (!in_block(bs, k, mn))
+					v = ((((bs == 5) | (bs == 6)) & (mn == k)) != 0) ? (T) 1 : (T) 0;
+				if (g.diag)
+					v *= g.diag[(idx_t) kc * g.diag_stride];
+			}
+			rb[i] = v;
+		}
+	};
+	auto store_a = [&](T *sa) {
+#pragma unroll
+		for (int i = 0; i < A_CNT; ++i) {
+			const T v = (amask >> i) & 1u ? ra[i] : (T) 0;
+			if (AKM)
+				sa[(a_mn + i * A_MSTEP) * SA + a_k] = v;
+			else
+				sa[(a_k + i * A_KSTEP) * SA + a_mn] = v;
+		}
+	};
+	auto store_b = [&](T *sb) {
+#pragma unroll
+		for (int i = 0; i < B_CNT; ++i) {
+			const T v = (bmask >> i) & 1u ? rb[i] : (T) 0;
+			if (BKM)
+				sb[(b_mn + i * B_NSTEP) * SB + b_k] = v;
+			else
+				sb[(b_k + i * B_KSTEP) * SB + b_mn] = v;
+		}
+	};
+
+	acc_t acc[TM][TN];
+#pragma unroll
+	for (int i = 0; i < TM; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+			acc[i][j] = (acc_t) (T) 0;
+
+	auto compute = [&](const T *sa) {
+		const T *sb = sa + A_SZ;
+#pragma unroll
+		for (int kk = 0; kk < BK / 4; ++kk) {
+			T af[TM], bf[TN];
+#pragma unroll
+			for (int i = 0; i < TM; ++i) {
+				const int m = wm * WTM + i * 16 + l15;
+				af[i] = AKM ? sa[m * SA + kk * 4 + lhi] : sa[(kk * 4 + lhi) * SA + m];
+			}
+#pragma unroll
+			for (int j = 0; j < TN; ++j) {
+				const int n = wn * WTN + j * 16 + l15;
+				bf[j] = BKM ? sb[n * SB + kk * 4 + lhi] : sb[(kk * 4 + lhi) * SB + n];
+			}
+#pragma unroll
+			for (int i = 0; i < TM; ++i)
+#pragma unroll
+				for (int j = 0; j < TN; ++j)
+					acc[i][j] = Mfma<T>::run(bf[j], af[i], acc[i][j]);
+		}
+	};
+
+	// K loop: nk tiles; tiles 0 .. nk-2 are full, the last one may be partial (k-checked loads).
+	// Iteration t multiplies tile t out of LDS buffer t&1 while the global loads of tile t+1 are in
+	// flight; they land in the other buffer after the MFMA section.  One barrier per tile.
+	const int nk = k_empty ? 0 : (k_end - k_begin + BK - 1) / BK;
+	constexpr int STAGE = A_SZ + B_SZ;
+	if (nk > 0) {
+		const bool tail = nk == 1;
+		load_a(k_begin, tail);
+		load_b(k_begin, tail);
+		store_a(smem);
+		store_b(smem + A_SZ);
+	}
+	__syncthreads();
+	int kt = 0;
+	for (; kt + 2 < nk; ++kt) { // tile kt+1 is full
+		const int k0 = k_begin + (kt + 1) * BK;
+		load_a(k0, false);
+		load_b(k0, false);
+		compute(smem + (kt & 1) * STAGE);
+		T *nxt = smem + ((kt + 1) & 1) * STAGE;
+		store_a(nxt);
+		store_b(nxt + A_SZ);
+		__syncthreads();
+	}
+	if (kt + 1 < nk) { // tile kt+1 is the last one
+		const int k0 = k_begin + (kt + 1) * BK;
+		load_a(k0, true);
+		load_b(k0, true);
+		compute(smem + (kt & 1) * STAGE);
+		T *nxt = smem + ((kt + 1) & 1) * STAGE;
+		store_a(nxt);
+		store_b(nxt + A_SZ);
+		__syncthreads();
+		++kt;
+	}
+	if (nk > 0)
+		compute(smem + (kt & 1) * STAGE);
+
+	// ---- epilogue: lane (l15, lhi), reg r of acc[i][j] holds
+	//      C[m_off + wm*WTM + i*16 + l15][n_off + wn*WTN + j*16 + row(r, lhi)]
+#pragma unroll
+	for (int j = 0; j < TN; ++j)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int n = n_off + wn * WTN + j * 16 + Mfma<T>::row(r, lhi);
+			if (n >= g.N)
+				continue;
+			const idx_t ncol = g.col_idx ? load_idx(g.col_idx, g.idx64, n) : (idx_t) n;
+#pragma unroll
+			for (int i = 0; i < TM; ++i) {
+				const int m = m_off + wm * WTM + i * 16 + l15;
+				if (m >= g.M || (g.lower && (m < n || (g.dst_strict && m == n))))
+					continue;
+				const idx_t mrow = g.row_idx ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
+				T *p = g.dst + mrow * g.drs + ncol * g.dcs;
+				const T v = acc[i][j][r];
+				if (g.atomic)
+					atomicAdd(p, g.alpha * v);
+				else if (g.add)
+					*p = __builtin_fma(g.alpha, v, *p);
+				else
+					*p = g.alpha * v;
+			}
+		}
+}
+
+// ------------------------------------------------------------------------------------------------
+// zero / constant fill restricted to a DstKind (K == 0 with Replace, split-K pre-zero)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void fill_kernel(T *p, idx_t rs, idx_t cs, idx_t M, idx_t N, int kind, T value, const void *row_idx,
+			    const void *col_idx, int idx64)
+{
+	const idx_t total = M * N;
+	for (idx_t e = (idx_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (idx_t) gridDim.x * blockDim.x) {
+		const idx_t i = e % M, j = e / M;
+		const int kd = kind & 3;
+		if ((kd == DST_LOWER && i < j) || (kd == DST_UPPER && i > j) || ((kind & 4) && i == j))
+			continue;
+		const idx_t r = row_idx ? load_idx(row_idx, idx64, (int) i) : i;
+		const idx_t c = col_idx ? load_idx(col_idx, idx64, (int) j) : j;
+		p[r * rs + c * cs] = value;
+	}
+}
+
+static inline idx_t iabs(idx_t x) { return x < 0 ? -x : x; }
+
+template <typename T> static void fill_ext(MatV<T> A, DstKind kind, T value, const GemmExtra<T> *ex)
+{
+	if (A.nrows == 0 || A.ncols == 0)
+		return;
+	// put the smaller stride on the fast index (only when no index arrays are involved)
+	const bool swap = !ex && iabs(A.cs) < iabs(A.rs);
+	MatV<T> V = swap ? A.t() : A;
+	DstKind k = kind;
+	if (swap && kind != DST_FULL)
+		k = kind == DST_LOWER ? DST_UPPER : DST_LOWER;
+	const idx_t total = V.nrows * V.ncols;
+	idx_t blocks = (total + 255) / 256;
+	if (blocks > 65536)
+		blocks = 65536;
+	hipLaunchKernelGGL(fill_kernel<T>, dim3((unsigned) blocks), dim3(256), 0, ctx().stream, V.p, V.rs, V.cs, V.nrows,
+			   V.ncols, (int) k | (ex && ex->dst_strict && kind != DST_FULL ? 4 : 0), value, ex ? (swap ? ex->col_idx : ex->row_idx) : nullptr,
+			   ex ? (swap ? ex->row_idx : ex->col_idx) : nullptr, ex ? ex->idx64 : 1);
+	FH_HIP(hipGetLastError());
+}
+
+template <typename T> void fill_dev(MatV<T> A, DstKind kind, T value) { fill_ext<T>(A, kind, value, nullptr); }
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, bool EXTRA>
+static void launch_cfg(const GemmArgs<T> &g, bool akm, bool bkm, int splits)
+{
+	constexpr int BK = 16;
+	constexpr int NT = WM * WN * 64;
+	int nblocks = g.tri_enum ? g.ntm * (g.ntm + 1) / 2 : g.ntm * g.ntn;
+	dim3 grid((unsigned) nblocks, 1, (unsigned) splits), block(NT);
+	hipStream_t s = ctx().stream;
+	if (akm && bkm)
+		hipLaunchKernelGGL((gemm_kernel<T, BM, BN, BK, WM, WN, true, true, EXTRA>), grid, block, 0, s, g);
+	else if (akm && !bkm)
+		hipLaunchKernelGGL((gemm_kernel<T, BM, BN, BK, WM, WN, true, false, EXTRA>), grid, block, 0, s, g);
+	else if (!akm && bkm)
+		hipLaunchKernelGGL((gemm_kernel<T, BM, BN, BK, WM, WN, false, true, EXTRA>), grid, block, 0, s, g);
+	else
+		hipLaunchKernelGGL((gemm_kernel<T, BM, BN, BK, WM, WN, false, false, EXTRA>), grid, block, 0, s, g);
+	FH_HIP(hipGetLastError());
+}
+
+template <typename T>
+void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> B, T alpha, const GemmExtra<T> *extra)
+{
+	FH_CHECK(A.nrows == C.nrows && B.ncols == C.ncols && A.ncols == B.nrows, "gemm: shape mismatch");
+	idx_t m = C.nrows, n = C.ncols, k = A.ncols;
+	if (m == 0 || n == 0)
+		return;
+	if (k == 0) { // faer/src/linalg/matmul/mod.rs:1190-1198
+		if (!add)
+			fill_ext<T>(C, kind, (T) 0, extra);
+		return;
+	}
+	FH_CHECK(m < (1L << 31) && n < (1L << 31) && k < (1L << 31), "gemm: dimension too large");
+	GemmExtra<T> ex;
+	if (extra)
+		ex = *extra;
+	const bool indexed = ex.row_idx || ex.col_idx;
+	// Upper(dst) == Lower(dst^T); dst^T = B^T diag A^T.  Also prefer the unit dst stride along m.
+	bool transpose = (kind == DST_UPPER) || (kind == DST_FULL && iabs(C.cs) == 1 && iabs(C.rs) != 1 && !indexed);
+	if (transpose) {
+		MatV<T> Ct = C.t();
+		MatV<const T> At = B.t(), Bt = A.t();
+		C = Ct;
+		A = At;
+		B = Bt;
+		std::swap(ex.row_idx, ex.col_idx);
+		std::swap(m, n);
+		static const int tr[7] = {0, 2, 1, 4, 3, 6, 5}; // FaerBlock of the transposed operand
+		const int as = tr[ex.b_struct], bs = tr[ex.a_struct];
+		ex.a_struct = as;
+		ex.b_struct = bs;
+		if (kind == DST_UPPER)
+			kind = DST_LOWER;
+		// diag sits between lhs and rhs in both orientations; the loader applies it to the rhs rows (k)
+	}
+
+	GemmArgs<T> g;
+	g.M = (int) m;
+	g.N = (int) n;
+	g.K = (int) k;
+	g.dst = C.p;
+	g.drs = C.rs;
+	g.dcs = C.cs;
+	g.a = A.p;
+	g.ars = A.rs;
+	g.acs = A.cs;
+	g.b = B.p;
+	g.brs = B.rs;
+	g.bcs = B.cs;
+	g.alpha = alpha;
+	g.add = add ? 1 : 0;
+	g.lower = kind == DST_LOWER ? 1 : 0;
+	g.atomic = 0;
+	g.row_idx = ex.row_idx;
+	g.col_idx = ex.col_idx;
+	g.idx64 = ex.idx64;
+	g.diag = ex.diag;
+	g.diag_stride = ex.diag_stride;
+	g.a_struct = ex.a_struct;
+	g.b_struct = ex.b_struct;
+	g.dst_strict = ex.dst_strict ? 1 : 0;
+	const bool extra_path = ex.diag || ex.a_struct || ex.b_struct;
+
+	// loader shapes: K-major when the k stride is the unit one (and the mn stride is not)
+	const bool akm = iabs(A.cs) == 1 && iabs(A.rs) != 1;
+	const bool bkm = iabs(B.rs) == 1 && iabs(B.cs) != 1;
+
+	// tile config: big tiles once the grid fills the chip (256 CUs x 2 workgroups), else 64x64
+	int variant = ctx().gemm_variant;
+	const idx_t tiles128 = ((m + 127) / 128) * ((n + 127) / 128) / (kind == DST_LOWER ? 2 : 1);
+	bool big = variant == 1 || (variant == 0 && tiles128 >= 384);
+	if (variant == 2)
+		big = false;
+	if (extra_path)
+		big = false;
+	const int bm = big ? 128 : 64;
+	g.ntm = (int) ((m + bm - 1) / bm);
+	g.ntn = (int) ((n + bm - 1) / bm);
+	g.tri_enum = (g.lower && m == n) ? 1 : 0;
+
+	// split-K for few-tile / deep-K products
+	idx_t tiles = g.tri_enum ? (idx_t) g.ntm * (g.ntm + 1) / 2 : (idx_t) g.ntm * g.ntn;
+	int splits = 1;
+	if (tiles < 256 && k >= 4096 && !indexed) {
+		splits = (int) ((512 + tiles - 1) / tiles);
+		idx_t max_splits = k / 1024;
+		if (splits > max_splits)
+			splits = (int) max_splits;
+		if (splits > 1024)
+			splits = 1024;
+		if (splits < 1)
+			splits = 1;
+	}
+	idx_t kps = (k + splits - 1) / splits;
+	kps = (kps + 15) / 16 * 16;
+	splits = (int) ((k + kps - 1) / kps);
+	g.k_per_split = (int) kps;
+	if (splits > 1) {
+		if (!add)
+			fill_ext<T>(C, kind, (T) 0, &ex);
+		g.atomic = 1;
+	}
+
+	if (extra_path)
+		launch_cfg<T, 64, 64, 2, 2, true>(g, akm, bkm, splits); // triangular operands / diag scaling
+	else if (big)
+		launch_cfg<T, 128, 128, 2, 2, false>(g, akm, bkm, splits);
+	else
+		launch_cfg<T, 64, 64, 2, 2, false>(g, akm, bkm, splits);
+}
+
+// faer/src/linalg/matmul/triangular.rs:1246-1495: only the structured part of each operand is accessed
+// (strict => diagonal is 0, unit => diagonal is 1) and only the structured part of dst is written.
+template <typename T>
+void matmul_triangular_dev(MatV<T> C, int c_s, bool add, MatV<const T> A, int a_s, MatV<const T> B, int b_s, T alpha)
+{
+	GemmExtra<T> ex;
+	ex.a_struct = a_s;
+	ex.b_struct = b_s;
+	DstKind kind = DST_FULL;
+	if (c_s == 1 || c_s == 3 || c_s == 5)
+		kind = DST_LOWER;
+	else if (c_s == 2 || c_s == 4 || c_s == 6)
+		kind = DST_UPPER;
+	ex.dst_strict = c_s >= 3;
+	gemm_dev<T>(C, kind, add, A, B, alpha, &ex);
+}
+
+template <typename T> double gemm_time_ms(MatV<T> C, MatV<const T> A, MatV<const T> B, int iters)
+{
+	hipEvent_t e0, e1;
+	FH_HIP(hipEventCreate(&e0));
+	FH_HIP(hipEventCreate(&e1));
+	gemm_dev<T>(C, DST_FULL, false, A, B, (T) 1); // warm
+	FH_HIP(hipEventRecord(e0, ctx().stream));
+	for (int i = 0; i < iters; ++i)
+		gemm_dev<T>(C, DST_FULL, false, A, B, (T) 1);
+	FH_HIP(hipEventRecord(e1, ctx().stream));
+	FH_HIP(hipEventSynchronize(e1));
+	float ms = 0;
+	FH_HIP(hipEventElapsedTime(&ms, e0, e1));
+	FH_HIP(hipEventDestroy(e0));
+	FH_HIP(hipEventDestroy(e1));
+	return (double) ms / iters;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA issue-rate probe (register-only): the measured ceiling next to the datasheet peak.
+// ------------------------------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(256) void mfma_peak_kernel(T *out, int iters)
+{
+	typedef typename Mfma<T>::acc_t acc_t;
+	acc_t c0 = (acc_t) (T) 0, c1 = c0, c2 = c0, c3 = c0;
+	T a = (T) (threadIdx.x & 7) * (T) 0.125, b = (T) 1.0 - (T) (threadIdx.x & 3) * (T) 0.25;
+	for (int i = 0; i < iters; ++i) {
+		c0 = Mfma<T>::run(a, b, c0);
+		c1 = Mfma<T>::run(a, b, c1);
+		c2 = Mfma<T>::run(a, b, c2);
+		c3 = Mfma<T>::run(a, b, c3);
+	}
+	acc_t s = c0 + c1 + c2 + c3;
+	if (s[0] + s[1] + s[2] + s[3] == (T) 123456789)
+		out[0] = s[0];
+}
+
+double mfma_peak_tflops(bool f64, int iters)
+{
+	ctx().ensure_device();
+	hipEvent_t e0, e1;
+	FH_HIP(hipEventCreate(&e0));
+	FH_HIP(hipEventCreate(&e1));
+	Scratch out(64);
+	const int blocks = 256 * 8; // 8 workgroups of 4 waves per CU
+	hipStream_t s = ctx().stream;
+	for (int rep = 0; rep < 2; ++rep) {
+		if (rep == 1)
+			FH_HIP(hipEventRecord(e0, s));
+		if (f64)
+			hipLaunchKernelGGL(mfma_peak_kernel<double>, dim3(blocks), dim3(256), 0, s, out.as<double>(), iters);
+		else
+			hipLaunchKernelGGL(mfma_peak_kernel<float>, dim3(blocks), dim3(256), 0, s, out.as<float>(), iters);
+	}
+	FH_HIP(hipEventRecord(e1, s));
+	FH_HIP(hipEventSynchronize(e1));
+	float ms = 0;
+	FH_HIP(hipEventElapsedTime(&ms, e0, e1));
+	FH_HIP(hipEventDestroy(e0));
+	FH_HIP(hipEventDestroy(e1));
+	const double flops = (double) blocks * 4 /*waves*/ * (double) iters * 4 /*mfma*/ * 2.0 * 16 * 16 * 4;
+	return flops / (ms * 1e-3) / 1e12;
+}
+
+template void gemm_dev<double>(MatV<double>, DstKind, bool, MatV<const double>, MatV<const double>, double,
+			       const GemmExtra<double> *);
+template void gemm_dev<float>(MatV<float>, DstKind, bool, MatV<const float>, MatV<const float>, float,
+			      const GemmExtra<float> *);
+template void matmul_triangular_dev<double>(MatV<double>, int, bool, MatV<const double>, int, MatV<const double>, int,
+					    double);
+template void matmul_triangular_dev<float>(MatV<float>, int, bool, MatV<const float>, int, MatV<const float>, int, float);
+template double gemm_time_ms<double>(MatV<double>, MatV<const double>, MatV<const double>, int);
+template double gemm_time_ms<float>(MatV<float>, MatV<const float>, MatV<const float>, int);
+template void fill_dev<double>(MatV<double>, DstKind, double);
+template void fill_dev<float>(MatV<float>, DstKind, float);
+
+} // namespace fh

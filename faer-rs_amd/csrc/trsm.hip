@@ -1,0 +1,138 @@
+// In-place triangular solve  X <- op(T)^-1 X  (left side) for gfx950.
+//
+// Replaces faer/src/linalg/triangular_solve.rs:16-604.  Same shape of
+// algorithm as the reference -- recurse on the triangle, off-diagonal block by GEMM
+// (triangular_solve.rs:420-604) -- but the leaf is GPU sized: instead of the reference's n <= 4 closed
+// forms, one wavefront solves a 64 x 64 triangle against 64 right-hand sides:
+//   * the triangle and its reciprocal diagonal sit in LDS and are read as wave-uniform broadcasts;
+//   * every lane owns ONE right-hand side, held in 64 registers, and runs the column-oriented (axpy)
+//     substitution: 2016 independent FMAs, no cross-lane traffic at all;
+//   * X is staged through a padded LDS tile so that global accesses run along whichever of its two
+//     strides is the small one (rows of a transposed Cholesky panel or columns of an LU block row);
+//   * like the reference's base case (triangular_solve.rs:98-198) the diagonal enters as a reciprocal
+//     computed once: x_j <- x_j * (1 / t_jj).
+// Upper triangles are lower triangles on the row/column reversed views (triangular_solve.rs:578-604);
+// every kernel here takes signed strides so the reversal is free.
+#include "common.h"
+
+namespace fh {
+
+template <typename T>
+__global__ __launch_bounds__(64) void trsm_leaf_kernel(const T *__restrict__ Lp, idx_t lrs, idx_t lcs, int n, int unit,
+							T *Xp, idx_t xrs, idx_t xcs, int nrhs, int lanes_along_rhs)
+{
+	constexpr int NB = 64, XP = NB + 1;
+	__shared__ T Ls[NB * NB]; // column major: Ls[j * NB + i] = L[i][j]
+	__shared__ T dinv[NB];
+	__shared__ T Xs[NB * XP]; // Xs[i * XP + c]
+	const int lane = threadIdx.x;
+	const int c0 = blockIdx.x * NB;
+	const int nc = min(NB, nrhs - c0);
+
+	// ---- stage the triangle (identity padded) ----
+	for (int e = lane; e < NB * NB; e += 64) {
+		const int i = e % NB, j = e / NB;
+		T v = (T) 0;
+		if (i < n && j < i)
+			v = Lp[(idx_t) i * lrs + (idx_t) j * lcs];
+		Ls[j * NB + i] = v;
+	}
+	{
+		T d = (T) 1;
+		if (lane < n && !unit)
+			d = (T) 1 / Lp[(idx_t) lane * lrs + (idx_t) lane * lcs];
+		dinv[lane] = d;
+	}
+	// ---- stage X: lanes run along the dimension with the smaller stride ----
+	if (lanes_along_rhs) {
+		for (int i = 0; i < n; ++i)
+			Xs[i * XP + lane] = lane < nc ? Xp[(idx_t) i * xrs + (idx_t) (c0 + lane) * xcs] : (T) 0;
+	} else {
+		for (int c = 0; c < nc; ++c)
+			if (lane < n)
+				Xs[lane * XP + c] = Xp[(idx_t) lane * xrs + (idx_t) (c0 + c) * xcs];
+	}
+	__syncthreads();
+
+	T x[NB];
+#pragma unroll
+	for (int i = 0; i < NB; ++i)
+		x[i] = (i < n && lane < nc) ? Xs[i * XP + lane] : (T) 0;
+
+#pragma unroll
+	for (int j = 0; j < NB; ++j) {
+		if (j < n) { // wave-uniform
+			const T xj = x[j] * dinv[j];
+			x[j] = xj;
+#pragma unroll
+			for (int i = j + 1; i < NB; ++i)
+				x[i] = __builtin_fma(-Ls[j * NB + i], xj, x[i]);
+		}
+	}
+
+#pragma unroll
+	for (int i = 0; i < NB; ++i)
+		if (i < n)
+			Xs[i * XP + lane] = x[i];
+	__syncthreads();
+	if (lanes_along_rhs) {
+		for (int i = 0; i < n; ++i)
+			if (lane < nc)
+				Xp[(idx_t) i * xrs + (idx_t) (c0 + lane) * xcs] = Xs[i * XP + lane];
+	} else {
+		for (int c = 0; c < nc; ++c)
+			if (lane < n)
+				Xp[(idx_t) lane * xrs + (idx_t) (c0 + c) * xcs] = Xs[lane * XP + c];
+	}
+}
+
+// triangular_solve.rs:200-215
+static idx_t trsm_block_size(idx_t n)
+{
+	const idx_t base_rem = n / 2;
+	idx_t r;
+	if (n >= 32)
+		r = (base_rem + 15) / 16 * 16;
+	else if (n >= 16)
+		r = (base_rem + 7) / 8 * 8;
+	else if (n >= 8)
+		r = (base_rem + 3) / 4 * 4;
+	else
+		r = base_rem;
+	return n - r;
+}
+
+template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X)
+{
+	FH_CHECK(L.nrows == L.ncols && X.nrows == L.nrows, "trsm: shape mismatch");
+	const idx_t n = L.nrows, k = X.ncols;
+	if (n == 0 || k == 0)
+		return;
+	if (n <= 64) {
+		auto ab = [](idx_t v) { return v < 0 ? -v : v; };
+		const int along_rhs = ab(X.cs) <= ab(X.rs) ? 1 : 0;
+		FH_CHECK(k < (1L << 31), "trsm: too many right-hand sides");
+		hipLaunchKernelGGL(trsm_leaf_kernel<T>, dim3((unsigned) ((k + 63) / 64)), dim3(64), 0, ctx().stream, L.p, L.rs,
+				   L.cs, (int) n, unit ? 1 : 0, X.p, X.rs, X.cs, (int) k, along_rhs);
+		FH_HIP(hipGetLastError());
+		return;
+	}
+	// triangular_solve.rs:452-484: solve the top block, eliminate it from the bottom rows by GEMM, recurse
+	const idx_t bs = trsm_block_size(n);
+	MatV<T> top = X.sub(0, 0, bs, k), bot = X.sub(bs, 0, n - bs, k);
+	trsm_lower_dev<T>(L.sub(0, 0, bs, bs), unit, top);
+	gemm_dev<T>(bot, DST_FULL, true, L.sub(bs, 0, n - bs, bs), top.c(), (T) -1);
+	trsm_lower_dev<T>(L.sub(bs, bs, n - bs, n - bs), unit, bot);
+}
+
+template <typename T> void trsm_upper_dev(MatV<const T> U, bool unit, MatV<T> X)
+{
+	trsm_lower_dev<T>(U.rev_rows().rev_cols(), unit, X.rev_rows());
+}
+
+template void trsm_lower_dev<double>(MatV<const double>, bool, MatV<double>);
+template void trsm_lower_dev<float>(MatV<const float>, bool, MatV<float>);
+template void trsm_upper_dev<double>(MatV<const double>, bool, MatV<double>);
+template void trsm_upper_dev<float>(MatV<const float>, bool, MatV<float>);
+
+} // namespace fh

@@ -1,0 +1,39 @@
+// Strided copy kernels (device <-> device views).
+#include "common.h"
+
+namespace fh {
+
+template <typename T>
+__global__ void copy_kernel(T *d, idx_t drs, idx_t dcs, const T *s, idx_t srs, idx_t scs, idx_t M, idx_t N)
+{
+	const idx_t total = M * N;
+	for (idx_t e = (idx_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (idx_t) gridDim.x * blockDim.x) {
+		const idx_t i = e % M, j = e / M;
+		d[i * drs + j * dcs] = s[i * srs + j * scs];
+	}
+}
+
+template <typename T> void copy_dev(MatV<T> dst, MatV<const T> src)
+{
+	FH_CHECK(dst.nrows == src.nrows && dst.ncols == src.ncols, "copy: shape mismatch");
+	if (dst.nrows == 0 || dst.ncols == 0)
+		return;
+	auto ab = [](idx_t x) { return x < 0 ? -x : x; };
+	if (ab(dst.cs) < ab(dst.rs)) { // fast index along the smaller dst stride
+		dst = dst.t();
+		src = src.t();
+	}
+	const idx_t total = dst.nrows * dst.ncols;
+	idx_t blocks = (total + 255) / 256;
+	if (blocks > 65536)
+		blocks = 65536;
+	hipLaunchKernelGGL(copy_kernel<T>, dim3((unsigned) blocks), dim3(256), 0, ctx().stream, dst.p, dst.rs, dst.cs, src.p,
+			   src.rs, src.cs, dst.nrows, dst.ncols);
+	FH_HIP(hipGetLastError());
+}
+
+template void copy_dev<double>(MatV<double>, MatV<const double>);
+template void copy_dev<float>(MatV<float>, MatV<const float>);
+template void copy_dev<long>(MatV<long>, MatV<const long>);
+
+} // namespace fh

@@ -1,0 +1,249 @@
+/*
+ * faer_hip.h -- C ABI of libfaer_hip.so, the MI355X (gfx950) dense backend for faer.
+ *
+ * Two boundaries are exported:
+ *
+ *  1. INNER boundary: faer_hip_gemm() has the argument list of
+ *     private_gemm_x86::gemm, the third-party kernel faer calls at
+ *       faer/src/linalg/matmul/mod.rs:1373-1411            (DstKind::Full)
+ *       faer/src/linalg/matmul/triangular.rs:641-680       (DstKind::Lower)
+ *       faer/src/linalg/matmul/internal/mod.rs:143-201     (row/col idx + diag)
+ *     minus the x86 `InstrSet` argument.  A 3-site #[cfg(feature = "hip")]
+ *     patch in faer routes every O(n^3) flop of every decomposition here
+ *     (INTEGRATION.md).
+ *
+ *  2. OUTER boundary: the f32/f64 subset of faer-ffi's C ABI
+ *     (faer-ffi/src/lib.rs, generated header faer-ffi/faer.h) with identical
+ *     repr(C) struct layouts and identical symbol names
+ *     (libfaer_v0_23_<fn>_<dtype>, index-typed ones libfaer_v0_23_<fn>_<u32|u64>_<dtype>),
+ *     so a C/C++ client of faer-ffi links against libfaer_hip.so unchanged and
+ *     gets whole factorizations executed on the GPU.
+ *
+ * Pointers: every matrix / slice pointer may be HOST memory (a faer::Mat) or
+ * DEVICE memory (hipMalloc / a torch tensor).  The library asks the HIP runtime
+ * (hipPointerGetAttributes) and stages host operands through device buffers;
+ * device operands are used in place with no copy.  Strides are in ELEMENTS and
+ * may be negative or non-unit (faer/src/mat/mod.rs:7-13).
+ *
+ * Errors: like faer (which panics across extern "C" on precondition
+ * violations, faer-ffi/src/lib.rs) a violated precondition or a HIP runtime
+ * failure prints a message to stderr and abort()s; numerical failure is
+ * reported by value through the *Status unions.  There is NO CPU fallback: if
+ * no gfx950 device is usable every compute entry point aborts.
+ */
+#ifndef FAER_HIP_H
+#define FAER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FAER_HIP_API __attribute__((visibility("default")))
+
+/* ---- repr(C) structs: field-for-field faer-ffi/src/lib.rs:12-113 (faer.h:203-258) ---- */
+typedef struct FaerMatRef { const void *ptr; size_t nrows; size_t ncols; ptrdiff_t row_stride; ptrdiff_t col_stride; } FaerMatRef;
+typedef struct FaerMatMut { void *ptr; size_t nrows; size_t ncols; ptrdiff_t row_stride; ptrdiff_t col_stride; } FaerMatMut;
+typedef struct FaerVecRef { const void *ptr; size_t len; ptrdiff_t stride; } FaerVecRef;
+typedef struct FaerVecMut { void *ptr; size_t len; ptrdiff_t stride; } FaerVecMut;
+/* len is an ELEMENT count (faer-ffi/src/lib.rs:251-258) */
+typedef struct FaerSliceRef { const void *ptr; size_t len; } FaerSliceRef;
+typedef struct FaerSliceMut { void *ptr; size_t len; } FaerSliceMut;
+
+typedef enum FaerAccum { FaerAccum_Replace = 0, FaerAccum_Add = 1 } FaerAccum;          /* lib.rs:59-64 */
+typedef enum FaerConj { FaerConj_No = 0, FaerConj_Yes = 1 } FaerConj;                   /* lib.rs:65-70 */
+typedef enum FaerParTag { FaerParTag_Seq = 0, FaerParTag_Rayon = 1 } FaerParTag;        /* lib.rs:71-76 */
+typedef struct FaerPar { FaerParTag tag; size_t nthreads; } FaerPar;                    /* lib.rs:77-82 */
+typedef enum FaerBlock {                                                                 /* lib.rs:83-93 */
+	FaerBlock_Rectangular = 0,
+	FaerBlock_TriangularLower = 1,
+	FaerBlock_TriangularUpper = 2,
+	FaerBlock_StrictTriangularLower = 3,
+	FaerBlock_StrictTriangularUpper = 4,
+	FaerBlock_UnitTriangularLower = 5,
+	FaerBlock_UnitTriangularUpper = 6
+} FaerBlock;
+typedef struct FaerLayout { size_t len_bytes; size_t align_bytes; } FaerLayout;          /* lib.rs:94-99 */
+typedef struct FaerMemAlloc { void *ptr; size_t len_bytes; } FaerMemAlloc;               /* lib.rs:108-113 */
+
+/* status unions: faer-ffi/src/lib.rs:552-595 + cerr! (:372-407), faer.h:383-469 */
+typedef enum FaerLltStatus_Tag { FaerLltStatus_Ok = 0, FaerLltStatus_NonPositivePivot = 1, FaerLltStatus_Unknown = 2 } FaerLltStatus_Tag;
+typedef struct FaerLltStatus {
+	FaerLltStatus_Tag tag;
+	union {
+		struct { size_t dynamic_regularization_count; } ok;
+		struct { size_t index; } non_positive_pivot;
+	};
+} FaerLltStatus;
+typedef enum FaerPartialPivLuStatus_Tag { FaerPartialPivLuStatus_Ok = 0, FaerPartialPivLuStatus_Unknown = 1 } FaerPartialPivLuStatus_Tag;
+typedef struct FaerPartialPivLuStatus {
+	FaerPartialPivLuStatus_Tag tag;
+	union { struct { size_t transposition_count; } ok; };
+} FaerPartialPivLuStatus;
+typedef enum FaerQrStatus_Tag { FaerQrStatus_Ok = 0, FaerQrStatus_Unknown = 1 } FaerQrStatus_Tag;
+typedef struct FaerQrStatus {
+	FaerQrStatus_Tag tag;
+	union { struct { size_t rank; } ok; };
+} FaerQrStatus;
+
+/* params: faer-ffi/src/lib.rs:650-690 (cparams!) */
+typedef struct FaerLltParams { size_t recursion_threshold; size_t block_size; } FaerLltParams;
+typedef struct FaerPartialPivLuParams { size_t recursion_threshold; size_t block_size; size_t par_threshold; } FaerPartialPivLuParams;
+typedef struct FaerQrParams { size_t blocking_threshold; size_t par_threshold; } FaerQrParams;
+/* faer-ffi/src/lib.rs:796-801; pointers to a real scalar of the matrix dtype (HOST memory), NULL == 0 */
+typedef struct FaerLltRegularization { const void *dynamic_regularization_delta; const void *dynamic_regularization_epsilon; } FaerLltRegularization;
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. INNER boundary -- replaces private_gemm_x86::gemm (call sites above).
+ * --------------------------------------------------------------------------------------------- */
+typedef enum FaerHipDType { FaerHipDType_F32 = 0, FaerHipDType_F64 = 1, FaerHipDType_C32 = 2, FaerHipDType_C64 = 3 } FaerHipDType;
+typedef enum FaerHipIType { FaerHipIType_U32 = 0, FaerHipIType_U64 = 1 } FaerHipIType;
+typedef enum FaerHipDstKind { FaerHipDstKind_Full = 0, FaerHipDstKind_Lower = 1, FaerHipDstKind_Upper = 2 } FaerHipDstKind;
+
+/* dst[row_idx[i], col_idx[j]] (or dst[i,j] when the index arrays are NULL), restricted to the
+ * Full / Lower (i>=j) / Upper (i<=j) part, <- [dst +] alpha * lhs * diag(diag) * rhs.
+ * Accum_Replace never reads dst.  F32/F64 only (C32/C64 abort: out of the north-star scope).
+ * n_threads is accepted for signature compatibility and ignored.  Thread safe. */
+FAER_HIP_API void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m, size_t n, size_t k,
+                                void *dst, ptrdiff_t dst_rs, ptrdiff_t dst_cs,
+                                const void *row_idx, const void *col_idx,
+                                FaerHipDstKind dst_kind, FaerAccum accum,
+                                const void *lhs, ptrdiff_t lhs_rs, ptrdiff_t lhs_cs, bool conj_lhs,
+                                const void *diag, ptrdiff_t diag_stride,
+                                const void *rhs, ptrdiff_t rhs_rs, ptrdiff_t rhs_cs, bool conj_rhs,
+                                const void *alpha, size_t n_threads);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. OUTER boundary -- faer-ffi symbol-compatible entry points (f32 / f64).
+ *    Each comment cites the Rust function in faer-ffi/src/lib.rs it replaces.
+ * --------------------------------------------------------------------------------------------- */
+/* lib.rs:855-871  la::matmul::matmul */
+FAER_HIP_API void libfaer_v0_23_matmul_f64(FaerMatMut C, FaerAccum accum, FaerMatRef A, FaerMatRef B, const void *alpha, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_matmul_f32(FaerMatMut C, FaerAccum accum, FaerMatRef A, FaerMatRef B, const void *alpha, FaerPar par);
+/* lib.rs:872-895  la::matmul::triangular::matmul */
+FAER_HIP_API void libfaer_v0_23_matmul_triangular_f64(FaerMatMut C, FaerBlock C_block, FaerAccum accum, FaerMatRef A, FaerBlock A_block, FaerMatRef B, FaerBlock B_block, const void *alpha, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_matmul_triangular_f32(FaerMatMut C, FaerBlock C_block, FaerAccum accum, FaerMatRef A, FaerBlock A_block, FaerMatRef B, FaerBlock B_block, const void *alpha, FaerPar par);
+/* lib.rs:896-937  la::triangular_solve::solve_{,unit_}{lower,upper}_triangular_in_place_with_conj */
+FAER_HIP_API void libfaer_v0_23_solve_triangular_lower_in_place_f64(FaerMatRef L, FaerConj L_conj, FaerMatMut rhs, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_solve_triangular_lower_in_place_f32(FaerMatRef L, FaerConj L_conj, FaerMatMut rhs, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_solve_triangular_upper_in_place_f64(FaerMatRef U, FaerConj U_conj, FaerMatMut rhs, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_solve_triangular_upper_in_place_f32(FaerMatRef U, FaerConj U_conj, FaerMatMut rhs, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_solve_unit_triangular_lower_in_place_f64(FaerMatRef L, FaerConj L_conj, FaerMatMut rhs, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_solve_unit_triangular_lower_in_place_f32(FaerMatRef L, FaerConj L_conj, FaerMatMut rhs, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_solve_unit_triangular_upper_in_place_f64(FaerMatRef U, FaerConj U_conj, FaerMatMut rhs, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_solve_unit_triangular_upper_in_place_f32(FaerMatRef U, FaerConj U_conj, FaerMatMut rhs, FaerPar par);
+
+/* lib.rs:650-655 (cparams! getter)  Auto<T> for LltParams: {64, 128} (cholesky/ldlt/factor.rs:705-714) */
+FAER_HIP_API FaerLltParams libfaer_v0_23_LltParams_f64(void);
+FAER_HIP_API FaerLltParams libfaer_v0_23_LltParams_f32(void);
+/* lib.rs:984-995  cholesky_in_place_scratch (cholesky/llt/factor.rs:58-66): dim scalars */
+FAER_HIP_API FaerLayout libfaer_v0_23_llt_factor_in_place_scratch_f64(size_t dim, FaerPar par, FaerLltParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_llt_factor_in_place_scratch_f32(size_t dim, FaerPar par, FaerLltParams params);
+/* lib.rs:996-1011  cholesky_in_place (cholesky/llt/factor.rs:67-97) */
+FAER_HIP_API FaerLltStatus libfaer_v0_23_llt_factor_in_place_f64(FaerMatMut A, FaerLltRegularization regularization, FaerPar par, FaerMemAlloc mem, FaerLltParams params);
+FAER_HIP_API FaerLltStatus libfaer_v0_23_llt_factor_in_place_f32(FaerMatMut A, FaerLltRegularization regularization, FaerPar par, FaerMemAlloc mem, FaerLltParams params);
+/* lib.rs:1012-1040  llt::solve::solve_in_place_with_conj (cholesky/llt/solve.rs:12-35) */
+FAER_HIP_API FaerLayout libfaer_v0_23_llt_solve_in_place_scratch_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API FaerLayout libfaer_v0_23_llt_solve_in_place_scratch_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_llt_solve_in_place_f64(FaerMatRef L, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API void libfaer_v0_23_llt_solve_in_place_f32(FaerMatRef L, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+
+/* lib.rs:679-685  Auto<T> for PartialPivLuParams: {16, 64, 128*128} (lu/partial_pivoting/factor.rs:212-222) */
+FAER_HIP_API FaerPartialPivLuParams libfaer_v0_23_PartialPivLuParams_f64(void);
+FAER_HIP_API FaerPartialPivLuParams libfaer_v0_23_PartialPivLuParams_f32(void);
+/* lib.rs:1952-1965  lu_in_place_scratch (lu/partial_pivoting/factor.rs:224-233): min(dim, block_size) indices.
+ * NB the ffi passes (dim, block_size) as (nrows, ncols). */
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_factor_in_place_scratch_u32_f64(size_t dim, size_t block_size, FaerPar par, FaerPartialPivLuParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_factor_in_place_scratch_u64_f64(size_t dim, size_t block_size, FaerPar par, FaerPartialPivLuParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_factor_in_place_scratch_u32_f32(size_t dim, size_t block_size, FaerPar par, FaerPartialPivLuParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_factor_in_place_scratch_u64_f32(size_t dim, size_t block_size, FaerPar par, FaerPartialPivLuParams params);
+/* lib.rs:1966-1984  lu_in_place (lu/partial_pivoting/factor.rs:234-295); perm_fwd[i] = source row of row i of P*A */
+FAER_HIP_API FaerPartialPivLuStatus libfaer_v0_23_partial_piv_lu_factor_in_place_u32_f64(FaerMatMut A, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerPar par, FaerMemAlloc mem, FaerPartialPivLuParams params);
+FAER_HIP_API FaerPartialPivLuStatus libfaer_v0_23_partial_piv_lu_factor_in_place_u64_f64(FaerMatMut A, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerPar par, FaerMemAlloc mem, FaerPartialPivLuParams params);
+FAER_HIP_API FaerPartialPivLuStatus libfaer_v0_23_partial_piv_lu_factor_in_place_u32_f32(FaerMatMut A, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerPar par, FaerMemAlloc mem, FaerPartialPivLuParams params);
+FAER_HIP_API FaerPartialPivLuStatus libfaer_v0_23_partial_piv_lu_factor_in_place_u64_f32(FaerMatMut A, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerPar par, FaerMemAlloc mem, FaerPartialPivLuParams params);
+
+/* lib.rs:667-671  Auto<T> for QrParams: {48*48, 192*256} (qr/no_pivoting/factor.rs:127-136) */
+FAER_HIP_API FaerQrParams libfaer_v0_23_QrParams_f64(void);
+FAER_HIP_API FaerQrParams libfaer_v0_23_QrParams_f32(void);
+/* lib.rs:1520-1527  recommended_block_size (qr/no_pivoting/factor.rs:91-116) */
+FAER_HIP_API size_t libfaer_v0_23_qr_recommended_block_size_f64(size_t nrows, size_t ncols);
+FAER_HIP_API size_t libfaer_v0_23_qr_recommended_block_size_f32(size_t nrows, size_t ncols);
+/* lib.rs:1528-1543  qr_in_place_scratch (qr/no_pivoting/factor.rs:305-316): block_size x ncols scalars */
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_factor_in_place_scratch_f64(size_t nrows, size_t ncols, size_t block_size, FaerPar par, FaerQrParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_factor_in_place_scratch_f32(size_t nrows, size_t ncols, size_t block_size, FaerPar par, FaerQrParams params);
+/* lib.rs:1544-1559  qr_in_place (qr/no_pivoting/factor.rs:258-301); Q_coeff is block_size x min(m,n) */
+FAER_HIP_API FaerQrStatus libfaer_v0_23_qr_factor_in_place_f64(FaerMatMut A, FaerMatMut Q_coeff, FaerPar par, FaerMemAlloc mem, FaerQrParams params);
+FAER_HIP_API FaerQrStatus libfaer_v0_23_qr_factor_in_place_f32(FaerMatMut A, FaerMatMut Q_coeff, FaerPar par, FaerMemAlloc mem, FaerQrParams params);
+/* lib.rs:1423-1470  apply_block_householder_sequence_{,transpose_}on_the_left_in_place_with_conj (householder.rs:724-808) */
+FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_on_the_left_scratch_f64(size_t dim, size_t block_size, size_t rhs_ncols);
+FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_on_the_left_scratch_f32(size_t dim, size_t block_size, size_t rhs_ncols);
+FAER_HIP_API void libfaer_v0_23_apply_householder_on_the_left_f64(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj householder_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API void libfaer_v0_23_apply_householder_on_the_left_f32(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj householder_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_transpose_on_the_left_scratch_f64(size_t dim, size_t block_size, size_t rhs_ncols);
+FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_transpose_on_the_left_scratch_f32(size_t dim, size_t block_size, size_t rhs_ncols);
+FAER_HIP_API void libfaer_v0_23_apply_householder_transpose_on_the_left_f64(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj householder_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API void libfaer_v0_23_apply_householder_transpose_on_the_left_f32(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj householder_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+
+/* lib.rs:2523-2543  get/set_global_parallelism (faer/src/lib.rs:1107-1150).  Stored and returned only:
+ * the GPU backend has no host thread pool. */
+FAER_HIP_API FaerPar libfaer_v0_23_get_global_par(void);
+FAER_HIP_API void libfaer_v0_23_set_global_par(FaerPar par);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3. Runtime control (new: the reference has no device).
+ * --------------------------------------------------------------------------------------------- */
+/* Library version / build target string, e.g. "faer_hip 0.1 gfx950". Never NULL. */
+FAER_HIP_API const char *faer_hip_version(void);
+/* Number of usable gfx950 devices (0 when none: compute entry points will abort). */
+FAER_HIP_API int faer_hip_device_count(void);
+/* Binds the calling thread to `device` (hipSetDevice). */
+FAER_HIP_API void faer_hip_set_device(int device);
+/* All work of the calling thread is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream).
+ * Lets a host framework (e.g. torch's current stream) order our kernels with its own. */
+FAER_HIP_API void faer_hip_set_stream(void *hip_stream);
+FAER_HIP_API void *faer_hip_get_stream(void);
+/* Blocks until all work enqueued on the calling thread's stream is done. */
+FAER_HIP_API void faer_hip_synchronize(void);
+/* Device memory helpers for C clients without another allocator. */
+FAER_HIP_API void *faer_hip_malloc(size_t bytes);
+FAER_HIP_API void faer_hip_free(void *ptr);
+FAER_HIP_API void faer_hip_memcpy_h2d(void *dst_device, const void *src_host, size_t bytes);
+FAER_HIP_API void faer_hip_memcpy_d2h(void *dst_host, const void *src_device, size_t bytes);
+/* Tuning knob used by bench.py / tests: selects the GEMM tile variant (0 = auto). */
+FAER_HIP_API void faer_hip_set_gemm_variant(int variant);
+/* Measures `iters` back-to-back launches of the dense GEMM kernel on the calling thread's stream with
+ * hipEvents and returns the average milliseconds per launch (operands must be device memory).
+ * bench.py uses it for the `roofline` object. */
+FAER_HIP_API double faer_hip_time_gemm_ms(FaerHipDType dtype, size_t m, size_t n, size_t k, void *dst, ptrdiff_t dst_cs,
+                                          const void *lhs, ptrdiff_t lhs_cs, const void *rhs, ptrdiff_t rhs_cs, int iters);
+/* Raw fp64/fp32 MFMA issue-rate probe: every wave of a full-chip grid runs `iters` dependent-free
+ * v_mfma 16x16x4 instructions from registers; returns achieved TFLOP/s.  The measured ceiling that
+ * roofline fractions are quoted against next to the datasheet peak. */
+FAER_HIP_API double faer_hip_mfma_peak_tflops(FaerHipDType dtype, int iters);
+
+/* ---------------------------------------------------------------------------------------------
+ * 4. Multi-GPU: 1-D block-column partition, one process per GPU.
+ *    The caller owns the transport: `bcast` is invoked with device buffers and must broadcast
+ *    `bytes` bytes from rank `root` to every rank on the calling thread's stream
+ *    (torch.distributed.broadcast over RCCL in bench.py; gloo in the CPU tests).
+ * --------------------------------------------------------------------------------------------- */
+typedef void (*FaerHipBcastFn)(void *user, void *device_buf, size_t bytes, int root);
+typedef struct FaerHipComm { int rank; int world_size; FaerHipBcastFn bcast; void *user; } FaerHipComm;
+
+/* Number of block columns of width `nb` owned by `rank` out of n columns distributed block-cyclically. */
+FAER_HIP_API size_t faer_hip_dist_local_ncols(size_t n, size_t nb, int rank, int world_size);
+/* Distributed partial-pivot LU of an m x n matrix whose block columns (width nb) are dealt block-cyclically
+ * over comm.world_size ranks; A_local holds this rank's columns (m x local_ncols, device memory, col-major).
+ * perm_fwd / perm_bwd (m entries, u64, HOST memory) are filled on every rank.  `panel_ws` is device scratch of
+ * at least m*nb scalars.  Same pivoting rule and result as the single-GPU entry point. */
+FAER_HIP_API FaerPartialPivLuStatus faer_hip_dist_partial_piv_lu_f64(FaerMatMut A_local, size_t n_global, size_t nb, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerHipComm comm, void *panel_ws);
+FAER_HIP_API FaerPartialPivLuStatus faer_hip_dist_partial_piv_lu_f32(FaerMatMut A_local, size_t n_global, size_t nb, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerHipComm comm, void *panel_ws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAER_HIP_H */

@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol
+declared in include/faer_hip.h, and its repr(C) structs have the layout of faer-ffi's (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from gpu_util import ROOT, fa
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "faer_hip.h")).read()
+    hdr = "\n".join(l for l in hdr.splitlines() if not l.startswith("#define"))
+    return re.findall(r"FAER_HIP_API\s+[^;(]*?\b(\w+)\s*\(", hdr)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    F = fa()
+    lib = F.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 60
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert b"gfx950" in lib.faer_hip_version()
+
+
+def test_struct_layouts_match_faer_ffi():
+    F = fa()
+    # faer-ffi/faer.h:203-217 MatRef/MatMut: ptr, nrows, ncols, row_stride, col_stride (5 x 8 bytes)
+    assert C.sizeof(F.MatRef) == 40 and C.sizeof(F.MatMut) == 40
+    assert [f[0] for f in F.MatRef._fields_] == ["ptr", "nrows", "ncols", "row_stride", "col_stride"]
+    assert C.sizeof(F.SliceMut) == 16 and C.sizeof(F.Par) == 16 and C.sizeof(F.MemAlloc) == 16
+    assert C.sizeof(F.LltStatus) == 16 and F.LltStatus.value.offset == 8  # tag + union
+    assert C.sizeof(F.PartialPivLuStatus) == 16 and C.sizeof(F.QrStatus) == 16
+
+
+def test_params_and_scratch_queries_need_no_gpu():
+    F = fa()
+    lib = F.lib()
+    p = lib.libfaer_v0_23_LltParams_f64()
+    assert (p.recursion_threshold, p.block_size) == (64, 128)  # cholesky/ldlt/factor.rs:705-714
+    p = lib.libfaer_v0_23_PartialPivLuParams_f64()
+    assert (p.recursion_threshold, p.block_size, p.par_threshold) == (16, 64, 128 * 128)
+    p = lib.libfaer_v0_23_QrParams_f32()
+    assert (p.blocking_threshold, p.par_threshold) == (48 * 48, 192 * 256)
+    lay = lib.libfaer_v0_23_llt_factor_in_place_scratch_f64(C.c_size_t(100), F.PAR_SEQ, F.LltParams(64, 128))
+    assert lay.len_bytes == 800
+    lay = lib.libfaer_v0_23_qr_factor_in_place_scratch_f32(C.c_size_t(1000), C.c_size_t(50), C.c_size_t(8), F.PAR_SEQ,
+                                                         F.QrParams(48 * 48, 192 * 256))
+    assert lay.len_bytes == 8 * 50 * 4
+    # qr/no_pivoting/factor.rs:91-116
+    for (m, n, want) in [(10, 2, 1), (100, 100, 8), (600, 600, 48), (1000000, 256, 256), (3000, 3000, 128), (5, 100, 4), (3, 1000, 3)]:
+        assert lib.libfaer_v0_23_qr_recommended_block_size_f64(C.c_size_t(m), C.c_size_t(n)) == want
+    lib.libfaer_v0_23_set_global_par(F.Par(1, 8))
+    g = lib.libfaer_v0_23_get_global_par()
+    assert (g.tag, g.nthreads) == (1, 8)
+    assert lib.faer_hip_dist_local_ncols(C.c_size_t(1000), C.c_size_t(128), 1, 4) == 256
+    assert lib.faer_hip_dist_local_ncols(C.c_size_t(1000), C.c_size_t(128), 3, 4) == 104
+
+
+def test_product_path_has_no_cpu_fallback():
+    """without a gfx950 device a compute entry point must fail loudly, not compute on the host"""
+    import subprocess
+    import sys
+
+    F = fa()
+    if F.lib().faer_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, __graft_entry__ as g; F = g.load_package();"
+            "a = np.eye(4, order='F'); c = np.zeros((4, 4), order='F'); F.matmul(c, 0, a, a, 1.0); print('computed')"
+            % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "computed" not in r.stdout
+    assert "no HIP device" in r.stderr or "faer_hip: fatal" in r.stderr

@@ -1,0 +1,179 @@
+"""GPU parity: TRSM, LLT, partial-pivot LU through the C-ABI vs the CPU oracle, with the reference's own
+test sizes and tolerances and full-size property tests."""
+import numpy as np
+import pytest
+
+from gpu_util import EPS, init_gpu, rnd, spd, to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------ trsm
+@pytest.mark.parametrize("n,k", [(1, 3), (4, 5), (7, 2), (33, 70), (64, 64), (65, 1), (128, 65), (200, 9), (300, 300)])
+@pytest.mark.parametrize("upper", [False, True])
+@pytest.mark.parametrize("unit", [False, True])
+@pytest.mark.parametrize("order", ["F", "C"])
+def test_trsm(oracle, n, k, upper, unit, order):
+    F = init_gpu()
+    rng = np.random.default_rng(n * 31 + k)
+    t = rnd(rng, n, n) / (n if unit else 1.0) + n * np.eye(n)
+    b = rnd(rng, n, k)
+    dx = to_dev(b, order)
+    fn = {(False, False): F.solve_lower_triangular_in_place, (True, False): F.solve_upper_triangular_in_place,
+          (False, True): F.solve_unit_lower_triangular_in_place, (True, True): F.solve_unit_upper_triangular_in_place}
+    fn[(upper, unit)](to_dev(t, order), dx)
+    got = to_host(dx)
+    ref = b.copy(order="F")
+    oracle.trsm(t, ref, upper=upper, unit=unit)
+    assert np.abs(got - ref).max() <= 64 * n * EPS[np.dtype(np.float64)] * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------- llt
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 31, 64, 65, 127, 128, 129, 240, 300, 1024])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_llt_vs_oracle(oracle, n, dtype):
+    """cholesky/ldlt/factor.rs:776-868 sizes; config R of BASELINE.json is n = 1024"""
+    F = init_gpu()
+    rng = np.random.default_rng(n)
+    a = spd(rng, n, dtype)
+    dl = to_dev(a)
+    assert F.llt_factor_in_place(dl) == 0
+    got = to_host(dl)
+    ref = a.copy(order="F")
+    assert oracle.llt_in_place(ref) == ("ok", 0)
+    e = EPS[np.dtype(dtype)]
+    assert (np.triu(got, 1) == np.triu(a, 1)).all()  # strict upper triangle untouched
+    L = np.tril(got).astype(np.float64)
+    assert np.abs(L @ L.T - a).max() <= 8 * n * e * np.abs(a).max()
+    assert np.abs(np.tril(got) - np.tril(ref)).max() <= 64 * n * e * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n,bad", [(10, 3), (100, 64), (300, 299), (200, 0), (700, 515)])
+def test_llt_non_positive_pivot(oracle, n, bad):
+    F = init_gpu()
+    rng = np.random.default_rng(7)
+    a = spd(rng, n)
+    a[bad, bad] = -1.0 if bad == 0 else (a[bad, :bad] @ np.linalg.solve(a[:bad, :bad], a[:bad, bad])) - 1.0
+    assert oracle.llt_in_place(a.copy(order="F")) == ("non_positive_pivot", bad)
+    with pytest.raises(F.LltError) as ei:
+        F.llt_factor_in_place(to_dev(a))
+    assert ei.value.index == bad
+
+
+def test_llt_regularization(oracle):
+    F = init_gpu()
+    a = np.diag([4.0, 1e-20, 9.0])
+    d = to_dev(a)
+    assert F.llt_factor_in_place(d, regularization=(1.0, 1e-10)) == 1
+    ref = a.copy(order="F")
+    assert oracle.llt_in_place(ref, reg_delta=1.0, reg_eps=1e-10) == ("ok", 1)
+    assert np.allclose(np.diag(to_host(d)), np.diag(ref))
+
+
+def test_llt_solve(oracle):
+    """cholesky/llt/solve.rs:56: A X ~ B, eps*128*8n"""
+    F = init_gpu()
+    rng = np.random.default_rng(8)
+    for n in (50, 200, 400):
+        a, b = spd(rng, n), rnd(rng, n, 7)
+        llt = F.Llt(to_dev(a))
+        x = to_dev(b)
+        llt.solve_in_place(x)
+        assert np.abs(a @ to_host(x) - b).max() <= 2.2e-16 * 128 * 8 * n * np.abs(b).max() * 10
+
+
+def test_llt_host_pointer():
+    F = init_gpu()
+    rng = np.random.default_rng(9)
+    a = spd(rng, 333)
+    l = a.copy(order="F")
+    assert F.llt_factor_in_place(l) == 0
+    L = np.tril(l)
+    assert np.abs(L @ L.T - a).max() < 1e-10 * np.abs(a).max()
+
+
+def test_llt_full_size_property():
+    """BASELINE config C (N = 16384 fp64): ||L L^T x - A x|| via matvecs, no oracle"""
+    import torch
+
+    F = init_gpu()
+    n = 16384
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g)
+    a = (a @ a.t() + n * torch.eye(n, dtype=torch.float64, device="cuda")).t()
+    l = a.clone()
+    assert F.llt_factor_in_place(l) == 0
+    F.synchronize()
+    L = torch.tril(l)
+    x = torch.randn((n, 4), dtype=torch.float64, device="cuda", generator=g)
+    r = L @ (L.t() @ x) - a @ x
+    assert r.abs().max().item() <= 64 * n * 2.3e-16 * (a.abs() @ x.abs()).max().item()
+
+
+# -------------------------------------------------------------------------------------------- lu
+@pytest.mark.parametrize("m,n", [(1, 1), (2, 2), (3, 3), (31, 31), (32, 32), (33, 33), (128, 128), (255, 255), (256, 256),
+                                 (257, 257), (300, 8), (8, 300), (40, 17), (17, 40), (1000, 1000), (2000, 64)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_plu_vs_oracle(oracle, m, n, dtype):
+    """lu/partial_pivoting/factor.rs:304-404 `test_plu` sizes; P^-1 L U ~ A (1e-13 scaled)"""
+    F = init_gpu()
+    rng = np.random.default_rng(m * 7 + n)
+    a = rnd(rng, m, n, dtype)
+    dlu = to_dev(a)
+    perm, perm_inv, nt = F.partial_piv_lu_factor_in_place(dlu)
+    lu = to_host(dlu)
+    perm = perm.astype(np.int64)
+    ref = a.copy(order="F")
+    rperm, rinv, rnt = oracle.lu_in_place(ref)
+    size = min(m, n)
+    e = EPS[np.dtype(dtype)]
+    L = (np.tril(lu[:, :size], -1) + np.eye(m, size)).astype(np.float64)
+    U = np.triu(lu[:size, :]).astype(np.float64)
+    assert (perm_inv.astype(np.int64)[perm] == np.arange(m)).all()
+    assert np.abs(L @ U - a[perm]).max() <= 16 * max(m, n) * e * np.abs(a).max()
+    assert np.abs(np.tril(lu, -1)).max(initial=0) <= 1.0 + 4 * e
+    # same pivot rule as the reference => same permutation (random data has no near ties)
+    assert (perm == rperm).all() and nt == rnt
+    assert np.abs(lu - ref).max() <= 64 * max(m, n) * e * max(1.0, np.abs(ref).max()) * 50
+
+
+def test_plu_ties_and_zero_column(oracle):
+    """first strictly largest |a_ij| wins; an all-zero column keeps the diagonal (factor.rs:35-43)"""
+    F = init_gpu()
+    a = np.array([[1.0, 2, 3, 4], [-1.0, 5, 6, 7], [1.0, 8, 9, 1], [0.5, 1, 1, 1]], order="F")
+    ref = a.copy(order="F")
+    rperm, _, _ = oracle.lu_in_place(ref)
+    d = to_dev(a)
+    perm, _, _ = F.partial_piv_lu_factor_in_place(d)
+    assert (perm.astype(np.int64) == rperm).all()
+    assert np.allclose(to_host(d), ref)
+    z = np.zeros((600, 5), order="F")
+    z[:, 1:] = np.random.default_rng(3).standard_normal((600, 4))
+    ref = z.copy(order="F")
+    rperm, _, _ = oracle.lu_in_place(ref)
+    d = to_dev(z)
+    perm, _, _ = F.partial_piv_lu_factor_in_place(d)
+    got = to_host(d)
+    assert (perm.astype(np.int64) == rperm).all()
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.allclose(got[~np.isnan(got)], ref[~np.isnan(ref)])
+
+
+def test_plu_full_size_property():
+    """BASELINE config L on one GPU (N = 16384 fp64): ||L U x - P A x||, |L| <= 1"""
+    import torch
+
+    F = init_gpu()
+    n = 16384
+    g = torch.Generator(device="cuda").manual_seed(2)
+    a = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g).t()
+    lu = a.clone()
+    perm, _, _ = F.partial_piv_lu_factor_in_place(lu)
+    F.synchronize()
+    p = torch.as_tensor(perm.astype(np.int64), device="cuda")
+    assert sorted(perm.tolist()) == list(range(n))
+    L = torch.tril(lu, -1) + torch.eye(n, dtype=torch.float64, device="cuda")
+    assert torch.tril(lu, -1).abs().max().item() <= 1.0 + 1e-14
+    x = torch.randn((n, 4), dtype=torch.float64, device="cuda", generator=g)
+    r = L @ (torch.triu(lu) @ x) - a[p] @ x
+    scale = (L.abs() @ (torch.triu(lu).abs() @ x.abs())).max().item()
+    assert r.abs().max().item() <= 64 * n * 2.3e-16 * scale

@@ -1,0 +1,162 @@
+"""GPU parity: GEMM / triangular product through the C-ABI vs the CPU oracle (SURVEY.md section 4:
+test_matmul, test_triangular, the matmul doctests).  Tolerance: |d| <= 4 K eps (|A||B|)_ij."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import EPS, fa, init_gpu, rnd, to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SHAPES = [(1, 1, 1), (15, 16, 17), (17, 15, 16), (127, 129, 128), (129, 127, 130), (64, 1, 33), (1, 70, 9), (5, 7, 0),
+          (256, 256, 256), (300, 200, 1000), (40, 3, 5000), (130, 130, 70), (1, 1, 300), (513, 67, 1)]
+
+
+def bound(a, b, c0, k, dtype, alpha):
+    e = EPS[np.dtype(dtype)]
+    return 4 * max(k, 1) * e * (abs(alpha) * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)) +
+                               np.abs(c0)) + 1e-300
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("layout", ["FFF", "CFF", "FCF", "CCF", "FFC", "CCC"])
+@pytest.mark.parametrize("m,n,k", SHAPES)
+def test_matmul_vs_oracle(oracle, dtype, layout, m, n, k):
+    F = init_gpu()
+    rng = np.random.default_rng(m * 1000003 + n * 1009 + k)
+    a, b, c0 = rnd(rng, m, k, dtype), rnd(rng, k, n, dtype), rnd(rng, m, n, dtype)
+    da, db = to_dev(a, layout[0]), to_dev(b, layout[1])
+    for accum, alpha in ((F.ACCUM_ADD, -0.5), (F.ACCUM_REPLACE, 2.0)):
+        dc = to_dev(c0 if accum == F.ACCUM_ADD else np.full((m, n), np.nan, dtype=dtype), layout[2])
+        F.matmul(dc, accum, da, db, alpha)
+        ref = c0.copy(order="F")
+        oracle.matmul(ref, a, b, alpha=alpha, accum_add=accum == F.ACCUM_ADD)
+        got = to_host(dc)
+        tol = bound(a, b, c0 if accum == F.ACCUM_ADD else 0 * c0, k, dtype, alpha)
+        assert np.isfinite(got).all()
+        assert (np.abs(got.astype(np.float64) - ref.astype(np.float64)) <= tol).all(), \
+            f"max err {np.abs(got - ref).max():.3e}"
+
+
+def test_golden_matmul_2x2():
+    F = init_gpu()
+    g = json.load(open(os.path.join(GOLD, "matmul_2x2.json")))
+    acc = to_dev(np.full((2, 2), np.nan))
+    F.matmul(acc, F.ACCUM_REPLACE, to_dev(np.array(g["lhs"])), to_dev(np.array(g["rhs"])), g["alpha"])
+    assert np.abs(to_host(acc) - np.array(g["target"])).max() < g["tol"]
+
+
+def test_matmul_negative_and_generic_strides(oracle):
+    F = init_gpu()
+    rng = np.random.default_rng(5)
+    a, b = rnd(rng, 70, 90), rnd(rng, 90, 50)
+    big_a, big_b = to_dev(np.zeros((140, 180))), to_dev(np.zeros((180, 100)))
+    big_a[::2, ::2] = to_dev(a)
+    big_b[::2, ::2] = to_dev(b)
+    va = big_a[::2, ::2].flip(0)  # generic (non unit) strides + reversed rows (torch has no negative strides)
+    vb = big_b[::2, ::2]
+    dc = to_dev(np.zeros((70, 50)))
+    F.matmul(dc, F.ACCUM_REPLACE, va, vb, 1.0)
+    assert np.abs(to_host(dc) - a[::-1] @ b).max() < 1e-11
+
+
+def test_matmul_host_pointers(oracle):
+    """host-resident operands (a faer::Mat): staged through device buffers by the library"""
+    F = init_gpu()
+    rng = np.random.default_rng(6)
+    a, b, c0 = rnd(rng, 200, 150), rnd(rng, 150, 120), rnd(rng, 200, 120)
+    c = c0.copy(order="F")
+    F.matmul(c, F.ACCUM_ADD, a[::-1, :], b[:, ::-1], 1.5)  # negative host strides too
+    assert np.abs(c - (c0 + 1.5 * a[::-1, :] @ b[:, ::-1])).max() < 1e-11
+
+
+STRUCTS = ["rect", "lower", "upper", "strict_lower", "strict_upper", "unit_lower", "unit_upper"]
+
+
+def dense_of(a, s):
+    n = a.shape[0]
+    return {"rect": a, "lower": np.tril(a), "upper": np.triu(a), "strict_lower": np.tril(a, -1),
+            "strict_upper": np.triu(a, 1), "unit_lower": np.tril(a, -1) + np.eye(n),
+            "unit_upper": np.triu(a, 1) + np.eye(n)}[s]
+
+
+def mask_of(n, s):
+    i, j = np.indices((n, n))
+    return {"rect": i >= -1, "lower": i >= j, "upper": i <= j, "strict_lower": i > j, "strict_upper": i < j,
+            "unit_lower": i > j, "unit_upper": i < j}[s]
+
+
+@pytest.mark.parametrize("cs", STRUCTS)
+@pytest.mark.parametrize("as_", STRUCTS)
+def test_triangular_matmul(oracle, cs, as_):
+    """matmul/mod.rs:2216-2266 `test_triangular`: all 7^3 structure triples, 1e-10, untouched part unchanged"""
+    F = init_gpu()
+    rng = np.random.default_rng(STRUCTS.index(cs) * 7 + STRUCTS.index(as_))
+    for bs_ in STRUCTS:
+        n = int(rng.integers(1, 100))
+        a, b, c0 = rnd(rng, n, n), rnd(rng, n, n), rnd(rng, n, n)
+        for accum in (F.ACCUM_ADD, F.ACCUM_REPLACE):
+            dc = to_dev(c0)
+            F.matmul_triangular(dc, cs, accum, to_dev(a), as_, to_dev(b), bs_, 2.5)
+            got = to_host(dc)
+            ref = c0.copy(order="F")
+            oracle.matmul_triangular(ref, cs, a, as_, b, bs_, alpha=2.5, accum_add=accum == F.ACCUM_ADD)
+            mk = mask_of(n, cs)
+            assert np.abs(got - ref)[mk].max(initial=0) < 1e-10, (cs, as_, bs_, n)
+            assert (got[~mk] == c0[~mk]).all(), (cs, as_, bs_, n)
+            full = (c0 if accum == F.ACCUM_ADD else 0) + 2.5 * dense_of(a, as_) @ dense_of(b, bs_)
+            assert np.abs(got - full)[mk].max(initial=0) < 1e-10
+
+
+@pytest.mark.parametrize("kind", ["lower", "upper"])
+@pytest.mark.parametrize("n,k", [(100, 37), (257, 128), (1000, 64)])
+def test_gemm_inner_boundary_dst_kind(kind, n, k):
+    """the private_gemm_x86::gemm(DstKind::Lower/Upper) call of triangular.rs:641-680"""
+    F = init_gpu()
+    rng = np.random.default_rng(n + k)
+    a, c0 = rnd(rng, n, k), rnd(rng, n, n)
+    dc = to_dev(c0)
+    F.gemm(dc, F.DST_LOWER if kind == "lower" else F.DST_UPPER, F.ACCUM_ADD, to_dev(a), to_dev(a).t(), -1.0)
+    got = to_host(dc)
+    full = c0 - a @ a.T
+    mk = np.tril(np.ones((n, n), bool)) if kind == "lower" else np.triu(np.ones((n, n), bool))
+    assert np.abs(got - full)[mk].max() < 1e-10
+    assert (got[~mk] == c0[~mk]).all()
+
+
+def test_gemm_inner_boundary_scatter_and_diag():
+    """row/col index scatter + fused diagonal scaling (matmul/internal/mod.rs:45-379 `spicy_matmul`)"""
+    F = init_gpu()
+    rng = np.random.default_rng(9)
+    m, n, k = 50, 40, 30
+    a, b, d = rnd(rng, m, k), rnd(rng, k, n), rng.standard_normal(k)
+    c0 = rnd(rng, 80, 70)
+    ri = rng.permutation(80)[:m].astype(np.uint64)
+    ci = rng.permutation(70)[:n].astype(np.uint64)
+    c = c0.copy(order="F")
+    F.gemm(c, F.DST_FULL, F.ACCUM_ADD, a, b, 1.0, row_idx=ri, col_idx=ci, diag=d)  # host operands
+    ref = c0.copy()
+    ref[np.ix_(ri.astype(int), ci.astype(int))] += a @ np.diag(d) @ b
+    assert np.abs(c - ref).max() < 1e-11
+
+
+def test_matmul_full_size_property():
+    """BASELINE config G (N = 8192 fp64): checksum (A B) x == A (B x), independent of the oracle"""
+    import torch
+
+    F = init_gpu()
+    n = 8192
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g).t()
+    b = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g).t()
+    c = torch.empty((n, n), dtype=torch.float64, device="cuda").t()
+    F.matmul(c, F.ACCUM_REPLACE, a, b, 1.0)
+    F.synchronize()
+    x = torch.randn((n,), dtype=torch.float64, device="cuda", generator=g)
+    lhs = c @ x
+    rhs = a @ (b @ x)
+    scale = (a.abs() @ (b.abs() @ x.abs())).max().item()
+    assert (lhs - rhs).abs().max().item() <= 8 * n * 2.3e-16 * scale
