@@ -56,7 +56,7 @@ def test_params_and_scratch_queries_need_no_gpu():
     g = lib.libfaer_v0_23_get_global_par()
     assert (g.tag, g.nthreads) == (1, 8)
     assert lib.faer_hip_dist_local_ncols(C.c_size_t(1000), C.c_size_t(128), 1, 4) == 256
-    assert lib.faer_hip_dist_local_ncols(C.c_size_t(1000), C.c_size_t(128), 3, 4) == 104
+    assert lib.faer_hip_dist_local_ncols(C.c_size_t(1000), C.c_size_t(128), 3, 4) == 232
 
 
 def test_product_path_has_no_cpu_fallback():
