@@ -1,13 +1,821 @@
-// Householder QR (placeholder until the kernels land; fails loudly, never falls back to the CPU).
+// Householder QR without pivoting for gfx950.
+//
+// Replaces faer/src/linalg/qr/no_pivoting/factor.rs:11-301 and the pieces of
+// faer/src/linalg/householder.rs it uses (make_householder_imp :59-107, upgrade_householder_factor :132-272,
+// apply_block_householder_* :370-808) -- SURVEY.md section 8a rows a24-a30.
+//
+// Output convention (householder.rs:1-33): R in the upper triangle, the tails of the reflectors v_j
+// (v_jj = 1 implicit) below it, and Q_coeff = one upper triangular T per block of `block_size` columns
+// with T_jj = tau_j = |v_j|^2 / 2 and T_ij = v_i^H v_j (i < j), so that H_0 .. H_{b-1} = I - V T^-1 V^H.
+//
+// Two paths, both on the GPU:
+//  * FAST (full column rank, the case of every benchmark shape): the reference's recursion on the block
+//    size (factor.rs:137-256), with every level-3 step on the MFMA GEMM (split-K for the K = nrows inner
+//    products) and an 8-column cooperative leaf: the panel's row chunks stay resident in LDS across the 8
+//    column steps, each step needs ONE device-wide reduction (the dot products x^H a_c of the current column
+//    with all remaining panel columns are summed in the same pass that would compute its norm, so the
+//    reflector, its tau and the update all follow from one all-reduce), plus one more for the 8x8 T block.
+//    The rank test of the reference (factor.rs:52-82) is evaluated on the fly; the first column that fails
+//    it raises a flag and the factorization is redone from a saved copy by
+//  * GENERAL (rank revealing): a literal restatement of qr_in_place_unblocked (factor.rs:11-86) with the
+//    running `row` kept in device memory (no host round trip per column), followed by the T blocks
+//    T = striu(V^H V) + diag(tau) per block of accepted reflectors.
+#include <climits>
+#include <limits>
+
 #include "common.h"
+
 namespace fh {
-template <typename T> long geqrf_dev(MatV<T>, MatV<T>, idx_t) { die("qr: not implemented yet", __FILE__, __LINE__); }
-template <typename T> void apply_householder_sequence_left_dev(MatV<const T>, MatV<const T>, MatV<T>, bool)
+
+// ------------------------------------------------------------------------------------------------
+// block reflector application (householder.rs:370-620, generic path)
+// ------------------------------------------------------------------------------------------------
+// M <- (I - V T^-H V^H) M  (forward)   or   (I - V T^-1 V^H) M  (!forward); V unit lower trapezoidal m x b
+template <typename T> static void apply_block_householder_dev(MatV<const T> V, MatV<const T> Tf, MatV<T> M, bool forward)
 {
-	die("apply_householder: not implemented yet", __FILE__, __LINE__);
+	const idx_t m = V.nrows, b = V.ncols, k = M.ncols;
+	if (b == 0 || k == 0 || m == 0)
+		return;
+	FH_CHECK(Tf.nrows == b && Tf.ncols == b && M.nrows == m && m >= b, "apply_block_householder: shape mismatch");
+	Scratch tmpb((size_t) b * (size_t) k * sizeof(T));
+	MatV<T> tmp{tmpb.as<T>(), b, k, 1, b};
+	MatV<const T> Vtop = V.sub(0, 0, b, b), Vbot = V.sub(b, 0, m - b, b);
+	MatV<T> Mtop = M.sub(0, 0, b, k), Mbot = M.sub(b, 0, m - b, k);
+	// tmp = V_top^H M_top + V_bot^H M_bot   (householder.rs:541-563)
+	matmul_triangular_dev<T>(tmp, 0, false, Vtop.t(), 6 /*unit upper*/, Mtop.c(), 0, (T) 1);
+	if (m > b)
+		gemm_dev<T>(tmp, DST_FULL, true, Vbot.t(), Mbot.c(), (T) 1);
+	// tmp <- T^-H tmp or T^-1 tmp          (householder.rs:564-578)
+	if (forward)
+		trsm_lower_dev<T>(Tf.t(), false, tmp);
+	else
+		trsm_upper_dev<T>(Tf, false, tmp);
+	// M -= V tmp                            (householder.rs:579-601)
+	matmul_triangular_dev<T>(Mtop, 0, true, Vtop, 5 /*unit lower*/, tmp.c(), 0, (T) -1);
+	if (m > b)
+		gemm_dev<T>(Mbot, DST_FULL, true, Vbot, tmp.c(), (T) -1);
 }
+
+// householder.rs:724-808
+template <typename T>
+void apply_householder_sequence_left_dev(MatV<const T> V, MatV<const T> H, MatV<T> M, bool transpose)
+{
+	const idx_t m = V.nrows, n = V.ncols;
+	const idx_t size = m < n ? m : n;
+	const idx_t block_size = H.nrows;
+	FH_CHECK(block_size > 0 && H.ncols == size && M.nrows == m, "apply_householder_sequence: shape mismatch");
+	if (transpose) {
+		for (idx_t j = 0; j < size;) {
+			const idx_t bs = block_size < size - j ? block_size : size - j;
+			apply_block_householder_dev<T>(V.sub(j, j, m - j, bs), H.sub(0, j, bs, bs), M.sub(j, 0, m - j, M.ncols),
+						       true);
+			j += bs;
+		}
+	} else {
+		idx_t j = size;
+		idx_t bs = size % block_size;
+		if (bs == 0)
+			bs = block_size;
+		while (j > 0) {
+			const idx_t jp = j - bs;
+			bs = block_size;
+			apply_block_householder_dev<T>(V.sub(jp, jp, m - jp, j - jp), H.sub(0, jp, j - jp, j - jp),
+						       M.sub(jp, 0, m - jp, M.ncols), false);
+			j = jp;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Lim;
+template <> struct Lim<double> {
+	static constexpr double eps = 2.220446049250313e-16, minpos = 2.2250738585072014e-308;
+};
+template <> struct Lim<float> {
+	static constexpr float eps = 1.1920929e-07f, minpos = 1.17549435e-38f;
+};
+
+static __device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1)
+		v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+static __device__ bool qr_grid_barrier(unsigned long long *cnt, unsigned long long target, int *s_flag)
+{
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		int ok = 0;
+		for (int spin = 0; spin < (1 << 22); ++spin) {
+			if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+				ok = 1;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		*s_flag = ok;
+	}
+	__syncthreads();
+	return *s_flag != 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST path leaf: cooperative 8-column Householder panel
+// ------------------------------------------------------------------------------------------------
+constexpr int QR_PW = 8;
+constexpr int QR_GMAX = 224;
+constexpr int QR_NPAIR = QR_PW * (QR_PW - 1) / 2; // 28
+constexpr int QR_SLOT = 32;			  // doubles per workgroup slot (>= QR_NPAIR, >= QR_PW)
+
+template <typename T> struct QrPanelArgs {
+	T *P;	     // panel view, row 0 = diagonal row of its first column
+	idx_t rs, cs;
+	int m, w;
+	int R;
+	const T *above; // A[0, abs_col0] (rows above the panel), same strides
+	int row_abs;	// number of rows above the panel
+	T *Tb;		// w x w block of Q_coeff (upper)
+	idx_t trs, tcs;
+	double *slots; // [2][G][QR_SLOT]
+	double *head;  // [2][QR_PW + 1]: row j of the panel (cols j..w) and |above|^2
+	unsigned long long *counter;
+	unsigned long long counter_base;
+	int *status; // [2] barrier timeout, [3] rank deficiency detected
+};
+
+// sums `vals[0..cnt)` over the workgroup into s_red[0..cnt) (every thread then reads s_red)
+template <int CNT> static __device__ __forceinline__ void block_sum(double (&vals)[CNT], double *s_part, double *s_red)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+	for (int c = 0; c < CNT; ++c) {
+		const double s = wave_sum(vals[c]);
+		if (lane == 0)
+			s_part[wave * CNT + c] = s;
+	}
+	__syncthreads();
+	if (tid < CNT)
+		s_red[tid] = s_part[tid] + s_part[CNT + tid] + s_part[2 * CNT + tid] + s_part[3 * CNT + tid];
+	__syncthreads();
+}
+
+template <typename T, int RMAX> __global__ __launch_bounds__(256) void qr_panel_kernel(const QrPanelArgs<T> a)
+{
+	__shared__ T Ps[QR_PW * RMAX]; // Ps[c * RMAX + r]
+	__shared__ double s_part[4 * QR_SLOT], s_red[QR_SLOT], s_S[QR_SLOT];
+	__shared__ double s_tau[QR_PW], s_head[QR_PW + 1];
+	__shared__ int s_flag;
+
+	const int tid = threadIdx.x;
+	const int g = blockIdx.x, G = gridDim.x;
+	const int r0 = g * a.R;
+	const int nr = min(a.R, a.m - r0);
+	const int w = a.w;
+	if (a.status[3] != 0)
+		return; // an earlier panel found a rank deficiency: the whole factorization is being abandoned
+
+	for (int c = 0; c < w; ++c)
+		for (int r = tid; r < nr; r += 256)
+			Ps[c * RMAX + r] = a.P[(idx_t) (r0 + r) * a.rs + (idx_t) c * a.cs];
+	__syncthreads();
+
+	const int steps = min(w, a.m);
+	int bar = 0;
+	bool timeout = false, deficient = false;
+	for (int j = 0; j < steps; ++j) {
+		const int q = bar & 1;
+		// ---- partial sums s_c = sum_{r > j} x_r a_rc, c = j .. w-1 (c == j gives |tail|^2)
+		double acc[QR_PW];
+#pragma unroll
+		for (int c = 0; c < QR_PW; ++c)
+			acc[c] = 0.0;
+		for (int r = tid; r < nr; r += 256) {
+			if (r0 + r > j) {
+				const double x = (double) Ps[j * RMAX + r];
+#pragma unroll
+				for (int c = 0; c < QR_PW; ++c)
+					if (c >= j && c < w)
+						acc[c] += x * (double) Ps[c * RMAX + r];
+			}
+		}
+		block_sum<QR_PW>(acc, s_part, s_red);
+		// after this block: s_S[c] = full sums, s_head[c] = row j of the panel, s_head[QR_PW] = |above|^2
+		{
+			// squared norm of column j above its diagonal: rows outside the panel + rows 0..j-1 of chunk 0
+			double ab[1] = {0.0};
+			if (g == 0) {
+				for (int i = tid; i < a.row_abs; i += 256) {
+					const double v = (double) a.above[(idx_t) i * a.rs + (idx_t) j * a.cs];
+					ab[0] += v * v;
+				}
+				for (int i = tid; i < j; i += 256) {
+					const double v = (double) Ps[j * RMAX + i];
+					ab[0] += v * v;
+				}
+			}
+			if (G > 1) {
+				if (tid < QR_PW)
+					a.slots[((size_t) q * G + g) * QR_SLOT + tid] = s_red[tid];
+				if (g == 0) {
+					block_sum<1>(ab, s_part, s_S);
+					if (tid < QR_PW)
+						a.head[q * (QR_PW + 1) + tid] = tid < w ? (double) Ps[tid * RMAX + j] : 0.0;
+					if (tid == 0)
+						a.head[q * (QR_PW + 1) + QR_PW] = s_S[0];
+				}
+				if (!qr_grid_barrier(a.counter, a.counter_base + (unsigned long long) G * (bar + 1), &s_flag)) {
+					timeout = true;
+					break;
+				}
+				++bar;
+				double tot[QR_PW];
+#pragma unroll
+				for (int c = 0; c < QR_PW; ++c)
+					tot[c] = 0.0;
+				for (int t = tid; t < G; t += 256)
+#pragma unroll
+					for (int c = 0; c < QR_PW; ++c)
+						tot[c] += a.slots[((size_t) q * G + t) * QR_SLOT + c];
+				block_sum<QR_PW>(tot, s_part, s_S);
+				if (tid <= QR_PW)
+					s_head[tid] = a.head[q * (QR_PW + 1) + tid];
+			} else {
+				if (tid < QR_PW) {
+					s_S[tid] = s_red[tid];
+					s_head[tid] = tid < w ? (double) Ps[tid * RMAX + j] : 0.0;
+				}
+				block_sum<1>(ab, s_part, s_red);
+				if (tid == 0)
+					s_head[QR_PW] = s_red[0];
+			}
+			__syncthreads();
+		}
+		// ---- reflector (householder.rs:59-107), evaluated identically by every thread
+		T head = (T) s_head[j];
+		const double above2 = s_head[QR_PW];
+		const T tail_norm = (T) sqrt(s_S[j]);
+		T head_norm = fabs(head);
+		if (head_norm < Lim<T>::minpos) {
+			head = (T) 0;
+			head_norm = (T) 0;
+		}
+		if (tail_norm < Lim<T>::minpos) {
+			// householder.rs:70-77 + factor.rs:59-63: tau = inf, nothing is scaled or updated; the column
+			// is accepted iff its head is non zero (e.g. the last column of a square matrix)
+			if (!(head_norm > (T) 0)) {
+				deficient = true;
+				break;
+			}
+			if (tid == 0)
+				s_tau[j] = (double) std::numeric_limits<T>::infinity();
+			__syncthreads();
+			continue;
+		}
+		const T norm = (T) hypot((double) head_norm, (double) tail_norm);
+		const T sign = head_norm != (T) 0 ? head * ((T) 1 / head_norm) : (T) 1;
+		const T signed_norm = sign * norm;
+		const T hinv = (T) 1 / (head + signed_norm);
+		const T tn = tail_norm * fabs(hinv);
+		const T tau = (T) 0.5 * ((T) 1 + tn * tn);
+		// rank test (factor.rs:52-82)
+		const T full_norm = (T) hypot((double) norm, sqrt(above2));
+		const T threshold = Lim<T>::eps * (T) ((double) (a.m - j) * 16.0) * full_norm;
+		const T tau_inv = (T) 1 / tau;
+		if (tau_inv < Lim<T>::minpos || !(norm > threshold)) {
+			deficient = true;
+			break;
+		}
+		if (tid == 0)
+			s_tau[j] = (double) tau;
+		// ---- update: v = x * hinv ; k_c = -(a_jc + v^H a_c) / tau ; a_c += k_c v   (factor.rs:65-80)
+		T kc[QR_PW];
+#pragma unroll
+		for (int c = 0; c < QR_PW; ++c)
+			kc[c] = (c > j && c < w) ? -(((T) s_head[c] + hinv * (T) s_S[c]) * tau_inv) : (T) 0;
+		for (int r = tid; r < nr; r += 256) {
+			if (r0 + r > j) {
+				const T v = Ps[j * RMAX + r] * hinv;
+				Ps[j * RMAX + r] = v;
+#pragma unroll
+				for (int c = 0; c < QR_PW; ++c)
+					if (c > j && c < w)
+						Ps[c * RMAX + r] += kc[c] * v;
+			}
+		}
+		if (g == 0 && tid < w) { // row j itself (chunk 0 owns it)
+			if (tid == j)
+				Ps[j * RMAX + j] = -signed_norm;
+			else if (tid > j)
+				Ps[tid * RMAX + j] += -(((T) s_head[tid] + hinv * (T) s_S[tid]) * tau_inv);
+		}
+		__syncthreads();
+	}
+	if (timeout || deficient) {
+		if (tid == 0)
+			atomicExch(a.status + (timeout ? 2 : 3), 1);
+		return;
+	}
+	// ---- T block: T_ij = v_i[j] + sum_{r > j} v_ri v_rj  (i < j) ; T_jj = tau_j
+	{
+		const int q = bar & 1;
+		double acc2[QR_NPAIR];
+#pragma unroll
+		for (int p = 0; p < QR_NPAIR; ++p)
+			acc2[p] = 0.0;
+		for (int r = tid; r < nr; r += 256) {
+			const int gr = r0 + r;
+			double v[QR_PW];
+#pragma unroll
+			for (int c = 0; c < QR_PW; ++c)
+				v[c] = c < w ? (double) Ps[c * RMAX + r] : 0.0;
+			int p = 0;
+#pragma unroll
+			for (int jj = 1; jj < QR_PW; ++jj)
+#pragma unroll
+				for (int i = 0; i < jj; ++i, ++p)
+					if (gr > jj)
+						acc2[p] += v[i] * v[jj];
+		}
+		block_sum<QR_NPAIR>(acc2, s_part, s_red);
+		if (G > 1) {
+			if (tid < QR_NPAIR)
+				a.slots[((size_t) q * G + g) * QR_SLOT + tid] = s_red[tid];
+			if (!qr_grid_barrier(a.counter, a.counter_base + (unsigned long long) G * (bar + 1), &s_flag)) {
+				if (tid == 0)
+					atomicExch(a.status + 2, 1);
+				return;
+			}
+			double tot[QR_NPAIR];
+#pragma unroll
+			for (int p = 0; p < QR_NPAIR; ++p)
+				tot[p] = 0.0;
+			if (g == 0) {
+				for (int t = tid; t < G; t += 256)
+#pragma unroll
+					for (int p = 0; p < QR_NPAIR; ++p)
+						tot[p] += a.slots[((size_t) q * G + t) * QR_SLOT + p];
+				block_sum<QR_NPAIR>(tot, s_part, s_red);
+			}
+		}
+		if (g == 0 && tid == 0) {
+			int p = 0;
+			for (int jj = 0; jj < w; ++jj)
+				a.Tb[(idx_t) jj * a.trs + (idx_t) jj * a.tcs] = (T) s_tau[jj];
+			for (int jj = 1; jj < QR_PW; ++jj)
+				for (int i = 0; i < jj; ++i, ++p)
+					if (jj < w)
+						a.Tb[(idx_t) i * a.trs + (idx_t) jj * a.tcs] =
+							(T) ((double) Ps[i * RMAX + jj] + s_red[p]);
+		}
+	}
+	for (int c = 0; c < w; ++c)
+		for (int r = tid; r < nr; r += 256)
+			a.P[(idx_t) (r0 + r) * a.rs + (idx_t) c * a.cs] = Ps[c * RMAX + r];
+}
+
+template <typename T> struct QrWork {
+	double *slots, *head;
+	unsigned long long *counter;
+	unsigned long long counter_base;
+	int *status;
+	const T *a_top; // A[0, 0]
+	idx_t rs, cs;
+};
+
+template <typename T> static constexpr int qr_rmax() { return sizeof(T) == 8 ? 2240 : 4480; }
+
+template <typename T> static void qr_leaf(MatV<T> P, MatV<T> Tb, idx_t row_abs, idx_t col_abs, QrWork<T> &wk)
+{
+	constexpr int RMAX = qr_rmax<T>();
+	const idx_t m = P.nrows;
+	const int w = (int) P.ncols;
+	int G = (int) ((m + RMAX - 1) / RMAX);
+	if (G < 1)
+		G = 1;
+	int R = (int) ((m + G - 1) / G);
+	R = (R + 63) / 64 * 64;
+	if (R > RMAX)
+		R = RMAX;
+	if (R < 64)
+		R = 64;
+	G = (int) ((m + R - 1) / R);
+	FH_CHECK(G <= QR_GMAX, "qr: panel too tall for the cooperative kernel");
+	QrPanelArgs<T> a;
+	a.P = P.p;
+	a.rs = P.rs;
+	a.cs = P.cs;
+	a.m = (int) m;
+	a.w = w;
+	a.R = R;
+	a.above = wk.a_top + col_abs * wk.cs;
+	a.row_abs = (int) row_abs;
+	a.Tb = Tb.p;
+	a.trs = Tb.rs;
+	a.tcs = Tb.cs;
+	a.slots = wk.slots;
+	a.head = wk.head;
+	a.counter = wk.counter;
+	a.counter_base = wk.counter_base;
+	a.status = wk.status;
+	hipLaunchKernelGGL((qr_panel_kernel<T, RMAX>), dim3(G), dim3(256), 0, ctx().stream, a);
+	FH_HIP(hipGetLastError());
+	if (G > 1) {
+		const int steps = w < (int) m ? w : (int) m;
+		wk.counter_base += (unsigned long long) G * (steps + 1);
+	}
+}
+
+// P: rows from the diagonal row of its first column; Tb: w x w block of Q_coeff
+template <typename T> static void qr_rec(MatV<T> P, MatV<T> Tb, idx_t row_abs, idx_t col_abs, QrWork<T> &wk)
+{
+	const idx_t m = P.nrows, w = P.ncols;
+	if (w == 0 || m == 0)
+		return;
+	if (w <= QR_PW) {
+		qr_leaf<T>(P, Tb, row_abs, col_abs, wk);
+		return;
+	}
+	idx_t w1 = ((w / 2 + QR_PW - 1) / QR_PW) * QR_PW;
+	if (w1 >= w)
+		w1 = w - QR_PW;
+	const idx_t w2 = w - w1;
+	MatV<T> V1 = P.sub(0, 0, m, w1), B = P.sub(0, w1, m, w2);
+	MatV<T> T11 = Tb.sub(0, 0, w1, w1), T12 = Tb.sub(0, w1, w1, w2), T22 = Tb.sub(w1, w1, w2, w2);
+	qr_rec<T>(V1, T11, row_abs, col_abs, wk);
+	apply_block_householder_dev<T>(V1.c(), T11.c(), B, true); // factor.rs:241-249
+	if (m > w1) {
+		MatV<T> P2 = P.sub(w1, w1, m - w1, w2);
+		qr_rec<T>(P2, T22, row_abs + w1, col_abs + w1, wk);
+		// T12 = V1[w1:, :]^H V2 (householder.rs:249-267): V2 unit lower trapezoidal (m - w1) x w2
+		const idx_t mt = m - w1;
+		const idx_t top = mt < w2 ? mt : w2;
+		MatV<const T> V1m = P.sub(w1, 0, top, w1).c(), V2top = P.sub(w1, w1, top, w2).c();
+		// rectangular (w1 x top) times unit-lower-trapezoidal top block: treat the top x w2 block as
+		// [unit lower | 0]; when mt < w2 only the leading mt x mt part is triangular
+		if (top == w2) {
+			matmul_triangular_dev<T>(T12, 0, false, V1m.t(), 0, V2top, 5, (T) 1);
+			if (mt > w2)
+				gemm_dev<T>(T12, DST_FULL, true, P.sub(w1 + w2, 0, mt - w2, w1).c().t(),
+					    P.sub(w1 + w2, w1, mt - w2, w2).c(), (T) 1);
+		} else {
+			FH_CHECK(false, "qr: internal: wide panel in the fast path");
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// GENERAL path: qr_in_place_unblocked (factor.rs:11-86) with `row` kept on the device
+// ------------------------------------------------------------------------------------------------
+struct GqState {
+	int row;     // accepted reflectors so far
+	int lim;     // min(size, m)
+	int mode;    // 1: the scaled tail is written this column
+	int apply;   // 1: update the remaining columns
+	int accept;  // 1: row += 1 afterwards
+	int active;  // 0 once row reached lim
+	double acc[6]; // scaled sums: above {sml, med, big}, tail {sml, med, big}
+	double hinv, tau_inv;
+};
+
+template <typename T> struct GqArgs {
+	T *A;
+	idx_t rs, cs;
+	int m, n, col;
+	GqState *st;
+	double *dots; // n entries
+	double *kvec; // n entries
+	T *taus;      // size entries
+};
+
+template <typename T> static __device__ __forceinline__ double scale_sml() { return sqrt((double) Lim<T>::minpos); }
+template <typename T> static __device__ __forceinline__ double scale_big() { return sqrt(1.0 / (double) Lim<T>::minpos); }
+
+// reductions/norm_l2.rs:6-45: three accumulators of (x*sml)^2, x^2, (x*big)^2, in the scalar type
+template <typename T> __global__ void gq_norms_kernel(const GqArgs<T> a)
+{
+	__shared__ double s_part[4 * 6], s_red[6];
+	const int row = a.st->row;
+	if (row >= a.st->lim)
+		return;
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	T acc[6] = {0, 0, 0, 0, 0, 0};
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.m; i += gridDim.x * blockDim.x) {
+		if (i == row)
+			continue;
+		const T x = a.A[(idx_t) i * a.rs + (idx_t) a.col * a.cs];
+		const int o = i < row ? 0 : 3;
+		acc[o + 0] += (x * sml) * (x * sml);
+		acc[o + 1] += x * x;
+		acc[o + 2] += (x * big) * (x * big);
+	}
+	double accd[6];
+	for (int k = 0; k < 6; ++k)
+		accd[k] = (double) acc[k];
+	block_sum<6>(accd, s_part, s_red);
+	if (threadIdx.x < 6)
+		atomicAdd(&a.st->acc[threadIdx.x], s_red[threadIdx.x]);
+}
+
+template <typename T> static __device__ T norm_from3(const double *acc)
+{
+	// reductions/norm_l2.rs:173-184
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	const T a0 = (T) acc[0], a1 = (T) acc[1], a2 = (T) acc[2];
+	if (a0 >= (T) 1)
+		return sqrt(a0) * big;
+	if (a1 >= (T) 1)
+		return sqrt(a1);
+	return sqrt(a2) * sml;
+}
+
+template <typename T> __global__ void gq_house_kernel(const GqArgs<T> a)
+{
+	GqState *st = a.st;
+	if (threadIdx.x != 0 || blockIdx.x != 0)
+		return;
+	const int row = st->row;
+	st->mode = 0;
+	st->apply = 0;
+	st->accept = 0;
+	st->active = row < st->lim ? 1 : 0;
+	if (!st->active)
+		return;
+	const T norm_above = norm_from3<T>(st->acc);
+	const T tail_norm = norm_from3<T>(st->acc + 3);
+	for (int k = 0; k < 6; ++k)
+		st->acc[k] = 0.0;
+	T *hp = a.A + (idx_t) row * a.rs + (idx_t) a.col * a.cs;
+	T head = *hp;
+	T head_norm = fabs(head);
+	T tau, inorm;
+	if (head_norm < Lim<T>::minpos) { // householder.rs:66-69
+		head = (T) 0;
+		head_norm = (T) 0;
+		*hp = head;
+	}
+	if (tail_norm < Lim<T>::minpos) { // householder.rs:70-77
+		tau = std::numeric_limits<T>::infinity();
+		inorm = head_norm;
+	} else {
+		const T norm = (T) hypot((double) head_norm, (double) tail_norm);
+		const T sign = head_norm != (T) 0 ? head * ((T) 1 / head_norm) : (T) 1;
+		const T signed_norm = sign * norm;
+		const T hinv = (T) 1 / (head + signed_norm);
+		*hp = -signed_norm;
+		const T tn = tail_norm * fabs(hinv);
+		tau = (T) 0.5 * ((T) 1 + tn * tn);
+		inorm = norm;
+		st->hinv = (double) hinv;
+		st->mode = 1;
+	}
+	const T full = (T) hypot((double) inorm, (double) norm_above);
+	const T threshold = Lim<T>::eps * (T) ((double) (a.m - row) * 16.0) * full;
+	const T tau_inv = (T) 1 / tau;
+	a.taus[row] = tau; // H[row] = tau (factor.rs:57)
+	st->tau_inv = (double) tau_inv;
+	if (tau_inv < Lim<T>::minpos) {
+		if (inorm > (T) 0)
+			st->accept = 1;
+	} else if (inorm > threshold) {
+		st->apply = 1;
+		st->accept = 1;
+	}
+}
+
+// v = tail * hinv written into column `row` (in place when row == col); when row != col the first
+// min(len, col - row) entries of the original tail are zeroed (factor.rs:39-50)
+template <typename T> __global__ void gq_scale_kernel(const GqArgs<T> a)
+{
+	const GqState *st = a.st;
+	if (!st->active)
+		return;
+	const int row = st->row, col = a.col;
+	const T hinv = (T) st->hinv;
+	for (int i = row + 1 + blockIdx.x * blockDim.x + threadIdx.x; i < a.m; i += gridDim.x * blockDim.x) {
+		T *src = a.A + (idx_t) i * a.rs + (idx_t) col * a.cs;
+		if (st->mode == 1)
+			a.A[(idx_t) i * a.rs + (idx_t) row * a.cs] = *src * hinv;
+		if (row != col && i - (row + 1) < col - row)
+			*src = (T) 0;
+	}
+}
+
+template <typename T> __global__ void gq_dots_kernel(const GqArgs<T> a)
+{
+	__shared__ double s_part[4], s_red[1];
+	const GqState *st = a.st;
+	if (!st->active || !st->apply)
+		return;
+	const int row = st->row;
+	const int c = a.col + 1 + blockIdx.y;
+	double acc[1] = {0.0};
+	for (int i = row + 1 + blockIdx.x * blockDim.x + threadIdx.x; i < a.m; i += gridDim.x * blockDim.x)
+		acc[0] += (double) a.A[(idx_t) i * a.rs + (idx_t) row * a.cs] * (double) a.A[(idx_t) i * a.rs + (idx_t) c * a.cs];
+	block_sum<1>(acc, s_part, s_red);
+	if (threadIdx.x == 0)
+		atomicAdd(&a.dots[c], s_red[0]);
+}
+
+template <typename T> __global__ void gq_heads_kernel(const GqArgs<T> a)
+{
+	const GqState *st = a.st;
+	const int c = a.col + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= a.n)
+		return;
+	if (st->active && st->apply) {
+		T *hp = a.A + (idx_t) st->row * a.rs + (idx_t) c * a.cs;
+		const T dot = *hp + (T) a.dots[c];
+		const T k = -(dot * (T) st->tau_inv);
+		*hp += k;
+		a.kvec[c] = (double) k;
+	}
+	a.dots[c] = 0.0;
+}
+
+template <typename T> __global__ void gq_update_kernel(const GqArgs<T> a)
+{
+	const GqState *st = a.st;
+	if (!st->active || !st->apply)
+		return;
+	const int row = st->row;
+	const int c = a.col + 1 + blockIdx.y;
+	const T k = (T) a.kvec[c];
+	for (int i = row + 1 + blockIdx.x * blockDim.x + threadIdx.x; i < a.m; i += gridDim.x * blockDim.x)
+		a.A[(idx_t) i * a.rs + (idx_t) c * a.cs] += k * a.A[(idx_t) i * a.rs + (idx_t) row * a.cs];
+}
+
+__global__ void gq_advance_kernel(GqState *st)
+{
+	if (st->active && st->accept)
+		st->row += 1;
+}
+
+template <typename T> static long qr_general(MatV<T> A, T *taus_dev)
+{
+	const idx_t m = A.nrows, n = A.ncols;
+	const idx_t size = m < n ? m : n;
+	hipStream_t s = ctx().stream;
+	Scratch stb(sizeof(GqState)), dotsb((size_t) n * 8 + 8), kb((size_t) n * 8 + 8);
+	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(GqState), s));
+	FH_HIP(hipMemsetAsync(dotsb.p, 0, (size_t) n * 8 + 8, s));
+	GqState init;
+	memset(&init, 0, sizeof(init));
+	init.lim = (int) size;
+	FH_HIP(hipMemcpyAsync(stb.p, &init, sizeof(init), hipMemcpyHostToDevice, s));
+	FH_HIP(hipStreamSynchronize(s)); // `init` lives on the stack
+	GqArgs<T> a;
+	a.A = A.p;
+	a.rs = A.rs;
+	a.cs = A.cs;
+	a.m = (int) m;
+	a.n = (int) n;
+	a.st = stb.as<GqState>();
+	a.dots = dotsb.as<double>();
+	a.kvec = kb.as<double>();
+	a.taus = taus_dev;
+	int rb = (int) ((m + 255) / 256);
+	if (rb > 1024)
+		rb = 1024;
+	if (rb < 1)
+		rb = 1;
+	for (idx_t col = 0; col < n; ++col) {
+		a.col = (int) col;
+		const int rem = (int) (n - col - 1);
+		hipLaunchKernelGGL(gq_norms_kernel<T>, dim3(rb), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(gq_house_kernel<T>, dim3(1), dim3(64), 0, s, a);
+		hipLaunchKernelGGL(gq_scale_kernel<T>, dim3(rb), dim3(256), 0, s, a);
+		if (rem > 0) {
+			for (int c0 = 0; c0 < rem; c0 += 32768) {
+				GqArgs<T> b = a;
+				b.col = (int) col + c0; // columns col+1+c0 ...
+				const int nc = rem - c0 < 32768 ? rem - c0 : 32768;
+				// dots/update index columns relative to b.col; `row`/v come from the state
+				hipLaunchKernelGGL(gq_dots_kernel<T>, dim3(rb, nc), dim3(256), 0, s, b);
+			}
+			hipLaunchKernelGGL(gq_heads_kernel<T>, dim3((rem + 255) / 256), dim3(256), 0, s, a);
+			for (int c0 = 0; c0 < rem; c0 += 32768) {
+				GqArgs<T> b = a;
+				b.col = (int) col + c0;
+				const int nc = rem - c0 < 32768 ? rem - c0 : 32768;
+				hipLaunchKernelGGL(gq_update_kernel<T>, dim3(rb, nc), dim3(256), 0, s, b);
+			}
+		}
+		hipLaunchKernelGGL(gq_advance_kernel, dim3(1), dim3(1), 0, s, a.st);
+	}
+	FH_HIP(hipGetLastError());
+	GqState fin;
+	FH_HIP(hipMemcpyAsync(&fin, stb.p, sizeof(fin), hipMemcpyDeviceToHost, s));
+	FH_HIP(hipStreamSynchronize(s));
+	return fin.row;
+}
+
+// Q_coeff post-processing.  mode 0: write T_jj = taus[j] for j < rank (general path);
+// always: Q_coeff[:, rank..] = 0 and the +inf diagonal of factor.rs:287-299.
+template <typename T>
+__global__ void qr_finalize_kernel(T *H, idx_t hrs, idx_t hcs, int bs, int size, int rank, const T *taus, int write_tau)
+{
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= size)
+		return;
+	if (j < rank) {
+		if (write_tau)
+			H[(idx_t) (j % bs) * hrs + (idx_t) j * hcs] = taus[j];
+		return;
+	}
+	for (int i = 0; i < bs; ++i)
+		H[(idx_t) i * hrs + (idx_t) j * hcs] = (T) 0;
+	// block containing j starts at col0 = j / bs * bs; the diagonal entries from max(rank, col0) on are +inf
+	const int col0 = j / bs * bs;
+	if (col0 >= rank / bs * bs) {
+		const int start = rank > col0 ? rank : col0;
+		if (j >= start)
+			H[(idx_t) (j - col0) * hrs + (idx_t) j * hcs] = std::numeric_limits<T>::infinity();
+	}
+}
+
+template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold)
+{
+	(void) blocking_threshold; // the GPU recursion always blocks; leaves are 8 columns wide
+	const idx_t m = A.nrows, n = A.ncols;
+	const idx_t size = m < n ? m : n;
+	const idx_t bs = H.nrows;
+	FH_CHECK(bs > 0 && H.ncols == size, "qr: Q_coeff must be block_size x min(nrows, ncols)");
+	FH_CHECK(m < (1L << 30) && n < (1L << 30), "qr: matrix too large");
+	if (size == 0)
+		return 0;
+	hipStream_t s = ctx().stream;
+	Scratch misc(256);
+	FH_HIP(hipMemsetAsync(misc.p, 0, 256, s));
+	int *status = misc.as<int>() + 8;
+	long rank = -1;
+
+	const bool fast_ok = m <= (idx_t) qr_rmax<T>() * QR_GMAX;
+	Scratch backup(fast_ok ? (size_t) m * (size_t) n * sizeof(T) : 256);
+	MatV<T> Bk{backup.as<T>(), m, n, 1, m};
+	if (fast_ok) {
+		copy_dev<T>(Bk, A.c());
+		Scratch slots((size_t) 2 * QR_GMAX * QR_SLOT * sizeof(double)), head((size_t) 2 * (QR_PW + 1) * sizeof(double));
+		QrWork<T> wk;
+		wk.slots = slots.as<double>();
+		wk.head = head.as<double>();
+		wk.counter = misc.as<unsigned long long>();
+		wk.counter_base = 0;
+		wk.status = status;
+		wk.a_top = A.p;
+		wk.rs = A.rs;
+		wk.cs = A.cs;
+		for (idx_t c0 = 0; c0 < size; c0 += bs) {
+			const idx_t wb = bs < size - c0 ? bs : size - c0;
+			MatV<T> P = A.sub(c0, c0, m - c0, wb);
+			MatV<T> Tb = H.sub(0, c0, wb, wb);
+			qr_rec<T>(P, Tb, c0, c0, wk);
+			if (c0 + wb < n) // factor.rs:241-249: apply Q_k^H to everything on the right
+				apply_block_householder_dev<T>(P.c(), Tb.c(), A.sub(c0, c0 + wb, m - c0, n - c0 - wb), true);
+		}
+		int st[4];
+		FH_HIP(hipMemcpyAsync(st, status, sizeof(st), hipMemcpyDeviceToHost, s));
+		FH_HIP(hipStreamSynchronize(s));
+		FH_CHECK(st[2] == 0, "qr: device barrier timed out in the panel kernel");
+		if (st[3] == 0)
+			rank = (long) size;
+		else
+			copy_dev<T>(A, Bk.c()); // rank deficient: redo from the saved copy on the general path
+	}
+	if (rank < 0) {
+		Scratch taus((size_t) size * sizeof(T));
+		rank = qr_general<T>(A, taus.as<T>());
+		// T blocks over the accepted reflectors: striu(V^H V) (householder.rs:185-209), diagonal = tau
+		for (idx_t c0 = 0; c0 < rank; c0 += bs) {
+			const idx_t wb = bs < rank - c0 ? bs : rank - c0;
+			MatV<T> Tb = H.sub(0, c0, wb, wb);
+			MatV<const T> Vtop = A.sub(c0, c0, wb, wb).c();
+			matmul_triangular_dev<T>(Tb, 6, false, Vtop.t(), 6, Vtop, 5, (T) 1);
+			if (m - c0 > wb) {
+				MatV<const T> Vbot = A.sub(c0 + wb, c0, m - c0 - wb, wb).c();
+				GemmExtra<T> ex;
+				ex.dst_strict = true;
+				gemm_dev<T>(Tb, DST_UPPER, true, Vbot.t(), Vbot, (T) 1, &ex);
+			}
+		}
+		hipLaunchKernelGGL(qr_finalize_kernel<T>, dim3((unsigned) ((size + 255) / 256)), dim3(256), 0, s, H.p, H.rs, H.cs,
+				   (int) bs, (int) size, (int) rank, taus.as<T>(), 1);
+		FH_HIP(hipGetLastError());
+		FH_HIP(hipStreamSynchronize(s)); // taus scratch is released on return
+	}
+	return rank;
+}
+
 template long geqrf_dev<double>(MatV<double>, MatV<double>, idx_t);
 template long geqrf_dev<float>(MatV<float>, MatV<float>, idx_t);
 template void apply_householder_sequence_left_dev<double>(MatV<const double>, MatV<const double>, MatV<double>, bool);
 template void apply_householder_sequence_left_dev<float>(MatV<const float>, MatV<const float>, MatV<float>, bool);
+
 } // namespace fh

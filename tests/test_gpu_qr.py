@@ -1,0 +1,115 @@
+"""GPU parity: Householder QR through the C-ABI vs the CPU oracle and the reference's known-answer test
+(test_qr, test_rank_deficient (shape), qr::tests::test_example)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import EPS, init_gpu, rnd, to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def q_from(F, dqr, dh, m, dtype):
+    q = to_dev(np.eye(m, dtype=dtype))
+    F.apply_block_householder_sequence_on_the_left_in_place(dqr, dh, q, transpose=False)
+    return to_host(q)
+
+
+def test_golden_qr_lstsq():
+    """faer/src/linalg/qr/mod.rs:116-191: 10x2 least squares vs the numpy solution, 1e-6"""
+    F = init_gpu()
+    g = json.load(open(os.path.join(GOLD, "qr_lstsq_10x2.json")))
+    a, b, x = np.array(g["a"]), np.array(g["b"]), np.array(g["expected_solution"])
+    m, n = a.shape
+    bs = F.qr_recommended_block_size(m, n)
+    assert bs == 1
+    dqr, dh = to_dev(a), to_dev(np.zeros((bs, n)))
+    assert F.qr_factor_in_place(dqr, dh) == 2
+    sol = to_dev(b)
+    F.apply_block_householder_sequence_on_the_left_in_place(dqr, dh, sol, transpose=True)
+    top = sol[:2, :]
+    F.solve_upper_triangular_in_place(dqr[:2, :2], top)
+    assert np.abs(to_host(top) - x).max() <= g["tol"]
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (2, 1), (10, 2), (33, 33), (100, 40), (40, 100), (257, 64), (512, 200),
+                                 (5000, 17), (3000, 256)])
+@pytest.mark.parametrize("bs", [1, 4, 15, 32, None])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_qr_full_rank_vs_oracle(oracle, m, n, bs, dtype):
+    """qr/no_pivoting/factor.rs:327-538 `test_qr`: Q R ~ A; plus factor-level parity with the oracle"""
+    F = init_gpu()
+    rng = np.random.default_rng(m * 131 + n)
+    a = rnd(rng, m, n, dtype)
+    size = min(m, n)
+    if bs is None:
+        bs = F.qr_recommended_block_size(m, n, dtype)
+        assert bs == oracle.qr_recommended_block_size(m, n, dtype)
+    bs = max(1, min(bs, size))
+    dqr, dh = to_dev(a), to_dev(np.zeros((bs, size), dtype=dtype))
+    rank = F.qr_factor_in_place(dqr, dh)
+    assert rank == size
+    qr, h = to_host(dqr), to_host(dh)
+    ref, rh = a.copy(order="F"), np.zeros((bs, size), dtype=dtype, order="F")
+    assert oracle.qr_in_place(ref, rh) == size
+    e = EPS[np.dtype(dtype)]
+    tol = 64 * max(m, n) * e * max(1.0, np.abs(a).max())
+    R = np.triu(qr).astype(np.float64)
+    q = q_from(F, dqr, dh, m, dtype).astype(np.float64)
+    assert np.abs(q @ R - a).max() <= tol
+    assert np.abs(q.T @ q - np.eye(m)).max() <= tol
+    # same Householder vectors / R / T as the reference algorithm (unique up to rounding)
+    assert np.abs(qr.astype(np.float64) - ref).max() <= 8 * tol
+    fin = np.isfinite(rh)
+    assert (np.isfinite(h) == fin).all()
+    up = np.zeros_like(fin)
+    for j0 in range(0, size, bs):
+        w = min(bs, size - j0)
+        up[:w, j0:j0 + w] = np.triu(np.ones((w, w), bool))
+    assert np.abs(h.astype(np.float64) - rh)[fin & up].max(initial=0) <= 8 * tol * max(1.0, np.abs(rh[fin & up]).max())
+
+
+@pytest.mark.parametrize("true_rank", [1, 2, 3, 5])
+@pytest.mark.parametrize("bs", [1, 15])
+def test_qr_rank_deficient(oracle, true_rank, bs):
+    """low rank products: rank >= true rank, Q R ~ A (factor.rs:327-538), same rank as the oracle"""
+    F = init_gpu()
+    rng = np.random.default_rng(11)
+    m, n = 120, 60
+    a = np.asfortranarray(rnd(rng, m, true_rank) @ rnd(rng, true_rank, n))
+    size = min(m, n)
+    dqr, dh = to_dev(a), to_dev(np.zeros((bs, size)))
+    rank = F.qr_factor_in_place(dqr, dh)
+    ref, rh = a.copy(order="F"), np.zeros((bs, size), order="F")
+    assert rank == oracle.qr_in_place(ref, rh)
+    assert true_rank <= rank < size
+    h = to_host(dh)
+    assert np.array_equal(np.isinf(h), np.isinf(rh)) and (h[:, rank:][np.isfinite(h[:, rank:])] == 0).all()
+    q = q_from(F, dqr, dh, m, np.float64)
+    assert np.abs(q @ np.triu(to_host(dqr)) - a).max() < 1e-10 * max(1.0, np.abs(a).max())
+
+
+def test_qr_tall_skinny_property():
+    """BASELINE config Q (1e6 x 256 fp32): R^T R ~ A^T A, |R| diag > 0 pattern, V^T V diag == 2 tau"""
+    import torch
+
+    F = init_gpu()
+    m, n = 1000000, 256
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn((n, m), dtype=torch.float32, device="cuda", generator=g).t()
+    qr = a.clone()
+    h = torch.zeros((n, n), dtype=torch.float32, device="cuda").t()
+    assert F.qr_factor_in_place(qr, h) == n
+    F.synchronize()
+    R = torch.triu(qr[:n, :]).double()
+    G = (a.double().t() @ a.double())
+    assert ((R.t() @ R - G).abs().max() / G.abs().max()).item() < 5e-5
+    V = torch.tril(qr, -1)
+    V[:n, :n] += torch.eye(n, dtype=torch.float32, device="cuda")
+    VtV = V.double().t() @ V.double()
+    T = h.double()
+    assert ((torch.diagonal(VtV) * 0.5 - torch.diagonal(T)).abs().max() / torch.diagonal(T).abs().max()).item() < 1e-4
+    assert ((torch.triu(VtV, 1) - torch.triu(T, 1)).abs().max()).item() < 1e-2
