@@ -757,7 +757,11 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 	int *status = misc.as<int>() + 8;
 	long rank = -1;
 
-	const bool fast_ok = m <= (idx_t) qr_rmax<T>() * QR_GMAX;
+	// The reference's rank test (factor.rs:52-58) accepts column 0 only if norm > eps * 16 * m * norm, i.e. it
+	// rejects EVERY column once 16 * eps * nrows >= 1 (fp32: nrows >= 524288).  That outcome (rank 0) is
+	// reproduced by the general path; the fast path would only discover it one launch later.
+	const bool ref_rejects_all = (double) Lim<T>::eps * 16.0 * (double) m >= 1.0;
+	const bool fast_ok = m <= (idx_t) qr_rmax<T>() * QR_GMAX && !ref_rejects_all;
 	Scratch backup(fast_ok ? (size_t) m * (size_t) n * sizeof(T) : 256);
 	MatV<T> Bk{backup.as<T>(), m, n, 1, m};
 	if (fast_ok) {

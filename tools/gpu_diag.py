@@ -99,7 +99,7 @@ if "lu" in which:
         del a, work
 
 if "qr" in which:
-    m, n = 1000000, 256
+    m, n = 500000, 256
     a = colmajor(m, n, torch.float32, 5)
     work = a.clone()
     h = torch.zeros((n, 256), dtype=torch.float32, device="cuda").t()
