@@ -244,7 +244,8 @@ def main():
             rng = np.random.default_rng(0)
             ha, hb = np.asfortranarray(rng.standard_normal((n, n))), np.asfortranarray(rng.standard_normal((n, n)))
             hc = np.zeros((n, n), order="F")
-            orc.matmul(hc, ha[:256, :256].copy(order="F") @ np.eye(256, n, order="F"), hb)  # warm (small)
+            hw = np.zeros((256, 256), order="F")
+            orc.matmul(hw, ha[:256, :256].copy(order="F"), hb[:256, :256].copy(order="F"))  # warm (small)
             t0 = time.perf_counter()
             orc.matmul(hc, ha, hb)
             t_mm = time.perf_counter() - t0

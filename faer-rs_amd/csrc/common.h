@@ -151,6 +151,7 @@ template <typename T> struct GemmExtra {
 	idx_t diag_stride = 0;
 	int a_struct = 0, b_struct = 0; // FaerBlock codes of the operands (triangular products)
 	bool dst_strict = false;	// with DST_LOWER / DST_UPPER: leave the diagonal untouched
+	bool force_big = false;		// use the 128x128 tile regardless of the grid size (in-place products)
 };
 
 // dst(kind) <- [dst +] alpha * A * diag * B        (gemm.hip)

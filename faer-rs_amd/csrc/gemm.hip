@@ -495,6 +495,8 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	bool big = variant == 1 || (variant == 0 && tiles128 >= 384);
 	if (variant == 2)
 		big = false;
+	if (ex.force_big)
+		big = true;
 	if (extra_path)
 		big = false;
 	const int bm = big ? 128 : 64;

@@ -86,6 +86,59 @@ __global__ __launch_bounds__(64) void trsm_leaf_kernel(const T *__restrict__ Lp,
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// Many right-hand sides: invert the 128 x 128 diagonal blocks once (one workgroup per block, all blocks in
+// ONE launch) and turn every leaf of the recursion into an MFMA GEMM  X_k <- inv(T_kk) X_k.
+// The product is done IN PLACE: the leaf has at most 128 rows, i.e. one tile of the 128 x 128 GEMM kernel
+// along the aliased dimension, and that kernel reads all of its K slices before its epilogue writes.
+// ------------------------------------------------------------------------------------------------
+constexpr int TRSM_IB = 128;
+
+template <typename T>
+__global__ __launch_bounds__(TRSM_IB) void trtri_diag_kernel(const T *__restrict__ Lp, idx_t lrs, idx_t lcs, int n, int unit,
+							       T *__restrict__ W)
+{
+	// W block b: column major TRSM_IB x TRSM_IB, lower triangular inverse of L[b*IB .., b*IB ..] (zeros above)
+	__shared__ T Ws[TRSM_IB * TRSM_IB]; // Ws[j * IB + c]: entry j of column c (thread c owns column c)
+	const int b = blockIdx.x, c = threadIdx.x;
+	const int r0 = b * TRSM_IB;
+	const int nb = min(TRSM_IB, n - r0);
+	const T *Lb = Lp + (idx_t) r0 * lrs + (idx_t) r0 * lcs;
+	// solve L w = e_c by forward substitution; w_j = 0 for j < c falls out of the recurrence
+	for (int i = 0; i < nb; ++i) {
+		T s = i == c ? (T) 1 : (T) 0;
+		for (int j = 0; j < i; ++j)
+			s = __builtin_fma(-Lb[(idx_t) i * lrs + (idx_t) j * lcs], Ws[j * TRSM_IB + c], s); // L entry is wave-uniform
+		if (!unit)
+			s = s * ((T) 1 / Lb[(idx_t) i * lrs + (idx_t) i * lcs]);
+		Ws[i * TRSM_IB + c] = c < nb ? s : (T) 0;
+	}
+	__syncthreads();
+	T *Wb = W + (size_t) b * TRSM_IB * TRSM_IB;
+	for (int e = c; e < TRSM_IB * TRSM_IB; e += TRSM_IB) {
+		const int i = e % TRSM_IB, col = e / TRSM_IB;
+		Wb[e] = (i < nb && col < nb) ? Ws[i * TRSM_IB + col] : (T) 0;
+	}
+}
+
+template <typename T> static void trsm_inv_rec(MatV<const T> L, MatV<T> X, const T *W, idx_t b0)
+{
+	const idx_t n = L.nrows, k = X.ncols;
+	if (n <= TRSM_IB) {
+		MatV<const T> Winv{W + (size_t) b0 * TRSM_IB * TRSM_IB, n, n, 1, TRSM_IB};
+		GemmExtra<T> ex;
+		ex.force_big = true; // one tile along the aliased dimension => in-place is safe
+		gemm_dev<T>(X, DST_FULL, false, Winv, X.c(), (T) 1, &ex);
+		return;
+	}
+	const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
+	const idx_t top = (nblk / 2) * TRSM_IB;
+	MatV<T> Xt = X.sub(0, 0, top, k), Xb = X.sub(top, 0, n - top, k);
+	trsm_inv_rec<T>(L.sub(0, 0, top, top), Xt, W, b0);
+	gemm_dev<T>(Xb, DST_FULL, true, L.sub(top, 0, n - top, top), Xt.c(), (T) -1);
+	trsm_inv_rec<T>(L.sub(top, top, n - top, n - top), Xb, W, b0 + top / TRSM_IB);
+}
+
 // triangular_solve.rs:200-215
 static idx_t trsm_block_size(idx_t n)
 {
@@ -108,6 +161,15 @@ template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X)
 	const idx_t n = L.nrows, k = X.ncols;
 	if (n == 0 || k == 0)
 		return;
+	if (n > 64 && k >= 256) {
+		const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
+		Scratch wb((size_t) nblk * TRSM_IB * TRSM_IB * sizeof(T));
+		hipLaunchKernelGGL(trtri_diag_kernel<T>, dim3((unsigned) nblk), dim3(TRSM_IB), 0, ctx().stream, L.p, L.rs, L.cs,
+				   (int) n, unit ? 1 : 0, wb.as<T>());
+		FH_HIP(hipGetLastError());
+		trsm_inv_rec<T>(L, X, wb.as<T>(), 0);
+		return;
+	}
 	if (n <= 64) {
 		auto ab = [](idx_t v) { return v < 0 ? -v : v; };
 		const int along_rhs = ab(X.cs) <= ab(X.rs) ? 1 : 0;

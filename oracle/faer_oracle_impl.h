@@ -397,24 +397,48 @@ long FN(oracle_lu_in_place)(T *a, long m, long n, long rs, long cs, long *perm, 
 }
 
 /* ---------------------------------------------------------------- norm_l2 */
-/* reductions/norm_l2.rs:6-45,173-184: three scaled accumulators; the
- * pairwise splitting (:46-82) only changes rounding, not semantics. */
+/* reductions/norm_l2.rs:6-45 (base: scaled accumulators sml/med/big), :46-62 (pairwise splitting at
+ * next_power_of_two((n + 1) / 2) above LINEAR_IMPL_THRESHOLD = 128, reductions/mod.rs:1), :173-184 (selection).
+ * The pairwise tree is what keeps a 1e7-long column within 1e-14 (test_norm_l2, norm_l2.rs:216-218); the
+ * lane order inside a <= 128 element leaf is the SIMD width's and is not pinned by the reference. */
+static void FN(norm_l2_x3_rec)(const T *x, long n, long stride, T sml, T big, T acc[3])
+{
+	if (n <= 128) {
+		T a_sml = 0, a_med = 0, a_big = 0;
+		for (long i = 0; i < n; i++) {
+			T v = x[i * stride];
+			a_sml = FMA(v * sml, v * sml, a_sml);
+			a_med = FMA(v, v, a_med);
+			a_big = FMA(v * big, v * big, a_big);
+		}
+		acc[0] = a_sml;
+		acc[1] = a_med;
+		acc[2] = a_big;
+		return;
+	}
+	long half = (n + 1) / 2, split = 1;
+	while (split < half)
+		split <<= 1;
+	T a0[3], a1[3];
+	FN(norm_l2_x3_rec)(x, split, stride, sml, big, a0);
+	FN(norm_l2_x3_rec)(x + split * stride, n - split, stride, sml, big, a1);
+	acc[0] = a0[0] + a1[0];
+	acc[1] = a0[1] + a1[1];
+	acc[2] = a0[2] + a1[2];
+}
+
 T FN(oracle_norm_l2)(const T *x, long n, long stride)
 {
 	T sml = SQRT(TMIN), big = SQRT(TMAX);
-	T a_sml = 0, a_med = 0, a_big = 0;
-	for (long i = 0; i < n; i++) {
-		T v = x[i * stride];
-		a_sml = FMA(v * sml, v * sml, a_sml);
-		a_med = FMA(v, v, a_med);
-		a_big = FMA(v * big, v * big, a_big);
-	}
-	if (a_sml >= 1)
-		return SQRT(a_sml) * big;
-	else if (a_med >= 1)
-		return SQRT(a_med);
+	T acc[3] = {0, 0, 0};
+	if (n > 0)
+		FN(norm_l2_x3_rec)(x, n, stride, sml, big, acc);
+	if (acc[0] >= 1)
+		return SQRT(acc[0]) * big;
+	else if (acc[1] >= 1)
+		return SQRT(acc[1]);
 	else
-		return SQRT(a_big) * sml;
+		return SQRT(acc[2]) * sml;
 }
 
 /* ------------------------------------------------------------ Householder */

@@ -315,3 +315,25 @@ def test_f32_paths(oracle):
     assert oracle.llt_in_place(l)[0] == "ok"
     L = np.tril(l)
     assert np.abs(L @ L.T - s).max() < 1e-3
+
+
+def test_norm_l2_reference_accuracy_kat(oracle):
+    """reductions/norm_l2.rs:216-218 (test_norm_l2): a 1e7-long column of 0.3 within 1e-14 of sqrt(0.09e7); this
+    is what pins the pairwise summation tree (a sequential fp sum fails it)."""
+    x = np.full(10_000_000, 0.3)
+    target = np.sqrt(0.3 * 0.3 * 10_000_000.0)
+    got = oracle.norm_l2(x)
+    assert abs(got - target) / max(abs(got), target) < 1e-14
+    for (m, n) in [(9, 10), (1023, 5), (42, 1)]:
+        for factor in [0.0, 1.0, 1e30, 1e250, 1e-30, 1e-250]:
+            mat = np.array([[factor * (i + j) for j in range(n)] for i in range(m)], dtype=np.float64)
+            for j in range(n):
+                col = np.ascontiguousarray(mat[:, j])
+                tgt = 0.0
+                for v in col:
+                    tgt = np.hypot(v, tgt)
+                r = oracle.norm_l2(col)
+                if factor == 0.0:
+                    assert r == tgt
+                else:
+                    assert abs(r - tgt) / max(abs(r), abs(tgt)) < 1e-14
