@@ -151,7 +151,10 @@ template <typename T> struct GemmExtra {
 	idx_t diag_stride = 0;
 	int a_struct = 0, b_struct = 0; // FaerBlock codes of the operands (triangular products)
 	bool dst_strict = false;	// with DST_LOWER / DST_UPPER: leave the diagonal untouched
-	bool force_big = false;		// use the 128x128 tile regardless of the grid size (in-place products)
+	// in-place product dst = alpha * A * B with dst aliasing an operand whose other factor is a square
+	// K x K (K <= 128) matrix: 1 = B aliases dst (dst = S * dst), 2 = A aliases dst (dst = dst * S).
+	// (The value refers to the operands as passed; gemm_dev swaps it when it transposes the problem.)
+	int inplace = 0;
 };
 
 // dst(kind) <- [dst +] alpha * A * diag * B        (gemm.hip)

@@ -358,6 +358,318 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 }
 
 // ------------------------------------------------------------------------------------------------
+// Software-pipelined variant of the dense kernel (no triangular operands / diag): same tiles, same LDS
+// images, same epilogue as gemm_kernel above, but the K loop is written as ONE dense MFMA stream per wave:
+//   * MFMA fragments are double buffered in registers: the ds_reads of k-step kk+1 are issued before the
+//     16 (4) MFMAs of k-step kk, so no MFMA waits on an LDS round trip;
+//   * the global loads of tile t+1 are spread over the MFMAs of k-step 0, the LDS stores of tile t+1 over
+//     the MFMAs of the last k-step (a v_mfma_f64_16x16x4 holds the pipe for 64 cycles = 16 issue slots, so
+//     one memory instruction per MFMA is free);
+//   * per-thread running pointers replace the per-load 64-bit stride multiplications;
+//   * the only bubble left per K tile is  barrier -> first fragment read of the next tile, which the
+//     second workgroup on the CU (2 waves per SIMD) covers.
+// sched_group_barrier pins the interleave (cdna_hip_programming.md T19); it is a scheduling hint only.
+// ------------------------------------------------------------------------------------------------
+#define FH_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+// compile-time unrolled interleave pattern for one k-step of NMMA MFMAs (the builtin needs constants):
+// KIND 0: MFMA + fragment ds_read + global loads; KIND 1: MFMA + fragment ds_read; KIND 2: MFMA + LDS stores
+template <int I, int NMMA, int NFR, int NLD, int KIND> struct SgbStep {
+	static __device__ __forceinline__ void run()
+	{
+		if constexpr (I < NMMA) {
+			FH_SGB(0x008, 1);
+			if constexpr (KIND != 2 && I < NFR)
+				FH_SGB(0x100, 1);
+			constexpr int CNT = (I + 1) * NLD / NMMA - I * NLD / NMMA;
+			if constexpr (KIND == 0 && CNT > 0)
+				FH_SGB(0x020, CNT);
+			if constexpr (KIND == 2 && CNT > 0)
+				FH_SGB(0x200, CNT);
+			SgbStep<I + 1, NMMA, NFR, NLD, KIND>::run();
+		}
+	}
+};
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool AKM, bool BKM>
+__global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kernel_p(const GemmArgs<T> g)
+{
+	constexpr int NT = WM * WN * 64;
+	constexpr int WTM = BM / WM, WTN = BN / WN; // wave tile
+	constexpr int TM = WTM / 16, TN = WTN / 16;
+	constexpr int SA = AKM ? BK + 2 : BM + 16; // LDS pitch (elements)
+	constexpr int SB = BKM ? BK + 2 : BN + 16;
+	constexpr int A_SZ = AKM ? BM * SA : BK * SA;
+	constexpr int B_SZ = BKM ? BN * SB : BK * SB;
+	constexpr int A_CNT = BM * BK / NT, B_CNT = BN * BK / NT; // elements per thread per tile
+	static_assert(BM * BK % NT == 0 && BN * BK % NT == 0, "tile/threads");
+	static_assert(NT % BM == 0 || AKM, "MN loader needs NT % BM == 0");
+	static_assert(NT % BN == 0 || BKM, "MN loader needs NT % BN == 0");
+	static_assert(NT % BK == 0 && BK == 16, "K loader needs NT % BK == 0");
+	typedef typename Mfma<T>::acc_t acc_t;
+
+	__shared__ T smem[2 * (A_SZ + B_SZ)];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int wm = wave % WM, wn = wave / WM;
+	const int l15 = lane & 15, lhi = lane >> 4;
+
+	// ---- tile coordinates (same mapping as gemm_kernel)
+	int tm, tn;
+	{
+		const int nblocks = gridDim.x;
+		const int pid = xcd_remap(blockIdx.x, nblocks);
+		if (g.tri_enum) {
+			int i = (int) ((sqrtf(8.0f * (float) pid + 1.0f) - 1.0f) * 0.5f);
+			while ((i + 1) * (i + 2) / 2 <= pid)
+				++i;
+			while (i * (i + 1) / 2 > pid)
+				--i;
+			tm = i;
+			tn = pid - i * (i + 1) / 2;
+		} else {
+			constexpr int G = 8;
+			const int per_group = G * g.ntn;
+			const int grp = pid / per_group;
+			const int first_m = grp * G;
+			const int gsz = min(g.ntm - first_m, G);
+			const int rem = pid - grp * per_group;
+			tm = first_m + rem % gsz;
+			tn = rem / gsz;
+		}
+	}
+	const int m_off = tm * BM, n_off = tn * BN;
+	if (g.lower && m_off + BM - 1 < n_off)
+		return; // tile entirely above the diagonal
+
+	const int k_begin = blockIdx.z * g.k_per_split;
+	const int k_end = min(g.K, k_begin + g.k_per_split);
+	const bool k_empty = k_begin >= k_end;
+	if (k_empty && (g.add || g.atomic))
+		return;
+
+	// ---- loader state (see gemm_kernel).  MN-major: one mn, A_CNT k's; K-major: one k, A_CNT mn's.
+	constexpr int A_KSTEP = AKM ? 0 : NT / BM, A_MSTEP = AKM ? NT / BK : 0;
+	constexpr int B_KSTEP = BKM ? 0 : NT / BN, B_NSTEP = BKM ? NT / BK : 0;
+	const int a_mn = AKM ? tid / BK : tid % BM;
+	const int a_k = AKM ? tid % BK : tid / BM;
+	const int b_mn = BKM ? tid / BK : tid % BN;
+	const int b_k = BKM ? tid % BK : tid / BN;
+	const int a_mn0 = m_off + a_mn, b_mn0 = n_off + b_mn;
+
+	T ra[A_CNT], rb[B_CNT];
+	unsigned amask = 0, bmask = 0;
+	unsigned a_mnmask = 0, b_mnmask = 0;
+#pragma unroll
+	for (int i = 0; i < A_CNT; ++i)
+		a_mnmask |= (unsigned) (a_mn0 + (AKM ? i * A_MSTEP : 0) < g.M) << i;
+#pragma unroll
+	for (int i = 0; i < B_CNT; ++i)
+		b_mnmask |= (unsigned) (b_mn0 + (BKM ? i * B_NSTEP : 0) < g.N) << i;
+
+	// running pointers: element (first mn, k_tile + first k) of the current tile
+	const T *pa = g.a + (AKM ? (idx_t) 0 : (idx_t) min(a_mn0, g.M - 1) * g.ars) + (idx_t) (k_begin + a_k) * g.acs;
+	const T *pb = g.b + (BKM ? (idx_t) 0 : (idx_t) min(b_mn0, g.N - 1) * g.bcs) + (idx_t) (k_begin + b_k) * g.brs;
+	const idx_t a_tile_step = (idx_t) BK * g.acs, b_tile_step = (idx_t) BK * g.brs;
+	const idx_t a_kstep = (idx_t) A_KSTEP * g.acs, b_kstep = (idx_t) B_KSTEP * g.brs; // wave uniform
+
+	// full tile: no k checks
+	auto load_a = [&]() {
+		amask = a_mnmask;
+#pragma unroll
+		for (int i = 0; i < A_CNT; ++i) {
+			const T *p = AKM ? pa + (idx_t) min(a_mn0 + i * A_MSTEP, g.M - 1) * g.ars : pa + (idx_t) i * a_kstep;
+			ra[i] = *p;
+		}
+	};
+	auto load_b = [&]() {
+		bmask = b_mnmask;
+#pragma unroll
+		for (int i = 0; i < B_CNT; ++i) {
+			const T *p = BKM ? pb + (idx_t) min(b_mn0 + i * B_NSTEP, g.N - 1) * g.bcs : pb + (idx_t) i * b_kstep;
+			rb[i] = *p;
+		}
+	};
+	// last (possibly partial) tile starting at k0: k >= k_end is clamped to k_end - 1 and masked
+	auto load_a_tail = [&](int k0) {
+		amask = a_mnmask;
+#pragma unroll
+		for (int i = 0; i < A_CNT; ++i) {
+			const int k = k0 + a_k + (AKM ? 0 : i * A_KSTEP);
+			const int back = max(k - (k_end - 1), 0);
+			if (back > 0)
+				amask &= ~(1u << i);
+			const T *p = AKM ? pa + (idx_t) min(a_mn0 + i * A_MSTEP, g.M - 1) * g.ars : pa + (idx_t) i * a_kstep;
+			ra[i] = *(p - (idx_t) back * g.acs);
+		}
+	};
+	auto load_b_tail = [&](int k0) {
+		bmask = b_mnmask;
+#pragma unroll
+		for (int i = 0; i < B_CNT; ++i) {
+			const int k = k0 + b_k + (BKM ? 0 : i * B_KSTEP);
+			const int back = max(k - (k_end - 1), 0);
+			if (back > 0)
+				bmask &= ~(1u << i);
+			const T *p = BKM ? pb + (idx_t) min(b_mn0 + i * B_NSTEP, g.N - 1) * g.bcs : pb + (idx_t) i * b_kstep;
+			rb[i] = *(p - (idx_t) back * g.brs);
+		}
+	};
+	auto store_a = [&](T *sa) {
+#pragma unroll
+		for (int i = 0; i < A_CNT; ++i) {
+			const T v = (amask >> i) & 1u ? ra[i] : (T) 0;
+			if (AKM)
+				sa[(a_mn + i * A_MSTEP) * SA + a_k] = v;
+			else
+				sa[(a_k + i * A_KSTEP) * SA + a_mn] = v;
+		}
+	};
+	auto store_b = [&](T *sb) {
+#pragma unroll
+		for (int i = 0; i < B_CNT; ++i) {
+			const T v = (bmask >> i) & 1u ? rb[i] : (T) 0;
+			if (BKM)
+				sb[(b_mn + i * B_NSTEP) * SB + b_k] = v;
+			else
+				sb[(b_k + i * B_KSTEP) * SB + b_mn] = v;
+		}
+	};
+
+	acc_t acc[TM][TN];
+#pragma unroll
+	for (int i = 0; i < TM; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+			acc[i][j] = (acc_t) (T) 0;
+
+	// fragment double buffer
+	T fa[2][TM], fb[2][TN];
+	const int a_frag_off = AKM ? (wm * WTM + l15) * SA + lhi : lhi * SA + wm * WTM + l15;
+	const int b_frag_off = BKM ? (wn * WTN + l15) * SB + lhi : lhi * SB + wn * WTN + l15;
+	auto read_frag = [&](const T *st, int kk, int buf) {
+		const T *sa = st + a_frag_off + (AKM ? kk * 4 : kk * 4 * SA);
+		const T *sb = st + A_SZ + b_frag_off + (BKM ? kk * 4 : kk * 4 * SB);
+#pragma unroll
+		for (int i = 0; i < TM; ++i)
+			fa[buf][i] = sa[AKM ? i * 16 * SA : i * 16];
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+			fb[buf][j] = sb[BKM ? j * 16 * SB : j * 16];
+	};
+	auto mma = [&](int buf) {
+#pragma unroll
+		for (int i = 0; i < TM; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = Mfma<T>::run(fb[buf][j], fa[buf][i], acc[i][j]);
+	};
+	constexpr int NMMA = TM * TN;	  // MFMAs per k-step
+	constexpr int NFR = TM + TN;	  // fragment ds_reads per k-step
+	constexpr int NLD = A_CNT + B_CNT; // global loads / LDS stores per tile
+
+	const int nk = k_empty ? 0 : (k_end - k_begin + BK - 1) / BK;
+	constexpr int STAGE = A_SZ + B_SZ;
+	if (nk > 0) {
+		if (nk == 1) {
+			load_a_tail(k_begin);
+			load_b_tail(k_begin);
+		} else {
+			load_a();
+			load_b();
+		}
+		store_a(smem);
+		store_b(smem + A_SZ);
+	}
+	__syncthreads();
+	if (nk > 0)
+		read_frag(smem, 0, 0);
+	int kt = 0;
+	for (; kt + 2 < nk; ++kt) { // tile kt+1 is full
+		const T *cur = smem + (kt & 1) * STAGE;
+		T *nxt = smem + ((kt + 1) & 1) * STAGE;
+		pa += a_tile_step;
+		pb += b_tile_step;
+		load_a();
+		load_b();
+		read_frag(cur, 1, 1);
+		mma(0);
+		// k-step 0: one global load per MFMA, the fragment reads of k-step 1 up front
+		SgbStep<0, NMMA, NFR, NLD, 0>::run();
+		read_frag(cur, 2, 0);
+		mma(1);
+		SgbStep<0, NMMA, NFR, NLD, 1>::run();
+		read_frag(cur, 3, 1);
+		mma(0);
+		SgbStep<0, NMMA, NFR, NLD, 1>::run();
+		store_a(nxt);
+		store_b(nxt + A_SZ);
+		mma(1);
+		// last k-step: the LDS stores of the next tile ride behind the MFMAs
+		SgbStep<0, NMMA, NFR, NLD, 2>::run();
+		__syncthreads();
+		read_frag(nxt, 0, 0);
+	}
+	if (kt + 1 < nk) { // tile kt+1 is the last one (k-checked loads)
+		const T *cur = smem + (kt & 1) * STAGE;
+		T *nxt = smem + ((kt + 1) & 1) * STAGE;
+		pa += a_tile_step;
+		pb += b_tile_step;
+		load_a_tail(k_begin + (kt + 1) * BK);
+		load_b_tail(k_begin + (kt + 1) * BK);
+		read_frag(cur, 1, 1);
+		mma(0);
+		read_frag(cur, 2, 0);
+		mma(1);
+		read_frag(cur, 3, 1);
+		mma(0);
+		store_a(nxt);
+		store_b(nxt + A_SZ);
+		mma(1);
+		__syncthreads();
+		read_frag(nxt, 0, 0);
+		++kt;
+	}
+	if (nk > 0) {
+		const T *cur = smem + (kt & 1) * STAGE;
+		read_frag(cur, 1, 1);
+		mma(0);
+		read_frag(cur, 2, 0);
+		mma(1);
+		read_frag(cur, 3, 1);
+		mma(0);
+		mma(1);
+	}
+
+	// ---- epilogue (identical to gemm_kernel)
+#pragma unroll
+	for (int j = 0; j < TN; ++j)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int n = n_off + wn * WTN + j * 16 + Mfma<T>::row(r, lhi);
+			if (n >= g.N)
+				continue;
+			const idx_t ncol = g.col_idx ? load_idx(g.col_idx, g.idx64, n) : (idx_t) n;
+#pragma unroll
+			for (int i = 0; i < TM; ++i) {
+				const int m = m_off + wm * WTM + i * 16 + l15;
+				if (m >= g.M || (g.lower && (m < n || (g.dst_strict && m == n))))
+					continue;
+				const idx_t mrow = g.row_idx ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
+				T *p = g.dst + mrow * g.drs + ncol * g.dcs;
+				const T v = acc[i][j][r];
+				if (g.atomic)
+					atomicAdd(p, g.alpha * v);
+				else if (g.add)
+					*p = __builtin_fma(g.alpha, v, *p);
+				else
+					*p = g.alpha * v;
+			}
+		}
+}
+
+// ------------------------------------------------------------------------------------------------
 // zero / constant fill restricted to a DstKind (K == 0 with Replace, split-K pre-zero)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -422,6 +734,25 @@ static void launch_cfg(const GemmArgs<T> &g, bool akm, bool bkm, int splits)
 	FH_HIP(hipGetLastError());
 }
 
+// software-pipelined dense kernel (gemm_kernel_p)
+template <typename T, int BM, int BN, int WM, int WN> static void launch_cfg_p(const GemmArgs<T> &g, bool akm, bool bkm, int splits)
+{
+	constexpr int BK = 16;
+	constexpr int NT = WM * WN * 64;
+	int nblocks = g.tri_enum ? g.ntm * (g.ntm + 1) / 2 : g.ntm * g.ntn;
+	dim3 grid((unsigned) nblocks, 1, (unsigned) splits), block(NT);
+	hipStream_t s = ctx().stream;
+	if (akm && bkm)
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, true>), grid, block, 0, s, g);
+	else if (akm && !bkm)
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, false>), grid, block, 0, s, g);
+	else if (!akm && bkm)
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, true>), grid, block, 0, s, g);
+	else
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, false>), grid, block, 0, s, g);
+	FH_HIP(hipGetLastError());
+}
+
 template <typename T>
 void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> B, T alpha, const GemmExtra<T> *extra)
 {
@@ -448,6 +779,8 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		A = At;
 		B = Bt;
 		std::swap(ex.row_idx, ex.col_idx);
+		if (ex.inplace)
+			ex.inplace = 3 - ex.inplace; // the aliased operand changes sides with the transposition
 		std::swap(m, n);
 		static const int tr[7] = {0, 2, 1, 4, 3, 6, 5}; // FaerBlock of the transposed operand
 		const int as = tr[ex.b_struct], bs = tr[ex.a_struct];
@@ -489,19 +822,44 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	const bool akm = iabs(A.cs) == 1 && iabs(A.rs) != 1;
 	const bool bkm = iabs(B.rs) == 1 && iabs(B.cs) != 1;
 
-	// tile config: big tiles once the grid fills the chip (256 CUs x 2 workgroups), else 64x64
-	int variant = ctx().gemm_variant;
+	// tile config.  ctx().gemm_variant: 0 = auto (pipelined kernels); 1 / 2 = force 128 / 64 tiles (pipelined);
+	// 11 / 12 = force 128 / 64 tiles on the non-pipelined kernel (A/B measurements).
+	// Measured on MI355X (profiles/r01_call2_gemm_variants.txt): the pipelined 128 x 128 tile is ahead of the
+	// 64 x 64 tile from N = 2048 (256 big tiles) upwards and 12 % ahead at N = 8192; below that the small tile
+	// gives the 256 CUs more workgroups.
+	const int variant = ctx().gemm_variant;
 	const idx_t tiles128 = ((m + 127) / 128) * ((n + 127) / 128) / (kind == DST_LOWER ? 2 : 1);
-	bool big = variant == 1 || (variant == 0 && tiles128 >= 384);
-	if (variant == 2)
-		big = false;
-	if (ex.force_big)
+	bool big = tiles128 >= 256;
+	if (variant == 1 || variant == 11)
 		big = true;
-	if (extra_path)
+	if (variant == 2 || variant == 12)
 		big = false;
-	const int bm = big ? 128 : 64;
+	const bool legacy = variant >= 10;
+	// in-place product (ex.inplace): the aliased operand and dst share rows (transposed orientation: A and C
+	// share their rows, one tile must cover all of N) or columns (B and C share their columns, one tile must
+	// cover all of M).  A 32-wide tile along the free dimension keeps the launch wide for skinny panels.
+	int bm = big ? 128 : 64, bn = bm;
+	int shape = big ? 0 : 1; // 0: 128x128  1: 64x64  2: 32x128  3: 128x32
+	if (ex.inplace) {
+		FH_CHECK(!extra_path && kind == DST_FULL && !indexed, "gemm: in-place product must be a plain one");
+		if (ex.inplace == 2) { // A aliases C: all of N inside one tile
+			FH_CHECK(n <= 128 && k == n, "gemm: in-place (A) product needs N == K <= 128");
+			bm = 32;
+			bn = 128;
+			shape = 2;
+		} else { // B aliases C: all of M inside one tile
+			FH_CHECK(m <= 128 && k == m, "gemm: in-place (B) product needs M == K <= 128");
+			bm = 128;
+			bn = 32;
+			shape = 3;
+		}
+	}
+	if (extra_path) {
+		bm = bn = 64;
+		shape = 1;
+	}
 	g.ntm = (int) ((m + bm - 1) / bm);
-	g.ntn = (int) ((n + bm - 1) / bm);
+	g.ntn = (int) ((n + bn - 1) / bn);
 	g.tri_enum = (g.lower && m == n) ? 1 : 0;
 
 	// split-K for few-tile / deep-K products
@@ -527,12 +885,22 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		g.atomic = 1;
 	}
 
+	if (ex.inplace)
+		FH_CHECK(splits == 1, "gemm: in-place product cannot be split along K");
 	if (extra_path)
 		launch_cfg<T, 64, 64, 2, 2, true>(g, akm, bkm, splits); // triangular operands / diag scaling
-	else if (big)
+	else if (shape == 2)
+		launch_cfg_p<T, 32, 128, 1, 4>(g, akm, bkm, splits);
+	else if (shape == 3)
+		launch_cfg_p<T, 128, 32, 4, 1>(g, akm, bkm, splits);
+	else if (legacy && big)
 		launch_cfg<T, 128, 128, 2, 2, false>(g, akm, bkm, splits);
-	else
+	else if (legacy)
 		launch_cfg<T, 64, 64, 2, 2, false>(g, akm, bkm, splits);
+	else if (big)
+		launch_cfg_p<T, 128, 128, 2, 2>(g, akm, bkm, splits);
+	else
+		launch_cfg_p<T, 64, 64, 2, 2>(g, akm, bkm, splits);
 }
 
 // faer/src/linalg/matmul/triangular.rs:1246-1495: only the structured part of each operand is accessed

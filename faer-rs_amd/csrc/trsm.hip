@@ -127,7 +127,7 @@ template <typename T> static void trsm_inv_rec(MatV<const T> L, MatV<T> X, const
 	if (n <= TRSM_IB) {
 		MatV<const T> Winv{W + (size_t) b0 * TRSM_IB * TRSM_IB, n, n, 1, TRSM_IB};
 		GemmExtra<T> ex;
-		ex.force_big = true; // one tile along the aliased dimension => in-place is safe
+		ex.inplace = 1; // X (the rhs operand) aliases dst; n <= 128 rows => one tile along the aliased dimension
 		gemm_dev<T>(X, DST_FULL, false, Winv, X.c(), (T) 1, &ex);
 		return;
 	}

@@ -33,7 +33,7 @@ if "gemm" in which:
         for n in (2048, 4096, 8192):
             a, b = colmajor(n, n, dtype, 1), colmajor(n, n, dtype, 2)
             c = torch.empty((n, n), dtype=dtype, device="cuda").t()
-            for variant in (1, 2):
+            for variant in (1, 2, 11, 12):
                 L.faer_hip_set_gemm_variant(variant)
                 ms = L.faer_hip_time_gemm_ms(C.c_int(dt), C.c_size_t(n), C.c_size_t(n), C.c_size_t(n), C.c_void_p(c.data_ptr()),
                                              C.c_ssize_t(n), C.c_void_p(a.data_ptr()), C.c_ssize_t(n),
