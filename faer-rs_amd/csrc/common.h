@@ -172,6 +172,8 @@ void matmul_triangular_dev(MatV<T> C, int c_s, bool add, MatV<const T> A, int a_
 // X <- op(T)^-1 X, T lower triangular n x n, X n x k (trsm.hip); upper handled by reversal
 template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X);
 template <typename T> void trsm_upper_dev(MatV<const T> U, bool unit, MatV<T> X);
+// same as trsm_lower_dev (non unit) with the inverses of L's 128 x 128 diagonal blocks precomputed in W
+template <typename T> void trsm_lower_pre_dev(MatV<const T> L, MatV<T> X, const T *W);
 
 // in-place lower Cholesky; returns >=0 regularization count or -(index+1)   (potrf.hip)
 template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps);

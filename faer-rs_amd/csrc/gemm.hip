@@ -24,28 +24,9 @@
 #include <type_traits>
 
 #include "common.h"
+#include "mfma.h"
 
 namespace fh {
-
-template <typename T> struct Mfma;
-template <> struct Mfma<double> {
-	typedef double acc_t __attribute__((ext_vector_type(4)));
-	static __device__ __forceinline__ acc_t run(double a, double b, acc_t c)
-	{
-		return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-	}
-	// f64 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
-	static __device__ __forceinline__ int row(int r, int lhi) { return lhi + 4 * r; }
-};
-template <> struct Mfma<float> {
-	typedef float acc_t __attribute__((ext_vector_type(4)));
-	static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
-	{
-		return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-	}
-	// f32 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg
-	static __device__ __forceinline__ int row(int r, int lhi) { return lhi * 4 + r; }
-};
 
 template <typename T> struct GemmArgs {
 	int M, N, K;
@@ -391,7 +372,7 @@ template <int I, int NMMA, int NFR, int NLD, int KIND> struct SgbStep {
 	}
 };
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, bool AKM, bool BKM>
+template <typename T, int BM, int BN, int BK, int WM, int WN, bool AKM, bool BKM, int PF>
 __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kernel_p(const GemmArgs<T> g)
 {
 	constexpr int NT = WM * WN * 64;
@@ -458,8 +439,11 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 	const int b_k = BKM ? tid % BK : tid / BN;
 	const int a_mn0 = m_off + a_mn, b_mn0 = n_off + b_mn;
 
-	T ra[A_CNT], rb[B_CNT];
-	unsigned amask = 0, bmask = 0;
+	// PF register sets: tile t + PF is in flight from HBM while tile t is multiplied (PF = 1 for the
+	// 128 x 128 tile whose accumulators need the registers; deeper for the small tiles, whose launches are
+	// short and latency bound: one HBM round trip per K tile would otherwise dominate them)
+	T ra[PF][A_CNT], rb[PF][B_CNT];
+	unsigned amask[PF], bmask[PF];
 	unsigned a_mnmask = 0, b_mnmask = 0;
 #pragma unroll
 	for (int i = 0; i < A_CNT; ++i)
@@ -475,61 +459,61 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 	const idx_t a_kstep = (idx_t) A_KSTEP * g.acs, b_kstep = (idx_t) B_KSTEP * g.brs; // wave uniform
 
 	// full tile: no k checks
-	auto load_a = [&]() {
-		amask = a_mnmask;
+	auto load_a = [&](T (&ra_)[A_CNT], unsigned &amask_) {
+		amask_ = a_mnmask;
 #pragma unroll
 		for (int i = 0; i < A_CNT; ++i) {
 			const T *p = AKM ? pa + (idx_t) min(a_mn0 + i * A_MSTEP, g.M - 1) * g.ars : pa + (idx_t) i * a_kstep;
-			ra[i] = *p;
+			ra_[i] = *p;
 		}
 	};
-	auto load_b = [&]() {
-		bmask = b_mnmask;
+	auto load_b = [&](T (&rb_)[B_CNT], unsigned &bmask_) {
+		bmask_ = b_mnmask;
 #pragma unroll
 		for (int i = 0; i < B_CNT; ++i) {
 			const T *p = BKM ? pb + (idx_t) min(b_mn0 + i * B_NSTEP, g.N - 1) * g.bcs : pb + (idx_t) i * b_kstep;
-			rb[i] = *p;
+			rb_[i] = *p;
 		}
 	};
 	// last (possibly partial) tile starting at k0: k >= k_end is clamped to k_end - 1 and masked
-	auto load_a_tail = [&](int k0) {
-		amask = a_mnmask;
+	auto load_a_tail = [&](T (&ra_)[A_CNT], unsigned &amask_, int k0) {
+		amask_ = a_mnmask;
 #pragma unroll
 		for (int i = 0; i < A_CNT; ++i) {
 			const int k = k0 + a_k + (AKM ? 0 : i * A_KSTEP);
 			const int back = max(k - (k_end - 1), 0);
 			if (back > 0)
-				amask &= ~(1u << i);
+				amask_ &= ~(1u << i);
 			const T *p = AKM ? pa + (idx_t) min(a_mn0 + i * A_MSTEP, g.M - 1) * g.ars : pa + (idx_t) i * a_kstep;
-			ra[i] = *(p - (idx_t) back * g.acs);
+			ra_[i] = *(p - (idx_t) back * g.acs);
 		}
 	};
-	auto load_b_tail = [&](int k0) {
-		bmask = b_mnmask;
+	auto load_b_tail = [&](T (&rb_)[B_CNT], unsigned &bmask_, int k0) {
+		bmask_ = b_mnmask;
 #pragma unroll
 		for (int i = 0; i < B_CNT; ++i) {
 			const int k = k0 + b_k + (BKM ? 0 : i * B_KSTEP);
 			const int back = max(k - (k_end - 1), 0);
 			if (back > 0)
-				bmask &= ~(1u << i);
+				bmask_ &= ~(1u << i);
 			const T *p = BKM ? pb + (idx_t) min(b_mn0 + i * B_NSTEP, g.N - 1) * g.bcs : pb + (idx_t) i * b_kstep;
-			rb[i] = *(p - (idx_t) back * g.brs);
+			rb_[i] = *(p - (idx_t) back * g.brs);
 		}
 	};
-	auto store_a = [&](T *sa) {
+	auto store_a = [&](T *sa, const T (&ra_)[A_CNT], unsigned amask_) {
 #pragma unroll
 		for (int i = 0; i < A_CNT; ++i) {
-			const T v = (amask >> i) & 1u ? ra[i] : (T) 0;
+			const T v = (amask_ >> i) & 1u ? ra_[i] : (T) 0;
 			if (AKM)
 				sa[(a_mn + i * A_MSTEP) * SA + a_k] = v;
 			else
 				sa[(a_k + i * A_KSTEP) * SA + a_mn] = v;
 		}
 	};
-	auto store_b = [&](T *sb) {
+	auto store_b = [&](T *sb, const T (&rb_)[B_CNT], unsigned bmask_) {
 #pragma unroll
 		for (int i = 0; i < B_CNT; ++i) {
-			const T v = (bmask >> i) & 1u ? rb[i] : (T) 0;
+			const T v = (bmask_ >> i) & 1u ? rb_[i] : (T) 0;
 			if (BKM)
 				sb[(b_mn + i * B_NSTEP) * SB + b_k] = v;
 			else
@@ -571,75 +555,132 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 
 	const int nk = k_empty ? 0 : (k_end - k_begin + BK - 1) / BK;
 	constexpr int STAGE = A_SZ + B_SZ;
-	if (nk > 0) {
-		if (nk == 1) {
-			load_a_tail(k_begin);
-			load_b_tail(k_begin);
-		} else {
-			load_a();
-			load_b();
+	if constexpr (PF == 1) {
+		if (nk > 0) {
+			if (nk == 1) {
+				load_a_tail(ra[0], amask[0], k_begin);
+				load_b_tail(rb[0], bmask[0], k_begin);
+			} else {
+				load_a(ra[0], amask[0]);
+				load_b(rb[0], bmask[0]);
+			}
+			store_a(smem, ra[0], amask[0]);
+			store_b(smem + A_SZ, rb[0], bmask[0]);
 		}
-		store_a(smem);
-		store_b(smem + A_SZ);
-	}
-	__syncthreads();
-	if (nk > 0)
-		read_frag(smem, 0, 0);
-	int kt = 0;
-	for (; kt + 2 < nk; ++kt) { // tile kt+1 is full
-		const T *cur = smem + (kt & 1) * STAGE;
-		T *nxt = smem + ((kt + 1) & 1) * STAGE;
-		pa += a_tile_step;
-		pb += b_tile_step;
-		load_a();
-		load_b();
-		read_frag(cur, 1, 1);
-		mma(0);
-		// k-step 0: one global load per MFMA, the fragment reads of k-step 1 up front
-		SgbStep<0, NMMA, NFR, NLD, 0>::run();
-		read_frag(cur, 2, 0);
-		mma(1);
-		SgbStep<0, NMMA, NFR, NLD, 1>::run();
-		read_frag(cur, 3, 1);
-		mma(0);
-		SgbStep<0, NMMA, NFR, NLD, 1>::run();
-		store_a(nxt);
-		store_b(nxt + A_SZ);
-		mma(1);
-		// last k-step: the LDS stores of the next tile ride behind the MFMAs
-		SgbStep<0, NMMA, NFR, NLD, 2>::run();
 		__syncthreads();
-		read_frag(nxt, 0, 0);
-	}
-	if (kt + 1 < nk) { // tile kt+1 is the last one (k-checked loads)
-		const T *cur = smem + (kt & 1) * STAGE;
-		T *nxt = smem + ((kt + 1) & 1) * STAGE;
-		pa += a_tile_step;
-		pb += b_tile_step;
-		load_a_tail(k_begin + (kt + 1) * BK);
-		load_b_tail(k_begin + (kt + 1) * BK);
-		read_frag(cur, 1, 1);
-		mma(0);
-		read_frag(cur, 2, 0);
-		mma(1);
-		read_frag(cur, 3, 1);
-		mma(0);
-		store_a(nxt);
-		store_b(nxt + A_SZ);
-		mma(1);
+		if (nk > 0)
+			read_frag(smem, 0, 0);
+		int kt = 0;
+		for (; kt + 2 < nk; ++kt) { // tile kt+1 is full
+			const T *cur = smem + (kt & 1) * STAGE;
+			T *nxt = smem + ((kt + 1) & 1) * STAGE;
+			pa += a_tile_step;
+			pb += b_tile_step;
+			load_a(ra[0], amask[0]);
+			load_b(rb[0], bmask[0]);
+			read_frag(cur, 1, 1);
+			mma(0);
+			// k-step 0: one global load per MFMA, the fragment reads of k-step 1 up front
+			SgbStep<0, NMMA, NFR, NLD, 0>::run();
+			read_frag(cur, 2, 0);
+			mma(1);
+			SgbStep<0, NMMA, NFR, NLD, 1>::run();
+			read_frag(cur, 3, 1);
+			mma(0);
+			SgbStep<0, NMMA, NFR, NLD, 1>::run();
+			store_a(nxt, ra[0], amask[0]);
+			store_b(nxt + A_SZ, rb[0], bmask[0]);
+			mma(1);
+			// last k-step: the LDS stores of the next tile ride behind the MFMAs
+			SgbStep<0, NMMA, NFR, NLD, 2>::run();
+			__syncthreads();
+			read_frag(nxt, 0, 0);
+		}
+		if (kt + 1 < nk) { // tile kt+1 is the last one (k-checked loads)
+			const T *cur = smem + (kt & 1) * STAGE;
+			T *nxt = smem + ((kt + 1) & 1) * STAGE;
+			pa += a_tile_step;
+			pb += b_tile_step;
+			load_a_tail(ra[0], amask[0], k_begin + (kt + 1) * BK);
+			load_b_tail(rb[0], bmask[0], k_begin + (kt + 1) * BK);
+			read_frag(cur, 1, 1);
+			mma(0);
+			read_frag(cur, 2, 0);
+			mma(1);
+			read_frag(cur, 3, 1);
+			mma(0);
+			store_a(nxt, ra[0], amask[0]);
+			store_b(nxt + A_SZ, rb[0], bmask[0]);
+			mma(1);
+			__syncthreads();
+			read_frag(nxt, 0, 0);
+			++kt;
+		}
+		if (nk > 0) {
+			const T *cur = smem + (kt & 1) * STAGE;
+			read_frag(cur, 1, 1);
+			mma(0);
+			read_frag(cur, 2, 0);
+			mma(1);
+			read_frag(cur, 3, 1);
+			mma(0);
+			mma(1);
+		}
+	} else {
+		// ring of PF register sets; pa / pb always point at the next tile to load (tile index `tl`)
+		int tl = 0;
+		auto load_next = [&](T (&ra_)[A_CNT], unsigned &amask_, T (&rb_)[B_CNT], unsigned &bmask_) {
+			if (tl == nk - 1) { // last tile: k-checked
+				load_a_tail(ra_, amask_, k_begin + tl * BK);
+				load_b_tail(rb_, bmask_, k_begin + tl * BK);
+			} else {
+				load_a(ra_, amask_);
+				load_b(rb_, bmask_);
+			}
+			pa += a_tile_step;
+			pb += b_tile_step;
+			++tl;
+		};
+#pragma unroll
+		for (int d = 0; d < PF; ++d)
+			if (d < nk)
+				load_next(ra[d], amask[d], rb[d], bmask[d]);
+		if (nk > 0) {
+			store_a(smem, ra[0], amask[0]);
+			store_b(smem + A_SZ, rb[0], bmask[0]);
+		}
 		__syncthreads();
-		read_frag(nxt, 0, 0);
-		++kt;
-	}
-	if (nk > 0) {
-		const T *cur = smem + (kt & 1) * STAGE;
-		read_frag(cur, 1, 1);
-		mma(0);
-		read_frag(cur, 2, 0);
-		mma(1);
-		read_frag(cur, 3, 1);
-		mma(0);
-		mma(1);
+		if (nk > 0)
+			read_frag(smem, 0, 0);
+		for (int kt = 0; kt < nk; kt += PF) {
+#pragma unroll
+			for (int d = 0; d < PF; ++d) {
+				const int t = kt + d;
+				if (t < nk) { // block uniform
+					const T *cur = smem + (t & 1) * STAGE;
+					T *nxt = smem + ((t + 1) & 1) * STAGE;
+					// slot d (tile t) already sits in LDS: refill it with tile t + PF
+					if (t + PF < nk)
+						load_next(ra[d], amask[d], rb[d], bmask[d]);
+					read_frag(cur, 1, 1);
+					mma(0);
+					read_frag(cur, 2, 0);
+					mma(1);
+					read_frag(cur, 3, 1);
+					mma(0);
+					if (t + 1 < nk) {
+						const int dn = (d + 1) % PF; // constant after unrolling
+						store_a(nxt, ra[dn], amask[dn]);
+						store_b(nxt + A_SZ, rb[dn], bmask[dn]);
+					}
+					mma(1);
+					if (t + 1 < nk) {
+						__syncthreads();
+						read_frag(nxt, 0, 0);
+					}
+				}
+			}
+		}
 	}
 
 	// ---- epilogue (identical to gemm_kernel)
@@ -738,18 +779,19 @@ static void launch_cfg(const GemmArgs<T> &g, bool akm, bool bkm, int splits)
 template <typename T, int BM, int BN, int WM, int WN> static void launch_cfg_p(const GemmArgs<T> &g, bool akm, bool bkm, int splits)
 {
 	constexpr int BK = 16;
+	constexpr int PF = (BM * BN >= 128 * 128) ? 1 : 4; // register prefetch depth (tiles)
 	constexpr int NT = WM * WN * 64;
 	int nblocks = g.tri_enum ? g.ntm * (g.ntm + 1) / 2 : g.ntm * g.ntn;
 	dim3 grid((unsigned) nblocks, 1, (unsigned) splits), block(NT);
 	hipStream_t s = ctx().stream;
 	if (akm && bkm)
-		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, true>), grid, block, 0, s, g);
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, true, PF>), grid, block, 0, s, g);
 	else if (akm && !bkm)
-		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, false>), grid, block, 0, s, g);
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, false, PF>), grid, block, 0, s, g);
 	else if (!akm && bkm)
-		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, true>), grid, block, 0, s, g);
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, true, PF>), grid, block, 0, s, g);
 	else
-		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, false>), grid, block, 0, s, g);
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, false, PF>), grid, block, 0, s, g);
 	FH_HIP(hipGetLastError());
 }
 

@@ -14,6 +14,7 @@
 // Upper triangles are lower triangles on the row/column reversed views (triangular_solve.rs:578-604);
 // every kernel here takes signed strides so the reversal is free.
 #include "common.h"
+#include "lds_blocks.h"
 
 namespace fh {
 
@@ -88,37 +89,25 @@ __global__ __launch_bounds__(64) void trsm_leaf_kernel(const T *__restrict__ Lp,
 
 // ------------------------------------------------------------------------------------------------
 // Many right-hand sides: invert the 128 x 128 diagonal blocks once (one workgroup per block, all blocks in
-// ONE launch) and turn every leaf of the recursion into an MFMA GEMM  X_k <- inv(T_kk) X_k.
-// The product is done IN PLACE: the leaf has at most 128 rows, i.e. one tile of the 128 x 128 GEMM kernel
-// along the aliased dimension, and that kernel reads all of its K slices before its epilogue writes.
+// ONE launch, MFMA recursive doubling in LDS -- lds_blocks.h) and turn every leaf of the recursion into an
+// MFMA GEMM  X_k <- inv(T_kk) X_k.  The product is done IN PLACE with a tile that covers the whole aliased
+// dimension (gemm.hip, GemmExtra::inplace).
 // ------------------------------------------------------------------------------------------------
-constexpr int TRSM_IB = 128;
+constexpr int TRSM_IB = LDS_NB;
 
 template <typename T>
-__global__ __launch_bounds__(TRSM_IB) void trtri_diag_kernel(const T *__restrict__ Lp, idx_t lrs, idx_t lcs, int n, int unit,
-							       T *__restrict__ W)
+__global__ __launch_bounds__(LDS_NT) void trtri_diag_kernel(const T *__restrict__ Lp, idx_t lrs, idx_t lcs, int n, int unit,
+							   T *__restrict__ W)
 {
-	// W block b: column major TRSM_IB x TRSM_IB, lower triangular inverse of L[b*IB .., b*IB ..] (zeros above)
-	__shared__ T Ws[TRSM_IB * TRSM_IB]; // Ws[j * IB + c]: entry j of column c (thread c owns column c)
-	const int b = blockIdx.x, c = threadIdx.x;
+	// W block b: column major TRSM_IB x TRSM_IB, inverse of L[b*IB .., b*IB ..] (identity padded, zeros above)
+	__shared__ T S[LDS_NB * LDS_LDP];
+	const int b = blockIdx.x;
 	const int r0 = b * TRSM_IB;
 	const int nb = min(TRSM_IB, n - r0);
-	const T *Lb = Lp + (idx_t) r0 * lrs + (idx_t) r0 * lcs;
-	// solve L w = e_c by forward substitution; w_j = 0 for j < c falls out of the recurrence
-	for (int i = 0; i < nb; ++i) {
-		T s = i == c ? (T) 1 : (T) 0;
-		for (int j = 0; j < i; ++j)
-			s = __builtin_fma(-Lb[(idx_t) i * lrs + (idx_t) j * lcs], Ws[j * TRSM_IB + c], s); // L entry is wave-uniform
-		if (!unit)
-			s = s * ((T) 1 / Lb[(idx_t) i * lrs + (idx_t) i * lcs]);
-		Ws[i * TRSM_IB + c] = c < nb ? s : (T) 0;
-	}
+	lds_load_lower<T>(S, Lp + (idx_t) r0 * lrs + (idx_t) r0 * lcs, lrs, lcs, nb);
 	__syncthreads();
-	T *Wb = W + (size_t) b * TRSM_IB * TRSM_IB;
-	for (int e = c; e < TRSM_IB * TRSM_IB; e += TRSM_IB) {
-		const int i = e % TRSM_IB, col = e / TRSM_IB;
-		Wb[e] = (i < nb && col < nb) ? Ws[i * TRSM_IB + col] : (T) 0;
-	}
+	lds_tri_inv_inplace<T>(S, unit);
+	lds_store_block<T>(S, W + (size_t) b * TRSM_IB * TRSM_IB, 1, TRSM_IB, TRSM_IB, false);
 }
 
 template <typename T> static void trsm_inv_rec(MatV<const T> L, MatV<T> X, const T *W, idx_t b0)
@@ -137,6 +126,16 @@ template <typename T> static void trsm_inv_rec(MatV<const T> L, MatV<T> X, const
 	trsm_inv_rec<T>(L.sub(0, 0, top, top), Xt, W, b0);
 	gemm_dev<T>(Xb, DST_FULL, true, L.sub(top, 0, n - top, top), Xt.c(), (T) -1);
 	trsm_inv_rec<T>(L.sub(top, top, n - top, n - top), Xb, W, b0 + top / TRSM_IB);
+}
+
+// X <- L^-1 X with the inverses of L's 128 x 128 diagonal blocks already in W (block i at W + i * 128 * 128,
+// column major, identity padded): the Cholesky leaves produce them as a by-product (potrf.hip).
+template <typename T> void trsm_lower_pre_dev(MatV<const T> L, MatV<T> X, const T *W)
+{
+	FH_CHECK(L.nrows == L.ncols && X.nrows == L.nrows, "trsm: shape mismatch");
+	if (L.nrows == 0 || X.ncols == 0)
+		return;
+	trsm_inv_rec<T>(L, X, W, 0);
 }
 
 // triangular_solve.rs:200-215
@@ -164,7 +163,7 @@ template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X)
 	if (n > 64 && k >= 256) {
 		const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
 		Scratch wb((size_t) nblk * TRSM_IB * TRSM_IB * sizeof(T));
-		hipLaunchKernelGGL(trtri_diag_kernel<T>, dim3((unsigned) nblk), dim3(TRSM_IB), 0, ctx().stream, L.p, L.rs, L.cs,
+		hipLaunchKernelGGL(trtri_diag_kernel<T>, dim3((unsigned) nblk), dim3(LDS_NT), 0, ctx().stream, L.p, L.rs, L.cs,
 				   (int) n, unit ? 1 : 0, wb.as<T>());
 		FH_HIP(hipGetLastError());
 		trsm_inv_rec<T>(L, X, wb.as<T>(), 0);
@@ -192,6 +191,8 @@ template <typename T> void trsm_upper_dev(MatV<const T> U, bool unit, MatV<T> X)
 	trsm_lower_dev<T>(U.rev_rows().rev_cols(), unit, X.rev_rows());
 }
 
+template void trsm_lower_pre_dev<double>(MatV<const double>, MatV<double>, const double *);
+template void trsm_lower_pre_dev<float>(MatV<const float>, MatV<float>, const float *);
 template void trsm_lower_dev<double>(MatV<const double>, bool, MatV<double>);
 template void trsm_lower_dev<float>(MatV<const float>, bool, MatV<float>);
 template void trsm_upper_dev<double>(MatV<const double>, bool, MatV<double>);
