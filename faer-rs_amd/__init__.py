@@ -23,6 +23,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfaer_hip.so")
+if os.environ.get("FAER_HIP_LIB"):  # developer override (instrumented builds); never a different backend
+    LIB_PATH = os.environ["FAER_HIP_LIB"]
 _LIB = None
 
 # ------------------------------------------------------------------ repr(C) structs (include/faer_hip.h)

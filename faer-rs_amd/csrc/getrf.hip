@@ -13,18 +13,20 @@
 //     the whole leaf (read from HBM once, written once);
 //   * per column: DPP/shuffle arg-max inside each wave, LDS across the 4 waves, then ONE all-to-all
 //     exchange per column through L2: every workgroup publishes its candidate {|a|, row, the candidate's
-//     whole panel row} and workgroup 0 publishes the diagonal row; after a single device-scope barrier every
+//     whole panel row} and workgroup 0 publishes the diagonal row; after a single all-to-all flag round every
 //     workgroup picks the winner itself, patches the two swapped rows from the published copies and
 //     performs scale + rank-1 update on its own rows.  No second synchronisation per column;
-//   * the barrier follows the gfx950 recipe (MI355X_MICROARCH.md, "barrier-counter"): plain stores,
-//     lane-0 agent release + s_waitcnt, relaxed monotonic counter, relaxed polling with s_sleep,
-//     lane-0 agent acquire.  Every spin is bounded; a timeout raises a device error instead of hanging.
+//   * the exchange follows the gfx950 recipe for in-launch hand-offs (xwg.h; cdna_hip_programming.md
+//     Guideline 16 R1): write-through (sc1) payload stores, one per-workgroup epoch flag, relaxed polling with
+//     s_sleep, sc1 loads on the consumer side -- no release/acquire fences.  Every spin is bounded; a timeout
+//     raises a device error instead of hanging.
 // Row interchanges of the outside columns are NOT applied one transposition at a time: the transposition
 // list is composed into a net row permutation in parallel (each row traces its source backwards through
 // the list) and applied as one gather.
 #include <climits>
 
 #include "common.h"
+#include "xwg.h"
 
 namespace fh {
 
@@ -51,28 +53,19 @@ static __device__ __forceinline__ void wave_argmax(double &v, int &r)
 	}
 }
 
-// Device-scope barrier among the gridDim.x resident workgroups of a launch.  Returns false on timeout.
-static __device__ bool grid_barrier(unsigned long long *cnt, unsigned long long target, int *s_flag)
-{
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		int ok = 0;
-		for (int spin = 0; spin < (1 << 22); ++spin) {
-			if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
-				ok = 1;
-				break;
-			}
-			__builtin_amdgcn_s_sleep(1);
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-		*s_flag = ok;
-	}
-	__syncthreads();
-	return *s_flag != 0;
-}
+// Optional phase timing of the panel kernel (build with -DFH_PANEL_TIMING; tools/gpu_panel_timing.sh).
+#ifdef FH_PANEL_TIMING
+#define FH_T(i)                                                                                                          \
+	do {                                                                                                             \
+		const long long now_ = (long long) __builtin_readcyclecounter();                                         \
+		tacc[i] += now_ - tlast;                                                                                 \
+		tlast = now_;                                                                                            \
+	} while (0)
+#else
+#define FH_T(i)                                                                                                          \
+	do {                                                                                                             \
+	} while (0)
+#endif
 
 template <typename T> struct PanelArgs {
 	T *P;
@@ -84,9 +77,10 @@ template <typename T> struct PanelArgs {
 	double *slot_val; // [2][G][1 + LU_W]  (candidate |a| then the candidate's panel row)
 	int *slot_row;	  // [2][G]
 	double *diag_row; // [2][LU_W]
-	unsigned long long *counter;
-	unsigned long long counter_base;
-	int *status; // status[2] = barrier timeout flag
+	xwg_u64 *flags;	  // [G] per-workgroup epoch flags (xwg.h)
+	xwg_u64 epoch_base;
+	int *status; // status[2] = exchange timeout flag
+	unsigned long long *dbg; // FH_PANEL_TIMING: 8 phase counters (cycles of workgroup 0, thread 0)
 };
 
 template <typename T, int RMAX> __global__ __launch_bounds__(256) void getrf_panel_kernel(const PanelArgs<T> a)
@@ -102,11 +96,16 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void getrf_pan
 	const int r0 = g * a.R;
 	const int nr = min(a.R, a.m - r0);
 	const int w = a.w;
+#ifdef FH_PANEL_TIMING
+	long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	long long tlast = (long long) __builtin_readcyclecounter();
+#endif
 
 	for (int c = 0; c < w; ++c)
 		for (int r = tid; r < nr; r += 256)
 			Ps[c * RMAX + r] = a.P[(idx_t) (r0 + r) * a.rs + (idx_t) c * a.cs];
 	__syncthreads();
+	FH_T(0);
 
 	const int steps = min(w, a.m);
 	bool failed = false;
@@ -154,28 +153,34 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void getrf_pan
 			}
 			__syncthreads();
 		} else {
-			// ---- 2. publish candidate (+ its panel row) and, from workgroup 0, the diagonal row
+			FH_T(1);
+			// ---- 2. publish candidate (+ its panel row) and, from workgroup 0, the diagonal row: write-through
+			//         stores issued by wave 0 only, then this workgroup's flag (xwg.h)
 			const int cand = s_p;
 			double *sv = a.slot_val + ((size_t) q * G + g) * (1 + LU_W);
 			if (tid == 0) {
-				a.slot_row[q * G + g] = cand;
-				sv[0] = s_v[0];
+				xwg_store_i(a.slot_row + q * G + g, cand);
+				xwg_store(sv, s_v[0]);
 			}
 			if (tid < w && cand != INT_MAX)
-				sv[1 + tid] = (double) Ps[tid * RMAX + (cand - r0)];
+				xwg_store(sv + 1 + tid, (double) Ps[tid * RMAX + (cand - r0)]);
 			if (g == 0 && tid < w)
-				a.diag_row[q * LU_W + tid] = (double) Ps[tid * RMAX + j]; // row j < 32 <= R lives in chunk 0
-			// ---- 3. one device-scope barrier per column
-			if (!grid_barrier(a.counter, a.counter_base + (unsigned long long) G * (j + 1), &s_flag)) {
+				xwg_store(a.diag_row + q * LU_W + tid, (double) Ps[tid * RMAX + j]); // row j < 32 <= R lives in chunk 0
+			if (tid < 64)
+				xwg_publish(a.flags, g, a.epoch_base + (xwg_u64) (j + 1), tid == 0);
+			FH_T(2);
+			// ---- 3. one all-to-all round per column
+			if (!xwg_wait_all(a.flags, G, a.epoch_base + (xwg_u64) (j + 1), &s_flag)) {
 				failed = true;
 				break;
 			}
+			FH_T(3);
 			// ---- 4. every workgroup picks the winner itself
 			double v = 0.0;
 			int r = INT_MAX, gw = 0;
 			for (int t = tid; t < G; t += 256) {
-				const int rr = a.slot_row[q * G + t];
-				const double vv = a.slot_val[((size_t) q * G + t) * (1 + LU_W)];
+				const int rr = xwg_load_i(a.slot_row + q * G + t);
+				const double vv = xwg_load(a.slot_val + ((size_t) q * G + t) * (1 + LU_W));
 				if (rr != INT_MAX && better(vv, rr, v, r)) {
 					v = vv;
 					r = rr;
@@ -200,12 +205,13 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void getrf_pan
 			p = s_p;
 			gw = s_gw;
 			if (tid < w) {
-				const T d = (T) a.diag_row[q * LU_W + tid];
+				const T d = (T) xwg_load(a.diag_row + q * LU_W + tid);
 				s_diag[tid] = d;
-				s_piv[tid] = p == j ? d : (T) a.slot_val[((size_t) q * G + gw) * (1 + LU_W) + 1 + tid];
+				s_piv[tid] = p == j ? d : (T) xwg_load(a.slot_val + ((size_t) q * G + gw) * (1 + LU_W) + 1 + tid);
 			}
 			__syncthreads();
 		}
+		FH_T(4);
 		// ---- 5. swap rows j <-> p inside the chunks that own them (from the published copies)
 		if (p != j) {
 			if (p >= r0 && p < r0 + nr && tid < w)
@@ -216,6 +222,7 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void getrf_pan
 		if (g == 0 && tid == 0)
 			a.piv[j] = a.row_base + p;
 		__syncthreads();
+		FH_T(5);
 		// ---- 6. scale by the reciprocal pivot and rank-1 update of the owned rows below the diagonal
 		//         (factor.rs:50-64; rank_update_imp: dst = fma(l_i, -u_c, dst))
 		const T inv = (T) 1 / s_piv[j];
@@ -228,6 +235,7 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void getrf_pan
 			}
 		}
 		__syncthreads();
+		FH_T(6);
 	}
 	if (failed) {
 		if (tid == 0)
@@ -237,6 +245,266 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void getrf_pan
 	for (int c = 0; c < w; ++c)
 		for (int r = tid; r < nr; r += 256)
 			a.P[(idx_t) (r0 + r) * a.rs + (idx_t) c * a.cs] = Ps[c * RMAX + r];
+#ifdef FH_PANEL_TIMING
+	FH_T(7);
+	if (g == 0 && tid == 0 && a.dbg)
+		for (int i = 0; i < 8; ++i)
+			atomicAdd(a.dbg + i, (unsigned long long) tacc[i]);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Register-resident panel kernel (the one the driver uses).  Phase timing of the LDS-resident kernel above
+// (profiles/r01_lu_panel_phase_timing.txt) showed that only ~1.6 us of its ~6.4 us per column was the
+// cross-workgroup hand-off; the rest was LDS round trips of the column scan, the winner selection and the
+// rank-1 update.  Here every thread keeps LU2_RPT whole panel rows in registers (32 columns each):
+//   * the column loop is unrolled at compile time (column index = template constant), so the update of the
+//     trailing columns is 31 - j register FMAs per row against the pivot row read once from LDS;
+//   * the local arg-max comes straight out of registers; wave reductions + one LDS hop across the 8 waves;
+//   * wave 0 alone runs the exchange: publish -> poll -> read the G candidate records -> pick the winner ->
+//     fetch its row and the diagonal row -> hand them to the workgroup through LDS (3 __syncthreads per column);
+//   * 1024 rows per workgroup => at most 16 workgroups for a 16384-row panel (fewer flags, fewer records).
+// ------------------------------------------------------------------------------------------------
+constexpr int LU2_NT = 512;		    // threads per workgroup
+constexpr int LU2_RPT = 2;		    // rows per thread
+constexpr int LU2_R = LU2_NT * LU2_RPT; // rows per workgroup
+constexpr int LU2_GMAX = 1024; // up to 2^20 rows
+
+template <typename T> struct Panel2Args {
+	T *P;
+	idx_t rs, cs;
+	int m, w;
+	int *piv; // piv[j] = row_base + pivot row
+	int row_base;
+	double *slots; // [2][G][LU2_SLOT]: {|a|, row (as double), 32 row entries}
+	double *diag;  // [2][LU_W]
+	xwg_u64 *flags;
+	xwg_u64 epoch_base;
+	int *status;
+};
+constexpr int LU2_SLOT = 2 + LU_W;
+
+template <typename T> struct Panel2Shared {
+	double wv[LU2_NT / 64];
+	int wr[LU2_NT / 64];
+	T cand[LU_W]; // this workgroup's candidate row
+	T drow[LU_W]; // row j (workgroup 0)
+	T piv[LU_W];  // winning pivot row
+	T diag[LU_W]; // row j as published
+	int p;	      // winning row (global)
+	int flag;
+};
+
+static __device__ __forceinline__ void wave_argmax2(double &v, int &r)
+{
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		const double ov = __shfl_xor(v, off, 64);
+		const int orow = __shfl_xor(r, off, 64);
+		if (better(ov, orow, v, r)) {
+			v = ov;
+			r = orow;
+		}
+	}
+}
+
+// one column step, J known at compile time; returns false on exchange timeout
+template <typename T, int J>
+static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x)[LU2_RPT][LU_W], Panel2Shared<T> &sh, int r0, int G)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int g = blockIdx.x;
+	const int q = J & 1;
+	// ---- 1. local arg-max of |a(:, J)| over owned rows >= J (first strictly largest, factor.rs:35-43)
+	double bv = 0.0;
+	int br = INT_MAX;
+#pragma unroll
+	for (int i = 0; i < LU2_RPT; ++i) {
+		const int gr = r0 + tid + i * LU2_NT;
+		const double av = fabs((double) x[i][J]);
+		if (gr >= J && gr < a.m && av > bv) {
+			bv = av;
+			br = gr;
+		}
+	}
+	wave_argmax2(bv, br);
+	if (lane == 0) {
+		sh.wv[wave] = bv;
+		sh.wr[wave] = br;
+	}
+	__syncthreads();
+	bv = sh.wv[0];
+	br = sh.wr[0];
+#pragma unroll
+	for (int k = 1; k < LU2_NT / 64; ++k)
+		if (better(sh.wv[k], sh.wr[k], bv, br)) {
+			bv = sh.wv[k];
+			br = sh.wr[k];
+		}
+	if (!(bv > 0.0))
+		br = INT_MAX; // zero / NaN-only chunk: no candidate
+	// the owners of the candidate row and (workgroup 0) of row J park them in LDS
+#pragma unroll
+	for (int i = 0; i < LU2_RPT; ++i) {
+		const int gr = r0 + tid + i * LU2_NT;
+		if (gr == br) {
+#pragma unroll
+			for (int c = 0; c < LU_W; ++c)
+				sh.cand[c] = x[i][c];
+		}
+		if (gr == J) {
+#pragma unroll
+			for (int c = 0; c < LU_W; ++c)
+				sh.drow[c] = x[i][c];
+		}
+	}
+	__syncthreads();
+	// ---- 2. wave 0: exchange and winner selection
+	if (G > 1) {
+		if (wave == 0) {
+			double *sv = a.slots + ((size_t) q * G + g) * LU2_SLOT;
+			if (lane == 0) {
+				xwg_store(sv, bv);
+				xwg_store(sv + 1, (double) br);
+			}
+			if (lane < LU_W && br != INT_MAX)
+				xwg_store(sv + 2 + lane, (double) sh.cand[lane]);
+			if (g == 0 && lane >= 32 && lane < 32 + LU_W)
+				xwg_store(a.diag + q * LU_W + (lane - 32), (double) sh.drow[lane - 32]);
+			const xwg_u64 epoch = a.epoch_base + (xwg_u64) (J + 1);
+			xwg_publish(a.flags, g, epoch, lane == 0);
+			int ok = 0;
+			for (int spin = 0; spin < (1 << 21); ++spin) {
+				bool all = true;
+				for (int t = lane; t < G; t += 64)
+					all = all && __hip_atomic_load(a.flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+				if (__all(all)) {
+					ok = 1;
+					break;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+			double v = 0.0;
+			int r = INT_MAX;
+			for (int t = lane; t < G; t += 64) {
+				const double *rec = a.slots + ((size_t) q * G + t) * LU2_SLOT;
+				const double vv = xwg_load(rec);
+				const int rr = (int) xwg_load(rec + 1);
+				if (rr != INT_MAX && better(vv, rr, v, r)) {
+					v = vv;
+					r = rr;
+				}
+			}
+			wave_argmax2(v, r);
+			const int p = r == INT_MAX ? J : r;
+			const int gw = r == INT_MAX ? 0 : r / LU2_R;
+			if (lane < LU_W) {
+				const T d = (T) xwg_load(a.diag + q * LU_W + lane);
+				sh.diag[lane] = d;
+				sh.piv[lane] = p == J ? d : (T) xwg_load(a.slots + ((size_t) q * G + gw) * LU2_SLOT + 2 + lane);
+			}
+			if (lane == 0) {
+				sh.p = p;
+				sh.flag = ok;
+			}
+		}
+	} else {
+		if (tid < LU_W) {
+			const int p = br == INT_MAX ? J : br;
+			sh.diag[tid] = sh.drow[tid];
+			sh.piv[tid] = p == J ? sh.drow[tid] : sh.cand[tid];
+			if (tid == 0) {
+				sh.p = p;
+				sh.flag = 1;
+			}
+		}
+	}
+	__syncthreads();
+	if (!sh.flag)
+		return false;
+	// ---- 3. swap rows J <-> p, scale by the reciprocal pivot, rank-1 update (factor.rs:45-64)
+	const int p = sh.p;
+	if (g == 0 && tid == 0)
+		a.piv[J] = a.row_base + p;
+	T pv[LU_W];
+#pragma unroll
+	for (int c = J; c < LU_W; ++c)
+		pv[c] = sh.piv[c];
+	const T inv = (T) 1 / pv[J];
+#pragma unroll
+	for (int i = 0; i < LU2_RPT; ++i) {
+		const int gr = r0 + tid + i * LU2_NT;
+		if (p != J) {
+			if (gr == p) {
+#pragma unroll
+				for (int c = 0; c < LU_W; ++c)
+					x[i][c] = sh.diag[c];
+			}
+			if (gr == J) {
+#pragma unroll
+				for (int c = 0; c < LU_W; ++c)
+					x[i][c] = sh.piv[c];
+			}
+		}
+		if (gr > J) {
+			const T l = x[i][J] * inv;
+			x[i][J] = l;
+#pragma unroll
+			for (int c = J + 1; c < LU_W; ++c)
+				x[i][c] = __builtin_fma(l, -pv[c], x[i][c]); // rank_update_imp: dst = fma(l_i, -u_c, dst)
+		}
+	}
+	return true;
+}
+
+template <typename T, int J> struct Panel2Steps {
+	static __device__ __forceinline__ bool run(const Panel2Args<T> &a, T (&x)[LU2_RPT][LU_W], Panel2Shared<T> &sh, int r0, int G,
+						   int steps)
+	{
+		if constexpr (J < LU_W) {
+			if (J >= steps)
+				return true;
+			if (!panel2_step<T, J>(a, x, sh, r0, G))
+				return false;
+			return Panel2Steps<T, J + 1>::run(a, x, sh, r0, G, steps);
+		} else {
+			return true;
+		}
+	}
+};
+
+template <typename T> __global__ __launch_bounds__(LU2_NT) void getrf_panel2_kernel(const Panel2Args<T> a)
+{
+	__shared__ Panel2Shared<T> sh;
+	const int tid = threadIdx.x;
+	const int g = blockIdx.x, G = gridDim.x;
+	const int r0 = g * LU2_R;
+	const int w = a.w;
+	T x[LU2_RPT][LU_W];
+#pragma unroll
+	for (int i = 0; i < LU2_RPT; ++i) {
+		const int gr = r0 + tid + i * LU2_NT;
+#pragma unroll
+		for (int c = 0; c < LU_W; ++c) {
+			const bool in = gr < a.m && c < w;
+			const T v = a.P[in ? (idx_t) gr * a.rs + (idx_t) c * a.cs : (idx_t) 0];
+			x[i][c] = in ? v : (T) 0;
+		}
+	}
+	const int steps = min(w, a.m);
+	if (!Panel2Steps<T, 0>::run(a, x, sh, r0, G, steps)) {
+		if (tid == 0)
+			atomicExch(a.status + 2, 1);
+		return;
+	}
+#pragma unroll
+	for (int i = 0; i < LU2_RPT; ++i) {
+		const int gr = r0 + tid + i * LU2_NT;
+#pragma unroll
+		for (int c = 0; c < LU_W; ++c)
+			if (gr < a.m && c < w)
+				a.P[(idx_t) gr * a.rs + (idx_t) c * a.cs] = x[i][c];
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -281,6 +549,58 @@ __global__ void scatter_rows_kernel(T *B, idx_t rs, idx_t cs, int nrows, int nco
 		B[(idx_t) d * rs + (idx_t) c * cs] = tmp[(size_t) c * nrows + d];
 }
 
+// One-launch variant for short transposition lists (nt <= LASWP_SMALL_NT: every node of the recursion below
+// 1024 columns, i.e. all but a handful of the calls): each workgroup owns LASWP_CC columns, rebuilds the net
+// permutation of the <= 2 nt affected rows itself (parallel backward trace through the list held in LDS),
+// gathers their sources into LDS and scatters them back -- no global temporary, no separate compose pass.
+constexpr int LASWP_SMALL_NT = 512;
+constexpr int LASWP_CC = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void laswp_small_kernel(T *B, idx_t rs, idx_t cs, int nrows, int ncols,
+							  const int *__restrict__ piv, int nt, int row_base)
+{
+	__shared__ int s_piv[LASWP_SMALL_NT];
+	__shared__ int s_dst[2 * LASWP_SMALL_NT], s_src[2 * LASWP_SMALL_NT];
+	__shared__ T tmp[LASWP_CC * 2 * LASWP_SMALL_NT];
+	const int tid = threadIdx.x;
+	for (int j = tid; j < nt; j += 256)
+		s_piv[j] = piv[j] - row_base;
+	__syncthreads();
+	// affected destinations: rows 0 .. nt-1 and the pivot rows >= nt (duplicates are harmless: same source)
+	const int ne = 2 * nt;
+	for (int e = tid; e < ne; e += 256) {
+		int d = e < nt ? e : s_piv[e - nt];
+		int pos = -1;
+		if (e < nt || d >= nt) {
+			pos = d;
+			for (int j = nt - 1; j >= 0; --j) {
+				const int pj = s_piv[j];
+				pos = pos == j ? pj : (pos == pj ? j : pos);
+			}
+			if (pos == d)
+				pos = -1; // row stays where it is
+		}
+		s_dst[e] = d;
+		s_src[e] = pos;
+	}
+	__syncthreads();
+	const int c0 = blockIdx.x * LASWP_CC;
+	const int nc = min(LASWP_CC, ncols - c0);
+	for (int idx = tid; idx < nc * ne; idx += 256) {
+		const int c = idx / ne, e = idx - c * ne;
+		const int sr = s_src[e];
+		if (sr >= 0)
+			tmp[idx] = B[(idx_t) sr * rs + (idx_t) (c0 + c) * cs];
+	}
+	__syncthreads();
+	for (int idx = tid; idx < nc * ne; idx += 256) {
+		const int c = idx / ne, e = idx - c * ne;
+		if (s_src[e] >= 0)
+			B[(idx_t) s_dst[e] * rs + (idx_t) (c0 + c) * cs] = tmp[idx];
+	}
+}
+
 // Applies the transpositions (j <-> piv[j] - row_base), j < nt, to all columns of B (B's row 0 is the
 // row the first transposition refers to).
 template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, int row_base)
@@ -289,6 +609,12 @@ template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, i
 		return;
 	const int nrows = (int) B.nrows;
 	hipStream_t s = ctx().stream;
+	if (nt <= LASWP_SMALL_NT) {
+		hipLaunchKernelGGL(laswp_small_kernel<T>, dim3((unsigned) ((B.ncols + LASWP_CC - 1) / LASWP_CC)), dim3(256), 0, s, B.p,
+				   B.rs, B.cs, nrows, (int) B.ncols, piv, nt, row_base);
+		FH_HIP(hipGetLastError());
+		return;
+	}
 	Scratch srcb((size_t) nrows * sizeof(int));
 	int *src = srcb.as<int>();
 	hipLaunchKernelGGL(compose_perm_kernel, dim3((nrows + 255) / 256), dim3(256), 0, s, piv, nt, row_base, nrows, src);
@@ -315,49 +641,40 @@ template <typename T> struct LuWork {
 	double *slot_val;   // [2][GMAX][1 + LU_W]
 	int *slot_row;	    // [2][GMAX]
 	double *diag_row;   // [2][LU_W]
-	unsigned long long *counter;
-	unsigned long long counter_base;
+	xwg_u64 *flags;	    // [LU_GMAX]
+	xwg_u64 epoch_base; // epochs consumed by earlier leaf launches of this factorization
 	int *status;
+	unsigned long long *dbg;
 };
 constexpr int LU_GMAX = 224;
 
 template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, LuWork<T> &wk)
 {
-	constexpr int RMAX = sizeof(T) == 8 ? 448 : 896;
 	const idx_t m = P.nrows;
 	const int w = (int) P.ncols;
 	FH_CHECK(w <= LU_W, "getrf leaf: panel too wide");
-	FH_CHECK(m <= (idx_t) RMAX * LU_GMAX, "partial_piv_lu: more rows than the cooperative panel kernel supports");
-	int G = (int) ((m + RMAX - 1) / RMAX);
+	FH_CHECK(m <= (idx_t) LU2_R * LU2_GMAX, "partial_piv_lu: more rows than the cooperative panel kernel supports");
+	int G = (int) ((m + LU2_R - 1) / LU2_R);
 	if (G < 1)
 		G = 1;
-	int R = (int) ((m + G - 1) / G);
-	R = (R + 63) / 64 * 64;
-	if (R > RMAX)
-		R = RMAX;
-	if (R < 64)
-		R = 64;
-	G = (int) ((m + R - 1) / R);
-	PanelArgs<T> a;
+	Panel2Args<T> a;
 	a.P = P.p;
 	a.rs = P.rs;
 	a.cs = P.cs;
 	a.m = (int) m;
 	a.w = w;
-	a.R = R;
 	a.piv = wk.piv + col0;
 	a.row_base = row_base;
-	a.slot_val = wk.slot_val;
-	a.slot_row = wk.slot_row;
-	a.diag_row = wk.diag_row;
-	a.counter = wk.counter;
-	a.counter_base = wk.counter_base;
+	a.slots = wk.slot_val;
+	a.diag = wk.diag_row;
+	a.flags = wk.flags;
+	a.epoch_base = wk.epoch_base;
 	a.status = wk.status;
-	hipLaunchKernelGGL((getrf_panel_kernel<T, RMAX>), dim3(G), dim3(256), 0, ctx().stream, a);
+	hipLaunchKernelGGL(getrf_panel2_kernel<T>, dim3(G), dim3(LU2_NT), 0, ctx().stream, a);
 	FH_HIP(hipGetLastError());
 	const int steps = w < (int) m ? w : (int) m;
 	if (G > 1)
-		wk.counter_base += (unsigned long long) G * steps;
+		wk.epoch_base += (xwg_u64) steps;
 }
 
 static idx_t next_pow2(idx_t n)
@@ -407,8 +724,8 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 	long n_trans = 0;
 	if (size > 0) {
 		Scratch pivb((size_t) size * sizeof(int));
-		Scratch slotv((size_t) 2 * LU_GMAX * (1 + LU_W) * sizeof(double));
-		Scratch slotr((size_t) 2 * LU_GMAX * sizeof(int));
+		Scratch slotv((size_t) 2 * LU2_GMAX * LU2_SLOT * sizeof(double));
+		Scratch slotr(256);
 		Scratch diag((size_t) 2 * LU_W * sizeof(double));
 		Scratch misc(256);
 		LuWork<T> wk;
@@ -416,10 +733,18 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		wk.slot_val = slotv.as<double>();
 		wk.slot_row = slotr.as<int>();
 		wk.diag_row = diag.as<double>();
-		wk.counter = misc.as<unsigned long long>();
-		wk.counter_base = 0;
+		Scratch flagb((size_t) LU2_GMAX * sizeof(xwg_u64));
+		wk.flags = flagb.as<xwg_u64>();
+		wk.epoch_base = 0;
 		wk.status = misc.as<int>() + 8;
 		FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
+		FH_HIP(hipMemsetAsync(flagb.p, 0, (size_t) LU2_GMAX * sizeof(xwg_u64), ctx().stream));
+		wk.dbg = nullptr;
+#ifdef FH_PANEL_TIMING
+		Scratch dbgb(64);
+		FH_HIP(hipMemsetAsync(dbgb.p, 0, 64, ctx().stream));
+		wk.dbg = dbgb.as<unsigned long long>();
+#endif
 
 		getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);
 		if (m < n) { // factor.rs:278-285 (+ the swaps of the columns right of the square part)
@@ -433,6 +758,15 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		FH_HIP(hipMemcpyAsync(st, wk.status, sizeof(st), hipMemcpyDeviceToHost, ctx().stream));
 		ctx().sync();
 		FH_CHECK(st[2] == 0, "partial_piv_lu: device barrier timed out in the panel kernel");
+#ifdef FH_PANEL_TIMING
+		{
+			unsigned long long d[8];
+			FH_HIP(hipMemcpy(d, wk.dbg, sizeof(d), hipMemcpyDeviceToHost));
+			fprintf(stderr, "panel timing (cycles of wg0/t0 summed over all leaves): load %llu | argmax %llu | publish %llu | wait %llu | pick %llu | "
+					"swap %llu | update %llu | store %llu\n",
+				d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+		}
+#endif
 		// factor.rs:274-277: perm = identity with the transpositions applied in order
 		for (idx_t j = 0; j < size; ++j) {
 			const idx_t p = piv[(size_t) j];

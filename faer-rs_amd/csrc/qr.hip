@@ -24,6 +24,7 @@
 #include <limits>
 
 #include "common.h"
+#include "xwg.h"
 
 namespace fh {
 
@@ -105,28 +106,6 @@ static __device__ __forceinline__ double wave_sum(double v)
 	return v;
 }
 
-static __device__ bool qr_grid_barrier(unsigned long long *cnt, unsigned long long target, int *s_flag)
-{
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		int ok = 0;
-		for (int spin = 0; spin < (1 << 22); ++spin) {
-			if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
-				ok = 1;
-				break;
-			}
-			__builtin_amdgcn_s_sleep(1);
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-		*s_flag = ok;
-	}
-	__syncthreads();
-	return *s_flag != 0;
-}
-
 // ------------------------------------------------------------------------------------------------
 // FAST path leaf: cooperative 8-column Householder panel
 // ------------------------------------------------------------------------------------------------
@@ -146,9 +125,9 @@ template <typename T> struct QrPanelArgs {
 	idx_t trs, tcs;
 	double *slots; // [2][G][QR_SLOT]
 	double *head;  // [2][QR_PW + 1]: row j of the panel (cols j..w) and |above|^2
-	unsigned long long *counter;
-	unsigned long long counter_base;
-	int *status; // [2] barrier timeout, [3] rank deficiency detected
+	xwg_u64 *flags; // [G] per-workgroup epoch flags (xwg.h)
+	xwg_u64 epoch_base;
+	int *status; // [2] exchange timeout, [3] rank deficiency detected
 };
 
 // sums `vals[0..cnt)` over the workgroup into s_red[0..cnt) (every thread then reads s_red)
@@ -222,16 +201,21 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void qr_panel_
 				}
 			}
 			if (G > 1) {
-				if (tid < QR_PW)
-					a.slots[((size_t) q * G + g) * QR_SLOT + tid] = s_red[tid];
-				if (g == 0) {
+				// all-to-all round (xwg.h): partial sums (+ from chunk 0: row j and |above|^2) as write-through
+				// stores of wave 0, one flag per workgroup, sc1 loads on the way back
+				if (g == 0)
 					block_sum<1>(ab, s_part, s_S);
+				if (tid < QR_PW)
+					xwg_store(a.slots + ((size_t) q * G + g) * QR_SLOT + tid, s_red[tid]);
+				if (g == 0) {
 					if (tid < QR_PW)
-						a.head[q * (QR_PW + 1) + tid] = tid < w ? (double) Ps[tid * RMAX + j] : 0.0;
+						xwg_store(a.head + q * (QR_PW + 1) + tid, tid < w ? (double) Ps[tid * RMAX + j] : 0.0);
 					if (tid == 0)
-						a.head[q * (QR_PW + 1) + QR_PW] = s_S[0];
+						xwg_store(a.head + q * (QR_PW + 1) + QR_PW, s_S[0]);
 				}
-				if (!qr_grid_barrier(a.counter, a.counter_base + (unsigned long long) G * (bar + 1), &s_flag)) {
+				if (tid < 64)
+					xwg_publish(a.flags, g, a.epoch_base + (xwg_u64) (bar + 1), tid == 0);
+				if (!xwg_wait_all(a.flags, G, a.epoch_base + (xwg_u64) (bar + 1), &s_flag)) {
 					timeout = true;
 					break;
 				}
@@ -243,10 +227,10 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void qr_panel_
 				for (int t = tid; t < G; t += 256)
 #pragma unroll
 					for (int c = 0; c < QR_PW; ++c)
-						tot[c] += a.slots[((size_t) q * G + t) * QR_SLOT + c];
+						tot[c] += xwg_load(a.slots + ((size_t) q * G + t) * QR_SLOT + c);
 				block_sum<QR_PW>(tot, s_part, s_S);
 				if (tid <= QR_PW)
-					s_head[tid] = a.head[q * (QR_PW + 1) + tid];
+					s_head[tid] = xwg_load(a.head + q * (QR_PW + 1) + tid);
 			} else {
 				if (tid < QR_PW) {
 					s_S[tid] = s_red[tid];
@@ -347,8 +331,10 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void qr_panel_
 		block_sum<QR_NPAIR>(acc2, s_part, s_red);
 		if (G > 1) {
 			if (tid < QR_NPAIR)
-				a.slots[((size_t) q * G + g) * QR_SLOT + tid] = s_red[tid];
-			if (!qr_grid_barrier(a.counter, a.counter_base + (unsigned long long) G * (bar + 1), &s_flag)) {
+				xwg_store(a.slots + ((size_t) q * G + g) * QR_SLOT + tid, s_red[tid]);
+			if (tid < 64)
+				xwg_publish(a.flags, g, a.epoch_base + (xwg_u64) (bar + 1), tid == 0);
+			if (!xwg_wait_all(a.flags, G, a.epoch_base + (xwg_u64) (bar + 1), &s_flag)) {
 				if (tid == 0)
 					atomicExch(a.status + 2, 1);
 				return;
@@ -361,7 +347,7 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void qr_panel_
 				for (int t = tid; t < G; t += 256)
 #pragma unroll
 					for (int p = 0; p < QR_NPAIR; ++p)
-						tot[p] += a.slots[((size_t) q * G + t) * QR_SLOT + p];
+						tot[p] += xwg_load(a.slots + ((size_t) q * G + t) * QR_SLOT + p);
 				block_sum<QR_NPAIR>(tot, s_part, s_red);
 			}
 		}
@@ -383,8 +369,8 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void qr_panel_
 
 template <typename T> struct QrWork {
 	double *slots, *head;
-	unsigned long long *counter;
-	unsigned long long counter_base;
+	xwg_u64 *flags;
+	xwg_u64 epoch_base;
 	int *status;
 	const T *a_top; // A[0, 0]
 	idx_t rs, cs;
@@ -422,14 +408,14 @@ template <typename T> static void qr_leaf(MatV<T> P, MatV<T> Tb, idx_t row_abs, 
 	a.tcs = Tb.cs;
 	a.slots = wk.slots;
 	a.head = wk.head;
-	a.counter = wk.counter;
-	a.counter_base = wk.counter_base;
+	a.flags = wk.flags;
+	a.epoch_base = wk.epoch_base;
 	a.status = wk.status;
 	hipLaunchKernelGGL((qr_panel_kernel<T, RMAX>), dim3(G), dim3(256), 0, ctx().stream, a);
 	FH_HIP(hipGetLastError());
 	if (G > 1) {
 		const int steps = w < (int) m ? w : (int) m;
-		wk.counter_base += (unsigned long long) G * (steps + 1);
+		wk.epoch_base += (xwg_u64) (steps + 1);
 	}
 }
 
@@ -770,8 +756,10 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 		QrWork<T> wk;
 		wk.slots = slots.as<double>();
 		wk.head = head.as<double>();
-		wk.counter = misc.as<unsigned long long>();
-		wk.counter_base = 0;
+		Scratch flagb((size_t) QR_GMAX * sizeof(xwg_u64));
+		FH_HIP(hipMemsetAsync(flagb.p, 0, (size_t) QR_GMAX * sizeof(xwg_u64), s));
+		wk.flags = flagb.as<xwg_u64>();
+		wk.epoch_base = 0;
 		wk.status = status;
 		wk.a_top = A.p;
 		wk.rs = A.rs;

@@ -30,13 +30,22 @@ __global__ __launch_bounds__(64) void trsm_leaf_kernel(const T *__restrict__ Lp,
 	const int c0 = blockIdx.x * NB;
 	const int nc = min(NB, nrhs - c0);
 
-	// ---- stage the triangle (identity padded) ----
-	for (int e = lane; e < NB * NB; e += 64) {
-		const int i = e % NB, j = e / NB;
-		T v = (T) 0;
-		if (i < n && j < i)
-			v = Lp[(idx_t) i * lrs + (idx_t) j * lcs];
-		Ls[j * NB + i] = v;
+	// ---- stage the triangle (identity padded); 8 independent loads in flight per lane ----
+	for (int e0 = lane; e0 < NB * NB; e0 += 64 * 8) {
+		T v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int e = e0 + u * 64;
+			const int i = e % NB, j = e / NB;
+			const bool in = i < n && j < i;
+			const T x = Lp[in ? (idx_t) i * lrs + (idx_t) j * lcs : (idx_t) 0];
+			v[u] = in ? x : (T) 0;
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int e = e0 + u * 64;
+			Ls[(e / NB) * NB + e % NB] = v[u];
+		}
 	}
 	{
 		T d = (T) 1;
@@ -44,14 +53,35 @@ __global__ __launch_bounds__(64) void trsm_leaf_kernel(const T *__restrict__ Lp,
 			d = (T) 1 / Lp[(idx_t) lane * lrs + (idx_t) lane * lcs];
 		dinv[lane] = d;
 	}
-	// ---- stage X: lanes run along the dimension with the smaller stride ----
+	// ---- stage X: lanes run along the dimension with the smaller stride; batches of 8 loads ----
 	if (lanes_along_rhs) {
-		for (int i = 0; i < n; ++i)
-			Xs[i * XP + lane] = lane < nc ? Xp[(idx_t) i * xrs + (idx_t) (c0 + lane) * xcs] : (T) 0;
+		for (int i0 = 0; i0 < n; i0 += 8) {
+			T v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const bool in = i0 + u < n && lane < nc;
+				const T x = Xp[in ? (idx_t) (i0 + u) * xrs + (idx_t) (c0 + lane) * xcs : (idx_t) 0];
+				v[u] = in ? x : (T) 0;
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				if (i0 + u < n)
+					Xs[(i0 + u) * XP + lane] = v[u];
+		}
 	} else {
-		for (int c = 0; c < nc; ++c)
-			if (lane < n)
-				Xs[lane * XP + c] = Xp[(idx_t) lane * xrs + (idx_t) (c0 + c) * xcs];
+		for (int cc = 0; cc < nc; cc += 8) {
+			T v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const bool in = cc + u < nc && lane < n;
+				const T x = Xp[in ? (idx_t) lane * xrs + (idx_t) (c0 + cc + u) * xcs : (idx_t) 0];
+				v[u] = in ? x : (T) 0;
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				if (cc + u < nc && lane < n)
+					Xs[lane * XP + cc + u] = v[u];
+		}
 	}
 	__syncthreads();
 
