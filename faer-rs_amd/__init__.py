@@ -138,6 +138,9 @@ def lib():
     L.faer_hip_mfma_peak_tflops.restype = C.c_double
     L.faer_hip_dist_local_ncols.restype = C.c_size_t
     _LIB = L
+    import atexit
+
+    atexit.register(L.faer_hip_shutdown)
     return L
 
 

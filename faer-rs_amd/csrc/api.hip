@@ -437,6 +437,7 @@ void faer_hip_set_device(int device)
 void faer_hip_set_stream(void *s) { ctx().stream = static_cast<hipStream_t>(s); }
 void *faer_hip_get_stream(void) { return ctx().stream; }
 void faer_hip_synchronize(void) { ctx().sync(); }
+void faer_hip_shutdown(void) { fh::ctx_shutdown(); }
 void *faer_hip_malloc(size_t bytes)
 {
 	ctx();

@@ -66,6 +66,17 @@ struct Ctx {
 	std::vector<Buf> pool;
 	int *status = nullptr; // 16 ints of device status words (pinned-host readable copy below)
 	int *status_host = nullptr;
+	// Look-ahead execution (factorizations): two internal streams on DISJOINT sets of CUs
+	// (hipExtStreamCreateWithCUMask): `la_bulk` runs the trailing-matrix GEMMs on most of the chip, `la_panel`
+	// the latency-bound diagonal-block / panel work on a few reserved CUs, so neither queue can starve the other.
+	hipStream_t la_bulk = nullptr, la_panel = nullptr;
+	int la_state = 0; // 0: not tried, 1: available, -1: unavailable
+	int la_panel_cus = 32;
+	std::vector<hipEvent_t> la_events;
+	size_t la_next_event = 0;
+	bool lookahead_streams(); // creates the streams on first use; false if the runtime refuses
+	hipEvent_t next_event();  // timing-disabled events, recycled per factorization (reset_events)
+	void reset_events() { la_next_event = 0; }
 
 	void ensure_device();
 	void *alloc(size_t bytes); // returns a device buffer valid until release()
@@ -73,6 +84,16 @@ struct Ctx {
 	void sync() { FH_HIP(hipStreamSynchronize(stream)); }
 };
 Ctx &ctx();
+void ctx_shutdown(); // releases the calling thread's look-ahead streams / events; safe without a device
+
+// RAII: run the enclosed launches on another stream
+struct StreamScope {
+	hipStream_t saved;
+	explicit StreamScope(hipStream_t s) : saved(ctx().stream) { ctx().stream = s; }
+	~StreamScope() { ctx().stream = saved; }
+	StreamScope(const StreamScope &) = delete;
+	StreamScope &operator=(const StreamScope &) = delete;
+};
 
 // RAII scratch
 struct Scratch {

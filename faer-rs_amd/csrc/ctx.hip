@@ -13,6 +13,26 @@ Ctx &ctx()
 	return g_ctx;
 }
 
+void ctx_shutdown()
+{
+	Ctx &c = g_ctx; // no ensure_device(): must be callable (as a no-op) on a machine without a GPU
+	if (c.device < 0)
+		return;
+	(void) hipStreamSynchronize(c.stream);
+	for (hipEvent_t e : c.la_events)
+		(void) hipEventDestroy(e);
+	c.la_events.clear();
+	c.la_next_event = 0;
+	if (c.la_state > 0) {
+		(void) hipStreamSynchronize(c.la_bulk);
+		(void) hipStreamSynchronize(c.la_panel);
+		(void) hipStreamDestroy(c.la_bulk);
+		(void) hipStreamDestroy(c.la_panel);
+		c.la_bulk = c.la_panel = nullptr;
+	}
+	c.la_state = 0;
+}
+
 void Ctx::ensure_device()
 {
 	if (device >= 0)
@@ -27,6 +47,56 @@ void Ctx::ensure_device()
 	FH_HIP(hipGetDeviceProperties(&prop, d));
 	FH_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "libfaer_hip is built for gfx950 (MI355X) only");
 	device = d;
+}
+
+bool Ctx::lookahead_streams()
+{
+	if (la_state != 0)
+		return la_state > 0;
+	la_state = -1;
+	if (getenv("FAER_HIP_NO_LOOKAHEAD"))
+		return false;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+		return false;
+	const int ncu = prop.multiProcessorCount;
+	if (const char *e = getenv("FAER_HIP_PANEL_CUS"))
+		la_panel_cus = atoi(e);
+	if (la_panel_cus < 8 || la_panel_cus > ncu / 2 || ncu > 1024)
+		return false;
+	// CU i of the mask is enabled by bit i; the last `la_panel_cus` CUs go to the panel stream
+	uint32_t mb[32], mp[32];
+	memset(mb, 0, sizeof(mb));
+	memset(mp, 0, sizeof(mp));
+	for (int i = 0; i < ncu; ++i) {
+		uint32_t *m = i < ncu - la_panel_cus ? mb : mp;
+		m[i / 32] |= 1u << (i % 32);
+	}
+	const uint32_t words = (uint32_t) ((ncu + 31) / 32);
+	hipStream_t b = nullptr, p = nullptr;
+	if (hipExtStreamCreateWithCUMask(&b, words, mb) != hipSuccess) {
+		(void) hipGetLastError();
+		return false;
+	}
+	if (hipExtStreamCreateWithCUMask(&p, words, mp) != hipSuccess) {
+		(void) hipGetLastError();
+		(void) hipStreamDestroy(b);
+		return false;
+	}
+	la_bulk = b;
+	la_panel = p;
+	la_state = 1;
+	return true;
+}
+
+hipEvent_t Ctx::next_event()
+{
+	if (la_next_event == la_events.size()) {
+		hipEvent_t e;
+		FH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		la_events.push_back(e);
+	}
+	return la_events[la_next_event++];
 }
 
 void *Ctx::alloc(size_t bytes)

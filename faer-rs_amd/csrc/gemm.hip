@@ -884,16 +884,28 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	int shape = big ? 0 : 1; // 0: 128x128  1: 64x64  2: 32x128  3: 128x32
 	if (ex.inplace) {
 		FH_CHECK(!extra_path && kind == DST_FULL && !indexed, "gemm: in-place product must be a plain one");
+		// long free dimension: the 128 x 128 tile (fewer, fatter workgroups; one per CU is enough to fill the
+		// chip); short one: 32-wide tiles keep the launch wide.  Either way ONE tile spans the aliased dimension.
 		if (ex.inplace == 2) { // A aliases C: all of N inside one tile
 			FH_CHECK(n <= 128 && k == n, "gemm: in-place (A) product needs N == K <= 128");
-			bm = 32;
-			bn = 128;
-			shape = 2;
+			if (m >= 4096) {
+				bm = bn = 128;
+				shape = 0;
+			} else {
+				bm = 32;
+				bn = 128;
+				shape = 2;
+			}
 		} else { // B aliases C: all of M inside one tile
 			FH_CHECK(m <= 128 && k == m, "gemm: in-place (B) product needs M == K <= 128");
-			bm = 128;
-			bn = 32;
-			shape = 3;
+			if (n >= 4096) {
+				bm = bn = 128;
+				shape = 0;
+			} else {
+				bm = 128;
+				bn = 32;
+				shape = 3;
+			}
 		}
 	}
 	if (extra_path) {
@@ -935,11 +947,11 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		launch_cfg_p<T, 32, 128, 1, 4>(g, akm, bkm, splits);
 	else if (shape == 3)
 		launch_cfg_p<T, 128, 32, 4, 1>(g, akm, bkm, splits);
-	else if (legacy && big)
+	else if (legacy && shape == 0)
 		launch_cfg<T, 128, 128, 2, 2, false>(g, akm, bkm, splits);
 	else if (legacy)
 		launch_cfg<T, 64, 64, 2, 2, false>(g, akm, bkm, splits);
-	else if (big)
+	else if (shape == 0)
 		launch_cfg_p<T, 128, 128, 2, 2>(g, akm, bkm, splits);
 	else
 		launch_cfg_p<T, 64, 64, 2, 2>(g, akm, bkm, splits);

@@ -32,12 +32,13 @@ namespace fh {
 constexpr int POTRF_NB = LDS_NB;
 constexpr int POTRF_PB = 32; // panel width inside the leaf
 
-// sq = sqrt(d) and inv = 1 / sq for a wave-uniform d > 0: v_rsq + the coupled Newton iteration that the
-// compiler's own sqrt expansion uses (two residual corrections => sq is the correctly rounded root in all but
-// rare half-ulp cases), and the reciprocal from the same iteration's h ~ 1 / (2 sq) instead of a separate
-// 12-instruction division: this chain is the serial part of the leaf (128 dependent columns).
-// Outside a safe exponent range (and for d <= 0 / NaN) it falls back to the library sqrt and division.
-static __device__ __forceinline__ void sqrt_and_recip(double d, double &sq, double &inv)
+// inv = 1 / sqrt(d) for a wave-uniform d > 0 on the shortest dependent chain: v_rsq_f64, one coupled Newton
+// step for (g ~ sqrt d, h ~ 1 / (2 sqrt d)) and one more step for h: 7 dependent operations instead of the
+// ~25 of sqrt() followed by a division.  This chain is the serial part of the leaf (128 dependent columns);
+// the result is within an ulp or two of the reference's (1 / sqrt(d)) (cholesky/ldlt/factor.rs:160-163), well
+// inside the parity tolerance.  Outside a safe exponent range it falls back to the library sqrt and division.
+// Returns false for the reference's failure cases (!(d > 0), sqrt not finite or zero).
+static __device__ __forceinline__ bool recip_sqrt(double d, double &inv)
 {
 	if (d > 1e-280 && d < 1e280) {
 		const double y = __builtin_amdgcn_rsq(d);
@@ -45,26 +46,35 @@ static __device__ __forceinline__ void sqrt_and_recip(double d, double &sq, doub
 		double r = __builtin_fma(-h, g, 0.5);
 		g = __builtin_fma(g, r, g);
 		h = __builtin_fma(h, r, h);
-		double e = __builtin_fma(-g, g, d);
-		g = __builtin_fma(e, h, g);
-		e = __builtin_fma(-g, g, d);
-		g = __builtin_fma(e, h, g);
 		r = __builtin_fma(-h, g, 0.5);
 		h = __builtin_fma(h, r, h);
-		r = __builtin_fma(-h, g, 0.5);
-		h = __builtin_fma(h, r, h);
-		sq = g;
 		inv = h + h;
-	} else {
-		sq = sqrt(d);
-		inv = 1.0 / sq;
+		return true;
 	}
+	const double sq = sqrt(d);
+	inv = 1.0 / sq;
+	return d > 0.0 && sq != 0.0 && isfinite(sq);
 }
-static __device__ __forceinline__ void sqrt_and_recip(float d, float &sq, float &inv)
+static __device__ __forceinline__ bool recip_sqrt(float d, float &inv)
 {
-	sq = sqrtf(d);
+	const float sq = sqrtf(d);
 	inv = 1.0f / sq;
+	return d > 0.0f && sq != 0.0f && isfinite(sq);
 }
+
+#ifdef FH_LEAF_TIMING
+#define FH_LT(i)                                                                                                         \
+	do {                                                                                                             \
+		const long long now_ = (long long) __builtin_readcyclecounter();                                         \
+		tacc[i] += now_ - tlast;                                                                                 \
+		tlast = now_;                                                                                            \
+	} while (0)
+__device__ unsigned long long g_leaf_timing[8];
+#else
+#define FH_LT(i)                                                                                                         \
+	do {                                                                                                             \
+	} while (0)
+#endif
 
 template <typename T>
 __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_t cs, int n, int regularize, T eps, T delta,
@@ -77,8 +87,13 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 		return; // an earlier block already failed
 	if (tid == 0)
 		s_fail = 0;
+#ifdef FH_LEAF_TIMING
+	long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	long long tlast = (long long) __builtin_readcyclecounter();
+#endif
 	lds_load_lower<T>(S, A, rs, cs, n);
 	__syncthreads();
+	FH_LT(0);
 
 	const int np = (n + POTRF_PB - 1) / POTRF_PB * POTRF_PB; // identity padded
 	int count = 0;
@@ -97,31 +112,52 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 			for (int c = 0; c < POTRF_PB; ++c)
 				a[c] = S[(j0 + c) * LDS_LDP + rr];
 			int fail_col = 0;
+			// the reciprocal root of column j is computed one iteration ahead, right after the diagonal entry
+			// a_jj has received its last update through the register path, so that the long latencies
+			// (rsq chain, LDS round trip of the multipliers) overlap instead of adding up
+			T inv;
+			bool ok;
+			{
+				T d = lane_bcast(a[0], 0);
+				if (regularize && d <= eps) { // cholesky/ldlt/factor.rs:122-131 (llt: sign == +1)
+					d = delta;
+					if (j0 < n)
+						++count;
+				}
+				ok = recip_sqrt(d, inv);
+			}
 #pragma unroll
 			for (int j = 0; j < POTRF_PB; ++j) {
 				if (fail_col == 0) { // wave uniform
-					T d = lane_bcast(a[j], j); // a_jj lives in lane j (diagonal rows)
-					if (regularize && d <= eps) { // cholesky/ldlt/factor.rs:122-131 (llt: sign == +1)
-						d = delta;
-						if (j0 + j < n)
-							++count;
-					}
-					T sq, inv;
-					sqrt_and_recip(d, sq, inv);
-					if (!(d > (T) 0) || sq == (T) 0 || !isfinite(sq)) {
+					if (!ok) {
 						fail_col = j0 + j + 1;
 					} else {
 						const T lj = a[j] * inv; // column j, diagonal entry included (factor.rs:160-174)
 						// column j is final: park it in the block image (every panel wave writes the same
-						// diagonal-block values) and fetch the multipliers l_kj back as broadcast reads --
-						// LDS operations of one wavefront execute in order
+						// diagonal-block values); the multipliers l_kj, k >= j + 2, come back as broadcast reads
+						// (LDS operations of one wavefront execute in order)
 						T *colj = S + (j0 + j) * LDS_LDP;
 						if (valid && (!diag_lane || lane >= j))
 							colj[row] = lj;
 						__builtin_amdgcn_wave_barrier();
+						T mult[POTRF_PB];
 #pragma unroll
-						for (int k = j + 1; k < POTRF_PB; ++k)
-							a[k] = __builtin_fma(-lj, colj[j0 + k], a[k]); // a_ik -= l_ij l_kj
+						for (int k = j + 2; k < POTRF_PB; ++k)
+							mult[k] = colj[j0 + k];
+						if (j + 1 < POTRF_PB) {
+							// critical path: next diagonal entry through v_readlane, then its reciprocal root
+							a[j + 1] = __builtin_fma(-lj, lane_bcast(lj, j + 1), a[j + 1]);
+							T d = lane_bcast(a[j + 1], j + 1);
+							if (regularize && d <= eps) {
+								d = delta;
+								if (j0 + j + 1 < n)
+									++count;
+							}
+							ok = recip_sqrt(d, inv);
+						}
+#pragma unroll
+						for (int k = j + 2; k < POTRF_PB; ++k)
+							a[k] = __builtin_fma(-lj, mult[k], a[k]); // a_ik -= l_ij l_kj
 					}
 				}
 			}
@@ -129,6 +165,7 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 				s_fail = fail_col;
 		}
 		__syncthreads();
+		FH_LT(1);
 		if (s_fail != 0) {
 			failed = true;
 			break;
@@ -163,9 +200,11 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 			}
 		}
 		__syncthreads();
+		FH_LT(2);
 	}
 	// ---- write back the lower triangle (also after a failure: the columns before the failing one are final)
 	lds_store_block<T>(S, A, rs, cs, n, true);
+	FH_LT(3);
 	if (failed) {
 		if (tid == 0)
 			atomicCAS(status, 0, offset + s_fail);
@@ -176,8 +215,15 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 	if (Winv) {
 		__syncthreads();
 		lds_tri_inv_inplace<T>(S, 0);
+		FH_LT(4);
 		lds_store_block<T>(S, Winv, 1, LDS_NB, LDS_NB, false);
+		FH_LT(5);
 	}
+#ifdef FH_LEAF_TIMING
+	if (tid == 0)
+		for (int i = 0; i < 8; ++i)
+			atomicAdd(&g_leaf_timing[i], (unsigned long long) tacc[i]);
+#endif
 }
 
 template <typename T>
@@ -203,6 +249,143 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 	potrf_rec<T>(A11, regularize, eps, delta, status, offset + h, Wbase, need_inv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Full inverse of a diagonal step block from the inverses of its 128-blocks (recursive doubling,
+// inv([L11 0; L21 L22]) = [W11 0; -W22 L21 W11, W22], every product an MFMA GEMM).  The look-ahead driver
+// builds it on the panel stream so that the panel solve of the bulk stream is two large GEMMs instead of a
+// recursion of many skinny ones.
+// ------------------------------------------------------------------------------------------------
+template <typename T> __global__ void place_diag_blocks_kernel(T *Wf, idx_t ld, const T *Wblk)
+{
+	// workgroup b copies the 128 x 128 inverse of block b onto the diagonal of Wf
+	const T *src = Wblk + (size_t) blockIdx.x * POTRF_NB * POTRF_NB;
+	T *dst = Wf + (idx_t) blockIdx.x * POTRF_NB * (ld + 1);
+	for (int e = threadIdx.x; e < POTRF_NB * POTRF_NB; e += blockDim.x) {
+		const int i = e % POTRF_NB, j = e / POTRF_NB;
+		dst[(idx_t) j * ld + i] = src[e];
+	}
+}
+
+template <typename T> static void tri_inv_full(MatV<const T> L, const T *Wblk, MatV<T> Wf, MatV<T> Tmp)
+{
+	const idx_t n = L.nrows;
+	FH_CHECK(n % POTRF_NB == 0 && Wf.nrows == n && Wf.ncols == n && Wf.rs == 1, "tri_inv_full: shape");
+	fill_dev<T>(Wf, DST_FULL, (T) 0);
+	hipLaunchKernelGGL(place_diag_blocks_kernel<T>, dim3((unsigned) (n / POTRF_NB)), dim3(256), 0, ctx().stream, Wf.p, Wf.cs,
+			   Wblk);
+	FH_HIP(hipGetLastError());
+	for (idx_t h = POTRF_NB; h < n; h *= 2)
+		for (idx_t base = 0; base + h < n; base += 2 * h) {
+			const idx_t h2 = (n - base - h) < h ? (n - base - h) : h; // rows of the lower block (ragged tail)
+			MatV<const T> W11 = Wf.sub(base, base, h, h).c(), W22 = Wf.sub(base + h, base + h, h2, h2).c();
+			MatV<T> Tm = Tmp.sub(base + h, base, h2, h), W21 = Wf.sub(base + h, base, h2, h);
+			gemm_dev<T>(Tm, DST_FULL, false, L.sub(base + h, base, h2, h), W11, (T) 1);
+			gemm_dev<T>(W21, DST_FULL, false, W22, Tm.c(), (T) -1);
+		}
+}
+
+// Right-looking driver with look-ahead for large matrices: steps of LA_NB columns,
+//     [panel stream]  D_k = chol(A_kk)                         (recursive driver above; latency bound, few CUs)
+//     [bulk stream]   P_k = A_{>k,k} L_kk^-T                   (MFMA products against the leaf inverses)
+//     [bulk stream]   A_{k+1,k+1} -= P_k[0] P_k[0]^T           -> releases D_{k+1} on the panel stream
+//     [bulk stream]   rest of the trailing matrix -= P_k P_k^T (K = LA_NB: compute bound)
+// The diagonal-block factorizations -- a chain of ~130 small dependent launches each -- run concurrently with
+// the trailing update of the previous step on CUs reserved for them (Ctx::lookahead_streams), instead of
+// leaving 255 CUs idle.  Same arithmetic per entry as the reference's right-looking sweep
+// (cholesky/ldlt/factor.rs:367-498) with a larger step.
+constexpr idx_t LA_NB = 1024;
+constexpr idx_t LA_TAIL = 0; // trailing size at which the pipeline would hand over to the recursive driver (measured: never pays)
+
+template <typename T>
+static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *status, T *Wbase, hipStream_t caller)
+{
+	Ctx &c = ctx();
+	const idx_t n = A.nrows;
+	const idx_t nsteps = (n + LA_NB - 1) / LA_NB;
+	c.reset_events();
+	hipEvent_t e0 = c.next_event();
+	FH_HIP(hipEventRecord(e0, caller));
+	FH_HIP(hipStreamWaitEvent(c.la_bulk, e0, 0));
+	FH_HIP(hipStreamWaitEvent(c.la_panel, e0, 0));
+	// workspaces: two full step-block inverses (double buffered over the steps), a temporary for building them,
+	// and the out-of-place result of the panel solve
+	Scratch wfb((size_t) 2 * LA_NB * LA_NB * sizeof(T)), tmb((size_t) LA_NB * LA_NB * sizeof(T));
+	Scratch xb((size_t) (n - LA_NB) * LA_NB * sizeof(T));
+	auto Wfull = [&](idx_t k) { return MatV<T>{wfb.as<T>() + (size_t) (k & 1) * LA_NB * LA_NB, LA_NB, LA_NB, 1, LA_NB}; };
+	MatV<T> Tmp{tmb.as<T>(), LA_NB, LA_NB, 1, LA_NB};
+	hipEvent_t ev_diag; // D_k factored (and inverted)
+	{
+		StreamScope sc(c.la_panel);
+		const idx_t w = LA_NB < n ? LA_NB : n;
+		potrf_rec<T>(A.sub(0, 0, w, w), regularize, eps, delta, status, 0, Wbase, nsteps > 1);
+		if (nsteps > 1)
+			tri_inv_full<T>(A.sub(0, 0, LA_NB, LA_NB).c(), Wbase, Wfull(0), Tmp);
+		ev_diag = c.next_event();
+		FH_HIP(hipEventRecord(ev_diag, c.la_panel));
+	}
+	idx_t tail0 = n; // first column of the part finished by the recursive driver
+	for (idx_t k = 0; k + 1 < nsteps; ++k) {
+		const idx_t j0 = k * LA_NB, j1 = j0 + LA_NB; // panel columns [j0, j1)
+		const idx_t r = n - j1;			   // rows below
+		const idx_t w1 = LA_NB < r ? LA_NB : r;	   // width of the next diagonal block
+		MatV<T> Pk = A.sub(j1, j0, r, LA_NB);
+		hipEvent_t ev_upd;
+		const bool last = r <= LA_TAIL;
+		{
+			StreamScope sc(c.la_bulk);
+			FH_HIP(hipStreamWaitEvent(c.la_bulk, ev_diag, 0));
+			// P_k <- P_k L_kk^-T  (cholesky/ldlt/factor.rs:422-426) as P_k W_k^T, W_k = inv(L_kk) lower triangular:
+			// the left half of the result only needs the top-left quarter of W_k
+			{
+				const idx_t hh = LA_NB / 2;
+				MatV<T> X{xb.as<T>(), r, LA_NB, 1, r};
+				MatV<const T> W = Wfull(k).c();
+				gemm_dev<T>(X.sub(0, 0, r, hh), DST_FULL, false, Pk.sub(0, 0, r, hh).c(), W.sub(0, 0, hh, hh).t(), (T) 1);
+				gemm_dev<T>(X.sub(0, hh, r, hh), DST_FULL, false, Pk.c(), W.sub(hh, 0, hh, LA_NB).t(), (T) 1);
+				copy_dev<T>(Pk, X.c());
+			}
+			if (last) {
+				// the remaining trailing matrix is small: one update, then the recursive driver on the whole chip
+				// (a chain of look-ahead steps would be bound by the diagonal-block latency from here on)
+				gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, Pk.c(), Pk.t().c(), (T) -1);
+				tail0 = j1;
+				break;
+			}
+			// next diagonal block first
+			MatV<const T> P0 = Pk.sub(0, 0, w1, LA_NB).c();
+			gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, P0, P0.t(), (T) -1);
+			ev_upd = c.next_event();
+			FH_HIP(hipEventRecord(ev_upd, c.la_bulk));
+		}
+		// (the remainder of the trailing update is enqueued BEFORE the panel stream's ~130 launches so that the
+		// bulk queue never runs dry while the host is busy enqueuing)
+		if (r > w1) {
+			StreamScope sc(c.la_bulk);
+			MatV<const T> P0 = Pk.sub(0, 0, w1, LA_NB).c(), P1 = Pk.sub(w1, 0, r - w1, LA_NB).c();
+			// block column k+1 below its diagonal block, then the remaining square (lower part only)
+			gemm_dev<T>(A.sub(j1 + w1, j1, r - w1, w1), DST_FULL, true, P1, P0.t(), (T) -1);
+			gemm_dev<T>(A.sub(j1 + w1, j1 + w1, r - w1, r - w1), DST_LOWER, true, P1, P1.t(), (T) -1);
+		}
+		{
+			StreamScope sc(c.la_panel);
+			FH_HIP(hipStreamWaitEvent(c.la_panel, ev_upd, 0));
+			potrf_rec<T>(A.sub(j1, j1, w1, w1), regularize, eps, delta, status, j1, Wbase, k + 2 < nsteps);
+			if (k + 2 < nsteps)
+				tri_inv_full<T>(A.sub(j1, j1, LA_NB, LA_NB).c(), Wbase + (size_t) (j1 / POTRF_NB) * POTRF_NB * POTRF_NB,
+						Wfull(k + 1), Tmp);
+			ev_diag = c.next_event();
+			FH_HIP(hipEventRecord(ev_diag, c.la_panel));
+		}
+	}
+	// rejoin the caller's stream
+	hipEvent_t eb = c.next_event();
+	FH_HIP(hipEventRecord(eb, c.la_bulk));
+	FH_HIP(hipStreamWaitEvent(caller, eb, 0));
+	FH_HIP(hipStreamWaitEvent(caller, ev_diag, 0));
+	if (tail0 < n)
+		potrf_rec<T>(A.sub(tail0, tail0, n - tail0, n - tail0), regularize, eps, delta, status, tail0, Wbase, false);
+}
+
 template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps)
 {
 	FH_CHECK(A.nrows == A.ncols, "potrf: matrix must be square");
@@ -217,10 +400,21 @@ template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps)
 	const idx_t nblk = (n + POTRF_NB - 1) / POTRF_NB;
 	Scratch winv(n > POTRF_NB ? (size_t) nblk * POTRF_NB * POTRF_NB * sizeof(T) : 256);
 	const int regularize = (reg_delta > (T) 0 && reg_eps > (T) 0) ? 1 : 0; // cholesky/llt/factor.rs:85-86
-	potrf_rec<T>(A, regularize, reg_eps, reg_delta, status, 0, winv.as<T>(), false);
+	if (n >= 6 * LA_NB && ctx().lookahead_streams())
+		potrf_lookahead<T>(A, regularize, reg_eps, reg_delta, status, winv.as<T>(), ctx().stream);
+	else
+		potrf_rec<T>(A, regularize, reg_eps, reg_delta, status, 0, winv.as<T>(), false);
 	int h[2] = {0, 0};
 	FH_HIP(hipMemcpyAsync(h, status, sizeof(h), hipMemcpyDeviceToHost, ctx().stream));
 	ctx().sync();
+#ifdef FH_LEAF_TIMING
+	{
+		unsigned long long d[8];
+		FH_HIP(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_leaf_timing), sizeof(d)));
+		fprintf(stderr, "leaf timing (cycles, thread 0, cumulative): load %llu | panel %llu | syrk %llu | store %llu | inverse %llu | store W %llu\n",
+			d[0], d[1], d[2], d[3], d[4], d[5]);
+	}
+#endif
 	if (h[0] != 0)
 		return -(long) h[0]; // -(index + 1)
 	return (long) h[1];

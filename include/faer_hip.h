@@ -208,6 +208,9 @@ FAER_HIP_API void faer_hip_set_stream(void *hip_stream);
 FAER_HIP_API void *faer_hip_get_stream(void);
 /* Blocks until all work enqueued on the calling thread's stream is done. */
 FAER_HIP_API void faer_hip_synchronize(void);
+/* Releases the calling thread's internal look-ahead streams and events (they are re-created on demand).
+ * Call before unloading the library or at process exit. */
+FAER_HIP_API void faer_hip_shutdown(void);
 /* Device memory helpers for C clients without another allocator. */
 FAER_HIP_API void *faer_hip_malloc(size_t bytes);
 FAER_HIP_API void faer_hip_free(void *ptr);

@@ -110,6 +110,47 @@ def test_llt_full_size_property():
     assert r.abs().max().item() <= 64 * n * 2.3e-16 * (a.abs() @ x.abs()).max().item()
 
 
+@pytest.mark.parametrize("n", [4096, 4363, 5120 + 77])
+def test_llt_lookahead_path(n):
+    """n >= 4096 runs the look-ahead driver (two CU-masked streams, 1024-column steps; potrf.hip): ragged last
+    step, entrywise L L^T == A on the lower triangle, untouched strict upper triangle, same answer twice"""
+    import torch
+
+    F = init_gpu()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    b = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g)
+    a = (b @ b.t() + n * torch.eye(n, dtype=torch.float64, device="cuda")).t()
+    marked = a.clone()
+    iu = torch.triu_indices(n, n, 1, device="cuda")
+    marked[iu[0], iu[1]] = -7.5
+    l = marked.clone()
+    assert F.llt_factor_in_place(l) == 0
+    F.synchronize()
+    assert (l[iu[0], iu[1]] == -7.5).all().item()
+    L = torch.tril(l)
+    err = (torch.tril(L @ L.t() - a)).abs().max().item()
+    assert err <= 32 * n * 2.3e-16 * a.abs().max().item()
+    l2 = marked.clone()
+    assert F.llt_factor_in_place(l2) == 0
+    F.synchronize()
+    assert torch.equal(l, l2)
+
+
+def test_llt_lookahead_failure_index():
+    """first non-positive pivot deep inside a later step of the look-ahead driver: same index as the definition"""
+    import torch
+
+    F = init_gpu()
+    n, bad = 5000, 3333
+    g = torch.Generator(device="cuda").manual_seed(5)
+    b = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g)
+    a = (b @ b.t() + n * torch.eye(n, dtype=torch.float64, device="cuda")).t().clone()
+    a[bad, bad] = -1.0
+    with pytest.raises(F.LltError) as ei:
+        F.llt_factor_in_place(a)
+    assert ei.value.index == bad
+
+
 # -------------------------------------------------------------------------------------------- lu
 @pytest.mark.parametrize("m,n", [(1, 1), (2, 2), (3, 3), (31, 31), (32, 32), (33, 33), (128, 128), (255, 255), (256, 256),
                                  (257, 257), (300, 8), (8, 300), (40, 17), (17, 40), (1000, 1000), (2000, 64)])

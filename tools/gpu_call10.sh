@@ -1,0 +1,12 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_factor.py -m gpu -q -x -k "llt" > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+tail -4 gpurun_out/pytest_gpu.log
+timeout 300 python tools/gpu_diag.py llt > gpurun_out/diag_call10.log 2>&1; echo "diag rc=$?"
+cat gpurun_out/diag_call10.log
+FAER_HIP_NO_LOOKAHEAD=1 timeout 300 python tools/gpu_diag.py llt 2>&1 | tail -1
+FAER_HIP_PANEL_CUS=16 timeout 300 python tools/gpu_diag.py llt 2>&1 | tail -1
+FAER_HIP_PANEL_CUS=64 timeout 300 python tools/gpu_diag.py llt 2>&1 | tail -1
+rm -rf gpurun_out/prof_llt10
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_llt10 -o llt -- python bench.py --workload llt --steps 3 --warmup 1 --no-extras --no-cpu > gpurun_out/prof_llt10.log 2>&1; echo "prof rc=$?"

@@ -66,7 +66,7 @@ def timeit(fn, reps=3):
 
 
 if "llt" in which:
-    for n in (4096, 16384):
+    for n in (4096, 8192, 16384):
         a = colmajor(n, n, seed=3)
         spd = (a @ a.t() + n * torch.eye(n, dtype=torch.float64, device="cuda")).t()
         work = spd.clone()
@@ -83,7 +83,7 @@ if "llt" in which:
         del a, spd, work
 
 if "lu" in which:
-    for n in (4096, 16384):
+    for n in (4096, 8192, 16384):
         a = colmajor(n, n, seed=4)
         work = a.clone()
 
