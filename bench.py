@@ -111,6 +111,21 @@ def main():
             return step, n ** 3 / 3.0, lambda: work.copy_(spd), f"llt_f64_n{n}", "f64"
         if name == "lu":
             n = n_override or 16384
+            if world > 1:
+                # BASELINE.json configs[3]: 1-D block-cyclic columns over the ranks, RCCL broadcast of each factored
+                # panel (csrc/dist_lu.h); the total work is fixed => strong scaling
+                nb = 512
+                ncols = F.dist_local_ncols(n, nb, rank, world)
+                a = colmajor(n, ncols, torch.float64, 40 + rank)
+                work = a.clone()
+                nsc = L.faer_hip_dist_panel_ws_scalars(C.c_size_t(n), C.c_size_t(nb), C.c_int(F.DTYPE_F64))
+                ws = torch.empty(nsc, dtype=torch.float64, device=dev)
+
+                def step():
+                    work.copy_(a)
+                    F.dist_partial_piv_lu(work, n, nb, rank, world, lambda t, root: dist.broadcast(t, src=root), panel_ws=ws)
+
+                return step, 2.0 * n ** 3 / 3.0 / world, lambda: work.copy_(a), f"lu_f64_n{n}_blockcyclic{nb}", "f64"
             a = colmajor(n, n, torch.float64, 4)
             work = a.clone()
 
@@ -173,12 +188,14 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (args.workload == "lu" and world > 1) else "weak",
         "vs_baseline": None,
         "dtype": dtype_name,
         "data": "synthetic",
         "config": {"workload": label, "layout": "column-major, resident in HBM",
-                   "sharding": "none" if world == 1 else f"block columns of C over {world} GPUs, no collective"},
+                   "sharding": "none" if world == 1 else (
+                       f"1-D block-cyclic columns over {world} GPUs, one RCCL broadcast per factored panel" if args.workload == "lu"
+                       else f"block columns of C over {world} GPUs, no collective")},
     }
 
     if rank == 0:

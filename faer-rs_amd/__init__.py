@@ -137,6 +137,7 @@ def lib():
     L.faer_hip_time_gemm_ms.restype = C.c_double
     L.faer_hip_mfma_peak_tflops.restype = C.c_double
     L.faer_hip_dist_local_ncols.restype = C.c_size_t
+    L.faer_hip_dist_panel_ws_scalars.restype = C.c_size_t
     _LIB = L
     import atexit
 
@@ -288,6 +289,52 @@ def partial_piv_lu_factor_in_place(a, index_dtype=np.uint64, par=PAR_SEQ):
     params = getattr(L, f"libfaer_v0_23_PartialPivLuParams_{suf}")()
     st = getattr(L, f"libfaer_v0_23_partial_piv_lu_factor_in_place_{it}_{suf}")(
         _mat(a, MatMut), SliceMut(fwd.ctypes.data, m), SliceMut(bwd.ctypes.data, m), par, MemAlloc(None, 0), params)
+    if st.tag != 0:
+        raise RuntimeError("PartialPivLuStatus::Unknown")
+    return fwd, bwd, st.transposition_count
+
+
+BcastFn = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+
+
+class HipComm(C.Structure):
+    """include/faer_hip.h FaerHipComm {rank, world_size, bcast, user}"""
+    _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("bcast", BcastFn), ("user", C.c_void_p)]
+
+
+def dist_local_ncols(n, nb, rank, world_size):
+    return lib().faer_hip_dist_local_ncols(C.c_size_t(n), C.c_size_t(nb), int(rank), int(world_size))
+
+
+def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast, panel_ws=None):
+    """Distributed partial-pivot LU (1-D block-cyclic columns, one process per GPU; csrc/dist_lu.h).
+
+    a_local  : this rank's block columns (nrows x dist_local_ncols, column major torch cuda tensor), factored in place
+    bcast    : callable(torch uint8 tensor viewing the DEVICE broadcast buffer, root) -- the transport, e.g.
+               lambda t, root: torch.distributed.broadcast(t, src=root)   (RCCL under the "nccl" backend)
+    returns  : (perm_fwd, perm_bwd, transposition_count), identical on every rank"""
+    import torch
+
+    suf, _, _ = _dtype_suffix(a_local)
+    m = a_local.shape[0]
+    L = lib()
+    dt = DTYPE_F64 if suf == "f64" else DTYPE_F32
+    if panel_ws is None:
+        nsc = L.faer_hip_dist_panel_ws_scalars(C.c_size_t(m), C.c_size_t(nb), C.c_int(dt))
+        panel_ws = torch.empty(nsc, dtype=a_local.dtype, device=a_local.device)
+    ws_bytes = panel_ws.view(torch.uint8)
+    base = panel_ws.data_ptr()
+
+    def cb(user, buf, nbytes, root):
+        off = buf - base
+        bcast(ws_bytes[off:off + nbytes], root)
+
+    comm = HipComm(int(rank), int(world_size), BcastFn(cb), None)
+    fwd = np.zeros(m, dtype=np.uint64)
+    bwd = np.zeros(m, dtype=np.uint64)
+    st = getattr(L, f"faer_hip_dist_partial_piv_lu_{suf}")(_mat(a_local, MatMut), C.c_size_t(n_global), C.c_size_t(nb),
+                                                            SliceMut(fwd.ctypes.data, m), SliceMut(bwd.ctypes.data, m), comm,
+                                                            C.c_void_p(base))
     if st.tag != 0:
         raise RuntimeError("PartialPivLuStatus::Unknown")
     return fwd, bwd, st.transposition_count

@@ -202,6 +202,12 @@ template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps);
 // partial pivot LU; perm/perm_inv are HOST arrays of idx_t (m entries)   (getrf.hip)
 template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv);
 
+// pieces of the LU driver used by the distributed driver (dist.hip): in-place factorization of an m x w panel
+// (w <= m) with the pivots left on the device (piv_dev[j] = row swapped with row j, relative to the panel), and
+// the application of such a transposition list to the rows of another block
+template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev);
+template <typename T> void laswp_rows_dev(MatV<T> B, const int *piv_dev, int nt);
+
 // Householder QR without pivoting (qr.hip); H is block_size x min(m,n) (device). returns rank
 template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold);
 template <typename T>

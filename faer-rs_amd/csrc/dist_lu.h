@@ -1,0 +1,118 @@
+// Distributed partial-pivot LU over a 1-D block-cyclic column partition: one process per
+// GPU, ONE exchange per block column -- a broadcast of {factored panel, its pivots} from the owner -- and purely
+// local row interchanges / triangular solves / trailing updates.  The caller owns the transport
+// (FaerHipComm::bcast: RCCL through torch.distributed in bench.py, gloo in the CPU tests).
+//
+// The orchestration is a template over a backend so that the world_size > 1 control flow can be exercised
+// without a GPU: dist.hip instantiates it with the device backend (the HIP kernels of getrf/trsm/gemm), the CPU
+// test suite with a small host backend that lives under tests/ (never linked into libfaer_hip.so).
+//
+// Same mathematics as the single-GPU driver (lu/partial_pivoting/factor.rs:68-187): the panel is factored by the
+// same recursive code on the owner, so pivots follow the reference's rule; the row interchanges reach every
+// column of every rank (factor.rs:127-185), A01 <- L00^-1 A01 and A11 -= A10 A01 run on the owners of the columns.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace fh {
+
+// Backend concept (B):
+//   typedef scalar T;
+//   struct View { T *p; long nrows, ncols, rs, cs; }   -- element (i, j) at p[i * rs + j * cs]
+//   void factor_panel(View P, int *piv_out)              -- in-place LU of the m x w panel; piv_out: w ints in the
+//                                                           same memory space as the matrix ("device" ints),
+//                                                           piv_out[j] = row (relative to the panel's row 0) swapped with j
+//   void laswp(View Bm, const int *piv, int nt)          -- applies (j <-> piv[j]), j < nt, to the rows of Bm
+//   void trsm_unit_lower(View L, View X)                 -- X <- L^-1 X
+//   void gemm_sub(View C, View A, View Bm)               -- C -= A * Bm
+//   void pack(View src, T *dst) / unpack                 -- contiguous column-major copies to / from the panel buffer
+//   void bcast(void *buf, size_t bytes, int root)        -- collective on the backend's memory space
+//   void to_host(int *dst, const int *src, size_t n)     -- pivots back to the host (synchronising)
+template <class B> struct DistLu {
+	typedef typename B::T T;
+	typedef typename B::View View;
+
+	static size_t hdr_scalars(long nb) { return ((size_t) nb * sizeof(int) + sizeof(T) - 1) / sizeof(T); }
+	static size_t ws_scalars(long m, long nb) { return hdr_scalars(nb) + (size_t) m * (size_t) nb; }
+
+	static size_t local_ncols(size_t n, size_t nb, int rank, int world)
+	{
+		const size_t nblk = (n + nb - 1) / nb;
+		size_t cols = 0;
+		for (size_t b = (size_t) rank; b < nblk; b += (size_t) world)
+			cols += (b + 1) * nb <= n ? nb : n - b * nb;
+		return cols;
+	}
+
+	// A_local: m x local_ncols (this rank's block columns, in increasing global order, contiguous).
+	// panel_ws: >= ws_scalars(m, nb) scalars in the backend's memory space: [pivots (nb ints) | packed panel].
+	// piv_host: min(m, n) ints, filled on every rank with ABSOLUTE pivot rows.
+	static void run(B &be, View A_local, long m, long n, long nb, int rank, int world, T *panel_ws, int *piv_host)
+	{
+		const long size = m < n ? m : n;
+		const long nblk = (size + nb - 1) / nb; // block columns that get factored
+		const long nblk_all = (n + nb - 1) / nb;
+		auto local_col0 = [&](long b) { // first local column of global block b (owned by this rank)
+			long c = 0;
+			for (long bb = rank; bb < b; bb += world)
+				c += (bb + 1) * nb <= n ? nb : n - bb * nb;
+			return c;
+		};
+		auto view = [&](long r0, long c0, long nr, long nc) {
+			return View{A_local.p + r0 * A_local.rs + c0 * A_local.cs, nr, nc, A_local.rs, A_local.cs};
+		};
+		int *piv_dev = reinterpret_cast<int *>(panel_ws); // header of the panel buffer
+		T *panel = panel_ws + hdr_scalars(nb);
+		std::vector<int> piv_blk((size_t) nb);
+		for (long k = 0; k < nblk; ++k) {
+			const int owner = (int) (k % world);
+			const long j0 = k * nb;
+			const long w = (j0 + nb <= size) ? nb : size - j0; // columns factored in this block
+			const long wcols = (j0 + nb <= n) ? nb : n - j0;     // columns the block really has (m < n tail)
+			const long rows = m - j0;
+			// ---- 1. the owner factors its panel in place and packs it
+			if (rank == owner) {
+				const long lc = local_col0(k);
+				be.factor_panel(view(j0, lc, rows, w), piv_dev);
+				be.pack(view(j0, lc, rows, w), panel);
+			}
+			// ---- 2. ONE broadcast per block column: panel (rows x w) + pivots
+			be.bcast(panel_ws, (hdr_scalars(nb) + (size_t) rows * (size_t) w) * sizeof(T), owner);
+			be.to_host(piv_blk.data(), piv_dev, (size_t) w);
+			for (long j = 0; j < w; ++j)
+				piv_host[j0 + j] = (int) (j0 + piv_blk[(size_t) j]);
+			// ---- 3. every rank: interchanges on all its other columns, then solve + update its later blocks
+			View Lp{panel, rows, w, 1, rows}; // packed panel: unit lower trapezoid (U11 in its top triangle)
+			for (long b = rank; b < nblk_all; b += world) {
+				const long bc0 = b * nb;
+				const long bw = (bc0 + nb <= n) ? nb : n - bc0;
+				const long lc = local_col0(b);
+				if (b == k) {
+					// the owner's panel columns were swapped by the panel factorization itself; a wider block
+					// (m < n tail) still has columns to the right of the factored ones
+					if (wcols > w) {
+						View R = view(j0, lc + w, rows, wcols - w);
+						be.laswp(R, piv_dev, (int) w);
+						be.trsm_unit_lower(View{Lp.p, w, w, Lp.rs, Lp.cs}, View{R.p, w, R.ncols, R.rs, R.cs});
+						if (rows > w)
+							be.gemm_sub(View{R.p + w * R.rs, rows - w, R.ncols, R.rs, R.cs},
+								    View{Lp.p + w * Lp.rs, rows - w, w, Lp.rs, Lp.cs}, View{R.p, w, R.ncols, R.rs, R.cs});
+					}
+					continue;
+				}
+				View Bk = view(j0, lc, rows, bw);
+				be.laswp(Bk, piv_dev, (int) w);
+				if (b > k) {
+					View top{Bk.p, w, bw, Bk.rs, Bk.cs};
+					be.trsm_unit_lower(View{Lp.p, w, w, Lp.rs, Lp.cs}, top); // A01 <- L00^-1 A01 (factor.rs:98-107)
+					if (rows > w)
+						be.gemm_sub(View{Bk.p + w * Bk.rs, rows - w, bw, Bk.rs, Bk.cs},
+							    View{Lp.p + w * Lp.rs, rows - w, w, Lp.rs, Lp.cs}, top); // A11 -= A10 A01 (:108-117)
+				}
+			}
+		}
+	}
+};
+
+} // namespace fh

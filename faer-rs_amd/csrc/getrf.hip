@@ -782,6 +782,40 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 	return n_trans;
 }
 
+template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev)
+{
+	const idx_t m = P.nrows, w = P.ncols;
+	FH_CHECK(w <= m, "getrf_panel: the panel must be tall");
+	if (w == 0)
+		return;
+	Scratch slotv((size_t) 2 * LU2_GMAX * LU2_SLOT * sizeof(double));
+	Scratch diag((size_t) 2 * LU_W * sizeof(double));
+	Scratch misc(256);
+	Scratch flagb((size_t) LU2_GMAX * sizeof(xwg_u64));
+	LuWork<T> wk;
+	wk.piv = piv_dev;
+	wk.slot_val = slotv.as<double>();
+	wk.slot_row = nullptr;
+	wk.diag_row = diag.as<double>();
+	wk.flags = flagb.as<xwg_u64>();
+	wk.epoch_base = 0;
+	wk.status = misc.as<int>() + 8;
+	wk.dbg = nullptr;
+	FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
+	FH_HIP(hipMemsetAsync(flagb.p, 0, (size_t) LU2_GMAX * sizeof(xwg_u64), ctx().stream));
+	getrf_rec<T>(P, 0, 0, wk);
+	int st[4] = {0, 0, 0, 0};
+	FH_HIP(hipMemcpyAsync(st, wk.status, sizeof(st), hipMemcpyDeviceToHost, ctx().stream));
+	ctx().sync(); // the scratch buffers above are released on return
+	FH_CHECK(st[2] == 0, "partial_piv_lu: device exchange timed out in the panel kernel");
+}
+
+template <typename T> void laswp_rows_dev(MatV<T> B, const int *piv_dev, int nt) { laswp_dev<T>(B, piv_dev, nt, 0); }
+
+template void getrf_panel_dev<double>(MatV<double>, int *);
+template void getrf_panel_dev<float>(MatV<float>, int *);
+template void laswp_rows_dev<double>(MatV<double>, const int *, int);
+template void laswp_rows_dev<float>(MatV<float>, const int *, int);
 template long getrf_dev<double>(MatV<double>, idx_t *, idx_t *);
 template long getrf_dev<float>(MatV<float>, idx_t *, idx_t *);
 

@@ -239,10 +239,15 @@ typedef struct FaerHipComm { int rank; int world_size; FaerHipBcastFn bcast; voi
 
 /* Number of block columns of width `nb` owned by `rank` out of n columns distributed block-cyclically. */
 FAER_HIP_API size_t faer_hip_dist_local_ncols(size_t n, size_t nb, int rank, int world_size);
+/* Scalars of device scratch the distributed LU needs for its broadcast buffer ({pivots, packed panel}). */
+FAER_HIP_API size_t faer_hip_dist_panel_ws_scalars(size_t nrows, size_t nb, FaerHipDType dtype);
 /* Distributed partial-pivot LU of an m x n matrix whose block columns (width nb) are dealt block-cyclically
  * over comm.world_size ranks; A_local holds this rank's columns (m x local_ncols, device memory, col-major).
  * perm_fwd / perm_bwd (m entries, u64, HOST memory) are filled on every rank.  `panel_ws` is device scratch of
- * at least m*nb scalars.  Same pivoting rule and result as the single-GPU entry point. */
+ * faer_hip_dist_panel_ws_scalars(m, nb) scalars.  Per block column: the owner factors its m_k x nb panel with
+ * the single-GPU panel code (same pivoting rule, lu/partial_pivoting/factor.rs:19-187), ONE broadcast ships
+ * {pivots, panel}, every rank applies the interchanges, the unit-lower solve and the trailing update to its own
+ * columns (csrc/dist_lu.h). */
 FAER_HIP_API FaerPartialPivLuStatus faer_hip_dist_partial_piv_lu_f64(FaerMatMut A_local, size_t n_global, size_t nb, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerHipComm comm, void *panel_ws);
 FAER_HIP_API FaerPartialPivLuStatus faer_hip_dist_partial_piv_lu_f32(FaerMatMut A_local, size_t n_global, size_t nb, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerHipComm comm, void *panel_ws);
 

@@ -1,0 +1,110 @@
+// TEST INFRASTRUCTURE ONLY (never linked into libfaer_hip.so): a host-memory backend for the distributed-LU
+// orchestration template of faer-rs_amd/csrc/dist_lu.h, so that the world_size > 1 control flow (ownership,
+// ONE broadcast per block column, interchanges / solve / update on the right columns) can run under gloo on a
+// machine without a GPU.  The arithmetic here is a plain restatement of lu_in_place_unblocked
+// (faer/src/linalg/lu/partial_pivoting/factor.rs:19-67) and of the obvious triple loops.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../faer-rs_amd/csrc/dist_lu.h"
+
+typedef void (*BcastFn)(void *user, void *buf, size_t bytes, int root);
+
+struct HostBackend {
+	typedef double T;
+	struct View {
+		T *p;
+		long nrows, ncols, rs, cs;
+	};
+	BcastFn cb;
+	void *user;
+	long n_bcast = 0;
+	size_t bytes_bcast = 0;
+
+	static T &at(View v, long i, long j) { return v.p[i * v.rs + j * v.cs]; }
+	void factor_panel(View P, int *piv_out)
+	{
+		const long m = P.nrows, w = P.ncols;
+		for (long j = 0; j < w; ++j) {
+			// factor.rs:35-43: first row of strictly largest |a|, all-zero column keeps the diagonal
+			long p = j;
+			double best = 0.0;
+			for (long i = j; i < m; ++i) {
+				const double av = std::fabs(at(P, i, j));
+				if (av > best) {
+					best = av;
+					p = i;
+				}
+			}
+			piv_out[j] = (int) p;
+			if (p != j)
+				for (long c = 0; c < w; ++c)
+					std::swap(at(P, j, c), at(P, p, c));
+			const double inv = 1.0 / at(P, j, j);
+			for (long i = j + 1; i < m; ++i) {
+				at(P, i, j) *= inv;
+				const double l = at(P, i, j);
+				for (long c = j + 1; c < w; ++c)
+					at(P, i, c) = std::fma(l, -at(P, j, c), at(P, i, c));
+			}
+		}
+	}
+	void laswp(View B, const int *piv, int nt)
+	{
+		for (int j = 0; j < nt; ++j)
+			if (piv[j] != j)
+				for (long c = 0; c < B.ncols; ++c)
+					std::swap(at(B, j, c), at(B, piv[j], c));
+	}
+	void trsm_unit_lower(View L, View X)
+	{
+		for (long c = 0; c < X.ncols; ++c)
+			for (long i = 0; i < L.nrows; ++i) {
+				double s = at(X, i, c);
+				for (long k = 0; k < i; ++k)
+					s -= at(L, i, k) * at(X, k, c);
+				at(X, i, c) = s;
+			}
+	}
+	void gemm_sub(View C, View A, View B)
+	{
+		for (long j = 0; j < C.ncols; ++j)
+			for (long i = 0; i < C.nrows; ++i) {
+				double s = 0.0;
+				for (long k = 0; k < A.ncols; ++k)
+					s += at(A, i, k) * at(B, k, j);
+				at(C, i, j) -= s;
+			}
+	}
+	void pack(View src, T *dst)
+	{
+		for (long j = 0; j < src.ncols; ++j)
+			for (long i = 0; i < src.nrows; ++i)
+				dst[j * src.nrows + i] = at(src, i, j);
+	}
+	void bcast(void *buf, size_t bytes, int root)
+	{
+		++n_bcast;
+		bytes_bcast += bytes;
+		cb(user, buf, bytes, root);
+	}
+	void to_host(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
+};
+
+extern "C" {
+// returns the number of broadcasts issued; stats[0] = bytes broadcast
+long test_dist_lu_f64(double *a_local, long m, long local_ncols, long ld, long n, long nb, int rank, int world, BcastFn cb, void *user,
+		      int *piv_out, unsigned long long *stats)
+{
+	HostBackend be;
+	be.cb = cb;
+	be.user = user;
+	std::vector<double> ws(fh::DistLu<HostBackend>::ws_scalars(m, nb));
+	HostBackend::View A{a_local, m, local_ncols, 1, ld};
+	fh::DistLu<HostBackend>::run(be, A, m, n, nb, rank, world, ws.data(), piv_out);
+	stats[0] = be.bytes_bcast;
+	return be.n_bcast;
+}
+long test_dist_local_ncols(long n, long nb, int rank, int world) { return (long) fh::DistLu<HostBackend>::local_ncols(n, nb, rank, world); }
+}

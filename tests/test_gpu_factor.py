@@ -218,3 +218,25 @@ def test_plu_full_size_property():
     r = L @ (torch.triu(lu) @ x) - a[p] @ x
     scale = (L.abs() @ (torch.triu(lu).abs() @ x.abs())).max().item()
     assert r.abs().max().item() <= 64 * n * 2.3e-16 * scale
+
+
+# -------------------------------------------------------------------------------------------- distributed lu
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,nb", [(512, 512, 64), (1000, 1000, 128), (700, 500, 96), (300, 420, 64)])
+def test_dist_lu_device_backend_single_rank(oracle, m, n, nb):
+    """the device backend of the distributed LU (csrc/dist.hip) on ONE rank (the broadcast is the identity):
+    same pivots as the oracle, factors within tolerance, exactly one broadcast per block column.  The multi-rank
+    control flow of the same template is covered on CPU by tests/test_dist_lu.py (gloo, world_size 2 and 3)."""
+    F = init_gpu()
+    rng = np.random.default_rng(21)
+    a = rnd(rng, m, n)
+    ref = a.copy(order="F")
+    perm, perm_inv, nt = oracle.lu_in_place(ref)
+    da = to_dev(a)
+    calls = []
+    fwd, bwd, cnt = F.dist_partial_piv_lu(da, n, nb, 0, 1, lambda t, root: calls.append((t.numel(), root)))
+    got = to_host(da)
+    assert np.array_equal(fwd.astype(np.int64), perm) and np.array_equal(bwd.astype(np.int64), perm_inv) and cnt == nt
+    tol = 64 * max(m, n) * EPS[np.dtype(np.float64)]
+    assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max())
+    assert len(calls) == (min(m, n) + nb - 1) // nb and all(r == 0 for _, r in calls)
