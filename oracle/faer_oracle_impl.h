@@ -125,6 +125,8 @@ static void FN(matmul_triangular)(FN(mat) dst, int dst_s, int accum_add, FN(mat)
 				  FN(mat) rhs, int rhs_s, T alpha)
 {
 	long m = dst.nrows, n = dst.ncols, k = lhs.ncols;
+	/* every (i, j) is an independent k-ordered chain: threading over columns does not change any result */
+#pragma omp parallel for schedule(dynamic, 4) if ((double)m * n * k > 1e6)
 	for (long j = 0; j < n; j++)
 		for (long i = 0; i < m; i++) {
 			if (!FN(in_struct)(dst_s, i, j))

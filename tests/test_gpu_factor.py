@@ -240,3 +240,26 @@ def test_dist_lu_device_backend_single_rank(oracle, m, n, nb):
     tol = 64 * max(m, n) * EPS[np.dtype(np.float64)]
     assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max())
     assert len(calls) == (min(m, n) + nb - 1) // nb and all(r == 0 for _, r in calls)
+
+
+def test_llt_lookahead_is_deterministic_under_interleaved_work():
+    """the two-stream look-ahead driver (n = 8192 here) must give the bitwise same factor every time, also with
+    unrelated work queued around it (a cross-stream race would show up as a mismatch or a spurious failure)"""
+    import torch
+
+    F = init_gpu()
+    n = 8192
+    g = torch.Generator(device="cuda").manual_seed(17)
+    b = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g)
+    a = (b @ b.t() + n * torch.eye(n, dtype=torch.float64, device="cuda")).t()
+    ref = None
+    for it in range(6):
+        work = a.clone()
+        if it % 2 == 1:
+            _ = b @ b
+        assert F.llt_factor_in_place(work) == 0
+        F.synchronize()
+        if ref is None:
+            ref = work
+        else:
+            assert torch.equal(torch.tril(work), torch.tril(ref)), f"iteration {it} differs"
