@@ -62,6 +62,7 @@ struct Ctx {
 		void *p;
 		size_t bytes;
 		bool used;
+		hipStream_t owner; // stream whose work last used the buffer: reuse is stream ordered only on that stream
 	};
 	std::vector<Buf> pool;
 	int *status = nullptr; // 16 ints of device status words (pinned-host readable copy below)
@@ -82,9 +83,23 @@ struct Ctx {
 	void *alloc(size_t bytes); // returns a device buffer valid until release()
 	void release(void *p);
 	void sync() { FH_HIP(hipStreamSynchronize(stream)); }
+	// after a point where every internal stream has been joined AND the caller's stream synchronised: free
+	// buffers may be handed to any stream again
+	void quiesce();
 };
 Ctx &ctx();
 void ctx_shutdown(); // releases the calling thread's look-ahead streams / events; safe without a device
+
+// stream `s` waits for event `e`; with FAER_HIP_LA_HOSTSYNC set the HOST waits instead (debugging aid that
+// takes hipStreamWaitEvent out of the picture)
+inline void stream_wait(hipStream_t s, hipEvent_t e)
+{
+	static const bool hostsync = getenv("FAER_HIP_LA_HOSTSYNC") != nullptr;
+	if (hostsync)
+		FH_HIP(hipEventSynchronize(e));
+	else
+		FH_HIP(hipStreamWaitEvent(s, e, 0));
+}
 
 // RAII: run the enclosed launches on another stream
 struct StreamScope {

@@ -6,6 +6,7 @@
 namespace fh {
 
 static thread_local Ctx g_ctx;
+static const hipStream_t ANY_STREAM = reinterpret_cast<hipStream_t>(~(uintptr_t) 0);
 
 Ctx &ctx()
 {
@@ -74,6 +75,20 @@ bool Ctx::lookahead_streams()
 	}
 	const uint32_t words = (uint32_t) ((ncu + 31) / 32);
 	hipStream_t b = nullptr, p = nullptr;
+	if (getenv("FAER_HIP_LA_SAME")) { // debugging aid: ONE internal stream for both roles (no concurrency at all)
+		FH_HIP(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+		la_bulk = la_panel = b;
+		la_state = 1;
+		return true;
+	}
+	if (getenv("FAER_HIP_NO_CUMASK")) { // debugging aid: plain streams, no CU partition
+		FH_HIP(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+		FH_HIP(hipStreamCreateWithFlags(&p, hipStreamNonBlocking));
+		la_bulk = b;
+		la_panel = p;
+		la_state = 1;
+		return true;
+	}
 	if (hipExtStreamCreateWithCUMask(&b, words, mb) != hipSuccess) {
 		(void) hipGetLastError();
 		return false;
@@ -104,13 +119,16 @@ void *Ctx::alloc(size_t bytes)
 	if (bytes == 0)
 		bytes = 256;
 	bytes = (bytes + 255) & ~(size_t) 255;
-	// best fit among free buffers
+	// best fit among the free buffers last used on THIS stream (a buffer released by host code may still be in
+	// use by queued kernels: handing it to work on the same stream is ordered, to another stream it is a race)
 	int best = -1;
 	for (size_t i = 0; i < pool.size(); ++i)
-		if (!pool[i].used && pool[i].bytes >= bytes && (best < 0 || pool[i].bytes < pool[best].bytes))
+		if (!pool[i].used && (pool[i].owner == stream || pool[i].owner == ANY_STREAM) && pool[i].bytes >= bytes &&
+		    (best < 0 || pool[i].bytes < pool[best].bytes))
 			best = (int) i;
 	if (best >= 0 && pool[best].bytes <= 2 * bytes + (1 << 20)) {
 		pool[best].used = true;
+		pool[best].owner = stream;
 		return pool[best].p;
 	}
 	void *p = nullptr;
@@ -127,8 +145,15 @@ void *Ctx::alloc(size_t bytes)
 		}
 		FH_HIP(hipMalloc(&p, bytes));
 	}
-	pool.push_back(Buf{p, bytes, true});
+	pool.push_back(Buf{p, bytes, true, stream});
 	return p;
+}
+
+void Ctx::quiesce()
+{
+	for (auto &b : pool)
+		if (!b.used)
+			b.owner = ANY_STREAM;
 }
 
 void Ctx::release(void *p)

@@ -17,9 +17,9 @@
 //     workgroup picks the winner itself, patches the two swapped rows from the published copies and
 //     performs scale + rank-1 update on its own rows.  No second synchronisation per column;
 //   * the exchange follows the gfx950 recipe for in-launch hand-offs (xwg.h; cdna_hip_programming.md
-//     Guideline 16 R1): write-through (sc1) payload stores, one per-workgroup epoch flag, relaxed polling with
-//     s_sleep, sc1 loads on the consumer side -- no release/acquire fences.  Every spin is bounded; a timeout
-//     raises a device error instead of hanging.
+//     Guideline 16 R2): data-tagged 8-byte granules written with write-through (sc1) stores and read back with
+//     sc1 loads -- no flags, no fences, no store drain; two memory round trips per column.  Every spin is
+//     bounded; a timeout raises a device error instead of hanging.
 // Row interchanges of the outside columns are NOT applied one transposition at a time: the transposition
 // list is composed into a net row permutation in parallel (each row traces its source backwards through
 // the list) and applied as one gather.
@@ -53,209 +53,9 @@ static __device__ __forceinline__ void wave_argmax(double &v, int &r)
 	}
 }
 
-// Optional phase timing of the panel kernel (build with -DFH_PANEL_TIMING; tools/gpu_panel_timing.sh).
-#ifdef FH_PANEL_TIMING
-#define FH_T(i)                                                                                                          \
-	do {                                                                                                             \
-		const long long now_ = (long long) __builtin_readcyclecounter();                                         \
-		tacc[i] += now_ - tlast;                                                                                 \
-		tlast = now_;                                                                                            \
-	} while (0)
-#else
-#define FH_T(i)                                                                                                          \
-	do {                                                                                                             \
-	} while (0)
-#endif
-
-template <typename T> struct PanelArgs {
-	T *P;
-	idx_t rs, cs;
-	int m, w;   // panel shape
-	int R;	    // rows per workgroup
-	int *piv;   // piv[j] = row_base + pivot row (absolute index in the top-level matrix)
-	int row_base;
-	double *slot_val; // [2][G][1 + LU_W]  (candidate |a| then the candidate's panel row)
-	int *slot_row;	  // [2][G]
-	double *diag_row; // [2][LU_W]
-	xwg_u64 *flags;	  // [G] per-workgroup epoch flags (xwg.h)
-	xwg_u64 epoch_base;
-	int *status; // status[2] = exchange timeout flag
-	unsigned long long *dbg; // FH_PANEL_TIMING: 8 phase counters (cycles of workgroup 0, thread 0)
-};
-
-template <typename T, int RMAX> __global__ __launch_bounds__(256) void getrf_panel_kernel(const PanelArgs<T> a)
-{
-	__shared__ T Ps[LU_W * RMAX]; // Ps[c * RMAX + r]
-	__shared__ double s_v[4];
-	__shared__ int s_r[4];
-	__shared__ T s_piv[LU_W], s_diag[LU_W];
-	__shared__ int s_p, s_gw, s_flag;
-
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int g = blockIdx.x, G = gridDim.x;
-	const int r0 = g * a.R;
-	const int nr = min(a.R, a.m - r0);
-	const int w = a.w;
-#ifdef FH_PANEL_TIMING
-	long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	long long tlast = (long long) __builtin_readcyclecounter();
-#endif
-
-	for (int c = 0; c < w; ++c)
-		for (int r = tid; r < nr; r += 256)
-			Ps[c * RMAX + r] = a.P[(idx_t) (r0 + r) * a.rs + (idx_t) c * a.cs];
-	__syncthreads();
-	FH_T(0);
-
-	const int steps = min(w, a.m);
-	bool failed = false;
-	for (int j = 0; j < steps; ++j) {
-		const int q = j & 1;
-		// ---- 1. local arg-max of |a(:, j)| over owned rows >= j (first strictly largest)
-		double bv = 0.0;
-		int br = INT_MAX;
-		for (int r = tid; r < nr; r += 256) {
-			const int gr = r0 + r;
-			if (gr >= j) {
-				const double av = fabs((double) Ps[j * RMAX + r]);
-				if (av > bv) {
-					bv = av;
-					br = gr;
-				}
-			}
-		}
-		wave_argmax(bv, br);
-		if (lane == 0) {
-			s_v[wave] = bv;
-			s_r[wave] = br;
-		}
-		__syncthreads();
-		if (tid == 0) {
-			double v = s_v[0];
-			int r = s_r[0];
-			for (int k = 1; k < 4; ++k)
-				if (better(s_v[k], s_r[k], v, r)) {
-					v = s_v[k];
-					r = s_r[k];
-				}
-			if (!(v > 0.0))
-				r = INT_MAX; // zero / NaN-only column chunk: no candidate
-			s_p = r;
-			s_v[0] = v;
-		}
-		__syncthreads();
-		int p; // global pivot row
-		if (G == 1) {
-			p = s_p == INT_MAX ? j : s_p;
-			if (tid < w) {
-				s_piv[tid] = Ps[tid * RMAX + p];
-				s_diag[tid] = Ps[tid * RMAX + j];
-			}
-			__syncthreads();
-		} else {
-			FH_T(1);
-			// ---- 2. publish candidate (+ its panel row) and, from workgroup 0, the diagonal row: write-through
-			//         stores issued by wave 0 only, then this workgroup's flag (xwg.h)
-			const int cand = s_p;
-			double *sv = a.slot_val + ((size_t) q * G + g) * (1 + LU_W);
-			if (tid == 0) {
-				xwg_store_i(a.slot_row + q * G + g, cand);
-				xwg_store(sv, s_v[0]);
-			}
-			if (tid < w && cand != INT_MAX)
-				xwg_store(sv + 1 + tid, (double) Ps[tid * RMAX + (cand - r0)]);
-			if (g == 0 && tid < w)
-				xwg_store(a.diag_row + q * LU_W + tid, (double) Ps[tid * RMAX + j]); // row j < 32 <= R lives in chunk 0
-			if (tid < 64)
-				xwg_publish(a.flags, g, a.epoch_base + (xwg_u64) (j + 1), tid == 0);
-			FH_T(2);
-			// ---- 3. one all-to-all round per column
-			if (!xwg_wait_all(a.flags, G, a.epoch_base + (xwg_u64) (j + 1), &s_flag)) {
-				failed = true;
-				break;
-			}
-			FH_T(3);
-			// ---- 4. every workgroup picks the winner itself
-			double v = 0.0;
-			int r = INT_MAX, gw = 0;
-			for (int t = tid; t < G; t += 256) {
-				const int rr = xwg_load_i(a.slot_row + q * G + t);
-				const double vv = xwg_load(a.slot_val + ((size_t) q * G + t) * (1 + LU_W));
-				if (rr != INT_MAX && better(vv, rr, v, r)) {
-					v = vv;
-					r = rr;
-				}
-			}
-			wave_argmax(v, r);
-			if (lane == 0) {
-				s_v[wave] = v;
-				s_r[wave] = r;
-			}
-			__syncthreads();
-			if (tid == 0) {
-				for (int k = 1; k < 4; ++k)
-					if (better(s_v[k], s_r[k], v, r)) {
-						v = s_v[k];
-						r = s_r[k];
-					}
-				s_p = r == INT_MAX ? j : r;
-				s_gw = r == INT_MAX ? 0 : r / a.R;
-			}
-			__syncthreads();
-			p = s_p;
-			gw = s_gw;
-			if (tid < w) {
-				const T d = (T) xwg_load(a.diag_row + q * LU_W + tid);
-				s_diag[tid] = d;
-				s_piv[tid] = p == j ? d : (T) xwg_load(a.slot_val + ((size_t) q * G + gw) * (1 + LU_W) + 1 + tid);
-			}
-			__syncthreads();
-		}
-		FH_T(4);
-		// ---- 5. swap rows j <-> p inside the chunks that own them (from the published copies)
-		if (p != j) {
-			if (p >= r0 && p < r0 + nr && tid < w)
-				Ps[tid * RMAX + (p - r0)] = s_diag[tid];
-			if (g == 0 && tid < w)
-				Ps[tid * RMAX + j] = s_piv[tid];
-		}
-		if (g == 0 && tid == 0)
-			a.piv[j] = a.row_base + p;
-		__syncthreads();
-		FH_T(5);
-		// ---- 6. scale by the reciprocal pivot and rank-1 update of the owned rows below the diagonal
-		//         (factor.rs:50-64; rank_update_imp: dst = fma(l_i, -u_c, dst))
-		const T inv = (T) 1 / s_piv[j];
-		for (int r = tid; r < nr; r += 256) {
-			if (r0 + r > j) {
-				const T l = Ps[j * RMAX + r] * inv;
-				Ps[j * RMAX + r] = l;
-				for (int c = j + 1; c < w; ++c)
-					Ps[c * RMAX + r] = __builtin_fma(l, -s_piv[c], Ps[c * RMAX + r]);
-			}
-		}
-		__syncthreads();
-		FH_T(6);
-	}
-	if (failed) {
-		if (tid == 0)
-			atomicExch(a.status + 2, 1);
-		return;
-	}
-	for (int c = 0; c < w; ++c)
-		for (int r = tid; r < nr; r += 256)
-			a.P[(idx_t) (r0 + r) * a.rs + (idx_t) c * a.cs] = Ps[c * RMAX + r];
-#ifdef FH_PANEL_TIMING
-	FH_T(7);
-	if (g == 0 && tid == 0 && a.dbg)
-		for (int i = 0; i < 8; ++i)
-			atomicAdd(a.dbg + i, (unsigned long long) tacc[i]);
-#endif
-}
-
 // ------------------------------------------------------------------------------------------------
-// Register-resident panel kernel (the one the driver uses).  Phase timing of the LDS-resident kernel above
-// (profiles/r01_lu_panel_phase_timing.txt) showed that only ~1.6 us of its ~6.4 us per column was the
+// Register-resident cooperative panel kernel.  Phase timing of its LDS-resident predecessor
+// (profiles/r01_lu_panel_phase_timing.txt) showed that only ~1.6 us of ~6.4 us per column was the
 // cross-workgroup hand-off; the rest was LDS round trips of the column scan, the winner selection and the
 // rank-1 update.  Here every thread keeps LU2_RPT whole panel rows in registers (32 columns each):
 //   * the column loop is unrolled at compile time (column index = template constant), so the update of the
@@ -276,13 +76,12 @@ template <typename T> struct Panel2Args {
 	int m, w;
 	int *piv; // piv[j] = row_base + pivot row
 	int row_base;
-	double *slots; // [2][G][LU2_SLOT]: {|a|, row (as double), 32 row entries}
-	double *diag;  // [2][LU_W]
-	xwg_u64 *flags;
+	xwg_u64 *gran;	    // [2][G][LU2_GSLOT] tagged granules: {row}, {|a| hi}, {|a| lo}, 32 x {hi, lo} row entries
+	xwg_u64 *gran_diag; // [2][2 * LU_W] row J as published by workgroup 0
 	xwg_u64 epoch_base;
 	int *status;
 };
-constexpr int LU2_SLOT = 2 + LU_W;
+constexpr int LU2_GSLOT = 3 + 2 * LU_W + 1; // granules per producer slot (padded to an even count)
 
 template <typename T> struct Panel2Shared {
 	double wv[LU2_NT / 64];
@@ -362,52 +161,92 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 	// ---- 2. wave 0: exchange and winner selection
 	if (G > 1) {
 		if (wave == 0) {
-			double *sv = a.slots + ((size_t) q * G + g) * LU2_SLOT;
+			// Data-tagged granules (xwg.h, recipe R2): every 8-byte word carries {epoch tag, 32 payload bits} and
+			// is written by ONE write-through store, so it needs neither a store drain nor a flag: a consumer that
+			// reads the expected tag has the data.  Two round trips per column (records, then the winner's row)
+			// instead of four (drain, flag, records, row).
+			const unsigned tag = (unsigned) (a.epoch_base + (xwg_u64) (J + 1));
+			xwg_u64 *sg = a.gran + ((size_t) q * G + g) * LU2_GSLOT;
 			if (lane == 0) {
-				xwg_store(sv, bv);
-				xwg_store(sv + 1, (double) br);
+				const xwg_u64 vb = (xwg_u64) __double_as_longlong(bv);
+				xwg_store_gran(sg + 0, tag, (unsigned) br);
+				xwg_store_gran(sg + 1, tag, (unsigned) (vb >> 32));
+				xwg_store_gran(sg + 2, tag, (unsigned) vb);
 			}
-			if (lane < LU_W && br != INT_MAX)
-				xwg_store(sv + 2 + lane, (double) sh.cand[lane]);
-			if (g == 0 && lane >= 32 && lane < 32 + LU_W)
-				xwg_store(a.diag + q * LU_W + (lane - 32), (double) sh.drow[lane - 32]);
-			const xwg_u64 epoch = a.epoch_base + (xwg_u64) (J + 1);
-			xwg_publish(a.flags, g, epoch, lane == 0);
+			if (lane < LU_W && br != INT_MAX) {
+				const xwg_u64 cb = (xwg_u64) __double_as_longlong((double) sh.cand[lane]);
+				xwg_store_gran(sg + 3 + 2 * lane, tag, (unsigned) (cb >> 32));
+				xwg_store_gran(sg + 4 + 2 * lane, tag, (unsigned) cb);
+			}
+			if (g == 0 && lane >= 32 && lane < 32 + LU_W) {
+				const xwg_u64 db = (xwg_u64) __double_as_longlong((double) sh.drow[lane - 32]);
+				xwg_u64 *dg = a.gran_diag + (size_t) q * 2 * LU_W + 2 * (lane - 32);
+				xwg_store_gran(dg, tag, (unsigned) (db >> 32));
+				xwg_store_gran(dg + 1, tag, (unsigned) db);
+			}
+			// ---- records of all producers (lane t reads producer t, strided for G > 64)
 			int ok = 0;
+			double v = 0.0;
+			int r = INT_MAX;
 			for (int spin = 0; spin < (1 << 21); ++spin) {
 				bool all = true;
-				for (int t = lane; t < G; t += 64)
-					all = all && __hip_atomic_load(a.flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+				v = 0.0;
+				r = INT_MAX;
+				for (int t = lane; t < G; t += 64) {
+					const xwg_u64 *rec = a.gran + ((size_t) q * G + t) * LU2_GSLOT;
+					const xwg_u64 g0 = xwg_load_gran(rec), g1 = xwg_load_gran(rec + 1), g2 = xwg_load_gran(rec + 2);
+					all = all && (unsigned) (g0 >> 32) == tag && (unsigned) (g1 >> 32) == tag && (unsigned) (g2 >> 32) == tag;
+					const int rr = (int) (unsigned) g0;
+					const double vv = __longlong_as_double((long long) (((g1 & 0xffffffffull) << 32) | (g2 & 0xffffffffull)));
+					if (rr != INT_MAX && better(vv, rr, v, r)) {
+						v = vv;
+						r = rr;
+					}
+				}
 				if (__all(all)) {
 					ok = 1;
 					break;
 				}
 				__builtin_amdgcn_s_sleep(1);
 			}
-			double v = 0.0;
-			int r = INT_MAX;
-			for (int t = lane; t < G; t += 64) {
-				const double *rec = a.slots + ((size_t) q * G + t) * LU2_SLOT;
-				const double vv = xwg_load(rec);
-				const int rr = (int) xwg_load(rec + 1);
-				if (rr != INT_MAX && better(vv, rr, v, r)) {
-					v = vv;
-					r = rr;
-				}
-			}
 			wave_argmax2(v, r);
 			const int p = r == INT_MAX ? J : r;
 			const int gw = r == INT_MAX ? 0 : r / LU2_R;
-			if (lane < LU_W) {
-				const T d = (T) xwg_load(a.diag + q * LU_W + lane);
-				sh.diag[lane] = d;
-				sh.piv[lane] = p == J ? d : (T) xwg_load(a.slots + ((size_t) q * G + gw) * LU2_SLOT + 2 + lane);
+			// ---- the winner's row and the diagonal row (lanes < 32: pivot row, lanes >= 32: row J)
+			if (ok) {
+				const bool want_piv = lane < LU_W && p != J;
+				const bool want_diag = lane >= 32 && lane < 32 + LU_W;
+				const xwg_u64 *src = want_piv ? a.gran + ((size_t) q * G + gw) * LU2_GSLOT + 3 + 2 * lane
+							      : a.gran_diag + (size_t) q * 2 * LU_W + 2 * ((lane - 32) & (LU_W - 1));
+				xwg_u64 h = 0, l = 0;
+				ok = 0;
+				for (int spin = 0; spin < (1 << 21); ++spin) {
+					bool got = true;
+					if (want_piv || want_diag) {
+						h = xwg_load_gran(src);
+						l = xwg_load_gran(src + 1);
+						got = (unsigned) (h >> 32) == tag && (unsigned) (l >> 32) == tag;
+					}
+					if (__all(got)) {
+						ok = 1;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(1);
+				}
+				const T val = (T) __longlong_as_double((long long) (((h & 0xffffffffull) << 32) | (l & 0xffffffffull)));
+				if (want_diag)
+					sh.diag[lane - 32] = val;
+				if (want_piv)
+					sh.piv[lane] = val;
 			}
 			if (lane == 0) {
 				sh.p = p;
 				sh.flag = ok;
 			}
 		}
+		__syncthreads();
+		if (sh.flag && sh.p == J && tid < LU_W)
+			sh.piv[tid] = sh.diag[tid]; // the diagonal row is the pivot row
 	} else {
 		if (tid < LU_W) {
 			const int p = br == INT_MAX ? J : br;
@@ -638,15 +477,11 @@ template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, i
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct LuWork {
 	int *piv;	    // device, min(m, n) entries, absolute rows
-	double *slot_val;   // [2][GMAX][1 + LU_W]
-	int *slot_row;	    // [2][GMAX]
-	double *diag_row;   // [2][LU_W]
-	xwg_u64 *flags;	    // [LU_GMAX]
+	xwg_u64 *gran;	    // [2][LU2_GMAX][LU2_GSLOT] tagged granules (zeroed once per factorization)
+	xwg_u64 *gran_diag; // [2][2 * LU_W]
 	xwg_u64 epoch_base; // epochs consumed by earlier leaf launches of this factorization
 	int *status;
-	unsigned long long *dbg;
 };
-constexpr int LU_GMAX = 224;
 
 template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, LuWork<T> &wk)
 {
@@ -665,9 +500,8 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 	a.w = w;
 	a.piv = wk.piv + col0;
 	a.row_base = row_base;
-	a.slots = wk.slot_val;
-	a.diag = wk.diag_row;
-	a.flags = wk.flags;
+	a.gran = wk.gran;
+	a.gran_diag = wk.gran_diag;
 	a.epoch_base = wk.epoch_base;
 	a.status = wk.status;
 	hipLaunchKernelGGL(getrf_panel2_kernel<T>, dim3(G), dim3(LU2_NT), 0, ctx().stream, a);
@@ -714,6 +548,80 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 	laswp_dev<T>(A10, wk.piv + col0 + bs, (int) (n - bs < m - bs ? n - bs : m - bs), row_base + (int) bs);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Right-looking driver with look-ahead for large matrices (same idea as potrf.hip): steps of LU_LA_NB columns,
+//     [panel stream]  P_k : recursive panel factorization above on the m_k x nb panel (cooperative leaves; <= 16
+//                     workgroups for 16384 rows, they fit the CUs reserved for this stream)
+//     [bulk stream]   columns of panel k+1 first: interchanges, U = L_kk^-1 A_k,k+1, A_{>k,k+1} -= L_{>k,k} U
+//                     -> releases P_{k+1} on the panel stream
+//     [bulk stream]   the same three operations on all remaining columns, then the interchanges of the
+//                     columns left of the panel
+// so the chain of per-column pivot exchanges (the serial part of LU) overlaps with the trailing GEMMs.
+// Same operations per entry as the reference's recursion (factor.rs:68-187) regrouped by block columns.
+// ------------------------------------------------------------------------------------------------
+constexpr idx_t LU_LA_NB = 512;
+
+template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipStream_t caller)
+{
+	Ctx &c = ctx();
+	const idx_t m = A.nrows, n = A.ncols; // n <= m
+	const idx_t nsteps = (n + LU_LA_NB - 1) / LU_LA_NB;
+	c.reset_events();
+	hipEvent_t e0 = c.next_event();
+	FH_HIP(hipEventRecord(e0, caller));
+	stream_wait(c.la_bulk, e0);
+	stream_wait(c.la_panel, e0);
+	hipEvent_t ev_panel;
+	{
+		StreamScope sc(c.la_panel);
+		const idx_t w0 = LU_LA_NB < n ? LU_LA_NB : n;
+		getrf_rec<T>(A.sub(0, 0, m, w0), 0, 0, wk);
+		ev_panel = c.next_event();
+		FH_HIP(hipEventRecord(ev_panel, c.la_panel));
+	}
+	// brings the columns [c0, c0 + nc) up to date with panel [j0, j0 + w): swaps, solve, update
+	auto update = [&](idx_t j0, idx_t w, idx_t c0, idx_t nc) {
+		const idx_t rows = m - j0, j1 = j0 + w;
+		laswp_dev<T>(A.sub(j0, c0, rows, nc), wk.piv + j0, (int) w, (int) j0);
+		MatV<T> U = A.sub(j0, c0, w, nc);
+		trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, U);
+		if (m > j1)
+			gemm_dev<T>(A.sub(j1, c0, m - j1, nc), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), U.c(), (T) -1);
+	};
+	for (idx_t k = 0; k < nsteps; ++k) {
+		const idx_t j0 = k * LU_LA_NB;
+		const idx_t w = LU_LA_NB < n - j0 ? LU_LA_NB : n - j0;
+		const idx_t j1 = j0 + w;
+		const idx_t w2 = j1 < n ? (LU_LA_NB < n - j1 ? LU_LA_NB : n - j1) : 0;
+		const idx_t j2 = j1 + w2;
+		hipEvent_t ev_next = nullptr;
+		{
+			StreamScope sc(c.la_bulk);
+			stream_wait(c.la_bulk, ev_panel);
+			if (w2 > 0) {
+				update(j0, w, j1, w2);
+				ev_next = c.next_event();
+				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
+			}
+			if (j2 < n)
+				update(j0, w, j2, n - j2);
+			if (j0 > 0) // factor.rs:127-185: the panel's transpositions act on the columns to its left as well
+				laswp_dev<T>(A.sub(j0, 0, m - j0, j0), wk.piv + j0, (int) w, (int) j0);
+		}
+		if (w2 > 0) {
+			StreamScope sc(c.la_panel);
+			stream_wait(c.la_panel, ev_next);
+			getrf_rec<T>(A.sub(j1, j1, m - j1, w2), (int) j1, (int) j1, wk);
+			ev_panel = c.next_event();
+			FH_HIP(hipEventRecord(ev_panel, c.la_panel));
+		}
+	}
+	hipEvent_t eb = c.next_event();
+	FH_HIP(hipEventRecord(eb, c.la_bulk));
+	stream_wait(caller, eb);
+	stream_wait(caller, ev_panel);
+}
+
 template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 {
 	const idx_t m = A.nrows, n = A.ncols;
@@ -724,29 +632,25 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 	long n_trans = 0;
 	if (size > 0) {
 		Scratch pivb((size_t) size * sizeof(int));
-		Scratch slotv((size_t) 2 * LU2_GMAX * LU2_SLOT * sizeof(double));
-		Scratch slotr(256);
-		Scratch diag((size_t) 2 * LU_W * sizeof(double));
+		const size_t gran_bytes = (size_t) 2 * LU2_GMAX * LU2_GSLOT * sizeof(xwg_u64), diag_bytes = (size_t) 4 * LU_W * sizeof(xwg_u64);
+		Scratch granb(gran_bytes + diag_bytes);
 		Scratch misc(256);
 		LuWork<T> wk;
 		wk.piv = pivb.as<int>();
-		wk.slot_val = slotv.as<double>();
-		wk.slot_row = slotr.as<int>();
-		wk.diag_row = diag.as<double>();
-		Scratch flagb((size_t) LU2_GMAX * sizeof(xwg_u64));
-		wk.flags = flagb.as<xwg_u64>();
+		wk.gran = granb.as<xwg_u64>();
+		wk.gran_diag = wk.gran + (size_t) 2 * LU2_GMAX * LU2_GSLOT;
 		wk.epoch_base = 0;
 		wk.status = misc.as<int>() + 8;
 		FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
-		FH_HIP(hipMemsetAsync(flagb.p, 0, (size_t) LU2_GMAX * sizeof(xwg_u64), ctx().stream));
-		wk.dbg = nullptr;
-#ifdef FH_PANEL_TIMING
-		Scratch dbgb(64);
-		FH_HIP(hipMemsetAsync(dbgb.p, 0, 64, ctx().stream));
-		wk.dbg = dbgb.as<unsigned long long>();
-#endif
+		FH_HIP(hipMemsetAsync(granb.p, 0, gran_bytes + diag_bytes, ctx().stream));
 
-		getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);
+		// look-ahead needs every workgroup of a cooperative leaf resident on the CUs reserved for the panel stream
+		const bool la = size >= 8 * LU_LA_NB && ctx().lookahead_streams() &&
+				(m + LU2_R - 1) / LU2_R <= (idx_t) ctx().la_panel_cus;
+		if (la)
+			getrf_lookahead<T>(A.sub(0, 0, m, size), wk, ctx().stream);
+		else
+			getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);
 		if (m < n) { // factor.rs:278-285 (+ the swaps of the columns right of the square part)
 			MatV<T> right = A.sub(0, size, m, n - size);
 			laswp_dev<T>(right, wk.piv, (int) size, 0);
@@ -758,15 +662,7 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		FH_HIP(hipMemcpyAsync(st, wk.status, sizeof(st), hipMemcpyDeviceToHost, ctx().stream));
 		ctx().sync();
 		FH_CHECK(st[2] == 0, "partial_piv_lu: device barrier timed out in the panel kernel");
-#ifdef FH_PANEL_TIMING
-		{
-			unsigned long long d[8];
-			FH_HIP(hipMemcpy(d, wk.dbg, sizeof(d), hipMemcpyDeviceToHost));
-			fprintf(stderr, "panel timing (cycles of wg0/t0 summed over all leaves): load %llu | argmax %llu | publish %llu | wait %llu | pick %llu | "
-					"swap %llu | update %llu | store %llu\n",
-				d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
-		}
-#endif
+		ctx().quiesce();
 		// factor.rs:274-277: perm = identity with the transpositions applied in order
 		for (idx_t j = 0; j < size; ++j) {
 			const idx_t p = piv[(size_t) j];
@@ -788,21 +684,17 @@ template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev)
 	FH_CHECK(w <= m, "getrf_panel: the panel must be tall");
 	if (w == 0)
 		return;
-	Scratch slotv((size_t) 2 * LU2_GMAX * LU2_SLOT * sizeof(double));
-	Scratch diag((size_t) 2 * LU_W * sizeof(double));
+	const size_t gran_bytes = (size_t) 2 * LU2_GMAX * LU2_GSLOT * sizeof(xwg_u64), diag_bytes = (size_t) 4 * LU_W * sizeof(xwg_u64);
+	Scratch granb(gran_bytes + diag_bytes);
 	Scratch misc(256);
-	Scratch flagb((size_t) LU2_GMAX * sizeof(xwg_u64));
 	LuWork<T> wk;
 	wk.piv = piv_dev;
-	wk.slot_val = slotv.as<double>();
-	wk.slot_row = nullptr;
-	wk.diag_row = diag.as<double>();
-	wk.flags = flagb.as<xwg_u64>();
+	wk.gran = granb.as<xwg_u64>();
+	wk.gran_diag = wk.gran + (size_t) 2 * LU2_GMAX * LU2_GSLOT;
 	wk.epoch_base = 0;
 	wk.status = misc.as<int>() + 8;
-	wk.dbg = nullptr;
 	FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
-	FH_HIP(hipMemsetAsync(flagb.p, 0, (size_t) LU2_GMAX * sizeof(xwg_u64), ctx().stream));
+	FH_HIP(hipMemsetAsync(granb.p, 0, gran_bytes + diag_bytes, ctx().stream));
 	getrf_rec<T>(P, 0, 0, wk);
 	int st[4] = {0, 0, 0, 0};
 	FH_HIP(hipMemcpyAsync(st, wk.status, sizeof(st), hipMemcpyDeviceToHost, ctx().stream));

@@ -102,15 +102,22 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 		// ---- panel step: rows j0 .. np-1 of columns j0 .. j0+31
 		const int below = np - j0 - POTRF_PB; // rows under the diagonal block (multiple of 32)
 		const int nw = below > 0 ? below / 32 : 1;
+		// every panel wave first LOADS its rows (the diagonal block's rows are loaded by all of them), and only after
+		// a workgroup barrier do the waves start writing finished columns back into the block image: without it
+		// a wave that runs ahead overwrites diagonal-block entries that a slower wave has not loaded yet (seen as
+		// rare spurious failures once other kernels shared the chip and skewed the waves)
+		const bool diag_lane = lane < 32;
+		const int row = diag_lane ? j0 + lane : j0 + POTRF_PB + wave * 32 + (lane - 32);
+		const bool valid = row < np;
+		T a[POTRF_PB];
 		if (wave < nw) {
-			const bool diag_lane = lane < 32;
-			const int row = diag_lane ? j0 + lane : j0 + POTRF_PB + wave * 32 + (lane - 32);
-			const bool valid = row < np;
 			const int rr = valid ? row : j0;
-			T a[POTRF_PB];
 #pragma unroll
 			for (int c = 0; c < POTRF_PB; ++c)
 				a[c] = S[(j0 + c) * LDS_LDP + rr];
+		}
+		__syncthreads();
+		if (wave < nw) {
 			int fail_col = 0;
 			// the reciprocal root of column j is computed one iteration ahead, right after the diagonal entry
 			// a_jj has received its last update through the register path, so that the long latencies
@@ -305,8 +312,8 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 	c.reset_events();
 	hipEvent_t e0 = c.next_event();
 	FH_HIP(hipEventRecord(e0, caller));
-	FH_HIP(hipStreamWaitEvent(c.la_bulk, e0, 0));
-	FH_HIP(hipStreamWaitEvent(c.la_panel, e0, 0));
+	stream_wait(c.la_bulk, e0);
+	stream_wait(c.la_panel, e0);
 	// workspaces: two full step-block inverses (double buffered over the steps), a temporary for building them,
 	// and the out-of-place result of the panel solve
 	Scratch wfb((size_t) 2 * LA_NB * LA_NB * sizeof(T)), tmb((size_t) LA_NB * LA_NB * sizeof(T));
@@ -333,7 +340,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		const bool last = r <= LA_TAIL;
 		{
 			StreamScope sc(c.la_bulk);
-			FH_HIP(hipStreamWaitEvent(c.la_bulk, ev_diag, 0));
+			stream_wait(c.la_bulk, ev_diag);
 			// P_k <- P_k L_kk^-T  (cholesky/ldlt/factor.rs:422-426) as P_k W_k^T, W_k = inv(L_kk) lower triangular:
 			// the left half of the result only needs the top-left quarter of W_k
 			{
@@ -368,7 +375,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		}
 		{
 			StreamScope sc(c.la_panel);
-			FH_HIP(hipStreamWaitEvent(c.la_panel, ev_upd, 0));
+			stream_wait(c.la_panel, ev_upd);
 			potrf_rec<T>(A.sub(j1, j1, w1, w1), regularize, eps, delta, status, j1, Wbase, k + 2 < nsteps);
 			if (k + 2 < nsteps)
 				tri_inv_full<T>(A.sub(j1, j1, LA_NB, LA_NB).c(), Wbase + (size_t) (j1 / POTRF_NB) * POTRF_NB * POTRF_NB,
@@ -380,8 +387,8 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 	// rejoin the caller's stream
 	hipEvent_t eb = c.next_event();
 	FH_HIP(hipEventRecord(eb, c.la_bulk));
-	FH_HIP(hipStreamWaitEvent(caller, eb, 0));
-	FH_HIP(hipStreamWaitEvent(caller, ev_diag, 0));
+	stream_wait(caller, eb);
+	stream_wait(caller, ev_diag);
 	if (tail0 < n)
 		potrf_rec<T>(A.sub(tail0, tail0, n - tail0, n - tail0), regularize, eps, delta, status, tail0, Wbase, false);
 }
@@ -407,6 +414,7 @@ template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps)
 	int h[2] = {0, 0};
 	FH_HIP(hipMemcpyAsync(h, status, sizeof(h), hipMemcpyDeviceToHost, ctx().stream));
 	ctx().sync();
+	ctx().quiesce();
 #ifdef FH_LEAF_TIMING
 	{
 		unsigned long long d[8];

@@ -39,6 +39,18 @@ static __device__ __forceinline__ int xwg_load_i(const int *p)
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// R2 granule: {tag (high 32 bits), 32 payload bits} in ONE naturally aligned 8-byte write-through store; a
+// reader that finds the expected tag has the payload (no flag, no fence, no store drain).  Granule memory must
+// be zeroed once per factorization and tags must never be 0.
+static __device__ __forceinline__ void xwg_store_gran(xwg_u64 *p, unsigned tag, unsigned value)
+{
+	__hip_atomic_store(p, ((xwg_u64) tag << 32) | (xwg_u64) value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ xwg_u64 xwg_load_gran(const xwg_u64 *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Called by the wave that issued the payload stores (all lanes): drain them, then lane `leader` raises the flag.
 static __device__ __forceinline__ void xwg_publish(xwg_u64 *flags, int g, xwg_u64 epoch, bool leader)
 {

@@ -220,6 +220,33 @@ def test_plu_full_size_property():
     assert r.abs().max().item() <= 64 * n * 2.3e-16 * scale
 
 
+@pytest.mark.parametrize("m,n", [(4096, 4096), (4500, 4321), (6000, 5000)])
+def test_plu_lookahead_path(m, n):
+    """min(m, n) >= 4096 runs the look-ahead LU driver (panel stream + bulk stream, 512-column steps, getrf.hip):
+    P A == L U entrywise, |L| <= 1, a valid permutation, and the bitwise same answer twice"""
+    import torch
+
+    F = init_gpu()
+    g = torch.Generator(device="cuda").manual_seed(m + n)
+    a = torch.randn((n, m), dtype=torch.float64, device="cuda", generator=g).t()
+    lu = a.clone()
+    perm, perm_inv, _ = F.partial_piv_lu_factor_in_place(lu)
+    F.synchronize()
+    assert sorted(perm.tolist()) == list(range(m)) and all(perm[perm_inv[i]] == i for i in range(0, m, 97))
+    p = torch.as_tensor(perm.astype(np.int64), device="cuda")
+    size = min(m, n)
+    L = torch.tril(lu, -1)[:, :size]
+    L[:size, :size] += torch.eye(size, dtype=torch.float64, device="cuda")
+    U = torch.triu(lu)[:size, :]
+    assert torch.tril(lu, -1).abs().max().item() <= 1.0 + 1e-14
+    err = (L @ U - a[p]).abs().max().item()
+    assert err <= 16 * size * 2.3e-16 * (L.abs() @ U.abs()).max().item()
+    lu2 = a.clone()
+    perm2, _, _ = F.partial_piv_lu_factor_in_place(lu2)
+    F.synchronize()
+    assert np.array_equal(perm, perm2) and torch.equal(lu, lu2)
+
+
 # -------------------------------------------------------------------------------------------- distributed lu
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,n,nb", [(512, 512, 64), (1000, 1000, 128), (700, 500, 96), (300, 420, 64)])

@@ -1,0 +1,5 @@
+#!/bin/bash
+export TMPDIR=/tmp
+run() { local fails=0; for i in $(seq 1 $2); do timeout 120 python -m pytest tests/test_gpu_factor.py -m gpu -q -x -k "llt_host_pointer or llt_full_size or test_llt_solve" > /tmp/o.log 2>&1 || { fails=$((fails+1)); grep -o "NonPositivePivot { index: [0-9]* }\|Error.*" /tmp/o.log | head -1; }; done; echo "$1: $fails failures of $2"; }
+FAER_HIP_NO_LOOKAHEAD=1 run nolookahead 12
+FAER_HIP_LA_SAME=1 run samestream 12
