@@ -30,7 +30,7 @@
 
 namespace fh {
 
-constexpr int LU_W = 32; // leaf width
+constexpr int LU_W = 32; // leaf width of the recursion
 
 struct Cand {
 	double v; // |a| (kept in double for both dtypes)
@@ -57,7 +57,7 @@ static __device__ __forceinline__ void wave_argmax(double &v, int &r)
 // Register-resident cooperative panel kernel.  Phase timing of its LDS-resident predecessor
 // (profiles/r01_lu_panel_phase_timing.txt) showed that only ~1.6 us of ~6.4 us per column was the
 // cross-workgroup hand-off; the rest was LDS round trips of the column scan, the winner selection and the
-// rank-1 update.  Here every thread keeps LU2_RPT whole panel rows in registers (32 columns each):
+// rank-1 update.  Here every thread keeps RPT whole panel rows in registers (W = 32 columns each):
 //   * the column loop is unrolled at compile time (column index = template constant), so the update of the
 //     trailing columns is 31 - j register FMAs per row against the pivot row read once from LDS;
 //   * the local arg-max comes straight out of registers; wave reductions + one LDS hop across the 8 waves;
@@ -65,10 +65,10 @@ static __device__ __forceinline__ void wave_argmax(double &v, int &r)
 //     fetch its row and the diagonal row -> hand them to the workgroup through LDS (3 __syncthreads per column);
 //   * 1024 rows per workgroup => at most 16 workgroups for a 16384-row panel (fewer flags, fewer records).
 // ------------------------------------------------------------------------------------------------
-constexpr int LU2_NT = 512;		    // threads per workgroup
-constexpr int LU2_RPT = 2;		    // rows per thread
-constexpr int LU2_R = LU2_NT * LU2_RPT; // rows per workgroup
-constexpr int LU2_GMAX = 1024; // up to 2^20 rows
+constexpr int LU2_NT = 512;	  // threads per workgroup
+constexpr int LU2_GMAX = 1024;	  // workgroups per panel (rows / (LU2_NT * RPT))
+constexpr int LU_WMAX = 64;	  // widest leaf
+constexpr int LU2_GSLOT = 4 + 2 * LU_WMAX; // granules per producer slot: {row}, {|a| hi}, {|a| lo}, pad, W x {hi, lo}
 
 template <typename T> struct Panel2Args {
 	T *P;
@@ -76,21 +76,20 @@ template <typename T> struct Panel2Args {
 	int m, w;
 	int *piv; // piv[j] = row_base + pivot row
 	int row_base;
-	xwg_u64 *gran;	    // [2][G][LU2_GSLOT] tagged granules: {row}, {|a| hi}, {|a| lo}, 32 x {hi, lo} row entries
-	xwg_u64 *gran_diag; // [2][2 * LU_W] row J as published by workgroup 0
+	xwg_u64 *gran;	    // [2][G][LU2_GSLOT] tagged granules
+	xwg_u64 *gran_diag; // [2][2 * LU_WMAX] row J as published by workgroup 0
 	xwg_u64 epoch_base;
 	int *status;
 };
-constexpr int LU2_GSLOT = 3 + 2 * LU_W + 1; // granules per producer slot (padded to an even count)
 
-template <typename T> struct Panel2Shared {
+template <typename T, int W> struct Panel2Shared {
 	double wv[LU2_NT / 64];
 	int wr[LU2_NT / 64];
-	T cand[LU_W]; // this workgroup's candidate row
-	T drow[LU_W]; // row j (workgroup 0)
-	T piv[LU_W];  // winning pivot row
-	T diag[LU_W]; // row j as published
-	int p;	      // winning row (global)
+	T cand[W]; // this workgroup's candidate row
+	T drow[W]; // row j (workgroup 0)
+	T piv[W];  // winning pivot row
+	T diag[W]; // row j as published
+	int p;	   // winning row (global)
 	int flag;
 };
 
@@ -107,10 +106,17 @@ static __device__ __forceinline__ void wave_argmax2(double &v, int &r)
 	}
 }
 
-// one column step, J known at compile time; returns false on exchange timeout
-template <typename T, int J>
-static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x)[LU2_RPT][LU_W], Panel2Shared<T> &sh, int r0, int G)
+static __device__ __forceinline__ double gran_pair_to_double(xwg_u64 h, xwg_u64 l)
 {
+	return __longlong_as_double((long long) (((h & 0xffffffffull) << 32) | (l & 0xffffffffull)));
+}
+
+// one column step, J known at compile time; returns false on exchange timeout.
+// W = leaf width (32 or 64, <= 64 so that wave 0 has one lane per panel column), RPT = rows per thread.
+template <typename T, int W, int RPT, int J>
+static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x)[RPT][W], Panel2Shared<T, W> &sh, int r0, int G)
+{
+	constexpr int R = LU2_NT * RPT;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int g = blockIdx.x;
 	const int q = J & 1;
@@ -118,7 +124,7 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 	double bv = 0.0;
 	int br = INT_MAX;
 #pragma unroll
-	for (int i = 0; i < LU2_RPT; ++i) {
+	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
 		const double av = fabs((double) x[i][J]);
 		if (gr >= J && gr < a.m && av > bv) {
@@ -144,16 +150,16 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 		br = INT_MAX; // zero / NaN-only chunk: no candidate
 	// the owners of the candidate row and (workgroup 0) of row J park them in LDS
 #pragma unroll
-	for (int i = 0; i < LU2_RPT; ++i) {
+	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
 		if (gr == br) {
 #pragma unroll
-			for (int c = 0; c < LU_W; ++c)
+			for (int c = 0; c < W; ++c)
 				sh.cand[c] = x[i][c];
 		}
 		if (gr == J) {
 #pragma unroll
-			for (int c = 0; c < LU_W; ++c)
+			for (int c = 0; c < W; ++c)
 				sh.drow[c] = x[i][c];
 		}
 	}
@@ -164,7 +170,7 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 			// Data-tagged granules (xwg.h, recipe R2): every 8-byte word carries {epoch tag, 32 payload bits} and
 			// is written by ONE write-through store, so it needs neither a store drain nor a flag: a consumer that
 			// reads the expected tag has the data.  Two round trips per column (records, then the winner's row)
-			// instead of four (drain, flag, records, row).
+			// instead of four (drain, flag, records, row).  Lane c handles panel column c.
 			const unsigned tag = (unsigned) (a.epoch_base + (xwg_u64) (J + 1));
 			xwg_u64 *sg = a.gran + ((size_t) q * G + g) * LU2_GSLOT;
 			if (lane == 0) {
@@ -173,14 +179,14 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 				xwg_store_gran(sg + 1, tag, (unsigned) (vb >> 32));
 				xwg_store_gran(sg + 2, tag, (unsigned) vb);
 			}
-			if (lane < LU_W && br != INT_MAX) {
+			if (lane < W && br != INT_MAX) {
 				const xwg_u64 cb = (xwg_u64) __double_as_longlong((double) sh.cand[lane]);
-				xwg_store_gran(sg + 3 + 2 * lane, tag, (unsigned) (cb >> 32));
-				xwg_store_gran(sg + 4 + 2 * lane, tag, (unsigned) cb);
+				xwg_store_gran(sg + 4 + 2 * lane, tag, (unsigned) (cb >> 32));
+				xwg_store_gran(sg + 5 + 2 * lane, tag, (unsigned) cb);
 			}
-			if (g == 0 && lane >= 32 && lane < 32 + LU_W) {
-				const xwg_u64 db = (xwg_u64) __double_as_longlong((double) sh.drow[lane - 32]);
-				xwg_u64 *dg = a.gran_diag + (size_t) q * 2 * LU_W + 2 * (lane - 32);
+			if (g == 0 && lane < W) {
+				const xwg_u64 db = (xwg_u64) __double_as_longlong((double) sh.drow[lane]);
+				xwg_u64 *dg = a.gran_diag + (size_t) q * 2 * LU_WMAX + 2 * lane;
 				xwg_store_gran(dg, tag, (unsigned) (db >> 32));
 				xwg_store_gran(dg + 1, tag, (unsigned) db);
 			}
@@ -197,7 +203,7 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 					const xwg_u64 g0 = xwg_load_gran(rec), g1 = xwg_load_gran(rec + 1), g2 = xwg_load_gran(rec + 2);
 					all = all && (unsigned) (g0 >> 32) == tag && (unsigned) (g1 >> 32) == tag && (unsigned) (g2 >> 32) == tag;
 					const int rr = (int) (unsigned) g0;
-					const double vv = __longlong_as_double((long long) (((g1 & 0xffffffffull) << 32) | (g2 & 0xffffffffull)));
+					const double vv = gran_pair_to_double(g1, g2);
 					if (rr != INT_MAX && better(vv, rr, v, r)) {
 						v = vv;
 						r = rr;
@@ -211,21 +217,25 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 			}
 			wave_argmax2(v, r);
 			const int p = r == INT_MAX ? J : r;
-			const int gw = r == INT_MAX ? 0 : r / LU2_R;
-			// ---- the winner's row and the diagonal row (lanes < 32: pivot row, lanes >= 32: row J)
+			const int gw = r == INT_MAX ? 0 : r / R;
+			// ---- the winner's row and the diagonal row
 			if (ok) {
-				const bool want_piv = lane < LU_W && p != J;
-				const bool want_diag = lane >= 32 && lane < 32 + LU_W;
-				const xwg_u64 *src = want_piv ? a.gran + ((size_t) q * G + gw) * LU2_GSLOT + 3 + 2 * lane
-							      : a.gran_diag + (size_t) q * 2 * LU_W + 2 * ((lane - 32) & (LU_W - 1));
-				xwg_u64 h = 0, l = 0;
+				const bool want = lane < W, want_piv = want && p != J;
+				const xwg_u64 *ps = a.gran + ((size_t) q * G + gw) * LU2_GSLOT + 4 + 2 * (lane & (W - 1));
+				const xwg_u64 *ds = a.gran_diag + (size_t) q * 2 * LU_WMAX + 2 * (lane & (W - 1));
+				xwg_u64 ph = 0, pl = 0, dh = 0, dl = 0;
 				ok = 0;
 				for (int spin = 0; spin < (1 << 21); ++spin) {
 					bool got = true;
-					if (want_piv || want_diag) {
-						h = xwg_load_gran(src);
-						l = xwg_load_gran(src + 1);
-						got = (unsigned) (h >> 32) == tag && (unsigned) (l >> 32) == tag;
+					if (want) {
+						dh = xwg_load_gran(ds);
+						dl = xwg_load_gran(ds + 1);
+						got = (unsigned) (dh >> 32) == tag && (unsigned) (dl >> 32) == tag;
+					}
+					if (want_piv) {
+						ph = xwg_load_gran(ps);
+						pl = xwg_load_gran(ps + 1);
+						got = got && (unsigned) (ph >> 32) == tag && (unsigned) (pl >> 32) == tag;
 					}
 					if (__all(got)) {
 						ok = 1;
@@ -233,22 +243,19 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 					}
 					__builtin_amdgcn_s_sleep(1);
 				}
-				const T val = (T) __longlong_as_double((long long) (((h & 0xffffffffull) << 32) | (l & 0xffffffffull)));
-				if (want_diag)
-					sh.diag[lane - 32] = val;
-				if (want_piv)
-					sh.piv[lane] = val;
+				if (want) {
+					const T dval = (T) gran_pair_to_double(dh, dl);
+					sh.diag[lane] = dval;
+					sh.piv[lane] = want_piv ? (T) gran_pair_to_double(ph, pl) : dval; // p == J: row J is the pivot row
+				}
 			}
 			if (lane == 0) {
 				sh.p = p;
 				sh.flag = ok;
 			}
 		}
-		__syncthreads();
-		if (sh.flag && sh.p == J && tid < LU_W)
-			sh.piv[tid] = sh.diag[tid]; // the diagonal row is the pivot row
 	} else {
-		if (tid < LU_W) {
+		if (tid < W) {
 			const int p = br == INT_MAX ? J : br;
 			sh.diag[tid] = sh.drow[tid];
 			sh.piv[tid] = p == J ? sh.drow[tid] : sh.cand[tid];
@@ -265,23 +272,23 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 	const int p = sh.p;
 	if (g == 0 && tid == 0)
 		a.piv[J] = a.row_base + p;
-	T pv[LU_W];
+	T pv[W];
 #pragma unroll
-	for (int c = J; c < LU_W; ++c)
+	for (int c = J; c < W; ++c)
 		pv[c] = sh.piv[c];
 	const T inv = (T) 1 / pv[J];
 #pragma unroll
-	for (int i = 0; i < LU2_RPT; ++i) {
+	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
 		if (p != J) {
 			if (gr == p) {
 #pragma unroll
-				for (int c = 0; c < LU_W; ++c)
+				for (int c = 0; c < W; ++c)
 					x[i][c] = sh.diag[c];
 			}
 			if (gr == J) {
 #pragma unroll
-				for (int c = 0; c < LU_W; ++c)
+				for (int c = 0; c < W; ++c)
 					x[i][c] = sh.piv[c];
 			}
 		}
@@ -289,58 +296,58 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 			const T l = x[i][J] * inv;
 			x[i][J] = l;
 #pragma unroll
-			for (int c = J + 1; c < LU_W; ++c)
+			for (int c = J + 1; c < W; ++c)
 				x[i][c] = __builtin_fma(l, -pv[c], x[i][c]); // rank_update_imp: dst = fma(l_i, -u_c, dst)
 		}
 	}
 	return true;
 }
 
-template <typename T, int J> struct Panel2Steps {
-	static __device__ __forceinline__ bool run(const Panel2Args<T> &a, T (&x)[LU2_RPT][LU_W], Panel2Shared<T> &sh, int r0, int G,
-						   int steps)
+template <typename T, int W, int RPT, int J> struct Panel2Steps {
+	static __device__ __forceinline__ bool run(const Panel2Args<T> &a, T (&x)[RPT][W], Panel2Shared<T, W> &sh, int r0, int G, int steps)
 	{
-		if constexpr (J < LU_W) {
+		if constexpr (J < W) {
 			if (J >= steps)
 				return true;
-			if (!panel2_step<T, J>(a, x, sh, r0, G))
+			if (!panel2_step<T, W, RPT, J>(a, x, sh, r0, G))
 				return false;
-			return Panel2Steps<T, J + 1>::run(a, x, sh, r0, G, steps);
+			return Panel2Steps<T, W, RPT, J + 1>::run(a, x, sh, r0, G, steps);
 		} else {
 			return true;
 		}
 	}
 };
 
-template <typename T> __global__ __launch_bounds__(LU2_NT) void getrf_panel2_kernel(const Panel2Args<T> a)
+template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void getrf_panel2_kernel(const Panel2Args<T> a)
 {
-	__shared__ Panel2Shared<T> sh;
+	__shared__ Panel2Shared<T, W> sh;
+	constexpr int R = LU2_NT * RPT;
 	const int tid = threadIdx.x;
 	const int g = blockIdx.x, G = gridDim.x;
-	const int r0 = g * LU2_R;
+	const int r0 = g * R;
 	const int w = a.w;
-	T x[LU2_RPT][LU_W];
+	T x[RPT][W];
 #pragma unroll
-	for (int i = 0; i < LU2_RPT; ++i) {
+	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
 #pragma unroll
-		for (int c = 0; c < LU_W; ++c) {
+		for (int c = 0; c < W; ++c) {
 			const bool in = gr < a.m && c < w;
 			const T v = a.P[in ? (idx_t) gr * a.rs + (idx_t) c * a.cs : (idx_t) 0];
 			x[i][c] = in ? v : (T) 0;
 		}
 	}
 	const int steps = min(w, a.m);
-	if (!Panel2Steps<T, 0>::run(a, x, sh, r0, G, steps)) {
+	if (!Panel2Steps<T, W, RPT, 0>::run(a, x, sh, r0, G, steps)) {
 		if (tid == 0)
 			atomicExch(a.status + 2, 1);
 		return;
 	}
 #pragma unroll
-	for (int i = 0; i < LU2_RPT; ++i) {
+	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
 #pragma unroll
-		for (int c = 0; c < LU_W; ++c)
+		for (int c = 0; c < W; ++c)
 			if (gr < a.m && c < w)
 				a.P[(idx_t) gr * a.rs + (idx_t) c * a.cs] = x[i][c];
 	}
@@ -483,13 +490,22 @@ template <typename T> struct LuWork {
 	int *status;
 };
 
+// rows per workgroup of the cooperative kernel for a leaf of w columns (registers: RPT x W scalars per thread)
+template <typename T> static int leaf_rows_per_wg(int w)
+{
+	(void) w;
+	const int rpt = 2;
+	return LU2_NT * rpt;
+}
+
 template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, LuWork<T> &wk)
 {
 	const idx_t m = P.nrows;
 	const int w = (int) P.ncols;
 	FH_CHECK(w <= LU_W, "getrf leaf: panel too wide");
-	FH_CHECK(m <= (idx_t) LU2_R * LU2_GMAX, "partial_piv_lu: more rows than the cooperative panel kernel supports");
-	int G = (int) ((m + LU2_R - 1) / LU2_R);
+	const int R = leaf_rows_per_wg<T>(w);
+	FH_CHECK(m <= (idx_t) R * LU2_GMAX, "partial_piv_lu: more rows than the cooperative panel kernel supports");
+	int G = (int) ((m + R - 1) / R);
 	if (G < 1)
 		G = 1;
 	Panel2Args<T> a;
@@ -504,7 +520,10 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 	a.gran_diag = wk.gran_diag;
 	a.epoch_base = wk.epoch_base;
 	a.status = wk.status;
-	hipLaunchKernelGGL(getrf_panel2_kernel<T>, dim3(G), dim3(LU2_NT), 0, ctx().stream, a);
+	hipStream_t s = ctx().stream;
+	// (a 64-wide instantiation halves the leaf count but its 64 fully unrolled column steps take tens of minutes
+	// to compile; the leaf stays 32 wide)
+	hipLaunchKernelGGL((getrf_panel2_kernel<T, 32, 2>), dim3(G), dim3(LU2_NT), 0, s, a);
 	FH_HIP(hipGetLastError());
 	const int steps = w < (int) m ? w : (int) m;
 	if (G > 1)
@@ -632,7 +651,7 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 	long n_trans = 0;
 	if (size > 0) {
 		Scratch pivb((size_t) size * sizeof(int));
-		const size_t gran_bytes = (size_t) 2 * LU2_GMAX * LU2_GSLOT * sizeof(xwg_u64), diag_bytes = (size_t) 4 * LU_W * sizeof(xwg_u64);
+		const size_t gran_bytes = (size_t) 2 * LU2_GMAX * LU2_GSLOT * sizeof(xwg_u64), diag_bytes = (size_t) 4 * LU_WMAX * sizeof(xwg_u64);
 		Scratch granb(gran_bytes + diag_bytes);
 		Scratch misc(256);
 		LuWork<T> wk;
@@ -645,8 +664,8 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		FH_HIP(hipMemsetAsync(granb.p, 0, gran_bytes + diag_bytes, ctx().stream));
 
 		// look-ahead needs every workgroup of a cooperative leaf resident on the CUs reserved for the panel stream
-		const bool la = size >= 8 * LU_LA_NB && ctx().lookahead_streams() &&
-				(m + LU2_R - 1) / LU2_R <= (idx_t) ctx().la_panel_cus;
+		const idx_t leaf_r = leaf_rows_per_wg<T>(LU_W);
+		const bool la = size >= 8 * LU_LA_NB && ctx().lookahead_streams() && (m + leaf_r - 1) / leaf_r <= (idx_t) ctx().la_panel_cus;
 		if (la)
 			getrf_lookahead<T>(A.sub(0, 0, m, size), wk, ctx().stream);
 		else
@@ -684,7 +703,7 @@ template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev)
 	FH_CHECK(w <= m, "getrf_panel: the panel must be tall");
 	if (w == 0)
 		return;
-	const size_t gran_bytes = (size_t) 2 * LU2_GMAX * LU2_GSLOT * sizeof(xwg_u64), diag_bytes = (size_t) 4 * LU_W * sizeof(xwg_u64);
+	const size_t gran_bytes = (size_t) 2 * LU2_GMAX * LU2_GSLOT * sizeof(xwg_u64), diag_bytes = (size_t) 4 * LU_WMAX * sizeof(xwg_u64);
 	Scratch granb(gran_bytes + diag_bytes);
 	Scratch misc(256);
 	LuWork<T> wk;
