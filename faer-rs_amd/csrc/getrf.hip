@@ -30,7 +30,7 @@
 
 namespace fh {
 
-constexpr int LU_W = 32; // leaf width of the recursion
+constexpr int LU_W = 64; // leaf width of the recursion
 
 struct Cand {
 	double v; // |a| (kept in double for both dtypes)
@@ -66,7 +66,7 @@ static __device__ __forceinline__ void wave_argmax(double &v, int &r)
 //   * 1024 rows per workgroup => at most 16 workgroups for a 16384-row panel (fewer flags, fewer records).
 // ------------------------------------------------------------------------------------------------
 constexpr int LU2_NT = 512;	  // threads per workgroup
-constexpr int LU2_GMAX = 1024;	  // workgroups per panel (rows / (LU2_NT * RPT))
+constexpr int LU2_GMAX = 2048;	  // workgroups per panel (rows / (LU2_NT * RPT))
 constexpr int LU_WMAX = 64;	  // widest leaf
 constexpr int LU2_GSLOT = 4 + 2 * LU_WMAX; // granules per producer slot: {row}, {|a| hi}, {|a| lo}, pad, W x {hi, lo}
 
@@ -111,14 +111,20 @@ static __device__ __forceinline__ double gran_pair_to_double(xwg_u64 h, xwg_u64 
 	return __longlong_as_double((long long) (((h & 0xffffffffull) << 32) | (l & 0xffffffffull)));
 }
 
-// one column step, J known at compile time; returns false on exchange timeout.
-// W = leaf width (32 or 64, <= 64 so that wave 0 has one lane per panel column), RPT = rows per thread.
-template <typename T, int W, int RPT, int J>
-static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x)[RPT][W], Panel2Shared<T, W> &sh, int r0, int G)
+// One column step.  The panel lives in registers in ROTATED order: after every group of 8 columns each row is
+// rotated left by 8 positions, so the column being eliminated always sits at a compile-time position JJ in
+// 0..7 while the group index `grp` is a run-time value.  That keeps the code to 8 unrolled step bodies for
+// any leaf width (a fully unrolled 64-column kernel takes tens of minutes to compile), finished columns stay
+// in the registers (positions >= lim = W - 8 grp) and keep taking part in the row interchanges.
+// Returns false on exchange timeout.  W <= 64 so that wave 0 has one lane per panel column.
+template <typename T, int W, int RPT, int JJ>
+static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x)[RPT][W], Panel2Shared<T, W> &sh, int r0, int G, int grp)
 {
 	constexpr int R = LU2_NT * RPT;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int g = blockIdx.x;
+	const int J = grp * 8 + JJ; // global panel column
+	const int lim = W - grp * 8; // positions < lim hold unfinished columns
 	const int q = J & 1;
 	// ---- 1. local arg-max of |a(:, J)| over owned rows >= J (first strictly largest, factor.rs:35-43)
 	double bv = 0.0;
@@ -126,7 +132,7 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 #pragma unroll
 	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
-		const double av = fabs((double) x[i][J]);
+		const double av = fabs((double) x[i][JJ]);
 		if (gr >= J && gr < a.m && av > bv) {
 			bv = av;
 			br = gr;
@@ -148,7 +154,7 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 		}
 	if (!(bv > 0.0))
 		br = INT_MAX; // zero / NaN-only chunk: no candidate
-	// the owners of the candidate row and (workgroup 0) of row J park them in LDS
+	// the owners of the candidate row and (workgroup 0) of row J park them in LDS (rotated order)
 #pragma unroll
 	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
@@ -170,7 +176,7 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 			// Data-tagged granules (xwg.h, recipe R2): every 8-byte word carries {epoch tag, 32 payload bits} and
 			// is written by ONE write-through store, so it needs neither a store drain nor a flag: a consumer that
 			// reads the expected tag has the data.  Two round trips per column (records, then the winner's row)
-			// instead of four (drain, flag, records, row).  Lane c handles panel column c.
+			// instead of four (drain, flag, records, row).  Lane c handles register position c.
 			const unsigned tag = (unsigned) (a.epoch_base + (xwg_u64) (J + 1));
 			xwg_u64 *sg = a.gran + ((size_t) q * G + g) * LU2_GSLOT;
 			if (lane == 0) {
@@ -268,58 +274,84 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 	__syncthreads();
 	if (!sh.flag)
 		return false;
-	// ---- 3. swap rows J <-> p, scale by the reciprocal pivot, rank-1 update (factor.rs:45-64)
+	// ---- 3. swap rows J <-> p (all W positions, finished columns included), scale by the reciprocal pivot,
+	//         rank-1 update of the unfinished columns (factor.rs:45-64)
 	const int p = sh.p;
 	if (g == 0 && tid == 0)
 		a.piv[J] = a.row_base + p;
-	T pv[W];
-#pragma unroll
-	for (int c = J; c < W; ++c)
-		pv[c] = sh.piv[c];
-	const T inv = (T) 1 / pv[J];
+	const T inv = (T) 1 / sh.piv[JJ];
+	T l[RPT];
 #pragma unroll
 	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
 		if (p != J) {
-			if (gr == p) {
+			// wave-uniform guards: exactly one lane of the whole grid owns each of the two rows, and without
+			// the guards the compiler speculates the 2 W LDS loads of every thread into registers
+			if (__any(gr == p)) {
+				if (gr == p) {
 #pragma unroll
-				for (int c = 0; c < W; ++c)
-					x[i][c] = sh.diag[c];
+					for (int c = 0; c < W; ++c)
+						x[i][c] = sh.diag[c];
+				}
 			}
-			if (gr == J) {
+			if (__any(gr == J)) {
+				if (gr == J) {
 #pragma unroll
-				for (int c = 0; c < W; ++c)
-					x[i][c] = sh.piv[c];
+					for (int c = 0; c < W; ++c)
+						x[i][c] = sh.piv[c];
+				}
 			}
 		}
+		l[i] = (T) 0;
 		if (gr > J) {
-			const T l = x[i][J] * inv;
-			x[i][J] = l;
+			l[i] = x[i][JJ] * inv;
+			x[i][JJ] = l[i];
+		}
+	}
+	// positions in blocks of 8: a block takes part while it still holds unfinished columns (wave-uniform test);
+	// rows with gr <= J carry l == 0 but must stay bitwise untouched (l * u could be NaN for an infinite u)
 #pragma unroll
-			for (int c = J + 1; c < W; ++c)
-				x[i][c] = __builtin_fma(l, -pv[c], x[i][c]); // rank_update_imp: dst = fma(l_i, -u_c, dst)
+	for (int cb = 0; cb < W / 8; ++cb) {
+		if (cb * 8 < lim) {
+			T u[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				u[k] = sh.piv[cb * 8 + k];
+#pragma unroll
+			for (int i = 0; i < RPT; ++i) {
+				const int gr = r0 + tid + i * LU2_NT;
+				if (gr > J) {
+#pragma unroll
+					for (int k = 0; k < 8; ++k)
+						if (cb * 8 + k > JJ)
+							x[i][cb * 8 + k] = __builtin_fma(l[i], -u[k], x[i][cb * 8 + k]); // rank_update_imp: fma(l_i, -u_c, dst)
+				}
+			}
 		}
 	}
 	return true;
 }
 
-template <typename T, int W, int RPT, int J> struct Panel2Steps {
-	static __device__ __forceinline__ bool run(const Panel2Args<T> &a, T (&x)[RPT][W], Panel2Shared<T, W> &sh, int r0, int G, int steps)
+template <typename T, int W, int RPT, int JJ> struct Panel2Group {
+	// the 8 column steps of group `grp`; stops at `steps`; returns 1 = group complete, 0 = stopped early, -1 = timeout
+	static __device__ __forceinline__ int run(const Panel2Args<T> &a, T (&x)[RPT][W], Panel2Shared<T, W> &sh, int r0, int G, int grp,
+						  int steps)
 	{
-		if constexpr (J < W) {
-			if (J >= steps)
-				return true;
-			if (!panel2_step<T, W, RPT, J>(a, x, sh, r0, G))
-				return false;
-			return Panel2Steps<T, W, RPT, J + 1>::run(a, x, sh, r0, G, steps);
+		if constexpr (JJ < 8) {
+			if (grp * 8 + JJ >= steps)
+				return 0;
+			if (!panel2_step<T, W, RPT, JJ>(a, x, sh, r0, G, grp))
+				return -1;
+			return Panel2Group<T, W, RPT, JJ + 1>::run(a, x, sh, r0, G, grp, steps);
 		} else {
-			return true;
+			return 1;
 		}
 	}
 };
 
 template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void getrf_panel2_kernel(const Panel2Args<T> a)
 {
+	static_assert((W & (W - 1)) == 0 && W % 8 == 0 && W <= 64, "leaf width");
 	__shared__ Panel2Shared<T, W> sh;
 	constexpr int R = LU2_NT * RPT;
 	const int tid = threadIdx.x;
@@ -338,18 +370,41 @@ template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void 
 		}
 	}
 	const int steps = min(w, a.m);
-	if (!Panel2Steps<T, W, RPT, 0>::run(a, x, sh, r0, G, steps)) {
-		if (tid == 0)
-			atomicExch(a.status + 2, 1);
-		return;
+	int rot = 0; // positions the rows have been rotated by so far
+	for (int grp = 0; grp * 8 < steps; ++grp) {
+		const int st = Panel2Group<T, W, RPT, 0>::run(a, x, sh, r0, G, grp, steps);
+		if (st < 0) {
+			if (tid == 0)
+				atomicExch(a.status + 2, 1);
+			return;
+		}
+		if (st == 0)
+			break;
+		// rotate every row left by 8: the finished columns go to the tail
+#pragma unroll
+		for (int i = 0; i < RPT; ++i) {
+			T t8[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				t8[k] = x[i][k];
+#pragma unroll
+			for (int c = 0; c + 8 < W; ++c)
+				x[i][c] = x[i][c + 8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				x[i][W - 8 + k] = t8[k];
+		}
+		rot += 8;
 	}
 #pragma unroll
 	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
 #pragma unroll
-		for (int c = 0; c < W; ++c)
-			if (gr < a.m && c < w)
-				a.P[(idx_t) gr * a.rs + (idx_t) c * a.cs] = x[i][c];
+		for (int c = 0; c < W; ++c) {
+			const int gc = (c + rot) & (W - 1); // global panel column of register position c
+			if (gr < a.m && gc < w)
+				a.P[(idx_t) gr * a.rs + (idx_t) gc * a.cs] = x[i][c];
+		}
 	}
 }
 
@@ -494,7 +549,7 @@ template <typename T> struct LuWork {
 template <typename T> static int leaf_rows_per_wg(int w)
 {
 	(void) w;
-	const int rpt = 2;
+	const int rpt = sizeof(T) == 8 ? 1 : 2;
 	return LU2_NT * rpt;
 }
 
@@ -521,9 +576,7 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 	a.epoch_base = wk.epoch_base;
 	a.status = wk.status;
 	hipStream_t s = ctx().stream;
-	// (a 64-wide instantiation halves the leaf count but its 64 fully unrolled column steps take tens of minutes
-	// to compile; the leaf stays 32 wide)
-	hipLaunchKernelGGL((getrf_panel2_kernel<T, 32, 2>), dim3(G), dim3(LU2_NT), 0, s, a);
+	hipLaunchKernelGGL((getrf_panel2_kernel<T, LU_W, (sizeof(T) == 8 ? 1 : 2)>), dim3(G), dim3(LU2_NT), 0, s, a);
 	FH_HIP(hipGetLastError());
 	const int steps = w < (int) m ? w : (int) m;
 	if (G > 1)

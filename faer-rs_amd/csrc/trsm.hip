@@ -190,7 +190,7 @@ template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X)
 	const idx_t n = L.nrows, k = X.ncols;
 	if (n == 0 || k == 0)
 		return;
-	if (n > 64 && k >= 256) {
+	if (n > 64 || k >= 64) { // explicit 128-block inverses + MFMA products; tiny solves keep the register leaf
 		const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
 		Scratch wb((size_t) nblk * TRSM_IB * TRSM_IB * sizeof(T));
 		hipLaunchKernelGGL(trtri_diag_kernel<T>, dim3((unsigned) nblk), dim3(LDS_NT), 0, ctx().stream, L.p, L.rs, L.cs,
