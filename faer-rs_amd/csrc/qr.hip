@@ -110,7 +110,7 @@ static __device__ __forceinline__ double wave_sum(double v)
 // FAST path leaf: cooperative 8-column Householder panel
 // ------------------------------------------------------------------------------------------------
 constexpr int QR_PW = 8;
-constexpr int QR_GMAX = 224;
+constexpr int QR_GMAX = 512;
 constexpr int QR_NPAIR = QR_PW * (QR_PW - 1) / 2; // 28
 constexpr int QR_SLOT = 32;			  // doubles per workgroup slot (>= QR_NPAIR, >= QR_PW)
 
@@ -367,6 +367,307 @@ template <typename T, int RMAX> __global__ __launch_bounds__(256) void qr_panel_
 			a.P[(idx_t) (r0 + r) * a.rs + (idx_t) c * a.cs] = Ps[c * RMAX + r];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-resident version of the panel kernel (the one the driver uses): same mathematics and the same
+// exchange as qr_panel_kernel above, but every thread keeps QR2_RPT whole panel rows (8 columns each) in
+// registers and the 8 column steps are unrolled at compile time, so the dot products x^H a_c, the scaling and
+// the rank-1 update are register FMAs instead of round trips through LDS (the LDS loops were ~3/4 of the old
+// kernel's time, exactly as in the LU panel: profiles/r01_lu_panel_phase_timing.txt).
+// ------------------------------------------------------------------------------------------------
+constexpr int QR2_NT = 512;
+template <typename T> static constexpr int qr2_rpt() { return sizeof(T) == 8 ? 4 : 8; }
+
+template <int CNT> static __device__ __forceinline__ void block_sum_nt(double (&vals)[CNT], double *s_part, double *s_red)
+{
+	// like block_sum, for QR2_NT threads: wave sums, then CNT threads add the 8 wave partials
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+	for (int c = 0; c < CNT; ++c) {
+		const double sv = wave_sum(vals[c]);
+		if (lane == 0)
+			s_part[wave * CNT + c] = sv;
+	}
+	__syncthreads();
+	if (tid < CNT) {
+		double t = 0.0;
+#pragma unroll
+		for (int k = 0; k < QR2_NT / 64; ++k)
+			t += s_part[k * CNT + tid];
+		s_red[tid] = t;
+	}
+	__syncthreads();
+}
+
+template <typename T> struct Qr2Shared {
+	double part[(QR2_NT / 64) * QR_SLOT], red[QR_SLOT], S[QR_SLOT];
+	double tau[QR_PW], head[QR_PW + 1];
+	T top[QR_PW][QR_PW]; // rows 0..7 of the panel (chunk 0): top[r][c]
+	int flag;
+};
+
+// one column step; false: leave (timeout or rank deficiency recorded in `why`)
+template <typename T, int RPT, int J>
+static __device__ __forceinline__ bool qr2_step(const QrPanelArgs<T> &a, T (&x)[RPT][QR_PW], Qr2Shared<T> &sh, int r0, int G, int &bar,
+						int &why)
+{
+	const int tid = threadIdx.x;
+	const int g = blockIdx.x;
+	const int w = a.w;
+	const int q = bar & 1;
+	// ---- partial sums s_c = sum_{r > J} x_r a_rc, c = J .. w-1 (c == J gives |tail|^2)
+	double acc[QR_PW];
+#pragma unroll
+	for (int c = 0; c < QR_PW; ++c)
+		acc[c] = 0.0;
+	double ab[1] = {0.0};
+#pragma unroll
+	for (int i = 0; i < RPT; ++i) {
+		const int gr = r0 + tid + i * QR2_NT;
+		if (gr > J && gr < a.m) {
+			const double xv = (double) x[i][J];
+#pragma unroll
+			for (int c = J; c < QR_PW; ++c)
+				if (c < w)
+					acc[c] += xv * (double) x[i][c];
+		}
+		if (gr < J) { // rows of the panel above the diagonal (chunk 0 only): part of |above|^2
+			const double v = (double) x[i][J];
+			ab[0] += v * v;
+		}
+	}
+	block_sum_nt<QR_PW>(acc, sh.part, sh.red);
+	// row J of the panel lives in thread J of chunk 0
+	if (g == 0 && tid == J) {
+#pragma unroll
+		for (int c = 0; c < QR_PW; ++c)
+			sh.top[J][c] = x[0][c];
+	}
+	if (g == 0) {
+		// rows above the panel (outside it)
+		for (int i = tid; i < a.row_abs; i += QR2_NT) {
+			const double v = (double) a.above[(idx_t) i * a.rs + (idx_t) J * a.cs];
+			ab[0] += v * v;
+		}
+		block_sum_nt<1>(ab, sh.part, sh.S); // sh.S[0] = |above|^2 (also publishes sh.top through its barriers)
+	}
+	if (G > 1) {
+		if (tid < QR_PW)
+			xwg_store(a.slots + ((size_t) q * G + g) * QR_SLOT + tid, sh.red[tid]);
+		if (g == 0) {
+			if (tid < QR_PW)
+				xwg_store(a.head + q * (QR_PW + 1) + tid, tid < w ? (double) sh.top[J][tid] : 0.0);
+			if (tid == 0)
+				xwg_store(a.head + q * (QR_PW + 1) + QR_PW, sh.S[0]);
+		}
+		if (tid < 64)
+			xwg_publish(a.flags, g, a.epoch_base + (xwg_u64) (bar + 1), tid == 0);
+		if (!xwg_wait_all(a.flags, G, a.epoch_base + (xwg_u64) (bar + 1), &sh.flag)) {
+			why = 2;
+			return false;
+		}
+		++bar;
+		double tot[QR_PW];
+#pragma unroll
+		for (int c = 0; c < QR_PW; ++c)
+			tot[c] = 0.0;
+		for (int t = tid; t < G; t += QR2_NT)
+#pragma unroll
+			for (int c = 0; c < QR_PW; ++c)
+				tot[c] += xwg_load(a.slots + ((size_t) q * G + t) * QR_SLOT + c);
+		block_sum_nt<QR_PW>(tot, sh.part, sh.S);
+		if (tid <= QR_PW)
+			sh.head[tid] = xwg_load(a.head + q * (QR_PW + 1) + tid);
+	} else {
+		__syncthreads(); // sh.S[0] (|above|^2) read below before sh.S is overwritten
+		const double above2 = sh.S[0];
+		__syncthreads();
+		if (tid < QR_PW) {
+			sh.S[tid] = sh.red[tid];
+			sh.head[tid] = tid < w ? (double) sh.top[J][tid] : 0.0;
+		}
+		if (tid == 0)
+			sh.head[QR_PW] = above2;
+	}
+	__syncthreads();
+	// ---- reflector (householder.rs:59-107), evaluated identically by every thread
+	T head = (T) sh.head[J];
+	const double above2 = sh.head[QR_PW];
+	const T tail_norm = (T) sqrt(sh.S[J]);
+	T head_norm = fabs(head);
+	if (head_norm < Lim<T>::minpos) {
+		head = (T) 0;
+		head_norm = (T) 0;
+	}
+	if (tail_norm < Lim<T>::minpos) {
+		// householder.rs:70-77 + factor.rs:59-63: tau = inf, nothing is scaled or updated; the column
+		// is accepted iff its head is non zero (e.g. the last column of a square matrix)
+		if (!(head_norm > (T) 0)) {
+			why = 3;
+			return false;
+		}
+		if (tid == 0)
+			sh.tau[J] = (double) std::numeric_limits<T>::infinity();
+		__syncthreads();
+		return true;
+	}
+	const T norm = (T) hypot((double) head_norm, (double) tail_norm);
+	const T sign = head_norm != (T) 0 ? head * ((T) 1 / head_norm) : (T) 1;
+	const T signed_norm = sign * norm;
+	const T hinv = (T) 1 / (head + signed_norm);
+	const T tn = tail_norm * fabs(hinv);
+	const T tau = (T) 0.5 * ((T) 1 + tn * tn);
+	// rank test (factor.rs:52-82)
+	const T full_norm = (T) hypot((double) norm, sqrt(above2));
+	const T threshold = Lim<T>::eps * (T) ((double) (a.m - J) * 16.0) * full_norm;
+	const T tau_inv = (T) 1 / tau;
+	if (tau_inv < Lim<T>::minpos || !(norm > threshold)) {
+		why = 3;
+		return false;
+	}
+	if (tid == 0)
+		sh.tau[J] = (double) tau;
+	// ---- update: v = x * hinv ; k_c = -(a_jc + v^H a_c) / tau ; a_c += k_c v   (factor.rs:65-80)
+	T kc[QR_PW];
+#pragma unroll
+	for (int c = 0; c < QR_PW; ++c)
+		kc[c] = (c > J && c < w) ? -(((T) sh.head[c] + hinv * (T) sh.S[c]) * tau_inv) : (T) 0;
+#pragma unroll
+	for (int i = 0; i < RPT; ++i) {
+		const int gr = r0 + tid + i * QR2_NT;
+		if (gr > J && gr < a.m) {
+			const T v = x[i][J] * hinv;
+			x[i][J] = v;
+#pragma unroll
+			for (int c = J + 1; c < QR_PW; ++c)
+				if (c < w)
+					x[i][c] += kc[c] * v;
+		}
+	}
+	if (g == 0 && tid == J) { // row J itself
+		x[0][J] = -signed_norm;
+#pragma unroll
+		for (int c = J + 1; c < QR_PW; ++c)
+			if (c < w)
+				x[0][c] += kc[c];
+	}
+	__syncthreads();
+	return true;
+}
+
+template <typename T, int RPT, int J> struct Qr2Steps {
+	static __device__ __forceinline__ bool run(const QrPanelArgs<T> &a, T (&x)[RPT][QR_PW], Qr2Shared<T> &sh, int r0, int G, int &bar,
+						   int &why, int steps)
+	{
+		if constexpr (J < QR_PW) {
+			if (J >= steps)
+				return true;
+			if (!qr2_step<T, RPT, J>(a, x, sh, r0, G, bar, why))
+				return false;
+			return Qr2Steps<T, RPT, J + 1>::run(a, x, sh, r0, G, bar, why, steps);
+		} else {
+			return true;
+		}
+	}
+};
+
+template <typename T, int RPT> __global__ __launch_bounds__(QR2_NT) void qr_panel2_kernel(const QrPanelArgs<T> a)
+{
+	__shared__ Qr2Shared<T> sh;
+	constexpr int R = QR2_NT * RPT;
+	const int tid = threadIdx.x;
+	const int g = blockIdx.x, G = gridDim.x;
+	const int r0 = g * R;
+	const int w = a.w;
+	if (a.status[3] != 0)
+		return; // an earlier panel found a rank deficiency: the whole factorization is being abandoned
+	T x[RPT][QR_PW];
+#pragma unroll
+	for (int i = 0; i < RPT; ++i) {
+		const int gr = r0 + tid + i * QR2_NT;
+#pragma unroll
+		for (int c = 0; c < QR_PW; ++c) {
+			const bool in = gr < a.m && c < w;
+			const T v = a.P[in ? (idx_t) gr * a.rs + (idx_t) c * a.cs : (idx_t) 0];
+			x[i][c] = in ? v : (T) 0;
+		}
+	}
+	const int steps = min(w, a.m);
+	int bar = 0, why = 0;
+	if (!Qr2Steps<T, RPT, 0>::run(a, x, sh, r0, G, bar, why, steps)) {
+		if (tid == 0)
+			atomicExch(a.status + why, 1);
+		return;
+	}
+	// ---- T block: T_ij = v_i[j] + sum_{r > j} v_ri v_rj  (i < j) ; T_jj = tau_j
+	{
+		const int q = bar & 1;
+		double acc2[QR_NPAIR];
+#pragma unroll
+		for (int p = 0; p < QR_NPAIR; ++p)
+			acc2[p] = 0.0;
+#pragma unroll
+		for (int i = 0; i < RPT; ++i) {
+			const int gr = r0 + tid + i * QR2_NT;
+			if (gr < a.m) {
+				int p = 0;
+#pragma unroll
+				for (int jj = 1; jj < QR_PW; ++jj)
+#pragma unroll
+					for (int ii = 0; ii < jj; ++ii, ++p)
+						if (gr > jj && jj < w)
+							acc2[p] += (double) x[i][ii] * (double) x[i][jj];
+			}
+		}
+		block_sum_nt<QR_NPAIR>(acc2, sh.part, sh.red);
+		// rows 0..7 of chunk 0 (V's top block) for the v_i[j] terms
+		if (g == 0 && tid < QR_PW) {
+#pragma unroll
+			for (int c = 0; c < QR_PW; ++c)
+				sh.top[tid][c] = x[0][c];
+		}
+		if (G > 1) {
+			if (tid < QR_NPAIR)
+				xwg_store(a.slots + ((size_t) q * G + g) * QR_SLOT + tid, sh.red[tid]);
+			if (tid < 64)
+				xwg_publish(a.flags, g, a.epoch_base + (xwg_u64) (bar + 1), tid == 0);
+			if (!xwg_wait_all(a.flags, G, a.epoch_base + (xwg_u64) (bar + 1), &sh.flag)) {
+				if (tid == 0)
+					atomicExch(a.status + 2, 1);
+				return;
+			}
+			double tot[QR_NPAIR];
+#pragma unroll
+			for (int p = 0; p < QR_NPAIR; ++p)
+				tot[p] = 0.0;
+			if (g == 0) {
+				for (int t = tid; t < G; t += QR2_NT)
+#pragma unroll
+					for (int p = 0; p < QR_NPAIR; ++p)
+						tot[p] += xwg_load(a.slots + ((size_t) q * G + t) * QR_SLOT + p);
+				block_sum_nt<QR_NPAIR>(tot, sh.part, sh.red);
+			}
+		}
+		__syncthreads();
+		if (g == 0 && tid == 0) {
+			int p = 0;
+			for (int jj = 0; jj < w; ++jj)
+				a.Tb[(idx_t) jj * a.trs + (idx_t) jj * a.tcs] = (T) sh.tau[jj];
+			for (int jj = 1; jj < QR_PW; ++jj)
+				for (int ii = 0; ii < jj; ++ii, ++p)
+					if (jj < w)
+						a.Tb[(idx_t) ii * a.trs + (idx_t) jj * a.tcs] = (T) ((double) sh.top[jj][ii] + sh.red[p]);
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < RPT; ++i) {
+		const int gr = r0 + tid + i * QR2_NT;
+#pragma unroll
+		for (int c = 0; c < QR_PW; ++c)
+			if (gr < a.m && c < w)
+				a.P[(idx_t) gr * a.rs + (idx_t) c * a.cs] = x[i][c];
+	}
+}
+
 template <typename T> struct QrWork {
 	double *slots, *head;
 	xwg_u64 *flags;
@@ -380,19 +681,12 @@ template <typename T> static constexpr int qr_rmax() { return sizeof(T) == 8 ? 2
 
 template <typename T> static void qr_leaf(MatV<T> P, MatV<T> Tb, idx_t row_abs, idx_t col_abs, QrWork<T> &wk)
 {
-	constexpr int RMAX = qr_rmax<T>();
+	constexpr int R = QR2_NT * qr2_rpt<T>();
 	const idx_t m = P.nrows;
 	const int w = (int) P.ncols;
-	int G = (int) ((m + RMAX - 1) / RMAX);
+	int G = (int) ((m + R - 1) / R);
 	if (G < 1)
 		G = 1;
-	int R = (int) ((m + G - 1) / G);
-	R = (R + 63) / 64 * 64;
-	if (R > RMAX)
-		R = RMAX;
-	if (R < 64)
-		R = 64;
-	G = (int) ((m + R - 1) / R);
 	FH_CHECK(G <= QR_GMAX, "qr: panel too tall for the cooperative kernel");
 	QrPanelArgs<T> a;
 	a.P = P.p;
@@ -411,7 +705,7 @@ template <typename T> static void qr_leaf(MatV<T> P, MatV<T> Tb, idx_t row_abs, 
 	a.flags = wk.flags;
 	a.epoch_base = wk.epoch_base;
 	a.status = wk.status;
-	hipLaunchKernelGGL((qr_panel_kernel<T, RMAX>), dim3(G), dim3(256), 0, ctx().stream, a);
+	hipLaunchKernelGGL((qr_panel2_kernel<T, qr2_rpt<T>()>), dim3(G), dim3(QR2_NT), 0, ctx().stream, a);
 	FH_HIP(hipGetLastError());
 	if (G > 1) {
 		const int steps = w < (int) m ? w : (int) m;
@@ -747,7 +1041,7 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 	// rejects EVERY column once 16 * eps * nrows >= 1 (fp32: nrows >= 524288).  That outcome (rank 0) is
 	// reproduced by the general path; the fast path would only discover it one launch later.
 	const bool ref_rejects_all = (double) Lim<T>::eps * 16.0 * (double) m >= 1.0;
-	const bool fast_ok = m <= (idx_t) qr_rmax<T>() * QR_GMAX && !ref_rejects_all;
+	const bool fast_ok = m <= (idx_t) QR2_NT * qr2_rpt<T>() * QR_GMAX && !ref_rejects_all;
 	Scratch backup(fast_ok ? (size_t) m * (size_t) n * sizeof(T) : 256);
 	MatV<T> Bk{backup.as<T>(), m, n, 1, m};
 	if (fast_ok) {
