@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="gemm", choices=["gemm", "llt", "lu", "qr"])
+    ap.add_argument("--workload", default="gemm", choices=["gemm", "llt", "lu", "qr", "gemv"])
     ap.add_argument("--n", type=int, default=0, help="override the matrix size (testing only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -97,6 +97,17 @@ def main():
                 F.matmul(c, F.ACCUM_REPLACE, a, b, 1.0)
 
             return step, 2.0 * n ** 3, None, f"dgemm_f64_n{n}", "f64"
+        if name == "gemv":
+            # level-2 shape of the same entry point (matmul with one rhs column): an HBM stream, not an MFMA kernel
+            n = n_override or 16384
+            a = colmajor(n, n, torch.float64, 6)
+            xv = colmajor(n, 1, torch.float64, 7)
+            yv = torch.empty((1, n), dtype=torch.float64, device=dev).t()
+
+            def step():
+                F.matmul(yv, F.ACCUM_REPLACE, a, xv, 1.0)
+
+            return step, 2.0 * n * n, None, f"dgemv_f64_n{n}", "f64"
         if name == "llt":
             n = n_override or 16384
             a = colmajor(n, n, torch.float64, 3)
@@ -233,7 +244,7 @@ def main():
             others = {}
             del step
             torch.cuda.empty_cache()
-            for name in ("gemm", "llt", "lu", "qr"):
+            for name in ("gemm", "llt", "lu", "qr", "gemv"):
                 if name == args.workload:
                     continue
                 try:
@@ -245,6 +256,14 @@ def main():
                     peak = FP64_MFMA_PEAK_TFLOPS if dn == "f64" else FP32_MFMA_PEAK_TFLOPS
                     others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3),
                                   "frac_of_mfma_peak": round(rate / 1e3 / peak, 4)}
+                    if args.workload == "gemm" and name in ("llt", "lu"):
+                        others[lb]["frac_of_dgemm_sustained"] = round(rate / value, 4)  # BASELINE target: >= 0.6
+                    if name == "gemv":  # HBM bound: algorithmic bytes = the matrix, read once
+                        gbs = (fl / 2.0) * 8 * 3 / t / 1e9
+                        others[lb] = {"GB/s": round(gbs, 1), "ms": round(t / 3 * 1e3, 3), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                    if name == "qr":  # also HBM bound as specified: algorithmic bytes 2 m n sizeof(f32)
+                        gbs = 2.0 * 500000 * 256 * 4 * 3 / t / 1e9
+                        others[lb]["GB/s_algorithmic"] = round(gbs, 1)
                     del st, ov
                     torch.cuda.empty_cache()
                 except Exception as ex:  # keep the headline line even if an extra fails

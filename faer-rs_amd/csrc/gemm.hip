@@ -811,6 +811,17 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	GemmExtra<T> ex;
 	if (extra)
 		ex = *extra;
+	// level-2 shapes leave for the streaming kernels (matmul/mod.rs:1215-1310: matvec / rank_update dispatch)
+	if (kind == DST_FULL && !ex.row_idx && !ex.col_idx && !ex.diag && !ex.a_struct && !ex.b_struct && !ex.inplace) {
+		if (k == 1 && m * n >= 1) {
+			rank1_dev<T>(C, add, A.p, A.rs, B.p, B.cs, alpha);
+			return;
+		}
+		if (n == 1 && gemv_dev<T>(m, k, A, B.p, B.rs, C.p, C.rs, alpha, add))
+			return;
+		if (m == 1 && gemv_dev<T>(n, k, B.t(), A.p, A.cs, C.p, C.cs, alpha, add))
+			return;
+	}
 	const bool indexed = ex.row_idx || ex.col_idx;
 	// Upper(dst) == Lower(dst^T); dst^T = B^T diag A^T.  Also prefer the unit dst stride along m.
 	bool transpose = (kind == DST_UPPER) || (kind == DST_FULL && iabs(C.cs) == 1 && iabs(C.rs) != 1 && !indexed);

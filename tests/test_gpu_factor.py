@@ -247,6 +247,37 @@ def test_plu_lookahead_path(m, n):
     assert np.array_equal(perm, perm2) and torch.equal(lu, lu2)
 
 
+def test_lookahead_paths_fp32():
+    """fp32 through the two-stream drivers: LLT n = 8192 (L L^T == A) and LU n = 4608 (P A == L U), tolerances
+    scaled with eps_f32"""
+    import torch
+
+    F = init_gpu()
+    eps = 1.2e-7
+    n = 8192
+    g = torch.Generator(device="cuda").manual_seed(8)
+    b = torch.randn((n, n), dtype=torch.float32, device="cuda", generator=g)
+    a = (b @ b.t() + n * torch.eye(n, dtype=torch.float32, device="cuda")).t()
+    l = a.clone()
+    assert F.llt_factor_in_place(l) == 0
+    F.synchronize()
+    L = torch.tril(l).double()
+    err = torch.tril(L @ L.t() - a.double()).abs().max().item()
+    assert err <= 8 * n * eps * a.abs().max().item()
+    n = 4608
+    a = torch.randn((n, n), dtype=torch.float32, device="cuda", generator=g).t()
+    lu = a.clone()
+    perm, _, _ = F.partial_piv_lu_factor_in_place(lu)
+    F.synchronize()
+    assert sorted(perm.tolist()) == list(range(n))
+    p = torch.as_tensor(perm.astype(np.int64), device="cuda")
+    Lm = (torch.tril(lu, -1) + torch.eye(n, dtype=torch.float32, device="cuda")).double()
+    U = torch.triu(lu).double()
+    assert torch.tril(lu, -1).abs().max().item() <= 1.0 + 1e-6
+    err = (Lm @ U - a.double()[p]).abs().max().item()
+    assert err <= 8 * n * eps * (Lm.abs() @ U.abs()).max().item()
+
+
 # -------------------------------------------------------------------------------------------- distributed lu
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,n,nb", [(512, 512, 64), (1000, 1000, 128), (700, 500, 96), (300, 420, 64)])

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SHAPES = [(1, 1, 1), (15, 16, 17), (17, 15, 16), (127, 129, 128), (129, 127, 130), (64, 1, 33), (1, 70, 9), (5, 7, 0),
-          (256, 256, 256), (300, 200, 1000), (40, 3, 5000), (130, 130, 70), (1, 1, 300), (513, 67, 1)]
+          (256, 256, 256), (300, 200, 1000), (40, 3, 5000), (130, 130, 70), (1, 1, 300), (513, 67, 1),
+          (8, 1, 20000), (1, 6, 9000), (2000, 1, 4100), (700, 900, 1)]  # level-2 shapes incl. split reductions
 
 
 def bound(a, b, c0, k, dtype, alpha):
