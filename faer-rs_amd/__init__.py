@@ -43,6 +43,10 @@ class SliceMut(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("len", C.c_size_t)]
 
 
+class SliceRef(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("len", C.c_size_t)]
+
+
 class Par(C.Structure):
     _fields_ = [("tag", C.c_int), ("nthreads", C.c_size_t)]
 
@@ -380,6 +384,34 @@ def _copy_f(a):
     return np.array(a, order="F", copy=True)
 
 
+def partial_piv_lu_solve_in_place(lu, perm_fwd, perm_bwd, rhs, transpose=False, par=PAR_SEQ):
+    """lu/partial_pivoting/solve.rs:20-80: rhs <- A^-1 rhs (or A^-T rhs); `lu` holds L (unit lower) and U packed"""
+    suf, _, _ = _dtype_suffix(lu)
+    it = "u64" if np.dtype(perm_fwd.dtype) == np.uint64 else "u32"
+    name = "partial_piv_lu_solve_transpose_in_place" if transpose else "partial_piv_lu_solve_in_place"
+    n = lu.shape[0]
+    getattr(lib(), f"libfaer_v0_23_{name}_{it}_{suf}")(
+        _mat(lu), _mat(lu), C.c_int(0), SliceRef(perm_fwd.ctypes.data, n), SliceRef(perm_bwd.ctypes.data, n), _mat(rhs, MatMut), par,
+        MemAlloc(None, 0))
+    return rhs
+
+
+def qr_solve_lstsq_in_place(qr, q_coeff, rhs, par=PAR_SEQ):
+    """qr/no_pivoting/solve.rs:38-75: the least squares solution ends in the top ncols rows of rhs"""
+    suf, _, _ = _dtype_suffix(qr)
+    getattr(lib(), f"libfaer_v0_23_qr_solve_lstsq_in_place_{suf}")(_mat(qr), _mat(q_coeff), _mat(qr), C.c_int(0), _mat(rhs, MatMut), par,
+                                                                   MemAlloc(None, 0))
+    return rhs
+
+
+def qr_solve_in_place(qr, q_coeff, rhs, transpose=False, par=PAR_SEQ):
+    """qr/no_pivoting/solve.rs:98-175: square systems, rhs <- A^-1 rhs or A^-T rhs"""
+    suf, _, _ = _dtype_suffix(qr)
+    name = "qr_solve_transpose_in_place" if transpose else "qr_solve_in_place"
+    getattr(lib(), f"libfaer_v0_23_{name}_{suf}")(_mat(qr), _mat(q_coeff), _mat(qr), C.c_int(0), _mat(rhs, MatMut), par, MemAlloc(None, 0))
+    return rhs
+
+
 class Llt:
     """solvers.rs:770-817: copies the lower triangle, factors, zeroes the strict upper triangle."""
 
@@ -406,18 +438,10 @@ class PartialPivLu:
         self.perm, self.perm_inv, self.transposition_count = partial_piv_lu_factor_in_place(self.lu)
 
     def solve_in_place(self, rhs):
-        # lu/partial_pivoting/solve.rs: x = U^-1 L^-1 P b
-        p = self.perm.astype(np.int64)
-        if _is_torch(rhs):
-            import torch
+        return partial_piv_lu_solve_in_place(self.lu, self.perm, self.perm_inv, rhs)
 
-            rhs.copy_(rhs[torch.as_tensor(p, device=rhs.device)])
-        else:
-            rhs[:] = rhs[p]
-        n = self.lu.shape[1]
-        solve_unit_lower_triangular_in_place(self.lu[:n, :n], rhs)
-        solve_upper_triangular_in_place(self.lu[:n, :n], rhs)
-        return rhs
+    def solve_transpose_in_place(self, rhs):
+        return partial_piv_lu_solve_in_place(self.lu, self.perm, self.perm_inv, rhs, transpose=True)
 
 
 class Qr:
@@ -435,3 +459,6 @@ class Qr:
 
     def Q_coeff(self):
         return self.q_coeff
+
+    def solve_lstsq_in_place(self, rhs):
+        return qr_solve_lstsq_in_place(self.qr, self.q_coeff, rhs)

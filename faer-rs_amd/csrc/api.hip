@@ -170,6 +170,67 @@ template <typename T> void apply_hh_api(FaerMatRef V, FaerMatRef H, FaerMatMut r
 	apply_householder_sequence_left_dev<T>(v.dev, h.dev, x.dev, transpose);
 }
 
+// rhs[i, :] <- rhs[perm[i], :]   (perm/mod.rs:256-294 permute_rows with dst == a copy of src); perm is a HOST slice
+template <typename T, typename I> void permute_rows_dev_api(MatV<T> X, const I *perm_host)
+{
+	const idx_t n = X.nrows, k = X.ncols;
+	if (n == 0 || k == 0)
+		return;
+	std::vector<idx_t> p64((size_t) n);
+	for (idx_t i = 0; i < n; ++i) {
+		p64[(size_t) i] = (idx_t) perm_host[i];
+		FH_CHECK(p64[(size_t) i] >= 0 && p64[(size_t) i] < n, "permutation index out of range");
+	}
+	Scratch pb((size_t) n * sizeof(idx_t)), tb((size_t) n * (size_t) k * sizeof(T));
+	FH_HIP(hipMemcpyAsync(pb.p, p64.data(), (size_t) n * sizeof(idx_t), hipMemcpyHostToDevice, ctx().stream));
+	MatV<T> tmp{tb.as<T>(), n, k, 1, n};
+	gather_rows_dev<T>(tmp, X.c(), pb.as<idx_t>());
+	copy_dev<T>(X, tmp.c());
+	ctx().sync(); // p64 and the scratch buffers go out of scope
+}
+
+// lu/partial_pivoting/solve.rs:20-50 and :52-80
+template <typename T, typename I>
+void lu_solve_api(FaerMatRef L, FaerMatRef U, FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, bool transpose)
+{
+	const size_t n = L.nrows;
+	FH_CHECK(L.ncols == n && U.nrows == n && U.ncols == n && rhs.nrows == n && pf.len >= n && pb.len >= n,
+		 "partial_piv_lu solve: dimension mismatch");
+	FH_CHECK(!is_device_ptr(pf.ptr) && !is_device_ptr(pb.ptr), "partial_piv_lu solve: perm slices must be host memory");
+	Staged<const T> l(view<T>(L), true, false), u(view<T>(U), true, false);
+	Staged<T> x(view<T>(rhs), true, true);
+	if (!transpose) {
+		permute_rows_dev_api<T, I>(x.dev, static_cast<const I *>(pf.ptr));
+		trsm_lower_dev<T>(l.dev, true, x.dev);
+		trsm_upper_dev<T>(u.dev, false, x.dev);
+	} else {
+		trsm_lower_dev<T>(u.dev.t(), false, x.dev);
+		trsm_upper_dev<T>(l.dev.t(), true, x.dev);
+		permute_rows_dev_api<T, I>(x.dev, static_cast<const I *>(pb.ptr)); // the inverse permutation
+	}
+}
+
+// qr/no_pivoting/solve.rs:38-75 (lstsq / square) and :140-175 (transpose)
+template <typename T> void qr_solve_api(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerMatMut rhs, bool transpose, bool square)
+{
+	const size_t m = Qb.nrows, n = Qb.ncols;
+	const size_t size = m < n ? m : n;
+	FH_CHECK(Qc.nrows > 0 && rhs.nrows == m && m >= n && Qc.ncols == size && R.nrows >= size && R.ncols == n,
+		 "qr solve: dimension mismatch");
+	if (square || transpose)
+		FH_CHECK(m == n && R.nrows == n, "qr solve: the factorization must be square");
+	Staged<const T> qb(view<T>(Qb), true, false), qc(view<T>(Qc), true, false), r(view<T>(R), true, false);
+	Staged<T> x(view<T>(rhs), true, true);
+	MatV<const T> Rtop = r.dev.sub(0, 0, (idx_t) size, (idx_t) n);
+	if (!transpose) {
+		apply_householder_sequence_left_dev<T>(qb.dev, qc.dev, x.dev, true); // Q^H rhs
+		trsm_upper_dev<T>(Rtop, false, x.dev.sub(0, 0, (idx_t) size, x.dev.ncols));
+	} else {
+		trsm_lower_dev<T>(Rtop.t(), false, x.dev);
+		apply_householder_sequence_left_dev<T>(qb.dev, qc.dev, x.dev, false); // Q rhs
+	}
+}
+
 FaerLayout layout(size_t bytes, size_t align) { return FaerLayout{bytes, align}; }
 
 } // namespace
@@ -393,6 +454,104 @@ void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m, size_t n, s
 		(void) par;                                                                                            \
 		(void) mem;                                                                                            \
 		apply_hh_api<T>(V, H, rhs, true);                                                                      \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_partial_piv_lu_solve_in_place_scratch_u32_##suf(size_t dim, size_t k, FaerPar par)     \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		return layout(dim * k * sizeof(T), 64);                                                                \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_partial_piv_lu_solve_in_place_scratch_u64_##suf(size_t dim, size_t k, FaerPar par)     \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		return layout(dim * k * sizeof(T), 64);                                                                \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_scratch_u32_##suf(size_t dim, size_t k, FaerPar par) \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		return layout(dim * k * sizeof(T), 64);                                                                \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_scratch_u64_##suf(size_t dim, size_t k, FaerPar par) \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		return layout(dim * k * sizeof(T), 64);                                                                \
+	}                                                                                                              \
+	void libfaer_v0_23_partial_piv_lu_solve_in_place_u32_##suf(FaerMatRef L, FaerMatRef U, FaerConj cj, FaerSliceRef pf, \
+								   FaerSliceRef pb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		lu_solve_api<T, uint32_t>(L, U, pf, pb, rhs, false);                                                   \
+	}                                                                                                              \
+	void libfaer_v0_23_partial_piv_lu_solve_in_place_u64_##suf(FaerMatRef L, FaerMatRef U, FaerConj cj, FaerSliceRef pf, \
+								   FaerSliceRef pb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		lu_solve_api<T, uint64_t>(L, U, pf, pb, rhs, false);                                                   \
+	}                                                                                                              \
+	void libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_u32_##suf(FaerMatRef L, FaerMatRef U, FaerConj cj,   \
+									     FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, \
+									     FaerPar par, FaerMemAlloc mem)                \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		lu_solve_api<T, uint32_t>(L, U, pf, pb, rhs, true);                                                    \
+	}                                                                                                              \
+	void libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_u64_##suf(FaerMatRef L, FaerMatRef U, FaerConj cj,   \
+									     FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, \
+									     FaerPar par, FaerMemAlloc mem)                \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		lu_solve_api<T, uint64_t>(L, U, pf, pb, rhs, true);                                                    \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_qr_solve_in_place_scratch_##suf(size_t dim, size_t bs, size_t k, FaerPar par)          \
+	{                                                                                                              \
+		(void) dim;                                                                                            \
+		(void) par;                                                                                            \
+		return layout(bs * k * sizeof(T), 64);                                                                 \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_qr_solve_transpose_in_place_scratch_##suf(size_t dim, size_t bs, size_t k, FaerPar par) \
+	{                                                                                                              \
+		(void) dim;                                                                                            \
+		(void) par;                                                                                            \
+		return layout(bs * k * sizeof(T), 64);                                                                 \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_qr_solve_lstsq_in_place_scratch_##suf(size_t nrows, size_t ncols, size_t bs, size_t k, \
+								       FaerPar par)                                         \
+	{                                                                                                              \
+		(void) nrows;                                                                                          \
+		(void) ncols;                                                                                          \
+		(void) par;                                                                                            \
+		return layout(bs * k * sizeof(T), 64);                                                                 \
+	}                                                                                                              \
+	void libfaer_v0_23_qr_solve_in_place_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj, FaerMatMut rhs, \
+						   FaerPar par, FaerMemAlloc mem)                                           \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		qr_solve_api<T>(Qb, Qc, R, rhs, false, true);                                                          \
+	}                                                                                                              \
+	void libfaer_v0_23_qr_solve_transpose_in_place_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj,   \
+							     FaerMatMut rhs, FaerPar par, FaerMemAlloc mem)                 \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		qr_solve_api<T>(Qb, Qc, R, rhs, true, true);                                                           \
+	}                                                                                                              \
+	void libfaer_v0_23_qr_solve_lstsq_in_place_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj,       \
+							 FaerMatMut rhs, FaerPar par, FaerMemAlloc mem)                     \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		qr_solve_api<T>(Qb, Qc, R, rhs, false, false);                                                         \
 	}
 FH_FOR_DTYPES(X)
 #undef X

@@ -234,5 +234,6 @@ void apply_householder_sequence_left_dev(MatV<const T> V, MatV<const T> H, MatV<
 // small utility kernels (util.hip)
 template <typename T> void fill_dev(MatV<T> A, DstKind kind, T value);
 template <typename T> void copy_dev(MatV<T> dst, MatV<const T> src);
+template <typename T> void gather_rows_dev(MatV<T> dst, MatV<const T> src, const idx_t *perm_dev); // dst[i,:] = src[perm[i],:]
 
 } // namespace fh

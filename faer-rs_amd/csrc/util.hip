@@ -32,6 +32,34 @@ template <typename T> void copy_dev(MatV<T> dst, MatV<const T> src)
 	FH_HIP(hipGetLastError());
 }
 
+// dst[i, j] = src[perm[i], j]   (perm in device memory)
+template <typename T>
+__global__ void gather_rows_perm_kernel(T *d, idx_t drs, idx_t dcs, const T *s, idx_t srs, idx_t scs, idx_t M, idx_t N,
+					const idx_t *__restrict__ perm)
+{
+	const idx_t total = M * N;
+	for (idx_t e = (idx_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (idx_t) gridDim.x * blockDim.x) {
+		const idx_t i = e % M, j = e / M;
+		d[i * drs + j * dcs] = s[perm[i] * srs + j * scs];
+	}
+}
+
+template <typename T> void gather_rows_dev(MatV<T> dst, MatV<const T> src, const idx_t *perm_dev)
+{
+	FH_CHECK(dst.nrows == src.nrows && dst.ncols == src.ncols, "gather_rows: shape mismatch");
+	if (dst.nrows == 0 || dst.ncols == 0)
+		return;
+	const idx_t total = dst.nrows * dst.ncols;
+	idx_t blocks = (total + 255) / 256;
+	if (blocks > 65536)
+		blocks = 65536;
+	hipLaunchKernelGGL(gather_rows_perm_kernel<T>, dim3((unsigned) blocks), dim3(256), 0, ctx().stream, dst.p, dst.rs, dst.cs, src.p,
+			   src.rs, src.cs, dst.nrows, dst.ncols, perm_dev);
+	FH_HIP(hipGetLastError());
+}
+
+template void gather_rows_dev<double>(MatV<double>, MatV<const double>, const idx_t *);
+template void gather_rows_dev<float>(MatV<float>, MatV<const float>, const idx_t *);
 template void copy_dev<double>(MatV<double>, MatV<const double>);
 template void copy_dev<float>(MatV<float>, MatV<const float>);
 template void copy_dev<long>(MatV<long>, MatV<const long>);

@@ -188,6 +188,42 @@ FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_transpose_on_the_left_sc
 FAER_HIP_API void libfaer_v0_23_apply_householder_transpose_on_the_left_f64(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj householder_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
 FAER_HIP_API void libfaer_v0_23_apply_householder_transpose_on_the_left_f32(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj householder_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
 
+
+/* lib.rs:1985-2056  lu::partial_pivoting::solve::{solve_in_place, solve_transpose_in_place}_with_conj
+ * (lu/partial_pivoting/solve.rs:20-80): rhs <- A^-1 rhs = U^-1 L^-1 P rhs, resp. rhs <- A^-T rhs.
+ * perm slices are HOST memory with `dim` entries (element count, see SURVEY.md section 8b caveat iii). */
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_solve_in_place_scratch_u32_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_solve_in_place_u32_f64(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_scratch_u32_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_u32_f64(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_solve_in_place_scratch_u32_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_solve_in_place_u32_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_scratch_u32_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_u32_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_solve_in_place_scratch_u64_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_solve_in_place_u64_f64(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_scratch_u64_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_u64_f64(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_solve_in_place_scratch_u64_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_solve_in_place_u64_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_scratch_u64_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_solve_transpose_in_place_u64_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+/* lib.rs:1560-1660  qr::no_pivoting::solve::{solve_in_place, solve_transpose_in_place, solve_lstsq_in_place}_with_conj
+ * (qr/no_pivoting/solve.rs:38-175): rhs <- R^-1 Q^H rhs (square or least squares: the solution is the top
+ * ncols rows of rhs), resp. rhs <- Q R^-T rhs. */
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_solve_in_place_scratch_f64(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_solve_in_place_f64(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_solve_transpose_in_place_scratch_f64(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_solve_transpose_in_place_f64(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_solve_lstsq_in_place_scratch_f64(size_t nrows, size_t ncols, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_solve_lstsq_in_place_f64(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_solve_in_place_scratch_f32(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_solve_in_place_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_solve_transpose_in_place_scratch_f32(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_solve_transpose_in_place_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_solve_lstsq_in_place_scratch_f32(size_t nrows, size_t ncols, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_solve_lstsq_in_place_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+
 /* lib.rs:2523-2543  get/set_global_parallelism (faer/src/lib.rs:1107-1150).  Stored and returned only:
  * the GPU backend has no host thread pool. */
 FAER_HIP_API FaerPar libfaer_v0_23_get_global_par(void);

@@ -321,3 +321,27 @@ def test_llt_lookahead_is_deterministic_under_interleaved_work():
             ref = work
         else:
             assert torch.equal(torch.tril(work), torch.tril(ref)), f"iteration {it} differs"
+
+
+# -------------------------------------------------------------------------------------------- solve side
+@pytest.mark.parametrize("n,k", [(1, 1), (17, 3), (200, 5), (513, 64), (1500, 300)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_plu_solve_and_transpose_solve(n, k, dtype):
+    """lu/partial_pivoting/solve.rs:20-80 through the C-ABI: A x = b and A^T x = b (reference test tolerances
+    are 1e-10-ish at n ~ 100 in fp64; scaled with n and eps here)"""
+    F = init_gpu()
+    rng = np.random.default_rng(n + k)
+    a = rnd(rng, n, n, dtype) + n * np.eye(n, dtype=dtype)  # well conditioned
+    b = rnd(rng, n, k, dtype)
+    lu = to_dev(a)
+    perm, perm_inv, _ = F.partial_piv_lu_factor_in_place(lu)
+    tol = 64 * n * EPS[np.dtype(dtype)]
+    x = to_dev(b)
+    F.partial_piv_lu_solve_in_place(lu, perm, perm_inv, x)
+    xs = to_host(x).astype(np.float64)
+    ref = np.linalg.solve(a.astype(np.float64), b.astype(np.float64))
+    assert np.abs(xs - ref).max() <= tol * max(1.0, np.abs(ref).max())
+    xt = to_dev(b)
+    F.partial_piv_lu_solve_in_place(lu, perm, perm_inv, xt, transpose=True)
+    reft = np.linalg.solve(a.astype(np.float64).T, b.astype(np.float64))
+    assert np.abs(to_host(xt).astype(np.float64) - reft).max() <= tol * max(1.0, np.abs(reft).max())

@@ -145,3 +145,27 @@ def test_qr_1e6_rows_fp32_matches_reference_semantics():
     h = torch.zeros((n, n), dtype=torch.float32, device="cuda").t()
     assert F.qr_factor_in_place(a, h) == 0
     assert torch.isinf(torch.diagonal(h)).all().item()
+
+
+@pytest.mark.parametrize("m,n,k", [(10, 2, 1), (100, 50, 3), (300, 300, 7), (2000, 130, 40)])
+def test_qr_solve_lstsq_and_square(m, n, k):
+    """qr/no_pivoting/solve.rs: least squares (reference test_lstsq: 100 x 50, k = 3) and, for square systems,
+    A x = b and A^T x = b"""
+    F = init_gpu()
+    rng = np.random.default_rng(m + n)
+    a = rnd(rng, m, n)
+    b = rnd(rng, m, k)
+    q = F.Qr(to_dev(a))
+    x = to_dev(b)
+    q.solve_lstsq_in_place(x)
+    got = to_host(x)[:n]
+    ref = np.linalg.lstsq(a, b, rcond=None)[0]
+    assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    if m == n:
+        y = to_dev(b)
+        F.qr_solve_in_place(q.Q_basis(), q.Q_coeff(), y)
+        assert np.abs(to_host(y) - np.linalg.solve(a, b)).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+        z = to_dev(b)
+        F.qr_solve_in_place(q.Q_basis(), q.Q_coeff(), z, transpose=True)
+        reft = np.linalg.solve(a.T, b)
+        assert np.abs(to_host(z) - reft).max() <= 1e-8 * max(1.0, np.abs(reft).max())
