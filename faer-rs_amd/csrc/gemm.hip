@@ -39,7 +39,9 @@ template <typename T> struct GemmArgs {
 	T alpha;
 	int add;    // 1: dst += ; 0: dst =
 	int lower;  // 1: only i >= j written
-	int atomic; // split-K: atomicAdd(alpha * partial)
+	int atomic; // split-K: 1 = atomicAdd(alpha * partial) (unused now), 2 = raw partial sums to `ws` (deterministic)
+	T *ws;	    // split-K workspace: slice z at ws + z * M * N, column major M x N
+
 	int k_per_split;
 	int ntm, ntn;
 	int tri_enum; // lower && square tiles: grid enumerates the lower triangle of tiles only
@@ -143,8 +145,8 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 			k_end = min(k_end, n_off + BN);
 	}
 	const bool k_empty = k_begin >= k_end;
-	if (k_empty && (g.add || g.atomic))
-		return; // nothing to accumulate (Replace still has to write zeros)
+	if (k_empty && g.atomic != 2 && (g.add || g.atomic))
+		return; // nothing to accumulate (Replace, and a split-K slice, still have to write zeros)
 
 	// ---- loader state.  MN-major: thread owns one mn index and A_CNT k's (stride KSTEP);
 	//      K-major: thread owns one k and A_CNT mn's (stride MSTEP).
@@ -328,7 +330,9 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				const idx_t mrow = g.row_idx ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
 				T *p = g.dst + mrow * g.drs + ncol * g.dcs;
 				const T v = acc[i][j][r];
-				if (g.atomic)
+				if (g.atomic == 2)
+					g.ws[((size_t) blockIdx.z * g.N + n) * g.M + m] = v; // reduced in a fixed order afterwards
+				else if (g.atomic)
 					atomicAdd(p, g.alpha * v);
 				else if (g.add)
 					*p = __builtin_fma(g.alpha, v, *p);
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 	const int k_begin = blockIdx.z * g.k_per_split;
 	const int k_end = min(g.K, k_begin + g.k_per_split);
 	const bool k_empty = k_begin >= k_end;
-	if (k_empty && (g.add || g.atomic))
+	if (k_empty && g.atomic != 2 && (g.add || g.atomic))
 		return;
 
 	// ---- loader state (see gemm_kernel).  MN-major: one mn, A_CNT k's; K-major: one k, A_CNT mn's.
@@ -700,7 +704,9 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				const idx_t mrow = g.row_idx ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
 				T *p = g.dst + mrow * g.drs + ncol * g.dcs;
 				const T v = acc[i][j][r];
-				if (g.atomic)
+				if (g.atomic == 2)
+					g.ws[((size_t) blockIdx.z * g.N + n) * g.M + m] = v; // reduced in a fixed order afterwards
+				else if (g.atomic)
 					atomicAdd(p, g.alpha * v);
 				else if (g.add)
 					*p = __builtin_fma(g.alpha, v, *p);
@@ -730,6 +736,45 @@ __global__ void fill_kernel(T *p, idx_t rs, idx_t cs, idx_t M, idx_t N, int kind
 }
 
 static inline idx_t iabs(idx_t x) { return x < 0 ? -x : x; }
+
+// second pass of the deterministic split-K: dst(kind) <- [dst +] alpha * sum_z ws[z].  The slice range is cut into
+// 16 fixed segments summed by 16 threads per element (independent loads in flight), the segment sums are
+// combined in segment order: the result depends on the split count only, never on scheduling.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(T *dst, idx_t drs, idx_t dcs, int M, int N, const T *__restrict__ ws,
+							    int splits, T alpha, int add, int lower, int strict)
+{
+	__shared__ T part[16][17];
+	const idx_t total = (idx_t) M * N;
+	const int le = threadIdx.x & 15, seg = threadIdx.x >> 4;
+	const idx_t e = (idx_t) blockIdx.x * 16 + le;
+	const int zs = (splits + 15) / 16;
+	const int z0 = seg * zs, z1 = min(splits, z0 + zs);
+	T acc[4] = {0, 0, 0, 0};
+	if (e < total) {
+		int z = z0;
+		for (; z + 4 <= z1; z += 4) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				acc[u] += ws[(size_t) (z + u) * total + e];
+		}
+		for (; z < z1; ++z)
+			acc[0] += ws[(size_t) z * total + e];
+	}
+	part[seg][le] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+	__syncthreads();
+	if (seg == 0 && e < total) {
+		const int m = (int) (e % M), n = (int) (e / M);
+		if (lower && (m < n || (strict && m == n)))
+			return;
+		T sum = (T) 0;
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+			sum += part[k][le];
+		T *p = dst + (idx_t) m * drs + (idx_t) n * dcs;
+		*p = add ? __builtin_fma(alpha, sum, *p) : alpha * sum;
+	}
+}
 
 template <typename T> static void fill_ext(MatV<T> A, DstKind kind, T value, const GemmExtra<T> *ex)
 {
@@ -861,6 +906,7 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	g.add = add ? 1 : 0;
 	g.lower = kind == DST_LOWER ? 1 : 0;
 	g.atomic = 0;
+	g.ws = nullptr;
 	g.row_idx = ex.row_idx;
 	g.col_idx = ex.col_idx;
 	g.idx64 = ex.idx64;
@@ -944,11 +990,13 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	kps = (kps + 15) / 16 * 16;
 	splits = (int) ((k + kps - 1) / kps);
 	g.k_per_split = (int) kps;
-	if (splits > 1) {
-		if (!add)
-			fill_ext<T>(C, kind, (T) 0, &ex);
-		g.atomic = 1;
-	}
+	// deep-K products are split over workgroups; the slices meet in a workspace and are added in a fixed order by
+	// a second small kernel, so the result does not depend on scheduling (hardware atomics would be faster by one
+	// launch but make every QR run differ in the last bits)
+	Scratch wsb(splits > 1 ? (size_t) splits * (size_t) m * (size_t) n * sizeof(T) : 256);
+	g.ws = wsb.as<T>();
+	if (splits > 1)
+		g.atomic = 2;
 
 	if (ex.inplace)
 		FH_CHECK(splits == 1, "gemm: in-place product cannot be split along K");
@@ -966,6 +1014,13 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		launch_cfg_p<T, 128, 128, 2, 2>(g, akm, bkm, splits);
 	else
 		launch_cfg_p<T, 64, 64, 2, 2>(g, akm, bkm, splits);
+	if (splits > 1) {
+		const idx_t total = m * n;
+		const idx_t blocks = (total + 15) / 16;
+		hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned) blocks), dim3(256), 0, ctx().stream, C.p, C.rs, C.cs, (int) m, (int) n,
+				   wsb.as<T>(), splits, alpha, add ? 1 : 0, g.lower, g.dst_strict);
+		FH_HIP(hipGetLastError());
+	}
 }
 
 // faer/src/linalg/matmul/triangular.rs:1246-1495: only the structured part of each operand is accessed

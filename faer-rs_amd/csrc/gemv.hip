@@ -5,7 +5,7 @@
 // before it reaches the GEMM.  They are pure HBM streams (A is read once, 2 flop per element), so they do not
 // go through the MFMA tile kernel: lanes run along whichever index of A has the unit stride, every lane keeps
 // several independent loads in flight, partial sums meet in LDS, and a long reduction dimension is split over
-// workgroups with hardware fp64 / fp32 atomics.
+// workgroups whose partial sums are added in a fixed order by a second small kernel (deterministic).
 //   y <- [y +] alpha * A x,  A m x k:   unit row stride  -> gemv_mn_kernel (lanes along m, workgroups over m x k slices)
 //                                       unit col stride  -> gemv_k_kernel  (one wave per row, lanes along k)
 //   C <- [C +] alpha * a b^T         -> rank1_kernel (lanes along the unit stride of C)
@@ -21,7 +21,7 @@ static inline idx_t iabs2(idx_t x) { return x < 0 ? -x : x; }
 template <typename T>
 __global__ __launch_bounds__(256) void gemv_mn_kernel(int m, int k, const T *__restrict__ a, idx_t ars, idx_t acs,
 						      const T *__restrict__ x, idx_t xs, T *y, idx_t ys, T alpha, int add, int k_per_slice,
-						      int atomic)
+						      int atomic, T *part)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	const int k0 = blockIdx.y * k_per_slice, k1 = min(k, k0 + k_per_slice);
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void gemv_mn_kernel(int m, int k, const T *__r
 	const T s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 	T *yp = y + (idx_t) i * ys;
 	if (atomic)
-		atomicAdd(yp, alpha * s);
+		part[(size_t) blockIdx.y * m + i] = s; // slices are added in index order by gemv_reduce_kernel
 	else if (add)
 		*yp = __builtin_fma(alpha, s, *yp);
 	else
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void gemv_mn_kernel(int m, int k, const T *__r
 template <typename T>
 __global__ __launch_bounds__(256) void gemv_k_kernel(int m, int k, const T *__restrict__ a, idx_t ars, idx_t acs,
 						     const T *__restrict__ x, idx_t xs, T *y, idx_t ys, T alpha, int add, int k_per_slice,
-						     int atomic)
+						     int atomic, T *part)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int i = blockIdx.x * 4 + wave;
@@ -75,11 +75,37 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(int m, int k, const T *__re
 	if (lane == 0) {
 		T *yp = y + (idx_t) i * ys;
 		if (atomic)
-			atomicAdd(yp, alpha * s);
+			part[(size_t) blockIdx.y * m + i] = s;
 		else if (add)
 			*yp = __builtin_fma(alpha, s, *yp);
 		else
 			*yp = alpha * s;
+	}
+}
+
+// y_i <- [y_i +] alpha * sum_z part[z][i]: 16 fixed slice segments per element, combined in segment order
+// (deterministic split reduction, same scheme as splitk_reduce_kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_reduce_kernel(int m, int slices, const T *__restrict__ part, T *y, idx_t ys, T alpha, int add)
+{
+	__shared__ T sp[16][17];
+	const int le = threadIdx.x & 15, seg = threadIdx.x >> 4;
+	const int i = blockIdx.x * 16 + le;
+	const int zs = (slices + 15) / 16;
+	const int z0 = seg * zs, z1 = min(slices, z0 + zs);
+	T s = (T) 0;
+	if (i < m)
+		for (int z = z0; z < z1; ++z)
+			s += part[(size_t) z * m + i];
+	sp[seg][le] = s;
+	__syncthreads();
+	if (seg == 0 && i < m) {
+		T sum = (T) 0;
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+			sum += sp[k][le];
+		T *yp = y + (idx_t) i * ys;
+		*yp = add ? __builtin_fma(alpha, sum, *yp) : alpha * sum;
 	}
 }
 
@@ -124,15 +150,17 @@ template <typename T> bool gemv_dev(idx_t m, idx_t k, MatV<const T> A, const T *
 	kps = (kps + 255) / 256 * 256;
 	slices = (k + kps - 1) / kps;
 	const int atomic = slices > 1 ? 1 : 0;
-	if (atomic && !add)
-		fill_dev<T>(MatV<T>{y, m, 1, ys, 0}, DST_FULL, (T) 0);
+	Scratch partb(atomic ? (size_t) slices * (size_t) m * sizeof(T) : 256);
 	dim3 grid((unsigned) row_blocks, (unsigned) slices);
 	if (mn)
 		hipLaunchKernelGGL(gemv_mn_kernel<T>, grid, dim3(256), 0, s, (int) m, (int) k, A.p, A.rs, A.cs, x, xs, y, ys, alpha, add ? 1 : 0,
-				   (int) kps, atomic);
+				   (int) kps, atomic, partb.as<T>());
 	else
 		hipLaunchKernelGGL(gemv_k_kernel<T>, grid, dim3(256), 0, s, (int) m, (int) k, A.p, A.rs, A.cs, x, xs, y, ys, alpha, add ? 1 : 0,
-				   (int) kps, atomic);
+				   (int) kps, atomic, partb.as<T>());
+	if (atomic)
+		hipLaunchKernelGGL(gemv_reduce_kernel<T>, dim3((unsigned) ((m + 15) / 16)), dim3(256), 0, s, (int) m, (int) slices, partb.as<T>(),
+				   y, ys, alpha, add ? 1 : 0);
 	FH_HIP(hipGetLastError());
 	return true;
 }
