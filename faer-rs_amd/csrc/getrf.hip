@@ -93,17 +93,34 @@ template <typename T, int W> struct Panel2Shared {
 	int flag;
 };
 
+// Wave-wide arg-max of (|a|, row) with the smaller row winning ties, on the DPP network instead of LDS-crossbar
+// shuffles: quad_perm + row_half_mirror + row_mirror reduce each row of 16 lanes, row_bcast:15 / row_bcast:31
+// carry the partial results across the four rows, lane 63 ends up with the wave result and broadcasts it.
+// (six data-parallel steps of ~7 VALU instructions each instead of eighteen ds_bpermute round trips.)
 static __device__ __forceinline__ void wave_argmax2(double &v, int &r)
 {
-#pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) {
-		const double ov = __shfl_xor(v, off, 64);
-		const int orow = __shfl_xor(r, off, 64);
-		if (better(ov, orow, v, r)) {
-			v = ov;
-			r = orow;
-		}
-	}
+#define FH_DPP_STEP(ctrl, rmask)                                                                                         \
+	do {                                                                                                             \
+		const int lo_ = __double2loint(v), hi_ = __double2hiint(v);                                              \
+		const int olo_ = __builtin_amdgcn_update_dpp(lo_, lo_, ctrl, rmask, 0xf, false);                         \
+		const int ohi_ = __builtin_amdgcn_update_dpp(hi_, hi_, ctrl, rmask, 0xf, false);                         \
+		const int or_ = __builtin_amdgcn_update_dpp(r, r, ctrl, rmask, 0xf, false);                              \
+		const double ov_ = __hiloint2double(ohi_, olo_);                                                         \
+		if (better(ov_, or_, v, r)) {                                                                            \
+			v = ov_;                                                                                         \
+			r = or_;                                                                                         \
+		}                                                                                                        \
+	} while (0)
+	FH_DPP_STEP(0xB1, 0xf);	 // quad_perm [1,0,3,2]
+	FH_DPP_STEP(0x4E, 0xf);	 // quad_perm [2,3,0,1]
+	FH_DPP_STEP(0x141, 0xf); // row_half_mirror
+	FH_DPP_STEP(0x140, 0xf); // row_mirror: every lane of a row now holds the row's best
+	FH_DPP_STEP(0x142, 0xa); // row_bcast:15 into rows 1 and 3
+	FH_DPP_STEP(0x143, 0xc); // row_bcast:31 into rows 2 and 3
+#undef FH_DPP_STEP
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+	v = __hiloint2double(hi, lo);
+	r = __builtin_amdgcn_readlane(r, 63);
 }
 
 static __device__ __forceinline__ double gran_pair_to_double(xwg_u64 h, xwg_u64 l)
