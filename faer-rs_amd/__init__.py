@@ -83,6 +83,24 @@ class QrParams(C.Structure):
     _fields_ = [("blocking_threshold", C.c_size_t), ("par_threshold", C.c_size_t)]
 
 
+class LdltRegularization(C.Structure):
+    """include/faer_hip.h FaerLdltRegularization {delta*, epsilon*, signs: SliceMut of i8}"""
+    _fields_ = [("dynamic_regularization_delta", C.c_void_p), ("dynamic_regularization_epsilon", C.c_void_p),
+                ("dynamic_regularization_signs", SliceMut)]
+
+
+class VecRef(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("len", C.c_size_t), ("stride", C.c_ssize_t)]
+
+
+class LdltError(Exception):
+    """faer::linalg::cholesky::ldlt::factor::LdltError::ZeroPivot { index }"""
+
+    def __init__(self, index):
+        super().__init__(f"ZeroPivot {{ index: {index} }}")
+        self.index = index
+
+
 class LltRegularization(C.Structure):
     _fields_ = [("dynamic_regularization_delta", C.c_void_p), ("dynamic_regularization_epsilon", C.c_void_p)]
 
@@ -124,6 +142,10 @@ def lib():
         getattr(L, f"libfaer_v0_23_qr_factor_in_place_{suf}").restype = QrStatus
         getattr(L, f"libfaer_v0_23_qr_recommended_block_size_{suf}").restype = C.c_size_t
         getattr(L, f"libfaer_v0_23_LltParams_{suf}").restype = LltParams
+        getattr(L, f"libfaer_v0_23_LdltParams_{suf}").restype = LltParams
+        getattr(L, f"libfaer_v0_23_ldlt_factor_in_place_{suf}").restype = LltStatus
+        getattr(L, f"libfaer_v0_23_ldlt_factor_in_place_scratch_{suf}").restype = Layout
+        getattr(L, f"libfaer_v0_23_ldlt_solve_in_place_scratch_{suf}").restype = Layout
         getattr(L, f"libfaer_v0_23_PartialPivLuParams_{suf}").restype = PartialPivLuParams
         getattr(L, f"libfaer_v0_23_QrParams_{suf}").restype = QrParams
         for it in ("u32", "u64"):
@@ -273,6 +295,38 @@ def llt_factor_in_place(a, regularization=(0.0, 0.0), par=PAR_SEQ):
     if st.tag == 1:
         raise LltError(st.value)
     raise RuntimeError("LltStatus::Unknown")
+
+
+def ldlt_factor_in_place(a, regularization=(0.0, 0.0), signs=None, par=PAR_SEQ):
+    """cholesky/ldlt/factor.rs:742-800: unit lower L strictly below the diagonal of `a`, D on it.
+    returns dynamic_regularization_count; raises LdltError(index) like Err(ZeroPivot{index})"""
+    suf, ct, _ = _dtype_suffix(a)
+    delta, eps = ct(regularization[0]), ct(regularization[1])
+    sl = SliceMut(None, 0)
+    if signs is not None:
+        signs = np.ascontiguousarray(signs, dtype=np.int8)
+        sl = SliceMut(signs.ctypes.data, signs.shape[0])
+    reg = LdltRegularization(C.cast(C.pointer(delta), C.c_void_p), C.cast(C.pointer(eps), C.c_void_p), sl)
+    L = lib()
+    params = getattr(L, f"libfaer_v0_23_LdltParams_{suf}")()
+    st = getattr(L, f"libfaer_v0_23_ldlt_factor_in_place_{suf}")(_mat(a, MatMut), reg, par, MemAlloc(None, 0), params)
+    if st.tag == 0:
+        return st.value
+    if st.tag == 1:
+        raise LdltError(st.value)
+    raise RuntimeError("LdltStatus::Unknown")
+
+
+def ldlt_solve_in_place(ld, rhs, par=PAR_SEQ):
+    """cholesky/ldlt/solve.rs:12-50 with L and D packed as ldlt_factor_in_place leaves them"""
+    suf, _, _ = _dtype_suffix(ld)
+    n = ld.shape[0]
+    if _is_torch(ld):
+        d = VecRef(ld.data_ptr(), n, ld.stride(0) + ld.stride(1))
+    else:
+        d = VecRef(ld.ctypes.data, n, (ld.strides[0] + ld.strides[1]) // ld.itemsize)
+    getattr(lib(), f"libfaer_v0_23_ldlt_solve_in_place_{suf}")(_mat(ld), d, C.c_int(0), _mat(rhs, MatMut), par, MemAlloc(None, 0))
+    return rhs
 
 
 def llt_solve_in_place(l, rhs, par=PAR_SEQ):

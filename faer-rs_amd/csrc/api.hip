@@ -84,6 +84,47 @@ template <typename T> FaerLltStatus llt_api(FaerMatMut A, FaerLltRegularization 
 	return st;
 }
 
+template <typename T> FaerLdltStatus ldlt_api(FaerMatMut A, FaerLdltRegularization reg)
+{
+	FH_CHECK(A.nrows == A.ncols, "ldlt: matrix must be square");
+	T delta = reg.dynamic_regularization_delta ? *static_cast<const T *>(reg.dynamic_regularization_delta) : (T) 0;
+	T eps = reg.dynamic_regularization_epsilon ? *static_cast<const T *>(reg.dynamic_regularization_epsilon) : (T) 0;
+	const signed char *signs = static_cast<const signed char *>(reg.dynamic_regularization_signs.ptr);
+	if (signs) {
+		FH_CHECK(reg.dynamic_regularization_signs.len >= A.nrows, "ldlt: the sign slice is shorter than the matrix");
+		FH_CHECK(!is_device_ptr(signs), "ldlt: the sign slice must be host memory");
+	}
+	long r;
+	{
+		Staged<T> a(view<T>(A), true, true);
+		r = sytrf_lower_dev<T>(a.dev, delta, eps, signs);
+	}
+	FaerLdltStatus st;
+	memset(&st, 0, sizeof(st));
+	if (r >= 0) {
+		st.tag = FaerLdltStatus_Ok;
+		st.ok.dynamic_regularization_count = (size_t) r;
+	} else {
+		st.tag = FaerLdltStatus_ZeroPivot;
+		st.zero_pivot.index = (size_t) (-r - 1);
+	}
+	return st;
+}
+
+// cholesky/ldlt/solve.rs:12-50: L y = b (unit lower), y <- D^-1 y, L^H x = y
+template <typename T> void ldlt_solve_api(FaerMatRef L, FaerVecRef D, FaerMatMut rhs)
+{
+	FH_CHECK(L.nrows == L.ncols && rhs.nrows == L.nrows && D.len == L.nrows, "ldlt solve: dimension mismatch");
+	Staged<const T> l(view<T>(L), true, false);
+	// D as an n x 1 view (stride in elements)
+	FaerMatRef Dm{D.ptr, D.len, 1, D.stride, 0};
+	Staged<const T> d(view<T>(Dm), true, false);
+	Staged<T> x(view<T>(rhs), true, true);
+	trsm_lower_dev<T>(l.dev, true, x.dev);
+	scale_rows_recip_dev<T>(x.dev, d.dev.p, d.dev.rs);
+	trsm_upper_dev<T>(l.dev.t(), true, x.dev);
+}
+
 template <typename T> void llt_solve_api(FaerMatRef L, FaerMatMut rhs)
 {
 	// cholesky/llt/solve.rs:12-35: L y = b ; L^H x = y
@@ -346,6 +387,36 @@ void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m, size_t n, s
 		trsm_api<T>(U, rhs, true, true);                                                                       \
 	}                                                                                                              \
 	FaerLltParams libfaer_v0_23_LltParams_##suf(void) { return FaerLltParams{64, 128}; }                            \
+	FaerLdltParams libfaer_v0_23_LdltParams_##suf(void) { return FaerLdltParams{64, 128}; }                         \
+	FaerLayout libfaer_v0_23_ldlt_factor_in_place_scratch_##suf(size_t dim, FaerPar par, FaerLdltParams params)     \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		(void) params;                                                                                         \
+		return layout(dim * sizeof(T), 64);                                                                    \
+	}                                                                                                              \
+	FaerLdltStatus libfaer_v0_23_ldlt_factor_in_place_##suf(FaerMatMut A, FaerLdltRegularization reg, FaerPar par,  \
+								FaerMemAlloc mem, FaerLdltParams params)                    \
+	{                                                                                                              \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		(void) params;                                                                                         \
+		return ldlt_api<T>(A, reg);                                                                            \
+	}                                                                                                              \
+	FaerLayout libfaer_v0_23_ldlt_solve_in_place_scratch_##suf(size_t dim, size_t rhs_ncols, FaerPar par)           \
+	{                                                                                                              \
+		(void) dim;                                                                                            \
+		(void) rhs_ncols;                                                                                      \
+		(void) par;                                                                                            \
+		return layout(0, 1);                                                                                   \
+	}                                                                                                              \
+	void libfaer_v0_23_ldlt_solve_in_place_##suf(FaerMatRef L, FaerVecRef D, FaerConj cj, FaerMatMut rhs, FaerPar par, \
+						     FaerMemAlloc mem)                                                      \
+	{                                                                                                              \
+		(void) cj;                                                                                             \
+		(void) par;                                                                                            \
+		(void) mem;                                                                                            \
+		ldlt_solve_api<T>(L, D, rhs);                                                                          \
+	}                                                                                                              \
 	FaerLayout libfaer_v0_23_llt_factor_in_place_scratch_##suf(size_t dim, FaerPar par, FaerLltParams params)       \
 	{                                                                                                              \
 		(void) par;                                                                                            \

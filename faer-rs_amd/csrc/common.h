@@ -217,6 +217,10 @@ template <typename T> void trsm_lower_pre_dev(MatV<const T> L, MatV<T> X, const 
 // in-place lower Cholesky; returns >=0 regularization count or -(index+1)   (potrf.hip)
 template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps);
 
+// in-place unit-lower L D L^T without pivoting (potrf.hip); L strictly below the diagonal, D on it; `signs_host`: n int8
+// expected pivot signs or NULL; returns >= 0 regularization count or -(index + 1) of the zero pivot
+template <typename T> long sytrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps, const signed char *signs_host);
+
 // partial pivot LU; perm/perm_inv are HOST arrays of idx_t (m entries)   (getrf.hip)
 template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv);
 
@@ -235,5 +239,6 @@ void apply_householder_sequence_left_dev(MatV<const T> V, MatV<const T> H, MatV<
 template <typename T> void fill_dev(MatV<T> A, DstKind kind, T value);
 template <typename T> void copy_dev(MatV<T> dst, MatV<const T> src);
 template <typename T> void gather_rows_dev(MatV<T> dst, MatV<const T> src, const idx_t *perm_dev); // dst[i,:] = src[perm[i],:]
+template <typename T> void scale_rows_recip_dev(MatV<T> X, const T *d, idx_t ds);		       // X[i,:] *= 1 / d[i]
 
 } // namespace fh

@@ -76,11 +76,16 @@ __device__ unsigned long long g_leaf_timing[8];
 	} while (0)
 #endif
 
-template <typename T>
+// LDLT == true: the same leaf for the unit-lower L D L^T factorization (cholesky/ldlt/factor.rs with is_llt ==
+// false): the pivot d_j is kept (no root), regularised according to its expected sign, a zero / non finite pivot
+// is the error, the column is divided by d_j, the updates are weighted by d_j, D goes to `Dout` and -- like the
+// reference's cholesky_in_place (:791-798) -- onto the diagonal of A.
+template <typename T, bool LDLT>
 __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_t cs, int n, int regularize, T eps, T delta,
-							   int *status, int offset, T *Winv)
+							   int *status, int offset, T *Winv, const signed char *signs, T *Dout)
 {
 	__shared__ T S[LDS_NB * LDS_LDP];
+	__shared__ T s_d[LDS_NB]; // LDLT: the pivots of this block
 	__shared__ int s_fail;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	if (status[0] != 0)
@@ -122,49 +127,70 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 			// the reciprocal root of column j is computed one iteration ahead, right after the diagonal entry
 			// a_jj has received its last update through the register path, so that the long latencies
 			// (rsq chain, LDS round trip of the multipliers) overlap instead of adding up
-			T inv;
+			T inv, dj = (T) 1; // dj: the pivot of the current column (LDLT)
 			bool ok;
-			{
-				T d = lane_bcast(a[0], 0);
-				if (regularize && d <= eps) { // cholesky/ldlt/factor.rs:122-131 (llt: sign == +1)
-					d = delta;
-					if (j0 < n)
-						++count;
+			// pivot of column jc from its updated diagonal entry d: regularisation (cholesky/ldlt/factor.rs:122-144;
+			// llt: sign == +1, only that correction is counted), then 1/sqrt(d) (LLT) or 1/d (LDLT)
+			auto pivot = [&](T d, int jc, T &inv_out, T &d_out) -> bool {
+				if (regularize) {
+					if constexpr (LDLT) {
+						const int sign = (signs && jc < n) ? (int) signs[offset + jc] : 0;
+						const bool small_or_negative = d <= eps, minus_small_or_positive = d >= -eps;
+						if (sign == 1 && small_or_negative) {
+							d = delta;
+							if (jc < n)
+								++count;
+						} else if (sign == -1 && minus_small_or_positive) {
+							d = -delta;
+						} else if (small_or_negative && minus_small_or_positive) {
+							d = d < (T) 0 ? -delta : delta;
+						}
+					} else if (d <= eps) {
+						d = delta;
+						if (jc < n)
+							++count;
+					}
 				}
-				ok = recip_sqrt(d, inv);
-			}
+				d_out = d;
+				if constexpr (LDLT) {
+					inv_out = (T) 1 / d;
+					return d != (T) 0 && isfinite(d);
+				} else {
+					return recip_sqrt(d, inv_out);
+				}
+			};
+			ok = pivot(lane_bcast(a[0], 0), j0, inv, dj);
 #pragma unroll
 			for (int j = 0; j < POTRF_PB; ++j) {
 				if (fail_col == 0) { // wave uniform
 					if (!ok) {
 						fail_col = j0 + j + 1;
+						if (LDLT && wave == 0 && lane == 0)
+							s_d[j0 + j] = dj; // the failing pivot still goes to D (factor.rs:343-347, :791-798)
 					} else {
 						const T lj = a[j] * inv; // column j, diagonal entry included (factor.rs:160-174)
+						const T wj = LDLT ? dj : (T) 1; // weight of column j in the updates: a_ik -= l_ij d_j l_kj
 						// column j is final: park it in the block image (every panel wave writes the same
 						// diagonal-block values); the multipliers l_kj, k >= j + 2, come back as broadcast reads
 						// (LDS operations of one wavefront execute in order)
 						T *colj = S + (j0 + j) * LDS_LDP;
 						if (valid && (!diag_lane || lane >= j))
 							colj[row] = lj;
+						if (LDLT && wave == 0 && lane == 0)
+							s_d[j0 + j] = dj;
 						__builtin_amdgcn_wave_barrier();
 						T mult[POTRF_PB];
 #pragma unroll
 						for (int k = j + 2; k < POTRF_PB; ++k)
-							mult[k] = colj[j0 + k];
+							mult[k] = colj[j0 + k] * wj;
 						if (j + 1 < POTRF_PB) {
-							// critical path: next diagonal entry through v_readlane, then its reciprocal root
-							a[j + 1] = __builtin_fma(-lj, lane_bcast(lj, j + 1), a[j + 1]);
-							T d = lane_bcast(a[j + 1], j + 1);
-							if (regularize && d <= eps) {
-								d = delta;
-								if (j0 + j + 1 < n)
-									++count;
-							}
-							ok = recip_sqrt(d, inv);
+							// critical path: next diagonal entry through v_readlane, then its pivot
+							a[j + 1] = __builtin_fma(-lj, lane_bcast(lj, j + 1) * wj, a[j + 1]);
+							ok = pivot(lane_bcast(a[j + 1], j + 1), j0 + j + 1, inv, dj);
 						}
 #pragma unroll
 						for (int k = j + 2; k < POTRF_PB; ++k)
-							a[k] = __builtin_fma(-lj, mult[k], a[k]); // a_ik -= l_ij l_kj
+							a[k] = __builtin_fma(-lj, mult[k], a[k]); // a_ik -= l_ij (d_j) l_kj
 					}
 				}
 			}
@@ -197,7 +223,7 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 				const T *pb = S + (j0 + lhi) * LDS_LDP + t0 + tj * 16 + l15;
 #pragma unroll
 				for (int kk = 0; kk < POTRF_PB; kk += 4)
-					acc = Mfma<T>::run(pa[kk * LDS_LDP], pb[kk * LDS_LDP], acc);
+					acc = Mfma<T>::run(pa[kk * LDS_LDP], LDLT ? pb[kk * LDS_LDP] * s_d[j0 + kk + lhi] : pb[kk * LDS_LDP], acc);
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					const int gi = t0 + ti * 16 + Mfma<T>::row(r, lhi), gj = t0 + tj * 16 + l15;
@@ -210,6 +236,16 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 		FH_LT(2);
 	}
 	// ---- write back the lower triangle (also after a failure: the columns before the failing one are final)
+	if constexpr (LDLT) {
+		// D for the columns 0 .. index (cholesky/ldlt/factor.rs:791-798), both on the diagonal of A and in Dout
+		const int init = failed ? s_fail : n;
+		__syncthreads();
+		if (tid < n && tid < init) {
+			S[tid * LDS_LDP + tid] = s_d[tid];
+			Dout[offset + tid] = s_d[tid];
+		}
+		__syncthreads();
+	}
 	lds_store_block<T>(S, A, rs, cs, n, true);
 	FH_LT(3);
 	if (failed) {
@@ -221,7 +257,7 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 		atomicAdd(status + 1, count);
 	if (Winv) {
 		__syncthreads();
-		lds_tri_inv_inplace<T>(S, 0);
+		lds_tri_inv_inplace<T>(S, LDLT ? 1 : 0);
 		FH_LT(4);
 		lds_store_block<T>(S, Winv, 1, LDS_NB, LDS_NB, false);
 		FH_LT(5);
@@ -241,8 +277,8 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 		return;
 	if (n <= POTRF_NB) {
 		T *W = need_inv ? Wbase + (size_t) (offset / POTRF_NB) * POTRF_NB * POTRF_NB : nullptr;
-		hipLaunchKernelGGL(potrf_leaf_kernel<T>, dim3(1), dim3(LDS_NT), 0, ctx().stream, A.p, A.rs, A.cs, (int) n, regularize,
-				   eps, delta, status, (int) offset, W);
+		hipLaunchKernelGGL((potrf_leaf_kernel<T, false>), dim3(1), dim3(LDS_NT), 0, ctx().stream, A.p, A.rs, A.cs, (int) n, regularize,
+				   eps, delta, status, (int) offset, W, (const signed char *) nullptr, (T *) nullptr);
 		FH_HIP(hipGetLastError());
 		return;
 	}
@@ -428,6 +464,90 @@ template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps)
 	return (long) h[1];
 }
 
+// ------------------------------------------------------------------------------------------------
+// L D L^T (unit lower L, diagonal D; no pivoting) -- cholesky/ldlt/factor.rs:367-498 with is_llt == false,
+// SURVEY.md section 8f item 1.  Same recursion by halves and the same leaf; the panel solve is the unit-lower
+// TRSM against the leaf inverses, then A10 is scaled by 1/D0 (:447-455) and the trailing update is the
+// diagonally weighted product of the spicy_matmul surface (:456-470): lower(A11) -= L10 D0 L10^T.
+// ------------------------------------------------------------------------------------------------
+template <typename T> __global__ void scale_cols_recip_kernel(T *X, idx_t rs, idx_t cs, idx_t m, idx_t n, const T *__restrict__ d)
+{
+	const idx_t total = m * n;
+	for (idx_t e = (idx_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (idx_t) gridDim.x * blockDim.x) {
+		const idx_t i = e % m, k = e / m;
+		X[i * rs + k * cs] *= (T) 1 / d[k];
+	}
+}
+
+template <typename T>
+static void sytrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase, bool need_inv, const signed char *signs,
+		      T *Dv)
+{
+	const idx_t n = A.nrows;
+	if (n == 0)
+		return;
+	if (n <= POTRF_NB) {
+		T *W = need_inv ? Wbase + (size_t) (offset / POTRF_NB) * POTRF_NB * POTRF_NB : nullptr;
+		hipLaunchKernelGGL((potrf_leaf_kernel<T, true>), dim3(1), dim3(LDS_NT), 0, ctx().stream, A.p, A.rs, A.cs, (int) n, regularize, eps,
+				   delta, status, (int) offset, W, signs, Dv);
+		FH_HIP(hipGetLastError());
+		return;
+	}
+	const idx_t h = ((n / 2 + POTRF_NB - 1) / POTRF_NB) * POTRF_NB;
+	MatV<T> A00 = A.sub(0, 0, h, h), A10 = A.sub(h, 0, n - h, h), A11 = A.sub(h, h, n - h, n - h);
+	sytrf_rec<T>(A00, regularize, eps, delta, status, offset, Wbase, true, signs, Dv);
+	// A10 <- A10 L00^-T (unit lower; the leaf inverses were taken of the unit triangles) = L10 D0
+	trsm_lower_pre_dev<T>(A00.c(), A10.t(), Wbase + (size_t) (offset / POTRF_NB) * POTRF_NB * POTRF_NB);
+	// A10 <- L10 = A10 D0^-1
+	{
+		const idx_t total = (n - h) * h;
+		idx_t blocks = (total + 255) / 256;
+		if (blocks > 65536)
+			blocks = 65536;
+		hipLaunchKernelGGL(scale_cols_recip_kernel<T>, dim3((unsigned) blocks), dim3(256), 0, ctx().stream, A10.p, A10.rs, A10.cs, n - h, h,
+				   Dv + offset);
+		FH_HIP(hipGetLastError());
+	}
+	// lower(A11) -= L10 D0 L10^T
+	GemmExtra<T> ex;
+	ex.diag = Dv + offset;
+	ex.diag_stride = 1;
+	gemm_dev<T>(A11, DST_LOWER, true, A10.c(), A10.t().c(), (T) -1, &ex);
+	sytrf_rec<T>(A11, regularize, eps, delta, status, offset + h, Wbase, need_inv, signs, Dv);
+}
+
+// returns >= 0: regularization count, < 0: -(index + 1) of the zero pivot.  `signs_host`: n int8 or NULL.
+template <typename T> long sytrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps, const signed char *signs_host)
+{
+	FH_CHECK(A.nrows == A.ncols, "ldlt: matrix must be square");
+	FH_CHECK(A.nrows < (1L << 30), "ldlt: matrix too large");
+	if (A.nrows == 0)
+		return 0;
+	const idx_t n = A.nrows;
+	Scratch st(64);
+	int *status = st.as<int>();
+	FH_HIP(hipMemsetAsync(status, 0, 64, ctx().stream));
+	const idx_t nblk = (n + POTRF_NB - 1) / POTRF_NB;
+	Scratch winv(n > POTRF_NB ? (size_t) nblk * POTRF_NB * POTRF_NB * sizeof(T) : 256);
+	Scratch dv((size_t) n * sizeof(T)), sg((size_t) n + 256);
+	const int regularize = (reg_delta > (T) 0 && reg_eps > (T) 0) ? 1 : 0; // cholesky/ldlt/factor.rs:766-767
+	const signed char *signs = nullptr;
+	if (signs_host && regularize) {
+		FH_HIP(hipMemcpyAsync(sg.p, signs_host, (size_t) n, hipMemcpyHostToDevice, ctx().stream));
+		signs = sg.as<signed char>();
+	}
+	sytrf_rec<T>(A, regularize, reg_eps, reg_delta, status, 0, winv.as<T>(), false, signs, dv.as<T>());
+	int h[2] = {0, 0};
+	FH_HIP(hipMemcpyAsync(h, status, sizeof(h), hipMemcpyDeviceToHost, ctx().stream));
+	ctx().sync();
+	ctx().quiesce();
+	if (h[0] != 0)
+		return -(long) h[0];
+	return (long) h[1];
+}
+
+template long sytrf_lower_dev<double>(MatV<double>, double, double, const signed char *);
+template long sytrf_lower_dev<float>(MatV<float>, float, float, const signed char *);
 template long potrf_lower_dev<double>(MatV<double>, double, double);
 template long potrf_lower_dev<float>(MatV<float>, float, float);
 

@@ -91,10 +91,22 @@ typedef struct FaerQrStatus {
 
 /* params: faer-ffi/src/lib.rs:650-690 (cparams!) */
 typedef struct FaerLltParams { size_t recursion_threshold; size_t block_size; } FaerLltParams;
+typedef struct FaerLdltParams { size_t recursion_threshold; size_t block_size; } FaerLdltParams; /* lib.rs:660-664 */
+/* lib.rs:572-575, faer.h:346-366: Ok{dynamic_regularization_count} | ZeroPivot{index} | Unknown */
+typedef enum FaerLdltStatus_Tag { FaerLdltStatus_Ok = 0, FaerLdltStatus_ZeroPivot = 1, FaerLdltStatus_Unknown = 2 } FaerLdltStatus_Tag;
+typedef struct FaerLdltStatus {
+	FaerLdltStatus_Tag tag;
+	union {
+		struct { size_t dynamic_regularization_count; } ok;
+		struct { size_t index; } zero_pivot;
+	};
+} FaerLdltStatus;
 typedef struct FaerPartialPivLuParams { size_t recursion_threshold; size_t block_size; size_t par_threshold; } FaerPartialPivLuParams;
 typedef struct FaerQrParams { size_t blocking_threshold; size_t par_threshold; } FaerQrParams;
 /* faer-ffi/src/lib.rs:796-801; pointers to a real scalar of the matrix dtype (HOST memory), NULL == 0 */
 typedef struct FaerLltRegularization { const void *dynamic_regularization_delta; const void *dynamic_regularization_epsilon; } FaerLltRegularization;
+/* lib.rs:820-828: signs is a slice of i8 (HOST memory, `dim` entries) or a null ptr */
+typedef struct FaerLdltRegularization { const void *dynamic_regularization_delta; const void *dynamic_regularization_epsilon; FaerSliceMut dynamic_regularization_signs; } FaerLdltRegularization;
 
 /* ---------------------------------------------------------------------------------------------
  * 1. INNER boundary -- replaces private_gemm_x86::gemm (call sites above).
@@ -223,6 +235,21 @@ FAER_HIP_API FaerLayout libfaer_v0_23_qr_solve_transpose_in_place_scratch_f32(si
 FAER_HIP_API void libfaer_v0_23_qr_solve_transpose_in_place_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
 FAER_HIP_API FaerLayout libfaer_v0_23_qr_solve_lstsq_in_place_scratch_f32(size_t nrows, size_t ncols, size_t block_size, size_t rhs_ncols, FaerPar par);
 FAER_HIP_API void libfaer_v0_23_qr_solve_lstsq_in_place_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+
+
+/* ---- next scope row: L D L^T without pivoting ---------------------------------
+ * lib.rs:1189-1217  ldlt::factor::cholesky_in_place (cholesky/ldlt/factor.rs:742-800): unit lower L strictly below
+ * the diagonal of A, D on it; lib.rs:1218-1250  ldlt::solve::solve_in_place_with_conj (cholesky/ldlt/solve.rs:12-50) */
+FAER_HIP_API FaerLdltParams libfaer_v0_23_LdltParams_f64(void);
+FAER_HIP_API FaerLdltParams libfaer_v0_23_LdltParams_f32(void);
+FAER_HIP_API FaerLayout libfaer_v0_23_ldlt_factor_in_place_scratch_f64(size_t dim, FaerPar par, FaerLdltParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_ldlt_factor_in_place_scratch_f32(size_t dim, FaerPar par, FaerLdltParams params);
+FAER_HIP_API FaerLdltStatus libfaer_v0_23_ldlt_factor_in_place_f64(FaerMatMut A, FaerLdltRegularization regularization, FaerPar par, FaerMemAlloc mem, FaerLdltParams params);
+FAER_HIP_API FaerLdltStatus libfaer_v0_23_ldlt_factor_in_place_f32(FaerMatMut A, FaerLdltRegularization regularization, FaerPar par, FaerMemAlloc mem, FaerLdltParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_ldlt_solve_in_place_scratch_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API FaerLayout libfaer_v0_23_ldlt_solve_in_place_scratch_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_ldlt_solve_in_place_f64(FaerMatRef L, FaerVecRef D, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API void libfaer_v0_23_ldlt_solve_in_place_f32(FaerMatRef L, FaerVecRef D, FaerConj A_conj, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
 
 /* lib.rs:2523-2543  get/set_global_parallelism (faer/src/lib.rs:1107-1150).  Stored and returned only:
  * the GPU backend has no host thread pool. */

@@ -284,6 +284,101 @@ static long FN(chol_rec)(FN(mat) A, T *D, long rec_threshold, long block_size, i
 	}
 	return count;
 }
+/* ------------------------------------------------------------------ LDLT */
+/* cholesky/ldlt/factor.rs:299-366 with is_llt == false: a_ij -= sum_k a_jk a_ik D_k; the pivot is regularised
+ * according to its expected sign (:318-340: only the sign == +1 correction is counted); a zero or non finite
+ * pivot is an error (ZeroPivot); the column, diagonal included, is multiplied by 1/d. */
+static long FN(ldlt_base)(FN(mat) A, T *D, int regularize, T eps, T delta, const signed char *signs)
+{
+	long n = A.nrows, count = 0;
+	for (long j = 0; j < n; j++) {
+		for (long i = j; i < n; i++) {
+			T sum = 0;
+			for (long k = 0; k < j; k++)
+				sum = sum + AT(A, j, k) * (AT(A, i, k) * D[k]);
+			AT(A, i, j) = AT(A, i, j) - sum;
+		}
+		T diag = AT(A, j, j);
+		if (regularize) {
+			int sign = signs ? (int)signs[j] : 0;
+			int small_or_negative = diag <= eps;
+			int minus_small_or_positive = diag >= -eps;
+			if (sign == 1 && small_or_negative) {
+				diag = delta;
+				count += 1;
+			} else if (sign == -1 && minus_small_or_positive) {
+				diag = -delta;
+			} else if (small_or_negative && minus_small_or_positive) {
+				diag = diag < 0 ? -delta : delta;
+			}
+		}
+		D[j] = diag;
+		if (diag == 0 || !isfinite(diag))
+			return -(j + 1);
+		T inv = (T)1 / diag;
+		for (long i = j; i < n; i++)
+			AT(A, i, j) = AT(A, i, j) * inv;
+	}
+	return count;
+}
+/* cholesky/ldlt/factor.rs:367-498, !is_llt branch (:428-434 unit lower solve, :447-470 scaling by 1/D and the
+ * diagonally weighted update).  The public entry point runs the left-looking sibling (:499-659), which
+ * computes the same factors in a different summation order. */
+static long FN(ldlt_rec)(FN(mat) A, T *D, long rec_threshold, long block_size, int regularize, T eps, T delta,
+			 const signed char *signs)
+{
+	long n = A.ncols;
+	if (n <= rec_threshold)
+		return FN(ldlt_base)(A, D, regularize, eps, delta, signs);
+	long count = 0;
+	long bs0 = FN(next_pow2)(n) / 2;
+	if (bs0 > block_size)
+		bs0 = block_size;
+	long j = 0;
+	while (j < n) {
+		long bs = bs0 < n - j ? bs0 : n - j;
+		long r1 = n - j - bs;
+		FN(mat) A00 = FN(sub)(A, j, j, bs, bs);
+		FN(mat) A10 = FN(sub)(A, j + bs, j, r1, bs);
+		FN(mat) A11 = FN(sub)(A, j + bs, j + bs, r1, r1);
+		long r = FN(ldlt_rec)(A00, D + j, rec_threshold, bs, regularize, eps, delta, signs ? signs + j : 0);
+		if (r < 0)
+			return -(j + (-r - 1) + 1);
+		count += r;
+		FN(trsm_lower)(A00, 1, FN(tr)(A10)); /* A10 <- A10 L00^-T (unit lower) = L10 D0 */
+		/* A11(lower) -= (L10 D0) L10^T, then A10 <- L10 */
+		for (long jj = 0; jj < r1; jj++)
+			for (long ii = jj; ii < r1; ii++) {
+				T acc = 0;
+				for (long k = 0; k < bs; k++)
+					acc = FMA(AT(A10, ii, k), AT(A10, jj, k) * ((T)1 / D[j + k]), acc);
+				AT(A11, ii, jj) = AT(A11, ii, jj) - acc;
+			}
+		for (long k = 0; k < bs; k++) {
+			T d = (T)1 / D[j + k];
+			for (long i = 0; i < r1; i++)
+				AT(A10, i, k) = AT(A10, i, k) * d;
+		}
+		j += bs;
+	}
+	return count;
+}
+/* cholesky/ldlt/factor.rs:742-800 cholesky_in_place: L (unit lower, strictly below the diagonal) and D (on the
+ * diagonal, written for the columns 0 .. index on failure).  Returns the regularization count or -(index+1). */
+long FN(oracle_ldlt_in_place)(T *a, long n, long rs, long cs, T reg_delta, T reg_eps, const signed char *signs,
+			      long rec_threshold, long block_size)
+{
+	FN(mat) A = {a, n, n, rs, cs};
+	T *D = (T *)malloc(sizeof(T) * (size_t)(n > 0 ? n : 1));
+	int regularize = (reg_delta > 0 && reg_eps > 0);
+	long r = FN(ldlt_rec)(A, D, rec_threshold, block_size, regularize, reg_eps, reg_delta, signs);
+	long init = r < 0 ? -r : n; /* index + 1 */
+	for (long i = 0; i < init; i++)
+		AT(A, i, i) = D[i];
+	free(D);
+	return r;
+}
+
 /* cholesky/llt/factor.rs:67-97.  Returns dynamic_regularization_count (>=0)
  * or -(index+1) for NonPositivePivot{index}. */
 long FN(oracle_llt_in_place)(T *a, long n, long rs, long cs, T reg_delta, T reg_eps, long rec_threshold,

@@ -46,7 +46,7 @@ def lib():
         _LIB = C.CDLL(build())
         for suf, ct in (("f64", C.c_double), ("f32", C.c_float)):
             getattr(_LIB, f"oracle_norm_l2_{suf}").restype = ct
-            for name in ("oracle_llt_in_place", "oracle_lu_in_place", "oracle_qr_in_place",
+            for name in ("oracle_llt_in_place", "oracle_ldlt_in_place", "oracle_lu_in_place", "oracle_qr_in_place",
                          "oracle_qr_recommended_block_size"):
                 getattr(_LIB, f"{name}_{suf}").restype = C.c_long
     return _LIB
@@ -107,6 +107,20 @@ def llt_in_place(a, reg_delta=0.0, reg_eps=0.0, recursion_threshold=64, block_si
     r = getattr(lib(), f"oracle_llt_in_place_{suf}")(_p(a), C.c_long(n), *_st(a), ct(reg_delta), ct(reg_eps),
                                                     C.c_long(recursion_threshold), C.c_long(block_size))
     return ("ok", r) if r >= 0 else ("non_positive_pivot", -r - 1)
+
+
+def ldlt_in_place(a, reg_delta=0.0, reg_eps=0.0, signs=None, recursion_threshold=64, block_size=128):
+    """cholesky/ldlt/factor.rs:742-800: unit lower L below the diagonal, D on it.
+    returns ('ok', count) or ('zero_pivot', index)"""
+    suf, ct = _suf(a)
+    n = a.shape[0]
+    sp = None
+    if signs is not None:
+        signs = np.ascontiguousarray(signs, dtype=np.int8)
+        sp = signs.ctypes.data_as(C.c_void_p)
+    r = getattr(lib(), f"oracle_ldlt_in_place_{suf}")(_p(a), C.c_long(n), *_st(a), ct(reg_delta), ct(reg_eps), sp,
+                                                     C.c_long(recursion_threshold), C.c_long(block_size))
+    return ("ok", r) if r >= 0 else ("zero_pivot", -r - 1)
 
 
 def lu_in_place(a, recursion_threshold=16):

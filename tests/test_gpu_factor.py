@@ -345,3 +345,92 @@ def test_plu_solve_and_transpose_solve(n, k, dtype):
     F.partial_piv_lu_solve_in_place(lu, perm, perm_inv, xt, transpose=True)
     reft = np.linalg.solve(a.astype(np.float64).T, b.astype(np.float64))
     assert np.abs(to_host(xt).astype(np.float64) - reft).max() <= tol * max(1.0, np.abs(reft).max())
+
+
+# -------------------------------------------------------------------------------------------- ldlt
+def _quasi_definite(rng, n, dtype=np.float64):
+    n1 = n // 2
+    h = rng.standard_normal((n, n))
+    H = h[:n1, :n1] @ h[:n1, :n1].T + n * np.eye(n1)
+    G = h[n1:, n1:] @ h[n1:, n1:].T + n * np.eye(n - n1)
+    B = h[n1:, :n1]
+    return np.asarray(np.block([[H, B.T], [B, -G]]), dtype=dtype, order="F"), n1
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 127, 128, 129, 257, 640, 1100])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ldlt_vs_oracle(oracle, n, dtype):
+    F = init_gpu()
+    rng = np.random.default_rng(n)
+    a, n1 = _quasi_definite(rng, n, dtype)
+    marked = a.copy(order="F")
+    iu = np.triu_indices(n, 1)
+    marked[iu] = -7.5
+    ref = marked.copy(order="F")
+    assert oracle.ldlt_in_place(ref) == ("ok", 0)
+    d = to_dev(marked)
+    assert F.ldlt_factor_in_place(d) == 0
+    got = to_host(d)
+    assert (got[iu] == -7.5).all()
+    tol = 64 * n * EPS[np.dtype(dtype)]
+    assert np.abs(np.tril(got) - np.tril(ref)).max() <= tol * max(1.0, np.abs(np.tril(ref)).max())
+    D = np.diag(got).astype(np.float64)
+    assert (D[:n1] > 0).all() and (D[n1:] < 0).all()
+
+
+def test_ldlt_zero_pivot_regularization_and_solve(oracle):
+    F = init_gpu()
+    rng = np.random.default_rng(3)
+    n, bad = 300, 211
+    a, _ = _quasi_definite(rng, n)
+    # make the leading (bad+1) x (bad+1) minor singular: row/column `bad` duplicates row/column 5
+    s = a.copy(order="F")
+    s[bad, :] = s[5, :]
+    s[:, bad] = s[:, 5]
+    s[bad, bad] = s[5, 5]
+    ref = s.copy(order="F")
+    kind, idx = oracle.ldlt_in_place(ref)
+    d = to_dev(s)
+    if kind == "zero_pivot":
+        with pytest.raises(F.LdltError) as ei:
+            F.ldlt_factor_in_place(d)
+        assert ei.value.index == idx
+    # regularization with expected signs: same count and factors as the oracle
+    signs = np.where(np.arange(n) < n // 2, 1, -1).astype(np.int8)
+    ref = s.copy(order="F")
+    r = oracle.ldlt_in_place(ref, 1e-2, 1e-9, signs=signs)
+    assert r[0] == "ok"
+    d = to_dev(s)
+    assert F.ldlt_factor_in_place(d, (1e-2, 1e-9), signs=signs) == r[1]
+    got = to_host(d)
+    assert np.abs(np.tril(got) - np.tril(ref)).max() <= 1e-6 * max(1.0, np.abs(np.tril(ref)).max())
+    # solve with a well conditioned matrix
+    ld = to_dev(a)
+    assert F.ldlt_factor_in_place(ld) == 0
+    b = rnd(rng, n, 5)
+    x = to_dev(b)
+    F.ldlt_solve_in_place(ld, x)
+    assert np.abs(to_host(x) - np.linalg.solve(a, b)).max() <= 1e-9
+
+
+def test_ldlt_large_property():
+    """n = 4096 fp64: L D L^T == A entrywise on the lower triangle"""
+    import torch
+
+    F = init_gpu()
+    n = 4096
+    n1 = n // 2
+    g = torch.Generator(device="cuda").manual_seed(12)
+    h = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g)
+    a = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    a[:n1, :n1] = h[:n1, :n1] @ h[:n1, :n1].t() + n * torch.eye(n1, dtype=torch.float64, device="cuda")
+    a[n1:, n1:] = -(h[n1:, n1:] @ h[n1:, n1:].t() + n * torch.eye(n - n1, dtype=torch.float64, device="cuda"))
+    a[n1:, :n1] = h[n1:, :n1]
+    a[:n1, n1:] = h[n1:, :n1].t()
+    w = a.t().clone().t()  # column major
+    assert F.ldlt_factor_in_place(w) == 0
+    F.synchronize()
+    L = torch.tril(w, -1) + torch.eye(n, dtype=torch.float64, device="cuda")
+    D = torch.diagonal(w)
+    err = torch.tril(L @ (D[:, None] * L.t()) - a).abs().max().item()
+    assert err <= 32 * n * 2.3e-16 * a.abs().max().item()

@@ -337,3 +337,45 @@ def test_norm_l2_reference_accuracy_kat(oracle):
                     assert r == tgt
                 else:
                     assert abs(r - tgt) / max(abs(r), abs(tgt)) < 1e-14
+
+
+# ------------------------------------------------------------------------------------------------ LDLT (section 8f, item 1)
+def _quasi_definite(rng, n, dtype=np.float64):
+    """[[H, B^T], [B, -G]] with H, G SPD: strongly factorizable without pivoting, D has n1 positive then negative entries"""
+    n1 = n // 2
+    h = rng.standard_normal((n, n))
+    H = h[:n1, :n1] @ h[:n1, :n1].T + n * np.eye(n1)
+    G = h[n1:, n1:] @ h[n1:, n1:].T + n * np.eye(n - n1)
+    B = h[n1:, :n1]
+    return np.asarray(np.block([[H, B.T], [B, -G]]), dtype=dtype, order="F"), n1
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 65, 129, 300])
+def test_ldlt_reconstructs_and_keeps_the_upper_triangle(oracle, n):
+    """cholesky/ldlt/factor.rs tests (:803-..., tolerance 1e-12 at n <= 64): L D L^H == A"""
+    rng = np.random.default_rng(n)
+    a, n1 = _quasi_definite(rng, n)
+    w = a.copy(order="F")
+    iu = np.triu_indices(n, 1)
+    w[iu] = -3.25
+    assert oracle.ldlt_in_place(w) == ("ok", 0)
+    assert (w[iu] == -3.25).all()
+    L, D = np.tril(w, -1) + np.eye(n), np.diag(w).copy()
+    assert np.abs(L @ np.diag(D) @ L.T - a).max() <= 1e-12 * max(1.0, np.abs(a).max())
+    assert (D[:n1] > 0).all() and (D[n1:] < 0).all()
+
+
+def test_ldlt_zero_pivot_and_regularization(oracle):
+    a = np.asfortranarray(np.array([[1.0, 2.0, 3.0], [2.0, 4.0, 1.0], [3.0, 1.0, 1.0]]))
+    w = a.copy(order="F")
+    assert oracle.ldlt_in_place(w) == ("zero_pivot", 1)
+    assert w[0, 0] == 1.0 and w[1, 1] == 0.0  # D is written up to and including the failing index (:791-798)
+    # the same matrix with dynamic regularization and expected signs (+, -, +): the zero pivot becomes -delta, not counted
+    w = a.copy(order="F")
+    assert oracle.ldlt_in_place(w, 1e-3, 1e-8, signs=[1, -1, 1]) == ("ok", 0)
+    assert w[1, 1] == -1e-3
+    # expected sign +1 on non positive pivots: corrected to +delta and counted (the last pivot turns negative once
+    # the second one has been lifted to +delta, so two corrections)
+    w = a.copy(order="F")
+    assert oracle.ldlt_in_place(w, 1e-3, 1e-8, signs=[1, 1, 1]) == ("ok", 2)
+    assert w[1, 1] == 1e-3 and w[2, 2] == 1e-3
