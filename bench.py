@@ -221,7 +221,7 @@ def main():
                     pmc = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
                 except Exception:
                     pmc = None
-            out["roofline"] = {"bound": "mfma", "kernel": "fh::gemm_kernel<double,128,128,16,2,2,...>",
+            out["roofline"] = {"bound": "mfma", "kernel": "fh::gemm_kernel_p<double,128,128,16,2,2,false,true,1>",
                                "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": pmc,
                                "algorithmic_flops_per_launch": flops, "launch_ms": round(launch_s * 1e3, 4)}
@@ -234,7 +234,7 @@ def main():
                                          C.c_void_p(c.data_ptr()), C.c_ssize_t(n), C.c_void_p(a.data_ptr()), C.c_ssize_t(n),
                                          C.c_void_p(b.data_ptr()), C.c_ssize_t(n), 5)
             achieved = 2.0 * n ** 3 / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "fh::gemm_kernel<double,128,128,16,2,2,...> (dgemm n=8192)",
+            out["roofline"] = {"bound": "mfma", "kernel": "fh::gemm_kernel_p<double,128,128,16,2,2,false,true,1> (dgemm n=8192)",
                                "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None}
             del a, b, c
