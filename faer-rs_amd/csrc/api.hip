@@ -691,6 +691,13 @@ void faer_hip_memcpy_d2h(void *d, const void *s, size_t bytes)
 	ctx().sync();
 }
 void faer_hip_set_gemm_variant(int v) { ctx().gemm_variant = v; }
+void faer_hip_debug_stream_xcc(int which, int nblocks, unsigned *out_host) { debug_stream_xcc(which, nblocks, out_host); }
+void *faer_hip_debug_internal_stream(int which)
+{
+	Ctx &c = ctx();
+	FH_CHECK(c.lookahead_streams(), "debug_internal_stream: look-ahead streams unavailable");
+	return which == 1 ? (void *) c.la_bulk : (void *) c.la_panel;
+}
 
 double faer_hip_time_gemm_ms(FaerHipDType dtype, size_t m, size_t n, size_t k, void *dst, ptrdiff_t dst_cs, const void *lhs,
 			     ptrdiff_t lhs_cs, const void *rhs, ptrdiff_t rhs_cs, int iters)

@@ -88,6 +88,7 @@ struct Ctx {
 	void quiesce();
 };
 Ctx &ctx();
+void debug_stream_xcc(int which, int nblocks, unsigned *out_host); // which: 0 caller's stream, 1 bulk, 2 panel
 void ctx_shutdown(); // releases the calling thread's look-ahead streams / events; safe without a device
 
 // stream `s` waits for event `e`; with FAER_HIP_LA_HOSTSYNC set the HOST waits instead (debugging aid that
@@ -191,6 +192,13 @@ template <typename T> struct GemmExtra {
 	// K x K (K <= 128) matrix: 1 = B aliases dst (dst = S * dst), 2 = A aliases dst (dst = dst * S).
 	// (The value refers to the operands as passed; gemm_dev swaps it when it transposes the problem.)
 	int inplace = 0;
+	// dense-kernel shortcuts for the factorization drivers (plain products only):
+	//   k_trim 1: rhs(k, n) is zero for k > n (upper triangular rhs with an explicitly zeroed lower part), 2: lhs(m, k)
+	//   is zero for k > m -- each tile stops its K loop at the end of its diagonal block instead of multiplying zeros;
+	//   tri_skip (DST_LOWER, square): the first `tri_skip` rows of the lower triangle (a multiple of 128) are left
+	//   untouched, i.e. one launch covers "block column below the leading block + remaining lower square".
+	int k_trim = 0;
+	idx_t tri_skip = 0;
 };
 
 // dst(kind) <- [dst +] alpha * A * diag * B        (gemm.hip)

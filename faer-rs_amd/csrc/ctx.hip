@@ -65,12 +65,22 @@ bool Ctx::lookahead_streams()
 		la_panel_cus = atoi(e);
 	if (la_panel_cus < 8 || la_panel_cus > ncu / 2 || ncu > 1024)
 		return false;
-	// CU i of the mask is enabled by bit i; the last `la_panel_cus` CUs go to the panel stream
+	// CU i of the mask is enabled by bit i.  FAER_HIP_PANEL_MASK picks the layout: "tail" (default) = the last
+	// `la_panel_cus` bits, "head" = the first ones, "mod8" = bits i with i % 8 == 7 (ncu / 8 of them).
+	// Measured (profiles/r01_exp_masks.txt): workgroups of a masked stream still land on all 8 XCDs for every
+	// layout -- the dispatcher deals workgroups to the XCDs round robin and the mask only selects CUs inside each,
+	// so a stream cannot be confined to one XCD (and its L2); "mod8" leaves XCDs without panel / bulk CUs and is
+	// 20 % slower, "head" == "tail".
+	const char *mode = getenv("FAER_HIP_PANEL_MASK");
+	const int layout = !mode ? 0 : !strcmp(mode, "head") ? 1 : !strcmp(mode, "mod8") ? 2 : 0;
+	if (layout == 2)
+		la_panel_cus = ncu / 8;
 	uint32_t mb[32], mp[32];
 	memset(mb, 0, sizeof(mb));
 	memset(mp, 0, sizeof(mp));
 	for (int i = 0; i < ncu; ++i) {
-		uint32_t *m = i < ncu - la_panel_cus ? mb : mp;
+		const bool panel = layout == 0 ? i >= ncu - la_panel_cus : layout == 1 ? i < la_panel_cus : i % 8 == 7;
+		uint32_t *m = panel ? mp : mb;
 		m[i / 32] |= 1u << (i % 32);
 	}
 	const uint32_t words = (uint32_t) ((ncu + 31) / 32);
@@ -102,6 +112,39 @@ bool Ctx::lookahead_streams()
 	la_panel = p;
 	la_state = 1;
 	return true;
+}
+
+// debugging aid: XCC id (low 4 bits) and HW_ID of the CU each block of a small grid lands on
+__global__ void xcc_probe_kernel(unsigned *out)
+{
+	unsigned xcc, hw;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+	// keep the block resident for a while so that a small grid spreads over the enabled CUs
+	const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+	while (__builtin_amdgcn_s_memtime() - t0 < 20000)
+		__builtin_amdgcn_s_sleep(8);
+	if (threadIdx.x == 0) {
+		out[2 * blockIdx.x] = xcc;
+		out[2 * blockIdx.x + 1] = hw;
+	}
+}
+
+void debug_stream_xcc(int which, int nblocks, unsigned *out_host)
+{
+	Ctx &c = ctx();
+	hipStream_t s = c.stream;
+	if (which != 0) {
+		FH_CHECK(c.lookahead_streams(), "debug_stream_xcc: look-ahead streams unavailable");
+		s = which == 1 ? c.la_bulk : c.la_panel;
+	}
+	unsigned *d = nullptr;
+	FH_HIP(hipMalloc(&d, (size_t) nblocks * 2 * sizeof(unsigned)));
+	hipLaunchKernelGGL(xcc_probe_kernel, dim3(nblocks), dim3(512), 0, s, d);
+	FH_HIP(hipGetLastError());
+	FH_HIP(hipStreamSynchronize(s));
+	FH_HIP(hipMemcpy(out_host, d, (size_t) nblocks * 2 * sizeof(unsigned), hipMemcpyDeviceToHost));
+	FH_HIP(hipFree(d));
 }
 
 hipEvent_t Ctx::next_event()

@@ -52,6 +52,8 @@ template <typename T> struct GemmArgs {
 	idx_t diag_stride;
 	int a_struct, b_struct; // FaerBlock codes of lhs (m x k) and rhs (k x n); EXTRA kernels only
 	int dst_strict;		// lower && strict: only i > j written
+	int k_trim;		// GemmExtra::k_trim (pipelined kernel only)
+	int tri_off;		// tri_enum: first tile of the enumeration (tiles of the skipped leading rows)
 };
 
 // FaerBlock membership test (faer/src/linalg/matmul/triangular.rs:906-977)
@@ -314,32 +316,51 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 
 	// ---- epilogue: lane (l15, lhi), reg r of acc[i][j] holds
 	//      C[m_off + wm*WTM + i*16 + l15][n_off + wn*WTN + j*16 + row(r, lhi)]
+	// (accumulate mode: the old values of a 16-column group are loaded together before the group is stored -- see
+	// gemm_kernel_p)
 #pragma unroll
-	for (int j = 0; j < TN; ++j)
+	for (int j = 0; j < TN; ++j) {
+		T *ptr[4][TM];
+		T old[4][TM];
+		unsigned okmask = 0;
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			const int n = n_off + wn * WTN + j * 16 + Mfma<T>::row(r, lhi);
-			if (n >= g.N)
-				continue;
-			const idx_t ncol = g.col_idx ? load_idx(g.col_idx, g.idx64, n) : (idx_t) n;
+			const bool n_ok = n < g.N;
+			const idx_t ncol = (n_ok && g.col_idx) ? load_idx(g.col_idx, g.idx64, n) : (idx_t) n;
 #pragma unroll
 			for (int i = 0; i < TM; ++i) {
 				const int m = m_off + wm * WTM + i * 16 + l15;
-				if (m >= g.M || (g.lower && (m < n || (g.dst_strict && m == n))))
-					continue;
-				const idx_t mrow = g.row_idx ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
-				T *p = g.dst + mrow * g.drs + ncol * g.dcs;
-				const T v = acc[i][j][r];
-				if (g.atomic == 2)
-					g.ws[((size_t) blockIdx.z * g.N + n) * g.M + m] = v; // reduced in a fixed order afterwards
-				else if (g.atomic)
-					atomicAdd(p, g.alpha * v);
-				else if (g.add)
-					*p = __builtin_fma(g.alpha, v, *p);
-				else
-					*p = g.alpha * v;
+				const bool ok = n_ok && m < g.M && !(g.lower && (m < n || (g.dst_strict && m == n)));
+				const idx_t mrow = (ok && g.row_idx) ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
+				ptr[r][i] = g.atomic == 2 ? g.ws + ((size_t) blockIdx.z * g.N + n) * g.M + m : g.dst + mrow * g.drs + ncol * g.dcs;
+				okmask |= (unsigned) ok << (r * TM + i);
 			}
 		}
+		if (g.add && !g.atomic) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+#pragma unroll
+				for (int i = 0; i < TM; ++i)
+					old[r][i] = (okmask >> (r * TM + i)) & 1u ? *ptr[r][i] : (T) 0;
+		}
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+#pragma unroll
+			for (int i = 0; i < TM; ++i) {
+				if (!((okmask >> (r * TM + i)) & 1u))
+					continue;
+				const T v = acc[i][j][r];
+				if (g.atomic == 2)
+					*ptr[r][i] = v; // raw slice sums, reduced in a fixed order afterwards
+				else if (g.atomic)
+					atomicAdd(ptr[r][i], g.alpha * v);
+				else if (g.add)
+					*ptr[r][i] = __builtin_fma(g.alpha, v, old[r][i]);
+				else
+					*ptr[r][i] = g.alpha * v;
+			}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -404,7 +425,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 	int tm, tn;
 	{
 		const int nblocks = gridDim.x;
-		const int pid = xcd_remap(blockIdx.x, nblocks);
+		const int pid = xcd_remap(blockIdx.x, nblocks) + g.tri_off;
 		if (g.tri_enum) {
 			int i = (int) ((sqrtf(8.0f * (float) pid + 1.0f) - 1.0f) * 0.5f);
 			while ((i + 1) * (i + 2) / 2 <= pid)
@@ -422,6 +443,9 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 			const int rem = pid - grp * per_group;
 			tm = first_m + rem % gsz;
 			tn = rem / gsz;
+			// trimmed K loops: the tiles with the long loops go first (longest-processing-time order)
+			if (g.k_trim == 1)
+				tn = g.ntn - 1 - tn;
 		}
 	}
 	const int m_off = tm * BM, n_off = tn * BN;
@@ -429,7 +453,11 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		return; // tile entirely above the diagonal
 
 	const int k_begin = blockIdx.z * g.k_per_split;
-	const int k_end = min(g.K, k_begin + g.k_per_split);
+	int k_end = min(g.K, k_begin + g.k_per_split);
+	if (g.k_trim == 1)
+		k_end = min(k_end, n_off + BN);
+	else if (g.k_trim == 2)
+		k_end = min(k_end, m_off + BM);
 	const bool k_empty = k_begin >= k_end;
 	if (k_empty && g.atomic != 2 && (g.add || g.atomic))
 		return;
@@ -687,33 +715,55 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		}
 	}
 
-	// ---- epilogue (identical to gemm_kernel)
+	// ---- epilogue: lane (l15, lhi), reg r of acc[i][j] holds C(m_off + wm*WTM + i*16 + l15, n_off + wn*WTN + j*16 +
+	// row(r, lhi)).  Accumulate mode first LOADS the 4 * TM old values of one 16-column group together and only then
+	// stores them (measured: prefetching the next group ahead of the stores is slower again): written as one
+	// read-modify-write per element the compiler has to keep every load behind the previous
+	// store (same base pointer, run-time strides), i.e. 16 * TN dependent memory round trips per wave -- ~30 us per
+	// 128 x 128 tile, 10 % of a K = 1024 update (profiles/r01_exp_syrk_rates.txt).
 #pragma unroll
-	for (int j = 0; j < TN; ++j)
+	for (int j = 0; j < TN; ++j) {
+		T *ptr[4][TM];
+		T old[4][TM];
+		unsigned okmask = 0;
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			const int n = n_off + wn * WTN + j * 16 + Mfma<T>::row(r, lhi);
-			if (n >= g.N)
-				continue;
-			const idx_t ncol = g.col_idx ? load_idx(g.col_idx, g.idx64, n) : (idx_t) n;
+			const bool n_ok = n < g.N;
+			const idx_t ncol = (n_ok && g.col_idx) ? load_idx(g.col_idx, g.idx64, n) : (idx_t) n;
 #pragma unroll
 			for (int i = 0; i < TM; ++i) {
 				const int m = m_off + wm * WTM + i * 16 + l15;
-				if (m >= g.M || (g.lower && (m < n || (g.dst_strict && m == n))))
-					continue;
-				const idx_t mrow = g.row_idx ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
-				T *p = g.dst + mrow * g.drs + ncol * g.dcs;
-				const T v = acc[i][j][r];
-				if (g.atomic == 2)
-					g.ws[((size_t) blockIdx.z * g.N + n) * g.M + m] = v; // reduced in a fixed order afterwards
-				else if (g.atomic)
-					atomicAdd(p, g.alpha * v);
-				else if (g.add)
-					*p = __builtin_fma(g.alpha, v, *p);
-				else
-					*p = g.alpha * v;
+				const bool ok = n_ok && m < g.M && !(g.lower && (m < n || (g.dst_strict && m == n)));
+				const idx_t mrow = (ok && g.row_idx) ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
+				ptr[r][i] = g.atomic == 2 ? g.ws + ((size_t) blockIdx.z * g.N + n) * g.M + m : g.dst + mrow * g.drs + ncol * g.dcs;
+				okmask |= (unsigned) ok << (r * TM + i);
 			}
 		}
+		if (g.add && !g.atomic) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+#pragma unroll
+				for (int i = 0; i < TM; ++i)
+					old[r][i] = (okmask >> (r * TM + i)) & 1u ? *ptr[r][i] : (T) 0;
+		}
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+#pragma unroll
+			for (int i = 0; i < TM; ++i) {
+				if (!((okmask >> (r * TM + i)) & 1u))
+					continue;
+				const T v = acc[i][j][r];
+				if (g.atomic == 2)
+					*ptr[r][i] = v; // raw slice sums, reduced in a fixed order afterwards
+				else if (g.atomic)
+					atomicAdd(ptr[r][i], g.alpha * v);
+				else if (g.add)
+					*ptr[r][i] = __builtin_fma(g.alpha, v, old[r][i]);
+				else
+					*ptr[r][i] = g.alpha * v;
+			}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -826,7 +876,7 @@ template <typename T, int BM, int BN, int WM, int WN> static void launch_cfg_p(c
 	constexpr int BK = 16;
 	constexpr int PF = (BM * BN >= 128 * 128) ? 1 : 4; // register prefetch depth (tiles)
 	constexpr int NT = WM * WN * 64;
-	int nblocks = g.tri_enum ? g.ntm * (g.ntm + 1) / 2 : g.ntm * g.ntn;
+	int nblocks = g.tri_enum ? g.ntm * (g.ntm + 1) / 2 - g.tri_off : g.ntm * g.ntn;
 	dim3 grid((unsigned) nblocks, 1, (unsigned) splits), block(NT);
 	hipStream_t s = ctx().stream;
 	if (akm && bkm)
@@ -879,6 +929,8 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		std::swap(ex.row_idx, ex.col_idx);
 		if (ex.inplace)
 			ex.inplace = 3 - ex.inplace; // the aliased operand changes sides with the transposition
+		if (ex.k_trim)
+			ex.k_trim = 3 - ex.k_trim;
 		std::swap(m, n);
 		static const int tr[7] = {0, 2, 1, 4, 3, 6, 5}; // FaerBlock of the transposed operand
 		const int as = tr[ex.b_struct], bs = tr[ex.a_struct];
@@ -915,7 +967,11 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	g.a_struct = ex.a_struct;
 	g.b_struct = ex.b_struct;
 	g.dst_strict = ex.dst_strict ? 1 : 0;
+	g.k_trim = ex.k_trim;
+	g.tri_off = 0;
 	const bool extra_path = ex.diag || ex.a_struct || ex.b_struct;
+	if (ex.k_trim || ex.tri_skip)
+		FH_CHECK(!extra_path && !indexed && !ex.inplace && ctx().gemm_variant < 10, "gemm: k_trim / tri_skip need the plain dense kernel");
 
 	// loader shapes: K-major when the k stride is the unit one (and the mn stride is not)
 	const bool akm = iabs(A.cs) == 1 && iabs(A.rs) != 1;
@@ -972,9 +1028,14 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	g.ntm = (int) ((m + bm - 1) / bm);
 	g.ntn = (int) ((n + bn - 1) / bn);
 	g.tri_enum = (g.lower && m == n) ? 1 : 0;
+	if (ex.tri_skip) {
+		FH_CHECK(g.tri_enum && ex.tri_skip % bm == 0 && ex.tri_skip < m, "gemm: tri_skip needs a square lower dst and a tile-aligned skip");
+		const int st = (int) (ex.tri_skip / bm);
+		g.tri_off = st * (st + 1) / 2;
+	}
 
 	// split-K for few-tile / deep-K products
-	idx_t tiles = g.tri_enum ? (idx_t) g.ntm * (g.ntm + 1) / 2 : (idx_t) g.ntm * g.ntn;
+	idx_t tiles = g.tri_enum ? (idx_t) g.ntm * (g.ntm + 1) / 2 - g.tri_off : (idx_t) g.ntm * g.ntn;
 	int splits = 1;
 	if (tiles < 256 && k >= 4096 && !indexed) {
 		splits = (int) ((512 + tiles - 1) / tiles);

@@ -292,6 +292,37 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 	potrf_rec<T>(A11, regularize, eps, delta, status, offset + h, Wbase, need_inv);
 }
 
+// Left-looking factorization of a tall panel P (R x w, R >= w; the top w x w block is the diagonal block) in 128
+// column blocks -- three launches per block on ONE dependent chain:
+//     block column j  -=  P[c0:, 0:c0] P[c0:c0+128, 0:c0]^T   (lower trapezoid, one GEMM with K = c0)
+//     leaf on the diagonal block                               (also yields its inverse W_j)
+//     rows below      <-  rows below * W_j^T                   (in-place MFMA product)
+// instead of the ~38 launches of the recursion above for 8 blocks.  Used where the diagonal-block chain is the
+// critical path (look-ahead panel stream, and the sequential tail where R is small enough that every launch is
+// latency bound anyway).  Same operations per entry as cholesky/ldlt/factor.rs:367-498 grouped by block columns.
+template <typename T>
+static void potrf_panel_flat(MatV<T> P, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase)
+{
+	const idx_t R = P.nrows, w = P.ncols;
+	for (idx_t c0 = 0; c0 < w; c0 += POTRF_NB) {
+		const idx_t nb = POTRF_NB < w - c0 ? POTRF_NB : w - c0;
+		if (c0 > 0)
+			gemm_dev<T>(P.sub(c0, c0, R - c0, nb), DST_LOWER, true, P.sub(c0, 0, R - c0, c0).c(), P.sub(c0, 0, nb, c0).t().c(), (T) -1);
+		T *W = Wbase + (size_t) ((offset + c0) / POTRF_NB) * POTRF_NB * POTRF_NB;
+		MatV<T> D = P.sub(c0, c0, nb, nb);
+		hipLaunchKernelGGL((potrf_leaf_kernel<T, false>), dim3(1), dim3(LDS_NT), 0, ctx().stream, D.p, D.rs, D.cs, (int) nb, regularize, eps,
+				   delta, status, (int) (offset + c0), W, (const signed char *) nullptr, (T *) nullptr);
+		FH_HIP(hipGetLastError());
+		if (R > c0 + nb) {
+			MatV<T> below = P.sub(c0 + nb, c0, R - c0 - nb, nb);
+			MatV<const T> Winv{W, nb, nb, 1, POTRF_NB};
+			GemmExtra<T> ex;
+			ex.inplace = 2; // the lhs aliases dst
+			gemm_dev<T>(below, DST_FULL, false, below.c(), Winv.t(), (T) 1, &ex);
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // Full inverse of a diagonal step block from the inverses of its 128-blocks (recursive doubling,
 // inv([L11 0; L21 L22]) = [W11 0; -W22 L21 W11, W22], every product an MFMA GEMM).  The look-ahead driver
@@ -337,96 +368,118 @@ template <typename T> static void tri_inv_full(MatV<const T> L, const T *Wblk, M
 // leaving 255 CUs idle.  Same arithmetic per entry as the reference's right-looking sweep
 // (cholesky/ldlt/factor.rs:367-498) with a larger step.
 constexpr idx_t LA_NB = 1024;
-constexpr idx_t LA_TAIL = 0; // trailing size at which the pipeline would hand over to the recursive driver (measured: never pays)
 
 template <typename T>
 static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *status, T *Wbase, hipStream_t caller)
 {
 	Ctx &c = ctx();
 	const idx_t n = A.nrows;
-	const idx_t nsteps = (n + LA_NB - 1) / LA_NB;
-	c.reset_events();
-	hipEvent_t e0 = c.next_event();
-	FH_HIP(hipEventRecord(e0, caller));
-	stream_wait(c.la_bulk, e0);
-	stream_wait(c.la_panel, e0);
-	// workspaces: two full step-block inverses (double buffered over the steps), a temporary for building them,
-	// and the out-of-place result of the panel solve
-	Scratch wfb((size_t) 2 * LA_NB * LA_NB * sizeof(T)), tmb((size_t) LA_NB * LA_NB * sizeof(T));
-	Scratch xb((size_t) (n - LA_NB) * LA_NB * sizeof(T));
-	auto Wfull = [&](idx_t k) { return MatV<T>{wfb.as<T>() + (size_t) (k & 1) * LA_NB * LA_NB, LA_NB, LA_NB, 1, LA_NB}; };
-	MatV<T> Tmp{tmb.as<T>(), LA_NB, LA_NB, 1, LA_NB};
-	hipEvent_t ev_diag; // D_k factored (and inverted)
-	{
-		StreamScope sc(c.la_panel);
-		const idx_t w = LA_NB < n ? LA_NB : n;
-		potrf_rec<T>(A.sub(0, 0, w, w), regularize, eps, delta, status, 0, Wbase, nsteps > 1);
-		if (nsteps > 1)
-			tri_inv_full<T>(A.sub(0, 0, LA_NB, LA_NB).c(), Wbase, Wfull(0), Tmp);
-		ev_diag = c.next_event();
-		FH_HIP(hipEventRecord(ev_diag, c.la_panel));
-	}
-	idx_t tail0 = n; // first column of the part finished by the recursive driver
-	for (idx_t k = 0; k + 1 < nsteps; ++k) {
-		const idx_t j0 = k * LA_NB, j1 = j0 + LA_NB; // panel columns [j0, j1)
-		const idx_t r = n - j1;			   // rows below
-		const idx_t w1 = LA_NB < r ? LA_NB : r;	   // width of the next diagonal block
-		MatV<T> Pk = A.sub(j1, j0, r, LA_NB);
-		hipEvent_t ev_upd;
-		const bool last = r <= LA_TAIL;
-		{
-			StreamScope sc(c.la_bulk);
-			stream_wait(c.la_bulk, ev_diag);
-			// P_k <- P_k L_kk^-T  (cholesky/ldlt/factor.rs:422-426) as P_k W_k^T, W_k = inv(L_kk) lower triangular:
-			// the left half of the result only needs the top-left quarter of W_k
-			{
-				const idx_t hh = LA_NB / 2;
-				MatV<T> X{xb.as<T>(), r, LA_NB, 1, r};
-				MatV<const T> W = Wfull(k).c();
-				gemm_dev<T>(X.sub(0, 0, r, hh), DST_FULL, false, Pk.sub(0, 0, r, hh).c(), W.sub(0, 0, hh, hh).t(), (T) 1);
-				gemm_dev<T>(X.sub(0, hh, r, hh), DST_FULL, false, Pk.c(), W.sub(hh, 0, hh, LA_NB).t(), (T) 1);
-				copy_dev<T>(Pk, X.c());
-			}
-			if (last) {
-				// the remaining trailing matrix is small: one update, then the recursive driver on the whole chip
-				// (a chain of look-ahead steps would be bound by the diagonal-block latency from here on)
-				gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, Pk.c(), Pk.t().c(), (T) -1);
-				tail0 = j1;
-				break;
-			}
-			// next diagonal block first
-			MatV<const T> P0 = Pk.sub(0, 0, w1, LA_NB).c();
-			gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, P0, P0.t(), (T) -1);
-			ev_upd = c.next_event();
-			FH_HIP(hipEventRecord(ev_upd, c.la_bulk));
-		}
-		// (the remainder of the trailing update is enqueued BEFORE the panel stream's ~130 launches so that the
-		// bulk queue never runs dry while the host is busy enqueuing)
-		if (r > w1) {
-			StreamScope sc(c.la_bulk);
-			MatV<const T> P0 = Pk.sub(0, 0, w1, LA_NB).c(), P1 = Pk.sub(w1, 0, r - w1, LA_NB).c();
-			// block column k+1 below its diagonal block, then the remaining square (lower part only)
-			gemm_dev<T>(A.sub(j1 + w1, j1, r - w1, w1), DST_FULL, true, P1, P0.t(), (T) -1);
-			gemm_dev<T>(A.sub(j1 + w1, j1 + w1, r - w1, r - w1), DST_LOWER, true, P1, P1.t(), (T) -1);
-		}
+	// Once the remaining matrix is small the chain "diagonal block -> panel solve -> next diagonal block" is longer
+	// than the trailing update it is meant to hide behind: the tail is factored on the caller's stream, whole chip,
+	// one tall left-looking panel + ONE trailing update per step.
+	// Look-ahead pays from ~10k rows upwards (measured, N = 8192: 13.3 ms sequential against 13.8 ms); below that and
+	// for the last `tail_rows` rows of a large matrix the steps run back to back on the caller's stream.
+	const idx_t tail_rows = getenv("FAER_HIP_LLT_TAIL") ? atol(getenv("FAER_HIP_LLT_TAIL")) : (n < 10 * LA_NB ? n : 4 * LA_NB);
+	idx_t ks = 0; // look-ahead steps
+	while (n - ks * LA_NB > tail_rows && (ks + 1) * LA_NB < n)
+		++ks;
+	if (ks > 0 && !c.lookahead_streams())
+		ks = 0;
+	if (ks > 0) {
+		c.reset_events();
+		hipEvent_t e0 = c.next_event();
+		FH_HIP(hipEventRecord(e0, caller));
+		stream_wait(c.la_bulk, e0);
+		stream_wait(c.la_panel, e0);
+		// workspaces: two full step-block inverses (double buffered over the steps), a temporary for building them,
+		// and two buffers for the out-of-place result X_k of the panel solve (the updates of step k read X_k, its
+		// copy into A happens off the critical path while step k+1 already fills the other buffer)
+		Scratch wfb((size_t) 2 * LA_NB * LA_NB * sizeof(T)), tmb((size_t) LA_NB * LA_NB * sizeof(T));
+		const size_t xsz = (size_t) (n - LA_NB) * LA_NB;
+		Scratch xb(2 * xsz * sizeof(T));
+		auto Wfull = [&](idx_t k) { return MatV<T>{wfb.as<T>() + (size_t) (k & 1) * LA_NB * LA_NB, LA_NB, LA_NB, 1, LA_NB}; };
+		MatV<T> Tmp{tmb.as<T>(), LA_NB, LA_NB, 1, LA_NB};
+		hipEvent_t ev_diag; // D_k factored (and inverted)
 		{
 			StreamScope sc(c.la_panel);
-			stream_wait(c.la_panel, ev_upd);
-			potrf_rec<T>(A.sub(j1, j1, w1, w1), regularize, eps, delta, status, j1, Wbase, k + 2 < nsteps);
-			if (k + 2 < nsteps)
-				tri_inv_full<T>(A.sub(j1, j1, LA_NB, LA_NB).c(), Wbase + (size_t) (j1 / POTRF_NB) * POTRF_NB * POTRF_NB,
-						Wfull(k + 1), Tmp);
+			potrf_panel_flat<T>(A.sub(0, 0, LA_NB, LA_NB), regularize, eps, delta, status, 0, Wbase);
+			tri_inv_full<T>(A.sub(0, 0, LA_NB, LA_NB).c(), Wbase, Wfull(0), Tmp);
 			ev_diag = c.next_event();
 			FH_HIP(hipEventRecord(ev_diag, c.la_panel));
 		}
+		// trailing size from which the update of the next diagonal block runs on the panel stream (it has slack to
+		// spare while the trailing matrix is large, and the bulk stream then issues two launches per step)
+		const idx_t dpanel_rmin = getenv("FAER_HIP_LLT_DPANEL") ? atol(getenv("FAER_HIP_LLT_DPANEL")) : 8192;
+		for (idx_t k = 0; k < ks; ++k) {
+			const idx_t j0 = k * LA_NB, j1 = j0 + LA_NB; // panel columns [j0, j1)
+			const idx_t r = n - j1;			   // rows below (> LA_NB for every look-ahead step but possibly the last)
+			const bool last = k + 1 == ks;		   // the tail driver takes over after this step
+			MatV<T> Pk = A.sub(j1, j0, r, LA_NB);
+			MatV<T> X{xb.as<T>() + (size_t) (k & 1) * xsz, r, LA_NB, 1, r};
+			MatV<const T> X0 = X.sub(0, 0, LA_NB < r ? LA_NB : r, LA_NB).c();
+			const bool d_on_panel = !last && dpanel_rmin > 0 && r >= dpanel_rmin;
+			hipEvent_t ev_upd;
+			{
+				StreamScope sc(c.la_bulk);
+				stream_wait(c.la_bulk, ev_diag);
+				// X_k = P_k L_kk^-T  (cholesky/ldlt/factor.rs:422-426) as P_k W_k^T, W_k = inv(L_kk).  One launch: W_k^T
+				// is upper triangular with an explicitly zero lower part, every tile stops its K loop at the end of its
+				// own diagonal block (3/4 of the flops of the full product on average)
+				GemmExtra<T> ex;
+				ex.k_trim = 1;
+				gemm_dev<T>(X, DST_FULL, false, Pk.c(), Wfull(k).c().t(), (T) 1, &ex);
+				if (last) {
+					gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X.c(), X.t().c(), (T) -1);
+				} else if (!d_on_panel) { // next diagonal block first
+					gemm_dev<T>(A.sub(j1, j1, LA_NB, LA_NB), DST_LOWER, true, X0, X0.t(), (T) -1);
+				}
+				ev_upd = c.next_event();
+				FH_HIP(hipEventRecord(ev_upd, c.la_bulk));
+			}
+			// (the remainder of the trailing update is enqueued BEFORE the panel stream's launches so that the bulk
+			// queue never runs dry while the host is busy enqueuing)
+			if (!last) {
+				StreamScope sc(c.la_bulk);
+				// block column k+1 below its diagonal block + the remaining lower square in ONE launch: the lower
+				// triangle of the whole trailing matrix minus its leading LA_NB rows
+				GemmExtra<T> ex;
+				ex.tri_skip = LA_NB;
+				gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X.c(), X.t().c(), (T) -1, &ex);
+			}
+			{
+				StreamScope sc(c.la_panel);
+				stream_wait(c.la_panel, ev_upd);
+				if (!last) {
+					if (d_on_panel)
+						gemm_dev<T>(A.sub(j1, j1, LA_NB, LA_NB), DST_LOWER, true, X0, X0.t(), (T) -1);
+					potrf_panel_flat<T>(A.sub(j1, j1, LA_NB, LA_NB), regularize, eps, delta, status, j1, Wbase);
+					if (k + 2 <= ks) // the next step is a look-ahead step as well: it solves against the full inverse
+						tri_inv_full<T>(A.sub(j1, j1, LA_NB, LA_NB).c(), Wbase + (size_t) (j1 / POTRF_NB) * POTRF_NB * POTRF_NB,
+								Wfull(k + 1), Tmp);
+					ev_diag = c.next_event();
+					FH_HIP(hipEventRecord(ev_diag, c.la_panel));
+				}
+				// L_{>k,k} = X_k goes home after the next step has been released (X buffer k & 1 is rewritten by the
+				// solve of step k+2, which waits for the diagonal block k+2, i.e. for this copy)
+				copy_dev<T>(Pk, X.c());
+			}
+		}
+		// rejoin the caller's stream
+		hipEvent_t eb = c.next_event(), ep = c.next_event();
+		FH_HIP(hipEventRecord(eb, c.la_bulk));
+		FH_HIP(hipEventRecord(ep, c.la_panel));
+		stream_wait(caller, eb);
+		stream_wait(caller, ep);
 	}
-	// rejoin the caller's stream
-	hipEvent_t eb = c.next_event();
-	FH_HIP(hipEventRecord(eb, c.la_bulk));
-	stream_wait(caller, eb);
-	stream_wait(caller, ev_diag);
-	if (tail0 < n)
-		potrf_rec<T>(A.sub(tail0, tail0, n - tail0, n - tail0), regularize, eps, delta, status, tail0, Wbase, false);
+	// ---- tail (everything, if the matrix is small): sequential, whole chip
+	for (idx_t j0 = ks * LA_NB; j0 < n; j0 += LA_NB) {
+		const idx_t w = LA_NB < n - j0 ? LA_NB : n - j0, R = n - j0;
+		potrf_panel_flat<T>(A.sub(j0, j0, R, w), regularize, eps, delta, status, j0, Wbase);
+		if (R > w) {
+			MatV<const T> P2 = A.sub(j0 + w, j0, R - w, w).c();
+			gemm_dev<T>(A.sub(j0 + w, j0 + w, R - w, R - w), DST_LOWER, true, P2, P2.t(), (T) -1);
+		}
+	}
 }
 
 template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps)
@@ -443,7 +496,10 @@ template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps)
 	const idx_t nblk = (n + POTRF_NB - 1) / POTRF_NB;
 	Scratch winv(n > POTRF_NB ? (size_t) nblk * POTRF_NB * POTRF_NB * sizeof(T) : 256);
 	const int regularize = (reg_delta > (T) 0 && reg_eps > (T) 0) ? 1 : 0; // cholesky/llt/factor.rs:85-86
-	if (n >= 6 * LA_NB && ctx().lookahead_streams())
+	// FAER_HIP_LLT_LA_MIN / FAER_HIP_LLT_TAIL: thresholds of the blocked driver (tests lower them to reach every
+	// code path at small sizes)
+	const idx_t la_min = getenv("FAER_HIP_LLT_LA_MIN") ? atol(getenv("FAER_HIP_LLT_LA_MIN")) : 2 * LA_NB;
+	if (n >= la_min && n > LA_NB)
 		potrf_lookahead<T>(A, regularize, reg_eps, reg_delta, status, winv.as<T>(), ctx().stream);
 	else
 		potrf_rec<T>(A, regularize, reg_eps, reg_delta, status, 0, winv.as<T>(), false);

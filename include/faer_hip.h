@@ -281,6 +281,11 @@ FAER_HIP_API void faer_hip_memcpy_h2d(void *dst_device, const void *src_host, si
 FAER_HIP_API void faer_hip_memcpy_d2h(void *dst_host, const void *src_device, size_t bytes);
 /* Tuning knob used by bench.py / tests: selects the GEMM tile variant (0 = auto). */
 FAER_HIP_API void faer_hip_set_gemm_variant(int variant);
+/* Debugging aid.  `which`: 0 = the caller's stream, 1 / 2 = the internal bulk / panel look-ahead stream; writes
+ * {XCC id, HW_ID} of the CU each of `nblocks` probe workgroups ran on (2 * nblocks words of host memory). */
+FAER_HIP_API void faer_hip_debug_stream_xcc(int which, int nblocks, unsigned *out_host);
+/* The internal CU-masked streams themselves (1 = bulk, 2 = panel), for microbenchmarks via faer_hip_set_stream. */
+FAER_HIP_API void *faer_hip_debug_internal_stream(int which);
 /* Measures `iters` back-to-back launches of the dense GEMM kernel on the calling thread's stream with
  * hipEvents and returns the average milliseconds per launch (operands must be device memory).
  * bench.py uses it for the `roofline` object. */

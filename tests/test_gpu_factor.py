@@ -110,13 +110,17 @@ def test_llt_full_size_property():
     assert r.abs().max().item() <= 64 * n * 2.3e-16 * (a.abs() @ x.abs()).max().item()
 
 
-@pytest.mark.parametrize("n", [4096, 4363, 5120 + 77])
-def test_llt_lookahead_path(n):
-    """n >= 4096 runs the look-ahead driver (two CU-masked streams, 1024-column steps; potrf.hip): ragged last
-    step, entrywise L L^T == A on the lower triangle, untouched strict upper triangle, same answer twice"""
+@pytest.mark.parametrize("n,tail", [(4096, 0), (4363, 0), (5120 + 77, 2048), (5120 + 77, 1 << 20), (6144, 3000), (3072 + 5, 1024)])
+def test_llt_lookahead_path(n, tail, monkeypatch):
+    """the blocked driver of large matrices (potrf.hip): look-ahead steps on two CU-masked streams (1024 columns
+    each) followed by the sequential tail of tall left-looking panels; thresholds lowered through the environment
+    so that every mix (look-ahead only, both, tail only) and a ragged last step run at test sizes.  Entrywise
+    L L^T == A on the lower triangle, untouched strict upper triangle, same answer twice"""
     import torch
 
     F = init_gpu()
+    monkeypatch.setenv("FAER_HIP_LLT_LA_MIN", "2048")
+    monkeypatch.setenv("FAER_HIP_LLT_TAIL", str(tail))
     g = torch.Generator(device="cuda").manual_seed(n)
     b = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g)
     a = (b @ b.t() + n * torch.eye(n, dtype=torch.float64, device="cuda")).t()
@@ -136,11 +140,15 @@ def test_llt_lookahead_path(n):
     assert torch.equal(l, l2)
 
 
-def test_llt_lookahead_failure_index():
-    """first non-positive pivot deep inside a later step of the look-ahead driver: same index as the definition"""
+@pytest.mark.parametrize("tail", [0, 2500, 1 << 20])
+def test_llt_lookahead_failure_index(tail, monkeypatch):
+    """first non-positive pivot deep inside a later step of the blocked driver (look-ahead step / tail panel):
+    same index as the definition"""
     import torch
 
     F = init_gpu()
+    monkeypatch.setenv("FAER_HIP_LLT_LA_MIN", "2048")
+    monkeypatch.setenv("FAER_HIP_LLT_TAIL", str(tail))
     n, bad = 5000, 3333
     g = torch.Generator(device="cuda").manual_seed(5)
     b = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g)
@@ -300,12 +308,14 @@ def test_dist_lu_device_backend_single_rank(oracle, m, n, nb):
     assert len(calls) == (min(m, n) + nb - 1) // nb and all(r == 0 for _, r in calls)
 
 
-def test_llt_lookahead_is_deterministic_under_interleaved_work():
-    """the two-stream look-ahead driver (n = 8192 here) must give the bitwise same factor every time, also with
-    unrelated work queued around it (a cross-stream race would show up as a mismatch or a spurious failure)"""
+def test_llt_lookahead_is_deterministic_under_interleaved_work(monkeypatch):
+    """the two-stream look-ahead driver (n = 8192, look-ahead down to 2048 remaining rows) must give the bitwise
+    same factor every time, also with unrelated work queued around it (a cross-stream race would show up as a
+    mismatch or a spurious failure)"""
     import torch
 
     F = init_gpu()
+    monkeypatch.setenv("FAER_HIP_LLT_TAIL", "2048")
     n = 8192
     g = torch.Generator(device="cuda").manual_seed(17)
     b = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g)
