@@ -505,11 +505,23 @@ __global__ __launch_bounds__(256) void laswp_small_kernel(T *B, idx_t rs, idx_t 
 	__syncthreads();
 	const int c0 = blockIdx.x * LASWP_CC;
 	const int nc = min(LASWP_CC, ncols - c0);
-	for (int idx = tid; idx < nc * ne; idx += 256) {
-		const int c = idx / ne, e = idx - c * ne;
-		const int sr = s_src[e];
-		if (sr >= 0)
-			tmp[idx] = B[(idx_t) sr * rs + (idx_t) (c0 + c) * cs];
+	// gather in batches of 8 independent loads per thread (one memory round trip per batch, not per element)
+	for (int idx0 = tid; idx0 < nc * ne; idx0 += 256 * 8) {
+		T v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int idx = idx0 + u * 256;
+			const bool in = idx < nc * ne;
+			const int c = in ? idx / ne : 0, e = in ? idx - c * ne : 0;
+			const int sr = in ? s_src[e] : -1;
+			v[u] = B[sr >= 0 ? (idx_t) sr * rs + (idx_t) (c0 + c) * cs : (idx_t) 0]; // unconditional load, clamped address
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int idx = idx0 + u * 256;
+			if (idx < nc * ne)
+				tmp[idx] = v[u];
+		}
 	}
 	__syncthreads();
 	for (int idx = tid; idx < nc * ne; idx += 256) {
@@ -560,6 +572,7 @@ template <typename T> struct LuWork {
 	xwg_u64 *gran_diag; // [2][2 * LU_W]
 	xwg_u64 epoch_base; // epochs consumed by earlier leaf launches of this factorization
 	int *status;
+	hipEvent_t after_leaf = nullptr; // look-ahead: the stream waits for this event right after the next leaf launch
 };
 
 // rows per workgroup of the cooperative kernel for a leaf of w columns (registers: RPT x W scalars per thread)
@@ -598,6 +611,10 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 	const int steps = w < (int) m ? w : (int) m;
 	if (G > 1)
 		wk.epoch_base += (xwg_u64) steps;
+	if (wk.after_leaf) { // the columns right of this leaf are brought up to date by another stream: join it now
+		stream_wait(s, wk.after_leaf);
+		wk.after_leaf = nullptr;
+	}
 }
 
 static idx_t next_pow2(idx_t n)
@@ -683,14 +700,23 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		const idx_t j1 = j0 + w;
 		const idx_t w2 = j1 < n ? (LU_LA_NB < n - j1 ? LU_LA_NB : n - j1) : 0;
 		const idx_t j2 = j1 + w2;
-		hipEvent_t ev_next = nullptr;
+		hipEvent_t ev_next = nullptr, ev_next2 = nullptr;
 		{
 			StreamScope sc(c.la_bulk);
 			stream_wait(c.la_bulk, ev_panel);
 			if (w2 > 0) {
-				update(j0, w, j1, w2);
+				// the next panel starts with a leaf on its first LU_W columns: release it as soon as those are up to
+				// date, the other columns of the panel follow while that leaf runs
+				static const bool nosplit = getenv("FAER_HIP_LU_SPLIT") && atoi(getenv("FAER_HIP_LU_SPLIT")) == 0; // A/B switch
+				const idx_t wa = (w2 < LU_W || nosplit) ? w2 : (idx_t) LU_W;
+				update(j0, w, j1, wa);
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
+				if (w2 > wa) {
+					update(j0, w, j1 + wa, w2 - wa);
+					ev_next2 = c.next_event();
+					FH_HIP(hipEventRecord(ev_next2, c.la_bulk));
+				}
 			}
 			if (j2 < n)
 				update(j0, w, j2, n - j2);
@@ -700,6 +726,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		if (w2 > 0) {
 			StreamScope sc(c.la_panel);
 			stream_wait(c.la_panel, ev_next);
+			wk.after_leaf = ev_next2;
 			getrf_rec<T>(A.sub(j1, j1, m - j1, w2), (int) j1, (int) j1, wk);
 			ev_panel = c.next_event();
 			FH_HIP(hipEventRecord(ev_panel, c.la_panel));

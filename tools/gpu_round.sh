@@ -10,6 +10,6 @@ timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_
 cat gpurun_out/${tag}_bench.json
 for wl in gemm llt lu qr; do
   rm -rf gpurun_out/prof_${tag}_$wl
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$wl -o $wl -- python bench.py --workload $wl --steps 3 --warmup 1 --no-extras --no-cpu > gpurun_out/prof_${tag}_$wl.log 2>&1; echo "prof $wl rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$wl -o $wl -- python bench.py --workload $wl --steps 10 --warmup 2 --no-extras --no-cpu > gpurun_out/prof_${tag}_$wl.log 2>&1; echo "prof $wl rc=$?"
   grep -o '"ms_per_step": [0-9.]*' gpurun_out/prof_${tag}_$wl.log
 done
