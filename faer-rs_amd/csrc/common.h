@@ -208,6 +208,10 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 // level-2 shapes (gemv.hip): matrix-vector product and rank-1 update, HBM streams outside the MFMA kernel
 template <typename T> bool gemv_dev(idx_t m, idx_t k, MatV<const T> A, const T *x, idx_t xs, T *y, idx_t ys, T alpha, bool add);
 template <typename T> void rank1_dev(MatV<T> C, bool add, const T *a, idx_t as, const T *b, idx_t bs, T alpha);
+// tall-skinny shapes (skinny.hip): streaming kernels; false if the shape / strides do not qualify
+template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV<const T> B, T alpha);
+// C <- [C +] alpha * sum_z ws[z] (slices of nrows x ncols, column major), fixed summation order (gemm.hip)
+template <typename T> void splitk_reduce_dev(MatV<T> C, const T *ws, int splits, T alpha, bool add);
 // average ms per launch of the dense kernel (hipEvents on the ctx stream)
 template <typename T> double gemm_time_ms(MatV<T> C, MatV<const T> A, MatV<const T> B, int iters);
 double mfma_peak_tflops(bool f64, int iters);

@@ -52,6 +52,7 @@ template <typename T> struct GemmArgs {
 	idx_t diag_stride;
 	int a_struct, b_struct; // FaerBlock codes of lhs (m x k) and rhs (k x n); EXTRA kernels only
 	int dst_strict;		// lower && strict: only i > j written
+	int epi_serial;		// 1: accumulate epilogue as one read-modify-write per element (A/B switch, see gemm_kernel_p)
 	int k_trim;		// GemmExtra::k_trim (pipelined kernel only)
 	int tri_off;		// tri_enum: first tile of the enumeration (tiles of the skipped leading rows)
 };
@@ -320,6 +321,8 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 	// gemm_kernel_p)
 #pragma unroll
 	for (int j = 0; j < TN; ++j) {
+		if (n_off + wn * WTN + j * 16 >= g.N)
+			continue; // the whole 16-column group lies outside dst (wave uniform)
 		T *ptr[4][TM];
 		T old[4][TM];
 		unsigned okmask = 0;
@@ -333,16 +336,23 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				const int m = m_off + wm * WTM + i * 16 + l15;
 				const bool ok = n_ok && m < g.M && !(g.lower && (m < n || (g.dst_strict && m == n)));
 				const idx_t mrow = (ok && g.row_idx) ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
-				ptr[r][i] = g.atomic == 2 ? g.ws + ((size_t) blockIdx.z * g.N + n) * g.M + m : g.dst + mrow * g.drs + ncol * g.dcs;
+				ptr[r][i] = !ok ? g.dst : g.atomic == 2 ? g.ws + ((size_t) blockIdx.z * g.N + n) * g.M + m : g.dst + mrow * g.drs + ncol * g.dcs;
 				okmask |= (unsigned) ok << (r * TM + i);
 			}
 		}
 		if (g.add && !g.atomic) {
 #pragma unroll
-			for (int r = 0; r < 4; ++r)
+			for (int r = 0; r < 4; ++r) {
+				if (n_off + wn * WTN + j * 16 + Mfma<T>::row(r, 0) >= g.N)
+					continue; // wave uniform: no lane has a valid column in this register
 #pragma unroll
-				for (int i = 0; i < TM; ++i)
-					old[r][i] = (okmask >> (r * TM + i)) & 1u ? *ptr[r][i] : (T) 0;
+				for (int i = 0; i < TM; ++i) {
+					if (m_off + wm * WTM + i * 16 >= g.M)
+						continue; // wave uniform
+					old[r][i] = *ptr[r][i]; // unconditional: masked lanes point at dst(0, 0) (a per-lane branch per element
+								 // would bring back one memory round trip per element)
+				}
+			}
 		}
 #pragma unroll
 		for (int r = 0; r < 4; ++r)
@@ -723,6 +733,8 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 	// 128 x 128 tile, 10 % of a K = 1024 update (profiles/r01_exp_syrk_rates.txt).
 #pragma unroll
 	for (int j = 0; j < TN; ++j) {
+		if (n_off + wn * WTN + j * 16 >= g.N)
+			continue; // the whole 16-column group lies outside dst (wave uniform)
 		T *ptr[4][TM];
 		T old[4][TM];
 		unsigned okmask = 0;
@@ -736,16 +748,32 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				const int m = m_off + wm * WTM + i * 16 + l15;
 				const bool ok = n_ok && m < g.M && !(g.lower && (m < n || (g.dst_strict && m == n)));
 				const idx_t mrow = (ok && g.row_idx) ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
-				ptr[r][i] = g.atomic == 2 ? g.ws + ((size_t) blockIdx.z * g.N + n) * g.M + m : g.dst + mrow * g.drs + ncol * g.dcs;
+				ptr[r][i] = !ok ? g.dst : g.atomic == 2 ? g.ws + ((size_t) blockIdx.z * g.N + n) * g.M + m : g.dst + mrow * g.drs + ncol * g.dcs;
 				okmask |= (unsigned) ok << (r * TM + i);
 			}
 		}
-		if (g.add && !g.atomic) {
+		if (g.add && !g.atomic && g.epi_serial) {
 #pragma unroll
 			for (int r = 0; r < 4; ++r)
 #pragma unroll
 				for (int i = 0; i < TM; ++i)
-					old[r][i] = (okmask >> (r * TM + i)) & 1u ? *ptr[r][i] : (T) 0;
+					if ((okmask >> (r * TM + i)) & 1u)
+						*ptr[r][i] = __builtin_fma(g.alpha, acc[i][j][r], *ptr[r][i]);
+			continue;
+		}
+		if (g.add && !g.atomic) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				if (n_off + wn * WTN + j * 16 + Mfma<T>::row(r, 0) >= g.N)
+					continue; // wave uniform: no lane has a valid column in this register
+#pragma unroll
+				for (int i = 0; i < TM; ++i) {
+					if (m_off + wm * WTM + i * 16 >= g.M)
+						continue; // wave uniform
+					old[r][i] = *ptr[r][i]; // unconditional: masked lanes point at dst(0, 0) (a per-lane branch per element
+								 // would bring back one memory round trip per element)
+				}
+			}
 		}
 #pragma unroll
 		for (int r = 0; r < 4; ++r)
@@ -825,6 +853,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(T *dst, idx_t drs, i
 		*p = add ? __builtin_fma(alpha, sum, *p) : alpha * sum;
 	}
 }
+
+template <typename T> void splitk_reduce_dev(MatV<T> C, const T *ws, int splits, T alpha, bool add)
+{
+	const idx_t total = C.nrows * C.ncols;
+	if (total == 0)
+		return;
+	hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned) ((total + 15) / 16)), dim3(256), 0, ctx().stream, C.p, C.rs, C.cs, (int) C.nrows,
+			   (int) C.ncols, ws, splits, alpha, add ? 1 : 0, 0, 0);
+	FH_HIP(hipGetLastError());
+}
+template void splitk_reduce_dev<double>(MatV<double>, const double *, int, double, bool);
+template void splitk_reduce_dev<float>(MatV<float>, const float *, int, float, bool);
 
 template <typename T> static void fill_ext(MatV<T> A, DstKind kind, T value, const GemmExtra<T> *ex)
 {
@@ -916,6 +956,9 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 			return;
 		if (m == 1 && gemv_dev<T>(n, k, B.t(), A.p, A.cs, C.p, C.cs, alpha, add))
 			return;
+		// one dimension huge, the other two tiny: HBM streams as well (block-reflector steps of a tall QR)
+		if (skinny_dev<T>(C, add, A, B, alpha))
+			return;
 	}
 	const bool indexed = ex.row_idx || ex.col_idx;
 	// Upper(dst) == Lower(dst^T); dst^T = B^T diag A^T.  Also prefer the unit dst stride along m.
@@ -969,6 +1012,10 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	g.dst_strict = ex.dst_strict ? 1 : 0;
 	g.k_trim = ex.k_trim;
 	g.tri_off = 0;
+	{
+		const char *e = getenv("FAER_HIP_GEMM_EPI");
+		g.epi_serial = e ? (atoi(e) == 0 ? 1 : 0) : 0;
+	}
 	const bool extra_path = ex.diag || ex.a_struct || ex.b_struct;
 	if (ex.k_trim || ex.tri_skip)
 		FH_CHECK(!extra_path && !indexed && !ex.inplace && ctx().gemm_variant < 10, "gemm: k_trim / tri_skip need the plain dense kernel");

@@ -13,7 +13,10 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SHAPES = [(1, 1, 1), (15, 16, 17), (17, 15, 16), (127, 129, 128), (129, 127, 130), (64, 1, 33), (1, 70, 9), (5, 7, 0),
           (256, 256, 256), (300, 200, 1000), (40, 3, 5000), (130, 130, 70), (1, 1, 300), (513, 67, 1),
-          (8, 1, 20000), (1, 6, 9000), (2000, 1, 4100), (700, 900, 1)]  # level-2 shapes incl. split reductions
+          (8, 1, 20000), (1, 6, 9000), (2000, 1, 4100), (700, 900, 1),  # level-2 shapes incl. split reductions
+          # tall-skinny streams (skinny.hip): update, transposed update, split reduction; ragged blocks
+          (20000, 8, 8), (20001, 30, 17), (16385, 32, 32), (17000, 3, 5), (8, 20000, 8), (32, 16400, 30),
+          (8, 8, 20000), (16, 13, 16500), (5, 16, 17001)]
 
 
 def bound(a, b, c0, k, dtype, alpha):
