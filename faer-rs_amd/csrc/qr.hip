@@ -126,6 +126,8 @@ template <typename T> struct QrPanelArgs {
 	double *slots; // [2][G][QR_SLOT]
 	double *head;  // [2][QR_PW + 1]: row j of the panel (cols j..w) and |above|^2
 	xwg_u64 *flags; // [G] per-workgroup epoch flags (xwg.h)
+	xwg_u64 *gran;	// [2][G][2 * QR_PW] tagged granules: the QR_PW column sums of every workgroup (column steps)
+	xwg_u64 *gran_head; // [2][2 * (QR_PW + 1)]: row j of the panel and |above|^2, published by workgroup 0
 	xwg_u64 epoch_base;
 	int *status; // [2] exchange timeout, [3] rank deficiency detected
 };
@@ -451,32 +453,73 @@ static __device__ __forceinline__ bool qr2_step(const QrPanelArgs<T> &a, T (&x)[
 		block_sum_nt<1>(ab, sh.part, sh.S); // sh.S[0] = |above|^2 (also publishes sh.top through its barriers)
 	}
 	if (G > 1) {
-		if (tid < QR_PW)
-			xwg_store(a.slots + ((size_t) q * G + g) * QR_SLOT + tid, sh.red[tid]);
-		if (g == 0) {
-			if (tid < QR_PW)
-				xwg_store(a.head + q * (QR_PW + 1) + tid, tid < w ? (double) sh.top[J][tid] : 0.0);
-			if (tid == 0)
-				xwg_store(a.head + q * (QR_PW + 1) + QR_PW, sh.S[0]);
+		// All-reduce of the QR_PW column sums with data-tagged granules (xwg.h, recipe R2): {tag, 32 payload bits}
+		// per 8-byte write-through store, no store drain, no flag, and the consumers fetch sums AND row j in the
+		// same round: one store latency + one load latency per column instead of drain + flag + two dependent
+		// reads.  Every thread owns the pairs pe = tid + QR2_NT * i of the G x QR_PW table, i.e. always column
+		// c = tid % QR_PW: fixed summation order (i ascending, lanes by xor 8 / 16 / 32, waves ascending).
+		const unsigned tag = (unsigned) (a.epoch_base + (xwg_u64) (bar + 1));
+		if (tid < QR_PW || (g == 0 && tid <= 2 * QR_PW)) {
+			const double v = tid < QR_PW ? sh.red[tid] : tid < 2 * QR_PW ? (tid - QR_PW < w ? (double) sh.top[J][tid - QR_PW] : 0.0) : sh.S[0];
+			xwg_u64 *dst = tid < QR_PW ? a.gran + ((size_t) q * G + g) * (2 * QR_PW) + 2 * tid
+					       : a.gran_head + (size_t) q * 2 * (QR_PW + 1) + 2 * (tid - QR_PW);
+			const xwg_u64 vb = (xwg_u64) __double_as_longlong(v);
+			xwg_store_gran(dst, tag, (unsigned) (vb >> 32));
+			xwg_store_gran(dst + 1, tag, (unsigned) vb);
 		}
-		if (tid < 64)
-			xwg_publish(a.flags, g, a.epoch_base + (xwg_u64) (bar + 1), tid == 0);
-		if (!xwg_wait_all(a.flags, G, a.epoch_base + (xwg_u64) (bar + 1), &sh.flag)) {
+		constexpr int MAXI = QR_GMAX * QR_PW / QR2_NT;
+		const int np = G * QR_PW;
+		xwg_u64 hi[MAXI], lo[MAXI], hh = 0, hl = 0;
+		const xwg_u64 *gq = a.gran + (size_t) q * G * (2 * QR_PW);
+		const xwg_u64 *hq = a.gran_head + (size_t) q * 2 * (QR_PW + 1) + 2 * (tid <= QR_PW ? tid : 0);
+		int ok = 0;
+		for (int spin = 0; spin < (1 << 21); ++spin) {
+			bool all = true;
+#pragma unroll
+			for (int i = 0; i < MAXI; ++i) {
+				const int pe = tid + QR2_NT * i;
+				if (pe < np) {
+					hi[i] = xwg_load_gran(gq + 2 * pe);
+					lo[i] = xwg_load_gran(gq + 2 * pe + 1);
+					all = all && (unsigned) (hi[i] >> 32) == tag && (unsigned) (lo[i] >> 32) == tag;
+				}
+			}
+			if (tid <= QR_PW) {
+				hh = xwg_load_gran(hq);
+				hl = xwg_load_gran(hq + 1);
+				all = all && (unsigned) (hh >> 32) == tag && (unsigned) (hl >> 32) == tag;
+			}
+			if (__all(all)) {
+				ok = 1;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+		if (!__syncthreads_and(ok)) {
 			why = 2;
 			return false;
 		}
 		++bar;
-		double tot[QR_PW];
+		double mine = 0.0;
 #pragma unroll
-		for (int c = 0; c < QR_PW; ++c)
-			tot[c] = 0.0;
-		for (int t = tid; t < G; t += QR2_NT)
+		for (int i = 0; i < MAXI; ++i)
+			if (tid + QR2_NT * i < np)
+				mine += __longlong_as_double((long long) (((hi[i] & 0xffffffffull) << 32) | (lo[i] & 0xffffffffull)));
+		mine += __shfl_xor(mine, 8, 64);
+		mine += __shfl_xor(mine, 16, 64);
+		mine += __shfl_xor(mine, 32, 64);
+		if ((tid & 63) < QR_PW)
+			sh.part[(tid >> 6) * QR_PW + (tid & 63)] = mine;
+		__syncthreads();
+		if (tid < QR_PW) {
+			double t = 0.0;
 #pragma unroll
-			for (int c = 0; c < QR_PW; ++c)
-				tot[c] += xwg_load(a.slots + ((size_t) q * G + t) * QR_SLOT + c);
-		block_sum_nt<QR_PW>(tot, sh.part, sh.S);
+			for (int k = 0; k < QR2_NT / 64; ++k)
+				t += sh.part[k * QR_PW + tid];
+			sh.S[tid] = t;
+		}
 		if (tid <= QR_PW)
-			sh.head[tid] = xwg_load(a.head + q * (QR_PW + 1) + tid);
+			sh.head[tid] = __longlong_as_double((long long) (((hh & 0xffffffffull) << 32) | (hl & 0xffffffffull)));
 	} else {
 		__syncthreads(); // sh.S[0] (|above|^2) read below before sh.S is overwritten
 		const double above2 = sh.S[0];
@@ -670,7 +713,7 @@ template <typename T, int RPT> __global__ __launch_bounds__(QR2_NT) void qr_pane
 
 template <typename T> struct QrWork {
 	double *slots, *head;
-	xwg_u64 *flags;
+	xwg_u64 *flags, *gran, *gran_head;
 	xwg_u64 epoch_base;
 	int *status;
 	const T *a_top; // A[0, 0]
@@ -703,6 +746,8 @@ template <typename T> static void qr_leaf(MatV<T> P, MatV<T> Tb, idx_t row_abs, 
 	a.slots = wk.slots;
 	a.head = wk.head;
 	a.flags = wk.flags;
+	a.gran = wk.gran;
+	a.gran_head = wk.gran_head;
 	a.epoch_base = wk.epoch_base;
 	a.status = wk.status;
 	hipLaunchKernelGGL((qr_panel2_kernel<T, qr2_rpt<T>()>), dim3(G), dim3(QR2_NT), 0, ctx().stream, a);
@@ -1053,6 +1098,11 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 		Scratch flagb((size_t) QR_GMAX * sizeof(xwg_u64));
 		FH_HIP(hipMemsetAsync(flagb.p, 0, (size_t) QR_GMAX * sizeof(xwg_u64), s));
 		wk.flags = flagb.as<xwg_u64>();
+		const size_t gran_n = (size_t) 2 * QR_GMAX * 2 * QR_PW + (size_t) 2 * 2 * (QR_PW + 1);
+		Scratch granb(gran_n * sizeof(xwg_u64));
+		FH_HIP(hipMemsetAsync(granb.p, 0, gran_n * sizeof(xwg_u64), s));
+		wk.gran = granb.as<xwg_u64>();
+		wk.gran_head = wk.gran + (size_t) 2 * QR_GMAX * 2 * QR_PW;
 		wk.epoch_base = 0;
 		wk.status = status;
 		wk.a_top = A.p;
