@@ -355,21 +355,55 @@ def partial_piv_lu_factor_in_place(a, index_dtype=np.uint64, par=PAR_SEQ):
 BcastFn = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 
 
+IbcastFn = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
+WaitFn = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+
+
 class HipComm(C.Structure):
-    """include/faer_hip.h FaerHipComm {rank, world_size, bcast, user}"""
-    _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("bcast", BcastFn), ("user", C.c_void_p)]
+    """include/faer_hip.h FaerHipComm {rank, world_size, bcast, user, ibcast, wait}"""
+    _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("bcast", BcastFn), ("user", C.c_void_p), ("ibcast", IbcastFn),
+                ("wait", WaitFn)]
+
+
+def _make_comm(rank, world_size, panel_ws, bcast, ibcast=None):
+    """FaerHipComm over a python transport.  bcast(tensor_view_of_the_device_buffer, root) is blocking (stream ordered);
+    ibcast(view, root) may return a handle with .wait() (e.g. torch.distributed.broadcast(..., async_op=True)):
+    the library then overlaps the transfer of the next panel with the trailing updates.  Returns (comm, keepalive)."""
+    import torch
+
+    ws_bytes = panel_ws.view(torch.uint8)
+    base = panel_ws.data_ptr()
+    pending = {}
+
+    def cb(user, buf, nbytes, root):
+        off = buf - base
+        bcast(ws_bytes[off:off + nbytes], root)
+
+    def icb(user, buf, nbytes, root, slot):
+        off = buf - base
+        pending[slot] = ibcast(ws_bytes[off:off + nbytes], root)
+
+    def wcb(user, slot):
+        h = pending.pop(slot, None)
+        if h is not None:
+            h.wait()
+
+    fns = (BcastFn(cb), IbcastFn(icb) if ibcast else IbcastFn(), WaitFn(wcb) if ibcast else WaitFn())
+    return HipComm(int(rank), int(world_size), fns[0], None, fns[1], fns[2]), fns
 
 
 def dist_local_ncols(n, nb, rank, world_size):
     return lib().faer_hip_dist_local_ncols(C.c_size_t(n), C.c_size_t(nb), int(rank), int(world_size))
 
 
-def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast, panel_ws=None):
+def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast, panel_ws=None, ibcast=None):
     """Distributed partial-pivot LU (1-D block-cyclic columns, one process per GPU; csrc/dist_lu.h).
 
     a_local  : this rank's block columns (nrows x dist_local_ncols, column major torch cuda tensor), factored in place
     bcast    : callable(torch uint8 tensor viewing the DEVICE broadcast buffer, root) -- the transport, e.g.
                lambda t, root: torch.distributed.broadcast(t, src=root)   (RCCL under the "nccl" backend)
+    ibcast   : optional callable(view, root) -> handle with .wait() (async broadcast): enables the overlap of the next
+               panel's transfer with the trailing updates
     returns  : (perm_fwd, perm_bwd, transposition_count), identical on every rank"""
     import torch
 
@@ -380,14 +414,8 @@ def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast, panel_ws
     if panel_ws is None:
         nsc = L.faer_hip_dist_panel_ws_scalars(C.c_size_t(m), C.c_size_t(nb), C.c_int(dt))
         panel_ws = torch.empty(nsc, dtype=a_local.dtype, device=a_local.device)
-    ws_bytes = panel_ws.view(torch.uint8)
+    comm, _keep = _make_comm(rank, world_size, panel_ws, bcast, ibcast)
     base = panel_ws.data_ptr()
-
-    def cb(user, buf, nbytes, root):
-        off = buf - base
-        bcast(ws_bytes[off:off + nbytes], root)
-
-    comm = HipComm(int(rank), int(world_size), BcastFn(cb), None)
     fwd = np.zeros(m, dtype=np.uint64)
     bwd = np.zeros(m, dtype=np.uint64)
     st = getattr(L, f"faer_hip_dist_partial_piv_lu_{suf}")(_mat(a_local, MatMut), C.c_size_t(n_global), C.c_size_t(nb),
@@ -396,6 +424,33 @@ def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast, panel_ws
     if st.tag != 0:
         raise RuntimeError("PartialPivLuStatus::Unknown")
     return fwd, bwd, st.transposition_count
+
+
+def dist_llt(a_local, n_global, nb, rank, world_size, bcast, panel_ws=None, ibcast=None, regularization=(0.0, 0.0)):
+    """Distributed Cholesky (lower; 1-D block-cyclic columns, one process per GPU; csrc/dist_llt.h).
+
+    a_local : this rank's block columns at full height (n x dist_local_ncols, column major torch cuda tensor)
+    returns : dynamic_regularization_count; raises LltError(index) (same index on every rank)"""
+    import torch
+
+    suf, ct, _ = _dtype_suffix(a_local)
+    L = lib()
+    dt = DTYPE_F64 if suf == "f64" else DTYPE_F32
+    if panel_ws is None:
+        L.faer_hip_dist_llt_ws_scalars.restype = C.c_size_t
+        nsc = L.faer_hip_dist_llt_ws_scalars(C.c_size_t(n_global), C.c_size_t(nb), C.c_int(dt))
+        panel_ws = torch.empty(nsc, dtype=a_local.dtype, device=a_local.device)
+    comm, _keep = _make_comm(rank, world_size, panel_ws, bcast, ibcast)
+    delta, eps = ct(regularization[0]), ct(regularization[1])
+    reg = LltRegularization(C.cast(C.pointer(delta), C.c_void_p), C.cast(C.pointer(eps), C.c_void_p))
+    fn = getattr(L, f"faer_hip_dist_llt_{suf}")
+    fn.restype = LltStatus
+    st = fn(_mat(a_local, MatMut), C.c_size_t(n_global), C.c_size_t(nb), reg, comm, C.c_void_p(panel_ws.data_ptr()))
+    if st.tag == 0:
+        return st.value
+    if st.tag == 1:
+        raise LltError(st.value)
+    raise RuntimeError("LltStatus::Unknown")
 
 
 def qr_recommended_block_size(nrows, ncols, dtype=np.float64):

@@ -228,6 +228,7 @@ template <typename T> void trsm_lower_pre_dev(MatV<const T> L, MatV<T> X, const 
 
 // in-place lower Cholesky; returns >=0 regularization count or -(index+1)   (potrf.hip)
 template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps);
+template <typename T> void potrf_panel_dev(MatV<T> P, T reg_delta, T reg_eps, int *status_dev, idx_t offset);
 
 // in-place unit-lower L D L^T without pivoting (potrf.hip); L strictly below the diagonal, D on it; `signs_host`: n int8
 // expected pivot signs or NULL; returns >= 0 regularization count or -(index + 1) of the zero pivot

@@ -3,6 +3,7 @@
 // this file is its device backend: every operation is one of the library's own HIP drivers on the calling
 // thread's stream, the broadcast is handed a DEVICE buffer.
 #include "common.h"
+#include "dist_llt.h"
 #include "dist_lu.h"
 using namespace fh;
 
@@ -24,9 +25,36 @@ template <typename S> struct DeviceBackend {
 	void pack(View src, T *dst) { copy_dev<T>(MatV<T>{dst, src.nrows, src.ncols, 1, src.nrows}, mv(src).c()); }
 	void bcast(void *buf, size_t bytes, int root)
 	{
-		FH_CHECK(comm.bcast != nullptr, "dist lu: FaerHipComm.bcast is NULL");
+		FH_CHECK(comm.bcast != nullptr, "dist: FaerHipComm.bcast is NULL");
 		comm.bcast(comm.user, buf, bytes, root);
 	}
+	// asynchronous pair when the transport offers one, else the blocking broadcast at `begin`
+	void bcast_begin(void *buf, size_t bytes, int root, int slot)
+	{
+		if (comm.ibcast && comm.wait)
+			comm.ibcast(comm.user, buf, bytes, root, slot);
+		else
+			bcast(buf, bytes, root);
+	}
+	void bcast_wait(int slot)
+	{
+		if (comm.ibcast && comm.wait)
+			comm.wait(comm.user, slot);
+	}
+	void copy_ints(int *dst, const int *src, size_t n)
+	{
+		FH_HIP(hipMemcpyAsync(dst, src, n * sizeof(int), hipMemcpyDeviceToDevice, ctx().stream));
+	}
+	void zero_ints(int *p, size_t n) { FH_HIP(hipMemsetAsync(p, 0, n * sizeof(int), ctx().stream)); }
+	void from_host(int *dst, const int *src, size_t n)
+	{
+		FH_HIP(hipMemcpyAsync(dst, src, n * sizeof(int), hipMemcpyHostToDevice, ctx().stream));
+		ctx().sync(); // `src` is a stack buffer of the caller
+	}
+	// ---- Cholesky (dist_llt.h)
+	T reg_delta = (T) 0, reg_eps = (T) 0;
+	void potrf_panel(View P, long offset, int *status) { potrf_panel_dev<T>(mv(P), reg_delta, reg_eps, status, (idx_t) offset); }
+	void syrk_sub(View C, View A, View Bt) { gemm_dev<T>(mv(C), DST_LOWER, true, mv(A).c(), mv(Bt).t().c(), (T) -1); }
 	void to_host(int *dst, const int *src, size_t n)
 	{
 		FH_HIP(hipMemcpyAsync(dst, src, n * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
@@ -72,9 +100,55 @@ FaerPartialPivLuStatus dist_lu_api(FaerMatMut A_local, size_t n_global, size_t n
 	return st;
 }
 
+template <typename T>
+FaerLltStatus dist_llt_api(FaerMatMut A_local, size_t n_global, size_t nb, FaerLltRegularization reg, FaerHipComm comm, void *panel_ws)
+{
+	typedef DeviceBackend<T> B;
+	const long n = (long) n_global;
+	FH_CHECK(comm.world_size >= 1 && comm.rank >= 0 && comm.rank < comm.world_size, "dist llt: bad communicator");
+	FH_CHECK(nb >= 1 && (long) nb <= (n > 0 ? n : 1), "dist llt: block width must be in [1, n]");
+	FH_CHECK((long) A_local.nrows == n, "dist llt: A_local must have n rows");
+	FH_CHECK((size_t) A_local.ncols == DistLu<B>::local_ncols(n_global, nb, comm.rank, comm.world_size),
+		 "dist llt: A_local has the wrong number of columns for this rank");
+	FH_CHECK(A_local.row_stride == 1, "dist llt: A_local must be column major");
+	FaerLltStatus st;
+	memset(&st, 0, sizeof(st));
+	st.tag = FaerLltStatus_Ok;
+	if (n == 0)
+		return st;
+	FH_CHECK(is_device_ptr(panel_ws) && (A_local.ncols == 0 || is_device_ptr(A_local.ptr)), "dist llt: A_local and panel_ws must be device memory");
+	B be;
+	be.comm = comm;
+	be.reg_delta = reg.dynamic_regularization_delta ? *static_cast<const T *>(reg.dynamic_regularization_delta) : (T) 0;
+	be.reg_eps = reg.dynamic_regularization_epsilon ? *static_cast<const T *>(reg.dynamic_regularization_epsilon) : (T) 0;
+	typename B::View Av{static_cast<T *>(A_local.ptr), n, (long) A_local.ncols, 1, (long) A_local.col_stride};
+	const long r = DistLlt<B>::run(be, Av, n, (long) nb, comm.rank, comm.world_size, static_cast<T *>(panel_ws));
+	ctx().sync();
+	if (r >= 0) {
+		st.ok.dynamic_regularization_count = (size_t) r;
+	} else {
+		st.tag = FaerLltStatus_NonPositivePivot;
+		st.non_positive_pivot.index = (size_t) (-r - 1);
+	}
+	return st;
+}
+
 } // namespace
 
 extern "C" {
+size_t faer_hip_dist_llt_ws_scalars(size_t n, size_t nb, FaerHipDType dtype)
+{
+	return dtype == FaerHipDType_F64 ? DistLlt<DeviceBackend<double>>::ws_scalars((long) n, (long) nb)
+					 : DistLlt<DeviceBackend<float>>::ws_scalars((long) n, (long) nb);
+}
+FaerLltStatus faer_hip_dist_llt_f64(FaerMatMut A, size_t n, size_t nb, FaerLltRegularization reg, FaerHipComm comm, void *ws)
+{
+	return dist_llt_api<double>(A, n, nb, reg, comm, ws);
+}
+FaerLltStatus faer_hip_dist_llt_f32(FaerMatMut A, size_t n, size_t nb, FaerLltRegularization reg, FaerHipComm comm, void *ws)
+{
+	return dist_llt_api<float>(A, n, nb, reg, comm, ws);
+}
 size_t faer_hip_dist_local_ncols(size_t n, size_t nb, int rank, int world_size)
 {
 	return DistLu<DeviceBackend<double>>::local_ncols(n, nb, rank, world_size);

@@ -26,15 +26,26 @@ namespace fh {
 //   void laswp(View Bm, const int *piv, int nt)          -- applies (j <-> piv[j]), j < nt, to the rows of Bm
 //   void trsm_unit_lower(View L, View X)                 -- X <- L^-1 X
 //   void gemm_sub(View C, View A, View Bm)               -- C -= A * Bm
-//   void pack(View src, T *dst) / unpack                 -- contiguous column-major copies to / from the panel buffer
-//   void bcast(void *buf, size_t bytes, int root)        -- collective on the backend's memory space
+//   void pack(View src, T *dst)                          -- contiguous column-major copy into the panel buffer
+//   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)
+//                                                        -- collective on the backend's memory space; may be
+//                                                           asynchronous (slot = 0 / 1, at most one in flight each)
+//   void copy_ints(int *dst, const int *src, size_t n)   -- inside the backend's memory space, stream ordered
 //   void to_host(int *dst, const int *src, size_t n)     -- pivots back to the host (synchronising)
+//
+// Look-ahead: the owner of block column k+1 brings that column up to date with panel k and factors it FIRST, then
+// starts its broadcast; every rank posts the receive before it runs the rest of update k, so the transfer of
+// panel k+1 and the latency-bound panel factorization on its owner overlap with the trailing updates of step k.
+// Two panel buffers alternate; the pivots stay in the backend's memory until the end (no host synchronisation
+// inside the loop).
 template <class B> struct DistLu {
 	typedef typename B::T T;
 	typedef typename B::View View;
 
-	static size_t hdr_scalars(long nb) { return ((size_t) nb * sizeof(int) + sizeof(T) - 1) / sizeof(T); }
-	static size_t ws_scalars(long m, long nb) { return hdr_scalars(nb) + (size_t) m * (size_t) nb; }
+	static size_t hdr_scalars(long nints) { return ((size_t) nints * sizeof(int) + sizeof(T) - 1) / sizeof(T); }
+	static size_t buf_scalars(long m, long nb) { return hdr_scalars(nb) + (size_t) m * (size_t) nb; }
+	// [all pivots: m ints][panel buffer 0: nb pivots + packed panel][panel buffer 1]
+	static size_t ws_scalars(long m, long nb) { return hdr_scalars(m) + 2 * buf_scalars(m, nb); }
 
 	static size_t local_ncols(size_t n, size_t nb, int rank, int world)
 	{
@@ -46,7 +57,7 @@ template <class B> struct DistLu {
 	}
 
 	// A_local: m x local_ncols (this rank's block columns, in increasing global order, contiguous).
-	// panel_ws: >= ws_scalars(m, nb) scalars in the backend's memory space: [pivots (nb ints) | packed panel].
+	// panel_ws: >= ws_scalars(m, nb) scalars in the backend's memory space.
 	// piv_host: min(m, n) ints, filled on every rank with ABSOLUTE pivot rows.
 	static void run(B &be, View A_local, long m, long n, long nb, int rank, int world, T *panel_ws, int *piv_host)
 	{
@@ -62,56 +73,76 @@ template <class B> struct DistLu {
 		auto view = [&](long r0, long c0, long nr, long nc) {
 			return View{A_local.p + r0 * A_local.rs + c0 * A_local.cs, nr, nc, A_local.rs, A_local.cs};
 		};
-		int *piv_dev = reinterpret_cast<int *>(panel_ws); // header of the panel buffer
-		T *panel = panel_ws + hdr_scalars(nb);
-		std::vector<int> piv_blk((size_t) nb);
-		for (long k = 0; k < nblk; ++k) {
-			const int owner = (int) (k % world);
-			const long j0 = k * nb;
-			const long w = (j0 + nb <= size) ? nb : size - j0; // columns factored in this block
-			const long wcols = (j0 + nb <= n) ? nb : n - j0;     // columns the block really has (m < n tail)
-			const long rows = m - j0;
-			// ---- 1. the owner factors its panel in place and packs it
-			if (rank == owner) {
-				const long lc = local_col0(k);
-				be.factor_panel(view(j0, lc, rows, w), piv_dev);
-				be.pack(view(j0, lc, rows, w), panel);
-			}
-			// ---- 2. ONE broadcast per block column: panel (rows x w) + pivots
-			be.bcast(panel_ws, (hdr_scalars(nb) + (size_t) rows * (size_t) w) * sizeof(T), owner);
-			be.to_host(piv_blk.data(), piv_dev, (size_t) w);
-			for (long j = 0; j < w; ++j)
-				piv_host[j0 + j] = (int) (j0 + piv_blk[(size_t) j]);
-			// ---- 3. every rank: interchanges on all its other columns, then solve + update its later blocks
-			View Lp{panel, rows, w, 1, rows}; // packed panel: unit lower trapezoid (U11 in its top triangle)
-			for (long b = rank; b < nblk_all; b += world) {
-				const long bc0 = b * nb;
-				const long bw = (bc0 + nb <= n) ? nb : n - bc0;
-				const long lc = local_col0(b);
-				if (b == k) {
-					// the owner's panel columns were swapped by the panel factorization itself; a wider block
-					// (m < n tail) still has columns to the right of the factored ones
-					if (wcols > w) {
-						View R = view(j0, lc + w, rows, wcols - w);
-						be.laswp(R, piv_dev, (int) w);
-						be.trsm_unit_lower(View{Lp.p, w, w, Lp.rs, Lp.cs}, View{R.p, w, R.ncols, R.rs, R.cs});
-						if (rows > w)
-							be.gemm_sub(View{R.p + w * R.rs, rows - w, R.ncols, R.rs, R.cs},
-								    View{Lp.p + w * Lp.rs, rows - w, w, Lp.rs, Lp.cs}, View{R.p, w, R.ncols, R.rs, R.cs});
-					}
-					continue;
-				}
-				View Bk = view(j0, lc, rows, bw);
-				be.laswp(Bk, piv_dev, (int) w);
-				if (b > k) {
-					View top{Bk.p, w, bw, Bk.rs, Bk.cs};
-					be.trsm_unit_lower(View{Lp.p, w, w, Lp.rs, Lp.cs}, top); // A01 <- L00^-1 A01 (factor.rs:98-107)
+		int *piv_all = reinterpret_cast<int *>(panel_ws); // pivots of every block, relative to their panel's row 0
+		T *bufs = panel_ws + hdr_scalars(m);
+		const size_t bsz = buf_scalars(m, nb);
+		auto piv_of = [&](long k) { return reinterpret_cast<int *>(bufs + (size_t) (k & 1) * bsz); };
+		auto panel_of = [&](long k) { return bufs + (size_t) (k & 1) * bsz + hdr_scalars(nb); };
+		auto fw = [&](long k) { return (k * nb + nb <= size) ? nb : size - k * nb; }; // columns factored in block k
+		auto bytes_of = [&](long k) { return (hdr_scalars(nb) + (size_t) (m - k * nb) * (size_t) fw(k)) * sizeof(T); };
+		auto factor_and_pack = [&](long k) { // owner of block column k
+			const long j0 = k * nb, w = fw(k), rows = m - j0, lc = local_col0(k);
+			be.factor_panel(view(j0, lc, rows, w), piv_of(k));
+			be.pack(view(j0, lc, rows, w), panel_of(k));
+		};
+		// applies panel k to block column b of this rank: interchanges everywhere, solve + update right of the panel
+		auto update = [&](long k, long b) {
+			const long j0 = k * nb, w = fw(k), rows = m - j0;
+			const long wcols = (j0 + nb <= n) ? nb : n - j0; // columns block k really has (m < n tail)
+			const int *piv = piv_of(k);
+			View Lp{panel_of(k), rows, w, 1, rows}; // packed panel: unit lower trapezoid (U11 in its top triangle)
+			const long bc0 = b * nb;
+			const long bw = (bc0 + nb <= n) ? nb : n - bc0;
+			const long lc = local_col0(b);
+			if (b == k) {
+				// the owner's panel columns were swapped by the panel factorization itself; a wider block
+				// (m < n tail) still has columns to the right of the factored ones
+				if (wcols > w) {
+					View R = view(j0, lc + w, rows, wcols - w);
+					be.laswp(R, piv, (int) w);
+					be.trsm_unit_lower(View{Lp.p, w, w, Lp.rs, Lp.cs}, View{R.p, w, R.ncols, R.rs, R.cs});
 					if (rows > w)
-						be.gemm_sub(View{Bk.p + w * Bk.rs, rows - w, bw, Bk.rs, Bk.cs},
-							    View{Lp.p + w * Lp.rs, rows - w, w, Lp.rs, Lp.cs}, top); // A11 -= A10 A01 (:108-117)
+						be.gemm_sub(View{R.p + w * R.rs, rows - w, R.ncols, R.rs, R.cs},
+							    View{Lp.p + w * Lp.rs, rows - w, w, Lp.rs, Lp.cs}, View{R.p, w, R.ncols, R.rs, R.cs});
 				}
+				return;
 			}
+			View Bk = view(j0, lc, rows, bw);
+			be.laswp(Bk, piv, (int) w);
+			if (b > k) {
+				View top{Bk.p, w, bw, Bk.rs, Bk.cs};
+				be.trsm_unit_lower(View{Lp.p, w, w, Lp.rs, Lp.cs}, top); // A01 <- L00^-1 A01 (factor.rs:98-107)
+				if (rows > w)
+					be.gemm_sub(View{Bk.p + w * Bk.rs, rows - w, bw, Bk.rs, Bk.cs},
+						    View{Lp.p + w * Lp.rs, rows - w, w, Lp.rs, Lp.cs}, top); // A11 -= A10 A01 (:108-117)
+			}
+		};
+		if (nblk > 0) {
+			if (rank == 0)
+				factor_and_pack(0);
+			be.bcast_begin(piv_of(0), bytes_of(0), 0, 0);
 		}
+		for (long k = 0; k < nblk; ++k) {
+			be.bcast_wait((int) (k & 1));
+			be.copy_ints(piv_all + k * nb, piv_of(k), (size_t) fw(k));
+			const bool ahead = k + 1 < nblk;
+			if (ahead) {
+				const int next_owner = (int) ((k + 1) % world);
+				if (rank == next_owner) {
+					update(k, k + 1);
+					factor_and_pack(k + 1);
+				}
+				be.bcast_begin(piv_of(k + 1), bytes_of(k + 1), next_owner, (int) ((k + 1) & 1));
+			}
+			for (long b = rank; b < nblk_all; b += world)
+				if (!(ahead && b == k + 1))
+					update(k, b);
+		}
+		std::vector<int> rel((size_t) size);
+		if (size > 0)
+			be.to_host(rel.data(), piv_all, (size_t) size);
+		for (long j = 0; j < size; ++j)
+			piv_host[j] = (int) ((j / nb) * nb + rel[(size_t) j]);
 	}
 };
 

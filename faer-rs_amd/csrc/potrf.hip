@@ -482,6 +482,24 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 	}
 }
 
+// Tall panel entry point for the distributed driver (dist_llt.h): Cholesky of the top square block of P and the
+// solve of the rows below it, left-looking in 128-column blocks (potrf_panel_flat).  status: 2 device ints,
+// [0] = first failing global index + 1 (kept if already set), [1] += regularisation count; no synchronisation.
+template <typename T> void potrf_panel_dev(MatV<T> P, T reg_delta, T reg_eps, int *status_dev, idx_t offset)
+{
+	FH_CHECK(P.nrows >= P.ncols, "potrf_panel: the panel must be tall");
+	if (P.ncols == 0)
+		return;
+	const idx_t nblk = (P.ncols + POTRF_NB - 1) / POTRF_NB;
+	Scratch winv((size_t) nblk * POTRF_NB * POTRF_NB * sizeof(T));
+	const int regularize = (reg_delta > (T) 0 && reg_eps > (T) 0) ? 1 : 0;
+	// potrf_panel_flat indexes the inverse blocks by (offset + c0) / 128: hand it a base shifted accordingly
+	T *Wbase = winv.as<T>() - (size_t) (offset / POTRF_NB) * POTRF_NB * POTRF_NB;
+	potrf_panel_flat<T>(P, regularize, reg_eps, reg_delta, status_dev, offset, Wbase);
+}
+template void potrf_panel_dev<double>(MatV<double>, double, double, int *, idx_t);
+template void potrf_panel_dev<float>(MatV<float>, float, float, int *, idx_t);
+
 template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps)
 {
 	FH_CHECK(A.nrows == A.ncols, "potrf: matrix must be square");

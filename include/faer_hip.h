@@ -303,11 +303,19 @@ FAER_HIP_API double faer_hip_mfma_peak_tflops(FaerHipDType dtype, int iters);
  *    (torch.distributed.broadcast over RCCL in bench.py; gloo in the CPU tests).
  * --------------------------------------------------------------------------------------------- */
 typedef void (*FaerHipBcastFn)(void *user, void *device_buf, size_t bytes, int root);
-typedef struct FaerHipComm { int rank; int world_size; FaerHipBcastFn bcast; void *user; } FaerHipComm;
+/* Optional asynchronous pair: `ibcast` starts the broadcast of `bytes` bytes at `device_buf` from `root` (ordered
+ * after the work already enqueued on the calling thread's stream), `wait` makes that stream wait for the broadcast
+ * started with the same `slot` (0 or 1; at most one broadcast per slot is in flight).  With both NULL the
+ * drivers fall back to the blocking `bcast` (same results, no overlap of transfers with compute). */
+typedef void (*FaerHipIbcastFn)(void *user, void *device_buf, size_t bytes, int root, int slot);
+typedef void (*FaerHipWaitFn)(void *user, int slot);
+typedef struct FaerHipComm {
+	int rank; int world_size; FaerHipBcastFn bcast; void *user; FaerHipIbcastFn ibcast; FaerHipWaitFn wait;
+} FaerHipComm;
 
 /* Number of block columns of width `nb` owned by `rank` out of n columns distributed block-cyclically. */
 FAER_HIP_API size_t faer_hip_dist_local_ncols(size_t n, size_t nb, int rank, int world_size);
-/* Scalars of device scratch the distributed LU needs for its broadcast buffer ({pivots, packed panel}). */
+/* Scalars of device scratch the distributed LU needs: all pivots + two broadcast buffers ({pivots, packed panel}). */
 FAER_HIP_API size_t faer_hip_dist_panel_ws_scalars(size_t nrows, size_t nb, FaerHipDType dtype);
 /* Distributed partial-pivot LU of an m x n matrix whose block columns (width nb) are dealt block-cyclically
  * over comm.world_size ranks; A_local holds this rank's columns (m x local_ncols, device memory, col-major).
@@ -315,9 +323,22 @@ FAER_HIP_API size_t faer_hip_dist_panel_ws_scalars(size_t nrows, size_t nb, Faer
  * faer_hip_dist_panel_ws_scalars(m, nb) scalars.  Per block column: the owner factors its m_k x nb panel with
  * the single-GPU panel code (same pivoting rule, lu/partial_pivoting/factor.rs:19-187), ONE broadcast ships
  * {pivots, panel}, every rank applies the interchanges, the unit-lower solve and the trailing update to its own
- * columns (csrc/dist_lu.h). */
+ * columns; look-ahead: the owner of the next block column updates and factors it first and its broadcast
+ * overlaps the remaining updates (csrc/dist_lu.h). */
 FAER_HIP_API FaerPartialPivLuStatus faer_hip_dist_partial_piv_lu_f64(FaerMatMut A_local, size_t n_global, size_t nb, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerHipComm comm, void *panel_ws);
 FAER_HIP_API FaerPartialPivLuStatus faer_hip_dist_partial_piv_lu_f32(FaerMatMut A_local, size_t n_global, size_t nb, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerHipComm comm, void *panel_ws);
+
+
+/* Distributed Cholesky (lower) of an n x n matrix, same partition and transport (csrc/dist_llt.h): A_local holds
+ * this rank's block columns at full height (n x local_ncols, device memory, col-major; only the lower triangle of
+ * the global matrix is referenced or written).  Per block column the owner factors the diagonal block and solves
+ * the rows below (cholesky/ldlt/factor.rs:407-433), ONE broadcast ships that column panel, every rank applies
+ * lower(A11) -= L10 L10^T (:436-446) to the block columns it owns, with the same look-ahead as the LU.
+ * `panel_ws`: device scratch of faer_hip_dist_llt_ws_scalars(n, nb) scalars.  The status is identical on all ranks
+ * (NonPositivePivot carries the smallest failing global index). */
+FAER_HIP_API size_t faer_hip_dist_llt_ws_scalars(size_t n, size_t nb, FaerHipDType dtype);
+FAER_HIP_API FaerLltStatus faer_hip_dist_llt_f64(FaerMatMut A_local, size_t n_global, size_t nb, FaerLltRegularization regularization, FaerHipComm comm, void *panel_ws);
+FAER_HIP_API FaerLltStatus faer_hip_dist_llt_f32(FaerMatMut A_local, size_t n_global, size_t nb, FaerLltRegularization regularization, FaerHipComm comm, void *panel_ws);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../faer-rs_amd/csrc/dist_llt.h"
 #include "../faer-rs_amd/csrc/dist_lu.h"
 
 typedef void (*BcastFn)(void *user, void *buf, size_t bytes, int root);
@@ -90,6 +91,51 @@ struct HostBackend {
 		cb(user, buf, bytes, root);
 	}
 	void to_host(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
+	// the look-ahead protocol of the drivers with a blocking transport: begin = the broadcast itself, wait = no-op;
+	// `begun` / `waited` let the tests check that every broadcast is started exactly once and awaited exactly once
+	long begun[2] = {0, 0}, waited[2] = {0, 0};
+	void bcast_begin(void *buf, size_t bytes, int root, int slot)
+	{
+		++begun[slot];
+		bcast(buf, bytes, root);
+	}
+	void bcast_wait(int slot) { ++waited[slot]; }
+	void copy_ints(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
+	void zero_ints(int *p, size_t n) { std::memset(p, 0, n * sizeof(int)); }
+	void from_host(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
+	// ---- Cholesky: plain restatement of cholesky/ldlt/factor.rs:122-174 (llt) on the tall panel, column by column
+	void potrf_panel(View P, long offset, int *status)
+	{
+		const long rows = P.nrows, w = P.ncols;
+		for (long j = 0; j < w; ++j) {
+			double d = at(P, j, j);
+			for (long k = 0; k < j; ++k)
+				d -= at(P, j, k) * at(P, j, k);
+			if (!(d > 0.0)) {
+				if (status[0] == 0)
+					status[0] = (int) (offset + j + 1);
+				return;
+			}
+			const double l = std::sqrt(d), inv = 1.0 / l;
+			at(P, j, j) = l;
+			for (long i = j + 1; i < rows; ++i) {
+				double s = at(P, i, j);
+				for (long k = 0; k < j; ++k)
+					s -= at(P, i, k) * at(P, j, k);
+				at(P, i, j) = s * inv;
+			}
+		}
+	}
+	void syrk_sub(View C, View A, View Bt)
+	{
+		for (long j = 0; j < C.ncols; ++j)
+			for (long i = j; i < C.nrows; ++i) { // rows 0..ncols-1: lower part only
+				double s = 0.0;
+				for (long k = 0; k < A.ncols; ++k)
+					s += at(A, i, k) * at(Bt, j, k);
+				at(C, i, j) -= s;
+			}
+	}
 };
 
 extern "C" {
@@ -105,6 +151,22 @@ long test_dist_lu_f64(double *a_local, long m, long local_ncols, long ld, long n
 	fh::DistLu<HostBackend>::run(be, A, m, n, nb, rank, world, ws.data(), piv_out);
 	stats[0] = be.bytes_bcast;
 	return be.n_bcast;
+}
+// returns what DistLlt::run returns; stats[0] = bytes broadcast, stats[1] = number of broadcasts
+long test_dist_llt_f64(double *a_local, long n, long local_ncols, long ld, long nb, int rank, int world, BcastFn cb, void *user,
+		       unsigned long long *stats)
+{
+	HostBackend be;
+	be.cb = cb;
+	be.user = user;
+	std::vector<double> ws(fh::DistLlt<HostBackend>::ws_scalars(n, nb));
+	HostBackend::View A{a_local, n, local_ncols, 1, ld};
+	const long r = fh::DistLlt<HostBackend>::run(be, A, n, nb, rank, world, ws.data());
+	stats[0] = be.bytes_bcast;
+	stats[1] = (unsigned long long) be.n_bcast;
+	stats[2] = (unsigned long long) (be.begun[0] + be.begun[1]);
+	stats[3] = (unsigned long long) (be.waited[0] + be.waited[1]);
+	return r;
 }
 long test_dist_local_ncols(long n, long nb, int rank, int world) { return (long) fh::DistLu<HostBackend>::local_ncols(n, nb, rank, world); }
 }

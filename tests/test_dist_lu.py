@@ -20,8 +20,8 @@ LIB = os.path.join(BUILD, "libdist_host_test.so")
 def build_lib():
     os.makedirs(BUILD, exist_ok=True)
     src = os.path.join(ROOT, "tests", "dist_host_backend.cpp")
-    hdr = os.path.join(ROOT, "faer-rs_amd", "csrc", "dist_lu.h")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ROOT, "faer-rs_amd", "csrc", h) for h in ("dist_lu.h", "dist_llt.h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", LIB, src])
     return LIB
 

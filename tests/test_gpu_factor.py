@@ -308,6 +308,87 @@ def test_dist_lu_device_backend_single_rank(oracle, m, n, nb):
     assert len(calls) == (min(m, n) + nb - 1) // nb and all(r == 0 for _, r in calls)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_async", [False, True])
+def test_dist_lu_device_backend_async_transport(oracle, use_async):
+    """the look-ahead protocol of the distributed LU with the optional asynchronous transport (ibcast / wait):
+    every broadcast is begun once and awaited once before its panel is used; same result as the blocking form"""
+    F = init_gpu()
+    m = n = 640
+    nb = 64
+    rng = np.random.default_rng(22)
+    a = rnd(rng, m, n)
+    ref = a.copy(order="F")
+    perm, _, nt = oracle.lu_in_place(ref)
+    da = to_dev(a)
+    log = []
+
+    class Handle:
+        def __init__(self, k):
+            self.k = k
+
+        def wait(self):
+            log.append(("wait", self.k))
+
+    def ibcast(t, root):
+        log.append(("begin", len([e for e in log if e[0] == "begin"])))
+        return Handle(log[-1][1])
+
+    fwd, _, cnt = F.dist_partial_piv_lu(da, n, nb, 0, 1, lambda t, root: log.append(("blocking", 0)), ibcast=ibcast if use_async else None)
+    assert np.array_equal(fwd.astype(np.int64), perm) and cnt == nt
+    assert np.abs(to_host(da) - ref).max() <= 64 * n * EPS[np.dtype(np.float64)] * max(1.0, np.abs(ref).max())
+    nblk = n // nb
+    if use_async:
+        begins = [e[1] for e in log if e[0] == "begin"]
+        waits = [e[1] for e in log if e[0] == "wait"]
+        assert begins == list(range(nblk)) and waits == list(range(nblk))
+        # look-ahead: panel k+1 is on its way before panel k+2 .. and never more than two in flight
+        for k in range(nblk):
+            assert log.index(("begin", k)) < log.index(("wait", k))
+            if k + 2 < nblk:
+                assert log.index(("wait", k)) < log.index(("begin", k + 2))
+    else:
+        assert len(log) == nblk
+
+
+# -------------------------------------------------------------------------------------------- distributed llt
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nb", [(512, 64), (1000, 128), (700, 96), (130, 256), (1536, 512)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dist_llt_device_backend_single_rank(oracle, n, nb, dtype):
+    """the device backend of the distributed Cholesky (csrc/dist.hip) on ONE rank: factor within tolerance of the
+    oracle, strict upper triangle untouched, one broadcast per block column.  Multi-rank control flow of the same
+    template: tests/test_dist_llt.py (gloo, world_size 2 and 3)."""
+    F = init_gpu()
+    rng = np.random.default_rng(n + nb)
+    a = spd(rng, n, dtype)
+    ref = a.copy(order="F")
+    assert oracle.llt_in_place(ref) == ("ok", 0)
+    marked = a.copy(order="F")
+    iu = np.triu_indices(n, 1)
+    marked[iu] = -7.5
+    da = to_dev(marked)
+    calls = []
+    assert F.dist_llt(da, n, min(nb, n), 0, 1, lambda t, root: calls.append(root)) == 0
+    got = to_host(da)
+    assert (got[iu] == -7.5).all()
+    il = np.tril_indices(n)
+    assert np.abs(got[il] - ref[il]).max() <= 64 * n * EPS[np.dtype(dtype)] * np.abs(ref[il]).max()
+    assert len(calls) == (n + min(nb, n) - 1) // min(nb, n)
+
+
+@pytest.mark.gpu
+def test_dist_llt_device_backend_failure_index():
+    F = init_gpu()
+    n, nb, bad = 900, 128, 517
+    rng = np.random.default_rng(4)
+    a = spd(rng, n, np.float64)
+    a[bad, bad] = -1.0
+    with pytest.raises(F.LltError) as ei:
+        F.dist_llt(to_dev(a), n, nb, 0, 1, lambda t, root: None)
+    assert ei.value.index == bad
+
+
 def test_llt_lookahead_is_deterministic_under_interleaved_work(monkeypatch):
     """the two-stream look-ahead driver (n = 8192, look-ahead down to 2048 remaining rows) must give the bitwise
     same factor every time, also with unrelated work queued around it (a cross-stream race would show up as a
