@@ -478,6 +478,96 @@ def apply_block_householder_sequence_on_the_left_in_place(basis, factor, rhs, tr
     return rhs
 
 
+def apply_block_householder_sequence_on_the_right_in_place(basis, factor, matrix, transpose=False, par=PAR_SEQ):
+    """householder.rs:813-854: matrix <- matrix Q (or matrix Q^H)"""
+    suf, _, _ = _dtype_suffix(matrix)
+    name = "apply_householder_transpose_on_the_right" if transpose else "apply_householder_on_the_right"
+    getattr(lib(), f"libfaer_v0_23_{name}_{suf}")(_mat(basis), _mat(factor), C.c_int(CONJ_NO), _mat(matrix, MatMut), par,
+                                                MemAlloc(None, 0))
+    return matrix
+
+
+def _diag_vec(ld):
+    n = ld.shape[0]
+    if _is_torch(ld):
+        return VecRef(ld.data_ptr(), n, ld.stride(0) + ld.stride(1))
+    return VecRef(ld.ctypes.data, n, (ld.strides[0] + ld.strides[1]) // ld.itemsize)
+
+
+def inverse_triangular_in_place(t_inv, t, upper=False, unit=False, par=PAR_SEQ):
+    """triangular_inverse.rs: the (unit) lower / upper triangle of t_inv <- inverse of the triangle of t; the rest of
+    t_inv (and, unit: its diagonal) is left untouched"""
+    suf, _, _ = _dtype_suffix(t)
+    name = f"inverse_{'unit_' if unit else ''}triangular_{'upper' if upper else 'lower'}_in_place"
+    getattr(lib(), f"libfaer_v0_23_{name}_{suf}")(_mat(t_inv, MatMut), _mat(t), par)
+    return t_inv
+
+
+def llt_reconstruct(out, l, par=PAR_SEQ):
+    """cholesky/llt/reconstruct.rs: lower(out) <- L L^H"""
+    suf, _, _ = _dtype_suffix(l)
+    getattr(lib(), f"libfaer_v0_23_llt_reconstruct_{suf}")(_mat(out, MatMut), _mat(l), par, MemAlloc(None, 0))
+    return out
+
+
+def llt_inverse(out, l, par=PAR_SEQ):
+    """cholesky/llt/inverse.rs: lower(out) <- (L L^H)^-1"""
+    suf, _, _ = _dtype_suffix(l)
+    getattr(lib(), f"libfaer_v0_23_llt_inverse_{suf}")(_mat(out, MatMut), _mat(l), par, MemAlloc(None, 0))
+    return out
+
+
+def ldlt_reconstruct(out, ld, par=PAR_SEQ):
+    """cholesky/ldlt/reconstruct.rs with L and D packed as ldlt_factor_in_place leaves them: lower(out) <- L D L^H"""
+    suf, _, _ = _dtype_suffix(ld)
+    getattr(lib(), f"libfaer_v0_23_ldlt_reconstruct_{suf}")(_mat(out, MatMut), _mat(ld), _diag_vec(ld), par, MemAlloc(None, 0))
+    return out
+
+
+def ldlt_inverse(out, ld, par=PAR_SEQ):
+    """cholesky/ldlt/inverse.rs: lower(out) <- (L D L^H)^-1"""
+    suf, _, _ = _dtype_suffix(ld)
+    getattr(lib(), f"libfaer_v0_23_ldlt_inverse_{suf}")(_mat(out, MatMut), _mat(ld), _diag_vec(ld), par, MemAlloc(None, 0))
+    return out
+
+
+def partial_piv_lu_reconstruct(out, lu, perm_fwd, perm_bwd, par=PAR_SEQ):
+    """lu/partial_pivoting/reconstruct.rs: out <- P^-1 L U (`lu` holds L and U packed, any m x n)"""
+    suf, _, _ = _dtype_suffix(lu)
+    it = "u64" if np.dtype(perm_fwd.dtype) == np.uint64 else "u32"
+    m = lu.shape[0]
+    getattr(lib(), f"libfaer_v0_23_partial_piv_lu_reconstruct_{it}_{suf}")(
+        _mat(out, MatMut), _mat(lu), _mat(lu), SliceRef(perm_fwd.ctypes.data, m), SliceRef(perm_bwd.ctypes.data, m), par, MemAlloc(None, 0))
+    return out
+
+
+def partial_piv_lu_inverse(out, lu, perm_fwd, perm_bwd, par=PAR_SEQ):
+    """lu/partial_pivoting/inverse.rs: out <- A^-1"""
+    suf, _, _ = _dtype_suffix(lu)
+    it = "u64" if np.dtype(perm_fwd.dtype) == np.uint64 else "u32"
+    n = lu.shape[0]
+    getattr(lib(), f"libfaer_v0_23_partial_piv_lu_inverse_{it}_{suf}")(
+        _mat(out, MatMut), _mat(lu), _mat(lu), SliceRef(perm_fwd.ctypes.data, n), SliceRef(perm_bwd.ctypes.data, n), par, MemAlloc(None, 0))
+    return out
+
+
+def qr_reconstruct(out, qr, q_coeff, par=PAR_SEQ):
+    """qr/no_pivoting/reconstruct.rs: out <- Q R (`qr` holds the Householder basis below the diagonal and R on / above it)"""
+    suf, _, _ = _dtype_suffix(qr)
+    m, n = qr.shape
+    size = min(m, n)
+    getattr(lib(), f"libfaer_v0_23_qr_reconstruct_{suf}")(_mat(out, MatMut), _mat(qr[:, :size]), _mat(q_coeff), _mat(qr[:size, :]), par,
+                                                        MemAlloc(None, 0))
+    return out
+
+
+def qr_inverse(out, qr, q_coeff, par=PAR_SEQ):
+    """qr/no_pivoting/inverse.rs: out <- A^-1 (square)"""
+    suf, _, _ = _dtype_suffix(qr)
+    getattr(lib(), f"libfaer_v0_23_qr_inverse_{suf}")(_mat(out, MatMut), _mat(qr), _mat(q_coeff), _mat(qr), par, MemAlloc(None, 0))
+    return out
+
+
 # ------------------------------------------------------------------ high level owners (faer/src/linalg/solvers.rs)
 def _empty_like_f(a, shape):
     if _is_torch(a):

@@ -274,6 +274,174 @@ template <typename T> void qr_solve_api(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef
 
 FaerLayout layout(size_t bytes, size_t align) { return FaerLayout{bytes, align}; }
 
+// ---- triangular inverse (triangular_inverse.rs:43-230): dst's other triangle (and, unit: its diagonal) is untouched
+template <typename T> void tri_inverse_api(FaerMatMut Out, FaerMatRef Tm, bool upper, bool unit)
+{
+	FH_CHECK(Tm.nrows == Tm.ncols && Out.nrows == Tm.nrows && Out.ncols == Tm.ncols, "triangular inverse: dimension mismatch");
+	Staged<const T> t(view<T>(Tm), true, false);
+	Staged<T> o(view<T>(Out), true, true); // keeps the triangle that is not written
+	if (upper)
+		tri_invert_lower_dev<T>(o.dev.t(), t.dev.t(), unit);
+	else
+		tri_invert_lower_dev<T>(o.dev, t.dev, unit);
+}
+
+// cholesky/llt/reconstruct.rs:14-40: lower(out) = L L^H
+template <typename T> void llt_reconstruct_api(FaerMatMut Out, FaerMatRef L)
+{
+	FH_CHECK(L.nrows == L.ncols && Out.nrows == L.nrows && Out.ncols == L.nrows, "llt reconstruct: dimension mismatch");
+	Staged<const T> l(view<T>(L), true, false);
+	Staged<T> o(view<T>(Out), true, true);
+	matmul_triangular_dev<T>(o.dev, 1, false, l.dev, 1, l.dev.t(), 2, (T) 1);
+}
+
+// cholesky/llt/inverse.rs:14-47: lower(out) = W^H W, W = inv(L)
+template <typename T> void llt_inverse_api(FaerMatMut Out, FaerMatRef L)
+{
+	const idx_t n = (idx_t) L.nrows;
+	FH_CHECK(L.nrows == L.ncols && Out.nrows == L.nrows && Out.ncols == L.nrows, "llt inverse: dimension mismatch");
+	Staged<const T> l(view<T>(L), true, false);
+	Staged<T> o(view<T>(Out), true, true);
+	Scratch wb((size_t) n * (size_t) n * sizeof(T) + 256);
+	MatV<T> W{wb.as<T>(), n, n, 1, n};
+	tri_invert_lower_dev<T>(W, l.dev, false);
+	matmul_triangular_dev<T>(o.dev, 1, false, W.t().c(), 2, W.c(), 1, (T) 1);
+	ctx().sync();
+}
+
+// cholesky/ldlt/reconstruct.rs:14-62: lower(out) = (L D) L^H, L unit lower
+template <typename T> void ldlt_reconstruct_api(FaerMatMut Out, FaerMatRef L, FaerVecRef D)
+{
+	const idx_t n = (idx_t) L.nrows;
+	FH_CHECK(L.nrows == L.ncols && Out.nrows == L.nrows && Out.ncols == L.nrows && D.len == L.nrows, "ldlt reconstruct: dimension mismatch");
+	Staged<const T> l(view<T>(L), true, false);
+	FaerMatRef Dm{D.ptr, D.len, 1, D.stride, 0};
+	Staged<const T> d(view<T>(Dm), true, false);
+	Staged<T> o(view<T>(Out), true, true);
+	Scratch wb((size_t) n * (size_t) n * sizeof(T) + 256);
+	MatV<T> LxD{wb.as<T>(), n, n, 1, n};
+	ldlt_scale_lower_dev<T>(LxD, l.dev, d.dev.p, d.dev.rs);
+	matmul_triangular_dev<T>(o.dev, 1, false, LxD.c(), 1, l.dev.t(), 6, (T) 1);
+	ctx().sync();
+}
+
+// cholesky/ldlt/inverse.rs:14-62: lower(out) = (W^H D^-1) W, W = inv(L) unit lower
+template <typename T> void ldlt_inverse_api(FaerMatMut Out, FaerMatRef L, FaerVecRef D)
+{
+	const idx_t n = (idx_t) L.nrows;
+	FH_CHECK(L.nrows == L.ncols && Out.nrows == L.nrows && Out.ncols == L.nrows && D.len == L.nrows, "ldlt inverse: dimension mismatch");
+	Staged<const T> l(view<T>(L), true, false);
+	FaerMatRef Dm{D.ptr, D.len, 1, D.stride, 0};
+	Staged<const T> d(view<T>(Dm), true, false);
+	Staged<T> o(view<T>(Out), true, true);
+	Scratch wb((size_t) n * (size_t) n * sizeof(T) + 256);
+	MatV<T> W{wb.as<T>(), n, n, 1, n};
+	tri_invert_lower_dev<T>(W, l.dev, true);
+	ldlt_inverse_prepare_dev<T>(W, d.dev.p, d.dev.rs);
+	matmul_triangular_dev<T>(o.dev, 1, false, W.c(), 2, W.c(), 5, (T) 1);
+	ctx().sync();
+}
+
+template <typename I> static void upload_perm(Scratch &buf, const void *perm_host, idx_t n)
+{
+	std::vector<idx_t> p64((size_t) n);
+	for (idx_t i = 0; i < n; ++i) {
+		p64[(size_t) i] = (idx_t) static_cast<const I *>(perm_host)[i];
+		FH_CHECK(p64[(size_t) i] >= 0 && p64[(size_t) i] < n, "permutation index out of range");
+	}
+	FH_HIP(hipMemcpyAsync(buf.p, p64.data(), (size_t) n * sizeof(idx_t), hipMemcpyHostToDevice, ctx().stream));
+	ctx().sync(); // p64 goes out of scope
+}
+
+// lu/partial_pivoting/reconstruct.rs:17-83: out = P^-1 (L U)
+template <typename T, typename I> void lu_reconstruct_api(FaerMatMut Out, FaerMatRef L, FaerMatRef U, FaerSliceRef pf, FaerSliceRef pb)
+{
+	const idx_t m = (idx_t) L.nrows, n = (idx_t) U.ncols;
+	const idx_t size = m < n ? m : n;
+	FH_CHECK(Out.nrows == L.nrows && Out.ncols == U.ncols && (idx_t) L.ncols >= size && (idx_t) U.nrows >= size && pf.len >= L.nrows &&
+			 pb.len >= L.nrows,
+		 "partial_piv_lu reconstruct: dimension mismatch");
+	FH_CHECK(!is_device_ptr(pf.ptr) && !is_device_ptr(pb.ptr), "partial_piv_lu reconstruct: perm slices must be host memory");
+	if (m == 0 || n == 0)
+		return;
+	Staged<const T> l(view<T>(L), true, false), u(view<T>(U), true, false);
+	Staged<T> o(view<T>(Out), false, true);
+	Scratch tb((size_t) m * (size_t) n * sizeof(T)), pbuf((size_t) m * sizeof(idx_t));
+	MatV<T> tmp{tb.as<T>(), m, n, 1, m};
+	matmul_triangular_dev<T>(tmp.sub(0, 0, size, size), 0, false, l.dev.sub(0, 0, size, size), 5, u.dev.sub(0, 0, size, size), 2, (T) 1);
+	if (m > n)
+		matmul_triangular_dev<T>(tmp.sub(size, 0, m - size, size), 0, false, l.dev.sub(size, 0, m - size, size), 0, u.dev.sub(0, 0, size, size), 2,
+					 (T) 1);
+	if (m < n)
+		matmul_triangular_dev<T>(tmp.sub(0, size, size, n - size), 0, false, l.dev.sub(0, 0, size, size), 5, u.dev.sub(0, size, size, n - size), 0,
+					 (T) 1);
+	upload_perm<I>(pbuf, pb.ptr, m); // permute_rows(out, tmp, perm.inverse()): out[i, :] = tmp[perm_bwd[i], :]
+	gather_rows_dev<T>(o.dev, tmp.c(), pbuf.as<idx_t>());
+	ctx().sync();
+}
+
+// lu/partial_pivoting/inverse.rs:15-62: out = U^-1 L^-1 P
+template <typename T, typename I> void lu_inverse_api(FaerMatMut Out, FaerMatRef L, FaerMatRef U, FaerSliceRef pf, FaerSliceRef pb)
+{
+	const idx_t n = (idx_t) L.ncols;
+	FH_CHECK((idx_t) L.nrows == n && (idx_t) U.nrows == n && (idx_t) U.ncols == n && (idx_t) Out.nrows == n && (idx_t) Out.ncols == n &&
+			 (idx_t) pf.len >= n && (idx_t) pb.len >= n,
+		 "partial_piv_lu inverse: dimension mismatch");
+	FH_CHECK(!is_device_ptr(pf.ptr) && !is_device_ptr(pb.ptr), "partial_piv_lu inverse: perm slices must be host memory");
+	if (n == 0)
+		return;
+	Staged<const T> l(view<T>(L), true, false), u(view<T>(U), true, false);
+	Staged<T> o(view<T>(Out), false, true);
+	Scratch tb((size_t) n * (size_t) n * sizeof(T)), pbuf((size_t) n * sizeof(idx_t));
+	MatV<T> tmp{tb.as<T>(), n, n, 1, n};
+	tri_invert_lower_dev<T>(o.dev, l.dev, true);	  // strict lower part of out
+	tri_invert_lower_dev<T>(o.dev.t(), u.dev.t(), false); // upper part (with diagonal) of out
+	matmul_triangular_dev<T>(tmp, 0, false, o.dev.c(), 2, o.dev.c(), 5, (T) 1);
+	upload_perm<I>(pbuf, pb.ptr, n); // permute_cols(out, tmp, perm.inverse()): out[:, j] = tmp[:, perm_bwd[j]]
+	gather_rows_dev<T>(o.dev.t(), tmp.t().c(), pbuf.as<idx_t>());
+	ctx().sync();
+}
+
+// qr/no_pivoting/reconstruct.rs:18-52: out = Q [R; 0]
+template <typename T> void qr_reconstruct_api(FaerMatMut Out, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R)
+{
+	const idx_t m = (idx_t) Qb.nrows, n = (idx_t) R.ncols;
+	const idx_t size = m < n ? m : n;
+	FH_CHECK((idx_t) Out.nrows == m && (idx_t) Out.ncols == n && (idx_t) Qb.ncols == size && (idx_t) Qc.ncols == size && (idx_t) R.nrows == size &&
+			 Qc.nrows > 0,
+		 "qr reconstruct: dimension mismatch");
+	Staged<const T> v(view<T>(Qb), true, false), h(view<T>(Qc), true, false), r(view<T>(R), true, false);
+	Staged<T> o(view<T>(Out), false, true);
+	MatV<const T> Rv = r.dev;
+	zero_then_upper_dev<T>(o.dev, &Rv);
+	apply_householder_sequence_left_dev<T>(v.dev, h.dev, o.dev, false);
+}
+
+// qr/no_pivoting/inverse.rs:17-58: out = R^-1 Q^H
+template <typename T> void qr_inverse_api(FaerMatMut Out, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R)
+{
+	const idx_t n = (idx_t) Qb.ncols;
+	FH_CHECK(Qc.nrows > 0 && (idx_t) Qb.nrows == n && (idx_t) Qc.ncols == n && (idx_t) R.nrows == n && (idx_t) R.ncols == n &&
+			 (idx_t) Out.nrows == n && (idx_t) Out.ncols == n,
+		 "qr inverse: dimension mismatch");
+	Staged<const T> v(view<T>(Qb), true, false), h(view<T>(Qc), true, false), r(view<T>(R), true, false);
+	Staged<T> o(view<T>(Out), false, true);
+	zero_then_upper_dev<T>(o.dev, nullptr);
+	tri_invert_lower_dev<T>(o.dev.t(), r.dev.t(), false);
+	// out <- out Q^H  ==  (Q out^T)^T   (householder.rs:836-854)
+	apply_householder_sequence_left_dev<T>(v.dev, h.dev, o.dev.t(), false);
+}
+
+// householder.rs:813-854: M <- M Q (transpose == false) or M Q^H (transpose == true), as left applications on M^T
+template <typename T> void apply_hh_right_api(FaerMatRef V, FaerMatRef H, FaerMatMut M, bool transpose)
+{
+	const size_t size = V.nrows < V.ncols ? V.nrows : V.ncols;
+	FH_CHECK(H.nrows > 0 && H.ncols == size && M.ncols == V.nrows, "apply_householder (right): dimension mismatch");
+	Staged<const T> v(view<T>(V), true, false), h(view<T>(H), true, false);
+	Staged<T> x(view<T>(M), true, true);
+	apply_householder_sequence_left_dev<T>(v.dev, h.dev, x.dev.t(), !transpose);
+}
+
 } // namespace
 
 extern "C" {
@@ -480,6 +648,118 @@ void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m, size_t n, s
 		(void) params;                                                                                         \
 		return lu_api<T, uint64_t>(A, pf, pb);                                                                 \
 	}                                                                                                              \
+	void libfaer_v0_23_inverse_triangular_lower_in_place_##suf(FaerMatMut T_inv, FaerMatRef Tm, FaerPar par) \
+	{ \
+		(void) par; tri_inverse_api<T>(T_inv, Tm, false, false); \
+	} \
+	void libfaer_v0_23_inverse_triangular_upper_in_place_##suf(FaerMatMut T_inv, FaerMatRef Tm, FaerPar par) \
+	{ \
+		(void) par; tri_inverse_api<T>(T_inv, Tm, true, false); \
+	} \
+	void libfaer_v0_23_inverse_unit_triangular_lower_in_place_##suf(FaerMatMut T_inv, FaerMatRef Tm, FaerPar par) \
+	{ \
+		(void) par; tri_inverse_api<T>(T_inv, Tm, false, true); \
+	} \
+	void libfaer_v0_23_inverse_unit_triangular_upper_in_place_##suf(FaerMatMut T_inv, FaerMatRef Tm, FaerPar par) \
+	{ \
+		(void) par; tri_inverse_api<T>(T_inv, Tm, true, true); \
+	} \
+	FaerLayout libfaer_v0_23_llt_reconstruct_scratch_##suf(size_t dim, FaerPar par) \
+	{ \
+		(void) dim; (void) par; return layout(0, 1); \
+	} \
+	void libfaer_v0_23_llt_reconstruct_##suf(FaerMatMut A, FaerMatRef L, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; llt_reconstruct_api<T>(A, L); \
+	} \
+	FaerLayout libfaer_v0_23_llt_inverse_scratch_##suf(size_t dim, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_llt_inverse_##suf(FaerMatMut A_inv, FaerMatRef L, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; llt_inverse_api<T>(A_inv, L); \
+	} \
+	FaerLayout libfaer_v0_23_ldlt_reconstruct_scratch_##suf(size_t dim, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_ldlt_reconstruct_##suf(FaerMatMut A, FaerMatRef L, FaerVecRef D, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; ldlt_reconstruct_api<T>(A, L, D); \
+	} \
+	FaerLayout libfaer_v0_23_ldlt_inverse_scratch_##suf(size_t dim, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_ldlt_inverse_##suf(FaerMatMut A_inv, FaerMatRef L, FaerVecRef D, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; ldlt_inverse_api<T>(A_inv, L, D); \
+	} \
+	FaerLayout libfaer_v0_23_partial_piv_lu_reconstruct_scratch_u32_##suf(size_t nrows, size_t ncols, FaerPar par) \
+	{ \
+		(void) par; return layout(nrows * ncols * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_partial_piv_lu_reconstruct_u32_##suf(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef pf, FaerSliceRef pb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; lu_reconstruct_api<T, uint32_t>(A, L, U, pf, pb); \
+	} \
+	FaerLayout libfaer_v0_23_partial_piv_lu_inverse_scratch_u32_##suf(size_t dim, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_partial_piv_lu_inverse_u32_##suf(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef pf, FaerSliceRef pb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; lu_inverse_api<T, uint32_t>(A_inv, L, U, pf, pb); \
+	} \
+	FaerLayout libfaer_v0_23_partial_piv_lu_reconstruct_scratch_u64_##suf(size_t nrows, size_t ncols, FaerPar par) \
+	{ \
+		(void) par; return layout(nrows * ncols * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_partial_piv_lu_reconstruct_u64_##suf(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef pf, FaerSliceRef pb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; lu_reconstruct_api<T, uint64_t>(A, L, U, pf, pb); \
+	} \
+	FaerLayout libfaer_v0_23_partial_piv_lu_inverse_scratch_u64_##suf(size_t dim, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_partial_piv_lu_inverse_u64_##suf(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef pf, FaerSliceRef pb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; lu_inverse_api<T, uint64_t>(A_inv, L, U, pf, pb); \
+	} \
+	FaerLayout libfaer_v0_23_qr_reconstruct_scratch_##suf(size_t nrows, size_t ncols, size_t bs, FaerPar par) \
+	{ \
+		(void) nrows; (void) par; return layout(bs * ncols * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_qr_reconstruct_##suf(FaerMatMut A, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; qr_reconstruct_api<T>(A, Qb, Qc, R); \
+	} \
+	FaerLayout libfaer_v0_23_qr_inverse_scratch_##suf(size_t dim, size_t bs, FaerPar par) \
+	{ \
+		(void) par; return layout(bs * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_qr_inverse_##suf(FaerMatMut A_inv, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; qr_inverse_api<T>(A_inv, Qb, Qc, R); \
+	} \
+	FaerLayout libfaer_v0_23_apply_householder_on_the_right_scratch_##suf(size_t dim, size_t bs, size_t k) \
+	{ \
+		(void) dim; return layout(bs * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_apply_householder_on_the_right_##suf(FaerMatRef V, FaerMatRef H, FaerConj cj, FaerMatMut M, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; apply_hh_right_api<T>(V, H, M, false); \
+	} \
+	FaerLayout libfaer_v0_23_apply_householder_transpose_on_the_right_scratch_##suf(size_t dim, size_t bs, size_t k) \
+	{ \
+		(void) dim; return layout(bs * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_apply_householder_transpose_on_the_right_##suf(FaerMatRef V, FaerMatRef H, FaerConj cj, FaerMatMut M, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; apply_hh_right_api<T>(V, H, M, true); \
+	} \
 	FaerQrParams libfaer_v0_23_QrParams_##suf(void) { return FaerQrParams{48 * 48, 192 * 256}; }                    \
 	size_t libfaer_v0_23_qr_recommended_block_size_##suf(size_t nrows, size_t ncols)                                \
 	{                                                                                                              \

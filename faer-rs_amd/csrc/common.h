@@ -208,6 +208,12 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 // level-2 shapes (gemv.hip): matrix-vector product and rank-1 update, HBM streams outside the MFMA kernel
 template <typename T> bool gemv_dev(idx_t m, idx_t k, MatV<const T> A, const T *x, idx_t xs, T *y, idx_t ys, T alpha, bool add);
 template <typename T> void rank1_dev(MatV<T> C, bool add, const T *a, idx_t as, const T *b, idx_t bs, T alpha);
+// extras.hip / trsm.hip: triangular inverse (triangular_inverse.rs) and helpers of the reconstruct / inverse entry points
+template <typename T> void trtri_diag_dev(MatV<const T> L, bool unit, T *W);
+template <typename T> void tri_invert_lower_dev(MatV<T> dst, MatV<const T> src, bool unit);
+template <typename T> void ldlt_scale_lower_dev(MatV<T> out, MatV<const T> L, const T *d, idx_t ds);
+template <typename T> void ldlt_inverse_prepare_dev(MatV<T> W, const T *d, idx_t ds);
+template <typename T> void zero_then_upper_dev(MatV<T> out, const MatV<const T> *R);
 // tall-skinny shapes (skinny.hip): streaming kernels; false if the shape / strides do not qualify
 template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV<const T> B, T alpha);
 // C <- [C +] alpha * sum_z ws[z] (slices of nrows x ncols, column major), fixed summation order (gemm.hip)

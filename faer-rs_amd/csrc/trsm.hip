@@ -140,6 +140,19 @@ __global__ __launch_bounds__(LDS_NT) void trtri_diag_kernel(const T *__restrict_
 	lds_store_block<T>(S, W + (size_t) b * TRSM_IB * TRSM_IB, 1, TRSM_IB, TRSM_IB, false);
 }
 
+// W block b <- inverse of the b-th 128 x 128 diagonal block of the lower triangular L (identity padded)
+template <typename T> void trtri_diag_dev(MatV<const T> L, bool unit, T *W)
+{
+	const idx_t n = L.nrows;
+	if (n == 0)
+		return;
+	const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
+	hipLaunchKernelGGL(trtri_diag_kernel<T>, dim3((unsigned) nblk), dim3(LDS_NT), 0, ctx().stream, L.p, L.rs, L.cs, (int) n, unit ? 1 : 0, W);
+	FH_HIP(hipGetLastError());
+}
+template void trtri_diag_dev<double>(MatV<const double>, bool, double *);
+template void trtri_diag_dev<float>(MatV<const float>, bool, float *);
+
 template <typename T> static void trsm_inv_rec(MatV<const T> L, MatV<T> X, const T *W, idx_t b0)
 {
 	const idx_t n = L.nrows, k = X.ncols;

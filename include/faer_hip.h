@@ -257,6 +257,69 @@ FAER_HIP_API FaerPar libfaer_v0_23_get_global_par(void);
 FAER_HIP_API void libfaer_v0_23_set_global_par(FaerPar par);
 
 /* ---------------------------------------------------------------------------------------------
+ * 2b. Triangular inverse, reconstruct / inverse of the factorizations, reflectors applied on the right
+ *     (faer-ffi/src/lib.rs:938-983, :1039-1075, :1247-1288, :1661-1720, :2071-2124, :1471-1518; f32/f64 subset).
+ *     Same argument lists as the reference; the `mem` scratch is accepted and ignored (device scratch is
+ *     pooled inside the library).  Triangular outputs leave the other triangle of `out` untouched.
+ * --------------------------------------------------------------------------------------------- */
+FAER_HIP_API void libfaer_v0_23_inverse_triangular_lower_in_place_f64(FaerMatMut T_inv, FaerMatRef T, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_inverse_triangular_upper_in_place_f64(FaerMatMut T_inv, FaerMatRef T, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_inverse_unit_triangular_lower_in_place_f64(FaerMatMut T_inv, FaerMatRef T, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_inverse_unit_triangular_upper_in_place_f64(FaerMatMut T_inv, FaerMatRef T, FaerPar par);
+FAER_HIP_API FaerLayout libfaer_v0_23_llt_reconstruct_scratch_f64(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_llt_reconstruct_f64(FaerMatMut A, FaerMatRef L, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_llt_inverse_scratch_f64(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_llt_inverse_f64(FaerMatMut A_inv, FaerMatRef L, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_ldlt_reconstruct_scratch_f64(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_ldlt_reconstruct_f64(FaerMatMut A, FaerMatRef L, FaerVecRef D, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_ldlt_inverse_scratch_f64(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_ldlt_inverse_f64(FaerMatMut A_inv, FaerMatRef L, FaerVecRef D, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_reconstruct_scratch_u32_f64(size_t nrows, size_t ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_reconstruct_u32_f64(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_inverse_scratch_u32_f64(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_inverse_u32_f64(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_reconstruct_scratch_u64_f64(size_t nrows, size_t ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_reconstruct_u64_f64(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_inverse_scratch_u64_f64(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_inverse_u64_f64(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_reconstruct_scratch_f64(size_t nrows, size_t ncols, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_reconstruct_f64(FaerMatMut A, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_inverse_scratch_f64(size_t dim, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_inverse_f64(FaerMatMut A_inv, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_on_the_right_scratch_f64(size_t dim, size_t block_size, size_t rhs_nrows);
+FAER_HIP_API void libfaer_v0_23_apply_householder_on_the_right_f64(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj conj, FaerMatMut matrix, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_transpose_on_the_right_scratch_f64(size_t dim, size_t block_size, size_t rhs_nrows);
+FAER_HIP_API void libfaer_v0_23_apply_householder_transpose_on_the_right_f64(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj conj, FaerMatMut matrix, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API void libfaer_v0_23_inverse_triangular_lower_in_place_f32(FaerMatMut T_inv, FaerMatRef T, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_inverse_triangular_upper_in_place_f32(FaerMatMut T_inv, FaerMatRef T, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_inverse_unit_triangular_lower_in_place_f32(FaerMatMut T_inv, FaerMatRef T, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_inverse_unit_triangular_upper_in_place_f32(FaerMatMut T_inv, FaerMatRef T, FaerPar par);
+FAER_HIP_API FaerLayout libfaer_v0_23_llt_reconstruct_scratch_f32(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_llt_reconstruct_f32(FaerMatMut A, FaerMatRef L, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_llt_inverse_scratch_f32(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_llt_inverse_f32(FaerMatMut A_inv, FaerMatRef L, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_ldlt_reconstruct_scratch_f32(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_ldlt_reconstruct_f32(FaerMatMut A, FaerMatRef L, FaerVecRef D, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_ldlt_inverse_scratch_f32(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_ldlt_inverse_f32(FaerMatMut A_inv, FaerMatRef L, FaerVecRef D, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_reconstruct_scratch_u32_f32(size_t nrows, size_t ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_reconstruct_u32_f32(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_inverse_scratch_u32_f32(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_inverse_u32_f32(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_reconstruct_scratch_u64_f32(size_t nrows, size_t ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_reconstruct_u64_f32(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_partial_piv_lu_inverse_scratch_u64_f32(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_partial_piv_lu_inverse_u64_f32(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_reconstruct_scratch_f32(size_t nrows, size_t ncols, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_reconstruct_f32(FaerMatMut A, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_qr_inverse_scratch_f32(size_t dim, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_qr_inverse_f32(FaerMatMut A_inv, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_on_the_right_scratch_f32(size_t dim, size_t block_size, size_t rhs_nrows);
+FAER_HIP_API void libfaer_v0_23_apply_householder_on_the_right_f32(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj conj, FaerMatMut matrix, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_transpose_on_the_right_scratch_f32(size_t dim, size_t block_size, size_t rhs_nrows);
+FAER_HIP_API void libfaer_v0_23_apply_householder_transpose_on_the_right_f32(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj conj, FaerMatMut matrix, FaerPar par, FaerMemAlloc mem);
+
+/* ---------------------------------------------------------------------------------------------
  * 3. Runtime control (new: the reference has no device).
  * --------------------------------------------------------------------------------------------- */
 /* Library version / build target string, e.g. "faer_hip 0.1 gfx950". Never NULL. */

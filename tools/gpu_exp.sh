@@ -1,4 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_factor.py tests/test_gpu_dist_two_ranks.py -m gpu -q -x 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_gpu_extras.py -m gpu -q -x 2>&1 | tail -25
