@@ -576,23 +576,56 @@ template <typename T> struct LuWork {
 };
 
 // rows per workgroup of the cooperative kernel for a leaf of w columns (registers: RPT x W scalars per thread)
-template <typename T> static int leaf_rows_per_wg(int w)
+// Leaf shapes: W columns x RPT rows per thread with W * RPT = 64 (fp64) or 128 (fp32) register scalars per thread.
+// Every workgroup of the cooperative kernel must be resident (one 512-thread workgroup per CU at this register
+// footprint), so tall panels trade leaf width for rows per workgroup: 64 columns up to 512 (1024) rows per
+// workgroup, ... 8 columns up to 4096 (8192).
+template <typename T> static int leaf_rpt(int w) { return (sizeof(T) == 8 ? 64 : 128) / w; }
+template <typename T> static int leaf_rows_per_wg(int w) { return LU2_NT * leaf_rpt<T>(w); }
+
+static int resident_workgroups()
 {
-	(void) w;
-	const int rpt = sizeof(T) == 8 ? 1 : 2;
-	return LU2_NT * rpt;
+	Ctx &c = ctx();
+	if (c.la_state > 0 && c.stream == c.la_panel)
+		return c.la_panel_cus;
+	static int ncu = 0;
+	if (ncu == 0) {
+		hipDeviceProp_t prop;
+		FH_HIP(hipGetDeviceProperties(&prop, c.device));
+		ncu = prop.multiProcessorCount;
+	}
+	return ncu;
+}
+
+// widest leaf whose workgroups are all resident for a panel of m rows
+template <typename T> static int leaf_width_for(idx_t m)
+{
+	const int cap = resident_workgroups();
+	for (int w = LU_W; w >= 8; w /= 2)
+		if ((m + leaf_rows_per_wg<T>(w) - 1) / leaf_rows_per_wg<T>(w) <= (idx_t) cap)
+			return w;
+	FH_CHECK(false, "partial_piv_lu: more rows than the cooperative panel kernel can keep resident (1,048,576 fp64 / 2,097,152 fp32 rows on 256 CUs)");
+	return 0;
+}
+
+template <typename T, int W> static void launch_leaf(int G, hipStream_t s, const Panel2Args<T> &a)
+{
+	hipLaunchKernelGGL((getrf_panel2_kernel<T, W, (sizeof(T) == 8 ? 64 : 128) / W>), dim3(G), dim3(LU2_NT), 0, s, a);
 }
 
 template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, LuWork<T> &wk)
 {
 	const idx_t m = P.nrows;
 	const int w = (int) P.ncols;
-	FH_CHECK(w <= LU_W, "getrf leaf: panel too wide");
-	const int R = leaf_rows_per_wg<T>(w);
-	FH_CHECK(m <= (idx_t) R * LU2_GMAX, "partial_piv_lu: more rows than the cooperative panel kernel supports");
+	int lw = leaf_width_for<T>(m);
+	FH_CHECK(w <= lw, "getrf leaf: panel too wide");
+	while (lw / 2 >= w && lw > 8)
+		lw /= 2; // a narrower panel fits the narrower (taller) shape just as well: fewer workgroups to synchronise
+	const int R = leaf_rows_per_wg<T>(lw);
 	int G = (int) ((m + R - 1) / R);
 	if (G < 1)
 		G = 1;
+	FH_CHECK(G <= LU2_GMAX, "partial_piv_lu: too many workgroups in the cooperative panel kernel");
 	Panel2Args<T> a;
 	a.P = P.p;
 	a.rs = P.rs;
@@ -606,7 +639,20 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 	a.epoch_base = wk.epoch_base;
 	a.status = wk.status;
 	hipStream_t s = ctx().stream;
-	hipLaunchKernelGGL((getrf_panel2_kernel<T, LU_W, (sizeof(T) == 8 ? 1 : 2)>), dim3(G), dim3(LU2_NT), 0, s, a);
+	switch (lw) {
+	case 64:
+		launch_leaf<T, 64>(G, s, a);
+		break;
+	case 32:
+		launch_leaf<T, 32>(G, s, a);
+		break;
+	case 16:
+		launch_leaf<T, 16>(G, s, a);
+		break;
+	default:
+		launch_leaf<T, 8>(G, s, a);
+		break;
+	}
 	FH_HIP(hipGetLastError());
 	const int steps = w < (int) m ? w : (int) m;
 	if (G > 1)
@@ -631,7 +677,7 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 	const idx_t m = P.nrows, n = P.ncols; // n <= m
 	if (n == 0)
 		return;
-	if (n <= LU_W) {
+	if (n <= leaf_width_for<T>(m)) {
 		getrf_leaf<T>(P, col0, row_base, wk);
 		return;
 	}

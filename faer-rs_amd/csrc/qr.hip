@@ -1086,7 +1086,11 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 	// rejects EVERY column once 16 * eps * nrows >= 1 (fp32: nrows >= 524288).  That outcome (rank 0) is
 	// reproduced by the general path; the fast path would only discover it one launch later.
 	const bool ref_rejects_all = (double) Lim<T>::eps * 16.0 * (double) m >= 1.0;
-	const bool fast_ok = m <= (idx_t) QR2_NT * qr2_rpt<T>() * QR_GMAX && !ref_rejects_all;
+	// the cooperative leaf needs all its workgroups resident: one 512-thread workgroup per CU at its register footprint
+	hipDeviceProp_t prop;
+	FH_HIP(hipGetDeviceProperties(&prop, ctx().device));
+	const idx_t gcap = prop.multiProcessorCount < QR_GMAX ? prop.multiProcessorCount : QR_GMAX;
+	const bool fast_ok = m <= (idx_t) QR2_NT * qr2_rpt<T>() * gcap && !ref_rejects_all;
 	Scratch backup(fast_ok ? (size_t) m * (size_t) n * sizeof(T) : 256);
 	MatV<T> Bk{backup.as<T>(), m, n, 1, m};
 	if (fast_ok) {

@@ -286,6 +286,24 @@ def test_lookahead_paths_fp32():
     assert err <= 8 * n * eps * (Lm.abs() @ U.abs()).max().item()
 
 
+@pytest.mark.parametrize("m,n,dtype", [(200000, 64, np.float64), (600000, 16, np.float64), (300000, 40, np.float32), (1100000, 8, np.float32),
+                                       (5000, 8, np.float64), (70000, 24, np.float64)])
+def test_plu_tall_panels_pick_a_resident_leaf_shape(oracle, m, n, dtype):
+    """tall panels: every workgroup of the cooperative leaf has to be resident, so the driver trades leaf width for
+    rows per workgroup (64 x 512 ... 8 x 4096 rows; getrf.hip leaf_width_for).  Same pivots as the oracle."""
+    F = init_gpu()
+    rng = np.random.default_rng(m + n)
+    a = rnd(rng, m, n, dtype)
+    dlu = to_dev(a)
+    perm, perm_inv, nt = F.partial_piv_lu_factor_in_place(dlu)
+    lu = to_host(dlu)
+    ref = a.copy(order="F")
+    rperm, _, rnt = oracle.lu_in_place(ref)
+    assert np.array_equal(perm.astype(np.int64), rperm) and nt == rnt
+    e = EPS[np.dtype(dtype)]
+    assert np.abs(lu - ref).max() <= 64 * n * e * max(1.0, np.abs(ref).max())
+
+
 # -------------------------------------------------------------------------------------------- distributed lu
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,n,nb", [(512, 512, 64), (1000, 1000, 128), (700, 500, 96), (300, 420, 64)])
