@@ -352,6 +352,42 @@ def partial_piv_lu_factor_in_place(a, index_dtype=np.uint64, par=PAR_SEQ):
     return fwd, bwd, st.transposition_count
 
 
+class FullPivLuParams(C.Structure):
+    _fields_ = [("par_threshold", C.c_size_t)]
+
+
+def full_piv_lu_factor_in_place(a, index_dtype=np.uint64, par=PAR_SEQ):
+    """lu/full_pivoting/factor.rs:452-525.  returns (row_fwd, row_bwd, col_fwd, col_bwd, transposition_count):
+    A[row_fwd][:, col_fwd] == L U with L unit lower trapezoidal and U upper trapezoidal packed in `a`"""
+    suf, _, _ = _dtype_suffix(a)
+    m, n = a.shape
+    it = "u64" if np.dtype(index_dtype) == np.uint64 else "u32"
+    rf, rb = np.zeros(m, dtype=index_dtype), np.zeros(m, dtype=index_dtype)
+    cf, cb = np.zeros(n, dtype=index_dtype), np.zeros(n, dtype=index_dtype)
+    L = lib()
+    pf = getattr(L, f"libfaer_v0_23_FullPivLuParams_{suf}")
+    pf.restype = FullPivLuParams
+    fn = getattr(L, f"libfaer_v0_23_full_piv_lu_factor_in_place_{it}_{suf}")
+    fn.restype = PartialPivLuStatus  # same layout: {tag, transposition_count}
+    st = fn(_mat(a, MatMut), SliceMut(rf.ctypes.data, m), SliceMut(rb.ctypes.data, m), SliceMut(cf.ctypes.data, n), SliceMut(cb.ctypes.data, n),
+            par, MemAlloc(None, 0), pf())
+    if st.tag != 0:
+        raise RuntimeError("FullPivLuStatus::Unknown")
+    return rf, rb, cf, cb, st.transposition_count
+
+
+def full_piv_lu_solve_in_place(lu, row_fwd, row_bwd, col_fwd, col_bwd, rhs, transpose=False, par=PAR_SEQ):
+    """lu/full_pivoting/solve.rs: rhs <- A^-1 rhs (or A^-T rhs)"""
+    suf, _, _ = _dtype_suffix(lu)
+    it = "u64" if np.dtype(row_fwd.dtype) == np.uint64 else "u32"
+    name = "full_piv_lu_solve_transpose_in_place" if transpose else "full_piv_lu_solve_in_place"
+    n = lu.shape[0]
+    getattr(lib(), f"libfaer_v0_23_{name}_{it}_{suf}")(
+        _mat(lu), _mat(lu), C.c_int(0), SliceRef(row_fwd.ctypes.data, n), SliceRef(row_bwd.ctypes.data, n), SliceRef(col_fwd.ctypes.data, n),
+        SliceRef(col_bwd.ctypes.data, n), _mat(rhs, MatMut), par, MemAlloc(None, 0))
+    return rhs
+
+
 BcastFn = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 
 

@@ -442,6 +442,61 @@ template <typename T> void apply_hh_right_api(FaerMatRef V, FaerMatRef H, FaerMa
 	apply_householder_sequence_left_dev<T>(v.dev, h.dev, x.dev.t(), !transpose);
 }
 
+// lu/full_pivoting/factor.rs:452-525
+template <typename T, typename I>
+FaerFullPivLuStatus full_lu_api(FaerMatMut A, FaerSliceMut rpf, FaerSliceMut rpb, FaerSliceMut cpf, FaerSliceMut cpb)
+{
+	const idx_t m = (idx_t) A.nrows, n = (idx_t) A.ncols;
+	FH_CHECK((idx_t) rpf.len == m && (idx_t) rpb.len == m && (idx_t) cpf.len == n && (idx_t) cpb.len == n,
+		 "full_piv_lu: perm slices must have nrows / ncols entries");
+	FH_CHECK(!is_device_ptr(rpf.ptr) && !is_device_ptr(rpb.ptr) && !is_device_ptr(cpf.ptr) && !is_device_ptr(cpb.ptr),
+		 "full_piv_lu: perm slices must be host memory");
+	std::vector<idx_t> rp((size_t) m), rpi((size_t) m), cp((size_t) n), cpi((size_t) n);
+	long nt;
+	{
+		Staged<T> a(view<T>(A), true, true);
+		nt = full_piv_lu_dev<T>(a.dev, rp.data(), rpi.data(), cp.data(), cpi.data());
+	}
+	for (idx_t i = 0; i < m; ++i) {
+		static_cast<I *>(rpf.ptr)[i] = (I) rp[(size_t) i];
+		static_cast<I *>(rpb.ptr)[i] = (I) rpi[(size_t) i];
+	}
+	for (idx_t j = 0; j < n; ++j) {
+		static_cast<I *>(cpf.ptr)[j] = (I) cp[(size_t) j];
+		static_cast<I *>(cpb.ptr)[j] = (I) cpi[(size_t) j];
+	}
+	FaerFullPivLuStatus st;
+	memset(&st, 0, sizeof(st));
+	st.tag = FaerFullPivLuStatus_Ok;
+	st.ok.transposition_count = (size_t) nt;
+	return st;
+}
+
+// lu/full_pivoting/solve.rs: A x = b (:22-60) and A^T x = b (:75-110)
+template <typename T, typename I>
+void full_lu_solve_api(FaerMatRef L, FaerMatRef U, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerMatMut rhs,
+		       bool transpose)
+{
+	const size_t n = L.nrows;
+	FH_CHECK(L.ncols == n && U.nrows == n && U.ncols == n && rhs.nrows == n && rpf.len >= n && rpb.len >= n && cpf.len >= n && cpb.len >= n,
+		 "full_piv_lu solve: dimension mismatch");
+	FH_CHECK(!is_device_ptr(rpf.ptr) && !is_device_ptr(rpb.ptr) && !is_device_ptr(cpf.ptr) && !is_device_ptr(cpb.ptr),
+		 "full_piv_lu solve: perm slices must be host memory");
+	Staged<const T> l(view<T>(L), true, false), u(view<T>(U), true, false);
+	Staged<T> x(view<T>(rhs), true, true);
+	if (!transpose) {
+		permute_rows_dev_api<T, I>(x.dev, static_cast<const I *>(rpf.ptr));
+		trsm_lower_dev<T>(l.dev, true, x.dev);
+		trsm_upper_dev<T>(u.dev, false, x.dev);
+		permute_rows_dev_api<T, I>(x.dev, static_cast<const I *>(cpb.ptr)); // col_perm.inverse()
+	} else {
+		permute_rows_dev_api<T, I>(x.dev, static_cast<const I *>(cpf.ptr));
+		trsm_lower_dev<T>(u.dev.t(), false, x.dev);
+		trsm_upper_dev<T>(l.dev.t(), true, x.dev);
+		permute_rows_dev_api<T, I>(x.dev, static_cast<const I *>(rpb.ptr)); // row_perm.inverse()
+	}
+}
+
 } // namespace
 
 extern "C" {
@@ -648,6 +703,58 @@ void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m, size_t n, s
 		(void) params;                                                                                         \
 		return lu_api<T, uint64_t>(A, pf, pb);                                                                 \
 	}                                                                                                              \
+	FaerFullPivLuParams libfaer_v0_23_FullPivLuParams_##suf(void) \
+	{ \
+		return FaerFullPivLuParams{256 * 512}; \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_factor_in_place_scratch_u32_##suf(size_t dim, size_t bs, FaerPar par, FaerFullPivLuParams params) \
+	{ \
+		(void) bs; (void) par; (void) params; return layout(dim * 2 * sizeof(size_t), sizeof(size_t)); \
+	} \
+	FaerFullPivLuStatus libfaer_v0_23_full_piv_lu_factor_in_place_u32_##suf(FaerMatMut A, FaerSliceMut rpf, FaerSliceMut rpb, FaerSliceMut cpf, FaerSliceMut cpb, FaerPar par, FaerMemAlloc mem, FaerFullPivLuParams params) \
+	{ \
+		(void) par; (void) mem; (void) params; return full_lu_api<T, uint32_t>(A, rpf, rpb, cpf, cpb); \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_solve_in_place_scratch_u32_##suf(size_t dim, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_full_piv_lu_solve_in_place_u32_##suf(FaerMatRef L, FaerMatRef U, FaerConj cj, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; full_lu_solve_api<T, uint32_t>(L, U, rpf, rpb, cpf, cpb, rhs, false); \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_solve_transpose_in_place_scratch_u32_##suf(size_t dim, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_full_piv_lu_solve_transpose_in_place_u32_##suf(FaerMatRef L, FaerMatRef U, FaerConj cj, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; full_lu_solve_api<T, uint32_t>(L, U, rpf, rpb, cpf, cpb, rhs, true); \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_factor_in_place_scratch_u64_##suf(size_t dim, size_t bs, FaerPar par, FaerFullPivLuParams params) \
+	{ \
+		(void) bs; (void) par; (void) params; return layout(dim * 2 * sizeof(size_t), sizeof(size_t)); \
+	} \
+	FaerFullPivLuStatus libfaer_v0_23_full_piv_lu_factor_in_place_u64_##suf(FaerMatMut A, FaerSliceMut rpf, FaerSliceMut rpb, FaerSliceMut cpf, FaerSliceMut cpb, FaerPar par, FaerMemAlloc mem, FaerFullPivLuParams params) \
+	{ \
+		(void) par; (void) mem; (void) params; return full_lu_api<T, uint64_t>(A, rpf, rpb, cpf, cpb); \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_solve_in_place_scratch_u64_##suf(size_t dim, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_full_piv_lu_solve_in_place_u64_##suf(FaerMatRef L, FaerMatRef U, FaerConj cj, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; full_lu_solve_api<T, uint64_t>(L, U, rpf, rpb, cpf, cpb, rhs, false); \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_solve_transpose_in_place_scratch_u64_##suf(size_t dim, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_full_piv_lu_solve_transpose_in_place_u64_##suf(FaerMatRef L, FaerMatRef U, FaerConj cj, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; full_lu_solve_api<T, uint64_t>(L, U, rpf, rpb, cpf, cpb, rhs, true); \
+	} \
 	void libfaer_v0_23_inverse_triangular_lower_in_place_##suf(FaerMatMut T_inv, FaerMatRef Tm, FaerPar par) \
 	{ \
 		(void) par; tri_inverse_api<T>(T_inv, Tm, false, false); \

@@ -102,6 +102,14 @@ typedef struct FaerLdltStatus {
 	};
 } FaerLdltStatus;
 typedef struct FaerPartialPivLuParams { size_t recursion_threshold; size_t block_size; size_t par_threshold; } FaerPartialPivLuParams;
+typedef struct FaerFullPivLuParams { size_t par_threshold; } FaerFullPivLuParams;
+typedef enum FaerFullPivLuStatus_Tag { FaerFullPivLuStatus_Ok = 0, FaerFullPivLuStatus_Unknown = 1 } FaerFullPivLuStatus_Tag;
+typedef struct FaerFullPivLuStatus {
+	FaerFullPivLuStatus_Tag tag;
+	union {
+		struct { size_t transposition_count; } ok;
+	};
+} FaerFullPivLuStatus;
 typedef struct FaerQrParams { size_t blocking_threshold; size_t par_threshold; } FaerQrParams;
 /* faer-ffi/src/lib.rs:796-801; pointers to a real scalar of the matrix dtype (HOST memory), NULL == 0 */
 typedef struct FaerLltRegularization { const void *dynamic_regularization_delta; const void *dynamic_regularization_epsilon; } FaerLltRegularization;
@@ -318,6 +326,38 @@ FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_on_the_right_scratch_f32
 FAER_HIP_API void libfaer_v0_23_apply_householder_on_the_right_f32(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj conj, FaerMatMut matrix, FaerPar par, FaerMemAlloc mem);
 FAER_HIP_API FaerLayout libfaer_v0_23_apply_householder_transpose_on_the_right_scratch_f32(size_t dim, size_t block_size, size_t rhs_nrows);
 FAER_HIP_API void libfaer_v0_23_apply_householder_transpose_on_the_right_f32(FaerMatRef householder_basis, FaerMatRef householder_factor, FaerConj conj, FaerMatMut matrix, FaerPar par, FaerMemAlloc mem);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2c. LU with full pivoting (faer-ffi/src/lib.rs:2125-2260; lu/full_pivoting/factor.rs, solve.rs): a level-2,
+ *     HBM-bound algorithm -- every step is one fused "rank-1 update + search of the next pivot" pass (csrc/fplu.hip).
+ *     Permutation slices are HOST memory (nrows / ncols entries).
+ * --------------------------------------------------------------------------------------------- */
+FAER_HIP_API FaerFullPivLuParams libfaer_v0_23_FullPivLuParams_f64(void);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_factor_in_place_scratch_u32_f64(size_t dim, size_t block_size, FaerPar par, FaerFullPivLuParams params);
+FAER_HIP_API FaerFullPivLuStatus libfaer_v0_23_full_piv_lu_factor_in_place_u32_f64(FaerMatMut A, FaerSliceMut row_perm_fwd, FaerSliceMut row_perm_bwd, FaerSliceMut col_perm_fwd, FaerSliceMut col_perm_bwd, FaerPar par, FaerMemAlloc mem, FaerFullPivLuParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_in_place_scratch_u32_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_in_place_u32_f64(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_transpose_in_place_scratch_u32_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_transpose_in_place_u32_f64(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_factor_in_place_scratch_u64_f64(size_t dim, size_t block_size, FaerPar par, FaerFullPivLuParams params);
+FAER_HIP_API FaerFullPivLuStatus libfaer_v0_23_full_piv_lu_factor_in_place_u64_f64(FaerMatMut A, FaerSliceMut row_perm_fwd, FaerSliceMut row_perm_bwd, FaerSliceMut col_perm_fwd, FaerSliceMut col_perm_bwd, FaerPar par, FaerMemAlloc mem, FaerFullPivLuParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_in_place_scratch_u64_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_in_place_u64_f64(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_transpose_in_place_scratch_u64_f64(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_transpose_in_place_u64_f64(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerFullPivLuParams libfaer_v0_23_FullPivLuParams_f32(void);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_factor_in_place_scratch_u32_f32(size_t dim, size_t block_size, FaerPar par, FaerFullPivLuParams params);
+FAER_HIP_API FaerFullPivLuStatus libfaer_v0_23_full_piv_lu_factor_in_place_u32_f32(FaerMatMut A, FaerSliceMut row_perm_fwd, FaerSliceMut row_perm_bwd, FaerSliceMut col_perm_fwd, FaerSliceMut col_perm_bwd, FaerPar par, FaerMemAlloc mem, FaerFullPivLuParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_in_place_scratch_u32_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_in_place_u32_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_transpose_in_place_scratch_u32_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_transpose_in_place_u32_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_factor_in_place_scratch_u64_f32(size_t dim, size_t block_size, FaerPar par, FaerFullPivLuParams params);
+FAER_HIP_API FaerFullPivLuStatus libfaer_v0_23_full_piv_lu_factor_in_place_u64_f32(FaerMatMut A, FaerSliceMut row_perm_fwd, FaerSliceMut row_perm_bwd, FaerSliceMut col_perm_fwd, FaerSliceMut col_perm_bwd, FaerPar par, FaerMemAlloc mem, FaerFullPivLuParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_in_place_scratch_u64_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_in_place_u64_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_transpose_in_place_scratch_u64_f32(size_t dim, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_transpose_in_place_u64_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
 
 /* ---------------------------------------------------------------------------------------------
  * 3. Runtime control (new: the reference has no device).

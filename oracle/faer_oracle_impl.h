@@ -498,6 +498,123 @@ long FN(oracle_lu_in_place)(T *a, long m, long n, long rs, long cs, long *perm, 
  * next_power_of_two((n + 1) / 2) above LINEAR_IMPL_THRESHOLD = 128, reductions/mod.rs:1), :173-184 (selection).
  * The pairwise tree is what keeps a 1e7-long column within 1e-14 (test_norm_l2, norm_l2.rs:216-218); the
  * lane order inside a <= 128 element leaf is the SIMD width's and is not pinned by the reference. */
+/* ------------------------------------------------------------------------------------------------
+ * LU with full pivoting -- faer/src/linalg/lu/full_pivoting/factor.rs
+ *   :255-273  best_in_matrix_fallback: column-major scan, strict '>' on |a| => first maximum in (col, row) order
+ *   :316-430  lu_in_place_unblocked: per step swap row / col to the pivot, scale the pivot column by the reciprocal
+ *             (the pivot ROW when the driver works on the transposed view), rank-1 update fused with the search of
+ *             the next pivot; a best score below the smallest positive normal ends the elimination (identity
+ *             transpositions from there on)
+ *   :452-525  lu_in_place: works on the view whose row stride is the smaller one, builds the permutations from
+ *             the transpositions
+ * ------------------------------------------------------------------------------------------------ */
+static void FN(fplu_best)(FN(mat) M, long *row, long *col, T *score)
+{
+	T max = 0;
+	*row = 0;
+	*col = 0;
+	for (long j = 0; j < M.ncols; j++)
+		for (long i = 0; i < M.nrows; i++) {
+			T v = AT(M, i, j);
+			v = v < 0 ? -v : v;
+			if (v > max) {
+				*row = i;
+				*col = j;
+				max = v;
+			}
+		}
+	*score = max;
+}
+
+static long FN(fplu_unblocked)(FN(mat) A, long *row_trans, long *col_trans, int transpose)
+{
+	long m = A.nrows, n = A.ncols, n_trans = 0;
+	if (m == 0 || n == 0)
+		return 0;
+	long size = m < n ? m : n;
+	long max_row, max_col;
+	T max_score;
+	FN(fplu_best)(A, &max_row, &max_col, &max_score);
+	for (long k = 0; k < size; k++) {
+		if (max_score < TMIN) {
+			for (long i = k; i < size; i++) {
+				row_trans[i] = i;
+				col_trans[i] = i;
+			}
+			break;
+		}
+		row_trans[k] = max_row;
+		col_trans[k] = max_col;
+		if (max_row != k) {
+			for (long j = 0; j < n; j++) {
+				T t = AT(A, k, j);
+				AT(A, k, j) = AT(A, max_row, j);
+				AT(A, max_row, j) = t;
+			}
+			n_trans++;
+		}
+		if (max_col != k) {
+			for (long i = 0; i < m; i++) {
+				T t = AT(A, i, k);
+				AT(A, i, k) = AT(A, i, max_col);
+				AT(A, i, max_col) = t;
+			}
+			n_trans++;
+		}
+		T inv = (T)1 / AT(A, k, k);
+		if (transpose)
+			for (long j = k + 1; j < n; j++)
+				AT(A, k, j) *= inv;
+		else
+			for (long i = k + 1; i < m; i++)
+				AT(A, i, k) *= inv;
+		if (k + 1 == size)
+			break;
+		/* A11 -= A10[:, k] A01[k, :], then the next pivot */
+		for (long j = k + 1; j < n; j++) {
+			T r = AT(A, k, j);
+			for (long i = k + 1; i < m; i++)
+				AT(A, i, j) = FMA(-AT(A, i, k), r, AT(A, i, j));
+		}
+		FN(fplu_best)(FN(sub)(A, k + 1, k + 1, m - k - 1, n - k - 1), &max_row, &max_col, &max_score);
+		max_row += k + 1;
+		max_col += k + 1;
+	}
+	return n_trans;
+}
+
+long FN(oracle_full_piv_lu_in_place)(T *a, long m, long n, long rs, long cs, long *row_perm, long *row_perm_inv, long *col_perm,
+				     long *col_perm_inv)
+{
+	FN(mat) A = {a, m, n, rs, cs};
+	long size = m < n ? m : n;
+	long *rt = (long *)calloc((size_t)(size > 0 ? size : 1), sizeof(long));
+	long *ct = (long *)calloc((size_t)(size > 0 ? size : 1), sizeof(long));
+	long ars = rs < 0 ? -rs : rs, acs = cs < 0 ? -cs : cs;
+	long nt = ars < acs ? FN(fplu_unblocked)(A, rt, ct, 0) : FN(fplu_unblocked)(FN(tr)(A), ct, rt, 1);
+	for (long i = 0; i < m; i++)
+		row_perm[i] = i;
+	for (long i = 0; i < size; i++) {
+		long t = row_perm[i];
+		row_perm[i] = row_perm[rt[i]];
+		row_perm[rt[i]] = t;
+	}
+	for (long i = 0; i < m; i++)
+		row_perm_inv[row_perm[i]] = i;
+	for (long j = 0; j < n; j++)
+		col_perm[j] = j;
+	for (long i = 0; i < size; i++) {
+		long t = col_perm[i];
+		col_perm[i] = col_perm[ct[i]];
+		col_perm[ct[i]] = t;
+	}
+	for (long j = 0; j < n; j++)
+		col_perm_inv[col_perm[j]] = j;
+	free(rt);
+	free(ct);
+	return nt;
+}
+
 static void FN(norm_l2_x3_rec)(const T *x, long n, long stride, T sml, T big, T acc[3])
 {
 	if (n <= 128) {

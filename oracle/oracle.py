@@ -47,7 +47,7 @@ def lib():
         for suf, ct in (("f64", C.c_double), ("f32", C.c_float)):
             getattr(_LIB, f"oracle_norm_l2_{suf}").restype = ct
             for name in ("oracle_llt_in_place", "oracle_ldlt_in_place", "oracle_lu_in_place", "oracle_qr_in_place",
-                         "oracle_qr_recommended_block_size"):
+                         "oracle_qr_recommended_block_size", "oracle_full_piv_lu_in_place"):
                 getattr(_LIB, f"{name}_{suf}").restype = C.c_long
     return _LIB
 
@@ -132,6 +132,17 @@ def lu_in_place(a, recursion_threshold=16):
     nt = getattr(lib(), f"oracle_lu_in_place_{suf}")(_p(a), C.c_long(m), C.c_long(n), *_st(a), _p(perm),
                                                     _p(perm_inv), C.c_long(recursion_threshold))
     return perm, perm_inv, nt
+
+
+def full_piv_lu_in_place(a):
+    """lu/full_pivoting/factor.rs:452-525.  returns (row_perm, row_perm_inv, col_perm, col_perm_inv, transposition_count);
+    on exit A[row_perm][:, col_perm] == L U with L unit lower trapezoidal, U upper trapezoidal packed in `a`"""
+    suf, _ = _suf(a)
+    m, n = a.shape
+    rp, rpi = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
+    cp, cpi = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    nt = getattr(lib(), f"oracle_full_piv_lu_in_place_{suf}")(_p(a), C.c_long(m), C.c_long(n), *_st(a), _p(rp), _p(rpi), _p(cp), _p(cpi))
+    return rp, rpi, cp, cpi, nt
 
 
 def qr_recommended_block_size(m, n, dtype=np.float64):

@@ -304,6 +304,65 @@ def test_plu_tall_panels_pick_a_resident_leaf_shape(oracle, m, n, dtype):
     assert np.abs(lu - ref).max() <= 64 * n * e * max(1.0, np.abs(ref).max())
 
 
+# -------------------------------------------------------------------------------------------- lu with full pivoting
+@pytest.mark.parametrize("m,n,layout", [(1, 1, "F"), (2, 3, "F"), (5, 5, "F"), (40, 30, "F"), (30, 40, "F"), (64, 64, "C"), (33, 50, "C"),
+                                        (300, 300, "F"), (1030, 700, "F"), (700, 1100, "C"), (2100, 9, "F")])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_full_piv_lu_vs_oracle(oracle, m, n, layout, dtype):
+    """csrc/fplu.hip through the C-ABI: IDENTICAL permutations (the pivot search is index work: first maximum in
+    (column, row) order of the view the reference works on), factors within tolerance, solve and transpose solve"""
+    F = init_gpu()
+    rng = np.random.default_rng(m * 31 + n)
+    a = np.array(rng.standard_normal((m, n)), dtype=dtype, order=layout)
+    ref = a.copy(order=layout)
+    rp, rpi, cp, cpi, nt = oracle.full_piv_lu_in_place(ref)
+    da = to_dev(a, layout)
+    rf, rb, cf, cb, cnt = F.full_piv_lu_factor_in_place(da)
+    assert np.array_equal(rf.astype(np.int64), rp) and np.array_equal(rb.astype(np.int64), rpi)
+    assert np.array_equal(cf.astype(np.int64), cp) and np.array_equal(cb.astype(np.int64), cpi) and cnt == nt
+    got = to_host(da)
+    e = EPS[np.dtype(dtype)]
+    assert np.abs(got - ref).max() <= 64 * max(m, n) * e * max(1.0, np.abs(ref).max())
+    if m == n and m > 1:
+        b = rnd(rng, n, 3, dtype)
+        a64 = a.astype(np.float64)
+        tol = 256 * n * e * np.linalg.cond(a64)
+        x = to_dev(b)
+        F.full_piv_lu_solve_in_place(da, rf, rb, cf, cb, x)
+        assert np.abs(a64 @ to_host(x) - b).max() <= tol * np.abs(b).max()
+        x = to_dev(b)
+        F.full_piv_lu_solve_in_place(da, rf, rb, cf, cb, x, transpose=True)
+        assert np.abs(a64.T @ to_host(x) - b).max() <= tol * np.abs(b).max()
+
+
+def test_full_piv_lu_singular_trailing_block_and_size_property():
+    """exactly singular trailing block: the elimination stops like the reference's (identity transpositions from
+    there on); N = 2048: P A Q x == L (U x) and |l_ij| <= 1, independent of the oracle"""
+    import torch
+
+    F = init_gpu()
+    a = np.zeros((6, 5), order="F")
+    a[:2, :2] = [[4.0, 1.0], [2.0, 3.0]]
+    da = to_dev(a)
+    rf, _, cf, _, _ = F.full_piv_lu_factor_in_place(da)
+    lu = to_host(da)
+    L = np.tril(lu[:, :5], -1) + np.eye(6, 5)
+    assert np.abs(L @ np.triu(lu[:5, :]) - a[rf.astype(int)][:, cf.astype(int)]).max() == 0.0
+    n = 2048
+    g = torch.Generator(device="cuda").manual_seed(9)
+    A = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g).t()
+    W = A.clone()
+    rf, _, cf, _, _ = F.full_piv_lu_factor_in_place(W)
+    F.synchronize()
+    x = torch.randn((n, 2), dtype=torch.float64, device="cuda", generator=g)
+    Lm = torch.tril(W, -1) + torch.eye(n, dtype=torch.float64, device="cuda")
+    p = torch.as_tensor(rf.astype(np.int64), device="cuda")
+    q = torch.as_tensor(cf.astype(np.int64), device="cuda")
+    r = (Lm @ (torch.triu(W) @ x) - A[p][:, q] @ x).abs().max().item()
+    assert r <= 64 * n * 2.3e-16 * (A.abs() @ x.abs()).max().item()
+    assert torch.tril(W, -1).abs().max().item() <= 1.0 + 1e-12
+
+
 # -------------------------------------------------------------------------------------------- distributed lu
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,n,nb", [(512, 512, 64), (1000, 1000, 128), (700, 500, 96), (300, 420, 64)])

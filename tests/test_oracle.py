@@ -379,3 +379,41 @@ def test_ldlt_zero_pivot_and_regularization(oracle):
     w = a.copy(order="F")
     assert oracle.ldlt_in_place(w, 1e-3, 1e-8, signs=[1, 1, 1]) == ("ok", 2)
     assert w[1, 1] == 1e-3 and w[2, 2] == 1e-3
+
+
+# ------------------------------------------------------------------------------------ LU with full pivoting
+@pytest.mark.parametrize("m,n,order", [(1, 1, "F"), (2, 3, "F"), (5, 5, "F"), (40, 30, "F"), (30, 40, "F"), (64, 64, "C"), (33, 50, "C"),
+                                       (100, 100, "F")])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_full_piv_lu_oracle_properties(oracle, m, n, order, dtype):
+    """lu/full_pivoting/factor.rs tests (:527-640): P A Q == L U within eps * n; plus what complete pivoting
+    guarantees by construction: |l_ij| <= 1 and |u_kk| >= every entry of the trailing block at step k"""
+    rng = np.random.default_rng(m * 31 + n)
+    a = np.array(rng.standard_normal((m, n)), dtype=dtype, order=order)
+    lu = a.copy(order=order)
+    rp, rpi, cp, cpi, nt = oracle.full_piv_lu_in_place(lu)
+    size = min(m, n)
+    assert (rpi[rp] == np.arange(m)).all() and (cpi[cp] == np.arange(n)).all()
+    L = (np.tril(lu[:, :size], -1) + np.eye(m, size)).astype(np.float64)
+    U = np.triu(lu[:size, :]).astype(np.float64)
+    e = np.finfo(dtype).eps
+    assert np.abs(L @ U - a[rp][:, cp]).max() <= 16 * max(m, n) * e * np.abs(a).max()
+    assert np.abs(np.tril(lu[:, :size], -1)).max(initial=0) <= 1.0 + 4 * e
+    d = np.abs(np.diag(U))
+    for k in range(size):
+        assert d[k] + 1e-300 >= np.abs(U[k, k:]).max() * (1 - 4 * e)
+    # transposition count == number of non-trivial row / column swaps that rebuild the permutations
+    assert 0 <= nt <= 2 * size
+
+
+def test_full_piv_lu_oracle_stops_on_an_exactly_singular_trailing_block(oracle):
+    """factor.rs:324-332: a best score below the smallest positive normal ends the elimination with identity
+    transpositions; the factors of the leading part are still exact"""
+    a = np.zeros((6, 5), order="F")
+    a[:2, :2] = [[4.0, 1.0], [2.0, 3.0]]
+    lu = a.copy(order="F")
+    rp, _, cp, _, nt = oracle.full_piv_lu_in_place(lu)
+    L = np.tril(lu[:, :5], -1) + np.eye(6, 5)
+    U = np.triu(lu[:5, :])
+    assert np.abs(L @ U - a[rp][:, cp]).max() == 0.0
+    assert (np.diag(U)[2:] == 0).all()
