@@ -78,24 +78,31 @@ __global__ __launch_bounds__(256) void fplu_update_kernel(T *V, idx_t rs, idx_t 
 		l[r] = (do_update && i < m) ? V[(idx_t) i * rs + (idx_t) k * cs] : (T) 0;
 	}
 	FpBest best{0.0, 0, 0};
+	// all FP_COLS x 4 elements of the thread are loaded before the first store: stores to V would otherwise pin every
+	// later load behind them (same base pointer) and the pass would run one memory round trip per column
+	T u[FP_COLS], v[FP_COLS][4];
+#pragma unroll
+	for (int jj = 0; jj < FP_COLS; ++jj) {
+		const int j = min(jb + jj, n - 1);
+		u[jj] = do_update ? V[(idx_t) k * rs + (idx_t) j * cs] : (T) 0;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int i = min(ib + tid + 256 * r, m - 1); // clamped: unconditional loads
+			v[jj][r] = V[(idx_t) i * rs + (idx_t) j * cs];
+		}
+	}
+#pragma unroll
 	for (int jj = 0; jj < FP_COLS; ++jj) {
 		const int j = jb + jj;
 		if (j >= n)
 			break; // uniform
-		const T u = do_update ? V[(idx_t) k * rs + (idx_t) j * cs] : (T) 0;
-		T v[4];
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			const int i = min(ib + tid + 256 * r, m - 1); // clamped: unconditional loads
-			v[r] = V[(idx_t) i * rs + (idx_t) j * cs];
-		}
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			const int i = ib + tid + 256 * r;
 			if (i < m) {
-				T x = v[r];
+				T x = v[jj][r];
 				if (do_update) {
-					x = __builtin_fma(-l[r], u, x);
+					x = __builtin_fma(-l[r], u[jj], x);
 					V[(idx_t) i * rs + (idx_t) j * cs] = x;
 				}
 				const FpBest c{fabs((double) x), i, j};
