@@ -19,8 +19,12 @@
 //   * blockIdx is remapped XCD-aware (each XCD's private L2 gets a contiguous run of tiles) and then
 //     rastered in groups of 8 tile rows; DstKind::Lower enumerates only the tiles that touch the lower
 //     triangle;
-//   * tall-skinny products (K >> M,N: the Householder T = V^H V products of QR) use split-K with fp64/fp32
-//     hardware atomics.
+//   * deep-K products with few output tiles use split-K: the slices write raw partial sums to a workspace which a
+//     second small kernel adds in a fixed order (deterministic; hardware atomics would make every run differ in
+//     the last bits);
+//   * the accumulate epilogue loads the old values of a 16-column group together before it stores them (one
+//     memory round trip per group instead of one per element, see gemm_kernel_p);
+//   * level-2 and tall-skinny shapes never reach this file's kernels: gemv.hip / skinny.hip stream them.
 #include <type_traits>
 
 #include "common.h"

@@ -8,21 +8,22 @@
 // large GEMMs.  The pivot rule is the reference's (factor.rs:35-43): first row of strictly largest
 // |a_ij|, an all-zero column keeps the diagonal.
 //
-// Leaf (<= 32 columns, any height): ONE cooperative launch, "wavefront-level pivot reduction":
-//   * the m x w panel is split in row chunks, one workgroup per chunk, each chunk RESIDENT IN LDS for
-//     the whole leaf (read from HBM once, written once);
-//   * per column: DPP/shuffle arg-max inside each wave, LDS across the 4 waves, then ONE all-to-all
-//     exchange per column through L2: every workgroup publishes its candidate {|a|, row, the candidate's
-//     whole panel row} and workgroup 0 publishes the diagonal row; after a single all-to-all flag round every
-//     workgroup picks the winner itself, patches the two swapped rows from the published copies and
-//     performs scale + rank-1 update on its own rows.  No second synchronisation per column;
-//   * the exchange follows the gfx950 recipe for in-launch hand-offs (xwg.h; cdna_hip_programming.md
-//     Guideline 16 R2): data-tagged 8-byte granules written with write-through (sc1) stores and read back with
-//     sc1 loads -- no flags, no fences, no store drain; two memory round trips per column.  Every spin is
-//     bounded; a timeout raises a device error instead of hanging.
-// Row interchanges of the outside columns are NOT applied one transposition at a time: the transposition
-// list is composed into a net row permutation in parallel (each row traces its source backwards through
-// the list) and applied as one gather.
+// Leaf (<= 64 columns): ONE cooperative launch, "wavefront-level pivot reduction" (getrf_panel2_kernel below):
+//   * the m x w panel is split in row chunks, one 512-thread workgroup per chunk, every thread keeping whole panel
+//     rows in REGISTERS for the whole leaf (read from HBM once, written once); the leaf shape (64 x 1 ... 8 x 8
+//     columns x rows per thread) is chosen so that all workgroups are resident;
+//   * per column: DPP arg-max inside each wave, LDS across the 8 waves, then ONE all-to-all exchange per column:
+//     every workgroup publishes its candidate {|a|, row, the candidate's whole panel row} and workgroup 0 the
+//     diagonal row; every workgroup picks the winner itself, patches the two swapped rows from the published
+//     copies and performs scale + rank-1 update on its own rows;
+//   * the exchange follows the gfx950 recipe for in-launch hand-offs (xwg.h; cdna_hip_programming.md Guideline 16
+//     R2): data-tagged 8-byte granules written with write-through (sc1) stores and read back with sc1 loads -- no
+//     flags, no fences, no store drain; two memory round trips per column.  Every spin is bounded; a timeout
+//     raises a device error instead of hanging.
+// Row interchanges of the outside columns are NOT applied one transposition at a time: the transposition list is
+// composed into a net row permutation in parallel (each row traces its source backwards through the list) and
+// applied as one gather.  Large matrices run the recursion with look-ahead on two CU-masked streams
+// (getrf_lookahead).
 #include <climits>
 
 #include "common.h"
@@ -32,27 +33,10 @@ namespace fh {
 
 constexpr int LU_W = 64; // leaf width of the recursion
 
-struct Cand {
-	double v; // |a| (kept in double for both dtypes)
-	int r;	  // global row, INT_MAX == none
-};
 static __device__ __forceinline__ bool better(double av, int ar, double bv, int br)
 {
 	return av > bv || (av == bv && ar < br);
 }
-static __device__ __forceinline__ void wave_argmax(double &v, int &r)
-{
-#pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) {
-		const double ov = __shfl_xor(v, off, 64);
-		const int orow = __shfl_xor(r, off, 64);
-		if (better(ov, orow, v, r)) {
-			v = ov;
-			r = orow;
-		}
-	}
-}
-
 // ------------------------------------------------------------------------------------------------
 // Register-resident cooperative panel kernel.  Phase timing of its LDS-resident predecessor
 // (profiles/r01_lu_panel_phase_timing.txt) showed that only ~1.6 us of ~6.4 us per column was the

@@ -4,9 +4,9 @@
 // cholesky/ldlt/factor.rs:7-498.
 //
 // The reference is right-looking with 128-column steps (factor.rs:392).  A rank-128 fp64 update is only
-// ~16 flop/byte -- at the MI355X machine balance -- so the GPU driver recurses by HALVES instead:
-//     A00 = L00 L00^T (recurse) ; A10 <- A10 L00^-T (TRSM) ; A11 -= A10 A10^T (MFMA SYRK, K = n/2) ; recurse A11
-// which performs the same arithmetic per entry but moves O(n^2 log n) bytes instead of O(n^3 / 128).
+// ~16 flop/byte -- at the MI355X machine balance -- so the GPU drivers use larger steps with the same arithmetic per
+// entry: recursion by HALVES below 2048 columns (potrf_rec), 1024-column steps above (potrf_lookahead: left-looking
+// panels in 128-column blocks, trailing updates with K = 1024, look-ahead on two CU-masked streams for large n).
 //
 // Leaf (n <= 128): ONE 512-thread workgroup, the block resident in LDS (lds_blocks.h), blocked right-looking
 // in four 32-column steps:

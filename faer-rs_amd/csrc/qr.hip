@@ -148,233 +148,11 @@ template <int CNT> static __device__ __forceinline__ void block_sum(double (&val
 	__syncthreads();
 }
 
-template <typename T, int RMAX> __global__ __launch_bounds__(256) void qr_panel_kernel(const QrPanelArgs<T> a)
-{
-	__shared__ T Ps[QR_PW * RMAX]; // Ps[c * RMAX + r]
-	__shared__ double s_part[4 * QR_SLOT], s_red[QR_SLOT], s_S[QR_SLOT];
-	__shared__ double s_tau[QR_PW], s_head[QR_PW + 1];
-	__shared__ int s_flag;
-
-	const int tid = threadIdx.x;
-	const int g = blockIdx.x, G = gridDim.x;
-	const int r0 = g * a.R;
-	const int nr = min(a.R, a.m - r0);
-	const int w = a.w;
-	if (a.status[3] != 0)
-		return; // an earlier panel found a rank deficiency: the whole factorization is being abandoned
-
-	for (int c = 0; c < w; ++c)
-		for (int r = tid; r < nr; r += 256)
-			Ps[c * RMAX + r] = a.P[(idx_t) (r0 + r) * a.rs + (idx_t) c * a.cs];
-	__syncthreads();
-
-	const int steps = min(w, a.m);
-	int bar = 0;
-	bool timeout = false, deficient = false;
-	for (int j = 0; j < steps; ++j) {
-		const int q = bar & 1;
-		// ---- partial sums s_c = sum_{r > j} x_r a_rc, c = j .. w-1 (c == j gives |tail|^2)
-		double acc[QR_PW];
-#pragma unroll
-		for (int c = 0; c < QR_PW; ++c)
-			acc[c] = 0.0;
-		for (int r = tid; r < nr; r += 256) {
-			if (r0 + r > j) {
-				const double x = (double) Ps[j * RMAX + r];
-#pragma unroll
-				for (int c = 0; c < QR_PW; ++c)
-					if (c >= j && c < w)
-						acc[c] += x * (double) Ps[c * RMAX + r];
-			}
-		}
-		block_sum<QR_PW>(acc, s_part, s_red);
-		// after this block: s_S[c] = full sums, s_head[c] = row j of the panel, s_head[QR_PW] = |above|^2
-		{
-			// squared norm of column j above its diagonal: rows outside the panel + rows 0..j-1 of chunk 0
-			double ab[1] = {0.0};
-			if (g == 0) {
-				for (int i = tid; i < a.row_abs; i += 256) {
-					const double v = (double) a.above[(idx_t) i * a.rs + (idx_t) j * a.cs];
-					ab[0] += v * v;
-				}
-				for (int i = tid; i < j; i += 256) {
-					const double v = (double) Ps[j * RMAX + i];
-					ab[0] += v * v;
-				}
-			}
-			if (G > 1) {
-				// all-to-all round (xwg.h): partial sums (+ from chunk 0: row j and |above|^2) as write-through
-				// stores of wave 0, one flag per workgroup, sc1 loads on the way back
-				if (g == 0)
-					block_sum<1>(ab, s_part, s_S);
-				if (tid < QR_PW)
-					xwg_store(a.slots + ((size_t) q * G + g) * QR_SLOT + tid, s_red[tid]);
-				if (g == 0) {
-					if (tid < QR_PW)
-						xwg_store(a.head + q * (QR_PW + 1) + tid, tid < w ? (double) Ps[tid * RMAX + j] : 0.0);
-					if (tid == 0)
-						xwg_store(a.head + q * (QR_PW + 1) + QR_PW, s_S[0]);
-				}
-				if (tid < 64)
-					xwg_publish(a.flags, g, a.epoch_base + (xwg_u64) (bar + 1), tid == 0);
-				if (!xwg_wait_all(a.flags, G, a.epoch_base + (xwg_u64) (bar + 1), &s_flag)) {
-					timeout = true;
-					break;
-				}
-				++bar;
-				double tot[QR_PW];
-#pragma unroll
-				for (int c = 0; c < QR_PW; ++c)
-					tot[c] = 0.0;
-				for (int t = tid; t < G; t += 256)
-#pragma unroll
-					for (int c = 0; c < QR_PW; ++c)
-						tot[c] += xwg_load(a.slots + ((size_t) q * G + t) * QR_SLOT + c);
-				block_sum<QR_PW>(tot, s_part, s_S);
-				if (tid <= QR_PW)
-					s_head[tid] = xwg_load(a.head + q * (QR_PW + 1) + tid);
-			} else {
-				if (tid < QR_PW) {
-					s_S[tid] = s_red[tid];
-					s_head[tid] = tid < w ? (double) Ps[tid * RMAX + j] : 0.0;
-				}
-				block_sum<1>(ab, s_part, s_red);
-				if (tid == 0)
-					s_head[QR_PW] = s_red[0];
-			}
-			__syncthreads();
-		}
-		// ---- reflector (householder.rs:59-107), evaluated identically by every thread
-		T head = (T) s_head[j];
-		const double above2 = s_head[QR_PW];
-		const T tail_norm = (T) sqrt(s_S[j]);
-		T head_norm = fabs(head);
-		if (head_norm < Lim<T>::minpos) {
-			head = (T) 0;
-			head_norm = (T) 0;
-		}
-		if (tail_norm < Lim<T>::minpos) {
-			// householder.rs:70-77 + factor.rs:59-63: tau = inf, nothing is scaled or updated; the column
-			// is accepted iff its head is non zero (e.g. the last column of a square matrix)
-			if (!(head_norm > (T) 0)) {
-				deficient = true;
-				break;
-			}
-			if (tid == 0)
-				s_tau[j] = (double) std::numeric_limits<T>::infinity();
-			__syncthreads();
-			continue;
-		}
-		const T norm = (T) hypot((double) head_norm, (double) tail_norm);
-		const T sign = head_norm != (T) 0 ? head * ((T) 1 / head_norm) : (T) 1;
-		const T signed_norm = sign * norm;
-		const T hinv = (T) 1 / (head + signed_norm);
-		const T tn = tail_norm * fabs(hinv);
-		const T tau = (T) 0.5 * ((T) 1 + tn * tn);
-		// rank test (factor.rs:52-82)
-		const T full_norm = (T) hypot((double) norm, sqrt(above2));
-		const T threshold = Lim<T>::eps * (T) ((double) (a.m - j) * 16.0) * full_norm;
-		const T tau_inv = (T) 1 / tau;
-		if (tau_inv < Lim<T>::minpos || !(norm > threshold)) {
-			deficient = true;
-			break;
-		}
-		if (tid == 0)
-			s_tau[j] = (double) tau;
-		// ---- update: v = x * hinv ; k_c = -(a_jc + v^H a_c) / tau ; a_c += k_c v   (factor.rs:65-80)
-		T kc[QR_PW];
-#pragma unroll
-		for (int c = 0; c < QR_PW; ++c)
-			kc[c] = (c > j && c < w) ? -(((T) s_head[c] + hinv * (T) s_S[c]) * tau_inv) : (T) 0;
-		for (int r = tid; r < nr; r += 256) {
-			if (r0 + r > j) {
-				const T v = Ps[j * RMAX + r] * hinv;
-				Ps[j * RMAX + r] = v;
-#pragma unroll
-				for (int c = 0; c < QR_PW; ++c)
-					if (c > j && c < w)
-						Ps[c * RMAX + r] += kc[c] * v;
-			}
-		}
-		if (g == 0 && tid < w) { // row j itself (chunk 0 owns it)
-			if (tid == j)
-				Ps[j * RMAX + j] = -signed_norm;
-			else if (tid > j)
-				Ps[tid * RMAX + j] += -(((T) s_head[tid] + hinv * (T) s_S[tid]) * tau_inv);
-		}
-		__syncthreads();
-	}
-	if (timeout || deficient) {
-		if (tid == 0)
-			atomicExch(a.status + (timeout ? 2 : 3), 1);
-		return;
-	}
-	// ---- T block: T_ij = v_i[j] + sum_{r > j} v_ri v_rj  (i < j) ; T_jj = tau_j
-	{
-		const int q = bar & 1;
-		double acc2[QR_NPAIR];
-#pragma unroll
-		for (int p = 0; p < QR_NPAIR; ++p)
-			acc2[p] = 0.0;
-		for (int r = tid; r < nr; r += 256) {
-			const int gr = r0 + r;
-			double v[QR_PW];
-#pragma unroll
-			for (int c = 0; c < QR_PW; ++c)
-				v[c] = c < w ? (double) Ps[c * RMAX + r] : 0.0;
-			int p = 0;
-#pragma unroll
-			for (int jj = 1; jj < QR_PW; ++jj)
-#pragma unroll
-				for (int i = 0; i < jj; ++i, ++p)
-					if (gr > jj)
-						acc2[p] += v[i] * v[jj];
-		}
-		block_sum<QR_NPAIR>(acc2, s_part, s_red);
-		if (G > 1) {
-			if (tid < QR_NPAIR)
-				xwg_store(a.slots + ((size_t) q * G + g) * QR_SLOT + tid, s_red[tid]);
-			if (tid < 64)
-				xwg_publish(a.flags, g, a.epoch_base + (xwg_u64) (bar + 1), tid == 0);
-			if (!xwg_wait_all(a.flags, G, a.epoch_base + (xwg_u64) (bar + 1), &s_flag)) {
-				if (tid == 0)
-					atomicExch(a.status + 2, 1);
-				return;
-			}
-			double tot[QR_NPAIR];
-#pragma unroll
-			for (int p = 0; p < QR_NPAIR; ++p)
-				tot[p] = 0.0;
-			if (g == 0) {
-				for (int t = tid; t < G; t += 256)
-#pragma unroll
-					for (int p = 0; p < QR_NPAIR; ++p)
-						tot[p] += xwg_load(a.slots + ((size_t) q * G + t) * QR_SLOT + p);
-				block_sum<QR_NPAIR>(tot, s_part, s_red);
-			}
-		}
-		if (g == 0 && tid == 0) {
-			int p = 0;
-			for (int jj = 0; jj < w; ++jj)
-				a.Tb[(idx_t) jj * a.trs + (idx_t) jj * a.tcs] = (T) s_tau[jj];
-			for (int jj = 1; jj < QR_PW; ++jj)
-				for (int i = 0; i < jj; ++i, ++p)
-					if (jj < w)
-						a.Tb[(idx_t) i * a.trs + (idx_t) jj * a.tcs] =
-							(T) ((double) Ps[i * RMAX + jj] + s_red[p]);
-		}
-	}
-	for (int c = 0; c < w; ++c)
-		for (int r = tid; r < nr; r += 256)
-			a.P[(idx_t) (r0 + r) * a.rs + (idx_t) c * a.cs] = Ps[c * RMAX + r];
-}
-
 // ------------------------------------------------------------------------------------------------
-// Register-resident version of the panel kernel (the one the driver uses): same mathematics and the same
-// exchange as qr_panel_kernel above, but every thread keeps QR2_RPT whole panel rows (8 columns each) in
-// registers and the 8 column steps are unrolled at compile time, so the dot products x^H a_c, the scaling and
-// the rank-1 update are register FMAs instead of round trips through LDS (the LDS loops were ~3/4 of the old
-// kernel's time, exactly as in the LU panel: profiles/r01_lu_panel_phase_timing.txt).
+// Register-resident panel kernel: every thread keeps QR2_RPT whole panel rows (8 columns each) in registers and
+// the 8 column steps are unrolled at compile time, so the dot products x^H a_c, the scaling and the rank-1 update
+// are register FMAs (in the first, LDS-resident version of this kernel the LDS loops were ~3/4 of its time,
+// exactly as in the LU panel: profiles/r01_lu_panel_phase_timing.txt).
 // ------------------------------------------------------------------------------------------------
 constexpr int QR2_NT = 512;
 template <typename T> static constexpr int qr2_rpt() { return sizeof(T) == 8 ? 4 : 8; }
