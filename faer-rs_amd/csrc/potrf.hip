@@ -380,12 +380,30 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 	// Look-ahead pays from ~10k rows upwards (measured, N = 8192: 13.3 ms sequential against 13.8 ms); below that and
 	// for the last `tail_rows` rows of a large matrix the steps run back to back on the caller's stream.
 	const idx_t tail_rows = getenv("FAER_HIP_LLT_TAIL") ? atol(getenv("FAER_HIP_LLT_TAIL")) : (n < 10 * LA_NB ? n : 4 * LA_NB);
-	idx_t ks = 0; // look-ahead steps
-	while (n - ks * LA_NB > tail_rows && (ks + 1) * LA_NB < n)
-		++ks;
+	// Step widths of the look-ahead part: the FIRST step is LA_NB wide (its diagonal block is factored with the rest
+	// of the chip idle), the following ones LA_NB2 (wider steps: K = LA_NB2 trailing updates run closer to the dense
+	// rate and there are fewer launch boundaries per factorization) while at least 2 * LA_NB2 rows remain.
+	const idx_t nb2 = getenv("FAER_HIP_LLT_NB2") ? atol(getenv("FAER_HIP_LLT_NB2")) : LA_NB;
+	FH_CHECK(nb2 >= LA_NB && nb2 % POTRF_NB == 0 && nb2 <= 4096, "potrf: FAER_HIP_LLT_NB2 must be a multiple of 128 in [1024, 4096]");
+	std::vector<idx_t> J; // look-ahead steps: panel columns [J[k], J[k + 1])
+	J.push_back(0);
+	while (true) {
+		const idx_t j0 = J.back();
+		idx_t w = J.size() == 1 ? LA_NB : nb2;
+		if (n - j0 - w < 2 * w)
+			w = LA_NB; // narrow steps again towards the end
+		if (!(n - j0 > tail_rows && j0 + w < n))
+			break;
+		J.push_back(j0 + w);
+	}
+	idx_t ks = (idx_t) J.size() - 1; // look-ahead steps
 	if (ks > 0 && !c.lookahead_streams())
 		ks = 0;
+	const idx_t tail0 = ks > 0 ? J[(size_t) ks] : 0;
 	if (ks > 0) {
+		idx_t wmax = LA_NB;
+		for (idx_t k = 0; k < ks; ++k)
+			wmax = J[(size_t) k + 1] - J[(size_t) k] > wmax ? J[(size_t) k + 1] - J[(size_t) k] : wmax;
 		c.reset_events();
 		hipEvent_t e0 = c.next_event();
 		FH_HIP(hipEventRecord(e0, caller));
@@ -394,16 +412,16 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		// workspaces: two full step-block inverses (double buffered over the steps), a temporary for building them,
 		// and two buffers for the out-of-place result X_k of the panel solve (the updates of step k read X_k, its
 		// copy into A happens off the critical path while step k+1 already fills the other buffer)
-		Scratch wfb((size_t) 2 * LA_NB * LA_NB * sizeof(T)), tmb((size_t) LA_NB * LA_NB * sizeof(T));
-		const size_t xsz = (size_t) (n - LA_NB) * LA_NB;
+		Scratch wfb((size_t) 2 * wmax * wmax * sizeof(T)), tmb((size_t) wmax * wmax * sizeof(T));
+		const size_t xsz = (size_t) (n - LA_NB) * wmax;
 		Scratch xb(2 * xsz * sizeof(T));
-		auto Wfull = [&](idx_t k) { return MatV<T>{wfb.as<T>() + (size_t) (k & 1) * LA_NB * LA_NB, LA_NB, LA_NB, 1, LA_NB}; };
-		MatV<T> Tmp{tmb.as<T>(), LA_NB, LA_NB, 1, LA_NB};
+		auto Wfull = [&](idx_t k, idx_t w) { return MatV<T>{wfb.as<T>() + (size_t) (k & 1) * wmax * wmax, w, w, 1, w}; };
 		hipEvent_t ev_diag; // D_k factored (and inverted)
 		{
 			StreamScope sc(c.la_panel);
-			potrf_panel_flat<T>(A.sub(0, 0, LA_NB, LA_NB), regularize, eps, delta, status, 0, Wbase);
-			tri_inv_full<T>(A.sub(0, 0, LA_NB, LA_NB).c(), Wbase, Wfull(0), Tmp);
+			const idx_t w0 = J[1];
+			potrf_panel_flat<T>(A.sub(0, 0, w0, w0), regularize, eps, delta, status, 0, Wbase);
+			tri_inv_full<T>(A.sub(0, 0, w0, w0).c(), Wbase, Wfull(0, w0), MatV<T>{tmb.as<T>(), w0, w0, 1, w0});
 			ev_diag = c.next_event();
 			FH_HIP(hipEventRecord(ev_diag, c.la_panel));
 		}
@@ -411,12 +429,13 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		// spare while the trailing matrix is large, and the bulk stream then issues two launches per step)
 		const idx_t dpanel_rmin = getenv("FAER_HIP_LLT_DPANEL") ? atol(getenv("FAER_HIP_LLT_DPANEL")) : 8192;
 		for (idx_t k = 0; k < ks; ++k) {
-			const idx_t j0 = k * LA_NB, j1 = j0 + LA_NB; // panel columns [j0, j1)
-			const idx_t r = n - j1;			   // rows below (> LA_NB for every look-ahead step but possibly the last)
-			const bool last = k + 1 == ks;		   // the tail driver takes over after this step
-			MatV<T> Pk = A.sub(j1, j0, r, LA_NB);
-			MatV<T> X{xb.as<T>() + (size_t) (k & 1) * xsz, r, LA_NB, 1, r};
-			MatV<const T> X0 = X.sub(0, 0, LA_NB < r ? LA_NB : r, LA_NB).c();
+			const idx_t j0 = J[(size_t) k], j1 = J[(size_t) k + 1], w = j1 - j0; // panel columns [j0, j1)
+			const idx_t r = n - j1;						       // rows below
+			const bool last = k + 1 == ks;					       // the tail driver takes over after this step
+			const idx_t w1 = last ? 0 : J[(size_t) k + 2] - j1;		       // width of the next look-ahead panel
+			MatV<T> Pk = A.sub(j1, j0, r, w);
+			MatV<T> X{xb.as<T>() + (size_t) (k & 1) * xsz, r, w, 1, r};
+			MatV<const T> X0 = X.sub(0, 0, w1, w).c();
 			const bool d_on_panel = !last && dpanel_rmin > 0 && r >= dpanel_rmin;
 			hipEvent_t ev_upd;
 			{
@@ -427,11 +446,11 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 				// own diagonal block (3/4 of the flops of the full product on average)
 				GemmExtra<T> ex;
 				ex.k_trim = 1;
-				gemm_dev<T>(X, DST_FULL, false, Pk.c(), Wfull(k).c().t(), (T) 1, &ex);
+				gemm_dev<T>(X, DST_FULL, false, Pk.c(), Wfull(k, w).c().t(), (T) 1, &ex);
 				if (last) {
 					gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X.c(), X.t().c(), (T) -1);
 				} else if (!d_on_panel) { // next diagonal block first
-					gemm_dev<T>(A.sub(j1, j1, LA_NB, LA_NB), DST_LOWER, true, X0, X0.t(), (T) -1);
+					gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
 				}
 				ev_upd = c.next_event();
 				FH_HIP(hipEventRecord(ev_upd, c.la_bulk));
@@ -441,9 +460,9 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 			if (!last) {
 				StreamScope sc(c.la_bulk);
 				// block column k+1 below its diagonal block + the remaining lower square in ONE launch: the lower
-				// triangle of the whole trailing matrix minus its leading LA_NB rows
+				// triangle of the whole trailing matrix minus its leading w1 rows
 				GemmExtra<T> ex;
-				ex.tri_skip = LA_NB;
+				ex.tri_skip = w1;
 				gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X.c(), X.t().c(), (T) -1, &ex);
 			}
 			{
@@ -451,11 +470,11 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 				stream_wait(c.la_panel, ev_upd);
 				if (!last) {
 					if (d_on_panel)
-						gemm_dev<T>(A.sub(j1, j1, LA_NB, LA_NB), DST_LOWER, true, X0, X0.t(), (T) -1);
-					potrf_panel_flat<T>(A.sub(j1, j1, LA_NB, LA_NB), regularize, eps, delta, status, j1, Wbase);
-					if (k + 2 <= ks) // the next step is a look-ahead step as well: it solves against the full inverse
-						tri_inv_full<T>(A.sub(j1, j1, LA_NB, LA_NB).c(), Wbase + (size_t) (j1 / POTRF_NB) * POTRF_NB * POTRF_NB,
-								Wfull(k + 1), Tmp);
+						gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
+					potrf_panel_flat<T>(A.sub(j1, j1, w1, w1), regularize, eps, delta, status, j1, Wbase);
+					// the next step is a look-ahead step as well: it solves against the full inverse
+					tri_inv_full<T>(A.sub(j1, j1, w1, w1).c(), Wbase + (size_t) (j1 / POTRF_NB) * POTRF_NB * POTRF_NB, Wfull(k + 1, w1),
+							MatV<T>{tmb.as<T>(), w1, w1, 1, w1});
 					ev_diag = c.next_event();
 					FH_HIP(hipEventRecord(ev_diag, c.la_panel));
 				}
@@ -472,7 +491,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		stream_wait(caller, ep);
 	}
 	// ---- tail (everything, if the matrix is small): sequential, whole chip
-	for (idx_t j0 = ks * LA_NB; j0 < n; j0 += LA_NB) {
+	for (idx_t j0 = tail0; j0 < n; j0 += LA_NB) {
 		const idx_t w = LA_NB < n - j0 ? LA_NB : n - j0, R = n - j0;
 		potrf_panel_flat<T>(A.sub(j0, j0, R, w), regularize, eps, delta, status, j0, Wbase);
 		if (R > w) {

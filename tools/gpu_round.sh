@@ -6,6 +6,8 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -3 gpurun_out/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 300 python tools/gpu_fuzz.py 300 7 2>&1 | tail -1
 timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"
 cat gpurun_out/${tag}_bench.json
 for wl in gemm llt lu qr; do
