@@ -388,6 +388,41 @@ def full_piv_lu_solve_in_place(lu, row_fwd, row_bwd, col_fwd, col_bwd, rhs, tran
     return rhs
 
 
+class ColPivQrParams(C.Structure):
+    _fields_ = [("blocking_threshold", C.c_size_t), ("par_threshold", C.c_size_t)]
+
+
+def colpiv_qr_factor_in_place(a, q_coeff, index_dtype=np.uint64, par=PAR_SEQ):
+    """qr/col_pivoting/factor.rs:356-395.  returns (col_fwd, col_bwd, transposition_count): A[:, col_fwd] == Q R with the
+    Householder basis below the diagonal of `a`, R on and above it, block factors in q_coeff (block_size x min(m, n))"""
+    suf, _, _ = _dtype_suffix(a)
+    n = a.shape[1]
+    it = "u64" if np.dtype(index_dtype) == np.uint64 else "u32"
+    cf, cb = np.zeros(n, dtype=index_dtype), np.zeros(n, dtype=index_dtype)
+    L = lib()
+    pf = getattr(L, f"libfaer_v0_23_ColPivQrParams_{suf}")
+    pf.restype = ColPivQrParams
+    fn = getattr(L, f"libfaer_v0_23_colpiv_qr_factor_in_place_{it}_{suf}")
+    fn.restype = PartialPivLuStatus  # same layout: {tag, transposition_count}
+    st = fn(_mat(a, MatMut), _mat(q_coeff, MatMut), SliceMut(cf.ctypes.data, n), SliceMut(cb.ctypes.data, n), par, MemAlloc(None, 0), pf())
+    if st.tag != 0:
+        raise RuntimeError("ColPivQrStatus::Unknown")
+    return cf, cb, st.transposition_count
+
+
+def colpiv_qr_solve_in_place(qr, q_coeff, col_fwd, col_bwd, rhs, mode="lstsq", par=PAR_SEQ):
+    """qr/col_pivoting/solve.rs; mode: 'lstsq' (m >= n, solution in the first n rows), 'solve' (square), 'transpose'"""
+    suf, _, _ = _dtype_suffix(qr)
+    it = "u64" if np.dtype(col_fwd.dtype) == np.uint64 else "u32"
+    name = {"lstsq": "colpiv_qr_solve_lstsq_in_place", "solve": "colpiv_qr_solve_in_place", "transpose": "colpiv_qr_solve_transpose_in_place"}[mode]
+    m, n = qr.shape
+    size = min(m, n)
+    getattr(lib(), f"libfaer_v0_23_{name}_{it}_{suf}")(_mat(qr[:, :size]), _mat(q_coeff), _mat(qr[:size, :]), C.c_int(0),
+                                                     SliceRef(col_fwd.ctypes.data, n), SliceRef(col_bwd.ctypes.data, n), _mat(rhs, MatMut), par,
+                                                     MemAlloc(None, 0))
+    return rhs
+
+
 BcastFn = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 
 

@@ -497,6 +497,52 @@ void full_lu_solve_api(FaerMatRef L, FaerMatRef U, FaerSliceRef rpf, FaerSliceRe
 	}
 }
 
+// qr/col_pivoting/factor.rs:356-395
+template <typename T, typename I> FaerColPivQrStatus colpiv_qr_api(FaerMatMut A, FaerMatMut Q, FaerSliceMut pf, FaerSliceMut pb)
+{
+	const idx_t n = (idx_t) A.ncols;
+	const size_t size = A.nrows < A.ncols ? A.nrows : A.ncols;
+	FH_CHECK(Q.nrows > 0 && Q.ncols == size, "colpiv_qr: Q_coeff must be block_size x min(nrows, ncols)");
+	FH_CHECK((idx_t) pf.len == n && (idx_t) pb.len == n, "colpiv_qr: perm slices must have ncols entries");
+	FH_CHECK(!is_device_ptr(pf.ptr) && !is_device_ptr(pb.ptr), "colpiv_qr: perm slices must be host memory");
+	std::vector<idx_t> cp((size_t) n), cpi((size_t) n);
+	long nt;
+	{
+		Staged<T> a(view<T>(A), true, true);
+		Staged<T> q(view<T>(Q), false, true);
+		nt = colpiv_qr_dev<T>(a.dev, q.dev, cp.data(), cpi.data());
+	}
+	for (idx_t j = 0; j < n; ++j) {
+		static_cast<I *>(pf.ptr)[j] = (I) cp[(size_t) j];
+		static_cast<I *>(pb.ptr)[j] = (I) cpi[(size_t) j];
+	}
+	FaerColPivQrStatus st;
+	memset(&st, 0, sizeof(st));
+	st.tag = FaerColPivQrStatus_Ok;
+	st.ok.transposition_count = (size_t) nt;
+	return st;
+}
+
+// qr/col_pivoting/solve.rs:52-80 (lstsq / square) and :158-184 (transpose)
+template <typename T, typename I>
+void colpiv_qr_solve_api(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, bool transpose, bool square)
+{
+	const size_t m = Qb.nrows, n = Qb.ncols;
+	const size_t size = m < n ? m : n;
+	FH_CHECK(pf.len >= n && pb.len >= n && !is_device_ptr(pf.ptr) && !is_device_ptr(pb.ptr), "colpiv_qr solve: perm slices (host memory, ncols entries)");
+	if (!transpose) {
+		qr_solve_api<T>(Qb, Qc, R, rhs, false, square);
+		Staged<T> x(view<T>(rhs), true, true);
+		permute_rows_dev_api<T, I>(x.dev.sub(0, 0, (idx_t) size, x.dev.ncols), static_cast<const I *>(pb.ptr)); // col_perm.inverse()
+	} else {
+		{
+			Staged<T> x(view<T>(rhs), true, true);
+			permute_rows_dev_api<T, I>(x.dev, static_cast<const I *>(pf.ptr));
+		}
+		qr_solve_api<T>(Qb, Qc, R, rhs, true, true);
+	}
+}
+
 } // namespace
 
 extern "C" {
@@ -754,6 +800,74 @@ void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m, size_t n, s
 	void libfaer_v0_23_full_piv_lu_solve_transpose_in_place_u64_##suf(FaerMatRef L, FaerMatRef U, FaerConj cj, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
 	{ \
 		(void) cj; (void) par; (void) mem; full_lu_solve_api<T, uint64_t>(L, U, rpf, rpb, cpf, cpb, rhs, true); \
+	} \
+	FaerColPivQrParams libfaer_v0_23_ColPivQrParams_##suf(void) \
+	{ \
+		return FaerColPivQrParams{48 * 48, 192 * 256}; \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_factor_in_place_scratch_u32_##suf(size_t nrows, size_t ncols, size_t bs, FaerPar par, FaerColPivQrParams params) \
+	{ \
+		(void) nrows; (void) bs; (void) par; (void) params; return layout(ncols * 2 * sizeof(T), 64); \
+	} \
+	FaerColPivQrStatus libfaer_v0_23_colpiv_qr_factor_in_place_u32_##suf(FaerMatMut A, FaerMatMut Q_coeff, FaerSliceMut pf, FaerSliceMut pb, FaerPar par, FaerMemAlloc mem, FaerColPivQrParams params) \
+	{ \
+		(void) par; (void) mem; (void) params; return colpiv_qr_api<T, uint32_t>(A, Q_coeff, pf, pb); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_solve_in_place_scratch_u32_##suf(size_t dim, size_t bs, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(bs * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_solve_in_place_u32_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj, FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; colpiv_qr_solve_api<T, uint32_t>(Qb, Qc, R, pf, pb, rhs, false, true); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_solve_transpose_in_place_scratch_u32_##suf(size_t dim, size_t bs, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(bs * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_solve_transpose_in_place_u32_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj, FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; colpiv_qr_solve_api<T, uint32_t>(Qb, Qc, R, pf, pb, rhs, true, true); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_scratch_u32_##suf(size_t nrows, size_t ncols, size_t bs, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(bs * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_u32_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj, FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; colpiv_qr_solve_api<T, uint32_t>(Qb, Qc, R, pf, pb, rhs, false, false); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_factor_in_place_scratch_u64_##suf(size_t nrows, size_t ncols, size_t bs, FaerPar par, FaerColPivQrParams params) \
+	{ \
+		(void) nrows; (void) bs; (void) par; (void) params; return layout(ncols * 2 * sizeof(T), 64); \
+	} \
+	FaerColPivQrStatus libfaer_v0_23_colpiv_qr_factor_in_place_u64_##suf(FaerMatMut A, FaerMatMut Q_coeff, FaerSliceMut pf, FaerSliceMut pb, FaerPar par, FaerMemAlloc mem, FaerColPivQrParams params) \
+	{ \
+		(void) par; (void) mem; (void) params; return colpiv_qr_api<T, uint64_t>(A, Q_coeff, pf, pb); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_solve_in_place_scratch_u64_##suf(size_t dim, size_t bs, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(bs * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_solve_in_place_u64_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj, FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; colpiv_qr_solve_api<T, uint64_t>(Qb, Qc, R, pf, pb, rhs, false, true); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_solve_transpose_in_place_scratch_u64_##suf(size_t dim, size_t bs, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(bs * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_solve_transpose_in_place_u64_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj, FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; colpiv_qr_solve_api<T, uint64_t>(Qb, Qc, R, pf, pb, rhs, true, true); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_scratch_u64_##suf(size_t nrows, size_t ncols, size_t bs, size_t k, FaerPar par) \
+	{ \
+		(void) par; return layout(bs * k * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_u64_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj, FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) cj; (void) par; (void) mem; colpiv_qr_solve_api<T, uint64_t>(Qb, Qc, R, pf, pb, rhs, false, false); \
 	} \
 	void libfaer_v0_23_inverse_triangular_lower_in_place_##suf(FaerMatMut T_inv, FaerMatRef Tm, FaerPar par) \
 	{ \

@@ -844,6 +844,408 @@ __global__ void qr_finalize_kernel(T *H, idx_t hrs, idx_t hcs, int bs, int size,
 	}
 }
 
+// T blocks over the first `rank` reflectors from their taus: striu(V^H V) (householder.rs:185-209), diagonal = tau;
+// the columns from `rank` on get the zero / +inf pattern of factor.rs:287-299
+template <typename T> static void qr_t_blocks_from_taus(MatV<T> A, MatV<T> H, idx_t rank, const T *taus)
+{
+	const idx_t m = A.nrows, n = A.ncols, bs = H.nrows;
+	const idx_t size = m < n ? m : n;
+	for (idx_t c0 = 0; c0 < rank; c0 += bs) {
+		const idx_t wb = bs < rank - c0 ? bs : rank - c0;
+		MatV<T> Tb = H.sub(0, c0, wb, wb);
+		MatV<const T> Vtop = A.sub(c0, c0, wb, wb).c();
+		matmul_triangular_dev<T>(Tb, 6, false, Vtop.t(), 6, Vtop, 5, (T) 1);
+		if (m - c0 > wb) {
+			MatV<const T> Vbot = A.sub(c0 + wb, c0, m - c0 - wb, wb).c();
+			GemmExtra<T> ex;
+			ex.dst_strict = true;
+			gemm_dev<T>(Tb, DST_UPPER, true, Vbot.t(), Vbot, (T) 1, &ex);
+		}
+	}
+	hipLaunchKernelGGL(qr_finalize_kernel<T>, dim3((unsigned) ((size + 255) / 256)), dim3(256), 0, ctx().stream, H.p, H.rs, H.cs, (int) bs,
+			   (int) size, (int) rank, taus, 1);
+	FH_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// QR with column pivoting -- faer/src/linalg/qr/col_pivoting/factor.rs:107-395.
+// A level-2, HBM-bound algorithm like the reference's: per step the remaining column of largest (down-dated) norm is
+// swapped in, its reflector is made, and the trailing rank-1 update is DELAYED by one step and fused with the dot
+// products of the next one (update_mat_and_dot_simd, :7-105) unless the best down-dated norm fell below
+// sqrt(eps) x the best norm at the last recomputation (:178-203: apply at once, recompute all norms).
+// Five small launches per step, no host synchronisation inside the loop; one workgroup per column in the passes
+// over the trailing matrix (lanes along the rows), the pivot search over the n norms by one workgroup.
+// ------------------------------------------------------------------------------------------------
+struct CpState {
+	double best_threshold, scale_fwd, scale_bwd;
+	double l, tau_inv;
+	int delayed, best_col, n_trans, pad;
+};
+
+template <typename T> struct CpArgs {
+	T *A;
+	idx_t rs, cs;
+	int m, n, size, k, delayed_ok;
+	T *norm, *dot, *taus;
+	int *perm;
+	CpState *st;
+};
+
+// sum over the workgroup (256 threads) of `cnt` doubles -> s_red (all threads may read it afterwards)
+template <int CNT> static __device__ __forceinline__ void cp_block_sum(double (&v)[CNT], double *s_part, double *s_red)
+{
+	block_sum<CNT>(v, s_part, s_red);
+}
+
+// norm_l2 (reductions/norm_l2.rs) of rows r0.. of column j by one workgroup of 256 threads
+template <typename T> static __device__ T cp_col_norm(const CpArgs<T> &a, int r0, int j, double *s_part, double *s_red)
+{
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	T acc[3] = {0, 0, 0};
+	for (int i = r0 + threadIdx.x; i < a.m; i += 256) {
+		const T x = a.A[(idx_t) i * a.rs + (idx_t) j * a.cs];
+		acc[0] += (x * sml) * (x * sml);
+		acc[1] += x * x;
+		acc[2] += (x * big) * (x * big);
+	}
+	double accd[3] = {(double) acc[0], (double) acc[1], (double) acc[2]};
+	cp_block_sum<3>(accd, s_part, s_red);
+	const T r = norm_from3<T>(s_red);
+	__syncthreads();
+	return r;
+}
+
+template <typename T> __global__ __launch_bounds__(256) void cp_norms_kernel(const CpArgs<T> a)
+{
+	__shared__ double s_part[4 * 3], s_red[3];
+	const int j = blockIdx.x;
+	const T v = cp_col_norm<T>(a, 0, j, s_part, s_red);
+	if (threadIdx.x == 0)
+		a.norm[j] = v;
+}
+
+// first maximum (strict '>') of norm[lo .. n)
+template <typename T> static __device__ void cp_argmax(const T *norm, int lo, int n, T &best, int &col, double *s_v, int *s_c)
+{
+	T bv = (T) 0;
+	int bc = lo;
+	for (int j = lo + threadIdx.x; j < n; j += blockDim.x) {
+		const T v = norm[j];
+		if (v > bv) { // ascending j per thread: the first maximum of the thread's subsequence
+			bv = v;
+			bc = j;
+		}
+	}
+	double v = (double) bv;
+	int cidx = bc;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		const double ov = __shfl_xor(v, off, 64);
+		const int oc = __shfl_xor(cidx, off, 64);
+		if (ov > v || (ov == v && ov > 0.0 && oc < cidx)) {
+			v = ov;
+			cidx = oc;
+		}
+	}
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (lane == 0) {
+		s_v[wave] = v;
+		s_c[wave] = cidx;
+	}
+	__syncthreads();
+	v = s_v[0];
+	cidx = s_c[0];
+	for (int w = 1; w < (int) blockDim.x / 64; ++w)
+		if (s_v[w] > v || (s_v[w] == v && s_v[w] > 0.0 && s_c[w] < cidx)) {
+			v = s_v[w];
+			cidx = s_c[w];
+		}
+	__syncthreads();
+	best = (T) v;
+	col = v > 0.0 ? cidx : lo;
+}
+
+// factor.rs:142-160: scale by the reciprocal of the largest column norm
+template <typename T> __global__ __launch_bounds__(1024) void cp_init_kernel(const CpArgs<T> a)
+{
+	__shared__ double s_v[16];
+	__shared__ int s_c[16];
+	T best;
+	int col;
+	cp_argmax<T>(a.norm, 0, a.n, best, col, s_v, s_c);
+	const T scale_bwd = (T) 1 / best;
+	for (int j = threadIdx.x; j < a.n; j += 1024) {
+		a.norm[j] = a.norm[j] * scale_bwd;
+		a.dot[j] = (T) 0;
+		a.perm[j] = j;
+	}
+	if (threadIdx.x == 0) {
+		a.st->scale_fwd = (double) best;
+		a.st->scale_bwd = (double) scale_bwd;
+		a.st->best_threshold = (double) ((best * scale_bwd) * (T) sqrt((double) Lim<T>::eps));
+		a.st->n_trans = 0;
+	}
+}
+
+// A *= scale (all of it with `upper` == 0, the upper triangle with the diagonal otherwise)
+template <typename T> __global__ void cp_scale_kernel(const CpArgs<T> a, int upper)
+{
+	const T sc = (T) (upper ? a.st->scale_fwd : a.st->scale_bwd);
+	const idx_t total = (idx_t) a.m * a.n;
+	for (idx_t e = (idx_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (idx_t) gridDim.x * blockDim.x) {
+		const idx_t i = e % a.m, j = e / a.m;
+		if (!upper || i <= j)
+			a.A[i * a.rs + j * a.cs] *= sc;
+	}
+}
+
+// factor.rs:163-177: best remaining column by the down-dated norms, decision "delayed update or recompute"
+template <typename T> __global__ __launch_bounds__(1024) void cp_select_kernel(const CpArgs<T> a)
+{
+	__shared__ double s_v[16];
+	__shared__ int s_c[16];
+	T best;
+	int col;
+	cp_argmax<T>(a.norm, a.k, a.n, best, col, s_v, s_c);
+	if (threadIdx.x == 0) {
+		a.st->delayed = (a.delayed_ok && a.k > 0 && (double) best >= a.st->best_threshold) ? 1 : 0;
+		a.st->best_col = col;
+	}
+}
+
+// factor.rs:178-203 (k > 0 and not delayed): A11 += A10[:, k-1] dot[k:], fresh norms; one workgroup per column
+template <typename T> __global__ __launch_bounds__(256) void cp_flush_kernel(const CpArgs<T> a)
+{
+	__shared__ double s_part[4 * 3], s_red[3];
+	if (a.st->delayed)
+		return;
+	const int j = a.k + blockIdx.x;
+	const T d = a.dot[j];
+	for (int i = a.k + threadIdx.x; i < a.m; i += 256) {
+		T *p = a.A + (idx_t) i * a.rs + (idx_t) j * a.cs;
+		*p = __builtin_fma(a.A[(idx_t) i * a.rs + (idx_t) (a.k - 1) * a.cs], d, *p);
+	}
+	__syncthreads();
+	const T v = cp_col_norm<T>(a, a.k, j, s_part, s_red);
+	if (threadIdx.x == 0)
+		a.norm[j] = v;
+}
+
+template <typename T> __global__ __launch_bounds__(1024) void cp_select2_kernel(const CpArgs<T> a)
+{
+	__shared__ double s_v[16];
+	__shared__ int s_c[16];
+	if (a.st->delayed)
+		return;
+	T best;
+	int col;
+	cp_argmax<T>(a.norm, a.k, a.n, best, col, s_v, s_c);
+	if (threadIdx.x == 0) {
+		a.st->best_col = col;
+		a.st->best_threshold = (double) (best * (T) sqrt((double) Lim<T>::eps));
+	}
+}
+
+// factor.rs:204-252: column swap, the pending update of column k, its reflector (householder.rs:59-107)
+template <typename T> __global__ __launch_bounds__(1024) void cp_house_kernel(const CpArgs<T> a)
+{
+	__shared__ double s_part[16 * 3], s_red[3];
+	const int tid = threadIdx.x, k = a.k;
+	const int bc = a.st->best_col, delayed = a.st->delayed;
+	if (bc != k) {
+		for (int i = tid; i < a.m; i += 1024) {
+			T *p = a.A + (idx_t) i * a.rs + (idx_t) k * a.cs, *q = a.A + (idx_t) i * a.rs + (idx_t) bc * a.cs;
+			const T x = *p, y = *q;
+			*p = y;
+			*q = x;
+		}
+		if (tid == 0) {
+			const int tp = a.perm[k];
+			a.perm[k] = a.perm[bc];
+			a.perm[bc] = tp;
+			const T td = a.dot[k], tn = a.norm[k];
+			a.dot[k] = a.dot[bc];
+			a.dot[bc] = td;
+			a.norm[k] = a.norm[bc];
+			a.norm[bc] = tn;
+			a.st->n_trans += 1;
+		}
+	}
+	__syncthreads();
+	const T l = delayed ? a.A[(idx_t) k * a.rs + (idx_t) (k - 1) * a.cs] : (T) 0;
+	const T r = a.dot[k];
+	__syncthreads();
+	// pending update of column k and the scaled sums of its tail in one pass
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	T acc[3] = {0, 0, 0};
+	for (int i = k + 1 + tid; i < a.m; i += 1024) {
+		T *p = a.A + (idx_t) i * a.rs + (idx_t) k * a.cs;
+		T x = *p;
+		if (delayed) {
+			x += r * a.A[(idx_t) i * a.rs + (idx_t) (k - 1) * a.cs];
+			*p = x;
+		}
+		acc[0] += (x * sml) * (x * sml);
+		acc[1] += x * x;
+		acc[2] += (x * big) * (x * big);
+	}
+	double accd[3] = {(double) acc[0], (double) acc[1], (double) acc[2]};
+	{ // 16 waves
+		const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const double sv = wave_sum(accd[c]);
+			if (lane == 0)
+				s_part[wave * 3 + c] = sv;
+		}
+		__syncthreads();
+		if (tid < 3) {
+			double t = 0.0;
+			for (int w = 0; w < 16; ++w)
+				t += s_part[w * 3 + tid];
+			s_red[tid] = t;
+		}
+		__syncthreads();
+	}
+	const T tail_norm = norm_from3<T>(s_red);
+	T *hp = a.A + (idx_t) k * a.rs + (idx_t) k * a.cs;
+	T head = *hp;
+	if (delayed)
+		head += l * r;
+	T head_norm = fabs(head);
+	if (head_norm < Lim<T>::minpos) {
+		head = (T) 0;
+		head_norm = (T) 0;
+	}
+	T tau, hinv = (T) 0;
+	bool scale_tail = false;
+	if (tail_norm < Lim<T>::minpos) {
+		tau = std::numeric_limits<T>::infinity();
+	} else {
+		const T norm = (T) hypot((double) head_norm, (double) tail_norm);
+		const T sign = head_norm != (T) 0 ? head * ((T) 1 / head_norm) : (T) 1;
+		const T signed_norm = sign * norm;
+		hinv = (T) 1 / (head + signed_norm);
+		head = -signed_norm;
+		const T tn = tail_norm * fabs(hinv);
+		tau = (T) 0.5 * ((T) 1 + tn * tn);
+		scale_tail = true;
+	}
+	__syncthreads();
+	if (scale_tail)
+		for (int i = k + 1 + tid; i < a.m; i += 1024)
+			a.A[(idx_t) i * a.rs + (idx_t) k * a.cs] *= hinv;
+	if (tid == 0) {
+		*hp = head;
+		a.taus[k] = tau;
+		a.st->tau_inv = (double) ((T) 1 / tau);
+		a.st->l = (double) l;
+	}
+	if (k + 1 == a.size && delayed) // factor.rs:253-262
+		for (int j = k + 1 + tid; j < a.n; j += 1024)
+			a.A[(idx_t) k * a.rs + (idx_t) j * a.cs] += l * a.dot[j];
+}
+
+// factor.rs:266-301 / update_mat_and_dot_simd (:60-98): one workgroup per trailing column
+template <typename T> __global__ __launch_bounds__(256) void cp_update_kernel(const CpArgs<T> a)
+{
+	__shared__ double s_part[4], s_red[1];
+	const int k = a.k, j = k + 1 + blockIdx.x, tid = threadIdx.x;
+	const int delayed = a.st->delayed;
+	const T b0 = a.dot[j];
+	T acc = (T) 0;
+	for (int i = k + 1 + tid; i < a.m; i += 256) {
+		T *p = a.A + (idx_t) i * a.rs + (idx_t) j * a.cs;
+		T dst = *p;
+		if (delayed) {
+			dst = __builtin_fma(a.A[(idx_t) i * a.rs + (idx_t) (k - 1) * a.cs], b0, dst);
+			*p = dst;
+		}
+		acc = __builtin_fma(a.A[(idx_t) i * a.rs + (idx_t) k * a.cs], dst, acc);
+	}
+	double accd[1] = {(double) acc};
+	cp_block_sum<1>(accd, s_part, s_red);
+	if (tid == 0) {
+		const T tau_inv = (T) a.st->tau_inv, l = (T) a.st->l;
+		T *up = a.A + (idx_t) k * a.rs + (idx_t) j * a.cs;
+		T u;
+		if (delayed) {
+			const T tmp = *up + l * b0;
+			const T d0 = (tmp + (T) s_red[0]) * (-tau_inv);
+			u = tmp + d0;
+			a.dot[j] = d0;
+		} else {
+			const T d = -((*up + (T) s_red[0]) * tau_inv);
+			u = *up + d;
+			a.dot[j] = d;
+		}
+		*up = u;
+		const T nj = a.norm[j];
+		a.norm[j] = sqrt(nj * nj - u * u);
+	}
+}
+
+// A: m x n, H: block_size x min(m, n); col_perm / col_perm_inv: HOST arrays of n entries.  Returns the transposition count.
+template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, idx_t *col_perm_inv)
+{
+	const idx_t m = A.nrows, n = A.ncols;
+	const idx_t size = m < n ? m : n;
+	FH_CHECK(H.nrows > 0 && H.ncols == size, "colpiv_qr: Q_coeff must be block_size x min(nrows, ncols)");
+	FH_CHECK(m < (1L << 30) && n < (1L << 30), "colpiv_qr: matrix too large");
+	for (idx_t j = 0; j < n; ++j)
+		col_perm[j] = col_perm_inv[j] = j;
+	if (size == 0)
+		return 0;
+	hipStream_t s = ctx().stream;
+	Scratch nb((size_t) (2 * n + size) * sizeof(T) + 256), pb((size_t) n * sizeof(int) + 256), stb(sizeof(CpState));
+	CpArgs<T> a;
+	a.A = A.p;
+	a.rs = A.rs;
+	a.cs = A.cs;
+	a.m = (int) m;
+	a.n = (int) n;
+	a.size = (int) size;
+	a.k = 0;
+	a.delayed_ok = A.rs == 1 ? 1 : 0; // the reference's SIMD path needs column-major storage (factor.rs:174-176)
+	a.norm = nb.as<T>();
+	a.dot = a.norm + n;
+	a.taus = a.dot + n;
+	a.perm = pb.as<int>();
+	a.st = stb.as<CpState>();
+	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(CpState), s));
+	hipLaunchKernelGGL(cp_norms_kernel<T>, dim3((unsigned) n), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(cp_init_kernel<T>, dim3(1), dim3(1024), 0, s, a);
+	hipLaunchKernelGGL(cp_scale_kernel<T>, dim3(1024), dim3(256), 0, s, a, 0);
+	for (idx_t k = 0; k < size; ++k) {
+		a.k = (int) k;
+		hipLaunchKernelGGL(cp_select_kernel<T>, dim3(1), dim3(1024), 0, s, a);
+		if (k > 0) {
+			hipLaunchKernelGGL(cp_flush_kernel<T>, dim3((unsigned) (n - k)), dim3(256), 0, s, a);
+			hipLaunchKernelGGL(cp_select2_kernel<T>, dim3(1), dim3(1024), 0, s, a);
+		}
+		hipLaunchKernelGGL(cp_house_kernel<T>, dim3(1), dim3(1024), 0, s, a);
+		if (k + 1 < size)
+			hipLaunchKernelGGL(cp_update_kernel<T>, dim3((unsigned) (n - k - 1)), dim3(256), 0, s, a);
+	}
+	hipLaunchKernelGGL(cp_scale_kernel<T>, dim3(1024), dim3(256), 0, s, a, 1);
+	FH_HIP(hipGetLastError());
+	qr_t_blocks_from_taus<T>(A, H, size, a.taus);
+	std::vector<int> hp((size_t) n);
+	CpState fin;
+	FH_HIP(hipMemcpyAsync(hp.data(), a.perm, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, s));
+	FH_HIP(hipMemcpyAsync(&fin, stb.p, sizeof(fin), hipMemcpyDeviceToHost, s));
+	FH_HIP(hipStreamSynchronize(s));
+	for (idx_t j = 0; j < n; ++j) {
+		FH_CHECK(hp[(size_t) j] >= 0 && hp[(size_t) j] < n, "colpiv_qr: corrupt permutation");
+		col_perm[j] = hp[(size_t) j];
+	}
+	for (idx_t j = 0; j < n; ++j)
+		col_perm_inv[col_perm[j]] = j;
+	return fin.n_trans;
+}
+template long colpiv_qr_dev<double>(MatV<double>, MatV<double>, idx_t *, idx_t *);
+template long colpiv_qr_dev<float>(MatV<float>, MatV<float>, idx_t *, idx_t *);
+
 template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold)
 {
 	(void) blocking_threshold; // the GPU recursion always blocks; leaves are 8 columns wide
@@ -910,22 +1312,7 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 	if (rank < 0) {
 		Scratch taus((size_t) size * sizeof(T));
 		rank = qr_general<T>(A, taus.as<T>());
-		// T blocks over the accepted reflectors: striu(V^H V) (householder.rs:185-209), diagonal = tau
-		for (idx_t c0 = 0; c0 < rank; c0 += bs) {
-			const idx_t wb = bs < rank - c0 ? bs : rank - c0;
-			MatV<T> Tb = H.sub(0, c0, wb, wb);
-			MatV<const T> Vtop = A.sub(c0, c0, wb, wb).c();
-			matmul_triangular_dev<T>(Tb, 6, false, Vtop.t(), 6, Vtop, 5, (T) 1);
-			if (m - c0 > wb) {
-				MatV<const T> Vbot = A.sub(c0 + wb, c0, m - c0 - wb, wb).c();
-				GemmExtra<T> ex;
-				ex.dst_strict = true;
-				gemm_dev<T>(Tb, DST_UPPER, true, Vbot.t(), Vbot, (T) 1, &ex);
-			}
-		}
-		hipLaunchKernelGGL(qr_finalize_kernel<T>, dim3((unsigned) ((size + 255) / 256)), dim3(256), 0, s, H.p, H.rs, H.cs,
-				   (int) bs, (int) size, (int) rank, taus.as<T>(), 1);
-		FH_HIP(hipGetLastError());
+		qr_t_blocks_from_taus<T>(A, H, rank, taus.as<T>());
 		FH_HIP(hipStreamSynchronize(s)); // taus scratch is released on return
 	}
 	return rank;

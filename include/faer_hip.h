@@ -103,6 +103,14 @@ typedef struct FaerLdltStatus {
 } FaerLdltStatus;
 typedef struct FaerPartialPivLuParams { size_t recursion_threshold; size_t block_size; size_t par_threshold; } FaerPartialPivLuParams;
 typedef struct FaerFullPivLuParams { size_t par_threshold; } FaerFullPivLuParams;
+typedef struct FaerColPivQrParams { size_t blocking_threshold; size_t par_threshold; } FaerColPivQrParams;
+typedef enum FaerColPivQrStatus_Tag { FaerColPivQrStatus_Ok = 0, FaerColPivQrStatus_Unknown = 1 } FaerColPivQrStatus_Tag;
+typedef struct FaerColPivQrStatus {
+	FaerColPivQrStatus_Tag tag;
+	union {
+		struct { size_t transposition_count; } ok;
+	};
+} FaerColPivQrStatus;
 typedef enum FaerFullPivLuStatus_Tag { FaerFullPivLuStatus_Ok = 0, FaerFullPivLuStatus_Unknown = 1 } FaerFullPivLuStatus_Tag;
 typedef struct FaerFullPivLuStatus {
 	FaerFullPivLuStatus_Tag tag;
@@ -358,6 +366,46 @@ FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_in_place_scratch_u64_f32
 FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_in_place_u64_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
 FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_solve_transpose_in_place_scratch_u64_f32(size_t dim, size_t rhs_ncols, FaerPar par);
 FAER_HIP_API void libfaer_v0_23_full_piv_lu_solve_transpose_in_place_u64_f32(FaerMatRef L, FaerMatRef U, FaerConj A_conj, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2d. QR with column pivoting (faer-ffi/src/lib.rs:1721-1876; qr/col_pivoting/factor.rs, solve.rs): HBM-bound;
+ *     delayed rank-1 updates fused with the next step's dot products, down-dated column norms with the reference's
+ *     recomputation rule (csrc/qr.hip, colpiv_qr_dev).  Permutation slices are HOST memory (ncols entries).
+ * --------------------------------------------------------------------------------------------- */
+FAER_HIP_API FaerColPivQrParams libfaer_v0_23_ColPivQrParams_f64(void);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_factor_in_place_scratch_u32_f64(size_t nrows, size_t ncols, size_t block_size, FaerPar par, FaerColPivQrParams params);
+FAER_HIP_API FaerColPivQrStatus libfaer_v0_23_colpiv_qr_factor_in_place_u32_f64(FaerMatMut A, FaerMatMut Q_coeff, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerPar par, FaerMemAlloc mem, FaerColPivQrParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_in_place_scratch_u32_f64(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_in_place_u32_f64(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_transpose_in_place_scratch_u32_f64(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_transpose_in_place_u32_f64(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_scratch_u32_f64(size_t nrows, size_t ncols, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_u32_f64(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_factor_in_place_scratch_u64_f64(size_t nrows, size_t ncols, size_t block_size, FaerPar par, FaerColPivQrParams params);
+FAER_HIP_API FaerColPivQrStatus libfaer_v0_23_colpiv_qr_factor_in_place_u64_f64(FaerMatMut A, FaerMatMut Q_coeff, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerPar par, FaerMemAlloc mem, FaerColPivQrParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_in_place_scratch_u64_f64(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_in_place_u64_f64(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_transpose_in_place_scratch_u64_f64(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_transpose_in_place_u64_f64(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_scratch_u64_f64(size_t nrows, size_t ncols, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_u64_f64(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerColPivQrParams libfaer_v0_23_ColPivQrParams_f32(void);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_factor_in_place_scratch_u32_f32(size_t nrows, size_t ncols, size_t block_size, FaerPar par, FaerColPivQrParams params);
+FAER_HIP_API FaerColPivQrStatus libfaer_v0_23_colpiv_qr_factor_in_place_u32_f32(FaerMatMut A, FaerMatMut Q_coeff, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerPar par, FaerMemAlloc mem, FaerColPivQrParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_in_place_scratch_u32_f32(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_in_place_u32_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_transpose_in_place_scratch_u32_f32(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_transpose_in_place_u32_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_scratch_u32_f32(size_t nrows, size_t ncols, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_u32_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_factor_in_place_scratch_u64_f32(size_t nrows, size_t ncols, size_t block_size, FaerPar par, FaerColPivQrParams params);
+FAER_HIP_API FaerColPivQrStatus libfaer_v0_23_colpiv_qr_factor_in_place_u64_f32(FaerMatMut A, FaerMatMut Q_coeff, FaerSliceMut perm_fwd, FaerSliceMut perm_bwd, FaerPar par, FaerMemAlloc mem, FaerColPivQrParams params);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_in_place_scratch_u64_f32(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_in_place_u64_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_transpose_in_place_scratch_u64_f32(size_t dim, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_transpose_in_place_u64_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_scratch_u64_f32(size_t nrows, size_t ncols, size_t block_size, size_t rhs_ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_u64_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
 
 /* ---------------------------------------------------------------------------------------------
  * 3. Runtime control (new: the reference has no device).

@@ -936,6 +936,161 @@ long FN(oracle_qr_in_place)(T *a, long m, long n, long rs, long cs, T *h, long b
 	return rank;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * QR with column pivoting -- faer/src/linalg/qr/col_pivoting/factor.rs
+ *   :107-330  qr_in_place_unblocked: columns scaled by 1 / (largest column norm); per step the remaining column
+ *             of largest (down-dated) norm is swapped in, its reflector is made, and the rank-1 update of the
+ *             trailing matrix is DELAYED by one step: it is applied while the next step computes its dot products
+ *             (update_mat_and_dot_simd, :7-105) -- the path the reference takes for f32 / f64 column-major input --
+ *             unless the best down-dated norm fell below sqrt(eps) times the best norm at the last recomputation:
+ *             then the update is applied at once and all norms are recomputed (:178-203).  Norms are down-dated
+ *             as sqrt(norm^2 - a_kj^2) (:96, :300).  The upper triangle is scaled back at the end (:305-309).
+ *   :356-395  qr_in_place: T blocks of the reflectors (householder::upgrade_householder_factor with prev size 1)
+ * `delayed_ok` == the reference's `T::SIMD_CAPABILITIES.is_simd() && A.row_stride() == 1`.
+ * ------------------------------------------------------------------------------------------------ */
+static long FN(colpiv_qr_unblocked)(FN(mat) A, T *H, long hs, long *col_perm, int delayed_ok)
+{
+	long m = A.nrows, n = A.ncols;
+	long size = m < n ? m : n;
+	long n_trans = 0;
+	for (long j = 0; j < n; j++)
+		col_perm[j] = j;
+	if (size == 0)
+		return 0;
+	T *dot = (T *)calloc((size_t)(n > 0 ? n : 1), sizeof(T));
+	T *norm = (T *)calloc((size_t)(n > 0 ? n : 1), sizeof(T));
+	T best = 0;
+	const T threshold = SQRT(TEPS);
+	for (long j = 0; j < n; j++) {
+		T val = FN(oracle_norm_l2)(&AT(A, 0, j), m, A.rs);
+		norm[j] = val;
+		if (val > best)
+			best = val;
+	}
+	const T scale_fwd = best, scale_bwd = (T)1 / best;
+	for (long j = 0; j < n; j++)
+		for (long i = 0; i < m; i++)
+			AT(A, i, j) *= scale_bwd;
+	for (long j = 0; j < n; j++)
+		norm[j] = norm[j] * scale_bwd;
+	best = best * scale_bwd;
+	T best_threshold = best * threshold;
+	for (long k = 0; k < size; k++) {
+		T new_best = 0;
+		long best_col = k;
+		for (long j = k; j < n; j++)
+			if (norm[j] > new_best) {
+				new_best = norm[j];
+				best_col = j;
+			}
+		const int delayed = delayed_ok && k > 0 && new_best >= best_threshold;
+		if (k > 0 && !delayed) {
+			/* A11 += A10[:, k-1] dot[k:], then fresh norms */
+			for (long j = k; j < n; j++) {
+				T d = dot[j];
+				for (long i = k; i < m; i++)
+					AT(A, i, j) = FMA(AT(A, i, k - 1), d, AT(A, i, j));
+			}
+			best = 0;
+			for (long j = k; j < n; j++) {
+				T val = FN(oracle_norm_l2)(&AT(A, k, j), m - k, A.rs);
+				norm[j] = val;
+				if (val > best) {
+					best = val;
+					best_col = j;
+				}
+			}
+			best_threshold = best * threshold;
+		}
+		if (best_col != k) {
+			n_trans++;
+			long tp = col_perm[best_col];
+			col_perm[best_col] = col_perm[k];
+			col_perm[k] = tp;
+			for (long i = 0; i < m; i++) {
+				T t = AT(A, i, k);
+				AT(A, i, k) = AT(A, i, best_col);
+				AT(A, i, best_col) = t;
+			}
+			T t = dot[k];
+			dot[k] = dot[best_col];
+			dot[best_col] = t;
+			t = norm[k];
+			norm[k] = norm[best_col];
+			norm[best_col] = t;
+		}
+		const T l = delayed ? AT(A, k, k - 1) : (T)0;
+		const T r = dot[k];
+		if (delayed) {
+			AT(A, k, k) += l * r;
+			for (long i = k + 1; i < m; i++)
+				AT(A, i, k) += r * AT(A, i, k - 1);
+		}
+		FN(hinfo) info = FN(make_householder)(&AT(A, k, k), m > k + 1 ? &AT(A, k + 1, k) : &AT(A, k, k), A.rs,
+						      m > k + 1 ? &AT(A, k + 1, k) : &AT(A, k, k), A.rs, m - k - 1);
+		const T tau_inv = (T)1 / info.tau;
+		H[k * hs] = info.tau;
+		if (k + 1 == size) {
+			if (delayed)
+				for (long j = k + 1; j < n; j++)
+					AT(A, k, j) += l * dot[j];
+			break;
+		}
+		for (long j = k + 1; j < n; j++) {
+			if (delayed) {
+				/* update_mat_and_dot_simd :60-98 (the SIMD lane split of the sum is not restated) */
+				const T b0 = dot[j];
+				T acc = 0;
+				for (long i = k + 1; i < m; i++) {
+					T dst = FMA(AT(A, i, k - 1), b0, AT(A, i, j));
+					acc = FMA(AT(A, i, k), dst, acc);
+					AT(A, i, j) = dst;
+				}
+				const T tmp = AT(A, k, j) + l * b0;
+				const T d0 = (tmp + acc) * (-tau_inv);
+				AT(A, k, j) = tmp + d0;
+				dot[j] = d0;
+			} else {
+				T acc = AT(A, k, j);
+				for (long i = k + 1; i < m; i++)
+					acc = FMA(AT(A, i, k), AT(A, i, j), acc);
+				const T d = -(acc * tau_inv);
+				AT(A, k, j) += d;
+				dot[j] = d;
+			}
+			norm[j] = SQRT(norm[j] * norm[j] - AT(A, k, j) * AT(A, k, j));
+		}
+	}
+	for (long j = 0; j < n; j++)
+		for (long i = 0; i <= j && i < m; i++)
+			AT(A, i, j) *= scale_fwd;
+	free(dot);
+	free(norm);
+	return n_trans;
+}
+
+long FN(oracle_colpiv_qr_in_place)(T *a, long m, long n, long rs, long cs, T *h, long block_size, long hrs, long hcs, long *col_perm,
+				   long *col_perm_inv)
+{
+	FN(mat) A = {a, m, n, rs, cs};
+	long size = m < n ? m : n;
+	FN(mat) H = {h, block_size, size, hrs, hcs};
+	long nt = FN(colpiv_qr_unblocked)(A, h, hcs, col_perm, rs == 1);
+	for (long j = 0; j < n; j++)
+		col_perm_inv[col_perm[j]] = j;
+	/* factor.rs:372-393 */
+	long j = 0;
+	while (j < size) {
+		long bs = block_size < size - j ? block_size : size - j;
+		FN(mat) Hb = FN(sub)(H, 0, j, bs, bs);
+		for (long c = 0; c < bs; c++)
+			AT(Hb, c, c) = AT(Hb, 0, c);
+		FN(upgrade_householder_factor)(Hb, FN(sub)(A, j, j, m - j, bs), bs, 1);
+		j += bs;
+	}
+	return nt;
+}
+
 /* householder.rs:724-808 : sequence apply on the left.
  * transpose != 0 => Q^H * M (blocks first to last), else Q * M (last to first). */
 void FN(oracle_apply_householder_sequence_left)(const T *v, long m, long n, long vrs, long vcs, const T *h,

@@ -47,7 +47,7 @@ def lib():
         for suf, ct in (("f64", C.c_double), ("f32", C.c_float)):
             getattr(_LIB, f"oracle_norm_l2_{suf}").restype = ct
             for name in ("oracle_llt_in_place", "oracle_ldlt_in_place", "oracle_lu_in_place", "oracle_qr_in_place",
-                         "oracle_qr_recommended_block_size", "oracle_full_piv_lu_in_place"):
+                         "oracle_qr_recommended_block_size", "oracle_full_piv_lu_in_place", "oracle_colpiv_qr_in_place"):
                 getattr(_LIB, f"{name}_{suf}").restype = C.c_long
     return _LIB
 
@@ -143,6 +143,17 @@ def full_piv_lu_in_place(a):
     cp, cpi = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
     nt = getattr(lib(), f"oracle_full_piv_lu_in_place_{suf}")(_p(a), C.c_long(m), C.c_long(n), *_st(a), _p(rp), _p(rpi), _p(cp), _p(cpi))
     return rp, rpi, cp, cpi, nt
+
+
+def colpiv_qr_in_place(a, h):
+    """qr/col_pivoting/factor.rs:356-395.  a: m x n (QR of A[:, col_perm] packed like qr_in_place), h: block_size x
+    min(m, n) Householder factors.  returns (col_perm, col_perm_inv, transposition_count)"""
+    suf, _ = _suf(a)
+    m, n = a.shape
+    cp, cpi = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    nt = getattr(lib(), f"oracle_colpiv_qr_in_place_{suf}")(_p(a), C.c_long(m), C.c_long(n), *_st(a), _p(h), C.c_long(h.shape[0]), *_st(h), _p(cp),
+                                                          _p(cpi))
+    return cp, cpi, nt
 
 
 def qr_recommended_block_size(m, n, dtype=np.float64):

@@ -188,3 +188,58 @@ def test_qr_is_bitwise_reproducible():
         F.synchronize()
         outs.append((qr, h))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+# ------------------------------------------------------------------------------------ QR with column pivoting
+@pytest.mark.parametrize("m,n,layout", [(1, 1, "F"), (5, 5, "F"), (40, 30, "F"), (30, 40, "F"), (64, 64, "C"), (200, 50, "F"), (1, 7, "F"), (7, 1, "F"),
+                                        (300, 300, "F"), (1500, 260, "F"), (700, 900, "F"), (257, 257, "C")])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_colpiv_qr_vs_oracle(oracle, m, n, layout, dtype):
+    """colpiv_qr_dev through the C-ABI: IDENTICAL column permutation (index work), R / reflectors / T blocks within
+    tolerance of the oracle, least-squares and square solves"""
+    F = init_gpu()
+    rng = np.random.default_rng(m * n)
+    a = np.array(rng.standard_normal((m, n)) * np.logspace(0, -3, n)[None, :], dtype=dtype, order=layout)
+    size = min(m, n)
+    bs = oracle.qr_recommended_block_size(m, n, dtype)
+    ref = a.copy(order=layout)
+    href = np.zeros((bs, size), dtype=dtype, order="F")
+    cp, cpi, nt = oracle.colpiv_qr_in_place(ref, href)
+    da = to_dev(a, layout)
+    dh = to_dev(np.zeros((bs, size), dtype=dtype, order="F"))
+    cf, cb, cnt = F.colpiv_qr_factor_in_place(da, dh)
+    assert np.array_equal(cf.astype(np.int64), cp) and np.array_equal(cb.astype(np.int64), cpi) and cnt == nt
+    e = EPS[np.dtype(dtype)]
+    tol = 256 * max(m, n) * e * max(1.0, np.abs(a).max())
+    assert np.abs(to_host(da) - ref).max() <= tol
+    hg = to_host(dh)
+    fin = np.isfinite(href)
+    assert np.array_equal(np.isfinite(hg), fin) and np.array_equal(hg[~fin], href[~fin])  # tau = +inf for an empty tail
+    assert np.abs(hg[fin] - href[fin]).max(initial=0) <= tol * 4
+    if m >= n and n > 1:
+        b = np.array(rng.standard_normal((m, 3)), dtype=dtype, order="F")
+        x = to_dev(b)
+        F.colpiv_qr_solve_in_place(da, dh, cf, cb, x, mode="lstsq")
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        sol = np.linalg.lstsq(a64, b64, rcond=None)[0]
+        assert np.abs(to_host(x)[:n] - sol).max() <= 4096 * max(m, n) * e * np.linalg.cond(a64) * max(1.0, np.abs(sol).max())
+
+
+def test_colpiv_qr_rank_revealing_property():
+    """a numerically rank-deficient matrix (rank 37 of 120 columns, N = 900 rows): |r_kk| collapses after the rank,
+    A P == Q R, independent of the oracle"""
+    import torch
+
+    F = init_gpu()
+    m, n, rk = 900, 120, 37
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal((m, rk)) @ rng.standard_normal((rk, n))).astype(np.float64)
+    da = to_dev(a)
+    bs = F.qr_recommended_block_size(m, n, np.float64)
+    dh = to_dev(np.zeros((bs, n), order="F"))
+    cf, cb, _ = F.colpiv_qr_factor_in_place(da, dh)
+    d = np.abs(np.diag(to_host(da)[:n, :n]))
+    assert d[rk - 1] > 1e-3 * d[0] and d[rk:].max() < 1e-10 * d[0]
+    out = to_dev(np.full((m, n), np.nan, order="F"))
+    F.qr_reconstruct(out, da, dh)
+    assert np.abs(to_host(out) - a[:, cf.astype(int)]).max() <= 256 * m * 2.3e-16 * np.abs(a).max()

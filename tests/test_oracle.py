@@ -417,3 +417,33 @@ def test_full_piv_lu_oracle_stops_on_an_exactly_singular_trailing_block(oracle):
     U = np.triu(lu[:5, :])
     assert np.abs(L @ U - a[rp][:, cp]).max() == 0.0
     assert (np.diag(U)[2:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------ QR with column pivoting
+@pytest.mark.parametrize("m,n,order", [(1, 1, "F"), (5, 5, "F"), (40, 30, "F"), (30, 40, "F"), (64, 64, "C"), (200, 50, "F"), (1, 7, "F"), (7, 1, "F"),
+                                       (300, 300, "F")])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_colpiv_qr_oracle_vs_lapack(oracle, m, n, order, dtype):
+    """qr/col_pivoting/factor.rs tests (:397-526): A P == Q R within eps * n.  Pinned further against LAPACK's
+    geqp3 (scipy.linalg.qr(pivoting=True)): same pivoting rule (largest down-dated column norm), so the same
+    permutation and the same |diag R| on matrices whose column norms are well separated"""
+    import scipy.linalg as sl
+
+    rng = np.random.default_rng(m * n)
+    a = np.array(rng.standard_normal((m, n)) * np.logspace(0, -3, n)[None, :], dtype=dtype, order=order)
+    qr = a.copy(order=order)
+    size = min(m, n)
+    bs = oracle.qr_recommended_block_size(m, n, dtype)
+    h = np.zeros((bs, size), dtype=dtype, order="F")
+    cp, cpi, nt = oracle.colpiv_qr_in_place(qr, h)
+    assert (cpi[cp] == np.arange(n)).all()
+    out = np.zeros((m, n), dtype=dtype, order="F")
+    out[:size, :] = np.triu(qr[:size, :])
+    oracle.apply_householder_sequence_left(np.asfortranarray(qr[:, :size]), h, out, False)
+    e = np.finfo(dtype).eps
+    assert np.abs(out.astype(np.float64) - a[:, cp].astype(np.float64)).max() <= 32 * max(m, n) * e * np.abs(a).max()
+    if dtype == np.float64:
+        _, r_ref, p_ref = sl.qr(a, mode="economic", pivoting=True)
+        assert np.array_equal(cp, p_ref)
+        d, dr = np.abs(np.diag(qr[:size, :size])), np.abs(np.diag(r_ref))
+        assert np.abs(d - dr).max() <= 64 * max(m, n) * e * dr.max()
