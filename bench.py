@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native dense backend for faer.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gemm|llt|lu|qr|gemv|fplu] [--no-extras] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gemm|llt|lu|qr|gemv|fplu|cpqr] [--no-extras] [--no-cpu]
 
 Metric (BASELINE.json): achieved fp64 GFLOP/s.  A "step" is one pass of the hot path over one batch of
 synthetic input that is already resident in HBM when the timed region starts:
@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="gemm", choices=["gemm", "llt", "lu", "qr", "gemv", "fplu"])
+    ap.add_argument("--workload", default="gemm", choices=["gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr"])
     ap.add_argument("--n", type=int, default=0, help="override the matrix size (testing only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -196,6 +196,19 @@ def main():
                 F.full_piv_lu_factor_in_place(work)
 
             return step, 2.0 * n ** 3 / 3.0, lambda: work.copy_(a), f"full_piv_lu_f64_n{n}", "f64"
+        if name == "cpqr":
+            # QR with column pivoting, HBM bound like the full-pivot LU
+            n = n_override or 4096
+            a = colmajor(n, n, torch.float64, 7)
+            work = a.clone()
+            bs = F.qr_recommended_block_size(n, n, np.float64)
+            h = torch.zeros((n, bs), dtype=torch.float64, device=dev).t()
+
+            def step():
+                work.copy_(a)
+                F.colpiv_qr_factor_in_place(work, h)
+
+            return step, 4.0 * n ** 3 / 3.0, lambda: work.copy_(a), f"colpiv_qr_f64_n{n}", "f64"
         raise ValueError(name)
 
     def timed(fn, steps, warmup):
@@ -279,7 +292,7 @@ def main():
             others = {}
             del step
             torch.cuda.empty_cache()
-            for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu"):
+            for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr"):
                 if name == args.workload:
                     continue
                 try:
@@ -296,6 +309,11 @@ def main():
                     if name == "gemv":  # HBM bound: algorithmic bytes = the matrix, read once
                         gbs = (fl / 2.0) * 8 * 3 / t / 1e9
                         others[lb] = {"GB/s": round(gbs, 1), "ms": round(t / 3 * 1e3, 3), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                    if name == "cpqr":  # HBM bound: the trailing matrix is read and written once per step
+                        nn = 4096
+                        gbs = sum(2.0 * (nn - k) ** 2 * 8 for k in range(nn)) * 3 / t / 1e9
+                        others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3), "GB/s_algorithmic": round(gbs, 1),
+                                      "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
                     if name == "fplu":  # HBM bound: the trailing matrix is read and written once per step
                         nn = 4096
                         gbs = sum(2.0 * (nn - k) ** 2 * 8 for k in range(1, nn)) * 3 / t / 1e9
