@@ -423,6 +423,50 @@ def colpiv_qr_solve_in_place(qr, q_coeff, col_fwd, col_bwd, rhs, mode="lstsq", p
     return rhs
 
 
+def _it(p):
+    return "u64" if np.dtype(p.dtype) == np.uint64 else "u32"
+
+
+def full_piv_lu_reconstruct(out, lu, row_fwd, row_bwd, col_fwd, col_bwd, par=PAR_SEQ):
+    """lu/full_pivoting/reconstruct.rs: out <- P^-1 L U Q^-1"""
+    suf, _, _ = _dtype_suffix(lu)
+    m, n = lu.shape
+    getattr(lib(), f"libfaer_v0_23_full_piv_lu_reconstruct_{_it(row_fwd)}_{suf}")(
+        _mat(out, MatMut), _mat(lu), _mat(lu), SliceRef(row_fwd.ctypes.data, m), SliceRef(row_bwd.ctypes.data, m), SliceRef(col_fwd.ctypes.data, n),
+        SliceRef(col_bwd.ctypes.data, n), par, MemAlloc(None, 0))
+    return out
+
+
+def full_piv_lu_inverse(out, lu, row_fwd, row_bwd, col_fwd, col_bwd, par=PAR_SEQ):
+    """lu/full_pivoting/inverse.rs: out <- A^-1"""
+    suf, _, _ = _dtype_suffix(lu)
+    n = lu.shape[0]
+    getattr(lib(), f"libfaer_v0_23_full_piv_lu_inverse_{_it(row_fwd)}_{suf}")(
+        _mat(out, MatMut), _mat(lu), _mat(lu), SliceRef(row_fwd.ctypes.data, n), SliceRef(row_bwd.ctypes.data, n), SliceRef(col_fwd.ctypes.data, n),
+        SliceRef(col_bwd.ctypes.data, n), par, MemAlloc(None, 0))
+    return out
+
+
+def colpiv_qr_reconstruct(out, qr, q_coeff, col_fwd, col_bwd, par=PAR_SEQ):
+    """qr/col_pivoting/reconstruct.rs: out <- Q R P^-1"""
+    suf, _, _ = _dtype_suffix(qr)
+    m, n = qr.shape
+    size = min(m, n)
+    getattr(lib(), f"libfaer_v0_23_colpiv_qr_reconstruct_{_it(col_fwd)}_{suf}")(
+        _mat(out, MatMut), _mat(qr[:, :size]), _mat(q_coeff), _mat(qr[:size, :]), SliceRef(col_fwd.ctypes.data, n), SliceRef(col_bwd.ctypes.data, n), par,
+        MemAlloc(None, 0))
+    return out
+
+
+def colpiv_qr_inverse(out, qr, q_coeff, col_fwd, col_bwd, par=PAR_SEQ):
+    """qr/col_pivoting/inverse.rs: out <- A^-1 (square)"""
+    suf, _, _ = _dtype_suffix(qr)
+    n = qr.shape[0]
+    getattr(lib(), f"libfaer_v0_23_colpiv_qr_inverse_{_it(col_fwd)}_{suf}")(
+        _mat(out, MatMut), _mat(qr), _mat(q_coeff), _mat(qr), SliceRef(col_fwd.ctypes.data, n), SliceRef(col_bwd.ctypes.data, n), par, MemAlloc(None, 0))
+    return out
+
+
 BcastFn = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 
 

@@ -543,6 +543,92 @@ void colpiv_qr_solve_api(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerSliceRe
 	}
 }
 
+// out(i, j) = tmp(rmap[i], cmap[j]) with host index maps (two gathers through a second temporary)
+template <typename T, typename I> static void gather_rows_cols(MatV<T> out, MatV<T> tmp, const void *rmap, const void *cmap)
+{
+	const idx_t m = out.nrows, n = out.ncols;
+	Scratch rb((size_t) m * sizeof(idx_t) + 256), cb((size_t) n * sizeof(idx_t) + 256), t2((size_t) m * (size_t) n * sizeof(T) + 256);
+	upload_perm<I>(rb, rmap, m);
+	upload_perm<I>(cb, cmap, n);
+	MatV<T> tmp2{t2.as<T>(), m, n, 1, m};
+	gather_rows_dev<T>(tmp2, tmp.c(), rb.as<idx_t>());
+	gather_rows_dev<T>(out.t(), tmp2.t().c(), cb.as<idx_t>());
+	ctx().sync();
+}
+
+// lu/full_pivoting/reconstruct.rs: out(i, j) = (L U)(row_perm_inv[i], col_perm_inv[j])
+template <typename T, typename I>
+void full_lu_reconstruct_api(FaerMatMut Out, FaerMatRef L, FaerMatRef U, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb)
+{
+	(void) rpf;
+	(void) cpf;
+	const idx_t m = (idx_t) L.nrows, n = (idx_t) U.ncols;
+	const idx_t size = m < n ? m : n;
+	FH_CHECK((idx_t) Out.nrows == m && (idx_t) Out.ncols == n && (idx_t) L.ncols >= size && (idx_t) U.nrows >= size && (idx_t) rpb.len >= m &&
+			 (idx_t) cpb.len >= n,
+		 "full_piv_lu reconstruct: dimension mismatch");
+	FH_CHECK(!is_device_ptr(rpb.ptr) && !is_device_ptr(cpb.ptr), "full_piv_lu reconstruct: perm slices must be host memory");
+	if (m == 0 || n == 0)
+		return;
+	Staged<const T> l(view<T>(L), true, false), u(view<T>(U), true, false);
+	Staged<T> o(view<T>(Out), false, true);
+	Scratch tb((size_t) m * (size_t) n * sizeof(T));
+	MatV<T> tmp{tb.as<T>(), m, n, 1, m};
+	matmul_triangular_dev<T>(tmp.sub(0, 0, size, size), 0, false, l.dev.sub(0, 0, size, size), 5, u.dev.sub(0, 0, size, size), 2, (T) 1);
+	if (m > n)
+		matmul_triangular_dev<T>(tmp.sub(size, 0, m - size, size), 0, false, l.dev.sub(size, 0, m - size, size), 0, u.dev.sub(0, 0, size, size), 2,
+					 (T) 1);
+	if (m < n)
+		matmul_triangular_dev<T>(tmp.sub(0, size, size, n - size), 0, false, l.dev.sub(0, 0, size, size), 5, u.dev.sub(0, size, size, n - size), 0,
+					 (T) 1);
+	gather_rows_cols<T, I>(o.dev, tmp, rpb.ptr, cpb.ptr);
+}
+
+// lu/full_pivoting/inverse.rs: out(i, j) = (U^-1 L^-1)(col_perm_inv[i], row_perm_inv[j])
+template <typename T, typename I>
+void full_lu_inverse_api(FaerMatMut Out, FaerMatRef L, FaerMatRef U, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb)
+{
+	(void) rpf;
+	(void) cpf;
+	const idx_t n = (idx_t) L.ncols;
+	FH_CHECK((idx_t) L.nrows == n && (idx_t) U.nrows == n && (idx_t) U.ncols == n && (idx_t) Out.nrows == n && (idx_t) Out.ncols == n &&
+			 (idx_t) rpb.len >= n && (idx_t) cpb.len >= n,
+		 "full_piv_lu inverse: dimension mismatch");
+	FH_CHECK(!is_device_ptr(rpb.ptr) && !is_device_ptr(cpb.ptr), "full_piv_lu inverse: perm slices must be host memory");
+	if (n == 0)
+		return;
+	Staged<const T> l(view<T>(L), true, false), u(view<T>(U), true, false);
+	Staged<T> o(view<T>(Out), false, true);
+	Scratch tb((size_t) n * (size_t) n * sizeof(T));
+	MatV<T> tmp{tb.as<T>(), n, n, 1, n};
+	tri_invert_lower_dev<T>(o.dev, l.dev, true);
+	tri_invert_lower_dev<T>(o.dev.t(), u.dev.t(), false);
+	matmul_triangular_dev<T>(tmp, 0, false, o.dev.c(), 2, o.dev.c(), 5, (T) 1);
+	gather_rows_cols<T, I>(o.dev, tmp, cpb.ptr, rpb.ptr);
+}
+
+// qr/col_pivoting/reconstruct.rs: (Q R) with its columns permuted back; inverse.rs: rows of R^-1 Q^H permuted back
+template <typename T, typename I>
+void colpiv_qr_reconstruct_api(FaerMatMut Out, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerSliceRef pf, FaerSliceRef pb)
+{
+	(void) pf;
+	const idx_t n = (idx_t) R.ncols;
+	FH_CHECK((idx_t) pb.len >= n && !is_device_ptr(pb.ptr), "colpiv_qr reconstruct: perm slices (host memory, ncols entries)");
+	qr_reconstruct_api<T>(Out, Qb, Qc, R);
+	Staged<T> o(view<T>(Out), true, true);
+	permute_rows_dev_api<T, I>(o.dev.t(), static_cast<const I *>(pb.ptr)); // permute_cols_in_place(out, col_perm.inverse())
+}
+template <typename T, typename I>
+void colpiv_qr_inverse_api(FaerMatMut Out, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerSliceRef pf, FaerSliceRef pb)
+{
+	(void) pf;
+	const idx_t n = (idx_t) R.ncols;
+	FH_CHECK((idx_t) pb.len >= n && !is_device_ptr(pb.ptr), "colpiv_qr inverse: perm slices (host memory, ncols entries)");
+	qr_inverse_api<T>(Out, Qb, Qc, R);
+	Staged<T> o(view<T>(Out), true, true);
+	permute_rows_dev_api<T, I>(o.dev, static_cast<const I *>(pb.ptr)); // permute_rows_in_place(out, col_perm.inverse())
+}
+
 } // namespace
 
 extern "C" {
@@ -868,6 +954,70 @@ void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m, size_t n, s
 	void libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_u64_##suf(FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerConj cj, FaerSliceRef pf, FaerSliceRef pb, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem) \
 	{ \
 		(void) cj; (void) par; (void) mem; colpiv_qr_solve_api<T, uint64_t>(Qb, Qc, R, pf, pb, rhs, false, false); \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_reconstruct_scratch_u32_##suf(size_t nrows, size_t ncols, FaerPar par) \
+	{ \
+		(void) par; return layout(nrows * ncols * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_full_piv_lu_reconstruct_u32_##suf(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; full_lu_reconstruct_api<T, uint32_t>(A, L, U, rpf, rpb, cpf, cpb); \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_inverse_scratch_u32_##suf(size_t dim, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_full_piv_lu_inverse_u32_##suf(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; full_lu_inverse_api<T, uint32_t>(A_inv, L, U, rpf, rpb, cpf, cpb); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_reconstruct_scratch_u32_##suf(size_t nrows, size_t ncols, size_t bs, FaerPar par) \
+	{ \
+		(void) nrows; (void) par; return layout(bs * ncols * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_reconstruct_u32_##suf(FaerMatMut A, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerSliceRef pf, FaerSliceRef pb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; colpiv_qr_reconstruct_api<T, uint32_t>(A, Qb, Qc, R, pf, pb); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_inverse_scratch_u32_##suf(size_t dim, size_t bs, FaerPar par) \
+	{ \
+		(void) par; return layout(bs * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_inverse_u32_##suf(FaerMatMut A_inv, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerSliceRef pf, FaerSliceRef pb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; colpiv_qr_inverse_api<T, uint32_t>(A_inv, Qb, Qc, R, pf, pb); \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_reconstruct_scratch_u64_##suf(size_t nrows, size_t ncols, FaerPar par) \
+	{ \
+		(void) par; return layout(nrows * ncols * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_full_piv_lu_reconstruct_u64_##suf(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; full_lu_reconstruct_api<T, uint64_t>(A, L, U, rpf, rpb, cpf, cpb); \
+	} \
+	FaerLayout libfaer_v0_23_full_piv_lu_inverse_scratch_u64_##suf(size_t dim, FaerPar par) \
+	{ \
+		(void) par; return layout(dim * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_full_piv_lu_inverse_u64_##suf(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef rpf, FaerSliceRef rpb, FaerSliceRef cpf, FaerSliceRef cpb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; full_lu_inverse_api<T, uint64_t>(A_inv, L, U, rpf, rpb, cpf, cpb); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_reconstruct_scratch_u64_##suf(size_t nrows, size_t ncols, size_t bs, FaerPar par) \
+	{ \
+		(void) nrows; (void) par; return layout(bs * ncols * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_reconstruct_u64_##suf(FaerMatMut A, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerSliceRef pf, FaerSliceRef pb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; colpiv_qr_reconstruct_api<T, uint64_t>(A, Qb, Qc, R, pf, pb); \
+	} \
+	FaerLayout libfaer_v0_23_colpiv_qr_inverse_scratch_u64_##suf(size_t dim, size_t bs, FaerPar par) \
+	{ \
+		(void) par; return layout(bs * dim * sizeof(T), 64); \
+	} \
+	void libfaer_v0_23_colpiv_qr_inverse_u64_##suf(FaerMatMut A_inv, FaerMatRef Qb, FaerMatRef Qc, FaerMatRef R, FaerSliceRef pf, FaerSliceRef pb, FaerPar par, FaerMemAlloc mem) \
+	{ \
+		(void) par; (void) mem; colpiv_qr_inverse_api<T, uint64_t>(A_inv, Qb, Qc, R, pf, pb); \
 	} \
 	void libfaer_v0_23_inverse_triangular_lower_in_place_##suf(FaerMatMut T_inv, FaerMatRef Tm, FaerPar par) \
 	{ \

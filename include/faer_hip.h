@@ -407,6 +407,40 @@ FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_transpose_in_place_u64_f32(FaerM
 FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_scratch_u64_f32(size_t nrows, size_t ncols, size_t block_size, size_t rhs_ncols, FaerPar par);
 FAER_HIP_API void libfaer_v0_23_colpiv_qr_solve_lstsq_in_place_u64_f32(FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerConj A_conj, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerMatMut rhs, FaerPar par, FaerMemAlloc mem);
 
+/* reconstruct / inverse of the pivoted factorizations (faer-ffi/src/lib.rs:1877-1950, :2246-2330) */
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_reconstruct_scratch_u32_f64(size_t nrows, size_t ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_reconstruct_u32_f64(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_inverse_scratch_u32_f64(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_inverse_u32_f64(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_reconstruct_scratch_u32_f64(size_t nrows, size_t ncols, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_reconstruct_u32_f64(FaerMatMut A, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_inverse_scratch_u32_f64(size_t dim, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_inverse_u32_f64(FaerMatMut A_inv, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_reconstruct_scratch_u64_f64(size_t nrows, size_t ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_reconstruct_u64_f64(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_inverse_scratch_u64_f64(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_inverse_u64_f64(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_reconstruct_scratch_u64_f64(size_t nrows, size_t ncols, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_reconstruct_u64_f64(FaerMatMut A, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_inverse_scratch_u64_f64(size_t dim, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_inverse_u64_f64(FaerMatMut A_inv, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_reconstruct_scratch_u32_f32(size_t nrows, size_t ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_reconstruct_u32_f32(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_inverse_scratch_u32_f32(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_inverse_u32_f32(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_reconstruct_scratch_u32_f32(size_t nrows, size_t ncols, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_reconstruct_u32_f32(FaerMatMut A, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_inverse_scratch_u32_f32(size_t dim, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_inverse_u32_f32(FaerMatMut A_inv, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_reconstruct_scratch_u64_f32(size_t nrows, size_t ncols, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_reconstruct_u64_f32(FaerMatMut A, FaerMatRef L, FaerMatRef U, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_full_piv_lu_inverse_scratch_u64_f32(size_t dim, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_full_piv_lu_inverse_u64_f32(FaerMatMut A_inv, FaerMatRef L, FaerMatRef U, FaerSliceRef row_perm_fwd, FaerSliceRef row_perm_bwd, FaerSliceRef col_perm_fwd, FaerSliceRef col_perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_reconstruct_scratch_u64_f32(size_t nrows, size_t ncols, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_reconstruct_u64_f32(FaerMatMut A, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_inverse_scratch_u64_f32(size_t dim, size_t block_size, FaerPar par);
+FAER_HIP_API void libfaer_v0_23_colpiv_qr_inverse_u64_f32(FaerMatMut A_inv, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+
 /* ---------------------------------------------------------------------------------------------
  * 3. Runtime control (new: the reference has no device).
  * --------------------------------------------------------------------------------------------- */

@@ -147,3 +147,43 @@ def test_apply_householder_on_the_right(m, n, k, transpose):
     F.apply_block_householder_sequence_on_the_right_in_place(basis, h, dm, transpose=transpose)
     ref = mat @ (Q.T if transpose else Q)
     assert np.abs(to_host(dm) - ref).max() <= 64 * m * 2.3e-16 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("m,n", [(1, 1), (5, 5), (130, 130), (300, 200), (200, 300), (500, 500)])
+def test_full_piv_lu_reconstruct_and_inverse(m, n, dtype):
+    F = init_gpu()
+    rng = np.random.default_rng(m * 7 + n)
+    a = rnd(rng, m, n, dtype)
+    lu = to_dev(a)
+    rf, rb, cf, cb, _ = F.full_piv_lu_factor_in_place(lu)
+    out = to_dev(np.full((m, n), np.nan, dtype=dtype, order="F"))
+    F.full_piv_lu_reconstruct(out, lu, rf, rb, cf, cb)
+    assert np.abs(to_host(out) - a).max() <= tol(max(m, n), dtype) * np.abs(a).max()
+    if m == n:
+        out = to_dev(np.full((n, n), np.nan, dtype=dtype, order="F"))
+        F.full_piv_lu_inverse(out, lu, rf, rb, cf, cb)
+        a64 = a.astype(np.float64)
+        assert np.abs(to_host(out).astype(np.float64) @ a64 - np.eye(n)).max() <= tol(n, dtype, 256) * np.linalg.cond(a64)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("m,n", [(1, 1), (5, 5), (130, 130), (300, 200), (40, 90), (400, 400)])
+def test_colpiv_qr_reconstruct_and_inverse(m, n, dtype):
+    F = init_gpu()
+    rng = np.random.default_rng(m * 11 + n)
+    a = rnd(rng, m, n, dtype)
+    if m == n:
+        a = (a + m ** 0.5 * np.eye(n, dtype=dtype)).astype(dtype)
+    qr = to_dev(a)
+    bs = F.qr_recommended_block_size(m, n, dtype)
+    h = to_dev(np.zeros((bs, min(m, n)), dtype=dtype, order="F"))
+    cf, cb, _ = F.colpiv_qr_factor_in_place(qr, h)
+    out = to_dev(np.full((m, n), np.nan, dtype=dtype, order="F"))
+    F.colpiv_qr_reconstruct(out, qr, h, cf, cb)
+    assert np.abs(to_host(out) - a).max() <= tol(max(m, n), dtype) * np.abs(a).max()
+    if m == n:
+        out = to_dev(np.full((n, n), np.nan, dtype=dtype, order="F"))
+        F.colpiv_qr_inverse(out, qr, h, cf, cb)
+        a64 = a.astype(np.float64)
+        assert np.abs(to_host(out).astype(np.float64) @ a64 - np.eye(n)).max() <= tol(n, dtype, 256) * np.linalg.cond(a64)
