@@ -1,3 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_extras.py -m gpu -q -x -k "full_piv or colpiv" 2>&1 | tail -12
+for i in 1 2 3 4 5 6; do timeout 200 python tools/gpu_stress_llt.py 2>&1 | grep -v amdgpu | tr '\n' ';'; echo; done
+for i in 1 2 3; do timeout 200 python tools/gpu_stress_llt.py side 2>&1 | grep -v amdgpu | tr '\n' ';'; echo; done
+for i in 1 2 3; do timeout 200 python tools/gpu_stress_lu.py 2>&1 | grep -v amdgpu | tr '\n' ';'; echo; done

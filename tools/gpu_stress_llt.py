@@ -22,6 +22,7 @@ big = torch.randn((8192, 8192), dtype=torch.float64, device="cuda")
 ref = None
 bad = 0
 ctx = torch.cuda.stream(side) if side is not None else torch.cuda.stream(torch.cuda.current_stream())
+torch.cuda.synchronize()  # the inputs were produced on the default stream: a side stream must not start before they exist
 with ctx:
     F.use_torch_stream()
     for it in range(24):
