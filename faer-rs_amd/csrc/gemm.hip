@@ -1088,9 +1088,16 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	// split-K for few-tile / deep-K products
 	idx_t tiles = g.tri_enum ? (idx_t) g.ntm * (g.ntm + 1) / 2 - g.tri_off : (idx_t) g.ntm * g.ntn;
 	int splits = 1;
-	if (tiles < 256 && k >= 4096 && !indexed) {
+	// Deep-K products with few output tiles are split along K.  Rectangular outputs (the V^H A / V^H V products of QR:
+	// K = rows of the panel, a few tiles of output) split from K = 1024 in slices of >= 256 (measured: square QR
+	// N = 4096 99.6 -> 80.2 ms); triangular outputs (the diagonal-block updates of the blocked Cholesky, which sit
+	// on its critical chain) keep the coarser rule, the finer one cost the N = 16384 factorization 0.6 ms.
+	static const idx_t splitk_mink = getenv("FAER_HIP_SPLITK_MINK") ? atol(getenv("FAER_HIP_SPLITK_MINK")) : 1024;
+	static const idx_t splitk_chunk = getenv("FAER_HIP_SPLITK_CHUNK") ? atol(getenv("FAER_HIP_SPLITK_CHUNK")) : 256;
+	const idx_t mink = kind == DST_FULL ? splitk_mink : 4096, chunk = kind == DST_FULL ? splitk_chunk : 1024;
+	if (tiles < 256 && k >= mink && !indexed && !ex.k_trim) {
 		splits = (int) ((512 + tiles - 1) / tiles);
-		idx_t max_splits = k / 1024;
+		idx_t max_splits = k / chunk;
 		if (splits > max_splits)
 			splits = (int) max_splits;
 		if (splits > 1024)

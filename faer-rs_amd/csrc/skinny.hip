@@ -3,7 +3,7 @@
 // 438-604 apply_block_householder..., qr/no_pivoting/factor.rs:160-301: V^H A, V^H V and A -= V (T V^H A) with
 // 8 .. 32 columns on each side) and they are pure HBM streams: a 128 x 128 MFMA tile would be 94 % padding and its
 // K loop one memory round trip per 16 rows.  Two streaming kernels instead:
-//   update:  C (M x N) <- [C +] alpha A (M x K) B (K x N),  K <= 16, N <= 32, M large, unit stride along m in A and C.
+//   update:  C (M x N) <- [C +] alpha A (M x K) B (K x N),  K <= 16, N <= 32, M >= 256 (measured: ahead of the MFMA tile from there), unit stride along m in A and C.
 //            One thread per row (R rows in flight): its K values of A stay in registers, B sits in LDS and is read
 //            as wave-uniform broadcasts, every C element is loaded and stored exactly once, lanes along m.
 //   reduce:  C (M x N) <- [C +] alpha A (M x K) B (K x N),  M, N <= 16, K large, unit stride along k in A and B.
@@ -175,7 +175,7 @@ template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV
 	if (off)
 		return false;
 	idx_t m = C.nrows, n = C.ncols, k = A.ncols;
-	constexpr idx_t LONG = 16384;
+	static const idx_t LONG = getenv("FAER_HIP_SKINNY_MIN") ? atol(getenv("FAER_HIP_SKINNY_MIN")) : 256;
 	// ---- update, possibly on the transposed problem (C^T = B^T A^T)
 	if (n >= LONG && m <= 32 && k <= 16 && iabs3(C.cs) == 1 && iabs3(B.cs) == 1) {
 		MatV<T> Ct = C.t();

@@ -1,5 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for i in 1 2 3 4 5 6; do timeout 200 python tools/gpu_stress_llt.py 2>&1 | grep -v amdgpu | tr '\n' ';'; echo; done
-for i in 1 2 3; do timeout 200 python tools/gpu_stress_llt.py side 2>&1 | grep -v amdgpu | tr '\n' ';'; echo; done
-for i in 1 2 3; do timeout 200 python tools/gpu_stress_lu.py 2>&1 | grep -v amdgpu | tr '\n' ';'; echo; done
+python tools/gpu_size_sweep.py 1024,2048,4096,8192 2>&1 | grep -v amdgpu.ids | tail -4
+python bench.py --workload qr --no-cpu --no-extras 2>&1 | grep -o "ms_per_step[^,]*"
+python bench.py --workload llt --no-cpu --no-extras 2>&1 | grep -o "ms_per_step[^,]*"
+python bench.py --workload lu --no-cpu --no-extras 2>&1 | grep -o "ms_per_step[^,]*"
+timeout 600 python -m pytest tests/test_gpu_qr.py tests/test_gpu_matmul.py -m gpu -q -x 2>&1 | tail -2
