@@ -27,6 +27,7 @@
 #include <climits>
 
 #include "common.h"
+#include "lds_blocks.h"
 #include "xwg.h"
 
 namespace fh {
@@ -311,13 +312,18 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 	}
 	// positions in blocks of 8: a block takes part while it still holds unfinished columns (wave-uniform test);
 	// rows with gr <= J carry l == 0 but must stay bitwise untouched (l * u could be NaN for an infinite u)
+	// The pivot row reaches the FMAs through the scalar unit: lane c of every wave reads position c ONCE from LDS,
+	// the multiplier of position p is v_readlane(.., p) (wave uniform, an SGPR operand of the FMA).  Read per thread
+	// from LDS instead, the 64 broadcast reads per thread and column keep the CU's one LDS pipe busy for ~3000
+	// cycles per column (8 waves x 64 reads); the readlanes run on the four SIMDs in parallel.
+	const T myu = sh.piv[lane & (W - 1)];
 #pragma unroll
 	for (int cb = 0; cb < W / 8; ++cb) {
 		if (cb * 8 < lim) {
 			T u[8];
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				u[k] = sh.piv[cb * 8 + k];
+				u[k] = lane_bcast(myu, cb * 8 + k);
 #pragma unroll
 			for (int i = 0; i < RPT; ++i) {
 				const int gr = r0 + tid + i * LU2_NT;

@@ -1,7 +1,8 @@
 #!/bin/bash
 export TMPDIR=/tmp
-python tools/gpu_size_sweep.py 1024,2048,4096,8192 2>&1 | grep -v amdgpu.ids | tail -4
-python bench.py --workload qr --no-cpu --no-extras 2>&1 | grep -o "ms_per_step[^,]*"
-python bench.py --workload llt --no-cpu --no-extras 2>&1 | grep -o "ms_per_step[^,]*"
-python bench.py --workload lu --no-cpu --no-extras 2>&1 | grep -o "ms_per_step[^,]*"
-timeout 600 python -m pytest tests/test_gpu_qr.py tests/test_gpu_matmul.py -m gpu -q -x 2>&1 | tail -2
+timeout 300 python -m pytest tests/test_gpu_factor.py -m gpu -q -x -k "plu or lu_" 2>&1 | tail -2
+for lib in tools/ab/libfaer_hip_head.so faer-rs_amd/libfaer_hip.so; do
+  echo "== $lib"
+  FAER_HIP_LIB=$PWD/$lib python tools/gpu_exp_l2.py lu 2>&1 | grep -v amdgpu
+  FAER_HIP_LIB=$PWD/$lib python tools/gpu_size_sweep.py 256,1024,4096 2>&1 | grep -v amdgpu | tail -3
+done
