@@ -301,14 +301,15 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 // critical path (look-ahead panel stream, and the sequential tail where R is small enough that every launch is
 // latency bound anyway).  Same operations per entry as cholesky/ldlt/factor.rs:367-498 grouped by block columns.
 template <typename T>
-static void potrf_panel_flat(MatV<T> P, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase)
+static void potrf_panel_flat(MatV<T> P, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase, idx_t wblk0 = 0)
 {
+	// the inverse of the 128-block starting at global column offset + c0 goes to slot (offset + c0) / 128 - wblk0 of Wbase
 	const idx_t R = P.nrows, w = P.ncols;
 	for (idx_t c0 = 0; c0 < w; c0 += POTRF_NB) {
 		const idx_t nb = POTRF_NB < w - c0 ? POTRF_NB : w - c0;
 		if (c0 > 0)
 			gemm_dev<T>(P.sub(c0, c0, R - c0, nb), DST_LOWER, true, P.sub(c0, 0, R - c0, c0).c(), P.sub(c0, 0, nb, c0).t().c(), (T) -1);
-		T *W = Wbase + (size_t) ((offset + c0) / POTRF_NB) * POTRF_NB * POTRF_NB;
+		T *W = Wbase + (size_t) ((offset + c0) / POTRF_NB - wblk0) * POTRF_NB * POTRF_NB;
 		MatV<T> D = P.sub(c0, c0, nb, nb);
 		hipLaunchKernelGGL((potrf_leaf_kernel<T, false>), dim3(1), dim3(LDS_NT), 0, ctx().stream, D.p, D.rs, D.cs, (int) nb, regularize, eps,
 				   delta, status, (int) (offset + c0), W, (const signed char *) nullptr, (T *) nullptr);
@@ -512,9 +513,7 @@ template <typename T> void potrf_panel_dev(MatV<T> P, T reg_delta, T reg_eps, in
 	const idx_t nblk = (P.ncols + POTRF_NB - 1) / POTRF_NB;
 	Scratch winv((size_t) nblk * POTRF_NB * POTRF_NB * sizeof(T));
 	const int regularize = (reg_delta > (T) 0 && reg_eps > (T) 0) ? 1 : 0;
-	// potrf_panel_flat indexes the inverse blocks by (offset + c0) / 128: hand it a base shifted accordingly
-	T *Wbase = winv.as<T>() - (size_t) (offset / POTRF_NB) * POTRF_NB * POTRF_NB;
-	potrf_panel_flat<T>(P, regularize, reg_eps, reg_delta, status_dev, offset, Wbase);
+	potrf_panel_flat<T>(P, regularize, reg_eps, reg_delta, status_dev, offset, winv.as<T>(), offset / POTRF_NB);
 }
 template void potrf_panel_dev<double>(MatV<double>, double, double, int *, idx_t);
 template void potrf_panel_dev<float>(MatV<float>, float, float, int *, idx_t);
