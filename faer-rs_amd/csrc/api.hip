@@ -1343,6 +1343,17 @@ void faer_hip_memcpy_d2h(void *d, const void *s, size_t bytes)
 }
 void faer_hip_set_gemm_variant(int v) { ctx().gemm_variant = v; }
 void faer_hip_debug_stream_xcc(int which, int nblocks, unsigned *out_host) { debug_stream_xcc(which, nblocks, out_host); }
+size_t faer_hip_debug_llt_plan(size_t n, size_t tail_rows, size_t nb2, size_t *starts, size_t cap)
+{
+	const std::vector<idx_t> J = llt_plan((idx_t) n, (idx_t) tail_rows, (idx_t) nb2);
+	for (size_t i = 0; i < J.size() && i < cap; ++i)
+		starts[i] = (size_t) J[i];
+	return J.size();
+}
+int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, int resident_workgroups)
+{
+	return lu_leaf_width((idx_t) nrows, dtype == FaerHipDType_F64 ? 8 : 4, resident_workgroups);
+}
 void *faer_hip_debug_internal_stream(int which)
 {
 	Ctx &c = ctx();

@@ -218,6 +218,9 @@ template <typename T> void zero_then_upper_dev(MatV<T> out, const MatV<const T> 
 template <typename T> long full_piv_lu_dev(MatV<T> A, idx_t *row_perm, idx_t *row_perm_inv, idx_t *col_perm, idx_t *col_perm_inv);
 // qr.hip: QR with column pivoting (perm arrays are host memory); returns the transposition count
 template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, idx_t *col_perm_inv);
+// pure host planning logic, exported for the CPU tests (faer_hip_debug_*)
+std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2);
+int lu_leaf_width(idx_t m, int elem_bytes, int resident_workgroups);
 // tall-skinny shapes (skinny.hip): streaming kernels; false if the shape / strides do not qualify
 template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV<const T> B, T alpha);
 // C <- [C +] alpha * sum_z ws[z] (slices of nrows x ncols, column major), fixed summation order (gemm.hip)

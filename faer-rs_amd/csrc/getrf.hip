@@ -587,15 +587,22 @@ static int resident_workgroups()
 	return ncu;
 }
 
-// widest leaf whose workgroups are all resident for a panel of m rows
+// widest leaf whose workgroups are all resident for a panel of m rows when `cap` workgroups fit the device at once;
+// 0 if not even the narrowest shape fits (pure host logic: faer_hip_debug_lu_leaf_width)
+int lu_leaf_width(idx_t m, int elem_bytes, int cap)
+{
+	for (int w = LU_W; w >= 8; w /= 2) {
+		const idx_t rows = (idx_t) LU2_NT * ((elem_bytes == 8 ? 64 : 128) / w);
+		if ((m + rows - 1) / rows <= (idx_t) cap)
+			return w;
+	}
+	return 0;
+}
 template <typename T> static int leaf_width_for(idx_t m)
 {
-	const int cap = resident_workgroups();
-	for (int w = LU_W; w >= 8; w /= 2)
-		if ((m + leaf_rows_per_wg<T>(w) - 1) / leaf_rows_per_wg<T>(w) <= (idx_t) cap)
-			return w;
-	FH_CHECK(false, "partial_piv_lu: more rows than the cooperative panel kernel can keep resident (1,048,576 fp64 / 2,097,152 fp32 rows on 256 CUs)");
-	return 0;
+	const int w = lu_leaf_width(m, (int) sizeof(T), resident_workgroups());
+	FH_CHECK(w > 0, "partial_piv_lu: more rows than the cooperative panel kernel can keep resident (1,048,576 fp64 / 2,097,152 fp32 rows on 256 CUs)");
+	return w;
 }
 
 template <typename T, int W> static void launch_leaf(int G, hipStream_t s, const Panel2Args<T> &a)

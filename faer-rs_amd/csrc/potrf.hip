@@ -370,6 +370,26 @@ template <typename T> static void tri_inv_full(MatV<const T> L, const T *Wblk, M
 // (cholesky/ldlt/factor.rs:367-498) with a larger step.
 constexpr idx_t LA_NB = 1024;
 
+// Step plan of the blocked driver (pure host logic, unit tested without a GPU through faer_hip_debug_llt_plan):
+// starts of the look-ahead panels; the last entry is where the sequential tail takes over.  The first step is LA_NB
+// wide, the following ones nb2 while at least 2 * nb2 rows remain behind them, LA_NB again towards the end; steps
+// stop once no more than `tail_rows` rows remain (or the next panel would reach the end of the matrix).
+std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2)
+{
+	std::vector<idx_t> J;
+	J.push_back(0);
+	while (true) {
+		const idx_t j0 = J.back();
+		idx_t w = J.size() == 1 ? LA_NB : nb2;
+		if (n - j0 - w < 2 * w)
+			w = LA_NB; // narrow steps again towards the end
+		if (!(n - j0 > tail_rows && j0 + w < n))
+			break;
+		J.push_back(j0 + w);
+	}
+	return J;
+}
+
 template <typename T>
 static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *status, T *Wbase, hipStream_t caller)
 {
@@ -386,17 +406,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 	// rate and there are fewer launch boundaries per factorization) while at least 2 * LA_NB2 rows remain.
 	const idx_t nb2 = getenv("FAER_HIP_LLT_NB2") ? atol(getenv("FAER_HIP_LLT_NB2")) : LA_NB;
 	FH_CHECK(nb2 >= LA_NB && nb2 % POTRF_NB == 0 && nb2 <= 4096, "potrf: FAER_HIP_LLT_NB2 must be a multiple of 128 in [1024, 4096]");
-	std::vector<idx_t> J; // look-ahead steps: panel columns [J[k], J[k + 1])
-	J.push_back(0);
-	while (true) {
-		const idx_t j0 = J.back();
-		idx_t w = J.size() == 1 ? LA_NB : nb2;
-		if (n - j0 - w < 2 * w)
-			w = LA_NB; // narrow steps again towards the end
-		if (!(n - j0 > tail_rows && j0 + w < n))
-			break;
-		J.push_back(j0 + w);
-	}
+	const std::vector<idx_t> J = llt_plan(n, tail_rows, nb2); // look-ahead steps: panel columns [J[k], J[k + 1])
 	idx_t ks = (idx_t) J.size() - 1; // look-ahead steps
 	if (ks > 0 && !c.lookahead_streams())
 		ks = 0;

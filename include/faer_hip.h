@@ -469,6 +469,11 @@ FAER_HIP_API void faer_hip_set_gemm_variant(int variant);
 /* Debugging aid.  `which`: 0 = the caller's stream, 1 / 2 = the internal bulk / panel look-ahead stream; writes
  * {XCC id, HW_ID} of the CU each of `nblocks` probe workgroups ran on (2 * nblocks words of host memory). */
 FAER_HIP_API void faer_hip_debug_stream_xcc(int which, int nblocks, unsigned *out_host);
+/* Host-side planning logic of the drivers, callable without a GPU (unit tests): the look-ahead panel starts of the
+ * blocked Cholesky (last entry = start of the sequential tail; returns the number of entries) and the leaf width
+ * the cooperative LU panel kernel picks for `nrows` rows when `resident_workgroups` workgroups fit the device. */
+FAER_HIP_API size_t faer_hip_debug_llt_plan(size_t n, size_t tail_rows, size_t nb2, size_t *starts, size_t cap);
+FAER_HIP_API int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, int resident_workgroups);
 /* The internal CU-masked streams themselves (1 = bulk, 2 = panel), for microbenchmarks via faer_hip_set_stream. */
 FAER_HIP_API void *faer_hip_debug_internal_stream(int which);
 /* Measures `iters` back-to-back launches of the dense GEMM kernel on the calling thread's stream with

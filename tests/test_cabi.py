@@ -73,3 +73,39 @@ def test_product_path_has_no_cpu_fallback():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "computed" not in r.stdout
     assert "no HIP device" in r.stderr or "faer_hip: fatal" in r.stderr
+
+
+def test_driver_planning_logic_needs_no_gpu():
+    """host-side decisions of the device drivers (pure functions, csrc/potrf.hip llt_plan, csrc/getrf.hip
+    lu_leaf_width): step plan of the blocked Cholesky and the leaf shape of the cooperative LU panel"""
+    F = fa()
+    lib = F.lib()
+    lib.faer_hip_debug_llt_plan.restype = C.c_size_t
+
+    def plan(n, tail, nb2=1024):
+        buf = (C.c_size_t * 64)()
+        cnt = lib.faer_hip_debug_llt_plan(C.c_size_t(n), C.c_size_t(tail), C.c_size_t(nb2), buf, C.c_size_t(64))
+        return [int(buf[i]) for i in range(cnt)]
+
+    # N = 16384, look-ahead until 4096 rows remain: 12 steps of 1024, tail from column 12288
+    assert plan(16384, 4096) == [1024 * i for i in range(13)]
+    # everything to the tail when the matrix is not larger than the tail threshold
+    assert plan(8192, 8192) == [0]
+    # ragged size: steps stop when the next panel would reach the end
+    assert plan(5197, 2048) == [0, 1024, 2048, 3072, 4096]
+    assert plan(5197, 0) == [0, 1024, 2048, 3072, 4096, 5120]  # the last 77 columns are the tail
+    # wider later steps: first step 1024, then 2048 while 2 * 2048 rows remain behind them, 1024 again at the end
+    assert plan(16384, 4096, 2048) == [0, 1024, 3072, 5120, 7168, 9216, 11264, 12288]
+    for n in (2049, 3000, 10240, 16384, 20000):
+        for tail in (0, 1024, 4096, 1 << 30):
+            j = plan(n, tail)
+            assert j[0] == 0 and all(b > a for a, b in zip(j, j[1:])) and j[-1] < n
+            assert all((b - a) % 128 == 0 for a, b in zip(j, j[1:]))
+
+    # LU leaf: 64 columns while ceil(rows / 512) workgroups are resident (fp64), narrower / taller shapes after that
+    w = lambda rows, dt, cap: lib.faer_hip_debug_lu_leaf_width(C.c_size_t(rows), C.c_int(dt), cap)  # noqa: E731
+    assert w(16384, F.DTYPE_F64, 32) == 64 and w(16384, F.DTYPE_F64, 256) == 64
+    assert w(16385, F.DTYPE_F64, 32) == 32  # 33 workgroups of 512 rows do not fit 32 CUs: 1024 rows per workgroup
+    assert w(200000, F.DTYPE_F64, 256) == 32 and w(600000, F.DTYPE_F64, 256) == 8
+    assert w(1048576, F.DTYPE_F64, 256) == 8 and w(1048577, F.DTYPE_F64, 256) == 0
+    assert w(300000, F.DTYPE_F32, 256) == 32 and w(2097152, F.DTYPE_F32, 256) == 8 and w(2097153, F.DTYPE_F32, 256) == 0
