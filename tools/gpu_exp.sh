@@ -1,8 +1,19 @@
 #!/bin/bash
+# Template of a one-visit A/B experiment (edit, then: gpurun --timeout 900 -- 'bash tools/gpu_exp.sh').
+# Everything compared must run inside ONE visit: the boxes of the pool differ by up to 15 % on latency-bound work.
+#   * env switches of the library ("Environment switches") select code paths per process;
+#   * FAER_HIP_LIB=/path/to/other/libfaer_hip.so loads another build (e.g. `git archive <commit> | tar -x -C /tmp/x &&
+#     make -C /tmp/x/faer-rs_amd/csrc && cp .../libfaer_hip.so tools/ab/old.so`: untracked *.so files travel with gpurun).
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_factor.py -m gpu -q -x -k "plu or lu_" 2>&1 | tail -2
-for lib in tools/ab/libfaer_hip_head.so faer-rs_amd/libfaer_hip.so; do
-  echo "== $lib"
-  FAER_HIP_LIB=$PWD/$lib python tools/gpu_exp_l2.py lu 2>&1 | grep -v amdgpu
-  FAER_HIP_LIB=$PWD/$lib python tools/gpu_size_sweep.py 256,1024,4096 2>&1 | grep -v amdgpu | tail -3
-done
+mkdir -p gpurun_out
+O=gpurun_out/exp.log
+: > $O
+run() { timeout 240 env "$@" python tools/gpu_exp_l2.py $WHAT $N >> $O 2>&1 || echo "FAILED: $* $WHAT" >> $O; }
+N=16384
+WHAT=lu
+run FAER_HIP_LU_SPLIT=0
+run FAER_HIP_LU_SPLIT=1
+WHAT=llt
+run FAER_HIP_LLT_TAIL=0
+run FAER_HIP_LLT_TAIL=4096
+grep -v amdgpu.ids $O
