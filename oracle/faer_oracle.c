@@ -2,8 +2,9 @@
  * CPU ORACLE -- TEST INFRASTRUCTURE ONLY (see faer_oracle_impl.h).
  *
  * Plain-C restatement of faer 0.24.4's CPU algorithms for the hot path
- * (GEMM, triangular product, TRSM, LLT, partial-pivot LU, Householder QR),
- * instantiated for f64 and f32.  Built by oracle/Makefile into
+ * (GEMM, triangular product, TRSM, LLT / LDLT, partial-pivot LU, Householder QR)
+ * and for the SURVEY.md section 8f rows built so far (LU with full pivoting, QR
+ * with column pivoting), instantiated for f64 and f32.  Built by oracle/Makefile into
  * oracle/libfaer_oracle.so and loaded through ctypes by oracle/oracle.py.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
@@ -11,8 +12,9 @@
  *
  * Parity: UNPINNED at bit level (reference GEMM lives in unvendored crates,
  * Rust toolchain absent => reference cannot be run here); pinned at tolerance
- * level against the reference's own known-answer test (qr/mod.rs:116-191),
- * its matmul doctests and LAPACK residual checks (tests/test_oracle.py).
+ * level against the reference's own known-answer tests (qr/mod.rs:116-191,
+ * reductions/norm_l2.rs:216-218), its matmul doctests, its property tests and
+ * LAPACK (residuals; geqp3's permutation for the col-pivot QR) -- tests/test_oracle.py.
  */
 #include <float.h>
 #include <math.h>
