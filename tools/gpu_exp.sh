@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 O=gpurun_out/exp.log
 : > $O
-run() { timeout 240 env "$@" python tools/gpu_exp_l2.py $WHAT $N >> $O 2>&1 || echo "FAILED: $* $WHAT" >> $O; }
+run() { timeout 240 env "$@" python tools/gpu_exp_one.py $WHAT $N >> $O 2>&1 || echo "FAILED: $* $WHAT" >> $O; }
 N=16384
 WHAT=lu
 run FAER_HIP_LU_SPLIT=0

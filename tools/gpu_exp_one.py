@@ -1,5 +1,5 @@
 """One-process experiment: XCC placement of the internal streams, LU / LLT timings under the current env switches
-(FAER_HIP_PANEL_MASK, FAER_HIP_PANEL_L2, FAER_HIP_LLT_MERGE, FAER_HIP_LLT_DPANEL).  GPU box only."""
+("Environment switches").  GPU box only."""
 import collections
 import ctypes
 import os
