@@ -109,3 +109,16 @@ def test_driver_planning_logic_needs_no_gpu():
     assert w(200000, F.DTYPE_F64, 256) == 32 and w(600000, F.DTYPE_F64, 256) == 8
     assert w(1048576, F.DTYPE_F64, 256) == 8 and w(1048577, F.DTYPE_F64, 256) == 0
     assert w(300000, F.DTYPE_F32, 256) == 32 and w(2097152, F.DTYPE_F32, 256) == 8 and w(2097153, F.DTYPE_F32, 256) == 0
+
+
+def test_header_is_valid_c99_and_cxx17(tmp_path):
+    """include/faer_hip.h is the drop-in boundary: it must compile on its own as plain C and as C++"""
+    import shutil
+    import subprocess
+
+    for comp, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++17", "cpp")):
+        if shutil.which(comp) is None:
+            pytest.skip(f"{comp} not available")
+        src = tmp_path / f"hdr.{ext}"
+        src.write_text('#include "faer_hip.h"\nint main(void) { return 0; }\n')
+        subprocess.check_call([comp, std, "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
