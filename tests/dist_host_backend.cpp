@@ -150,6 +150,9 @@ long test_dist_lu_f64(double *a_local, long m, long local_ncols, long ld, long n
 	HostBackend::View A{a_local, m, local_ncols, 1, ld};
 	fh::DistLu<HostBackend>::run(be, A, m, n, nb, rank, world, ws.data(), piv_out);
 	stats[0] = be.bytes_bcast;
+	stats[1] = (unsigned long long) (be.begun[0] + be.begun[1]);
+	stats[2] = (unsigned long long) (be.waited[0] + be.waited[1]);
+	stats[3] = (unsigned long long) (be.begun[0] > be.begun[1] ? be.begun[0] - be.begun[1] : be.begun[1] - be.begun[0]);
 	return be.n_bcast;
 }
 // returns what DistLlt::run returns; stats[0] = bytes broadcast, stats[1] = number of broadcasts

@@ -55,7 +55,8 @@ piv = np.zeros(min(m, n), dtype=np.int32)
 stats = (C.c_ulonglong * 4)()
 nbc = lib.test_dist_lu_f64(a_loc.ctypes.data_as(C.c_void_p), C.c_long(m), C.c_long(a_loc.shape[1]), C.c_long(max(m, 1)), C.c_long(n), C.c_long(nb),
                            rank, world, cb, None, piv.ctypes.data_as(C.c_void_p), stats)
-np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cols=np.array(cols, dtype=np.int64), a_loc=a_loc, piv=piv, nbc=nbc, bytes=stats[0])
+np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cols=np.array(cols, dtype=np.int64), a_loc=a_loc, piv=piv, nbc=nbc, bytes=stats[0],
+         begun=stats[1], waited=stats[2], slot_skew=stats[3])
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -107,3 +108,5 @@ def test_dist_lu_matches_single_process_oracle(tmp_path, oracle, world, m, n, nb
     expect_bytes = sum(hdr + (m - k * nb) * min(nb, size - k * nb) * 8 for k in range(nblk))
     for r in res:
         assert int(r["nbc"]) == nblk and int(r["bytes"]) == expect_bytes
+        # look-ahead protocol: every broadcast begun once and awaited once, the two buffer slots used alternately
+        assert int(r["begun"]) == nblk and int(r["waited"]) == nblk and int(r["slot_skew"]) <= 1
