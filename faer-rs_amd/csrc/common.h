@@ -39,6 +39,11 @@ namespace fh {
 
 typedef long idx_t;
 
+// typed fused multiply-add: __builtin_fma is the DOUBLE builtin -- called with floats it converts to fp64 and back
+// (three extra conversions per operation and the quarter-rate fp64 pipe); templates must use this overload pair
+static __device__ __forceinline__ double fh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+static __device__ __forceinline__ float fh_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 template <typename T> struct MatV {
 	T *p;
 	idx_t nrows, ncols, rs, cs;
@@ -209,7 +214,6 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 template <typename T> bool gemv_dev(idx_t m, idx_t k, MatV<const T> A, const T *x, idx_t xs, T *y, idx_t ys, T alpha, bool add);
 template <typename T> void rank1_dev(MatV<T> C, bool add, const T *a, idx_t as, const T *b, idx_t bs, T alpha);
 // extras.hip / trsm.hip: triangular inverse (triangular_inverse.rs) and helpers of the reconstruct / inverse entry points
-template <typename T> void trtri_diag_dev(MatV<const T> L, bool unit, T *W);
 template <typename T> void tri_invert_lower_dev(MatV<T> dst, MatV<const T> src, bool unit);
 template <typename T> void ldlt_scale_lower_dev(MatV<T> out, MatV<const T> L, const T *d, idx_t ds);
 template <typename T> void ldlt_inverse_prepare_dev(MatV<T> W, const T *d, idx_t ds);
@@ -236,8 +240,9 @@ void matmul_triangular_dev(MatV<T> C, int c_s, bool add, MatV<const T> A, int a_
 // X <- op(T)^-1 X, T lower triangular n x n, X n x k (trsm.hip); upper handled by reversal
 template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X);
 template <typename T> void trsm_upper_dev(MatV<const T> U, bool unit, MatV<T> X);
-// same as trsm_lower_dev (non unit) with the inverses of L's 128 x 128 diagonal blocks precomputed in W
+// same as trsm_lower_dev with the packed images (trsm_pack.h) of L's 128 x 128 diagonal blocks already in W
 template <typename T> void trsm_lower_pre_dev(MatV<const T> L, MatV<T> X, const T *W);
+template <typename T> void trsm_pack_dev(MatV<const T> L, bool unit, T *W);
 
 // in-place lower Cholesky; returns >=0 regularization count or -(index+1)   (potrf.hip)
 template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps);

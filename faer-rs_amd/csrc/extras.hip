@@ -8,8 +8,37 @@
 // MFMA inversions of trsm.hip (all diagonal blocks in ONE launch), and every level above is two structured
 // products per block pair (only the lower triangles of dst are read, its strict upper triangle is never touched).
 #include "common.h"
+#include "lds_blocks.h"
 
 namespace fh {
+
+// The only consumer of explicit 128 x 128 block inverses left in the library: triangular_inverse.rs IS an explicit
+// inverse.  One 512-thread workgroup per diagonal block, all blocks in one launch (lds_blocks.h: 16 x 16 blocks by
+// substitution, then recursive doubling on the MFMA pipe in LDS).
+template <typename T>
+__global__ __launch_bounds__(LDS_NT) void trtri_diag_kernel(const T *__restrict__ Lp, idx_t lrs, idx_t lcs, int n, int unit,
+							   T *__restrict__ W)
+{
+	// W block b: column major 128 x 128, inverse of L[b*128 .., b*128 ..] (identity padded, zeros above)
+	__shared__ T S[LDS_NB * LDS_LDP];
+	const int b = blockIdx.x;
+	const int r0 = b * LDS_NB;
+	const int nb = min(LDS_NB, n - r0);
+	lds_load_lower<T>(S, Lp + (idx_t) r0 * lrs + (idx_t) r0 * lcs, lrs, lcs, nb);
+	__syncthreads();
+	lds_tri_inv_inplace<T>(S, unit);
+	lds_store_block<T>(S, W + (size_t) b * LDS_NB * LDS_NB, 1, LDS_NB, LDS_NB, false);
+}
+
+template <typename T> static void trtri_diag_dev(MatV<const T> L, bool unit, T *W)
+{
+	const idx_t n = L.nrows;
+	if (n == 0)
+		return;
+	const idx_t nblk = (n + LDS_NB - 1) / LDS_NB;
+	hipLaunchKernelGGL(trtri_diag_kernel<T>, dim3((unsigned) nblk), dim3(LDS_NT), 0, ctx().stream, L.p, L.rs, L.cs, (int) n, unit ? 1 : 0, W);
+	FH_HIP(hipGetLastError());
+}
 
 // dst(lower [strict]) <- W blocks: block b of the diagonal from W + b * 128 * 128 (column major 128 x 128)
 template <typename T>

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void fplu_update_kernel(T *V, idx_t rs, idx_t 
 			if (i < m) {
 				T x = v[jj][r];
 				if (do_update) {
-					x = __builtin_fma(-l[r], u[jj], x);
+					x = fh_fma(-l[r], u[jj], x);
 					V[(idx_t) i * rs + (idx_t) j * cs] = x;
 				}
 				const FpBest c{fabs((double) x), i, j};

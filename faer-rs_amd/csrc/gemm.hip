@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				else if (g.atomic)
 					atomicAdd(ptr[r][i], g.alpha * v);
 				else if (g.add)
-					*ptr[r][i] = __builtin_fma(g.alpha, v, old[r][i]);
+					*ptr[r][i] = fh_fma(g.alpha, v, old[r][i]);
 				else
 					*ptr[r][i] = g.alpha * v;
 			}
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 #pragma unroll
 				for (int i = 0; i < TM; ++i)
 					if ((okmask >> (r * TM + i)) & 1u)
-						*ptr[r][i] = __builtin_fma(g.alpha, acc[i][j][r], *ptr[r][i]);
+						*ptr[r][i] = fh_fma(g.alpha, acc[i][j][r], *ptr[r][i]);
 			continue;
 		}
 		if (g.add && !g.atomic) {
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				else if (g.atomic)
 					atomicAdd(ptr[r][i], g.alpha * v);
 				else if (g.add)
-					*ptr[r][i] = __builtin_fma(g.alpha, v, old[r][i]);
+					*ptr[r][i] = fh_fma(g.alpha, v, old[r][i]);
 				else
 					*ptr[r][i] = g.alpha * v;
 			}
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(T *dst, idx_t drs, i
 		for (int k = 0; k < 16; ++k)
 			sum += part[k][le];
 		T *p = dst + (idx_t) m * drs + (idx_t) n * dcs;
-		*p = add ? __builtin_fma(alpha, sum, *p) : alpha * sum;
+		*p = add ? fh_fma(alpha, sum, *p) : alpha * sum;
 	}
 }
 

@@ -33,16 +33,16 @@ __global__ __launch_bounds__(256) void gemv_mn_kernel(int m, int k, const T *__r
 	for (; p + 4 <= k1; p += 4) {
 #pragma unroll
 		for (int u = 0; u < 4; ++u)
-			acc[u] = __builtin_fma(ap[(idx_t) (p + u) * acs], x[(idx_t) (p + u) * xs], acc[u]);
+			acc[u] = fh_fma(ap[(idx_t) (p + u) * acs], x[(idx_t) (p + u) * xs], acc[u]);
 	}
 	for (; p < k1; ++p)
-		acc[0] = __builtin_fma(ap[(idx_t) p * acs], x[(idx_t) p * xs], acc[0]);
+		acc[0] = fh_fma(ap[(idx_t) p * acs], x[(idx_t) p * xs], acc[0]);
 	const T s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 	T *yp = y + (idx_t) i * ys;
 	if (atomic)
 		part[(size_t) blockIdx.y * m + i] = s; // slices are added in index order by gemv_reduce_kernel
 	else if (add)
-		*yp = __builtin_fma(alpha, s, *yp);
+		*yp = fh_fma(alpha, s, *yp);
 	else
 		*yp = alpha * s;
 }
@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(int m, int k, const T *__re
 	for (; p + 192 < k1; p += 256) {
 #pragma unroll
 		for (int u = 0; u < 4; ++u)
-			acc[u] = __builtin_fma(ap[(idx_t) (p + 64 * u) * acs], x[(idx_t) (p + 64 * u) * xs], acc[u]);
+			acc[u] = fh_fma(ap[(idx_t) (p + 64 * u) * acs], x[(idx_t) (p + 64 * u) * xs], acc[u]);
 	}
 	for (; p < k1; p += 64)
-		acc[0] = __builtin_fma(ap[(idx_t) p * acs], x[(idx_t) p * xs], acc[0]);
+		acc[0] = fh_fma(ap[(idx_t) p * acs], x[(idx_t) p * xs], acc[0]);
 	T s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
 	for (int off = 32; off >= 1; off >>= 1)
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void gemv_k_kernel(int m, int k, const T *__re
 		if (atomic)
 			part[(size_t) blockIdx.y * m + i] = s;
 		else if (add)
-			*yp = __builtin_fma(alpha, s, *yp);
+			*yp = fh_fma(alpha, s, *yp);
 		else
 			*yp = alpha * s;
 	}
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void gemv_reduce_kernel(int m, int slices, con
 		for (int k = 0; k < 16; ++k)
 			sum += sp[k][le];
 		T *yp = y + (idx_t) i * ys;
-		*yp = add ? __builtin_fma(alpha, sum, *yp) : alpha * sum;
+		*yp = add ? fh_fma(alpha, sum, *yp) : alpha * sum;
 	}
 }
 
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void rank1_kernel(int m, int n, T *c, idx_t cr
 	for (int j = blockIdx.y; j < n; j += gridDim.y) {
 		T *p = c + (idx_t) i * crs + (idx_t) j * ccs;
 		const T bj = b[(idx_t) j * bs];
-		*p = add ? __builtin_fma(ai, bj, *p) : ai * bj;
+		*p = add ? fh_fma(ai, bj, *p) : ai * bj;
 	}
 }
 

@@ -331,7 +331,7 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 #pragma unroll
 					for (int k = 0; k < 8; ++k)
 						if (cb * 8 + k > JJ)
-							x[i][cb * 8 + k] = __builtin_fma(l[i], -u[k], x[i][cb * 8 + k]); // rank_update_imp: fma(l_i, -u_c, dst)
+							x[i][cb * 8 + k] = fh_fma(l[i], -u[k], x[i][cb * 8 + k]); // rank_update_imp: fma(l_i, -u_c, dst)
 				}
 			}
 		}

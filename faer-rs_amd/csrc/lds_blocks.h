@@ -79,7 +79,7 @@ template <typename T> static __device__ void lds_tri_inv_inplace(T *S, int unit)
 			T s = (i == c) ? (T) 1 : (T) 0;
 #pragma unroll
 			for (int k = 0; k < i; ++k)
-				s = __builtin_fma(-li[k], w[k], s);
+				s = fh_fma(-li[k], w[k], s);
 			w[i] = s * lane_bcast(dl, i);
 			asm volatile("" ::: "memory"); // keep the next rows' loads from piling up in registers
 		}

@@ -19,13 +19,14 @@
 //   * semantics of the reference's base kernel (factor.rs:122-174): d = a_jj (optionally regularised and
 //     counted), fail with the GLOBAL column index if !(d > 0), every entry of column j -- the diagonal one
 //     included -- is multiplied by the reciprocal 1 / sqrt(d).
-// The leaf also inverts its own L_kk in place in LDS (lds_tri_inv_inplace) and stores the inverse in the
-// factorization's workspace: the TRSMs of all enclosing recursion levels then run as MFMA GEMMs against those
-// inverses (trsm_lower_pre_dev) with no further triangular kernels.
+// The leaf also writes the PACKED IMAGE of its L_kk (trsm_pack.h) into the factorization's workspace: the panel
+// solves of all enclosing levels substitute against it (trsm_lower_pre_dev: substitution inside the 128-blocks like
+// the reference's triangular_solve.rs, MFMA products off the diagonal) without a separate packing launch.
 // Failure is reported through a device status word (first failing GLOBAL column index + 1); later
 // kernels see it and become no-ops, so the host synchronises exactly once per factorization.
 #include "common.h"
 #include "lds_blocks.h"
+#include "trsm_pack.h"
 
 namespace fh {
 
@@ -43,11 +44,11 @@ static __device__ __forceinline__ bool recip_sqrt(double d, double &inv)
 	if (d > 1e-280 && d < 1e280) {
 		const double y = __builtin_amdgcn_rsq(d);
 		double g = d * y, h = 0.5 * y;
-		double r = __builtin_fma(-h, g, 0.5);
-		g = __builtin_fma(g, r, g);
-		h = __builtin_fma(h, r, h);
-		r = __builtin_fma(-h, g, 0.5);
-		h = __builtin_fma(h, r, h);
+		double r = fh_fma(-h, g, 0.5);
+		g = fh_fma(g, r, g);
+		h = fh_fma(h, r, h);
+		r = fh_fma(-h, g, 0.5);
+		h = fh_fma(h, r, h);
 		inv = h + h;
 		return true;
 	}
@@ -185,12 +186,12 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 							mult[k] = colj[j0 + k] * wj;
 						if (j + 1 < POTRF_PB) {
 							// critical path: next diagonal entry through v_readlane, then its pivot
-							a[j + 1] = __builtin_fma(-lj, lane_bcast(lj, j + 1) * wj, a[j + 1]);
+							a[j + 1] = fh_fma(-lj, lane_bcast(lj, j + 1) * wj, a[j + 1]);
 							ok = pivot(lane_bcast(a[j + 1], j + 1), j0 + j + 1, inv, dj);
 						}
 #pragma unroll
 						for (int k = j + 2; k < POTRF_PB; ++k)
-							a[k] = __builtin_fma(-lj, mult[k], a[k]); // a_ik -= l_ij (d_j) l_kj
+							a[k] = fh_fma(-lj, mult[k], a[k]); // a_ik -= l_ij (d_j) l_kj
 					}
 				}
 			}
@@ -256,11 +257,31 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 	if (tid == 0 && count > 0)
 		atomicAdd(status + 1, count);
 	if (Winv) {
+		// packed image of L_kk for the substitution leaf of the panel solves (unit diagonal for LDLT)
+		typedef TriPack<T> P;
+		__shared__ int toff[TP_H];
+		if (tid < TP_H)
+			toff[tid] = P::tri_off(tid);
+		for (int e = tid; e < P::TRI; e += LDS_NT) {
+			Winv[P::OFF_T00 + e] = (T) 0;
+			Winv[P::OFF_T11 + e] = (T) 0;
+		}
 		__syncthreads();
-		lds_tri_inv_inplace<T>(S, LDLT ? 1 : 0);
+		for (int e = tid; e < LDS_NB * LDS_NB; e += LDS_NT) {
+			const int i = e % LDS_NB, j = e / LDS_NB;
+			if (j > i)
+				continue;
+			const T v = S[j * LDS_LDP + i];
+			if (i == j)
+				Winv[P::OFF_DINV + i] = (LDLT || i >= n) ? (T) 1 : (T) 1 / v;
+			else if (i < TP_H)
+				Winv[P::OFF_T00 + toff[j] + (i - j - 1)] = v;
+			else if (j >= TP_H)
+				Winv[P::OFF_T11 + toff[j - TP_H] + (i - j - 1)] = v;
+			else
+				Winv[P::OFF_T10 + (i - TP_H) * TP_H + j] = v;
+		}
 		FH_LT(4);
-		lds_store_block<T>(S, Winv, 1, LDS_NB, LDS_NB, false);
-		FH_LT(5);
 	}
 #ifdef FH_LEAF_TIMING
 	if (tid == 0)
@@ -276,7 +297,7 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 	if (n == 0)
 		return;
 	if (n <= POTRF_NB) {
-		T *W = need_inv ? Wbase + (size_t) (offset / POTRF_NB) * POTRF_NB * POTRF_NB : nullptr;
+		T *W = need_inv ? Wbase + (size_t) (offset / POTRF_NB) * TriPack<T>::SIZE : nullptr;
 		hipLaunchKernelGGL((potrf_leaf_kernel<T, false>), dim3(1), dim3(LDS_NT), 0, ctx().stream, A.p, A.rs, A.cs, (int) n, regularize,
 				   eps, delta, status, (int) offset, W, (const signed char *) nullptr, (T *) nullptr);
 		FH_HIP(hipGetLastError());
@@ -286,7 +307,7 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 	MatV<T> A00 = A.sub(0, 0, h, h), A10 = A.sub(h, 0, n - h, h), A11 = A.sub(h, h, n - h, n - h);
 	potrf_rec<T>(A00, regularize, eps, delta, status, offset, Wbase, true);
 	// A10 <- A10 L00^-T, expressed like the reference (cholesky/ldlt/factor.rs:422-426) as L00 \ A10^T
-	trsm_lower_pre_dev<T>(A00.c(), A10.t(), Wbase + (size_t) (offset / POTRF_NB) * POTRF_NB * POTRF_NB);
+	trsm_lower_pre_dev<T>(A00.c(), A10.t(), Wbase + (size_t) (offset / POTRF_NB) * TriPack<T>::SIZE);
 	// lower(A11) -= A10 A10^T  (cholesky/ldlt/factor.rs:436-446 -> triangular.rs:602 DstKind::Lower)
 	gemm_dev<T>(A11, DST_LOWER, true, A10.c(), A10.t().c(), (T) -1);
 	potrf_rec<T>(A11, regularize, eps, delta, status, offset + h, Wbase, need_inv);
@@ -295,8 +316,8 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 // Left-looking factorization of a tall panel P (R x w, R >= w; the top w x w block is the diagonal block) in 128
 // column blocks -- three launches per block on ONE dependent chain:
 //     block column j  -=  P[c0:, 0:c0] P[c0:c0+128, 0:c0]^T   (lower trapezoid, one GEMM with K = c0)
-//     leaf on the diagonal block                               (also yields its inverse W_j)
-//     rows below      <-  rows below * W_j^T                   (in-place MFMA product)
+//     leaf on the diagonal block                               (also yields the packed image W_j of L_jj)
+//     rows below      <-  rows below * L_jj^-T                 (substitution leaf against W_j, trsm.hip)
 // instead of the ~38 launches of the recursion above for 8 blocks.  Used where the diagonal-block chain is the
 // critical path (look-ahead panel stream, and the sequential tail where R is small enough that every launch is
 // latency bound anyway).  Same operations per entry as cholesky/ldlt/factor.rs:367-498 grouped by block columns.
@@ -309,59 +330,19 @@ static void potrf_panel_flat(MatV<T> P, int regularize, T eps, T delta, int *sta
 		const idx_t nb = POTRF_NB < w - c0 ? POTRF_NB : w - c0;
 		if (c0 > 0)
 			gemm_dev<T>(P.sub(c0, c0, R - c0, nb), DST_LOWER, true, P.sub(c0, 0, R - c0, c0).c(), P.sub(c0, 0, nb, c0).t().c(), (T) -1);
-		T *W = Wbase + (size_t) ((offset + c0) / POTRF_NB - wblk0) * POTRF_NB * POTRF_NB;
+		T *W = Wbase + (size_t) ((offset + c0) / POTRF_NB - wblk0) * TriPack<T>::SIZE;
 		MatV<T> D = P.sub(c0, c0, nb, nb);
 		hipLaunchKernelGGL((potrf_leaf_kernel<T, false>), dim3(1), dim3(LDS_NT), 0, ctx().stream, D.p, D.rs, D.cs, (int) nb, regularize, eps,
 				   delta, status, (int) (offset + c0), W, (const signed char *) nullptr, (T *) nullptr);
 		FH_HIP(hipGetLastError());
-		if (R > c0 + nb) {
-			MatV<T> below = P.sub(c0 + nb, c0, R - c0 - nb, nb);
-			MatV<const T> Winv{W, nb, nb, 1, POTRF_NB};
-			GemmExtra<T> ex;
-			ex.inplace = 2; // the lhs aliases dst
-			gemm_dev<T>(below, DST_FULL, false, below.c(), Winv.t(), (T) 1, &ex);
-		}
+		if (R > c0 + nb) // rows below <- rows below * L_kk^-T: substitution leaf, lanes along the rows of the panel
+			trsm_lower_pre_dev<T>(D.c(), P.sub(c0 + nb, c0, R - c0 - nb, nb).t(), W);
 	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// Full inverse of a diagonal step block from the inverses of its 128-blocks (recursive doubling,
-// inv([L11 0; L21 L22]) = [W11 0; -W22 L21 W11, W22], every product an MFMA GEMM).  The look-ahead driver
-// builds it on the panel stream so that the panel solve of the bulk stream is two large GEMMs instead of a
-// recursion of many skinny ones.
-// ------------------------------------------------------------------------------------------------
-template <typename T> __global__ void place_diag_blocks_kernel(T *Wf, idx_t ld, const T *Wblk)
-{
-	// workgroup b copies the 128 x 128 inverse of block b onto the diagonal of Wf
-	const T *src = Wblk + (size_t) blockIdx.x * POTRF_NB * POTRF_NB;
-	T *dst = Wf + (idx_t) blockIdx.x * POTRF_NB * (ld + 1);
-	for (int e = threadIdx.x; e < POTRF_NB * POTRF_NB; e += blockDim.x) {
-		const int i = e % POTRF_NB, j = e / POTRF_NB;
-		dst[(idx_t) j * ld + i] = src[e];
-	}
-}
-
-template <typename T> static void tri_inv_full(MatV<const T> L, const T *Wblk, MatV<T> Wf, MatV<T> Tmp)
-{
-	const idx_t n = L.nrows;
-	FH_CHECK(n % POTRF_NB == 0 && Wf.nrows == n && Wf.ncols == n && Wf.rs == 1, "tri_inv_full: shape");
-	fill_dev<T>(Wf, DST_FULL, (T) 0);
-	hipLaunchKernelGGL(place_diag_blocks_kernel<T>, dim3((unsigned) (n / POTRF_NB)), dim3(256), 0, ctx().stream, Wf.p, Wf.cs,
-			   Wblk);
-	FH_HIP(hipGetLastError());
-	for (idx_t h = POTRF_NB; h < n; h *= 2)
-		for (idx_t base = 0; base + h < n; base += 2 * h) {
-			const idx_t h2 = (n - base - h) < h ? (n - base - h) : h; // rows of the lower block (ragged tail)
-			MatV<const T> W11 = Wf.sub(base, base, h, h).c(), W22 = Wf.sub(base + h, base + h, h2, h2).c();
-			MatV<T> Tm = Tmp.sub(base + h, base, h2, h), W21 = Wf.sub(base + h, base, h2, h);
-			gemm_dev<T>(Tm, DST_FULL, false, L.sub(base + h, base, h2, h), W11, (T) 1);
-			gemm_dev<T>(W21, DST_FULL, false, W22, Tm.c(), (T) -1);
-		}
 }
 
 // Right-looking driver with look-ahead for large matrices: steps of LA_NB columns,
 //     [panel stream]  D_k = chol(A_kk)                         (recursive driver above; latency bound, few CUs)
-//     [bulk stream]   P_k = A_{>k,k} L_kk^-T                   (MFMA products against the leaf inverses)
+//     [bulk stream]   P_k = A_{>k,k} L_kk^-T                   (in place: substitution leaves + MFMA products)
 //     [bulk stream]   A_{k+1,k+1} -= P_k[0] P_k[0]^T           -> releases D_{k+1} on the panel stream
 //     [bulk stream]   rest of the trailing matrix -= P_k P_k^T (K = LA_NB: compute bound)
 // The diagonal-block factorizations -- a chain of ~130 small dependent launches each -- run concurrently with
@@ -412,32 +393,21 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		ks = 0;
 	const idx_t tail0 = ks > 0 ? J[(size_t) ks] : 0;
 	if (ks > 0) {
-		idx_t wmax = LA_NB;
-		for (idx_t k = 0; k < ks; ++k)
-			wmax = J[(size_t) k + 1] - J[(size_t) k] > wmax ? J[(size_t) k + 1] - J[(size_t) k] : wmax;
 		c.reset_events();
 		hipEvent_t e0 = c.next_event();
 		FH_HIP(hipEventRecord(e0, caller));
 		stream_wait(c.la_bulk, e0);
 		stream_wait(c.la_panel, e0);
-		// workspaces: two full step-block inverses (double buffered over the steps), a temporary for building them,
-		// and two buffers for the out-of-place result X_k of the panel solve (the updates of step k read X_k, its
-		// copy into A happens off the critical path while step k+1 already fills the other buffer)
-		Scratch wfb((size_t) 2 * wmax * wmax * sizeof(T)), tmb((size_t) wmax * wmax * sizeof(T));
-		const size_t xsz = (size_t) (n - LA_NB) * wmax;
-		Scratch xb(2 * xsz * sizeof(T));
-		auto Wfull = [&](idx_t k, idx_t w) { return MatV<T>{wfb.as<T>() + (size_t) (k & 1) * wmax * wmax, w, w, 1, w}; };
-		hipEvent_t ev_diag; // D_k factored (and inverted)
+		hipEvent_t ev_diag; // D_k factored (its packed 128-blocks are in Wbase)
 		{
 			StreamScope sc(c.la_panel);
 			const idx_t w0 = J[1];
 			potrf_panel_flat<T>(A.sub(0, 0, w0, w0), regularize, eps, delta, status, 0, Wbase);
-			tri_inv_full<T>(A.sub(0, 0, w0, w0).c(), Wbase, Wfull(0, w0), MatV<T>{tmb.as<T>(), w0, w0, 1, w0});
 			ev_diag = c.next_event();
 			FH_HIP(hipEventRecord(ev_diag, c.la_panel));
 		}
 		// trailing size from which the update of the next diagonal block runs on the panel stream (it has slack to
-		// spare while the trailing matrix is large, and the bulk stream then issues two launches per step)
+		// spare while the trailing matrix is large, and the bulk stream then issues fewer launches per step)
 		const idx_t dpanel_rmin = getenv("FAER_HIP_LLT_DPANEL") ? atol(getenv("FAER_HIP_LLT_DPANEL")) : 8192;
 		for (idx_t k = 0; k < ks; ++k) {
 			const idx_t j0 = J[(size_t) k], j1 = J[(size_t) k + 1], w = j1 - j0; // panel columns [j0, j1)
@@ -445,21 +415,18 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 			const bool last = k + 1 == ks;					       // the tail driver takes over after this step
 			const idx_t w1 = last ? 0 : J[(size_t) k + 2] - j1;		       // width of the next look-ahead panel
 			MatV<T> Pk = A.sub(j1, j0, r, w);
-			MatV<T> X{xb.as<T>() + (size_t) (k & 1) * xsz, r, w, 1, r};
-			MatV<const T> X0 = X.sub(0, 0, w1, w).c();
+			MatV<const T> X = Pk.c(), X0 = Pk.sub(0, 0, w1, w).c();
 			const bool d_on_panel = !last && dpanel_rmin > 0 && r >= dpanel_rmin;
 			hipEvent_t ev_upd;
 			{
 				StreamScope sc(c.la_bulk);
 				stream_wait(c.la_bulk, ev_diag);
-				// X_k = P_k L_kk^-T  (cholesky/ldlt/factor.rs:422-426) as P_k W_k^T, W_k = inv(L_kk).  One launch: W_k^T
-				// is upper triangular with an explicitly zero lower part, every tile stops its K loop at the end of its
-				// own diagonal block (3/4 of the flops of the full product on average)
-				GemmExtra<T> ex;
-				ex.k_trim = 1;
-				gemm_dev<T>(X, DST_FULL, false, Pk.c(), Wfull(k, w).c().t(), (T) 1, &ex);
+				// P_k <- P_k L_kk^-T in place (cholesky/ldlt/factor.rs:422-426): the reference's TRSM recursion on the
+				// 128-blocks of L_kk -- substitution leaves against the packed diagonal blocks the panel stream
+				// left in Wbase, MFMA products in between
+				trsm_lower_pre_dev<T>(A.sub(j0, j0, w, w).c(), Pk.t(), Wbase + (size_t) (j0 / POTRF_NB) * TriPack<T>::SIZE);
 				if (last) {
-					gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X.c(), X.t().c(), (T) -1);
+					gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1);
 				} else if (!d_on_panel) { // next diagonal block first
 					gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
 				}
@@ -474,24 +441,16 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 				// triangle of the whole trailing matrix minus its leading w1 rows
 				GemmExtra<T> ex;
 				ex.tri_skip = w1;
-				gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X.c(), X.t().c(), (T) -1, &ex);
+				gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1, &ex);
 			}
-			{
+			if (!last) {
 				StreamScope sc(c.la_panel);
 				stream_wait(c.la_panel, ev_upd);
-				if (!last) {
-					if (d_on_panel)
-						gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
-					potrf_panel_flat<T>(A.sub(j1, j1, w1, w1), regularize, eps, delta, status, j1, Wbase);
-					// the next step is a look-ahead step as well: it solves against the full inverse
-					tri_inv_full<T>(A.sub(j1, j1, w1, w1).c(), Wbase + (size_t) (j1 / POTRF_NB) * POTRF_NB * POTRF_NB, Wfull(k + 1, w1),
-							MatV<T>{tmb.as<T>(), w1, w1, 1, w1});
-					ev_diag = c.next_event();
-					FH_HIP(hipEventRecord(ev_diag, c.la_panel));
-				}
-				// L_{>k,k} = X_k goes home after the next step has been released (X buffer k & 1 is rewritten by the
-				// solve of step k+2, which waits for the diagonal block k+2, i.e. for this copy)
-				copy_dev<T>(Pk, X.c());
+				if (d_on_panel)
+					gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
+				potrf_panel_flat<T>(A.sub(j1, j1, w1, w1), regularize, eps, delta, status, j1, Wbase);
+				ev_diag = c.next_event();
+				FH_HIP(hipEventRecord(ev_diag, c.la_panel));
 			}
 		}
 		// rejoin the caller's stream
@@ -521,7 +480,7 @@ template <typename T> void potrf_panel_dev(MatV<T> P, T reg_delta, T reg_eps, in
 	if (P.ncols == 0)
 		return;
 	const idx_t nblk = (P.ncols + POTRF_NB - 1) / POTRF_NB;
-	Scratch winv((size_t) nblk * POTRF_NB * POTRF_NB * sizeof(T));
+	Scratch winv((size_t) nblk * TriPack<T>::BYTES);
 	const int regularize = (reg_delta > (T) 0 && reg_eps > (T) 0) ? 1 : 0;
 	potrf_panel_flat<T>(P, regularize, reg_eps, reg_delta, status_dev, offset, winv.as<T>(), offset / POTRF_NB);
 }
@@ -540,7 +499,7 @@ template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps)
 	FH_HIP(hipMemsetAsync(status, 0, 64, ctx().stream));
 	// one 128 x 128 inverse per diagonal block (only the blocks that some TRSM will use are filled)
 	const idx_t nblk = (n + POTRF_NB - 1) / POTRF_NB;
-	Scratch winv(n > POTRF_NB ? (size_t) nblk * POTRF_NB * POTRF_NB * sizeof(T) : 256);
+	Scratch winv(n > POTRF_NB ? (size_t) nblk * TriPack<T>::BYTES : 256);
 	const int regularize = (reg_delta > (T) 0 && reg_eps > (T) 0) ? 1 : 0; // cholesky/llt/factor.rs:85-86
 	// FAER_HIP_LLT_LA_MIN / FAER_HIP_LLT_TAIL: thresholds of the blocked driver (tests lower them to reach every
 	// code path at small sizes)
@@ -589,7 +548,7 @@ static void sytrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 	if (n == 0)
 		return;
 	if (n <= POTRF_NB) {
-		T *W = need_inv ? Wbase + (size_t) (offset / POTRF_NB) * POTRF_NB * POTRF_NB : nullptr;
+		T *W = need_inv ? Wbase + (size_t) (offset / POTRF_NB) * TriPack<T>::SIZE : nullptr;
 		hipLaunchKernelGGL((potrf_leaf_kernel<T, true>), dim3(1), dim3(LDS_NT), 0, ctx().stream, A.p, A.rs, A.cs, (int) n, regularize, eps,
 				   delta, status, (int) offset, W, signs, Dv);
 		FH_HIP(hipGetLastError());
@@ -599,7 +558,7 @@ static void sytrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 	MatV<T> A00 = A.sub(0, 0, h, h), A10 = A.sub(h, 0, n - h, h), A11 = A.sub(h, h, n - h, n - h);
 	sytrf_rec<T>(A00, regularize, eps, delta, status, offset, Wbase, true, signs, Dv);
 	// A10 <- A10 L00^-T (unit lower; the leaf inverses were taken of the unit triangles) = L10 D0
-	trsm_lower_pre_dev<T>(A00.c(), A10.t(), Wbase + (size_t) (offset / POTRF_NB) * POTRF_NB * POTRF_NB);
+	trsm_lower_pre_dev<T>(A00.c(), A10.t(), Wbase + (size_t) (offset / POTRF_NB) * TriPack<T>::SIZE);
 	// A10 <- L10 = A10 D0^-1
 	{
 		const idx_t total = (n - h) * h;
@@ -630,7 +589,7 @@ template <typename T> long sytrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps, co
 	int *status = st.as<int>();
 	FH_HIP(hipMemsetAsync(status, 0, 64, ctx().stream));
 	const idx_t nblk = (n + POTRF_NB - 1) / POTRF_NB;
-	Scratch winv(n > POTRF_NB ? (size_t) nblk * POTRF_NB * POTRF_NB * sizeof(T) : 256);
+	Scratch winv(n > POTRF_NB ? (size_t) nblk * TriPack<T>::BYTES : 256);
 	Scratch dv((size_t) n * sizeof(T)), sg((size_t) n + 256);
 	const int regularize = (reg_delta > (T) 0 && reg_eps > (T) 0) ? 1 : 0; // cholesky/ldlt/factor.rs:766-767
 	const signed char *signs = nullptr;

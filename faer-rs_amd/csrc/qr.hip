@@ -1023,7 +1023,7 @@ template <typename T> __global__ __launch_bounds__(256) void cp_flush_kernel(con
 	const T d = a.dot[j];
 	for (int i = a.k + threadIdx.x; i < a.m; i += 256) {
 		T *p = a.A + (idx_t) i * a.rs + (idx_t) j * a.cs;
-		*p = __builtin_fma(a.A[(idx_t) i * a.rs + (idx_t) (a.k - 1) * a.cs], d, *p);
+		*p = fh_fma(a.A[(idx_t) i * a.rs + (idx_t) (a.k - 1) * a.cs], d, *p);
 	}
 	__syncthreads();
 	const T v = cp_col_norm<T>(a, a.k, j, s_part, s_red);
@@ -1158,10 +1158,10 @@ template <typename T> __global__ __launch_bounds__(256) void cp_update_kernel(co
 		T *p = a.A + (idx_t) i * a.rs + (idx_t) j * a.cs;
 		T dst = *p;
 		if (delayed) {
-			dst = __builtin_fma(a.A[(idx_t) i * a.rs + (idx_t) (k - 1) * a.cs], b0, dst);
+			dst = fh_fma(a.A[(idx_t) i * a.rs + (idx_t) (k - 1) * a.cs], b0, dst);
 			*p = dst;
 		}
-		acc = __builtin_fma(a.A[(idx_t) i * a.rs + (idx_t) k * a.cs], dst, acc);
+		acc = fh_fma(a.A[(idx_t) i * a.rs + (idx_t) k * a.cs], dst, acc);
 	}
 	double accd[1] = {(double) acc};
 	cp_block_sum<1>(accd, s_part, s_red);

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void skinny_update_kernel(int M, int N, int K,
 				for (int r = 0; r < R; ++r)
 #pragma unroll
 					for (int u = 0; u < U; ++u)
-						acc[r][u] = __builtin_fma(av[r][k], bv[u], acc[r][u]);
+						acc[r][u] = fh_fma(av[r][k], bv[u], acc[r][u]);
 			}
 		}
 #pragma unroll
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void skinny_update_kernel(int M, int N, int K,
 #pragma unroll
 			for (int u = 0; u < U; ++u)
 				if (m < M && n0 + u < N)
-					c[(idx_t) m * crs + (idx_t) (n0 + u) * ccs] = add ? __builtin_fma(alpha, acc[r][u], cv[r][u]) : alpha * acc[r][u];
+					c[(idx_t) m * crs + (idx_t) (n0 + u) * ccs] = add ? fh_fma(alpha, acc[r][u], cv[r][u]) : alpha * acc[r][u];
 		}
 	}
 }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(int M, int N, int K,
 				for (int i = 0; i < 8; ++i)
 #pragma unroll
 					for (int j = 0; j < 8; ++j)
-						acc[i][j] = __builtin_fma(av[h][i], bv[h][j], acc[i][j]);
+						acc[i][j] = fh_fma(av[h][i], bv[h][j], acc[i][j]);
 			}
 		}
 	}

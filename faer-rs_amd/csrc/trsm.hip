@@ -15,6 +15,7 @@
 // every kernel here takes signed strides so the reversal is free.
 #include "common.h"
 #include "lds_blocks.h"
+#include "trsm_pack.h"
 
 namespace fh {
 
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64) void trsm_leaf_kernel(const T *__restrict__ Lp,
 			x[j] = xj;
 #pragma unroll
 			for (int i = j + 1; i < NB; ++i)
-				x[i] = __builtin_fma(-Ls[j * NB + i], xj, x[i]);
+				x[i] = fh_fma(-Ls[j * NB + i], xj, x[i]);
 		}
 	}
 
@@ -118,67 +119,276 @@ __global__ __launch_bounds__(64) void trsm_leaf_kernel(const T *__restrict__ Lp,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Many right-hand sides: invert the 128 x 128 diagonal blocks once (one workgroup per block, all blocks in
-// ONE launch, MFMA recursive doubling in LDS -- lds_blocks.h) and turn every leaf of the recursion into an
-// MFMA GEMM  X_k <- inv(T_kk) X_k.  The product is done IN PLACE with a tile that covers the whole aliased
-// dimension (gemm.hip, GemmExtra::inplace).
+// Many right-hand sides / large triangles.  The reference's recursion (triangular_solve.rs:452-484: solve with
+// the top-left block, eliminate it from the rows below with ONE GEMM, recurse on the bottom-right block) runs
+// on 128-row blocks; every off-diagonal step is an MFMA GEMM, every 128 x 128 diagonal block is solved by
+// SUBSTITUTION in trsm_leaf128_kernel -- no explicit inverses anywhere (round 1 multiplied by inverted diagonal
+// blocks, whose error grows with cond(T_kk); substitution is backward stable like the reference).
+//
+// trsm_leaf128_kernel: one workgroup = 2 wavefronts, each wavefront 64 right-hand sides, one per lane.
+//   * the packed image of the diagonal block (trsm_pack.h: two packed 64 x 64 triangles, the 64 x 64 block
+//     between them, reciprocal diagonal) is copied to LDS with 16-byte loads; every multiplier is then a
+//     wave-uniform LDS broadcast;
+//   * half 0: the lane's 64 values sit in registers, column-oriented substitution (2016 FMAs, the diagonal
+//     enters as a reciprocal like triangular_solve.rs:113);  half 1: b_i - sum_j t_ij x_j for the 64 rows below
+//     with the solved x_j still in registers (64 x 64 FMAs per lane, four partial sums), then the same
+//     substitution code on the second triangle.  fp64 vector FMA runs at the MFMA rate on gfx950, so nothing
+//     is lost against a matrix-core formulation and no layout change is needed between the phases;
+//   * global accesses run along whichever stride of X is the small one: directly when that is the right-hand
+//     side index (rows of a transposed Cholesky panel), through a padded LDS tile otherwise (columns of X).
 // ------------------------------------------------------------------------------------------------
-constexpr int TRSM_IB = LDS_NB;
+constexpr int TRSM_IB = TP_NB;
+constexpr int TL_XP = TP_H + 1; // pitch of the per-wave 64 x 64 exchange tile
 
+// W block b <- packed image of the b-th 128 x 128 diagonal block of the lower triangular L
 template <typename T>
-__global__ __launch_bounds__(LDS_NT) void trtri_diag_kernel(const T *__restrict__ Lp, idx_t lrs, idx_t lcs, int n, int unit,
-							   T *__restrict__ W)
+__global__ __launch_bounds__(256) void trsm_pack_kernel(const T *__restrict__ Lp, idx_t lrs, idx_t lcs, int n, int unit, T *__restrict__ W)
 {
-	// W block b: column major TRSM_IB x TRSM_IB, inverse of L[b*IB .., b*IB ..] (identity padded, zeros above)
-	__shared__ T S[LDS_NB * LDS_LDP];
+	typedef TriPack<T> P;
+	__shared__ int toff[TP_H];
 	const int b = blockIdx.x;
-	const int r0 = b * TRSM_IB;
-	const int nb = min(TRSM_IB, n - r0);
-	lds_load_lower<T>(S, Lp + (idx_t) r0 * lrs + (idx_t) r0 * lcs, lrs, lcs, nb);
+	const int r0 = b * TP_NB;
+	const int nb = min(TP_NB, n - r0);
+	if (threadIdx.x < TP_H)
+		toff[threadIdx.x] = P::tri_off(threadIdx.x);
+	T *img = W + (size_t) b * P::SIZE;
+	// alignment holes of the packed triangles must read as zeros (they are multiplied into padding lanes only, but
+	// NaN garbage would still propagate): clear the two triangles first
+	for (int e = threadIdx.x; e < P::TRI; e += blockDim.x) {
+		img[P::OFF_T00 + e] = (T) 0;
+		img[P::OFF_T11 + e] = (T) 0;
+	}
 	__syncthreads();
-	lds_tri_inv_inplace<T>(S, unit);
-	lds_store_block<T>(S, W + (size_t) b * TRSM_IB * TRSM_IB, 1, TRSM_IB, TRSM_IB, false);
+	const T *L0 = Lp + (idx_t) r0 * lrs + (idx_t) r0 * lcs;
+	constexpr int U = 8;
+	for (int e0 = threadIdx.x; e0 < TP_NB * TP_NB; e0 += 256 * U) {
+		T v[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int e = e0 + u * 256;
+			const int i = e % TP_NB, j = e / TP_NB;
+			const bool in = i < nb && j <= i;
+			const T x = L0[in ? (idx_t) i * lrs + (idx_t) j * lcs : (idx_t) 0];
+			v[u] = in ? x : (T) 0;
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int e = e0 + u * 256;
+			const int i = e % TP_NB, j = e / TP_NB;
+			if (j > i)
+				continue;
+			if (i == j) {
+				img[P::OFF_DINV + i] = (unit || i >= nb) ? (T) 1 : (T) 1 / v[u];
+			} else if (i < TP_H) {
+				img[P::OFF_T00 + toff[j] + (i - j - 1)] = v[u];
+			} else if (j >= TP_H) {
+				img[P::OFF_T11 + toff[j - TP_H] + (i - j - 1)] = v[u];
+			} else {
+				img[P::OFF_T10 + (i - TP_H) * TP_H + j] = v[u];
+			}
+		}
+	}
 }
 
-// W block b <- inverse of the b-th 128 x 128 diagonal block of the lower triangular L (identity padded)
-template <typename T> void trtri_diag_dev(MatV<const T> L, bool unit, T *W)
+template <typename T> void trsm_pack_dev(MatV<const T> L, bool unit, T *W)
 {
 	const idx_t n = L.nrows;
 	if (n == 0)
 		return;
-	const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
-	hipLaunchKernelGGL(trtri_diag_kernel<T>, dim3((unsigned) nblk), dim3(LDS_NT), 0, ctx().stream, L.p, L.rs, L.cs, (int) n, unit ? 1 : 0, W);
+	const idx_t nblk = (n + TP_NB - 1) / TP_NB;
+	hipLaunchKernelGGL(trsm_pack_kernel<T>, dim3((unsigned) nblk), dim3(256), 0, ctx().stream, L.p, L.rs, L.cs, (int) n, unit ? 1 : 0, W);
 	FH_HIP(hipGetLastError());
 }
-template void trtri_diag_dev<double>(MatV<const double>, bool, double *);
-template void trtri_diag_dev<float>(MatV<const float>, bool, float *);
+template void trsm_pack_dev<double>(MatV<const double>, bool, double *);
+template void trsm_pack_dev<float>(MatV<const float>, bool, float *);
 
-template <typename T> static void trsm_inv_rec(MatV<const T> L, MatV<T> X, const T *W, idx_t b0)
+// column-oriented substitution on one packed 64 x 64 triangle: x <- tri^-1 x, multipliers from LDS broadcasts
+template <typename T> static __device__ __forceinline__ void tl_subst(T (&x)[TP_H], const T *__restrict__ tri, const T *__restrict__ dinv)
+{
+	typedef TriPack<T> P;
+#pragma unroll
+	for (int j = 0; j < TP_H; ++j) {
+		const T xj = x[j] * dinv[j];
+		x[j] = xj;
+#pragma unroll
+		for (int i = j + 1; i < TP_H; ++i)
+			x[i] = fh_fma(-tri[P::tri_off(j) + (i - j - 1)], xj, x[i]);
+		if ((j & 3) == 3)
+			asm volatile("" ::: "memory"); // keep the broadcast loads of later columns from piling up in registers
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__ img, int n, T *Xp, idx_t xss, idx_t xcs, int nrhs,
+							   int lanes_along_rhs)
+{
+	typedef TriPack<T> P;
+	extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
+	T *Ls = reinterpret_cast<T *>(tl_smem); // packed image
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	T *Xs = Ls + P::SIZE + wave * (TP_H * TL_XP); // this wave's 64 x 65 exchange tile: Xs[s * TL_XP + c]
+	const int c0 = (blockIdx.x * 2 + wave) * 64;
+	const int nc = min(64, nrhs - c0); // may be <= 0 for the second wave of the last workgroup
+	const bool act = lane < nc;
+
+	// ---- packed triangle -> LDS, 16-byte loads (the image is 16-byte aligned and a multiple of 16 bytes long)
+	{
+		typedef int v4i __attribute__((ext_vector_type(4)));
+		const v4i *src = reinterpret_cast<const v4i *>(img);
+		v4i *dst = reinterpret_cast<v4i *>(Ls);
+		constexpr int NV = (int) (P::BYTES / 16);
+		for (int e = threadIdx.x; e < NV; e += 128)
+			dst[e] = src[e];
+	}
+	// rows s0 .. s0+63 of this wave's 64 right-hand sides -> Xs (zero padded), lanes along the small stride
+	auto load_half = [&](int s0) {
+		const int ns = min(TP_H, n - s0);
+		if (lanes_along_rhs) {
+#pragma unroll
+			for (int i0 = 0; i0 < TP_H; i0 += 16) {
+				T v[16];
+#pragma unroll
+				for (int u = 0; u < 16; ++u) {
+					const bool in = i0 + u < ns && act;
+					const T t = Xp[in ? (idx_t) (s0 + i0 + u) * xss + (idx_t) (c0 + lane) * xcs : (idx_t) 0];
+					v[u] = in ? t : (T) 0;
+				}
+#pragma unroll
+				for (int u = 0; u < 16; ++u)
+					Xs[(i0 + u) * TL_XP + lane] = v[u];
+			}
+		} else {
+			for (int cc = 0; cc < 64; cc += 8) {
+				T v[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					const bool in = cc + u < nc && lane < ns;
+					const T t = Xp[in ? (idx_t) (s0 + lane) * xss + (idx_t) (c0 + cc + u) * xcs : (idx_t) 0];
+					v[u] = in ? t : (T) 0;
+				}
+#pragma unroll
+				for (int u = 0; u < 8; ++u)
+					Xs[lane * TL_XP + cc + u] = v[u];
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	};
+	auto store_half = [&](int s0) {
+		const int ns = min(TP_H, n - s0);
+		__builtin_amdgcn_wave_barrier();
+		if (lanes_along_rhs) {
+#pragma unroll 8
+			for (int i = 0; i < TP_H; ++i)
+				if (i < ns && act)
+					Xp[(idx_t) (s0 + i) * xss + (idx_t) (c0 + lane) * xcs] = Xs[i * TL_XP + lane];
+		} else {
+			for (int cc = 0; cc < nc; cc += 8) {
+				T v[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u)
+					v[u] = Xs[lane * TL_XP + min(cc + u, 63)];
+#pragma unroll
+				for (int u = 0; u < 8; ++u)
+					if (cc + u < nc && lane < ns)
+						Xp[(idx_t) (s0 + lane) * xss + (idx_t) (c0 + cc + u) * xcs] = v[u];
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	};
+
+	// ---- half 0: substitution on T00 (lane = right-hand side, register = row)
+	T y[TP_H];
+	load_half(0);
+#pragma unroll
+	for (int i = 0; i < TP_H; ++i)
+		y[i] = Xs[i * TL_XP + lane];
+	__syncthreads(); // the image is in LDS
+	tl_subst<T>(y, Ls + P::OFF_T00, Ls + P::OFF_DINV);
+#pragma unroll
+	for (int i = 0; i < TP_H; ++i)
+		Xs[i * TL_XP + lane] = y[i];
+	store_half(0);
+	if (n <= TP_H)
+		return;
+	// ---- half 1: b_i - sum_j T10(i, j) y_j with the solved y_j still in registers and the rows of T10 as LDS
+	// broadcasts (four partial sums per row), then the same substitution on T11
+	load_half(TP_H);
+	{
+		const T *t10 = Ls + P::OFF_T10;
+#pragma unroll 2
+		for (int i = 0; i < TP_H; ++i) {
+			T a0 = (T) 0, a1 = (T) 0, a2 = (T) 0, a3 = (T) 0;
+			const T *row = t10 + i * TP_H;
+#pragma unroll
+			for (int j = 0; j < TP_H; j += 4) {
+				a0 = fh_fma(row[j], y[j], a0);
+				a1 = fh_fma(row[j + 1], y[j + 1], a1);
+				a2 = fh_fma(row[j + 2], y[j + 2], a2);
+				a3 = fh_fma(row[j + 3], y[j + 3], a3);
+			}
+			Xs[i * TL_XP + lane] -= (a0 + a1) + (a2 + a3);
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	T z[TP_H];
+#pragma unroll
+	for (int i = 0; i < TP_H; ++i)
+		z[i] = Xs[i * TL_XP + lane];
+	tl_subst<T>(z, Ls + P::OFF_T11, Ls + P::OFF_DINV + TP_H);
+#pragma unroll
+	for (int i = 0; i < TP_H; ++i)
+		Xs[i * TL_XP + lane] = z[i];
+	store_half(TP_H);
+}
+
+template <typename T> static size_t trsm_leaf128_lds()
+{
+	return TriPack<T>::BYTES + (size_t) 2 * TP_H * TL_XP * sizeof(T);
+}
+
+// X (n <= 128 rows) <- T^-1 X with the packed image of T
+template <typename T> static void trsm_leaf128_launch(const T *img, MatV<T> X)
+{
+	const idx_t n = X.nrows, k = X.ncols;
+	if (n == 0 || k == 0)
+		return;
+	FH_CHECK(n <= TP_NB && k < (1L << 31), "trsm leaf: shape");
+	static bool attr_done = false; // raise the dynamic LDS limit once per process and type
+	if (!attr_done) {
+		FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_leaf128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+					   (int) trsm_leaf128_lds<T>()));
+		attr_done = true;
+	}
+	auto ab = [](idx_t v) { return v < 0 ? -v : v; };
+	const int along_rhs = ab(X.cs) <= ab(X.rs) ? 1 : 0;
+	hipLaunchKernelGGL(trsm_leaf128_kernel<T>, dim3((unsigned) ((k + 127) / 128)), dim3(128), trsm_leaf128_lds<T>(), ctx().stream, img, (int) n,
+			   X.p, X.rs, X.cs, (int) k, along_rhs);
+	FH_HIP(hipGetLastError());
+}
+
+template <typename T> static void trsm_rec(MatV<const T> L, MatV<T> X, const T *W, idx_t b0)
 {
 	const idx_t n = L.nrows, k = X.ncols;
 	if (n <= TRSM_IB) {
-		MatV<const T> Winv{W + (size_t) b0 * TRSM_IB * TRSM_IB, n, n, 1, TRSM_IB};
-		GemmExtra<T> ex;
-		ex.inplace = 1; // X (the rhs operand) aliases dst; n <= 128 rows => one tile along the aliased dimension
-		gemm_dev<T>(X, DST_FULL, false, Winv, X.c(), (T) 1, &ex);
+		trsm_leaf128_launch<T>(W + (size_t) b0 * TriPack<T>::SIZE, X);
 		return;
 	}
 	const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
 	const idx_t top = (nblk / 2) * TRSM_IB;
 	MatV<T> Xt = X.sub(0, 0, top, k), Xb = X.sub(top, 0, n - top, k);
-	trsm_inv_rec<T>(L.sub(0, 0, top, top), Xt, W, b0);
+	trsm_rec<T>(L.sub(0, 0, top, top), Xt, W, b0);
 	gemm_dev<T>(Xb, DST_FULL, true, L.sub(top, 0, n - top, top), Xt.c(), (T) -1);
-	trsm_inv_rec<T>(L.sub(top, top, n - top, n - top), Xb, W, b0 + top / TRSM_IB);
+	trsm_rec<T>(L.sub(top, top, n - top, n - top), Xb, W, b0 + top / TRSM_IB);
 }
 
-// X <- L^-1 X with the inverses of L's 128 x 128 diagonal blocks already in W (block i at W + i * 128 * 128,
-// column major, identity padded): the Cholesky leaves produce them as a by-product (potrf.hip).
+// X <- L^-1 X with the packed images of L's 128 x 128 diagonal blocks already in W (block i at
+// W + i * TriPack<T>::SIZE): the Cholesky leaves produce them as a by-product (potrf.hip).
 template <typename T> void trsm_lower_pre_dev(MatV<const T> L, MatV<T> X, const T *W)
 {
 	FH_CHECK(L.nrows == L.ncols && X.nrows == L.nrows, "trsm: shape mismatch");
 	if (L.nrows == 0 || X.ncols == 0)
 		return;
-	trsm_inv_rec<T>(L, X, W, 0);
+	trsm_rec<T>(L, X, W, 0);
 }
 
 // triangular_solve.rs:200-215
@@ -203,30 +413,20 @@ template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X)
 	const idx_t n = L.nrows, k = X.ncols;
 	if (n == 0 || k == 0)
 		return;
-	if (n > 64 || k >= 64) { // explicit 128-block inverses + MFMA products; tiny solves keep the register leaf
+	if (n > 64 || k >= 64) { // packed diagonal blocks + substitution leaves + MFMA products off the diagonal
 		const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
-		Scratch wb((size_t) nblk * TRSM_IB * TRSM_IB * sizeof(T));
-		hipLaunchKernelGGL(trtri_diag_kernel<T>, dim3((unsigned) nblk), dim3(LDS_NT), 0, ctx().stream, L.p, L.rs, L.cs,
-				   (int) n, unit ? 1 : 0, wb.as<T>());
-		FH_HIP(hipGetLastError());
-		trsm_inv_rec<T>(L, X, wb.as<T>(), 0);
+		Scratch wb((size_t) nblk * TriPack<T>::BYTES);
+		trsm_pack_dev<T>(L, unit, wb.as<T>());
+		trsm_rec<T>(L, X, wb.as<T>(), 0);
 		return;
 	}
-	if (n <= 64) {
-		auto ab = [](idx_t v) { return v < 0 ? -v : v; };
-		const int along_rhs = ab(X.cs) <= ab(X.rs) ? 1 : 0;
-		FH_CHECK(k < (1L << 31), "trsm: too many right-hand sides");
-		hipLaunchKernelGGL(trsm_leaf_kernel<T>, dim3((unsigned) ((k + 63) / 64)), dim3(64), 0, ctx().stream, L.p, L.rs,
-				   L.cs, (int) n, unit ? 1 : 0, X.p, X.rs, X.cs, (int) k, along_rhs);
-		FH_HIP(hipGetLastError());
-		return;
-	}
-	// triangular_solve.rs:452-484: solve the top block, eliminate it from the bottom rows by GEMM, recurse
-	const idx_t bs = trsm_block_size(n);
-	MatV<T> top = X.sub(0, 0, bs, k), bot = X.sub(bs, 0, n - bs, k);
-	trsm_lower_dev<T>(L.sub(0, 0, bs, bs), unit, top);
-	gemm_dev<T>(bot, DST_FULL, true, L.sub(bs, 0, n - bs, bs), top.c(), (T) -1);
-	trsm_lower_dev<T>(L.sub(bs, bs, n - bs, n - bs), unit, bot);
+	// tiny solve: one wavefront stages the triangle itself (a single launch)
+	auto ab = [](idx_t v) { return v < 0 ? -v : v; };
+	const int along_rhs = ab(X.cs) <= ab(X.rs) ? 1 : 0;
+	FH_CHECK(k < (1L << 31), "trsm: too many right-hand sides");
+	hipLaunchKernelGGL(trsm_leaf_kernel<T>, dim3((unsigned) ((k + 63) / 64)), dim3(64), 0, ctx().stream, L.p, L.rs, L.cs, (int) n,
+			   unit ? 1 : 0, X.p, X.rs, X.cs, (int) k, along_rhs);
+	FH_HIP(hipGetLastError());
 }
 
 template <typename T> void trsm_upper_dev(MatV<const T> U, bool unit, MatV<T> X)
