@@ -242,6 +242,11 @@ def gemm(dst, dst_kind, accum, lhs, rhs, alpha=1.0, row_idx=None, col_idx=None, 
     def idx(v):
         if v is None:
             return None, 1
+        if _is_torch(v):  # device index array: int32 / int64 storage read as u32 / u64 (indices are non-negative)
+            import torch
+
+            assert v.dtype in (torch.int32, torch.int64) and v.is_contiguous()
+            return C.c_void_p(v.data_ptr()), (1 if v.dtype == torch.int64 else 0)
         assert v.dtype in (np.uint32, np.uint64)
         return C.c_void_p(v.ctypes.data), (1 if v.dtype == np.uint64 else 0)
 

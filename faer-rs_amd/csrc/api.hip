@@ -688,7 +688,7 @@ void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m, size_t n, s
 		ex.col_idx = col_idx ? ci.dev.p : nullptr;
 		ex.idx64 = isz == 8;
 		ex.diag = diag ? dg.dev.p : nullptr;
-		ex.diag_stride = (idx_t) diag_stride;
+		ex.diag_stride = dg.dev.rs; // 1 for a staged host vector, the caller's stride for a device one
 		MatV<T> Cv{c.dev.p, (idx_t) m, (idx_t) n, c.dev.rs, c.dev.cs};
 		gemm_dev<T>(Cv, (DstKind) dst_kind, add, a.dev, b.dev, *static_cast<const T *>(alpha), &ex);
 	};

@@ -140,40 +140,93 @@ template <typename T> inline void view_span(const MatV<T> &v, idx_t &lo, idx_t &
 	hi = (r > 0 ? r : 0) + (c > 0 ? c : 0);
 }
 
-// Host->device staging of one operand.  If the view already lives in device memory it is used in
-// place; otherwise the (contiguous span of the) view is copied to a scratch buffer keeping the strides,
-// and copied back on destruction when `writeback` is set.
+// Host->device staging of one operand.  If the view already lives in device memory it is used in place;
+// otherwise EXACTLY the elements of the view are copied into a dense device buffer (and copied back on
+// destruction when `writeback` is set).  The gaps of a strided host view -- the parent matrix's entries between
+// the columns of a `submatrix_mut`, which other rayon workers may be writing at the same time -- are never read
+// and never written (round 1 staged the whole contiguous span and wrote it back, gaps included).
+//   * unit row stride, positive column stride (a faer::Mat or a block of one): one hipMemcpy2DAsync, column major;
+//   * unit column stride, positive row stride (a transposed view): the same, row major;
+//   * anything else (negative / non-unit strides): packed through a temporary host buffer.
 template <typename T> struct Staged {
+	typedef typename std::remove_const<T>::type U;
 	MatV<T> dev;
-	T *host_base = nullptr;
+	MatV<T> host;
 	void *buf = nullptr;
-	size_t bytes = 0;
+	U *pack = nullptr; // host-side packing buffer (mode 3)
+	int mode = 0;	   // 0: device operand, 1: column-major 2-D copy, 2: row-major 2-D copy, 3: host packed (column major)
 	bool writeback = false;
+
+	// host pitch (elements) of the 2-D copy; a single column / row may carry any outer stride (even 0)
+	idx_t hpitch() const
+	{
+		if (mode == 1)
+			return host.ncols == 1 ? host.nrows : host.cs;
+		return host.nrows == 1 ? host.ncols : host.rs;
+	}
 
 	Staged(MatV<T> v, bool copy_in, bool writeback_)
 	{
-		typedef typename std::remove_const<T>::type U;
 		dev = v;
+		host = v;
 		if (v.nrows == 0 || v.ncols == 0 || is_device_ptr(v.p))
 			return;
-		idx_t lo, hi;
-		view_span(v, lo, hi);
-		bytes = (size_t)(hi - lo + 1) * sizeof(T);
+		const size_t bytes = (size_t) v.nrows * (size_t) v.ncols * sizeof(T);
 		buf = ctx().alloc(bytes);
-		host_base = const_cast<T *>(v.p) + lo;
-		if (copy_in)
-			FH_HIP(hipMemcpyAsync(buf, (const void *)host_base, bytes, hipMemcpyHostToDevice, ctx().stream));
-		dev.p = reinterpret_cast<T *>(static_cast<U *>(buf) - lo);
 		writeback = writeback_;
+		const idx_t pitch_limit = (idx_t) 1 << 30; // bytes; beyond it (never for a real Mat) fall back to packing
+		if (v.rs == 1 && (v.cs >= v.nrows || v.ncols == 1) && v.cs * (idx_t) sizeof(T) < pitch_limit) {
+			mode = 1;
+			dev = MatV<T>{static_cast<T *>(buf), v.nrows, v.ncols, 1, v.nrows};
+		} else if (v.cs == 1 && (v.rs >= v.ncols || v.nrows == 1) && v.rs * (idx_t) sizeof(T) < pitch_limit) {
+			mode = 2;
+			dev = MatV<T>{static_cast<T *>(buf), v.nrows, v.ncols, v.ncols, 1};
+		} else {
+			mode = 3;
+			dev = MatV<T>{static_cast<T *>(buf), v.nrows, v.ncols, 1, v.nrows};
+			pack = static_cast<U *>(malloc(bytes));
+			FH_CHECK(pack != nullptr, "staging: out of host memory");
+		}
+		if (!copy_in)
+			return;
+		if (mode == 1) {
+			FH_HIP(hipMemcpy2DAsync(buf, (size_t) v.nrows * sizeof(T), (const void *) v.p, (size_t) hpitch() * sizeof(T),
+						(size_t) v.nrows * sizeof(T), (size_t) v.ncols, hipMemcpyHostToDevice, ctx().stream));
+		} else if (mode == 2) {
+			FH_HIP(hipMemcpy2DAsync(buf, (size_t) v.ncols * sizeof(T), (const void *) v.p, (size_t) hpitch() * sizeof(T),
+						(size_t) v.ncols * sizeof(T), (size_t) v.nrows, hipMemcpyHostToDevice, ctx().stream));
+		} else {
+			for (idx_t j = 0; j < v.ncols; ++j)
+				for (idx_t i = 0; i < v.nrows; ++i)
+					pack[j * v.nrows + i] = v.p[i * v.rs + j * v.cs];
+			FH_HIP(hipMemcpyAsync(buf, pack, bytes, hipMemcpyHostToDevice, ctx().stream));
+			FH_HIP(hipStreamSynchronize(ctx().stream)); // `pack` is reused by the write-back
+		}
 	}
 	~Staged()
 	{
 		if (!buf)
 			return;
 		if (writeback) {
-			FH_HIP(hipMemcpyAsync((void *)host_base, buf, bytes, hipMemcpyDeviceToHost, ctx().stream));
-			FH_HIP(hipStreamSynchronize(ctx().stream));
+			U *hp = const_cast<U *>(host.p);
+			if (mode == 1) {
+				FH_HIP(hipMemcpy2DAsync((void *) hp, (size_t) hpitch() * sizeof(T), buf, (size_t) host.nrows * sizeof(T),
+							(size_t) host.nrows * sizeof(T), (size_t) host.ncols, hipMemcpyDeviceToHost, ctx().stream));
+				FH_HIP(hipStreamSynchronize(ctx().stream));
+			} else if (mode == 2) {
+				FH_HIP(hipMemcpy2DAsync((void *) hp, (size_t) hpitch() * sizeof(T), buf, (size_t) host.ncols * sizeof(T),
+							(size_t) host.ncols * sizeof(T), (size_t) host.nrows, hipMemcpyDeviceToHost, ctx().stream));
+				FH_HIP(hipStreamSynchronize(ctx().stream));
+			} else {
+				FH_HIP(hipMemcpyAsync(pack, buf, (size_t) host.nrows * (size_t) host.ncols * sizeof(T), hipMemcpyDeviceToHost,
+						      ctx().stream));
+				FH_HIP(hipStreamSynchronize(ctx().stream));
+				for (idx_t j = 0; j < host.ncols; ++j)
+					for (idx_t i = 0; i < host.nrows; ++i)
+						hp[i * host.rs + j * host.cs] = pack[j * host.nrows + i];
+			}
 		}
+		free(pack);
 		ctx().release(buf);
 	}
 	Staged(const Staged &) = delete;

@@ -1246,6 +1246,30 @@ template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, 
 template long colpiv_qr_dev<double>(MatV<double>, MatV<double>, idx_t *, idx_t *);
 template long colpiv_qr_dev<float>(MatV<float>, MatV<float>, idx_t *, idx_t *);
 
+// Backup copy of A for the fast path, fused with the range guard of the fp64 fast path: the cooperative leaf
+// accumulates PLAIN squares and dot products in fp64 (exact for fp32 data, whose squares cannot leave the fp64
+// range), whereas the reference's norm_l2 keeps three differently scaled accumulators
+// (reductions/norm_l2.rs:6-45,173-184) and stays accurate for |x| ~ 1e+-250.  fp64 data with a non-zero entry
+// outside [1e-120, 1e120] (or a non-finite one) therefore raises the "abandon the fast path" flag and the
+// factorization runs on the general path, which restates norm_l2 literally.
+template <typename T>
+__global__ void copy_guard_kernel(T *d, idx_t drs, idx_t dcs, const T *s, idx_t srs, idx_t scs, idx_t M, idx_t N, int *flag)
+{
+	const idx_t total = M * N;
+	bool bad = false;
+	for (idx_t e = (idx_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (idx_t) gridDim.x * blockDim.x) {
+		const idx_t i = e % M, j = e / M;
+		const T v = s[i * srs + j * scs];
+		d[i * drs + j * dcs] = v;
+		if constexpr (sizeof(T) == 8) {
+			const double av = fabs((double) v);
+			bad = bad || (av != 0.0 && !(av >= 1e-120 && av <= 1e120));
+		}
+	}
+	if (__any(bad) && (threadIdx.x & 63) == 0)
+		atomicExch(flag, 1);
+}
+
 template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold)
 {
 	(void) blocking_threshold; // the GPU recursion always blocks; leaves are 8 columns wide
@@ -1274,7 +1298,21 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 	Scratch backup(fast_ok ? (size_t) m * (size_t) n * sizeof(T) : 256);
 	MatV<T> Bk{backup.as<T>(), m, n, 1, m};
 	if (fast_ok) {
-		copy_dev<T>(Bk, A.c());
+		{
+			const idx_t total = m * n;
+			idx_t blocks = (total + 255) / 256;
+			if (blocks > 65536)
+				blocks = 65536;
+			MatV<T> Ad = A, Bd = Bk;
+			auto ab = [](idx_t x) { return x < 0 ? -x : x; };
+			if (ab(Ad.cs) < ab(Ad.rs)) { // fast index along the smaller stride
+				Ad = Ad.t();
+				Bd = Bd.t();
+			}
+			hipLaunchKernelGGL(copy_guard_kernel<T>, dim3((unsigned) blocks), dim3(256), 0, s, Bd.p, Bd.rs, Bd.cs, Ad.p, Ad.rs, Ad.cs,
+					   Ad.nrows, Ad.ncols, status + 3);
+			FH_HIP(hipGetLastError());
+		}
 		Scratch slots((size_t) 2 * QR_GMAX * QR_SLOT * sizeof(double)), head((size_t) 2 * (QR_PW + 1) * sizeof(double));
 		QrWork<T> wk;
 		wk.slots = slots.as<double>();

@@ -231,14 +231,23 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	const int nc = min(64, nrhs - c0); // may be <= 0 for the second wave of the last workgroup
 	const bool act = lane < nc;
 
-	// ---- packed triangle -> LDS, 16-byte loads (the image is 16-byte aligned and a multiple of 16 bytes long)
+	// ---- packed triangle -> LDS, 16-byte loads (the image is 16-byte aligned and a multiple of 16 bytes long);
+	// batches of 11 independent loads per thread: three memory round trips for the whole image, not one per vector
 	{
 		typedef int v4i __attribute__((ext_vector_type(4)));
 		const v4i *src = reinterpret_cast<const v4i *>(img);
 		v4i *dst = reinterpret_cast<v4i *>(Ls);
-		constexpr int NV = (int) (P::BYTES / 16);
-		for (int e = threadIdx.x; e < NV; e += 128)
-			dst[e] = src[e];
+		constexpr int NV = (int) (P::BYTES / 16), U = 11;
+		for (int e0 = threadIdx.x; e0 < NV; e0 += 128 * U) {
+			v4i v[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+				v[u] = src[min(e0 + u * 128, NV - 1)];
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+				if (e0 + u * 128 < NV)
+					dst[e0 + u * 128] = v[u];
+		}
 	}
 	// rows s0 .. s0+63 of this wave's 64 right-hand sides -> Xs (zero padded), lanes along the small stride
 	auto load_half = [&](int s0) {

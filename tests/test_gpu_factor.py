@@ -183,7 +183,10 @@ def test_plu_vs_oracle(oracle, m, n, dtype):
     assert np.abs(np.tril(lu, -1)).max(initial=0) <= 1.0 + 4 * e
     # same pivot rule as the reference => same permutation (random data has no near ties)
     assert (perm == rperm).all() and nt == rnt
-    assert np.abs(lu - ref).max() <= 64 * max(m, n) * e * max(1.0, np.abs(ref).max()) * 50
+    # factor-level agreement with the oracle: two LU codes with the same pivots differ by the forward error of the
+    # factorization, c n eps kappa, kappa = condition of the pivoted leading block
+    kappa = np.linalg.cond(a[perm][:size, :size].astype(np.float64)) if size > 0 else 1.0
+    assert np.abs(lu - ref).max() <= 4 * max(m, n) * e * kappa * max(1.0, np.abs(ref).max())
 
 
 def test_plu_ties_and_zero_column(oracle):

@@ -147,6 +147,88 @@ def test_gemm_inner_boundary_scatter_and_diag():
     assert np.abs(c - ref).max() < 1e-11
 
 
+@pytest.mark.parametrize("itype", [np.uint32, np.uint64])
+@pytest.mark.parametrize("where", ["host", "device"])
+@pytest.mark.parametrize("kind", ["full", "lower"])
+def test_gemm_inner_boundary_scatter_index_types(itype, where, kind):
+    """spicy_matmul surface (matmul/internal/mod.rs:143-201): u32 AND u64 index arrays, host and device operands,
+    Full and Lower dst (the sparse supernodal callers pass u32 indices and a triangular dst)"""
+    import torch
+
+    F = init_gpu()
+    rng = np.random.default_rng(11)
+    m = n = 150
+    k = 70
+    a, d = rnd(rng, m, k), rng.standard_normal(k)
+    b = np.asfortranarray(a.T) if kind == "lower" else rnd(rng, k, n)
+    c0 = rnd(rng, 400, 400)
+    sel = np.sort(rng.permutation(400)[:m])  # increasing: the lower triangle of the scattered block stays lower
+    ri = sel.astype(itype)
+    ci = (sel if kind == "lower" else rng.permutation(400)[:n]).astype(itype)
+    full = a @ np.diag(d) @ b
+    ref = c0.copy()
+    blk = ref[np.ix_(ri.astype(int), ci.astype(int))]
+    blk += np.tril(full) if kind == "lower" else full
+    ref[np.ix_(ri.astype(int), ci.astype(int))] = blk
+    dk = F.DST_LOWER if kind == "lower" else F.DST_FULL
+    if where == "host":
+        c = c0.copy(order="F")
+        F.gemm(c, dk, F.ACCUM_ADD, a, b, 1.0, row_idx=ri, col_idx=ci, diag=d)
+        got = c
+    else:
+        dc = to_dev(c0)
+        it = np.int32 if itype == np.uint32 else np.int64
+        dri, dci = torch.from_numpy(ri.astype(it)).cuda(), torch.from_numpy(ci.astype(it)).cuda()
+        F.gemm(dc, dk, F.ACCUM_ADD, to_dev(a), to_dev(b), 1.0, row_idx=dri, col_idx=dci, diag=torch.from_numpy(d).cuda())
+        got = to_host(dc)
+    assert np.abs(got - ref).max() < 1e-11
+    untouched = np.ones_like(c0, bool)
+    untouched[np.ix_(ri.astype(int), ci.astype(int))] = False
+    assert (got[untouched] == c0[untouched]).all()
+
+
+@pytest.mark.parametrize("layout", ["F_block", "C_block", "strided", "reversed"])
+@pytest.mark.parametrize("accum", ["replace", "add"])
+def test_host_submatrix_dst_leaves_the_parent_untouched(layout, accum):
+    """a host dst that is a view of a larger matrix -- dst.submatrix_mut(..) of a parent Mat, the
+    call pattern faer's own recursions produce -- must only have ITS elements written; the parent's entries between
+    the view's columns are never read back or rewritten (with Replace they were staged as garbage in round 1)"""
+    F = init_gpu()
+    rng = np.random.default_rng(12)
+    parent0 = rnd(rng, 60, 50, order="F" if layout != "C_block" else "C")
+    parent = parent0.copy(order="K")
+    view = {"F_block": parent[7:37, 5:25], "C_block": parent[7:37, 5:25], "strided": parent[3:57:2, 1:49:3],
+            "reversed": parent[40:10:-1, 30:10:-1]}[layout]
+    m, n = view.shape
+    a, b = rnd(rng, m, 13), rnd(rng, 13, n)
+    before = view.copy()
+    mask = np.zeros(parent.shape, bool)
+    pm = {"F_block": mask[7:37, 5:25], "C_block": mask[7:37, 5:25], "strided": mask[3:57:2, 1:49:3],
+          "reversed": mask[40:10:-1, 30:10:-1]}[layout]
+    pm[...] = True
+    if accum == "replace":
+        view[...] = np.nan  # Replace never reads dst
+        F.matmul(view, F.ACCUM_REPLACE, a, b, 2.0)
+        want = 2.0 * (a @ b)
+    else:
+        F.matmul(view, F.ACCUM_ADD, a, b, 2.0)
+        want = before + 2.0 * (a @ b)
+    assert np.abs(view - want).max() < 1e-12
+    assert (parent[~mask] == parent0[~mask]).all()
+    # the same through the inner boundary (faer_hip_gemm, Full / Replace) and an in-place factorization of a block
+    view[...] = before
+    F.gemm(view, F.DST_FULL, F.ACCUM_REPLACE, a, b, 1.0)
+    assert np.abs(view - a @ b).max() < 1e-12 and (parent[~mask] == parent0[~mask]).all()
+    if m == n:
+        g = rng.standard_normal((m, m))
+        view[...] = g @ g.T + m * np.eye(m)
+        spd = view.copy()
+        assert F.llt_factor_in_place(view) == 0
+        L = np.tril(view)
+        assert np.abs(L @ L.T - spd).max() < 1e-10 * np.abs(spd).max()
+        assert (parent[~mask] == parent0[~mask]).all()
+
+
 def test_matmul_full_size_property():
     """BASELINE config G (N = 8192 fp64): checksum (A B) x == A (B x), independent of the oracle"""
     import torch

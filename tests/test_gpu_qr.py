@@ -243,3 +243,34 @@ def test_colpiv_qr_rank_revealing_property():
     out = to_dev(np.full((m, n), np.nan, order="F"))
     F.qr_reconstruct(out, da, dh)
     assert np.abs(to_host(out) - a[:, cf.astype(int)]).max() <= 256 * m * 2.3e-16 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("m,n", [(9, 10), (1023, 5), (42, 1), (3000, 40)])
+@pytest.mark.parametrize("factor", [1e30, 1e100, 1e160, 1e250, 1e-30, 1e-100, 1e-160, 1e-250])
+def test_qr_norm_l2_scaling_cases(oracle, m, n, factor):
+    """reductions/norm_l2.rs:174-197 (`test_norm_l2` factors) THROUGH qr_factor_in_place: the column norms of an
+    fp64 matrix scaled by 1e+-250 must neither overflow nor underflow (the reference's norm_l2 keeps three scaled
+    accumulators, norm_l2.rs:6-45,173-184).  Same rank, R, V and T as the oracle, relative to the scale."""
+    F = init_gpu()
+    rng = np.random.default_rng(m + n)
+    a = np.asfortranarray(rnd(rng, m, n) * factor)
+    size = min(m, n)
+    bs = max(1, min(F.qr_recommended_block_size(m, n), size))
+    dqr, dh = to_dev(a), to_dev(np.zeros((bs, size)))
+    rank = F.qr_factor_in_place(dqr, dh)
+    qr, h = to_host(dqr), to_host(dh)
+    ref, rh = a.copy(order="F"), np.zeros((bs, size), order="F")
+    assert oracle.qr_in_place(ref, rh) == size and rank == size
+    assert np.isfinite(qr).all()
+    e = EPS[np.dtype(np.float64)]
+    up = np.triu(np.ones((m, n), bool))
+    # R carries the scale, V (below the diagonal) and T do not
+    assert np.abs(qr - ref)[up].max() <= 512 * max(m, n) * e * factor * np.abs(ref / factor)[up].max()
+    assert np.abs(qr - ref)[~up].max(initial=0) <= 512 * max(m, n) * e
+    tu = np.zeros((bs, size), bool)
+    for j0 in range(0, size, bs):
+        w = min(bs, size - j0)
+        tu[:w, j0:j0 + w] = np.triu(np.ones((w, w), bool))
+    fin = np.isfinite(rh)
+    assert (np.isfinite(h) == fin).all()
+    assert np.abs(h - rh)[fin & tu].max(initial=0) <= 512 * max(m, n) * e * max(1.0, np.abs(rh[fin & tu]).max(initial=0))

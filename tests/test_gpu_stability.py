@@ -52,7 +52,7 @@ def test_trsm_is_backward_stable(oracle, kind, n, small_solution, upper, order):
 @pytest.mark.parametrize("dtype", [np.float32])
 @pytest.mark.parametrize("kind", ["mixed", "kahan", "growth"])
 @pytest.mark.parametrize("n", [129, 700])
-def test_trsm_is_backward_stable_f32(kind, n, dtype):
+def test_trsm_is_backward_stable_f32(oracle, kind, n, dtype):
     F = init_gpu()
     rng = np.random.default_rng(n)
     t = sc.triangle(kind, n, rng)
@@ -61,8 +61,13 @@ def test_trsm_is_backward_stable_f32(kind, n, dtype):
     t = t.astype(dtype)
     x0 = rng.standard_normal((n, 33)).astype(dtype)
     b = (t.astype(np.float64) @ x0.astype(np.float64)).astype(dtype)
-    dx = to_dev(b)
     unit = sc.is_unit(kind)
+    ref = b.copy(order="F")
+    with np.errstate(all="ignore"):
+        oracle.trsm(np.asfortranarray(t), ref, upper=False, unit=unit)
+    if not np.isfinite(ref).all():
+        pytest.skip("the substitution itself overflows in fp32 (error growth 2^k)")
+    dx = to_dev(b)
     (F.solve_unit_lower_triangular_in_place if unit else F.solve_lower_triangular_in_place)(to_dev(t), dx)
     got = to_host(dx)
     assert np.isfinite(got).all()
