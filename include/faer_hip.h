@@ -148,6 +148,10 @@ FAER_HIP_API void faer_hip_gemm(FaerHipDType dtype, FaerHipIType itype, size_t m
  * 2. OUTER boundary -- faer-ffi symbol-compatible entry points (f32 / f64).
  *    Each comment cites the Rust function in faer-ffi/src/lib.rs it replaces.
  * --------------------------------------------------------------------------------------------- */
+/* A client that includes the reference's own faer-ffi/faer.h for these prototypes (tests/cabi_client/) defines
+ * FAER_HIP_NO_FFI_PROTOTYPES before including this header and gets the types and the faer_hip_* functions only
+ * (two declarations of one symbol with layout-identical but differently named struct types do not mix in C). */
+#ifndef FAER_HIP_NO_FFI_PROTOTYPES
 /* lib.rs:855-871  la::matmul::matmul */
 FAER_HIP_API void libfaer_v0_23_matmul_f64(FaerMatMut C, FaerAccum accum, FaerMatRef A, FaerMatRef B, const void *alpha, FaerPar par);
 FAER_HIP_API void libfaer_v0_23_matmul_f32(FaerMatMut C, FaerAccum accum, FaerMatRef A, FaerMatRef B, const void *alpha, FaerPar par);
@@ -440,6 +444,7 @@ FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_reconstruct_scratch_u64_f32(size
 FAER_HIP_API void libfaer_v0_23_colpiv_qr_reconstruct_u64_f32(FaerMatMut A, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
 FAER_HIP_API FaerLayout libfaer_v0_23_colpiv_qr_inverse_scratch_u64_f32(size_t dim, size_t block_size, FaerPar par);
 FAER_HIP_API void libfaer_v0_23_colpiv_qr_inverse_u64_f32(FaerMatMut A_inv, FaerMatRef Q_basis, FaerMatRef Q_coeff, FaerMatRef R, FaerSliceRef perm_fwd, FaerSliceRef perm_bwd, FaerPar par, FaerMemAlloc mem);
+#endif /* FAER_HIP_NO_FFI_PROTOTYPES */
 
 /* ---------------------------------------------------------------------------------------------
  * 3. Runtime control (new: the reference has no device).
