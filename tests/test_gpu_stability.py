@@ -3,6 +3,8 @@ held to the backward-error bound that the reference's substitution-based solver 
 (faer/src/linalg/triangular_solve.rs:98-198,452-484) on ill-conditioned inputs -- graded / Kahan / growth / factor
 triangles, right-hand sides with small solutions (stability_cases.py).  The same cases and bounds are run against
 the oracle on the CPU (test_stability_oracle.py)."""
+import functools
+
 import numpy as np
 import pytest
 
@@ -16,14 +18,26 @@ C_TRI = 4.0   # componentwise: |T X - B| <= C_TRI n eps (|T| |X| + |B|)
 C_NORM = 8.0  # normwise: ||A X - B|| <= C_NORM n eps ||A|| ||X||
 
 
+@functools.lru_cache(maxsize=None)
+def _triangle(kind, n):
+    return sc.triangle(kind, n, np.random.default_rng(n + len(kind)))
+
+
+@functools.lru_cache(maxsize=None)
+def _ill(n, cond, spd):
+    return sc.ill_conditioned(n, cond, np.random.default_rng(n + int(spd)), spd=spd)
+
+
 @pytest.mark.parametrize("kind", sc.TRI_KINDS)
 @pytest.mark.parametrize("n", [100, 129, 700, 2000])
 @pytest.mark.parametrize("small_solution", [False, True])
 @pytest.mark.parametrize("upper,order", [(False, "F"), (True, "F"), (False, "C")])
 def test_trsm_is_backward_stable(oracle, kind, n, small_solution, upper, order):
+    if n == 2000 and (upper or order == "C"):
+        pytest.skip("the large size runs once per kind (host-side reference arithmetic dominates the test time)")
     F = init_gpu()
     rng = np.random.default_rng(n + len(kind))
-    t = sc.triangle(kind, n, rng)
+    t = _triangle(kind, n)
     k = 70 if n <= 700 else 9
     b = sc.tri_rhs(t, k, rng, small_solution)
     ref = b.copy(order="F")
@@ -80,7 +94,7 @@ def test_partial_piv_lu_solve_ill_conditioned(n, cond):
     """lu/partial_pivoting/solve.rs: P A = L U, x = U^-1 L^-1 P b; b = A x0 so that the solution is small"""
     F = init_gpu()
     rng = np.random.default_rng(n)
-    a = sc.ill_conditioned(n, cond, rng)
+    a = _ill(n, cond, False)
     x0 = rng.standard_normal((n, 11))
     b = a @ x0
     lu = F.PartialPivLu(to_dev(a))
@@ -98,7 +112,7 @@ def test_qr_solve_ill_conditioned(n, cond):
     """qr/no_pivoting/solve.rs: x = R^-1 Q^T b (cond stays below the reference's rank threshold 16 eps m, factor.rs:52-58)"""
     F = init_gpu()
     rng = np.random.default_rng(n + 1)
-    a = sc.ill_conditioned(n, cond, rng)
+    a = _ill(n, cond, False)
     x0 = rng.standard_normal((n, 11))
     b = a @ x0
     qr = F.Qr(to_dev(a))
@@ -107,18 +121,18 @@ def test_qr_solve_ill_conditioned(n, cond):
     assert sc.norm_backward_error(a, to_host(x), b) <= C_NORM * n * EPS
 
 
-@pytest.mark.parametrize("n", [100, 129, 700, 2000, 4500])
+@pytest.mark.parametrize("n", [100, 129, 700, 2000, 2600])
 @pytest.mark.parametrize("cond", [1e6, 1e12])
 def test_llt_ill_conditioned(n, cond, monkeypatch):
     """cholesky/llt: the factorization's panel solves (A10 L00^-T, cholesky/ldlt/factor.rs:422-426) and llt::solve go
     through the same TRSM; an SPD matrix with cond up to 1e12 must factor with ||L L^T - A|| and the solve's
-    residual at the n eps level.  n = 4500 runs the look-ahead driver (threshold lowered)."""
+    residual at the n eps level.  n = 2600 runs the look-ahead driver (thresholds lowered)."""
     F = init_gpu()
-    if n > 4096:
+    if n > 2048:
         monkeypatch.setenv("FAER_HIP_LLT_LA_MIN", "2048")
         monkeypatch.setenv("FAER_HIP_LLT_TAIL", "1024")
     rng = np.random.default_rng(n + 2)
-    a = sc.ill_conditioned(n, cond, rng, spd=True)
+    a = _ill(n, cond, True)
     d = to_dev(a)
     assert F.llt_factor_in_place(d) == 0
     L = np.tril(to_host(d))
