@@ -435,6 +435,33 @@ template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void 
 // ------------------------------------------------------------------------------------------------
 constexpr int LU3_NSLOT = 3; // epochs of granule slots kept alive
 
+// -DFH_PANEL_TIMING: s_memtime phase accounting of workgroup 0 / wave 0 (make -C csrc timing; tools/gpu_lu_phases.sh)
+#ifdef FH_PANEL_TIMING
+__device__ unsigned long long g_panel_timing[16];
+#define FH_PT(i)                                                                                                         \
+	do {                                                                                                             \
+		if (blockIdx.x == 0 && threadIdx.x == 0) {                                                               \
+			const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                    \
+			atomicAdd(&g_panel_timing[i], now_ - pt_last);                                                   \
+			pt_last = now_;                                                                                  \
+		}                                                                                                        \
+	} while (0)
+#define FH_PT_DECL unsigned long long pt_last = __builtin_amdgcn_s_memtime()
+#define FH_PT_COUNT(i, v)                                                                                                \
+	do {                                                                                                             \
+		if (blockIdx.x == 0 && threadIdx.x == 0)                                                                 \
+			atomicAdd(&g_panel_timing[i], (unsigned long long) (v));                                         \
+	} while (0)
+#else
+#define FH_PT(i)                                                                                                         \
+	do {                                                                                                             \
+	} while (0)
+#define FH_PT_DECL
+#define FH_PT_COUNT(i, v)                                                                                                \
+	do {                                                                                                             \
+	} while (0)
+#endif
+
 template <typename T, int W> struct Panel3Shared {
 	double wv[LU2_NT / 64];
 	int wr[LU2_NT / 64];
@@ -504,6 +531,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 	const int g = blockIdx.x;
 	const int J = grp * 8 + JJ;
 	const int q = J % LU3_NSLOT;
+	FH_PT_DECL;
 	// ---- 1. local arg-max of |a(:, J)| over the active rows (logical index >= J), first strictly largest
 	double bv = 0.0;
 	int br = INT_MAX;
@@ -524,6 +552,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 	if (tid == 0)
 		sh.hasdiag = 0;
 	__syncthreads();
+	FH_PT(0); // local arg-max + barrier
 	bv = sh.wv[0];
 	br = sh.wr[0];
 #pragma unroll
@@ -549,6 +578,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 		}
 	}
 	__syncthreads();
+	FH_PT(1); // workgroup winner + parking the candidate row + barrier
 	// ---- 2. wave 0: publish, one round of loads, winner
 	if (G > 1) {
 		if (wave == 0) {
@@ -571,8 +601,10 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 				xwg_store_gran(dg, tag, (unsigned) (db >> 32));
 				xwg_store_gran(dg + 1, tag, (unsigned) db);
 			}
+			FH_PT(2); // publish (granule stores issued)
 			// the previous step's pivot row must be parked before this workgroup can be seen two steps ahead
 			int ok = pend3_finish<T, W>(pd, sh, lane) ? 1 : 0;
+			FH_PT(3); // previous pivot row landed
 			// ---- records of all producers, header AND the 8 group values (lane t reads producer t)
 			double v = 0.0;
 			int r = INT_MAX, bt = 0; // this lane's best record: value, logical row, producer
@@ -615,6 +647,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 								gv[k] = gran_pair_to_double(gh[k], gl[k]);
 						}
 					}
+					FH_PT_COUNT(12, 1); // poll sweeps
 					if (__all(all)) {
 						ok = 1;
 						break;
@@ -622,6 +655,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 					__builtin_amdgcn_s_sleep(1);
 				}
 			}
+			FH_PT(4); // records of all producers arrived
 			double wv_ = v;
 			int wr_ = r;
 			wave_argmax2(wv_, wr_);
@@ -682,6 +716,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 				pd.h = xwg_load_gran(rowsrc);
 				pd.l = xwg_load_gran(rowsrc + 1);
 			}
+			FH_PT(5); // winner selection, group values to LDS, asynchronous row fetch issued
 		}
 	} else {
 		if (tid < W) {
@@ -697,6 +732,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 		}
 	}
 	__syncthreads();
+	FH_PT(6); // barrier
 	if (!sh.flag)
 		return false;
 	// ---- 3. relabel (the swap J <-> p of factor.rs:45-48), scale by the reciprocal pivot, update the group columns
@@ -724,6 +760,8 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 				x[i][k] = fh_fma(l, -u[k], x[i][k]); // rank_update_imp: fma(l_i, -u_c, dst)
 		}
 	}
+	FH_PT(7); // relabel + group update
+	FH_PT_COUNT(13, 1); // columns
 	return true;
 }
 
@@ -775,6 +813,7 @@ template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void 
 		for (int i = 0; i < RPT; ++i)
 			nret[i] = (lgr[i] >= J0 && lgr[i] < a.m) ? 8 : 0;
 		const int ng = Panel3Group<T, W, RPT, 0>::run(a, x, lgr, nret, sh, pd, G, grp, steps);
+		FH_PT_DECL;
 		bool bad = ng < 0;
 		if (!bad && G > 1 && wave == 0)
 			bad = !pend3_finish<T, W>(pd, sh, lane);
@@ -783,6 +822,7 @@ template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void 
 				atomicExch(a.status + 2, 1);
 			return;
 		}
+		FH_PT(8); // last pivot row landed + barrier
 		// ---- end of the group: the pivot rows of the trailing positions, U_t = row_t - sum_{s<t} l_ts U_s (lane = position),
 		// then the rank-ng update of this thread's rows; pivots t >= nret[i] do not act on row i
 		if (lim > 8) {
@@ -820,6 +860,7 @@ template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void 
 				}
 			}
 		}
+		FH_PT(9); // rank-8 update of the trailing positions
 		if (ng < 8)
 			break;
 		// rotate every row left by 8: the finished columns go to the tail
@@ -838,6 +879,7 @@ template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void 
 		}
 		rot += 8;
 		__syncthreads(); // sh.stage is rewritten by the next group
+		FH_PT(10); // rotation + barrier
 	}
 	// every row goes to its logical position
 #pragma unroll
@@ -1282,6 +1324,21 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		ctx().sync();
 		FH_CHECK(st[2] == 0, "partial_piv_lu: device barrier timed out in the panel kernel");
 		ctx().quiesce();
+#ifdef FH_PANEL_TIMING
+		{
+			unsigned long long d[16];
+			FH_HIP(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_panel_timing), sizeof(d)));
+			const double c = d[13] ? (double) d[13] : 1.0;
+			fprintf(stderr,
+				"panel3 phases (s_memtime ticks per column, wg 0 / thread 0, %llu columns): argmax+bar %.0f | pick+park+bar %.0f | publish %.0f | "
+				"prev row %.0f | records %.0f (%.2f sweeps) | winner+issue %.0f | bar %.0f | relabel+group %.0f || per group: last row+bar %.0f | "
+				"rank-8 %.0f | rotate+bar %.0f\n",
+				d[13], d[0] / c, d[1] / c, d[2] / c, d[3] / c, d[4] / c, d[12] / c, d[5] / c, d[6] / c, d[7] / c, d[8] * 8 / c, d[9] * 8 / c,
+				d[10] * 8 / c);
+			unsigned long long z[16] = {0};
+			FH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_panel_timing), z, sizeof(z)));
+		}
+#endif
 		// factor.rs:274-277: perm = identity with the transpositions applied in order
 		for (idx_t j = 0; j < size; ++j) {
 			const idx_t p = piv[(size_t) j];

@@ -272,14 +272,13 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 			if (j > i)
 				continue;
 			const T v = S[j * LDS_LDP + i];
-			if (i == j)
-				Winv[P::OFF_DINV + i] = (LDLT || i >= n) ? (T) 1 : (T) 1 / v;
-			else if (i < TP_H)
-				Winv[P::OFF_T00 + toff[j] + (i - j - 1)] = v;
+			const T val = i == j ? ((LDLT || i >= n) ? (T) 1 : (T) 1 / v) : v; // the diagonal enters as its reciprocal
+			if (i < TP_H)
+				Winv[P::OFF_T00 + toff[j] + (i - j)] = val;
 			else if (j >= TP_H)
-				Winv[P::OFF_T11 + toff[j - TP_H] + (i - j - 1)] = v;
+				Winv[P::OFF_T11 + toff[j - TP_H] + (i - j)] = val;
 			else
-				Winv[P::OFF_T10 + (i - TP_H) * TP_H + j] = v;
+				Winv[P::OFF_T10 + (i - TP_H) * TP_H + j] = val;
 		}
 		FH_LT(4);
 	}

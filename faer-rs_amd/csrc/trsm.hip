@@ -177,15 +177,13 @@ __global__ __launch_bounds__(256) void trsm_pack_kernel(const T *__restrict__ Lp
 			const int i = e % TP_NB, j = e / TP_NB;
 			if (j > i)
 				continue;
-			if (i == j) {
-				img[P::OFF_DINV + i] = (unit || i >= nb) ? (T) 1 : (T) 1 / v[u];
-			} else if (i < TP_H) {
-				img[P::OFF_T00 + toff[j] + (i - j - 1)] = v[u];
-			} else if (j >= TP_H) {
-				img[P::OFF_T11 + toff[j - TP_H] + (i - j - 1)] = v[u];
-			} else {
-				img[P::OFF_T10 + (i - TP_H) * TP_H + j] = v[u];
-			}
+			const T val = i == j ? ((unit || i >= nb) ? (T) 1 : (T) 1 / v[u]) : v[u]; // the diagonal enters as its reciprocal
+			if (i < TP_H)
+				img[P::OFF_T00 + toff[j] + (i - j)] = val;
+			else if (j >= TP_H)
+				img[P::OFF_T11 + toff[j - TP_H] + (i - j)] = val;
+			else
+				img[P::OFF_T10 + (i - TP_H) * TP_H + j] = val;
 		}
 	}
 }
@@ -202,21 +200,126 @@ template <typename T> void trsm_pack_dev(MatV<const T> L, bool unit, T *W)
 template void trsm_pack_dev<double>(MatV<const double>, bool, double *);
 template void trsm_pack_dev<float>(MatV<const float>, bool, float *);
 
-// column-oriented substitution on one packed 64 x 64 triangle: x <- tri^-1 x, multipliers from LDS broadcasts
-template <typename T> static __device__ __forceinline__ void tl_subst(T (&x)[TP_H], const T *__restrict__ tri, const T *__restrict__ dinv)
+// ---- software-pipelined LDS streams -------------------------------------------------------------------------------
+// Every multiplier of the substitution is a wave-uniform LDS broadcast.  Left to the compiler, each pair of FMAs waits
+// for its own ds_read_b128 (~100 cycles with one wavefront per SIMD: 24 cycles per FMA measured, profiles/
+// r02_trsm_leaf.txt).  The packed triangle is therefore consumed as ONE linear stream of 16-byte reads with TL_D of
+// them in flight: read R is waited for with lgkmcnt(TL_D - 1), its FMAs issue, read R + TL_D goes out into the same
+// ring register.  The reads and waits are inline asm (the compiler neither reorders nor counts them); LDS operations
+// complete in order, so any LDS traffic the compiler adds around them only makes the waits stricter.
+constexpr int TL_D = 16;
+
+template <typename T> struct V16;
+template <> struct V16<double> {
+	typedef double type __attribute__((ext_vector_type(2)));
+};
+template <> struct V16<float> {
+	typedef float type __attribute__((ext_vector_type(4)));
+};
+template <int OFF, typename V> static __device__ __forceinline__ void lds_read128(V &dst, unsigned base)
 {
-	typedef TriPack<T> P;
-#pragma unroll
-	for (int j = 0; j < TP_H; ++j) {
-		const T xj = x[j] * dinv[j];
-		x[j] = xj;
-#pragma unroll
-		for (int i = j + 1; i < TP_H; ++i)
-			x[i] = fh_fma(-tri[P::tri_off(j) + (i - j - 1)], xj, x[i]);
-		if ((j & 3) == 3)
-			asm volatile("" ::: "memory"); // keep the broadcast loads of later columns from piling up in registers
-	}
+	asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(OFF));
 }
+template <int CNT, typename V> static __device__ __forceinline__ void lds_wait(V &v)
+{
+	asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(CNT));
+}
+
+// x <- tri^-1 x, column oriented (the diagonal enters as a reciprocal: first entry of every column block)
+template <typename T, int J, int K> struct SubstRead {
+	typedef TriPack<T> P;
+	typedef typename V16<T>::type V;
+	static constexpr int EPR = P::ALIGN;			   // elements per read
+	static constexpr int NR = P::TRI / EPR;			   // reads of the whole triangle
+	static constexpr int R = P::tri_off(J) / EPR + K;	   // linear read index
+	static constexpr int NRJ = P::col_len(J) / EPR;	   // reads of column J
+	static __device__ __forceinline__ void run(T (&x)[TP_H], V (&ring)[TL_D], unsigned base, T &xj)
+	{
+		if constexpr (K < NRJ) {
+			constexpr int S = R % TL_D;
+			lds_wait<(R + TL_D <= NR ? TL_D - 1 : NR - 1 - R)>(ring[S]);
+#pragma unroll
+			for (int u = 0; u < EPR; ++u) {
+				constexpr int dummy = 0;
+				(void) dummy;
+				const int e = K * EPR + u; // position inside the column block: 0 = 1 / t_jj, e = row J + e
+				if (e == 0) {
+					xj = x[J] * ring[S][u];
+					x[J] = xj;
+				} else if (J + e < TP_H) {
+					x[J + e] = fh_fma(-ring[S][u], xj, x[J + e]);
+				}
+			}
+			if constexpr (R + TL_D < NR)
+				lds_read128<(R + TL_D) * 16>(ring[S], base);
+			SubstRead<T, J, K + 1>::run(x, ring, base, xj);
+		}
+	}
+};
+template <typename T, int J> struct SubstCol {
+	typedef typename V16<T>::type V;
+	static __device__ __forceinline__ void run(T (&x)[TP_H], V (&ring)[TL_D], unsigned base)
+	{
+		if constexpr (J < TP_H) {
+			T xj;
+			SubstRead<T, J, 0>::run(x, ring, base, xj);
+			SubstCol<T, J + 1>::run(x, ring, base);
+		}
+	}
+};
+template <typename T, int R> struct PipeFill { // the first TL_D reads of a stream starting at `base`
+	typedef typename V16<T>::type V;
+	static __device__ __forceinline__ void run(V (&ring)[TL_D], unsigned base)
+	{
+		if constexpr (R < TL_D) {
+			lds_read128<R * 16>(ring[R], base);
+			PipeFill<T, R + 1>::run(ring, base);
+		}
+	}
+};
+template <typename T> static __device__ __forceinline__ void tl_subst(T (&x)[TP_H], const T *tri)
+{
+	typename V16<T>::type ring[TL_D];
+	const unsigned base = (unsigned) (size_t) tri; // LDS byte address
+	PipeFill<T, 0>::run(ring, base);
+	SubstCol<T, 0>::run(x, ring, base);
+}
+
+// acc[u] = sum_j T10(i0 + u, j) x_j for TL_EB rows at a time: the reads walk the TL_EB rows column pair by column pair
+// (so that consecutive FMAs feed different accumulators), same pipelining
+constexpr int TL_EB = 8;
+template <typename T, int L> struct ElimRead {
+	typedef TriPack<T> P;
+	typedef typename V16<T>::type V;
+	static constexpr int EPR = P::ALIGN;
+	static constexpr int RPR = TP_H / EPR;	 // reads per row
+	static constexpr int NL = TL_EB * RPR;	 // reads per block of rows
+	static constexpr int off(int l) { return ((l % TL_EB) * TP_H + (l / TL_EB) * EPR) * (int) sizeof(T); } // row l % EB, column group l / EB
+	static __device__ __forceinline__ void run(const T (&x)[TP_H], T (&acc)[TL_EB][2], V (&ring)[TL_D], unsigned base)
+	{
+		if constexpr (L < NL) {
+			constexpr int S = L % TL_D;
+			constexpr int u = L % TL_EB, kk = L / TL_EB;
+			lds_wait<(L + TL_D <= NL ? TL_D - 1 : NL - 1 - L)>(ring[S]);
+#pragma unroll
+			for (int e = 0; e < EPR; ++e)
+				acc[u][e & 1] = fh_fma(ring[S][e], x[kk * EPR + e], acc[u][e & 1]);
+			if constexpr (L + TL_D < NL)
+				lds_read128<off(L + TL_D)>(ring[S], base);
+			ElimRead<T, L + 1>::run(x, acc, ring, base);
+		}
+	}
+};
+template <typename T, int L> struct ElimFill {
+	typedef typename V16<T>::type V;
+	static __device__ __forceinline__ void run(V (&ring)[TL_D], unsigned base)
+	{
+		if constexpr (L < TL_D) {
+			lds_read128<ElimRead<T, 0>::off(L)>(ring[L], base);
+			ElimFill<T, L + 1>::run(ring, base);
+		}
+	}
+};
 
 template <typename T>
 __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__ img, int n, T *Xp, idx_t xss, idx_t xcs, int nrhs,
@@ -312,7 +415,7 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	for (int i = 0; i < TP_H; ++i)
 		y[i] = Xs[i * TL_XP + lane];
 	__syncthreads(); // the image is in LDS
-	tl_subst<T>(y, Ls + P::OFF_T00, Ls + P::OFF_DINV);
+	tl_subst<T>(y, Ls + P::OFF_T00);
 #pragma unroll
 	for (int i = 0; i < TP_H; ++i)
 		Xs[i * TL_XP + lane] = y[i];
@@ -322,28 +425,25 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	// ---- half 1: b_i - sum_j T10(i, j) y_j with the solved y_j still in registers and the rows of T10 as LDS
 	// broadcasts (four partial sums per row), then the same substitution on T11
 	load_half(TP_H);
-	{
-		const T *t10 = Ls + P::OFF_T10;
-#pragma unroll 2
-		for (int i = 0; i < TP_H; ++i) {
-			T a0 = (T) 0, a1 = (T) 0, a2 = (T) 0, a3 = (T) 0;
-			const T *row = t10 + i * TP_H;
+	for (int i0 = 0; i0 < TP_H; i0 += TL_EB) {
+		typename V16<T>::type ring[TL_D];
+		T acc[TL_EB][2];
 #pragma unroll
-			for (int j = 0; j < TP_H; j += 4) {
-				a0 = fh_fma(row[j], y[j], a0);
-				a1 = fh_fma(row[j + 1], y[j + 1], a1);
-				a2 = fh_fma(row[j + 2], y[j + 2], a2);
-				a3 = fh_fma(row[j + 3], y[j + 3], a3);
-			}
-			Xs[i * TL_XP + lane] -= (a0 + a1) + (a2 + a3);
-		}
+		for (int u = 0; u < TL_EB; ++u)
+			acc[u][0] = acc[u][1] = (T) 0;
+		const unsigned base = (unsigned) (size_t) (Ls + P::OFF_T10 + i0 * TP_H);
+		ElimFill<T, 0>::run(ring, base);
+		ElimRead<T, 0>::run(y, acc, ring, base);
+#pragma unroll
+		for (int u = 0; u < TL_EB; ++u)
+			Xs[(i0 + u) * TL_XP + lane] -= acc[u][0] + acc[u][1];
 	}
 	__builtin_amdgcn_wave_barrier();
 	T z[TP_H];
 #pragma unroll
 	for (int i = 0; i < TP_H; ++i)
 		z[i] = Xs[i * TL_XP + lane];
-	tl_subst<T>(z, Ls + P::OFF_T11, Ls + P::OFF_DINV + TP_H);
+	tl_subst<T>(z, Ls + P::OFF_T11);
 #pragma unroll
 	for (int i = 0; i < TP_H; ++i)
 		Xs[i * TL_XP + lane] = z[i];

@@ -10,11 +10,11 @@
 //   T = [ T00  0  ]    T00, T11: 64 x 64 lower triangular, T10: 64 x 64
 //       [ T10 T11 ]
 //
-//   image = [ tri(T00) | T10 row major | tri(T11) | recip diag (128) ]
-//   tri(): column j holds the entries BELOW the diagonal (rows j+1 .. 63) starting at an offset aligned to 16
-//          bytes, so that the wave-uniform broadcast reads of the unrolled substitution pair up into ds_read_b128;
-//   recip diag: 1 / t_jj (1 for a unit triangle and for identity padding) -- the reference multiplies by the
-//          reciprocal too (triangular_solve.rs:113,121).
+//   image = [ tri(T00) | T10 row major | tri(T11) ]
+//   tri(): column j is the block [ 1 / t_jj, t_{j+1,j}, ..., t_{63,j} ] (64 - j entries) starting at an offset aligned
+//          to 16 bytes.  The substitution consumes the packed triangle as ONE linear stream of 16-byte LDS reads
+//          (trsm.hip, software pipelined), reciprocal diagonal included -- the reference multiplies by the
+//          reciprocal too (triangular_solve.rs:113,121); it is 1 for a unit triangle and for identity padding.
 // Rows / columns beyond the block's real size are identity padded.
 #pragma once
 #include "common.h"
@@ -26,7 +26,7 @@ constexpr int TP_H = 64;   // half
 
 template <typename T> struct TriPack {
 	static constexpr int ALIGN = 16 / (int) sizeof(T); // elements per 16 bytes
-	static constexpr int col_len(int j) { return (TP_H - 1 - j + ALIGN - 1) / ALIGN * ALIGN; }
+	static constexpr int col_len(int j) { return (TP_H - j + ALIGN - 1) / ALIGN * ALIGN; } // 1 / diag + the entries below it
 	static constexpr int tri_off(int j)
 	{
 		int o = 0;
@@ -38,30 +38,8 @@ template <typename T> struct TriPack {
 	static constexpr int OFF_T00 = 0;
 	static constexpr int OFF_T10 = TRI;			   // row major: T10t[i * 64 + j] = T(64 + i, j)
 	static constexpr int OFF_T11 = TRI + TP_H * TP_H;
-	static constexpr int OFF_DINV = 2 * TRI + TP_H * TP_H;
-	static constexpr int SIZE = OFF_DINV + TP_NB; // elements per block image (a multiple of ALIGN)
+	static constexpr int SIZE = 2 * TRI + TP_H * TP_H; // elements per block image (a multiple of ALIGN)
 	static constexpr size_t BYTES = (size_t) SIZE * sizeof(T);
-};
-
-// position of entry (i, j), i > j, of the 128 x 128 block inside the image
-template <typename T> __host__ __device__ inline int tripack_pos(int i, int j)
-{
-	typedef TriPack<T> P;
-	if (i < TP_H)
-		return P::OFF_T00 + P::tri_off(j) + (i - j - 1);
-	if (j >= TP_H)
-		return P::OFF_T11 + P::tri_off(j - TP_H) + (i - j - 1);
-	return P::OFF_T10 + (i - TP_H) * TP_H + j;
-}
-
-// run-time column offsets (the device code that packs -- not the unrolled leaf -- indexes with run-time j)
-template <typename T> struct TriOffTable {
-	int off[TP_H];
-	constexpr TriOffTable() : off()
-	{
-		for (int j = 0; j < TP_H; ++j)
-			off[j] = TriPack<T>::tri_off(j);
-	}
 };
 
 } // namespace fh
