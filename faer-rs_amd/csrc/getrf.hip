@@ -469,9 +469,9 @@ template <typename T, int W> struct Panel3Shared {
 	T drow[W];	 // the row with logical index J, if this workgroup holds it
 	T stage[8][W];	 // the pivot rows of the current group as they were when they were chosen
 	T pivg[8];	 // group part of the current pivot row
+	T pinv;		 // reciprocal of the pivot
 	int p;		 // winning row (logical index)
 	int flag;	 // exchange completed
-	int hasdiag;	 // this workgroup holds the row with logical index J
 };
 
 // wave 0's outstanding fetch of a pivot row's positions 8 .. W-1 (one granule pair per lane)
@@ -531,6 +531,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 	const int g = blockIdx.x;
 	const int J = grp * 8 + JJ;
 	const int q = J % LU3_NSLOT;
+	const unsigned tag = (unsigned) (a.epoch_base + (xwg_u64) (J + 1));
 	FH_PT_DECL;
 	// ---- 1. local arg-max of |a(:, J)| over the active rows (logical index >= J), first strictly largest
 	double bv = 0.0;
@@ -549,8 +550,6 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 		sh.wv[wave] = bv;
 		sh.wr[wave] = br;
 	}
-	if (tid == 0)
-		sh.hasdiag = 0;
 	__syncthreads();
 	FH_PT(0); // local arg-max + barrier
 	bv = sh.wv[0];
@@ -563,48 +562,79 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 		}
 	if (!(bv > 0.0))
 		br = INT_MAX; // zero / NaN-only chunk: no candidate
+	// The wave that OWNS the candidate row publishes it itself -- no second workgroup barrier, and the 8 group values
+	// (all the other workgroups need on the dependent chain) go out first, straight from registers through the scalar
+	// unit; the other positions follow through a wave-private LDS transposition.  A workgroup without a candidate
+	// publishes the row with logical index J instead if it holds it (the pivot row of an all-zero column, factor.rs:35-43).
+	xwg_u64 *sg = a.gran + ((size_t) q * G + g) * LU2_GSLOT;
+	{
+		const int want = br != INT_MAX ? br : J;
+		bool mine = false;
+		T gsel[8];
 #pragma unroll
-	for (int i = 0; i < RPT; ++i) {
-		if (lgr[i] == br && br != INT_MAX) {
+		for (int k = 0; k < 8; ++k)
+			gsel[k] = (T) 0;
 #pragma unroll
-			for (int c = 0; c < W; ++c)
-				sh.cand[c] = x[i][c];
+		for (int i = 0; i < RPT; ++i) {
+			if (lgr[i] == want) {
+				mine = true;
+#pragma unroll
+				for (int k = 0; k < 8; ++k)
+					gsel[k] = x[i][k];
+			}
 		}
-		if (lgr[i] == J) {
+		const unsigned long long own = __ballot(mine);
+		if (own != 0ull) { // wave uniform: this wave holds the row
+			const int ol = __builtin_ctzll(own);
+			T *park = br != INT_MAX ? sh.cand : sh.drow;
+			if (G > 1) {
+				T sel = lane_bcast(gsel[0], ol);
 #pragma unroll
-			for (int c = 0; c < W; ++c)
-				sh.drow[c] = x[i][c];
-			sh.hasdiag = 1;
+				for (int k = 1; k < 8; ++k) {
+					const T vk = lane_bcast(gsel[k], ol);
+					sel = lane == k ? vk : sel;
+				}
+				xwg_u64 *dstg = br != INT_MAX ? sg + 4 : a.gran_diag + (size_t) q * 2 * LU_WMAX;
+				if (lane < 8) {
+					const xwg_u64 cb = (xwg_u64) __double_as_longlong((double) sel);
+					xwg_store_gran(dstg + 2 * lane, tag, (unsigned) (cb >> 32));
+					xwg_store_gran(dstg + 2 * lane + 1, tag, (unsigned) cb);
+				}
+			}
+			// whole row -> LDS (wave private until the next barrier), then positions 8 .. W-1 to the granules
+			if (mine) {
+#pragma unroll
+				for (int i = 0; i < RPT; ++i)
+					if (lgr[i] == want) {
+#pragma unroll
+						for (int c = 0; c < W; ++c)
+							park[c] = x[i][c];
+					}
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (G > 1 && lane >= 8 && lane < W) {
+				xwg_u64 *dstg = br != INT_MAX ? sg + 4 : a.gran_diag + (size_t) q * 2 * LU_WMAX;
+				const xwg_u64 cb = (xwg_u64) __double_as_longlong((double) park[lane]);
+				xwg_store_gran(dstg + 2 * lane, tag, (unsigned) (cb >> 32));
+				xwg_store_gran(dstg + 2 * lane + 1, tag, (unsigned) cb);
+			}
 		}
 	}
-	__syncthreads();
-	FH_PT(1); // workgroup winner + parking the candidate row + barrier
-	// ---- 2. wave 0: publish, one round of loads, winner
+	FH_PT(1); // workgroup winner + publication of the candidate row by its wave
+	// ---- 2. wave 0: header, one round of loads, winner
 	if (G > 1) {
 		if (wave == 0) {
-			const unsigned tag = (unsigned) (a.epoch_base + (xwg_u64) (J + 1));
-			xwg_u64 *sg = a.gran + ((size_t) q * G + g) * LU2_GSLOT;
+			// the previous step's pivot row must be parked before this workgroup can be seen two steps ahead (its loads
+			// are older than everything issued in this step: no store is waited for here)
+			int ok = pend3_finish<T, W>(pd, sh, lane) ? 1 : 0;
+			FH_PT(3); // previous pivot row landed
 			if (lane == 0) {
 				const xwg_u64 vb = (xwg_u64) __double_as_longlong(bv);
 				xwg_store_gran(sg + 0, tag, (unsigned) br);
 				xwg_store_gran(sg + 1, tag, (unsigned) (vb >> 32));
 				xwg_store_gran(sg + 2, tag, (unsigned) vb);
 			}
-			if (lane < W && br != INT_MAX) {
-				const xwg_u64 cb = (xwg_u64) __double_as_longlong((double) sh.cand[lane]);
-				xwg_store_gran(sg + 4 + 2 * lane, tag, (unsigned) (cb >> 32));
-				xwg_store_gran(sg + 5 + 2 * lane, tag, (unsigned) cb);
-			}
-			if (sh.hasdiag && lane < W) {
-				const xwg_u64 db = (xwg_u64) __double_as_longlong((double) sh.drow[lane]);
-				xwg_u64 *dg = a.gran_diag + (size_t) q * 2 * LU_WMAX + 2 * lane;
-				xwg_store_gran(dg, tag, (unsigned) (db >> 32));
-				xwg_store_gran(dg + 1, tag, (unsigned) db);
-			}
-			FH_PT(2); // publish (granule stores issued)
-			// the previous step's pivot row must be parked before this workgroup can be seen two steps ahead
-			int ok = pend3_finish<T, W>(pd, sh, lane) ? 1 : 0;
-			FH_PT(3); // previous pivot row landed
+			FH_PT(2); // header published
 			// ---- records of all producers, header AND the 8 group values (lane t reads producer t)
 			double v = 0.0;
 			int r = INT_MAX, bt = 0; // this lane's best record: value, logical row, producer
@@ -671,8 +701,8 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 				const int gw = __builtin_amdgcn_readlane(bt, src);
 				rowsrc = a.gran + ((size_t) q * G + gw) * LU2_GSLOT + 4 + 2 * (lane & (W - 1));
 			} else {
-				// no candidate anywhere: the row with logical index J is the pivot row (factor.rs:35-43); its holder
-				// published it -- blocking fetch of the group part (rare path)
+				// no candidate anywhere: the row with logical index J is the pivot row; its holder (a workgroup without
+				// a candidate, like all of them) published it -- blocking fetch of the group part (rare path)
 				rowsrc = a.gran_diag + (size_t) q * 2 * LU_WMAX + 2 * (lane & (W - 1));
 				xwg_u64 dh = 0, dl = 0;
 				if (ok) {
@@ -705,6 +735,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 				sh.stage[JJ][lane] = (T) sel;
 			}
 			if (lane == 0) {
+				sh.pinv = (T) 1 / (T) gv[JJ]; // factor.rs:50 `recip()`, computed once per workgroup
 				sh.p = p;
 				sh.flag = ok;
 			}
@@ -719,12 +750,15 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 			FH_PT(5); // winner selection, group values to LDS, asynchronous row fetch issued
 		}
 	} else {
+		__syncthreads(); // the parked rows
 		if (tid < W) {
 			const int p = br == INT_MAX ? J : br;
-			const T val = p == J ? sh.drow[tid] : sh.cand[tid];
+			const T val = br == INT_MAX ? sh.drow[tid] : sh.cand[tid];
 			sh.stage[JJ][tid] = val;
 			if (tid < 8)
 				sh.pivg[tid] = val;
+			if (tid == JJ)
+				sh.pinv = (T) 1 / val;
 			if (tid == 0) {
 				sh.p = p;
 				sh.flag = 1;
@@ -739,7 +773,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 	const int p = sh.p;
 	if (g == 0 && tid == 0)
 		a.piv[J] = a.row_base + p;
-	const T inv = (T) 1 / sh.pivg[JJ];
+	const T inv = sh.pinv;
 	T u[8];
 #pragma unroll
 	for (int k = 0; k < 8; ++k)

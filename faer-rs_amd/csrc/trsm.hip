@@ -334,97 +334,133 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	const int nc = min(64, nrhs - c0); // may be <= 0 for the second wave of the last workgroup
 	const bool act = lane < nc;
 
-	// ---- packed triangle -> LDS, 16-byte loads (the image is 16-byte aligned and a multiple of 16 bytes long);
-	// batches of 11 independent loads per thread: three memory round trips for the whole image, not one per vector
+	// Memory phases are organised by ROUND TRIPS, not by data: every batch below is a set of independent loads in
+	// flight together (a leaf spends ~1.5 us per dependent round trip when the chip is busy -- with 8-deep batches the
+	// loads alone took ~40 us of a ~60 us leaf, profiles/r02_trsm_leaf.txt).
+	//   trip 1: first half of the packed image + this wave's 64 x 64 block of right-hand sides (rows 0 .. 63)
+	//   trip 2: second half of the image (+ rows 64 .. 127 when lanes run along the right-hand sides: they go
+	//           straight to the exchange tile, which that layout does not need for anything else)
+	typedef int v4i __attribute__((ext_vector_type(4)));
+	const v4i *isrc = reinterpret_cast<const v4i *>(img);
+	v4i *idst = reinterpret_cast<v4i *>(Ls);
+	constexpr int NV = (int) (P::BYTES / 16), UA = (NV / 128 + 2) / 2, UB = (NV - UA * 128 + 127) / 128; // two batches per thread
+	static_assert(UB > 0 && UB <= UA, "image batches");
+	const bool two = n > TP_H;
+	const int ns0 = min(TP_H, n), ns1 = two ? n - TP_H : 0;
+	T y[TP_H];
 	{
-		typedef int v4i __attribute__((ext_vector_type(4)));
-		const v4i *src = reinterpret_cast<const v4i *>(img);
-		v4i *dst = reinterpret_cast<v4i *>(Ls);
-		constexpr int NV = (int) (P::BYTES / 16), U = 11;
-		for (int e0 = threadIdx.x; e0 < NV; e0 += 128 * U) {
-			v4i v[U];
+		v4i va[UA];
 #pragma unroll
-			for (int u = 0; u < U; ++u)
-				v[u] = src[min(e0 + u * 128, NV - 1)];
-#pragma unroll
-			for (int u = 0; u < U; ++u)
-				if (e0 + u * 128 < NV)
-					dst[e0 + u * 128] = v[u];
-		}
-	}
-	// rows s0 .. s0+63 of this wave's 64 right-hand sides -> Xs (zero padded), lanes along the small stride
-	auto load_half = [&](int s0) {
-		const int ns = min(TP_H, n - s0);
+		for (int u = 0; u < UA; ++u)
+			va[u] = isrc[threadIdx.x + u * 128];
 		if (lanes_along_rhs) {
 #pragma unroll
-			for (int i0 = 0; i0 < TP_H; i0 += 16) {
-				T v[16];
+			for (int i = 0; i < TP_H; ++i) {
+				const bool in = i < ns0 && act;
+				const T t = Xp[in ? (idx_t) i * xss + (idx_t) (c0 + lane) * xcs : (idx_t) 0];
+				y[i] = in ? t : (T) 0;
+			}
+		} else {
 #pragma unroll
-				for (int u = 0; u < 16; ++u) {
-					const bool in = i0 + u < ns && act;
-					const T t = Xp[in ? (idx_t) (s0 + i0 + u) * xss + (idx_t) (c0 + lane) * xcs : (idx_t) 0];
+			for (int cc = 0; cc < TP_H; ++cc) {
+				const bool in = cc < nc && lane < ns0;
+				const T t = Xp[in ? (idx_t) lane * xss + (idx_t) (c0 + cc) * xcs : (idx_t) 0];
+				y[cc] = in ? t : (T) 0; // transposed: y[cc] is (row = lane, rhs = cc) until it has been through the tile
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < UA; ++u)
+			idst[threadIdx.x + u * 128] = va[u];
+	}
+	{
+		v4i vb[UB];
+#pragma unroll
+		for (int u = 0; u < UB; ++u)
+			vb[u] = isrc[min(UA * 128 + (int) threadIdx.x + u * 128, NV - 1)];
+		if (!lanes_along_rhs) {
+#pragma unroll
+			for (int cc = 0; cc < TP_H; ++cc)
+				Xs[lane * TL_XP + cc] = y[cc];
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int i = 0; i < TP_H; ++i)
+				y[i] = Xs[i * TL_XP + lane];
+			__builtin_amdgcn_wave_barrier();
+		} else if (two) {
+			// rows 64 .. 127 -> tile, two batches of 32 loads
+#pragma unroll
+			for (int i0 = 0; i0 < TP_H; i0 += 32) {
+				T v[32];
+#pragma unroll
+				for (int u = 0; u < 32; ++u) {
+					const bool in = i0 + u < ns1 && act;
+					const T t = Xp[in ? (idx_t) (TP_H + i0 + u) * xss + (idx_t) (c0 + lane) * xcs : (idx_t) 0];
 					v[u] = in ? t : (T) 0;
 				}
 #pragma unroll
-				for (int u = 0; u < 16; ++u)
+				for (int u = 0; u < 32; ++u)
 					Xs[(i0 + u) * TL_XP + lane] = v[u];
 			}
-		} else {
-			for (int cc = 0; cc < 64; cc += 8) {
-				T v[8];
-#pragma unroll
-				for (int u = 0; u < 8; ++u) {
-					const bool in = cc + u < nc && lane < ns;
-					const T t = Xp[in ? (idx_t) (s0 + lane) * xss + (idx_t) (c0 + cc + u) * xcs : (idx_t) 0];
-					v[u] = in ? t : (T) 0;
-				}
-#pragma unroll
-				for (int u = 0; u < 8; ++u)
-					Xs[lane * TL_XP + cc + u] = v[u];
-			}
 		}
-		__builtin_amdgcn_wave_barrier();
-	};
-	auto store_half = [&](int s0) {
-		const int ns = min(TP_H, n - s0);
-		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int u = 0; u < UB; ++u)
+			if (UA * 128 + (int) threadIdx.x + u * 128 < NV)
+				idst[UA * 128 + (int) threadIdx.x + u * 128] = vb[u];
+	}
+	__syncthreads(); // the image is in LDS
+
+	// rows s0 .. s0+63 of the solution, held in v (lane = right-hand side), back to X
+	auto store_half = [&](const T (&v)[TP_H], int s0, int ns) {
 		if (lanes_along_rhs) {
-#pragma unroll 8
+#pragma unroll
 			for (int i = 0; i < TP_H; ++i)
 				if (i < ns && act)
-					Xp[(idx_t) (s0 + i) * xss + (idx_t) (c0 + lane) * xcs] = Xs[i * TL_XP + lane];
+					Xp[(idx_t) (s0 + i) * xss + (idx_t) (c0 + lane) * xcs] = v[i];
 		} else {
-			for (int cc = 0; cc < nc; cc += 8) {
-				T v[8];
+			__builtin_amdgcn_wave_barrier();
 #pragma unroll
-				for (int u = 0; u < 8; ++u)
-					v[u] = Xs[lane * TL_XP + min(cc + u, 63)];
+			for (int i = 0; i < TP_H; ++i)
+				Xs[i * TL_XP + lane] = v[i];
+			__builtin_amdgcn_wave_barrier();
 #pragma unroll
-				for (int u = 0; u < 8; ++u)
-					if (cc + u < nc && lane < ns)
-						Xp[(idx_t) (s0 + lane) * xss + (idx_t) (c0 + cc + u) * xcs] = v[u];
+			for (int c8 = 0; c8 < TP_H; c8 += 16) {
+				T w[16];
+#pragma unroll
+				for (int u = 0; u < 16; ++u)
+					w[u] = Xs[lane * TL_XP + c8 + u];
+#pragma unroll
+				for (int u = 0; u < 16; ++u)
+					if (c8 + u < nc && lane < ns)
+						Xp[(idx_t) (s0 + lane) * xss + (idx_t) (c0 + c8 + u) * xcs] = w[u];
 			}
+			__builtin_amdgcn_wave_barrier();
 		}
-		__builtin_amdgcn_wave_barrier();
 	};
 
 	// ---- half 0: substitution on T00 (lane = right-hand side, register = row)
-	T y[TP_H];
-	load_half(0);
-#pragma unroll
-	for (int i = 0; i < TP_H; ++i)
-		y[i] = Xs[i * TL_XP + lane];
-	__syncthreads(); // the image is in LDS
 	tl_subst<T>(y, Ls + P::OFF_T00);
-#pragma unroll
-	for (int i = 0; i < TP_H; ++i)
-		Xs[i * TL_XP + lane] = y[i];
-	store_half(0);
-	if (n <= TP_H)
+	store_half(y, 0, ns0);
+	if (!two)
 		return;
 	// ---- half 1: b_i - sum_j T10(i, j) y_j with the solved y_j still in registers and the rows of T10 as LDS
-	// broadcasts (four partial sums per row), then the same substitution on T11
-	load_half(TP_H);
+	// broadcasts, then the same substitution on T11
+	if (!lanes_along_rhs) {
+		// rows 64 .. 127 through the tile (free again now), two batches of 32 right-hand sides
+#pragma unroll
+		for (int c8 = 0; c8 < TP_H; c8 += 32) {
+			T v[32];
+#pragma unroll
+			for (int u = 0; u < 32; ++u) {
+				const bool in = c8 + u < nc && lane < ns1;
+				const T t = Xp[in ? (idx_t) (TP_H + lane) * xss + (idx_t) (c0 + c8 + u) * xcs : (idx_t) 0];
+				v[u] = in ? t : (T) 0;
+			}
+#pragma unroll
+			for (int u = 0; u < 32; ++u)
+				Xs[lane * TL_XP + c8 + u] = v[u];
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
 	for (int i0 = 0; i0 < TP_H; i0 += TL_EB) {
 		typename V16<T>::type ring[TL_D];
 		T acc[TL_EB][2];
@@ -444,10 +480,7 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	for (int i = 0; i < TP_H; ++i)
 		z[i] = Xs[i * TL_XP + lane];
 	tl_subst<T>(z, Ls + P::OFF_T11);
-#pragma unroll
-	for (int i = 0; i < TP_H; ++i)
-		Xs[i * TL_XP + lane] = z[i];
-	store_half(TP_H);
+	store_half(z, TP_H, ns1);
 }
 
 template <typename T> static size_t trsm_leaf128_lds()
