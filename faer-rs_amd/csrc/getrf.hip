@@ -523,9 +523,16 @@ template <typename T> struct Panel3Args {
 	int *status;
 };
 
-template <typename T, int W, int RPT, int JJ>
+// One column step.  The 8 group columns sit in a ROTATING WINDOW, positions 0 .. 7 of every register row: the column
+// being eliminated is always position 0 and after the step the window is rotated left by one (the finished column --
+// the multipliers -- goes to position 7), so that ONE copy of this code serves all 8 columns of a group (JJ is a
+// run-time value).  Code size is the point: fully unrolled, the 8 steps of a group were ~100 KB of straight-line code,
+// more than the 64 KB instruction cache two CUs share, and the panel kernels ran at the speed of instruction fetch
+// (profiles/r02_lu_panel_phases.txt).  After the 8 steps of a group the window is back in natural order with the
+// multipliers l_0 .. l_7 in positions 0 .. 7, which is what the end-of-group update reads.
+template <typename T, int W, int RPT>
 static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x)[RPT][W], int (&lgr)[RPT], int (&nret)[RPT], Panel3Shared<T, W> &sh,
-						   Pend3 &pd, int G, int grp)
+						Pend3 &pd, int G, int grp, int JJ)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int g = blockIdx.x;
@@ -539,7 +546,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 #pragma unroll
 	for (int i = 0; i < RPT; ++i) {
 		const int lr = lgr[i];
-		const double av = fabs((double) x[i][JJ]);
+		const double av = fabs((double) x[i][0]);
 		if (lr >= J && lr < a.m && av > 0.0 && better(av, lr, bv, br)) {
 			bv = av;
 			br = lr;
@@ -735,7 +742,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 				sh.stage[JJ][lane] = (T) sel;
 			}
 			if (lane == 0) {
-				sh.pinv = (T) 1 / (T) gv[JJ]; // factor.rs:50 `recip()`, computed once per workgroup
+				sh.pinv = (T) 1 / (T) gv[0]; // factor.rs:50 `recip()`, computed once per workgroup
 				sh.p = p;
 				sh.flag = ok;
 			}
@@ -757,7 +764,7 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 			sh.stage[JJ][tid] = val;
 			if (tid < 8)
 				sh.pivg[tid] = val;
-			if (tid == JJ)
+			if (tid == 0)
 				sh.pinv = (T) 1 / val;
 			if (tid == 0) {
 				sh.p = p;
@@ -787,33 +794,24 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 		if (lr == J)
 			nret[i] = JJ; // retired: pivots JJ .. 7 of this group do not act on it
 		if (lr > J && lr < a.m) {
-			const T l = x[i][JJ] * inv;
-			x[i][JJ] = l;
+			const T l = x[i][0] * inv;
+			x[i][0] = l;
 #pragma unroll
-			for (int k = JJ + 1; k < 8; ++k)
-				x[i][k] = fh_fma(l, -u[k], x[i][k]); // rank_update_imp: fma(l_i, -u_c, dst)
+			for (int k = 1; k < 8; ++k)
+				if (k <= 7 - JJ) // wave uniform: positions beyond hold the multipliers of the finished columns
+					x[i][k] = fh_fma(l, -u[k], x[i][k]); // rank_update_imp: fma(l_i, -u_c, dst)
 		}
+		// rotate the window: position 0 (finished) goes to position 7
+		const T f = x[i][0];
+#pragma unroll
+		for (int k = 0; k < 7; ++k)
+			x[i][k] = x[i][k + 1];
+		x[i][7] = f;
 	}
 	FH_PT(7); // relabel + group update
 	FH_PT_COUNT(13, 1); // columns
 	return true;
 }
-
-template <typename T, int W, int RPT, int JJ> struct Panel3Group {
-	static __device__ __forceinline__ int run(const Panel3Args<T> &a, T (&x)[RPT][W], int (&lgr)[RPT], int (&nret)[RPT], Panel3Shared<T, W> &sh,
-						  Pend3 &pd, int G, int grp, int steps)
-	{
-		if constexpr (JJ < 8) {
-			if (grp * 8 + JJ >= steps)
-				return JJ; // pivots done in this group
-			if (!panel3_step<T, W, RPT, JJ>(a, x, lgr, nret, sh, pd, G, grp))
-				return -1;
-			return Panel3Group<T, W, RPT, JJ + 1>::run(a, x, lgr, nret, sh, pd, G, grp, steps);
-		} else {
-			return 8;
-		}
-	}
-};
 
 template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void getrf_panel3_kernel(const Panel3Args<T> a)
 {
@@ -846,9 +844,25 @@ template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void 
 #pragma unroll
 		for (int i = 0; i < RPT; ++i)
 			nret[i] = (lgr[i] >= J0 && lgr[i] < a.m) ? 8 : 0;
-		const int ng = Panel3Group<T, W, RPT, 0>::run(a, x, lgr, nret, sh, pd, G, grp, steps);
+		int ng = 0;
+		bool bad = false;
+		for (; ng < 8 && J0 + ng < steps; ++ng)
+			if (!panel3_step<T, W, RPT>(a, x, lgr, nret, sh, pd, G, grp, ng)) {
+				bad = true;
+				break;
+			}
+		// a partial last group: finish the 8 rotations so that the window is back in natural order
+		for (int r8 = ng; r8 < 8 && !bad; ++r8) {
+#pragma unroll
+			for (int i = 0; i < RPT; ++i) {
+				const T f = x[i][0];
+#pragma unroll
+				for (int k = 0; k < 7; ++k)
+					x[i][k] = x[i][k + 1];
+				x[i][7] = f;
+			}
+		}
 		FH_PT_DECL;
-		bool bad = ng < 0;
 		if (!bad && G > 1 && wave == 0)
 			bad = !pend3_finish<T, W>(pd, sh, lane);
 		if (__syncthreads_or(bad ? 1 : 0)) {
@@ -867,7 +881,8 @@ template <typename T, int W, int RPT> __global__ __launch_bounds__(LU2_NT) void 
 				T acc = sh.stage[t][c];
 #pragma unroll
 				for (int s2 = 0; s2 < t; ++s2)
-					acc = fh_fma(-sh.stage[t][s2], ut[s2], acc);
+					acc = fh_fma(-sh.stage[t][8 - t + s2], ut[s2], acc); // l_ts as published at step t: window position 8 - t + s
+
 				ut[t] = t < ng ? acc : (T) 0;
 			}
 #pragma unroll

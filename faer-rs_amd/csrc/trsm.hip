@@ -145,19 +145,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void trsm_pack_kernel(const T *__restrict__ Lp, idx_t lrs, idx_t lcs, int n, int unit, T *__restrict__ W)
 {
 	typedef TriPack<T> P;
-	__shared__ int toff[TP_H];
 	const int b = blockIdx.x;
 	const int r0 = b * TP_NB;
 	const int nb = min(TP_NB, n - r0);
-	if (threadIdx.x < TP_H)
-		toff[threadIdx.x] = P::tri_off(threadIdx.x);
 	T *img = W + (size_t) b * P::SIZE;
 	// alignment holes of the packed triangles must read as zeros (they are multiplied into padding lanes only, but
 	// NaN garbage would still propagate): clear the two triangles first
-	for (int e = threadIdx.x; e < P::TRI; e += blockDim.x) {
+	for (int e = threadIdx.x; e < P::TRI; e += blockDim.x) { // the strictly upper parts of the diagonal 8 x 8 blocks
 		img[P::OFF_T00 + e] = (T) 0;
 		img[P::OFF_T11 + e] = (T) 0;
 	}
+	for (int e = threadIdx.x; e < P::PAD; e += blockDim.x)
+		img[P::SIZE - P::PAD + e] = (T) 0;
 	__syncthreads();
 	const T *L0 = Lp + (idx_t) r0 * lrs + (idx_t) r0 * lcs;
 	constexpr int U = 8;
@@ -179,9 +178,9 @@ __global__ __launch_bounds__(256) void trsm_pack_kernel(const T *__restrict__ Lp
 				continue;
 			const T val = i == j ? ((unit || i >= nb) ? (T) 1 : (T) 1 / v[u]) : v[u]; // the diagonal enters as its reciprocal
 			if (i < TP_H)
-				img[P::OFF_T00 + toff[j] + (i - j)] = val;
+				img[P::OFF_T00 + P::tri_pos(i, j)] = val;
 			else if (j >= TP_H)
-				img[P::OFF_T11 + toff[j - TP_H] + (i - j)] = val;
+				img[P::OFF_T11 + P::tri_pos(i - TP_H, j - TP_H)] = val;
 			else
 				img[P::OFF_T10 + (i - TP_H) * TP_H + j] = val;
 		}
@@ -225,45 +224,48 @@ template <int CNT, typename V> static __device__ __forceinline__ void lds_wait(V
 	asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(CNT));
 }
 
-// x <- tri^-1 x, column oriented (the diagonal enters as a reciprocal: first entry of every column block)
-template <typename T, int J, int K> struct SubstRead {
+// x <- tri^-1 x.  One group of 8 columns per iteration of a run-time loop (trsm_pack.h): the 8 x 8 diagonal block
+// first (column oriented, the diagonal enters as a reciprocal), then the blocks of 8 rows below it -- the code of all
+// seven is there, the triangle leaves early -- and the registers rotate by 8 so that the next group is at 0 .. 7 again.
+// Linear read index inside a group: L = ((pb * 8 + jj) * 8) / EPR + r.
+template <typename T, int PB, int JJ, int RD> struct SubstRead {
 	typedef TriPack<T> P;
 	typedef typename V16<T>::type V;
-	static constexpr int EPR = P::ALIGN;			   // elements per read
-	static constexpr int NR = P::TRI / EPR;			   // reads of the whole triangle
-	static constexpr int R = P::tri_off(J) / EPR + K;	   // linear read index
-	static constexpr int NRJ = P::col_len(J) / EPR;	   // reads of column J
-	static __device__ __forceinline__ void run(T (&x)[TP_H], V (&ring)[TL_D], unsigned base, T &xj)
+	static constexpr int EPR = P::ALIGN;
+	static constexpr int RPC = 8 / EPR; // reads per column of a block
+	static constexpr int L = (PB * 8 + JJ) * RPC + RD;
+	static __device__ __forceinline__ void run(T (&x)[TP_H], T (&xj)[8], V (&ring)[TL_D], unsigned base)
 	{
-		if constexpr (K < NRJ) {
-			constexpr int S = R % TL_D;
-			lds_wait<(R + TL_D <= NR ? TL_D - 1 : NR - 1 - R)>(ring[S]);
+		constexpr int S = L % TL_D;
+		lds_wait<TL_D - 1>(ring[S]);
 #pragma unroll
-			for (int u = 0; u < EPR; ++u) {
-				constexpr int dummy = 0;
-				(void) dummy;
-				const int e = K * EPR + u; // position inside the column block: 0 = 1 / t_jj, e = row J + e
-				if (e == 0) {
-					xj = x[J] * ring[S][u];
-					x[J] = xj;
-				} else if (J + e < TP_H) {
-					x[J + e] = fh_fma(-ring[S][u], xj, x[J + e]);
+		for (int u = 0; u < EPR; ++u) {
+			const int e = RD * EPR + u; // row inside the block
+			if (PB == 0) {
+				if (e == JJ) {
+					xj[JJ] = x[JJ] * ring[S][u];
+					x[JJ] = xj[JJ];
+				} else if (e > JJ) {
+					x[e] = fh_fma(-ring[S][u], xj[JJ], x[e]);
 				}
+			} else {
+				x[PB * 8 + e] = fh_fma(-ring[S][u], xj[JJ], x[PB * 8 + e]);
 			}
-			if constexpr (R + TL_D < NR)
-				lds_read128<(R + TL_D) * 16>(ring[S], base);
-			SubstRead<T, J, K + 1>::run(x, ring, base, xj);
 		}
+		lds_read128<(L + TL_D) * 16>(ring[S], base); // may run past the group: harmless read-ahead (image pad)
+		if constexpr (RD + 1 < RPC)
+			SubstRead<T, PB, JJ, RD + 1>::run(x, xj, ring, base);
+		else if constexpr (JJ + 1 < 8)
+			SubstRead<T, PB, JJ + 1, 0>::run(x, xj, ring, base);
 	}
 };
-template <typename T, int J> struct SubstCol {
+template <typename T, int PB, int NBLK> struct SubstBlocks {
 	typedef typename V16<T>::type V;
-	static __device__ __forceinline__ void run(T (&x)[TP_H], V (&ring)[TL_D], unsigned base)
+	static __device__ __forceinline__ void run(T (&x)[TP_H], T (&xj)[8], V (&ring)[TL_D], unsigned base)
 	{
-		if constexpr (J < TP_H) {
-			T xj;
-			SubstRead<T, J, 0>::run(x, ring, base, xj);
-			SubstCol<T, J + 1>::run(x, ring, base);
+		if constexpr (PB < NBLK) {
+			SubstRead<T, PB, 0, 0>::run(x, xj, ring, base);
+			SubstBlocks<T, PB + 1, NBLK>::run(x, xj, ring, base);
 		}
 	}
 };
@@ -277,12 +279,49 @@ template <typename T, int R> struct PipeFill { // the first TL_D reads of a stre
 		}
 	}
 };
-template <typename T> static __device__ __forceinline__ void tl_subst(T (&x)[TP_H], const T *tri)
+template <typename T, int R> struct PipeDrain {
+	typedef typename V16<T>::type V;
+	static __device__ __forceinline__ void run(V (&ring)[TL_D])
+	{
+		if constexpr (R < TL_D) {
+			lds_wait<0>(ring[R]);
+			PipeDrain<T, R + 1>::run(ring);
+		}
+	}
+};
+// One group: the diagonal 8 x 8 block, then NBLK - 1 blocks of 8 rows below it with NO test whether the triangle
+// has that many left: register positions past the end of the triangle are dead (their rows went to `out` when
+// they were finished), the FMAs on them and the multipliers read for them (whatever follows the group in the
+// image) are wasted work that keeps the code regular.  Finished rows 8 g .. 8 g + 7 go to out[(8 g + k) * TL_XP].
+template <typename T, int NBLK>
+static __device__ __forceinline__ void tl_subst_group(T (&x)[TP_H], typename V16<T>::type (&ring)[TL_D], const T *tri, int g, T *out)
+{
+	typedef TriPack<T> P;
+	const unsigned base = (unsigned) (size_t) (tri + P::goff(g)); // LDS byte address of the group
+	T xj[8];
+	PipeFill<T, 0>::run(ring, base);
+	SubstBlocks<T, 0, NBLK>::run(x, xj, ring, base);
+	// drain the read-ahead while the ring registers are still live (a read landing in a register the compiler has
+	// reused for something else would corrupt it: the reads are asm, their unused outputs look dead to it)
+	PipeDrain<T, 0>::run(ring);
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		out[(g * 8 + k) * TL_XP] = xj[k];
+#pragma unroll
+	for (int c = 0; c + 8 < TP_H; ++c)
+		x[c] = x[c + 8];
+}
+// x <- tri^-1 x; the solution goes to out[row * TL_XP] (the caller's column of the exchange tile), x is destroyed.
+// Groups 0 .. 3 run the 8-block code (6.5 needed on average), groups 4 .. 7 a 4-block copy (2.5 needed).
+template <typename T> static __device__ __forceinline__ void tl_subst(T (&x)[TP_H], const T *tri, T *out)
 {
 	typename V16<T>::type ring[TL_D];
-	const unsigned base = (unsigned) (size_t) tri; // LDS byte address
-	PipeFill<T, 0>::run(ring, base);
-	SubstCol<T, 0>::run(x, ring, base);
+#pragma unroll 1
+	for (int g = 0; g < 4; ++g)
+		tl_subst_group<T, 8>(x, ring, tri, g, out);
+#pragma unroll 1
+	for (int g = 4; g < 8; ++g)
+		tl_subst_group<T, 4>(x, ring, tri, g, out);
 }
 
 // acc[u] = sum_j T10(i0 + u, j) x_j for TL_EB rows at a time: the reads walk the TL_EB rows column pair by column pair
@@ -335,94 +374,59 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	const bool act = lane < nc;
 
 	// Memory phases are organised by ROUND TRIPS, not by data: every batch below is a set of independent loads in
-	// flight together (a leaf spends ~1.5 us per dependent round trip when the chip is busy -- with 8-deep batches the
-	// loads alone took ~40 us of a ~60 us leaf, profiles/r02_trsm_leaf.txt).
-	//   trip 1: first half of the packed image + this wave's 64 x 64 block of right-hand sides (rows 0 .. 63)
-	//   trip 2: second half of the image (+ rows 64 .. 127 when lanes run along the right-hand sides: they go
-	//           straight to the exchange tile, which that layout does not need for anything else)
+	// flight together (a leaf spends ~1.5 us per dependent round trip when the chip is busy), and the code is kept
+	// SMALL (run-time loops around 16- / 32-deep batches): the whole kernel has to stay inside the 64 KB instruction
+	// cache, straight-line code runs at the speed of instruction fetch (profiles/r02_trsm_leaf.txt).
 	typedef int v4i __attribute__((ext_vector_type(4)));
 	const v4i *isrc = reinterpret_cast<const v4i *>(img);
 	v4i *idst = reinterpret_cast<v4i *>(Ls);
-	constexpr int NV = (int) (P::BYTES / 16), UA = (NV / 128 + 2) / 2, UB = (NV - UA * 128 + 127) / 128; // two batches per thread
-	static_assert(UB > 0 && UB <= UA, "image batches");
+	constexpr int NV = (int) (P::BYTES / 16), UI = 12; // image: batches of 12 vectors per thread
 	const bool two = n > TP_H;
 	const int ns0 = min(TP_H, n), ns1 = two ? n - TP_H : 0;
-	T y[TP_H];
-	{
-		v4i va[UA];
-#pragma unroll
-		for (int u = 0; u < UA; ++u)
-			va[u] = isrc[threadIdx.x + u * 128];
+
+	// rows s0 .. s0+ns-1 of this wave's 64 right-hand sides -> tile (zero padded), lanes along the small stride
+	auto load_half = [&](int s0, int ns) {
 		if (lanes_along_rhs) {
-#pragma unroll
-			for (int i = 0; i < TP_H; ++i) {
-				const bool in = i < ns0 && act;
-				const T t = Xp[in ? (idx_t) i * xss + (idx_t) (c0 + lane) * xcs : (idx_t) 0];
-				y[i] = in ? t : (T) 0;
-			}
-		} else {
-#pragma unroll
-			for (int cc = 0; cc < TP_H; ++cc) {
-				const bool in = cc < nc && lane < ns0;
-				const T t = Xp[in ? (idx_t) lane * xss + (idx_t) (c0 + cc) * xcs : (idx_t) 0];
-				y[cc] = in ? t : (T) 0; // transposed: y[cc] is (row = lane, rhs = cc) until it has been through the tile
-			}
-		}
-#pragma unroll
-		for (int u = 0; u < UA; ++u)
-			idst[threadIdx.x + u * 128] = va[u];
-	}
-	{
-		v4i vb[UB];
-#pragma unroll
-		for (int u = 0; u < UB; ++u)
-			vb[u] = isrc[min(UA * 128 + (int) threadIdx.x + u * 128, NV - 1)];
-		if (!lanes_along_rhs) {
-#pragma unroll
-			for (int cc = 0; cc < TP_H; ++cc)
-				Xs[lane * TL_XP + cc] = y[cc];
-			__builtin_amdgcn_wave_barrier();
-#pragma unroll
-			for (int i = 0; i < TP_H; ++i)
-				y[i] = Xs[i * TL_XP + lane];
-			__builtin_amdgcn_wave_barrier();
-		} else if (two) {
-			// rows 64 .. 127 -> tile, two batches of 32 loads
-#pragma unroll
+#pragma unroll 1
 			for (int i0 = 0; i0 < TP_H; i0 += 32) {
 				T v[32];
 #pragma unroll
 				for (int u = 0; u < 32; ++u) {
-					const bool in = i0 + u < ns1 && act;
-					const T t = Xp[in ? (idx_t) (TP_H + i0 + u) * xss + (idx_t) (c0 + lane) * xcs : (idx_t) 0];
+					const bool in = i0 + u < ns && act;
+					const T t = Xp[in ? (idx_t) (s0 + i0 + u) * xss + (idx_t) (c0 + lane) * xcs : (idx_t) 0];
 					v[u] = in ? t : (T) 0;
 				}
 #pragma unroll
 				for (int u = 0; u < 32; ++u)
 					Xs[(i0 + u) * TL_XP + lane] = v[u];
 			}
+		} else {
+#pragma unroll 1
+			for (int c8 = 0; c8 < TP_H; c8 += 32) {
+				T v[32];
+#pragma unroll
+				for (int u = 0; u < 32; ++u) {
+					const bool in = c8 + u < nc && lane < ns;
+					const T t = Xp[in ? (idx_t) (s0 + lane) * xss + (idx_t) (c0 + c8 + u) * xcs : (idx_t) 0];
+					v[u] = in ? t : (T) 0;
+				}
+#pragma unroll
+				for (int u = 0; u < 32; ++u)
+					Xs[lane * TL_XP + c8 + u] = v[u];
+			}
 		}
-#pragma unroll
-		for (int u = 0; u < UB; ++u)
-			if (UA * 128 + (int) threadIdx.x + u * 128 < NV)
-				idst[UA * 128 + (int) threadIdx.x + u * 128] = vb[u];
-	}
-	__syncthreads(); // the image is in LDS
-
-	// rows s0 .. s0+63 of the solution, held in v (lane = right-hand side), back to X
-	auto store_half = [&](const T (&v)[TP_H], int s0, int ns) {
+		__builtin_amdgcn_wave_barrier();
+	};
+	// rows s0 .. s0+ns-1 of the solution, tile -> X
+	auto store_half = [&](int s0, int ns) {
+		__builtin_amdgcn_wave_barrier();
 		if (lanes_along_rhs) {
-#pragma unroll
+#pragma unroll 16
 			for (int i = 0; i < TP_H; ++i)
 				if (i < ns && act)
-					Xp[(idx_t) (s0 + i) * xss + (idx_t) (c0 + lane) * xcs] = v[i];
+					Xp[(idx_t) (s0 + i) * xss + (idx_t) (c0 + lane) * xcs] = Xs[i * TL_XP + lane];
 		} else {
-			__builtin_amdgcn_wave_barrier();
-#pragma unroll
-			for (int i = 0; i < TP_H; ++i)
-				Xs[i * TL_XP + lane] = v[i];
-			__builtin_amdgcn_wave_barrier();
-#pragma unroll
+#pragma unroll 1
 			for (int c8 = 0; c8 < TP_H; c8 += 16) {
 				T w[16];
 #pragma unroll
@@ -433,34 +437,52 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 					if (c8 + u < nc && lane < ns)
 						Xp[(idx_t) (s0 + lane) * xss + (idx_t) (c0 + c8 + u) * xcs] = w[u];
 			}
-			__builtin_amdgcn_wave_barrier();
-		}
-	};
-
-	// ---- half 0: substitution on T00 (lane = right-hand side, register = row)
-	tl_subst<T>(y, Ls + P::OFF_T00);
-	store_half(y, 0, ns0);
-	if (!two)
-		return;
-	// ---- half 1: b_i - sum_j T10(i, j) y_j with the solved y_j still in registers and the rows of T10 as LDS
-	// broadcasts, then the same substitution on T11
-	if (!lanes_along_rhs) {
-		// rows 64 .. 127 through the tile (free again now), two batches of 32 right-hand sides
-#pragma unroll
-		for (int c8 = 0; c8 < TP_H; c8 += 32) {
-			T v[32];
-#pragma unroll
-			for (int u = 0; u < 32; ++u) {
-				const bool in = c8 + u < nc && lane < ns1;
-				const T t = Xp[in ? (idx_t) (TP_H + lane) * xss + (idx_t) (c0 + c8 + u) * xcs : (idx_t) 0];
-				v[u] = in ? t : (T) 0;
-			}
-#pragma unroll
-			for (int u = 0; u < 32; ++u)
-				Xs[lane * TL_XP + c8 + u] = v[u];
 		}
 		__builtin_amdgcn_wave_barrier();
+	};
+
+	// trip 1: first image batch + the top rows; then the rest of the image
+	{
+		v4i va[UI];
+#pragma unroll
+		for (int u = 0; u < UI; ++u)
+			va[u] = isrc[min((int) threadIdx.x + u * 128, NV - 1)];
+		load_half(0, ns0);
+#pragma unroll
+		for (int u = 0; u < UI; ++u)
+			if ((int) threadIdx.x + u * 128 < NV)
+				idst[threadIdx.x + u * 128] = va[u];
 	}
+#pragma unroll 1
+	for (int e0 = UI * 128 + (int) threadIdx.x; e0 < NV; e0 += UI * 128) {
+		v4i va[UI];
+#pragma unroll
+		for (int u = 0; u < UI; ++u)
+			va[u] = isrc[min(e0 + u * 128, NV - 1)];
+#pragma unroll
+		for (int u = 0; u < UI; ++u)
+			if (e0 + u * 128 < NV)
+				idst[e0 + u * 128] = va[u];
+	}
+	__syncthreads(); // the image is in LDS
+
+	// ---- half 0: substitution on T00 (lane = right-hand side, register = row); the solution goes back to the tile
+	T y[TP_H];
+#pragma unroll
+	for (int i = 0; i < TP_H; ++i)
+		y[i] = Xs[i * TL_XP + lane];
+	tl_subst<T>(y, Ls + P::OFF_T00, Xs + lane);
+	store_half(0, ns0);
+	if (!two)
+		return;
+	// ---- half 1: b_i - sum_j T10(i, j) y_j with the solved y_j in registers and the rows of T10 as LDS broadcasts,
+	// then the same substitution on T11
+#pragma unroll
+	for (int i = 0; i < TP_H; ++i)
+		y[i] = Xs[i * TL_XP + lane];
+	__builtin_amdgcn_wave_barrier();
+	load_half(TP_H, ns1);
+#pragma unroll 1
 	for (int i0 = 0; i0 < TP_H; i0 += TL_EB) {
 		typename V16<T>::type ring[TL_D];
 		T acc[TL_EB][2];
@@ -475,12 +497,11 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 			Xs[(i0 + u) * TL_XP + lane] -= acc[u][0] + acc[u][1];
 	}
 	__builtin_amdgcn_wave_barrier();
-	T z[TP_H];
 #pragma unroll
 	for (int i = 0; i < TP_H; ++i)
-		z[i] = Xs[i * TL_XP + lane];
-	tl_subst<T>(z, Ls + P::OFF_T11);
-	store_half(z, TP_H, ns1);
+		y[i] = Xs[i * TL_XP + lane];
+	tl_subst<T>(y, Ls + P::OFF_T11, Xs + lane);
+	store_half(TP_H, ns1);
 }
 
 template <typename T> static size_t trsm_leaf128_lds()
