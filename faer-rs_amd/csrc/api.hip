@@ -1350,6 +1350,8 @@ size_t faer_hip_debug_llt_plan(size_t n, size_t tail_rows, size_t nb2, size_t *s
 		starts[i] = (size_t) J[i];
 	return J.size();
 }
+void faer_hip_debug_dump_timing(void) { trsm_dump_timing(); }
+
 int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, int resident_workgroups)
 {
 	return lu_leaf_width((idx_t) nrows, dtype == FaerHipDType_F64 ? 8 : 4, resident_workgroups);

@@ -296,6 +296,7 @@ template <typename T> void trsm_upper_dev(MatV<const T> U, bool unit, MatV<T> X)
 // same as trsm_lower_dev with the packed images (trsm_pack.h) of L's 128 x 128 diagonal blocks already in W
 template <typename T> void trsm_lower_pre_dev(MatV<const T> L, MatV<T> X, const T *W);
 template <typename T> void trsm_pack_dev(MatV<const T> L, bool unit, T *W);
+void trsm_dump_timing(); // timing build only (no-op otherwise)
 
 // in-place lower Cholesky; returns >=0 regularization count or -(index+1)   (potrf.hip)
 template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps);

@@ -138,6 +138,41 @@ __global__ __launch_bounds__(64) void trsm_leaf_kernel(const T *__restrict__ Lp,
 //     side index (rows of a transposed Cholesky panel), through a padded LDS tile otherwise (columns of X).
 // ------------------------------------------------------------------------------------------------
 constexpr int TRSM_IB = TP_NB;
+
+// -DFH_PANEL_TIMING: s_memtime phase accounting of the substitution leaf (workgroup 0 / thread 0), printed and reset
+// by faer_hip_debug_dump_timing() (timing build only: make -C csrc timing)
+#ifdef FH_PANEL_TIMING
+__device__ unsigned long long g_leaf128_timing[16];
+#define FH_TT(i)                                                                                                         \
+	do {                                                                                                             \
+		if (blockIdx.x == 0 && threadIdx.x == 0) {                                                               \
+			const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                    \
+			atomicAdd(&g_leaf128_timing[i], now_ - tt_last);                                                 \
+			tt_last = now_;                                                                                  \
+		}                                                                                                        \
+	} while (0)
+#define FH_TT_DECL unsigned long long tt_last = __builtin_amdgcn_s_memtime()
+void trsm_dump_timing()
+{
+	unsigned long long d[16];
+	FH_HIP(hipDeviceSynchronize());
+	FH_HIP(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_leaf128_timing), sizeof(d)));
+	const double c = d[15] ? (double) d[15] : 1.0;
+	fprintf(stderr,
+		"trsm leaf128 phases (s_memtime ticks per launch, wg 0 / thread 0, %llu launches): image+rows0 %.0f | rest of image+bar %.0f | subst0 %.0f | "
+		"store0 %.0f | reload+rows1 %.0f | eliminate %.0f | subst1 %.0f | store1 %.0f\n",
+		d[15], d[0] / c, d[1] / c, d[2] / c, d[3] / c, d[4] / c, d[5] / c, d[6] / c, d[7] / c);
+	unsigned long long z[16] = {0};
+	FH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_leaf128_timing), z, sizeof(z)));
+}
+#else
+#define FH_TT(i)                                                                                                         \
+	do {                                                                                                             \
+	} while (0)
+#define FH_TT_DECL
+void trsm_dump_timing() {}
+#endif
+
 constexpr int TL_XP = TP_H + 1; // pitch of the per-wave 64 x 64 exchange tile
 
 // W block b <- packed image of the b-th 128 x 128 diagonal block of the lower triangular L
@@ -441,6 +476,7 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 		__builtin_amdgcn_wave_barrier();
 	};
 
+	FH_TT_DECL;
 	// trip 1: first image batch + the top rows; then the rest of the image
 	{
 		v4i va[UI];
@@ -453,6 +489,7 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 			if ((int) threadIdx.x + u * 128 < NV)
 				idst[threadIdx.x + u * 128] = va[u];
 	}
+	FH_TT(0);
 #pragma unroll 1
 	for (int e0 = UI * 128 + (int) threadIdx.x; e0 < NV; e0 += UI * 128) {
 		v4i va[UI];
@@ -465,6 +502,7 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 				idst[e0 + u * 128] = va[u];
 	}
 	__syncthreads(); // the image is in LDS
+	FH_TT(1);
 
 	// ---- half 0: substitution on T00 (lane = right-hand side, register = row); the solution goes back to the tile
 	T y[TP_H];
@@ -472,7 +510,9 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	for (int i = 0; i < TP_H; ++i)
 		y[i] = Xs[i * TL_XP + lane];
 	tl_subst<T>(y, Ls + P::OFF_T00, Xs + lane);
+	FH_TT(2);
 	store_half(0, ns0);
+	FH_TT(3);
 	if (!two)
 		return;
 	// ---- half 1: b_i - sum_j T10(i, j) y_j with the solved y_j in registers and the rows of T10 as LDS broadcasts,
@@ -482,6 +522,7 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 		y[i] = Xs[i * TL_XP + lane];
 	__builtin_amdgcn_wave_barrier();
 	load_half(TP_H, ns1);
+	FH_TT(4);
 #pragma unroll 1
 	for (int i0 = 0; i0 < TP_H; i0 += TL_EB) {
 		typename V16<T>::type ring[TL_D];
@@ -497,11 +538,18 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 			Xs[(i0 + u) * TL_XP + lane] -= acc[u][0] + acc[u][1];
 	}
 	__builtin_amdgcn_wave_barrier();
+	FH_TT(5);
 #pragma unroll
 	for (int i = 0; i < TP_H; ++i)
 		y[i] = Xs[i * TL_XP + lane];
 	tl_subst<T>(y, Ls + P::OFF_T11, Xs + lane);
+	FH_TT(6);
 	store_half(TP_H, ns1);
+	FH_TT(7);
+#ifdef FH_PANEL_TIMING
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		atomicAdd(&g_leaf128_timing[15], 1ull);
+#endif
 }
 
 template <typename T> static size_t trsm_leaf128_lds()

@@ -479,6 +479,8 @@ FAER_HIP_API void faer_hip_debug_stream_xcc(int which, int nblocks, unsigned *ou
  * the cooperative LU panel kernel picks for `nrows` rows when `resident_workgroups` workgroups fit the device. */
 FAER_HIP_API size_t faer_hip_debug_llt_plan(size_t n, size_t tail_rows, size_t nb2, size_t *starts, size_t cap);
 FAER_HIP_API int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, int resident_workgroups);
+/* Instrumented builds (make -C csrc timing): prints and resets the in-kernel phase counters; a no-op otherwise. */
+FAER_HIP_API void faer_hip_debug_dump_timing(void);
 /* The internal CU-masked streams themselves (1 = bulk, 2 = panel), for microbenchmarks via faer_hip_set_stream. */
 FAER_HIP_API void *faer_hip_debug_internal_stream(int which);
 /* Measures `iters` back-to-back launches of the dense GEMM kernel on the calling thread's stream with
