@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override the matrix size (testing only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--transport", default="torch", choices=["torch", "rccl"],
+                    help="multi-GPU lu/llt: broadcast through torch.distributed (RCCL under the nccl backend) or the library's own "
+                         "RCCL transport (ncclBroadcast on a dedicated stream, no Python callback in the loop)")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,6 +86,15 @@ def main():
     torch.cuda.set_device(local_rank)
     F.use_torch_stream()
     dev = torch.device("cuda", local_rank)
+
+    rccl = None
+    if dist is not None and args.transport == "rccl" and args.workload in ("lu", "llt"):
+        # the 128-byte ncclUniqueId of the library's own communicator travels through the torch process group
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(F.RcclTransport.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        rccl = F.RcclTransport(bytes(idt.cpu().numpy().tobytes()), rank, world)
 
     def barrier():
         if dist is not None:
@@ -136,8 +148,11 @@ def main():
 
             def step():
                 work.copy_(a)
-                F.dist_llt(work, n, nb, rank, world, lambda t, root: dist.broadcast(t, src=root), panel_ws=ws,
-                           ibcast=lambda t, root: dist.broadcast(t, src=root, async_op=True))
+                if rccl is not None:
+                    F.dist_llt(work, n, nb, rank, world, panel_ws=ws, transport=rccl)
+                else:
+                    F.dist_llt(work, n, nb, rank, world, lambda t, root: dist.broadcast(t, src=root), panel_ws=ws,
+                               ibcast=lambda t, root: dist.broadcast(t, src=root, async_op=True))
 
             return step, n ** 3 / 3.0 / world, lambda: work.copy_(a), f"llt_f64_n{n}_blockcyclic{nb}", "f64"
         if name == "llt":
@@ -166,8 +181,11 @@ def main():
 
                 def step():
                     work.copy_(a)
-                    F.dist_partial_piv_lu(work, n, nb, rank, world, lambda t, root: dist.broadcast(t, src=root), panel_ws=ws,
-                                          ibcast=lambda t, root: dist.broadcast(t, src=root, async_op=True))
+                    if rccl is not None:
+                        F.dist_partial_piv_lu(work, n, nb, rank, world, panel_ws=ws, transport=rccl)
+                    else:
+                        F.dist_partial_piv_lu(work, n, nb, rank, world, lambda t, root: dist.broadcast(t, src=root), panel_ws=ws,
+                                              ibcast=lambda t, root: dist.broadcast(t, src=root, async_op=True))
 
                 return step, 2.0 * n ** 3 / 3.0 / world, lambda: work.copy_(a), f"lu_f64_n{n}_blockcyclic{nb}", "f64"
             a = colmajor(n, n, torch.float64, 4)

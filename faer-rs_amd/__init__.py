@@ -512,11 +512,42 @@ def _make_comm(rank, world_size, panel_ws, bcast, ibcast=None):
     return HipComm(int(rank), int(world_size), fns[0], None, fns[1], fns[2]), fns
 
 
+class RcclTransport:
+    """Built-in transport of the distributed drivers (include/faer_hip.h, csrc/rccl_transport.hip): ncclBroadcast on a
+    dedicated stream, event-ordered against the caller's stream; no Python callback in the factorization loop.
+
+    Collective: every rank constructs it with the same 128-byte id (rank 0: RcclTransport.unique_id(), shipped to the
+    others by the application, e.g. torch.distributed.broadcast of a uint8 tensor)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        rc = lib().faer_hip_rccl_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"faer_hip_rccl_unique_id failed ({rc}): librccl.so not loadable?")
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, world_size):
+        L = lib()
+        L.faer_hip_rccl_create.restype = C.c_void_p
+        L.faer_hip_rccl_comm.restype = HipComm
+        L.faer_hip_rccl_comm.argtypes = [C.c_void_p]
+        L.faer_hip_rccl_destroy.argtypes = [C.c_void_p]
+        assert len(unique_id) == 128
+        self.handle = L.faer_hip_rccl_create((C.c_ubyte * 128).from_buffer_copy(unique_id), int(rank), int(world_size))
+        self.comm = L.faer_hip_rccl_comm(C.c_void_p(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib().faer_hip_rccl_destroy(C.c_void_p(self.handle))
+            self.handle = None
+
+
 def dist_local_ncols(n, nb, rank, world_size):
     return lib().faer_hip_dist_local_ncols(C.c_size_t(n), C.c_size_t(nb), int(rank), int(world_size))
 
 
-def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast, panel_ws=None, ibcast=None):
+def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast=None, panel_ws=None, ibcast=None, transport=None):
     """Distributed partial-pivot LU (1-D block-cyclic columns, one process per GPU; csrc/dist_lu.h).
 
     a_local  : this rank's block columns (nrows x dist_local_ncols, column major torch cuda tensor), factored in place
@@ -524,6 +555,7 @@ def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast, panel_ws
                lambda t, root: torch.distributed.broadcast(t, src=root)   (RCCL under the "nccl" backend)
     ibcast   : optional callable(view, root) -> handle with .wait() (async broadcast): enables the overlap of the next
                panel's transfer with the trailing updates
+    transport: an RcclTransport instead of the two callables (direct RCCL, no Python in the loop)
     returns  : (perm_fwd, perm_bwd, transposition_count), identical on every rank"""
     import torch
 
@@ -534,7 +566,7 @@ def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast, panel_ws
     if panel_ws is None:
         nsc = L.faer_hip_dist_panel_ws_scalars(C.c_size_t(m), C.c_size_t(nb), C.c_int(dt))
         panel_ws = torch.empty(nsc, dtype=a_local.dtype, device=a_local.device)
-    comm, _keep = _make_comm(rank, world_size, panel_ws, bcast, ibcast)
+    comm, _keep = (transport.comm, None) if transport is not None else _make_comm(rank, world_size, panel_ws, bcast, ibcast)
     base = panel_ws.data_ptr()
     fwd = np.zeros(m, dtype=np.uint64)
     bwd = np.zeros(m, dtype=np.uint64)
@@ -546,7 +578,7 @@ def dist_partial_piv_lu(a_local, n_global, nb, rank, world_size, bcast, panel_ws
     return fwd, bwd, st.transposition_count
 
 
-def dist_llt(a_local, n_global, nb, rank, world_size, bcast, panel_ws=None, ibcast=None, regularization=(0.0, 0.0)):
+def dist_llt(a_local, n_global, nb, rank, world_size, bcast=None, panel_ws=None, ibcast=None, regularization=(0.0, 0.0), transport=None):
     """Distributed Cholesky (lower; 1-D block-cyclic columns, one process per GPU; csrc/dist_llt.h).
 
     a_local : this rank's block columns at full height (n x dist_local_ncols, column major torch cuda tensor)
@@ -560,7 +592,7 @@ def dist_llt(a_local, n_global, nb, rank, world_size, bcast, panel_ws=None, ibca
         L.faer_hip_dist_llt_ws_scalars.restype = C.c_size_t
         nsc = L.faer_hip_dist_llt_ws_scalars(C.c_size_t(n_global), C.c_size_t(nb), C.c_int(dt))
         panel_ws = torch.empty(nsc, dtype=a_local.dtype, device=a_local.device)
-    comm, _keep = _make_comm(rank, world_size, panel_ws, bcast, ibcast)
+    comm, _keep = (transport.comm, None) if transport is not None else _make_comm(rank, world_size, panel_ws, bcast, ibcast)
     delta, eps = ct(regularization[0]), ct(regularization[1])
     reg = LltRegularization(C.cast(C.pointer(delta), C.c_void_p), C.cast(C.pointer(eps), C.c_void_p))
     fn = getattr(L, f"faer_hip_dist_llt_{suf}")

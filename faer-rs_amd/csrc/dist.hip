@@ -41,6 +41,65 @@ template <typename S> struct DeviceBackend {
 		if (comm.ibcast && comm.wait)
 			comm.wait(comm.user, slot);
 	}
+	// ---- two-stream schedule inside the rank (dist_lu.h): the rest of update k on the bulk stream, the look-ahead part
+	// (update of block column k+1 + its panel factorization, cooperative leaves on the reserved CUs) on the panel stream
+	bool two = false;
+	hipStream_t caller = nullptr;
+	hipEvent_t ev0 = nullptr, ev_bulk = nullptr;
+	void streams_init()
+	{
+		caller = ctx().stream;
+		two = !getenv("FAER_HIP_DIST_ONE_STREAM") && ctx().lookahead_streams();
+		if (two)
+			ctx().reset_events();
+	}
+	void step_begin()
+	{
+		if (!two)
+			return;
+		// the bulk stream's reads of the panel buffer that the next receive overwrites, and its writes to the columns the
+		// look-ahead part touches, are older than everything issued from here on
+		if (ev_bulk)
+			stream_wait(caller, ev_bulk);
+		ev0 = ctx().next_event();
+		FH_HIP(hipEventRecord(ev0, caller));
+	}
+	void rest_begin()
+	{
+		if (!two)
+			return;
+		stream_wait(ctx().la_bulk, ev0);
+		ctx().stream = ctx().la_bulk;
+	}
+	void rest_end()
+	{
+		if (!two)
+			return;
+		ev_bulk = ctx().next_event();
+		FH_HIP(hipEventRecord(ev_bulk, ctx().la_bulk));
+		ctx().stream = caller;
+	}
+	void ahead_begin()
+	{
+		if (!two)
+			return;
+		stream_wait(ctx().la_panel, ev0);
+		ctx().stream = ctx().la_panel;
+	}
+	void ahead_end()
+	{
+		if (!two)
+			return;
+		hipEvent_t e = ctx().next_event();
+		FH_HIP(hipEventRecord(e, ctx().la_panel));
+		ctx().stream = caller;
+		stream_wait(caller, e); // the broadcast of the new panel is ordered behind it
+	}
+	void run_end()
+	{
+		if (two && ev_bulk)
+			stream_wait(caller, ev_bulk);
+	}
 	void copy_ints(int *dst, const int *src, size_t n)
 	{
 		FH_HIP(hipMemcpyAsync(dst, src, n * sizeof(int), hipMemcpyDeviceToDevice, ctx().stream));
@@ -77,10 +136,15 @@ FaerPartialPivLuStatus dist_lu_api(FaerMatMut A_local, size_t n_global, size_t n
 	FH_CHECK(A_local.row_stride == 1, "dist lu: A_local must be column major");
 	B be;
 	be.comm = comm;
+	be.streams_init();
 	typename B::View Av{static_cast<T *>(A_local.ptr), m, (long) A_local.ncols, 1, (long) A_local.col_stride};
 	const long size = m < n ? m : n;
 	std::vector<int> piv((size_t) size);
 	DistLu<B>::run(be, Av, m, n, (long) nb, comm.rank, comm.world_size, static_cast<T *>(panel_ws), piv.data());
+	if (be.two) { // the pivots came back with a synchronisation of the caller's stream, which had joined both internal ones
+		ctx().sync();
+		ctx().quiesce();
+	}
 	// lu/partial_pivoting/factor.rs:274-277: perm = identity with the transpositions applied in order
 	unsigned long long *f = static_cast<unsigned long long *>(pf.ptr), *b = static_cast<unsigned long long *>(pb.ptr);
 	for (long i = 0; i < m; ++i)

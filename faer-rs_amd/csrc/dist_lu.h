@@ -30,12 +30,20 @@ namespace fh {
 //   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)
 //                                                        -- collective on the backend's memory space; may be
 //                                                           asynchronous (slot = 0 / 1, at most one in flight each)
+//   void step_begin() / void rest_begin() / rest_end() / ahead_begin() / ahead_end()
+//                                                        -- scheduling hooks (no-ops for a synchronous backend): the
+//                                                           device backend runs the "rest" updates of a step on the
+//                                                           bulk stream and the look-ahead part (update + panel of
+//                                                           block column k+1) on the CU-masked panel stream
 //   void copy_ints(int *dst, const int *src, size_t n)   -- inside the backend's memory space, stream ordered
 //   void to_host(int *dst, const int *src, size_t n)     -- pivots back to the host (synchronising)
 //
 // Look-ahead: the owner of block column k+1 brings that column up to date with panel k and factors it FIRST, then
 // starts its broadcast; every rank posts the receive before it runs the rest of update k, so the transfer of
 // panel k+1 and the latency-bound panel factorization on its owner overlap with the trailing updates of step k.
+// On the owner itself the REST of update k is issued first (an asynchronous backend queues it on its bulk stream) and
+// the look-ahead part second (on its panel stream): the two run concurrently inside the rank, exactly like the two
+// streams of the single-GPU driver (getrf.hip, getrf_lookahead).
 // Two panel buffers alternate; the pivots stay in the backend's memory until the end (no host synchronisation
 // inside the loop).
 template <class B> struct DistLu {
@@ -125,19 +133,30 @@ template <class B> struct DistLu {
 		for (long k = 0; k < nblk; ++k) {
 			be.bcast_wait((int) (k & 1));
 			be.copy_ints(piv_all + k * nb, piv_of(k), (size_t) fw(k));
+			be.step_begin();
 			const bool ahead = k + 1 < nblk;
-			if (ahead) {
-				const int next_owner = (int) ((k + 1) % world);
-				if (rank == next_owner) {
-					update(k, k + 1);
-					factor_and_pack(k + 1);
-				}
+			const int next_owner = ahead ? (int) ((k + 1) % world) : -1;
+			auto rest = [&]() {
+				be.rest_begin();
+				for (long b = rank; b < nblk_all; b += world)
+					if (!(ahead && b == k + 1))
+						update(k, b);
+				be.rest_end();
+			};
+			if (ahead && rank == next_owner) {
+				rest(); // queued first: runs beside the panel below on an asynchronous backend
+				be.ahead_begin();
+				update(k, k + 1);
+				factor_and_pack(k + 1);
+				be.ahead_end();
 				be.bcast_begin(piv_of(k + 1), bytes_of(k + 1), next_owner, (int) ((k + 1) & 1));
+			} else {
+				if (ahead) // post the receive before the updates: the transfer overlaps them
+					be.bcast_begin(piv_of(k + 1), bytes_of(k + 1), next_owner, (int) ((k + 1) & 1));
+				rest();
 			}
-			for (long b = rank; b < nblk_all; b += world)
-				if (!(ahead && b == k + 1))
-					update(k, b);
 		}
+		be.run_end();
 		std::vector<int> rel((size_t) size);
 		if (size > 0)
 			be.to_host(rel.data(), piv_all, (size_t) size);

@@ -503,6 +503,8 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	}
 	__syncthreads(); // the image is in LDS
 	FH_TT(1);
+	if (nc <= 0)
+		return; // the second wavefront of the last workgroup helped with the image only: the LDS pipe is the other one's
 
 	// ---- half 0: substitution on T00 (lane = right-hand side, register = row); the solution goes back to the tile
 	T y[TP_H];

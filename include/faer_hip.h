@@ -510,6 +510,15 @@ typedef struct FaerHipComm {
 	int rank; int world_size; FaerHipBcastFn bcast; void *user; FaerHipIbcastFn ibcast; FaerHipWaitFn wait;
 } FaerHipComm;
 
+/* Built-in transport: RCCL broadcasts on a dedicated stream, ordered against the calling thread's stream with events
+ * (csrc/rccl_transport.hip).  librccl is dlopen-ed on first use.  Rank 0 obtains the 128-byte ncclUniqueId with
+ * faer_hip_rccl_unique_id (0 = ok) and the application ships it to the other ranks; every rank then calls
+ * faer_hip_rccl_create (collective) and passes faer_hip_rccl_comm(handle) to the faer_hip_dist_* entry points. */
+FAER_HIP_API int faer_hip_rccl_unique_id(void *out_128_bytes);
+FAER_HIP_API void *faer_hip_rccl_create(const void *unique_id_128_bytes, int rank, int world_size);
+FAER_HIP_API FaerHipComm faer_hip_rccl_comm(void *handle);
+FAER_HIP_API void faer_hip_rccl_destroy(void *handle);
+
 /* Number of block columns of width `nb` owned by `rank` out of n columns distributed block-cyclically. */
 FAER_HIP_API size_t faer_hip_dist_local_ncols(size_t n, size_t nb, int rank, int world_size);
 /* Scalars of device scratch the distributed LU needs: all pivots + two broadcast buffers ({pivots, packed panel}). */

@@ -100,6 +100,13 @@ struct HostBackend {
 		bcast(buf, bytes, root);
 	}
 	void bcast_wait(int slot) { ++waited[slot]; }
+	// scheduling hooks of the asynchronous device backend: nothing to do on the host
+	void step_begin() {}
+	void rest_begin() {}
+	void rest_end() {}
+	void ahead_begin() {}
+	void ahead_end() {}
+	void run_end() {}
 	void copy_ints(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
 	void zero_ints(int *p, size_t n) { std::memset(p, 0, n * sizeof(int)); }
 	void from_host(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
