@@ -153,8 +153,8 @@ template <typename T, typename I> FaerPartialPivLuStatus lu_api(FaerMatMut A, Fa
 	}
 	FaerPartialPivLuStatus st;
 	memset(&st, 0, sizeof(st));
-	st.tag = FaerPartialPivLuStatus_Ok;
-	st.ok.transposition_count = (size_t) nt;
+	st.tag = nt >= 0 ? FaerPartialPivLuStatus_Ok : FaerPartialPivLuStatus_Unknown; // Unknown: exchange timeout (getrf.hip)
+	st.ok.transposition_count = nt >= 0 ? (size_t) nt : 0;
 	return st;
 }
 

@@ -642,6 +642,10 @@ static __device__ __forceinline__ bool panel3_step(const Panel3Args<T> &a, T (&x
 				xwg_store_gran(sg + 2, tag, (unsigned) vb);
 			}
 			FH_PT(2); // header published
+			// a sweep issued before the other workgroups' stores have landed costs a whole round trip before the next
+			// one can start: give them a head start (tunable; 0 = poll at once)
+			for (int d = 0; d < a.poll_delay; ++d)
+				__builtin_amdgcn_s_sleep(1);
 			// ---- records of all producers, header AND the 8 group values (lane t reads producer t)
 			double v = 0.0;
 			int r = INT_MAX, bt = 0; // this lane's best record: value, logical row, producer
@@ -1106,12 +1110,11 @@ static int resident_workgroups()
 	Ctx &c = ctx();
 	if (c.la_state > 0 && c.stream == c.la_panel)
 		return c.la_panel_cus;
-	static int ncu = 0;
-	if (ncu == 0) {
+	static const int ncu = [&]() { // initialised once, thread safe (function-local static)
 		hipDeviceProp_t prop;
 		FH_HIP(hipGetDeviceProperties(&prop, c.device));
-		ncu = prop.multiProcessorCount;
-	}
+		return prop.multiProcessorCount;
+	}();
 	return ncu;
 }
 
@@ -1155,6 +1158,8 @@ template <typename T, int W> static void launch_leaf(int G, hipStream_t s, const
 		b.gran_diag = a.gran_diag;
 		b.epoch_base = a.epoch_base;
 		b.status = a.status;
+		static const int delay = getenv("FAER_HIP_LU_POLL_DELAY") ? atoi(getenv("FAER_HIP_LU_POLL_DELAY")) : 0;
+		b.poll_delay = G > 1 ? delay : 0;
 		hipLaunchKernelGGL((getrf_panel3_kernel<T, W, (sizeof(T) == 8 ? 64 : 128) / W>), dim3(G), dim3(LU2_NT), 0, s, b);
 		return;
 	}
@@ -1265,6 +1270,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 {
 	Ctx &c = ctx();
 	const idx_t m = A.nrows, n = A.ncols; // n <= m
+	const idx_t size_all = n;		      // every column is a pivot column (n <= m)
 	const idx_t nsteps = (n + LU_LA_NB - 1) / LU_LA_NB;
 	c.reset_events();
 	hipEvent_t e0 = c.next_event();
@@ -1314,8 +1320,24 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			}
 			if (j2 < n)
 				update(j0, w, j2, n - j2);
-			if (j0 > 0) // factor.rs:127-185: the panel's transpositions act on the columns to its left as well
-				laswp_dev<T>(A.sub(j0, 0, m - j0, j0), wk.piv + j0, (int) w, (int) j0);
+			// factor.rs:127-185: the panel's transpositions act on the columns to its left as well.  Nothing reads those
+			// columns again during the factorization, so the interchanges of `defer` consecutive panels are applied
+			// TOGETHER, as one composed row permutation per target block (one gather pass over the left part per group of
+			// panels instead of one scattered pass per panel: the per-panel passes were ~10 ms of the bulk stream's
+			// ~110 ms at N = 16384, profiles/r02_lu_kernel_stats.csv).  Bitwise the same result: row interchanges commute
+			// with everything that does not touch the rows' columns.
+			static const idx_t defer = getenv("FAER_HIP_LU_LEFT_DEFER") ? atol(getenv("FAER_HIP_LU_LEFT_DEFER")) : 8;
+			const idx_t grp0 = (k / defer) * defer; // first panel of this group
+			if (k + 1 == nsteps || (k + 1) % defer == 0) {
+				const idx_t jg0 = grp0 * LU_LA_NB;
+				const idx_t gend = j1 < size_all ? j1 : size_all; // pivots [jg0, gend) belong to the group
+				if (jg0 > 0)
+					laswp_dev<T>(A.sub(jg0, 0, m - jg0, jg0), wk.piv + jg0, (int) (gend - jg0), (int) jg0);
+				for (idx_t kb = grp0; kb < k; ++kb) { // inside the group: block kb gets the interchanges of the panels after it
+					const idx_t c0 = kb * LU_LA_NB, r0 = c0 + LU_LA_NB;
+					laswp_dev<T>(A.sub(r0, c0, m - r0, LU_LA_NB), wk.piv + r0, (int) (gend - r0), (int) r0);
+				}
+			}
 		}
 		if (w2 > 0) {
 			StreamScope sc(c.la_panel);
@@ -1371,8 +1393,17 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		FH_HIP(hipMemcpyAsync(piv.data(), wk.piv, (size_t) size * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
 		FH_HIP(hipMemcpyAsync(st, wk.status, sizeof(st), hipMemcpyDeviceToHost, ctx().stream));
 		ctx().sync();
-		FH_CHECK(st[2] == 0, "partial_piv_lu: device barrier timed out in the panel kernel");
 		ctx().quiesce();
+		if (st[2] != 0) {
+			// The cooperative panel kernel did not get all its workgroups resident within its bounded spin (CUs held by
+			// another process or stream: residency is not something a plain launch can be promised).  The
+			// matrix is partially factored; this is reported through the boundary's own status channel
+			// (PartialPivLuStatus::Unknown, faer-ffi/src/lib.rs:591-595) instead of aborting the caller's process.
+			fprintf(stderr, "faer_hip: partial_piv_lu: the cross-workgroup exchange of the panel kernel timed out (GPU shared with other work?)\n");
+			for (idx_t i = 0; i < m; ++i)
+				perm_inv[i] = i;
+			return -1;
+		}
 #ifdef FH_PANEL_TIMING
 		{
 			unsigned long long d[16];
