@@ -521,6 +521,7 @@ template <typename T> struct Panel3Args {
 	xwg_u64 *gran_diag; // [LU3_NSLOT][2 * LU_WMAX]: the row with logical index J
 	xwg_u64 epoch_base;
 	int *status;
+	int poll_delay; // 64-cycle sleeps between publishing and the first sweep (FAER_HIP_LU_POLL_DELAY)
 };
 
 // One column step.  The 8 group columns sit in a ROTATING WINDOW, positions 0 .. 7 of every register row: the column
