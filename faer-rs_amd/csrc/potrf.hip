@@ -259,25 +259,18 @@ __global__ __launch_bounds__(LDS_NT) void potrf_leaf_kernel(T *A, idx_t rs, idx_
 	if (Winv) {
 		// packed image of L_kk for the substitution leaf of the panel solves (unit diagonal for LDLT)
 		typedef TriPack<T> P;
-		for (int e = tid; e < P::TRI; e += LDS_NT) {
-			Winv[P::OFF_T00 + e] = (T) 0;
-			Winv[P::OFF_T11 + e] = (T) 0;
-		}
-		for (int e = tid; e < P::PAD; e += LDS_NT)
-			Winv[P::SIZE - P::PAD + e] = (T) 0;
+		for (int e = tid; e < TP_NT * P::DG_SZ; e += LDS_NT) // alignment holes of the diagonal tiles
+			Winv[P::OFF_DG + e] = (T) 0;
 		__syncthreads();
 		for (int e = tid; e < LDS_NB * LDS_NB; e += LDS_NT) {
 			const int i = e % LDS_NB, j = e / LDS_NB;
 			if (j > i)
 				continue;
 			const T v = S[j * LDS_LDP + i];
+			bool neg;
+			const int ps = P::pos(i, j, neg);
 			const T val = i == j ? ((LDLT || i >= n) ? (T) 1 : (T) 1 / v) : v; // the diagonal enters as its reciprocal
-			if (i < TP_H)
-				Winv[P::OFF_T00 + P::tri_pos(i, j)] = val;
-			else if (j >= TP_H)
-				Winv[P::OFF_T11 + P::tri_pos(i - TP_H, j - TP_H)] = val;
-			else
-				Winv[P::OFF_T10 + (i - TP_H) * TP_H + j] = val;
+			Winv[ps] = neg ? -val : val;
 		}
 		FH_LT(4);
 	}

@@ -15,6 +15,7 @@
 // every kernel here takes signed strides so the reversal is free.
 #include "common.h"
 #include "lds_blocks.h"
+#include "mfma.h"
 #include "trsm_pack.h"
 
 namespace fh {
@@ -186,12 +187,8 @@ __global__ __launch_bounds__(256) void trsm_pack_kernel(const T *__restrict__ Lp
 	T *img = W + (size_t) b * P::SIZE;
 	// alignment holes of the packed triangles must read as zeros (they are multiplied into padding lanes only, but
 	// NaN garbage would still propagate): clear the two triangles first
-	for (int e = threadIdx.x; e < P::TRI; e += blockDim.x) { // the strictly upper parts of the diagonal 8 x 8 blocks
-		img[P::OFF_T00 + e] = (T) 0;
-		img[P::OFF_T11 + e] = (T) 0;
-	}
-	for (int e = threadIdx.x; e < P::PAD; e += blockDim.x)
-		img[P::SIZE - P::PAD + e] = (T) 0;
+	for (int e = threadIdx.x; e < TP_NT * P::DG_SZ; e += blockDim.x) // alignment holes of the diagonal tiles
+		img[P::OFF_DG + e] = (T) 0;
 	__syncthreads();
 	const T *L0 = Lp + (idx_t) r0 * lrs + (idx_t) r0 * lcs;
 	constexpr int U = 8;
@@ -211,13 +208,10 @@ __global__ __launch_bounds__(256) void trsm_pack_kernel(const T *__restrict__ Lp
 			const int i = e % TP_NB, j = e / TP_NB;
 			if (j > i)
 				continue;
+			bool neg;
+			const int ps = P::pos(i, j, neg);
 			const T val = i == j ? ((unit || i >= nb) ? (T) 1 : (T) 1 / v[u]) : v[u]; // the diagonal enters as its reciprocal
-			if (i < TP_H)
-				img[P::OFF_T00 + P::tri_pos(i, j)] = val;
-			else if (j >= TP_H)
-				img[P::OFF_T11 + P::tri_pos(i - TP_H, j - TP_H)] = val;
-			else
-				img[P::OFF_T10 + (i - TP_H) * TP_H + j] = val;
+			img[ps] = neg ? -val : val;
 		}
 	}
 }
@@ -233,167 +227,6 @@ template <typename T> void trsm_pack_dev(MatV<const T> L, bool unit, T *W)
 }
 template void trsm_pack_dev<double>(MatV<const double>, bool, double *);
 template void trsm_pack_dev<float>(MatV<const float>, bool, float *);
-
-// ---- software-pipelined LDS streams -------------------------------------------------------------------------------
-// Every multiplier of the substitution is a wave-uniform LDS broadcast.  Left to the compiler, each pair of FMAs waits
-// for its own ds_read_b128 (~100 cycles with one wavefront per SIMD: 24 cycles per FMA measured, profiles/
-// r02_trsm_leaf.txt).  The packed triangle is therefore consumed as ONE linear stream of 16-byte reads with TL_D of
-// them in flight: read R is waited for with lgkmcnt(TL_D - 1), its FMAs issue, read R + TL_D goes out into the same
-// ring register.  The reads and waits are inline asm (the compiler neither reorders nor counts them); LDS operations
-// complete in order, so any LDS traffic the compiler adds around them only makes the waits stricter.
-constexpr int TL_D = 16;
-
-template <typename T> struct V16;
-template <> struct V16<double> {
-	typedef double type __attribute__((ext_vector_type(2)));
-};
-template <> struct V16<float> {
-	typedef float type __attribute__((ext_vector_type(4)));
-};
-template <int OFF, typename V> static __device__ __forceinline__ void lds_read128(V &dst, unsigned base)
-{
-	asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(OFF));
-}
-template <int CNT, typename V> static __device__ __forceinline__ void lds_wait(V &v)
-{
-	asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(CNT));
-}
-
-// x <- tri^-1 x.  One group of 8 columns per iteration of a run-time loop (trsm_pack.h): the 8 x 8 diagonal block
-// first (column oriented, the diagonal enters as a reciprocal), then the blocks of 8 rows below it -- the code of all
-// seven is there, the triangle leaves early -- and the registers rotate by 8 so that the next group is at 0 .. 7 again.
-// Linear read index inside a group: L = ((pb * 8 + jj) * 8) / EPR + r.
-template <typename T, int PB, int JJ, int RD> struct SubstRead {
-	typedef TriPack<T> P;
-	typedef typename V16<T>::type V;
-	static constexpr int EPR = P::ALIGN;
-	static constexpr int RPC = 8 / EPR; // reads per column of a block
-	static constexpr int L = (PB * 8 + JJ) * RPC + RD;
-	static __device__ __forceinline__ void run(T (&x)[TP_H], T (&xj)[8], V (&ring)[TL_D], unsigned base)
-	{
-		constexpr int S = L % TL_D;
-		lds_wait<TL_D - 1>(ring[S]);
-#pragma unroll
-		for (int u = 0; u < EPR; ++u) {
-			const int e = RD * EPR + u; // row inside the block
-			if (PB == 0) {
-				if (e == JJ) {
-					xj[JJ] = x[JJ] * ring[S][u];
-					x[JJ] = xj[JJ];
-				} else if (e > JJ) {
-					x[e] = fh_fma(-ring[S][u], xj[JJ], x[e]);
-				}
-			} else {
-				x[PB * 8 + e] = fh_fma(-ring[S][u], xj[JJ], x[PB * 8 + e]);
-			}
-		}
-		lds_read128<(L + TL_D) * 16>(ring[S], base); // may run past the group: harmless read-ahead (image pad)
-		if constexpr (RD + 1 < RPC)
-			SubstRead<T, PB, JJ, RD + 1>::run(x, xj, ring, base);
-		else if constexpr (JJ + 1 < 8)
-			SubstRead<T, PB, JJ + 1, 0>::run(x, xj, ring, base);
-	}
-};
-template <typename T, int PB, int NBLK> struct SubstBlocks {
-	typedef typename V16<T>::type V;
-	static __device__ __forceinline__ void run(T (&x)[TP_H], T (&xj)[8], V (&ring)[TL_D], unsigned base)
-	{
-		if constexpr (PB < NBLK) {
-			SubstRead<T, PB, 0, 0>::run(x, xj, ring, base);
-			SubstBlocks<T, PB + 1, NBLK>::run(x, xj, ring, base);
-		}
-	}
-};
-template <typename T, int R> struct PipeFill { // the first TL_D reads of a stream starting at `base`
-	typedef typename V16<T>::type V;
-	static __device__ __forceinline__ void run(V (&ring)[TL_D], unsigned base)
-	{
-		if constexpr (R < TL_D) {
-			lds_read128<R * 16>(ring[R], base);
-			PipeFill<T, R + 1>::run(ring, base);
-		}
-	}
-};
-template <typename T, int R> struct PipeDrain {
-	typedef typename V16<T>::type V;
-	static __device__ __forceinline__ void run(V (&ring)[TL_D])
-	{
-		if constexpr (R < TL_D) {
-			lds_wait<0>(ring[R]);
-			PipeDrain<T, R + 1>::run(ring);
-		}
-	}
-};
-// One group: the diagonal 8 x 8 block, then NBLK - 1 blocks of 8 rows below it with NO test whether the triangle
-// has that many left: register positions past the end of the triangle are dead (their rows went to `out` when
-// they were finished), the FMAs on them and the multipliers read for them (whatever follows the group in the
-// image) are wasted work that keeps the code regular.  Finished rows 8 g .. 8 g + 7 go to out[(8 g + k) * TL_XP].
-template <typename T, int NBLK>
-static __device__ __forceinline__ void tl_subst_group(T (&x)[TP_H], typename V16<T>::type (&ring)[TL_D], const T *tri, int g, T *out)
-{
-	typedef TriPack<T> P;
-	const unsigned base = (unsigned) (size_t) (tri + P::goff(g)); // LDS byte address of the group
-	T xj[8];
-	PipeFill<T, 0>::run(ring, base);
-	SubstBlocks<T, 0, NBLK>::run(x, xj, ring, base);
-	// drain the read-ahead while the ring registers are still live (a read landing in a register the compiler has
-	// reused for something else would corrupt it: the reads are asm, their unused outputs look dead to it)
-	PipeDrain<T, 0>::run(ring);
-#pragma unroll
-	for (int k = 0; k < 8; ++k)
-		out[(g * 8 + k) * TL_XP] = xj[k];
-#pragma unroll
-	for (int c = 0; c + 8 < TP_H; ++c)
-		x[c] = x[c + 8];
-}
-// x <- tri^-1 x; the solution goes to out[row * TL_XP] (the caller's column of the exchange tile), x is destroyed.
-// Groups 0 .. 3 run the 8-block code (6.5 needed on average), groups 4 .. 7 a 4-block copy (2.5 needed).
-template <typename T> static __device__ __forceinline__ void tl_subst(T (&x)[TP_H], const T *tri, T *out)
-{
-	typename V16<T>::type ring[TL_D];
-#pragma unroll 1
-	for (int g = 0; g < 4; ++g)
-		tl_subst_group<T, 8>(x, ring, tri, g, out);
-#pragma unroll 1
-	for (int g = 4; g < 8; ++g)
-		tl_subst_group<T, 4>(x, ring, tri, g, out);
-}
-
-// acc[u] = sum_j T10(i0 + u, j) x_j for TL_EB rows at a time: the reads walk the TL_EB rows column pair by column pair
-// (so that consecutive FMAs feed different accumulators), same pipelining
-constexpr int TL_EB = 8;
-template <typename T, int L> struct ElimRead {
-	typedef TriPack<T> P;
-	typedef typename V16<T>::type V;
-	static constexpr int EPR = P::ALIGN;
-	static constexpr int RPR = TP_H / EPR;	 // reads per row
-	static constexpr int NL = TL_EB * RPR;	 // reads per block of rows
-	static constexpr int off(int l) { return ((l % TL_EB) * TP_H + (l / TL_EB) * EPR) * (int) sizeof(T); } // row l % EB, column group l / EB
-	static __device__ __forceinline__ void run(const T (&x)[TP_H], T (&acc)[TL_EB][2], V (&ring)[TL_D], unsigned base)
-	{
-		if constexpr (L < NL) {
-			constexpr int S = L % TL_D;
-			constexpr int u = L % TL_EB, kk = L / TL_EB;
-			lds_wait<(L + TL_D <= NL ? TL_D - 1 : NL - 1 - L)>(ring[S]);
-#pragma unroll
-			for (int e = 0; e < EPR; ++e)
-				acc[u][e & 1] = fh_fma(ring[S][e], x[kk * EPR + e], acc[u][e & 1]);
-			if constexpr (L + TL_D < NL)
-				lds_read128<off(L + TL_D)>(ring[S], base);
-			ElimRead<T, L + 1>::run(x, acc, ring, base);
-		}
-	}
-};
-template <typename T, int L> struct ElimFill {
-	typedef typename V16<T>::type V;
-	static __device__ __forceinline__ void run(V (&ring)[TL_D], unsigned base)
-	{
-		if constexpr (L < TL_D) {
-			lds_read128<ElimRead<T, 0>::off(L)>(ring[L], base);
-			ElimFill<T, L + 1>::run(ring, base);
-		}
-	}
-};
 
 template <typename T>
 __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__ img, int n, T *Xp, idx_t xss, idx_t xcs, int nrhs,
@@ -506,45 +339,113 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	if (nc <= 0)
 		return; // the second wavefront of the last workgroup helped with the image only: the LDS pipe is the other one's
 
-	// ---- half 0: substitution on T00 (lane = right-hand side, register = row); the solution goes back to the tile
-	T y[TP_H];
+	// One 64-row half, X resident in the tile (Xs[row * TL_XP + rhs]); `bt0`: its first tile row in the 128-block.
+	//   per 16-row tile bi:  C (accumulator layout) <- tile;  C -= T[bi][bj] X_bj for the solved tiles bj < bi on the
+	//   matrix cores (A = the negated tile from the image, B = rows of X_bj read from the tile);  C -> tile;  then the
+	//   16 x 16 diagonal tile by substitution, lane = right-hand side (diagonal as a reciprocal, triangular_solve.rs:113)
+	typedef typename Mfma<T>::acc_t acc_t;
+	const int l15 = lane & 15, lhi = lane >> 4;
+	auto solve_half = [&](int bt0) {
+#pragma unroll 1
+		for (int bi = 0; bi < 4; ++bi) {
+			if (bi > 0) {
+				acc_t C[4];
 #pragma unroll
-	for (int i = 0; i < TP_H; ++i)
-		y[i] = Xs[i * TL_XP + lane];
-	tl_subst<T>(y, Ls + P::OFF_T00, Xs + lane);
+				for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+					for (int r = 0; r < 4; ++r)
+						C[jt][r] = Xs[(16 * bi + Mfma<T>::row(r, lhi)) * TL_XP + 16 * jt + l15];
+#pragma unroll 1
+				for (int bj = 0; bj < bi; ++bj) {
+					const T *At = Ls + P::od_tile(bt0 + bi, bt0 + bj);
+#pragma unroll
+					for (int kk = 0; kk < 4; ++kk) {
+						const T av = At[kk * 64 + lane];
+#pragma unroll
+						for (int jt = 0; jt < 4; ++jt)
+							C[jt] = Mfma<T>::run(av, Xs[(16 * bj + 4 * kk + lhi) * TL_XP + 16 * jt + l15], C[jt]);
+					}
+				}
+#pragma unroll
+				for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+					for (int r = 0; r < 4; ++r)
+						Xs[(16 * bi + Mfma<T>::row(r, lhi)) * TL_XP + 16 * jt + l15] = C[jt][r];
+				__builtin_amdgcn_wave_barrier();
+			}
+			T x16[TP_TS];
+#pragma unroll
+			for (int i = 0; i < TP_TS; ++i)
+				x16[i] = Xs[(16 * bi + i) * TL_XP + lane];
+			const T *dg = Ls + P::OFF_DG + (bt0 + bi) * P::DG_SZ;
+#pragma unroll
+			for (int j = 0; j < TP_TS; ++j) {
+				const T xj = x16[j] * dg[P::dg_off(j)];
+				x16[j] = xj;
+#pragma unroll
+				for (int i = j + 1; i < TP_TS; ++i)
+					x16[i] = fh_fma(-dg[P::dg_off(j) + (i - j)], xj, x16[i]);
+			}
+#pragma unroll
+			for (int i = 0; i < TP_TS; ++i)
+				Xs[(16 * bi + i) * TL_XP + lane] = x16[i];
+			__builtin_amdgcn_wave_barrier();
+		}
+	};
+
+	// ---- half 0
+	solve_half(0);
 	FH_TT(2);
 	store_half(0, ns0);
 	FH_TT(3);
 	if (!two)
 		return;
-	// ---- half 1: b_i - sum_j T10(i, j) y_j with the solved y_j in registers and the rows of T10 as LDS broadcasts,
-	// then the same substitution on T11
+	// ---- half 1: rows 64 .. 127 come straight from X in accumulator layout, C -= T[4 + bi'][bj] X_bj against the solved
+	// top half (still in the tile) on the matrix cores, all four tiles of C in registers; only then do they replace the
+	// top half in the tile and get solved like it
+	{
+		acc_t C[4][4];
 #pragma unroll
-	for (int i = 0; i < TP_H; ++i)
-		y[i] = Xs[i * TL_XP + lane];
-	__builtin_amdgcn_wave_barrier();
-	load_half(TP_H, ns1);
-	FH_TT(4);
+		for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+			for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const int row = TP_H + 16 * bi + Mfma<T>::row(r, lhi), rhs = c0 + 16 * jt + l15;
+					const bool in = row < n && rhs < nrhs;
+					const T t = Xp[in ? (idx_t) row * xss + (idx_t) rhs * xcs : (idx_t) 0];
+					C[bi][jt][r] = in ? t : (T) 0;
+				}
+		FH_TT(4);
 #pragma unroll 1
-	for (int i0 = 0; i0 < TP_H; i0 += TL_EB) {
-		typename V16<T>::type ring[TL_D];
-		T acc[TL_EB][2];
+		for (int bj = 0; bj < 4; ++bj) {
 #pragma unroll
-		for (int u = 0; u < TL_EB; ++u)
-			acc[u][0] = acc[u][1] = (T) 0;
-		const unsigned base = (unsigned) (size_t) (Ls + P::OFF_T10 + i0 * TP_H);
-		ElimFill<T, 0>::run(ring, base);
-		ElimRead<T, 0>::run(y, acc, ring, base);
+			for (int kk = 0; kk < 4; ++kk) {
+				T bv[4];
 #pragma unroll
-		for (int u = 0; u < TL_EB; ++u)
-			Xs[(i0 + u) * TL_XP + lane] -= acc[u][0] + acc[u][1];
+				for (int jt = 0; jt < 4; ++jt)
+					bv[jt] = Xs[(16 * bj + 4 * kk + lhi) * TL_XP + 16 * jt + l15];
+#pragma unroll
+				for (int bi = 0; bi < 4; ++bi) {
+					const T av = Ls[P::od_tile(4 + bi, bj) + kk * 64 + lane];
+#pragma unroll
+					for (int jt = 0; jt < 4; ++jt)
+						C[bi][jt] = Mfma<T>::run(av, bv[jt], C[bi][jt]);
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+			for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					Xs[(16 * bi + Mfma<T>::row(r, lhi)) * TL_XP + 16 * jt + l15] = C[bi][jt][r];
+		__builtin_amdgcn_wave_barrier();
 	}
-	__builtin_amdgcn_wave_barrier();
 	FH_TT(5);
-#pragma unroll
-	for (int i = 0; i < TP_H; ++i)
-		y[i] = Xs[i * TL_XP + lane];
-	tl_subst<T>(y, Ls + P::OFF_T11, Xs + lane);
+	solve_half(4);
 	FH_TT(6);
 	store_half(TP_H, ns1);
 	FH_TT(7);

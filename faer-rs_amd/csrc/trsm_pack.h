@@ -10,18 +10,20 @@
 //   T = [ T00  0  ]    T00, T11: 64 x 64 lower triangular, T10: 64 x 64
 //       [ T10 T11 ]
 //
-//   image = [ tri(T00) | T10 row major | tri(T11) | pad ]
-//   tri(): the triangle in the order the substitution consumes it -- groups of 8 columns; inside group g the
-//          8 x 8 blocks of rows 8 (g + pb), pb = 0 .. 7 - g; inside a block column by column, 8 entries each:
-//              pos(i, j) = goff(j / 8) + ((i / 8 - j / 8) * 8 + j % 8) * 8 + i % 8,   goff(g) = 64 (8 g - g (g - 1) / 2).
-//          The diagonal holds the RECIPROCAL 1 / t_jj (1 for a unit triangle / identity padding) -- the reference
-//          multiplies by the reciprocal too (triangular_solve.rs:113,121) -- and the strictly upper entries of the
-//          diagonal blocks are zero.  The leaf runs ONE copy of the code for a group (8 x 8 diagonal block, then the
-//          blocks below it, leaving early when the triangle ends) in a run-time loop and rotates its registers by 8
-//          per group: the fully unrolled triangle was 129 KB of straight-line code, twice the instruction cache, and
-//          ran at the speed of instruction fetch (profiles/r02_trsm_leaf.txt).
-//   pad:   the group code is regular (no test for the end of the triangle) and software pipelined: it reads past the
-//          last group.
+// The block is cut into 16 x 16 tiles (the shape of v_mfma_{f64,f32}_16x16x4):
+//   * the 28 tiles BELOW the diagonal are multiplied on the matrix cores: X_bi -= T[bi][bj] X_bj with the solved rows
+//     X_bj as the B operand.  They are stored NEGATED, tile after tile (index bi (bi - 1) / 2 + bj), each in the order
+//     the A operand is consumed: K step kk (4 columns), then lane l = (column & 3) * 16 + row -- one conflict-free
+//     ds_read_b64 per lane and K step;
+//   * the 8 DIAGONAL tiles are solved by substitution on the vector ALU (lane = right-hand side, the 16 rows in
+//     registers, multipliers as wave-uniform LDS broadcasts): column j of a diagonal tile is the block
+//     [ 1 / t_jj, t_{j+1,j}, ..., t_{15,j} ] starting at an offset aligned to 16 bytes.  The diagonal holds the
+//     RECIPROCAL (1 for a unit triangle / identity padding): the reference multiplies by the reciprocal too
+//     (triangular_solve.rs:113,121).
+// Why tiles: a wave-uniform multiplier costs a whole LDS return slot (64 lanes x 16 bytes for two useful doubles), and
+// ONE wavefront gets a ds_read_b128 through about every 27 cycles (profiles/r02_trsm_leaf_phases.txt) -- a purely
+// vector-ALU substitution of the 128 x 128 block is bound by that, not by its FMAs.  The matrix cores take per-lane
+// operands: 15/16 of the multipliers no longer need a broadcast.
 // Rows / columns beyond the block's real size are identity padded.
 #pragma once
 #include "common.h"
@@ -31,20 +33,36 @@ namespace fh {
 constexpr int TP_NB = 128; // block
 constexpr int TP_H = 64;   // half
 
+constexpr int TP_TS = 16;	      // tile
+constexpr int TP_NT = TP_NB / TP_TS;  // tiles per side (8)
+
 template <typename T> struct TriPack {
 	static constexpr int ALIGN = 16 / (int) sizeof(T); // elements per 16 bytes
-	static constexpr int GW = 8;			   // columns per group, rows per block
-	static constexpr int NG = TP_H / GW;
-	static __host__ __device__ constexpr int goff(int g) { return 64 * (8 * g - g * (g - 1) / 2); }
-	// position of entry (i, j), i >= j, of a 64 x 64 triangle
-	static __host__ __device__ constexpr int tri_pos(int i, int j) { return goff(j >> 3) + (((i >> 3) - (j >> 3)) * 8 + (j & 7)) * 8 + (i & 7); }
-	static constexpr int TRI = goff(NG); // elements of one packed 64 x 64 triangle (2304)
-	static constexpr int OFF_T00 = 0;
-	static constexpr int OFF_T10 = TRI; // row major: T10t[i * 64 + j] = T(64 + i, j)
-	static constexpr int OFF_T11 = TRI + TP_H * TP_H;
-	static constexpr int PAD = 256; // the regular group code reads up to 3 blocks + 16 vectors past the last group (trsm.hip)
-	static constexpr int SIZE = 2 * TRI + TP_H * TP_H + PAD;
+	static constexpr int OD_TILES = TP_NT * (TP_NT - 1) / 2;
+	static constexpr int OD_SZ = TP_TS * TP_TS;
+	static __host__ __device__ constexpr int dg_col_len(int j) { return (TP_TS - j + ALIGN - 1) / ALIGN * ALIGN; }
+	static __host__ __device__ constexpr int dg_off(int j)
+	{
+		int o = 0;
+		for (int c = 0; c < j; ++c)
+			o += dg_col_len(c);
+		return o;
+	}
+	static constexpr int DG_SZ = dg_off(TP_TS);
+	static constexpr int OFF_DG = OD_TILES * OD_SZ;
+	static constexpr int SIZE = OFF_DG + TP_NT * DG_SZ; // elements per block image (a multiple of ALIGN)
 	static constexpr size_t BYTES = (size_t) SIZE * sizeof(T);
+	static __host__ __device__ constexpr int od_tile(int bi, int bj) { return (bi * (bi - 1) / 2 + bj) * OD_SZ; }
+	// position of entry (i, j), i >= j, of the 128 x 128 block; `negate`: the entry is stored negated (off-diagonal
+	// tiles); the diagonal entries (i == j) are stored as reciprocals by the packers
+	static __host__ __device__ int pos(int i, int j, bool &negate)
+	{
+		const int bi = i >> 4, bj = j >> 4, ii = i & 15, jj = j & 15;
+		negate = bi > bj;
+		if (bi > bj)
+			return od_tile(bi, bj) + (jj >> 2) * 64 + (jj & 3) * 16 + ii;
+		return OFF_DG + bi * DG_SZ + dg_off(jj) + (ii - jj);
+	}
 };
 
 } // namespace fh
