@@ -1137,10 +1137,15 @@ template <typename T> static int leaf_width_for(idx_t m)
 	return w;
 }
 
-// FAER_HIP_LU_PANEL=2 selects the first-generation panel kernel (two hops per column, physical row exchange): A/B switch
+// FAER_HIP_LU_PANEL=3 selects the second-generation panel kernel (one hop per column on the dependent chain, logical
+// row indices instead of physical interchanges, rotating 8-column window).  Measured in one visit on the same MI355X
+// (profiles/r02_exp_lu_panel.txt): N = 16384 takes 141.0 ms with the first-generation kernel and 145.1 ms with this
+// one -- the second hop it removes was already overlapped, and neither the hop count nor the code size (100 KB ->
+// 33 KB) is what bounds the column step (its ~10 dependent synchronisation points are).  The default stays the
+// first-generation kernel; the second one is kept selectable because it is the basis for fusing steps.
 static bool lu_use_panel3()
 {
-	static const bool v = !(getenv("FAER_HIP_LU_PANEL") && atoi(getenv("FAER_HIP_LU_PANEL")) == 2);
+	static const bool v = getenv("FAER_HIP_LU_PANEL") && atoi(getenv("FAER_HIP_LU_PANEL")) == 3;
 	return v;
 }
 
@@ -1327,7 +1332,10 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// panels instead of one scattered pass per panel: the per-panel passes were ~10 ms of the bulk stream's
 			// ~110 ms at N = 16384, profiles/r02_lu_kernel_stats.csv).  Bitwise the same result: row interchanges commute
 			// with everything that does not touch the rows' columns.
-			static const idx_t defer = getenv("FAER_HIP_LU_LEFT_DEFER") ? atol(getenv("FAER_HIP_LU_LEFT_DEFER")) : 8;
+			// Default 1 (every panel at once): with 8 the composed passes moved ~8 ms off the bulk stream's per-panel
+			// scattered passes but cost as much again in compose_perm / gather / scatter launches and a serial tail
+			// (142.6 vs 145.1 ms at N = 16384, profiles/r02_exp_lu_panel.txt).
+			static const idx_t defer = getenv("FAER_HIP_LU_LEFT_DEFER") ? atol(getenv("FAER_HIP_LU_LEFT_DEFER")) : 1;
 			const idx_t grp0 = (k / defer) * defer; // first panel of this group
 			if (k + 1 == nsteps || (k + 1) % defer == 0) {
 				const idx_t jg0 = grp0 * LU_LA_NB;

@@ -228,9 +228,12 @@ template <typename T> void trsm_pack_dev(MatV<const T> L, bool unit, T *W)
 template void trsm_pack_dev<double>(MatV<const double>, bool, double *);
 template void trsm_pack_dev<float>(MatV<const float>, bool, float *);
 
-template <typename T>
+// DIRECT: there is no packed image in memory -- the workgroup packs the triangle (img = T(0, 0), strides trs / tcs,
+// `unit`) into LDS itself.  Used for single-block solves (n <= 128), where a separate packing launch (~20 us on the
+// dependent chain of an LU panel) would serve one leaf launch only.
+template <typename T, bool DIRECT>
 __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__ img, int n, T *Xp, idx_t xss, idx_t xcs, int nrhs,
-							   int lanes_along_rhs)
+							   int lanes_along_rhs, idx_t trs, idx_t tcs, int unit)
 {
 	typedef TriPack<T> P;
 	extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
@@ -310,29 +313,64 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	};
 
 	FH_TT_DECL;
-	// trip 1: first image batch + the top rows; then the rest of the image
-	{
-		v4i va[UI];
-#pragma unroll
-		for (int u = 0; u < UI; ++u)
-			va[u] = isrc[min((int) threadIdx.x + u * 128, NV - 1)];
+	if constexpr (DIRECT) {
+		// the lower triangle of T straight from the matrix (strided) into the packed image: the alignment holes of the
+		// diagonal tiles first, then 33-deep batches of independent loads (two round trips for the 8256 entries)
+		for (int e = threadIdx.x; e < TP_NT * P::DG_SZ; e += 128)
+			Ls[P::OFF_DG + e] = (T) 0;
+		__syncthreads();
 		load_half(0, ns0);
-#pragma unroll
-		for (int u = 0; u < UI; ++u)
-			if ((int) threadIdx.x + u * 128 < NV)
-				idst[threadIdx.x + u * 128] = va[u];
-	}
-	FH_TT(0);
+		constexpr int UD = 33;
 #pragma unroll 1
-	for (int e0 = UI * 128 + (int) threadIdx.x; e0 < NV; e0 += UI * 128) {
-		v4i va[UI];
+		for (int e0 = threadIdx.x; e0 < TP_NB * (TP_NB + 1) / 2; e0 += 128 * UD) {
+			T v[UD];
+			int ps[UD];
 #pragma unroll
-		for (int u = 0; u < UI; ++u)
-			va[u] = isrc[min(e0 + u * 128, NV - 1)];
+			for (int u = 0; u < UD; ++u) {
+				// e enumerates the lower triangle row by row: e = i (i + 1) / 2 + j
+				const int e = min(e0 + u * 128, TP_NB * (TP_NB + 1) / 2 - 1);
+				int i = (int) ((sqrtf(8.0f * (float) e + 1.0f) - 1.0f) * 0.5f);
+				i += (i + 1) * (i + 2) / 2 <= e;
+				i -= i * (i + 1) / 2 > e;
+				const int j = e - i * (i + 1) / 2;
+				const bool in = i < n;
+				const T t = img[in ? (idx_t) i * trs + (idx_t) j * tcs : (idx_t) 0];
+				bool neg;
+				ps[u] = e0 + u * 128 < TP_NB * (TP_NB + 1) / 2 ? P::pos(i, j, neg) : -1;
+				const T val = i == j ? ((unit || !in) ? (T) 1 : (T) 1 / t) : (in ? t : (T) 0);
+				v[u] = neg ? -val : val;
+			}
 #pragma unroll
-		for (int u = 0; u < UI; ++u)
-			if (e0 + u * 128 < NV)
-				idst[e0 + u * 128] = va[u];
+			for (int u = 0; u < UD; ++u)
+				if (ps[u] >= 0)
+					Ls[ps[u]] = v[u];
+		}
+		FH_TT(0);
+	} else {
+		// trip 1: first image batch + the top rows; then the rest of the image
+		{
+			v4i va[UI];
+#pragma unroll
+			for (int u = 0; u < UI; ++u)
+				va[u] = isrc[min((int) threadIdx.x + u * 128, NV - 1)];
+			load_half(0, ns0);
+#pragma unroll
+			for (int u = 0; u < UI; ++u)
+				if ((int) threadIdx.x + u * 128 < NV)
+					idst[threadIdx.x + u * 128] = va[u];
+		}
+		FH_TT(0);
+#pragma unroll 1
+		for (int e0 = UI * 128 + (int) threadIdx.x; e0 < NV; e0 += UI * 128) {
+			v4i va[UI];
+#pragma unroll
+			for (int u = 0; u < UI; ++u)
+				va[u] = isrc[min(e0 + u * 128, NV - 1)];
+#pragma unroll
+			for (int u = 0; u < UI; ++u)
+				if (e0 + u * 128 < NV)
+					idst[e0 + u * 128] = va[u];
+		}
 	}
 	__syncthreads(); // the image is in LDS
 	FH_TT(1);
@@ -460,8 +498,8 @@ template <typename T> static size_t trsm_leaf128_lds()
 	return TriPack<T>::BYTES + (size_t) 2 * TP_H * TL_XP * sizeof(T);
 }
 
-// X (n <= 128 rows) <- T^-1 X with the packed image of T
-template <typename T> static void trsm_leaf128_launch(const T *img, MatV<T> X)
+// X (n <= 128 rows) <- T^-1 X with the packed image of T, or (img == nullptr) with the triangle Ld itself
+template <typename T> static void trsm_leaf128_launch(const T *img, MatV<T> X, MatV<const T> Ld = MatV<const T>{nullptr, 0, 0, 0, 0}, bool unit = false)
 {
 	const idx_t n = X.nrows, k = X.ncols;
 	if (n == 0 || k == 0)
@@ -469,14 +507,21 @@ template <typename T> static void trsm_leaf128_launch(const T *img, MatV<T> X)
 	FH_CHECK(n <= TP_NB && k < (1L << 31), "trsm leaf: shape");
 	static bool attr_done = false; // raise the dynamic LDS limit once per process and type
 	if (!attr_done) {
-		FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_leaf128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_leaf128_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+					   (int) trsm_leaf128_lds<T>()));
+		FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_leaf128_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
 					   (int) trsm_leaf128_lds<T>()));
 		attr_done = true;
 	}
 	auto ab = [](idx_t v) { return v < 0 ? -v : v; };
 	const int along_rhs = ab(X.cs) <= ab(X.rs) ? 1 : 0;
-	hipLaunchKernelGGL(trsm_leaf128_kernel<T>, dim3((unsigned) ((k + 127) / 128)), dim3(128), trsm_leaf128_lds<T>(), ctx().stream, img, (int) n,
-			   X.p, X.rs, X.cs, (int) k, along_rhs);
+	const dim3 grid((unsigned) ((k + 127) / 128));
+	if (img)
+		hipLaunchKernelGGL((trsm_leaf128_kernel<T, false>), grid, dim3(128), trsm_leaf128_lds<T>(), ctx().stream, img, (int) n, X.p, X.rs, X.cs,
+				   (int) k, along_rhs, (idx_t) 0, (idx_t) 0, 0);
+	else
+		hipLaunchKernelGGL((trsm_leaf128_kernel<T, true>), grid, dim3(128), trsm_leaf128_lds<T>(), ctx().stream, Ld.p, (int) n, X.p, X.rs, X.cs,
+				   (int) k, along_rhs, Ld.rs, Ld.cs, unit ? 1 : 0);
 	FH_HIP(hipGetLastError());
 }
 
@@ -527,6 +572,10 @@ template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X)
 	const idx_t n = L.nrows, k = X.ncols;
 	if (n == 0 || k == 0)
 		return;
+	if (n <= TRSM_IB && (n > 64 || k >= 64)) { // one block: the leaf packs the triangle itself (no packing launch)
+		trsm_leaf128_launch<T>(nullptr, X, L, unit);
+		return;
+	}
 	if (n > 64 || k >= 64) { // packed diagonal blocks + substitution leaves + MFMA products off the diagonal
 		const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
 		Scratch wb((size_t) nblk * TriPack<T>::BYTES);
