@@ -314,36 +314,39 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 
 	FH_TT_DECL;
 	if constexpr (DIRECT) {
-		// the lower triangle of T straight from the matrix (strided) into the packed image: the alignment holes of the
-		// diagonal tiles first, then 33-deep batches of independent loads (two round trips for the 8256 entries)
+		// the lower triangle of T straight from the matrix (strided) into the packed image: thread = row, 32 columns per
+		// batch of independent loads (four round trips), cheap index arithmetic (the column is wave uniform)
+		__shared__ int dgo[TP_TS];
+		if (threadIdx.x < TP_TS)
+			dgo[threadIdx.x] = P::dg_off(threadIdx.x);
 		for (int e = threadIdx.x; e < TP_NT * P::DG_SZ; e += 128)
-			Ls[P::OFF_DG + e] = (T) 0;
+			Ls[P::OFF_DG + e] = (T) 0; // alignment holes of the diagonal tiles
 		__syncthreads();
 		load_half(0, ns0);
-		constexpr int UD = 33;
+		{
+			const int i = threadIdx.x, bi = i >> 4, ii = i & 15;
+			const bool in_i = i < n;
 #pragma unroll 1
-		for (int e0 = threadIdx.x; e0 < TP_NB * (TP_NB + 1) / 2; e0 += 128 * UD) {
-			T v[UD];
-			int ps[UD];
+			for (int j0 = 0; j0 < TP_NB; j0 += 32) {
+				T v[32];
 #pragma unroll
-			for (int u = 0; u < UD; ++u) {
-				// e enumerates the lower triangle row by row: e = i (i + 1) / 2 + j
-				const int e = min(e0 + u * 128, TP_NB * (TP_NB + 1) / 2 - 1);
-				int i = (int) ((sqrtf(8.0f * (float) e + 1.0f) - 1.0f) * 0.5f);
-				i += (i + 1) * (i + 2) / 2 <= e;
-				i -= i * (i + 1) / 2 > e;
-				const int j = e - i * (i + 1) / 2;
-				const bool in = i < n;
-				const T t = img[in ? (idx_t) i * trs + (idx_t) j * tcs : (idx_t) 0];
-				bool neg;
-				ps[u] = e0 + u * 128 < TP_NB * (TP_NB + 1) / 2 ? P::pos(i, j, neg) : -1;
-				const T val = i == j ? ((unit || !in) ? (T) 1 : (T) 1 / t) : (in ? t : (T) 0);
-				v[u] = neg ? -val : val;
+				for (int u = 0; u < 32; ++u) {
+					const int j = j0 + u;
+					const bool ld = in_i && j <= i;
+					const T t = img[ld ? (idx_t) i * trs + (idx_t) j * tcs : (idx_t) 0];
+					v[u] = ld ? t : (T) 0;
+				}
+#pragma unroll
+				for (int u = 0; u < 32; ++u) {
+					const int j = j0 + u, bj = j >> 4, jj = j & 15;
+					if (j > i)
+						continue;
+					if (bi > bj)
+						Ls[P::od_tile(bi, bj) + (jj >> 2) * 64 + (jj & 3) * 16 + ii] = -v[u];
+					else
+						Ls[P::OFF_DG + bi * P::DG_SZ + dgo[jj] + (ii - jj)] = i == j ? ((unit || !in_i) ? (T) 1 : (T) 1 / v[u]) : v[u];
+				}
 			}
-#pragma unroll
-			for (int u = 0; u < UD; ++u)
-				if (ps[u] >= 0)
-					Ls[ps[u]] = v[u];
 		}
 		FH_TT(0);
 	} else {
