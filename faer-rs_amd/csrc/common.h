@@ -83,6 +83,8 @@ struct Ctx {
 	bool lookahead_streams(); // creates the streams on first use; false if the runtime refuses
 	hipEvent_t next_event();  // timing-disabled events, recycled per factorization (reset_events)
 	void reset_events() { la_next_event = 0; }
+	int ncu = 0;
+	int stream_cus(); // compute units the current stream can occupy (the look-ahead streams are CU masked)
 
 	void ensure_device();
 	void *alloc(size_t bytes); // returns a device buffer valid until release()
@@ -312,7 +314,7 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv);
 // pieces of the LU driver used by the distributed driver (dist.hip): in-place factorization of an m x w panel
 // (w <= m) with the pivots left on the device (piv_dev[j] = row swapped with row j, relative to the panel), and
 // the application of such a transposition list to the rows of another block
-template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev);
+template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev, int *status_dev = nullptr);
 template <typename T> void laswp_rows_dev(MatV<T> B, const int *piv_dev, int nt);
 
 // Householder QR without pivoting (qr.hip); H is block_size x min(m,n) (device). returns rank

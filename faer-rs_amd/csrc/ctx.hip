@@ -34,6 +34,20 @@ void ctx_shutdown()
 	c.la_state = 0;
 }
 
+int Ctx::stream_cus()
+{
+	if (ncu == 0) {
+		hipDeviceProp_t prop;
+		FH_HIP(hipGetDeviceProperties(&prop, device));
+		ncu = prop.multiProcessorCount;
+	}
+	if (la_state > 0 && stream == la_panel)
+		return la_panel_cus;
+	if (la_state > 0 && stream == la_bulk)
+		return ncu - la_panel_cus;
+	return ncu;
+}
+
 void Ctx::ensure_device()
 {
 	if (device >= 0)

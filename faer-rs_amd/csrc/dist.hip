@@ -18,7 +18,8 @@ template <typename S> struct DeviceBackend {
 	FaerHipComm comm;
 
 	static MatV<T> mv(View v) { return MatV<T>{v.p, v.nrows, v.ncols, v.rs, v.cs}; }
-	void factor_panel(View P, int *piv_out) { getrf_panel_dev<T>(mv(P), piv_out); }
+	int *lu_status = nullptr; // 16 zeroed device ints: the panel kernels' status words, read once at the end
+	void factor_panel(View P, int *piv_out) { getrf_panel_dev<T>(mv(P), piv_out, lu_status); }
 	void laswp(View B, const int *piv, int nt) { laswp_rows_dev<T>(mv(B), piv, nt); }
 	void trsm_unit_lower(View L, View X) { trsm_lower_dev<T>(mv(L).c(), true, mv(X)); }
 	void gemm_sub(View C, View A, View B) { gemm_dev<T>(mv(C), DST_FULL, true, mv(A).c(), mv(B).c(), (T) -1); }
@@ -137,13 +138,23 @@ FaerPartialPivLuStatus dist_lu_api(FaerMatMut A_local, size_t n_global, size_t n
 	B be;
 	be.comm = comm;
 	be.streams_init();
+	Scratch stb(64);
+	be.lu_status = stb.as<int>();
+	FH_HIP(hipMemsetAsync(stb.p, 0, 64, ctx().stream)); // older than everything the run queues on any stream (step_begin)
 	typename B::View Av{static_cast<T *>(A_local.ptr), m, (long) A_local.ncols, 1, (long) A_local.col_stride};
 	const long size = m < n ? m : n;
 	std::vector<int> piv((size_t) size);
 	DistLu<B>::run(be, Av, m, n, (long) nb, comm.rank, comm.world_size, static_cast<T *>(panel_ws), piv.data());
-	if (be.two) { // the pivots came back with a synchronisation of the caller's stream, which had joined both internal ones
-		ctx().sync();
+	int lst[4] = {0, 0, 0, 0};
+	FH_HIP(hipMemcpyAsync(lst, be.lu_status, sizeof(lst), hipMemcpyDeviceToHost, ctx().stream));
+	ctx().sync(); // the run joined both internal streams into the caller's
+	if (be.two)
 		ctx().quiesce();
+	if (lst[2] != 0) { // a cooperative panel kernel of THIS rank gave up waiting for its peers (getrf.hip): factors are garbage
+		FaerPartialPivLuStatus bad;
+		memset(&bad, 0, sizeof(bad));
+		bad.tag = FaerPartialPivLuStatus_Unknown;
+		return bad;
 	}
 	// lu/partial_pivoting/factor.rs:274-277: perm = identity with the transpositions applied in order
 	unsigned long long *f = static_cast<unsigned long long *>(pf.ptr), *b = static_cast<unsigned long long *>(pb.ptr);

@@ -1443,13 +1443,17 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 	return n_trans;
 }
 
-template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev)
+// `status_dev` (optional, 16 zeroed device ints owned by the caller): the kernels' status words go there and NOTHING is
+// waited for -- the caller looks at word 2 (exchange timed out) once, after its own final synchronisation.  The
+// distributed LU calls it this way for every block column: no host synchronisation inside its loop (dist_lu.h).
+template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev, int *status_dev)
 {
 	const idx_t m = P.nrows, w = P.ncols;
 	FH_CHECK(w <= m, "getrf_panel: the panel must be tall");
 	if (w == 0)
 		return;
 	const size_t gran_bytes = (size_t) LU3_NSLOT * LU2_GMAX * LU2_GSLOT * sizeof(xwg_u64), diag_bytes = (size_t) LU3_NSLOT * 2 * LU_WMAX * sizeof(xwg_u64);
+	// released on return while the kernels may still be queued: the pool hands a buffer back to the SAME stream only
 	Scratch granb(gran_bytes + diag_bytes);
 	Scratch misc(256);
 	LuWork<T> wk;
@@ -1457,20 +1461,21 @@ template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev)
 	wk.gran = granb.as<xwg_u64>();
 	wk.gran_diag = wk.gran + (size_t) LU3_NSLOT * LU2_GMAX * LU2_GSLOT;
 	wk.epoch_base = 0;
-	wk.status = misc.as<int>() + 8;
+	wk.status = status_dev ? status_dev : misc.as<int>() + 8;
 	FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
 	FH_HIP(hipMemsetAsync(granb.p, 0, gran_bytes + diag_bytes, ctx().stream));
 	getrf_rec<T>(P, 0, 0, wk);
+	if (status_dev)
+		return;
 	int st[4] = {0, 0, 0, 0};
 	FH_HIP(hipMemcpyAsync(st, wk.status, sizeof(st), hipMemcpyDeviceToHost, ctx().stream));
-	ctx().sync(); // the scratch buffers above are released on return
+	ctx().sync();
 	FH_CHECK(st[2] == 0, "partial_piv_lu: device exchange timed out in the panel kernel");
 }
-
 template <typename T> void laswp_rows_dev(MatV<T> B, const int *piv_dev, int nt) { laswp_dev<T>(B, piv_dev, nt, 0); }
 
-template void getrf_panel_dev<double>(MatV<double>, int *);
-template void getrf_panel_dev<float>(MatV<float>, int *);
+template void getrf_panel_dev<double>(MatV<double>, int *, int *);
+template void getrf_panel_dev<float>(MatV<float>, int *, int *);
 template void laswp_rows_dev<double>(MatV<double>, const int *, int);
 template void laswp_rows_dev<float>(MatV<float>, const int *, int);
 template long getrf_dev<double>(MatV<double>, idx_t *, idx_t *);

@@ -126,17 +126,21 @@ __global__ __launch_bounds__(64) void trsm_leaf_kernel(const T *__restrict__ Lp,
 // SUBSTITUTION in trsm_leaf128_kernel -- no explicit inverses anywhere (round 1 multiplied by inverted diagonal
 // blocks, whose error grows with cond(T_kk); substitution is backward stable like the reference).
 //
-// trsm_leaf128_kernel: one workgroup = 2 wavefronts, each wavefront 64 right-hand sides, one per lane.
-//   * the packed image of the diagonal block (trsm_pack.h: two packed 64 x 64 triangles, the 64 x 64 block
-//     between them, reciprocal diagonal) is copied to LDS with 16-byte loads; every multiplier is then a
-//     wave-uniform LDS broadcast;
-//   * half 0: the lane's 64 values sit in registers, column-oriented substitution (2016 FMAs, the diagonal
-//     enters as a reciprocal like triangular_solve.rs:113);  half 1: b_i - sum_j t_ij x_j for the 64 rows below
-//     with the solved x_j still in registers (64 x 64 FMAs per lane, four partial sums), then the same
-//     substitution code on the second triangle.  fp64 vector FMA runs at the MFMA rate on gfx950, so nothing
-//     is lost against a matrix-core formulation and no layout change is needed between the phases;
+// trsm_leaf128_kernel: one workgroup = 4 wavefronts (one per SIMD), each wavefront RW = 16 or 32 right-hand sides.
+//   * the packed image of the diagonal block (trsm_pack.h: 28 negated 16 x 16 tiles below the diagonal in MFMA
+//     operand order, 8 diagonal tiles column by column with the reciprocal diagonal) is copied to LDS with 16-byte
+//     loads, or built there from the strided triangle itself (DIRECT: single-block solves, no packing launch);
+//   * the 64 x RW slice of X a wavefront works on lives in its LDS exchange tile; per 16-row tile: the rows are
+//     brought up to date with the solved tiles above on the matrix cores (accumulator layout), then the 16 x 16
+//     diagonal tile is solved by substitution on the vector ALU, lane = right-hand side, multipliers as LDS
+//     broadcasts, the diagonal as a reciprocal like triangular_solve.rs:113;
+//   * rows 64 .. 127 are loaded straight into accumulators, eliminated against the solved top half (256 MFMAs per
+//     16 right-hand sides) and then solved like the top half;
+//   * the MFMA phases of a wavefront scale with its share of the right-hand sides, the substitution phases wait for
+//     LDS broadcasts whatever the lane count: 16 right-hand sides per wavefront as long as that needs at most one
+//     workgroup per compute unit of the stream, 32 beyond (trsm_leaf128_launch);
 //   * global accesses run along whichever stride of X is the small one: directly when that is the right-hand
-//     side index (rows of a transposed Cholesky panel), through a padded LDS tile otherwise (columns of X).
+//     side index (rows of a transposed Cholesky panel), through the tile otherwise (columns of X).
 // ------------------------------------------------------------------------------------------------
 constexpr int TRSM_IB = TP_NB;
 
@@ -174,7 +178,8 @@ void trsm_dump_timing()
 void trsm_dump_timing() {}
 #endif
 
-constexpr int TL_XP = TP_H + 1; // pitch of the per-wave 64 x 64 exchange tile
+constexpr int TL_NW = 4;	   // wavefronts per workgroup of the substitution leaf
+constexpr int TL_NT = TL_NW * 64;
 
 // W block b <- packed image of the b-th 128 x 128 diagonal block of the lower triangular L
 template <typename T>
@@ -231,17 +236,21 @@ template void trsm_pack_dev<float>(MatV<const float>, bool, float *);
 // DIRECT: there is no packed image in memory -- the workgroup packs the triangle (img = T(0, 0), strides trs / tcs,
 // `unit`) into LDS itself.  Used for single-block solves (n <= 128), where a separate packing launch (~20 us on the
 // dependent chain of an LU panel) would serve one leaf launch only.
-template <typename T, bool DIRECT>
-__global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__ img, int n, T *Xp, idx_t xss, idx_t xcs, int nrhs,
-							   int lanes_along_rhs, idx_t trs, idx_t tcs, int unit)
+template <typename T, bool DIRECT, int RW>
+__global__ __launch_bounds__(TL_NT) void trsm_leaf128_kernel(const T *__restrict__ img, int n, T *Xp, idx_t xss, idx_t xcs, int nrhs,
+							     int lanes_along_rhs, idx_t trs, idx_t tcs, int unit)
 {
 	typedef TriPack<T> P;
+	static_assert(RW == 16 || RW == 32, "right-hand sides per wavefront");
+	constexpr int XP = RW + 1;   // pitch of the per-wave 64 x RW exchange tile
+	constexpr int JT = RW / 16;  // 16-column groups of right-hand sides per wavefront (MFMA N tiles)
+	constexpr int NT = TL_NT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
 	T *Ls = reinterpret_cast<T *>(tl_smem); // packed image
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	T *Xs = Ls + P::SIZE + wave * (TP_H * TL_XP); // this wave's 64 x 65 exchange tile: Xs[s * TL_XP + c]
-	const int c0 = (blockIdx.x * 2 + wave) * 64;
-	const int nc = min(64, nrhs - c0); // may be <= 0 for the second wave of the last workgroup
+	T *Xs = Ls + P::SIZE + wave * (TP_H * XP); // this wave's exchange tile: Xs[s * XP + c]
+	const int c0 = (blockIdx.x * TL_NW + wave) * RW;
+	const int nc = min(RW, nrhs - c0); // may be <= 0 for the trailing waves of the last workgroup
 	const bool act = lane < nc;
 
 	// Memory phases are organised by ROUND TRIPS, not by data: every batch below is a set of independent loads in
@@ -251,11 +260,11 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	typedef int v4i __attribute__((ext_vector_type(4)));
 	const v4i *isrc = reinterpret_cast<const v4i *>(img);
 	v4i *idst = reinterpret_cast<v4i *>(Ls);
-	constexpr int NV = (int) (P::BYTES / 16), UI = 12; // image: batches of 12 vectors per thread
+	constexpr int NV = (int) (P::BYTES / 16), UI = 6; // image: batches of 6 vectors per thread
 	const bool two = n > TP_H;
 	const int ns0 = min(TP_H, n), ns1 = two ? n - TP_H : 0;
 
-	// rows s0 .. s0+ns-1 of this wave's 64 right-hand sides -> tile (zero padded), lanes along the small stride
+	// rows s0 .. s0+ns-1 of this wave's RW right-hand sides -> tile (zero padded), lanes along the small stride
 	auto load_half = [&](int s0, int ns) {
 		if (lanes_along_rhs) {
 #pragma unroll 1
@@ -267,24 +276,23 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 					const T t = Xp[in ? (idx_t) (s0 + i0 + u) * xss + (idx_t) (c0 + lane) * xcs : (idx_t) 0];
 					v[u] = in ? t : (T) 0;
 				}
+				if (lane < RW) {
 #pragma unroll
-				for (int u = 0; u < 32; ++u)
-					Xs[(i0 + u) * TL_XP + lane] = v[u];
+					for (int u = 0; u < 32; ++u)
+						Xs[(i0 + u) * XP + lane] = v[u];
+				}
 			}
 		} else {
-#pragma unroll 1
-			for (int c8 = 0; c8 < TP_H; c8 += 32) {
-				T v[32];
+			T v[RW];
 #pragma unroll
-				for (int u = 0; u < 32; ++u) {
-					const bool in = c8 + u < nc && lane < ns;
-					const T t = Xp[in ? (idx_t) (s0 + lane) * xss + (idx_t) (c0 + c8 + u) * xcs : (idx_t) 0];
-					v[u] = in ? t : (T) 0;
-				}
-#pragma unroll
-				for (int u = 0; u < 32; ++u)
-					Xs[lane * TL_XP + c8 + u] = v[u];
+			for (int u = 0; u < RW; ++u) {
+				const bool in = u < nc && lane < ns;
+				const T t = Xp[in ? (idx_t) (s0 + lane) * xss + (idx_t) (c0 + u) * xcs : (idx_t) 0];
+				v[u] = in ? t : (T) 0;
 			}
+#pragma unroll
+			for (int u = 0; u < RW; ++u)
+				Xs[lane * XP + u] = v[u];
 		}
 		__builtin_amdgcn_wave_barrier();
 	};
@@ -295,14 +303,14 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 #pragma unroll 16
 			for (int i = 0; i < TP_H; ++i)
 				if (i < ns && act)
-					Xp[(idx_t) (s0 + i) * xss + (idx_t) (c0 + lane) * xcs] = Xs[i * TL_XP + lane];
+					Xp[(idx_t) (s0 + i) * xss + (idx_t) (c0 + lane) * xcs] = Xs[i * XP + lane];
 		} else {
 #pragma unroll 1
-			for (int c8 = 0; c8 < TP_H; c8 += 16) {
+			for (int c8 = 0; c8 < RW; c8 += 16) {
 				T w[16];
 #pragma unroll
 				for (int u = 0; u < 16; ++u)
-					w[u] = Xs[lane * TL_XP + c8 + u];
+					w[u] = Xs[lane * XP + c8 + u];
 #pragma unroll
 				for (int u = 0; u < 16; ++u)
 					if (c8 + u < nc && lane < ns)
@@ -315,26 +323,34 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	FH_TT_DECL;
 	if constexpr (DIRECT) {
 		// the lower triangle of T straight from the matrix (strided) into the packed image: thread = row, 32 columns per
-		// batch of independent loads (four round trips), cheap index arithmetic (the column is wave uniform)
+		// batch of independent loads, the two halves of the workgroup take alternate batches (two round trips each);
+		// cheap index arithmetic (the column is wave uniform)
 		__shared__ int dgo[TP_TS];
 		if (threadIdx.x < TP_TS)
 			dgo[threadIdx.x] = P::dg_off(threadIdx.x);
-		for (int e = threadIdx.x; e < TP_NT * P::DG_SZ; e += 128)
+		for (int e = threadIdx.x; e < TP_NT * P::DG_SZ; e += NT)
 			Ls[P::OFF_DG + e] = (T) 0; // alignment holes of the diagonal tiles
 		__syncthreads();
-		load_half(0, ns0);
+		if (nc > 0)
+			load_half(0, ns0);
 		{
-			const int i = threadIdx.x, bi = i >> 4, ii = i & 15;
+			const int i = threadIdx.x & (TP_NB - 1), bi = i >> 4, ii = i & 15;
 			const bool in_i = i < n;
 #pragma unroll 1
-			for (int j0 = 0; j0 < TP_NB; j0 += 32) {
+			for (int j0 = (threadIdx.x >> 7) * 32; j0 < TP_NB; j0 += 32 * (NT / TP_NB)) {
 				T v[32];
+				if (j0 < n) {
 #pragma unroll
-				for (int u = 0; u < 32; ++u) {
-					const int j = j0 + u;
-					const bool ld = in_i && j <= i;
-					const T t = img[ld ? (idx_t) i * trs + (idx_t) j * tcs : (idx_t) 0];
-					v[u] = ld ? t : (T) 0;
+					for (int u = 0; u < 32; ++u) {
+						const int j = j0 + u;
+						const bool ld = in_i && j <= i;
+						const T t = img[ld ? (idx_t) i * trs + (idx_t) j * tcs : (idx_t) 0];
+						v[u] = ld ? t : (T) 0;
+					}
+				} else {
+#pragma unroll
+					for (int u = 0; u < 32; ++u)
+						v[u] = (T) 0; // identity padding only: no round trip
 				}
 #pragma unroll
 				for (int u = 0; u < 32; ++u) {
@@ -355,47 +371,49 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 			v4i va[UI];
 #pragma unroll
 			for (int u = 0; u < UI; ++u)
-				va[u] = isrc[min((int) threadIdx.x + u * 128, NV - 1)];
-			load_half(0, ns0);
+				va[u] = isrc[min((int) threadIdx.x + u * NT, NV - 1)];
+			if (nc > 0)
+				load_half(0, ns0);
 #pragma unroll
 			for (int u = 0; u < UI; ++u)
-				if ((int) threadIdx.x + u * 128 < NV)
-					idst[threadIdx.x + u * 128] = va[u];
+				if ((int) threadIdx.x + u * NT < NV)
+					idst[threadIdx.x + u * NT] = va[u];
 		}
 		FH_TT(0);
 #pragma unroll 1
-		for (int e0 = UI * 128 + (int) threadIdx.x; e0 < NV; e0 += UI * 128) {
+		for (int e0 = UI * NT + (int) threadIdx.x; e0 < NV; e0 += UI * NT) {
 			v4i va[UI];
 #pragma unroll
 			for (int u = 0; u < UI; ++u)
-				va[u] = isrc[min(e0 + u * 128, NV - 1)];
+				va[u] = isrc[min(e0 + u * NT, NV - 1)];
 #pragma unroll
 			for (int u = 0; u < UI; ++u)
-				if (e0 + u * 128 < NV)
-					idst[e0 + u * 128] = va[u];
+				if (e0 + u * NT < NV)
+					idst[e0 + u * NT] = va[u];
 		}
 	}
 	__syncthreads(); // the image is in LDS
 	FH_TT(1);
 	if (nc <= 0)
-		return; // the second wavefront of the last workgroup helped with the image only: the LDS pipe is the other one's
+		return; // the trailing wavefronts of the last workgroup helped with the image only
 
-	// One 64-row half, X resident in the tile (Xs[row * TL_XP + rhs]); `bt0`: its first tile row in the 128-block.
+	// One 64-row half, X resident in the tile (Xs[row * XP + rhs]); `bt0`: its first tile row in the 128-block.
 	//   per 16-row tile bi:  C (accumulator layout) <- tile;  C -= T[bi][bj] X_bj for the solved tiles bj < bi on the
 	//   matrix cores (A = the negated tile from the image, B = rows of X_bj read from the tile);  C -> tile;  then the
 	//   16 x 16 diagonal tile by substitution, lane = right-hand side (diagonal as a reciprocal, triangular_solve.rs:113)
 	typedef typename Mfma<T>::acc_t acc_t;
 	const int l15 = lane & 15, lhi = lane >> 4;
+	const bool rl = lane < RW; // lanes that own a right-hand side in the substitution
 	auto solve_half = [&](int bt0) {
 #pragma unroll 1
 		for (int bi = 0; bi < 4; ++bi) {
 			if (bi > 0) {
-				acc_t C[4];
+				acc_t C[JT];
 #pragma unroll
-				for (int jt = 0; jt < 4; ++jt)
+				for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
 					for (int r = 0; r < 4; ++r)
-						C[jt][r] = Xs[(16 * bi + Mfma<T>::row(r, lhi)) * TL_XP + 16 * jt + l15];
+						C[jt][r] = Xs[(16 * bi + Mfma<T>::row(r, lhi)) * XP + 16 * jt + l15];
 #pragma unroll 1
 				for (int bj = 0; bj < bi; ++bj) {
 					const T *At = Ls + P::od_tile(bt0 + bi, bt0 + bj);
@@ -403,21 +421,21 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 					for (int kk = 0; kk < 4; ++kk) {
 						const T av = At[kk * 64 + lane];
 #pragma unroll
-						for (int jt = 0; jt < 4; ++jt)
-							C[jt] = Mfma<T>::run(av, Xs[(16 * bj + 4 * kk + lhi) * TL_XP + 16 * jt + l15], C[jt]);
+						for (int jt = 0; jt < JT; ++jt)
+							C[jt] = Mfma<T>::run(av, Xs[(16 * bj + 4 * kk + lhi) * XP + 16 * jt + l15], C[jt]);
 					}
 				}
 #pragma unroll
-				for (int jt = 0; jt < 4; ++jt)
+				for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
 					for (int r = 0; r < 4; ++r)
-						Xs[(16 * bi + Mfma<T>::row(r, lhi)) * TL_XP + 16 * jt + l15] = C[jt][r];
+						Xs[(16 * bi + Mfma<T>::row(r, lhi)) * XP + 16 * jt + l15] = C[jt][r];
 				__builtin_amdgcn_wave_barrier();
 			}
 			T x16[TP_TS];
 #pragma unroll
 			for (int i = 0; i < TP_TS; ++i)
-				x16[i] = Xs[(16 * bi + i) * TL_XP + lane];
+				x16[i] = Xs[(16 * bi + i) * XP + (rl ? lane : 0)];
 			const T *dg = Ls + P::OFF_DG + (bt0 + bi) * P::DG_SZ;
 #pragma unroll
 			for (int j = 0; j < TP_TS; ++j) {
@@ -427,9 +445,11 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 				for (int i = j + 1; i < TP_TS; ++i)
 					x16[i] = fh_fma(-dg[P::dg_off(j) + (i - j)], xj, x16[i]);
 			}
+			if (rl) {
 #pragma unroll
-			for (int i = 0; i < TP_TS; ++i)
-				Xs[(16 * bi + i) * TL_XP + lane] = x16[i];
+				for (int i = 0; i < TP_TS; ++i)
+					Xs[(16 * bi + i) * XP + lane] = x16[i];
+			}
 			__builtin_amdgcn_wave_barrier();
 		}
 	};
@@ -445,11 +465,11 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 	// top half (still in the tile) on the matrix cores, all four tiles of C in registers; only then do they replace the
 	// top half in the tile and get solved like it
 	{
-		acc_t C[4][4];
+		acc_t C[4][JT];
 #pragma unroll
 		for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-			for (int jt = 0; jt < 4; ++jt)
+			for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					const int row = TP_H + 16 * bi + Mfma<T>::row(r, lhi), rhs = c0 + 16 * jt + l15;
@@ -462,15 +482,15 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 		for (int bj = 0; bj < 4; ++bj) {
 #pragma unroll
 			for (int kk = 0; kk < 4; ++kk) {
-				T bv[4];
+				T bv[JT];
 #pragma unroll
-				for (int jt = 0; jt < 4; ++jt)
-					bv[jt] = Xs[(16 * bj + 4 * kk + lhi) * TL_XP + 16 * jt + l15];
+				for (int jt = 0; jt < JT; ++jt)
+					bv[jt] = Xs[(16 * bj + 4 * kk + lhi) * XP + 16 * jt + l15];
 #pragma unroll
 				for (int bi = 0; bi < 4; ++bi) {
 					const T av = Ls[P::od_tile(4 + bi, bj) + kk * 64 + lane];
 #pragma unroll
-					for (int jt = 0; jt < 4; ++jt)
+					for (int jt = 0; jt < JT; ++jt)
 						C[bi][jt] = Mfma<T>::run(av, bv[jt], C[bi][jt]);
 				}
 			}
@@ -479,10 +499,10 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 #pragma unroll
 		for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-			for (int jt = 0; jt < 4; ++jt)
+			for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
 				for (int r = 0; r < 4; ++r)
-					Xs[(16 * bi + Mfma<T>::row(r, lhi)) * TL_XP + 16 * jt + l15] = C[bi][jt][r];
+					Xs[(16 * bi + Mfma<T>::row(r, lhi)) * XP + 16 * jt + l15] = C[bi][jt][r];
 		__builtin_amdgcn_wave_barrier();
 	}
 	FH_TT(5);
@@ -496,36 +516,56 @@ __global__ __launch_bounds__(128) void trsm_leaf128_kernel(const T *__restrict__
 #endif
 }
 
-template <typename T> static size_t trsm_leaf128_lds()
+template <typename T, int RW> static size_t trsm_leaf128_lds()
 {
-	return TriPack<T>::BYTES + (size_t) 2 * TP_H * TL_XP * sizeof(T);
+	return TriPack<T>::BYTES + (size_t) TL_NW * TP_H * (RW + 1) * sizeof(T);
 }
 
-// X (n <= 128 rows) <- T^-1 X with the packed image of T, or (img == nullptr) with the triangle Ld itself
+template <typename T, bool DIRECT, int RW>
+static void trsm_leaf128_go(const T *src, idx_t n, MatV<T> X, int along_rhs, idx_t trs, idx_t tcs, int unit)
+{
+	static bool attr_done = false; // raise the dynamic LDS limit once per process and instance
+	const size_t lds = trsm_leaf128_lds<T, RW>();
+	if (!attr_done) {
+		FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_leaf128_kernel<T, DIRECT, RW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+					   (int) lds));
+		attr_done = true;
+	}
+	const idx_t k = X.ncols;
+	const dim3 grid((unsigned) ((k + TL_NW * RW - 1) / (TL_NW * RW)));
+	hipLaunchKernelGGL((trsm_leaf128_kernel<T, DIRECT, RW>), grid, dim3(TL_NT), lds, ctx().stream, src, (int) n, X.p, X.rs, X.cs, (int) k, along_rhs, trs,
+			   tcs, unit);
+	FH_HIP(hipGetLastError());
+}
+
+// X (n <= 128 rows) <- T^-1 X with the packed image of T, or (img == nullptr) with the triangle Ld itself.
+// Four wavefronts per workgroup (one per SIMD), 16 right-hand sides per wavefront while that still gives at most one
+// workgroup per compute unit of the stream, else 32: the matrix-core phases of a wavefront shrink with its share of the
+// right-hand sides, the substitution phases do not care (they wait for LDS broadcasts).
 template <typename T> static void trsm_leaf128_launch(const T *img, MatV<T> X, MatV<const T> Ld = MatV<const T>{nullptr, 0, 0, 0, 0}, bool unit = false)
 {
 	const idx_t n = X.nrows, k = X.ncols;
 	if (n == 0 || k == 0)
 		return;
 	FH_CHECK(n <= TP_NB && k < (1L << 31), "trsm leaf: shape");
-	static bool attr_done = false; // raise the dynamic LDS limit once per process and type
-	if (!attr_done) {
-		FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_leaf128_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-					   (int) trsm_leaf128_lds<T>()));
-		FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_leaf128_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-					   (int) trsm_leaf128_lds<T>()));
-		attr_done = true;
-	}
 	auto ab = [](idx_t v) { return v < 0 ? -v : v; };
 	const int along_rhs = ab(X.cs) <= ab(X.rs) ? 1 : 0;
-	const dim3 grid((unsigned) ((k + 127) / 128));
-	if (img)
-		hipLaunchKernelGGL((trsm_leaf128_kernel<T, false>), grid, dim3(128), trsm_leaf128_lds<T>(), ctx().stream, img, (int) n, X.p, X.rs, X.cs,
-				   (int) k, along_rhs, (idx_t) 0, (idx_t) 0, 0);
-	else
-		hipLaunchKernelGGL((trsm_leaf128_kernel<T, true>), grid, dim3(128), trsm_leaf128_lds<T>(), ctx().stream, Ld.p, (int) n, X.p, X.rs, X.cs,
-				   (int) k, along_rhs, Ld.rs, Ld.cs, unit ? 1 : 0);
-	FH_HIP(hipGetLastError());
+	static const int force = []() {
+		const char *e = getenv("FAER_HIP_TRSM_RW"); // 16 / 32: A/B switch
+		return e ? atoi(e) : 0;
+	}();
+	const bool narrow = force ? force == 16 : (k + TL_NW * 16 - 1) / (TL_NW * 16) <= (idx_t) ctx().stream_cus();
+	if (img) {
+		if (narrow)
+			trsm_leaf128_go<T, false, 16>(img, n, X, along_rhs, 0, 0, 0);
+		else
+			trsm_leaf128_go<T, false, 32>(img, n, X, along_rhs, 0, 0, 0);
+	} else {
+		if (narrow)
+			trsm_leaf128_go<T, true, 16>(Ld.p, n, X, along_rhs, Ld.rs, Ld.cs, unit ? 1 : 0);
+		else
+			trsm_leaf128_go<T, true, 32>(Ld.p, n, X, along_rhs, Ld.rs, Ld.cs, unit ? 1 : 0);
+	}
 }
 
 template <typename T> static void trsm_rec(MatV<const T> L, MatV<T> X, const T *W, idx_t b0)
