@@ -415,6 +415,17 @@ def colpiv_qr_factor_in_place(a, q_coeff, index_dtype=np.uint64, par=PAR_SEQ):
     return cf, cb, st.transposition_count
 
 
+def tridiag_in_place(a, householder):
+    """faer::linalg::evd::tridiag::tridiag_in_place (evd/tridiag.rs:274): `a` (n x n, self-adjoint, only the lower triangle
+    is used) -> the tridiagonal T on its diagonal / subdiagonal (a = Q T Q^H), the reflectors of Q below the subdiagonal,
+    their block factors in `householder` (block_size x (n - 1))"""
+    suf, _, _ = _dtype_suffix(a)
+    fn = getattr(lib(), f"faer_hip_tridiag_in_place_{suf}")
+    fn.restype = None
+    fn(_mat(a, MatMut), _mat(householder, MatMut))
+    return a, householder
+
+
 def colpiv_qr_solve_in_place(qr, q_coeff, col_fwd, col_bwd, rhs, mode="lstsq", par=PAR_SEQ):
     """qr/col_pivoting/solve.rs; mode: 'lstsq' (m >= n, solution in the first n rows), 'solve' (square), 'transpose'"""
     suf, _, _ = _dtype_suffix(qr)

@@ -497,6 +497,21 @@ void full_lu_solve_api(FaerMatRef L, FaerMatRef U, FaerSliceRef rpf, FaerSliceRe
 	}
 }
 
+// evd/tridiag.rs:274-299
+template <typename T> void tridiag_api(FaerMatMut A, FaerMatMut Hh)
+{
+	FH_CHECK(A.nrows == A.ncols, "tridiag: the matrix must be square");
+	FH_CHECK(Hh.ncols == (A.nrows > 0 ? A.nrows - 1 : 0), "tridiag: householder must have n - 1 columns"); // tridiag.rs:287
+	if (A.nrows == 0)
+		return; // :288-290
+	FH_CHECK(Hh.nrows > 0 || A.nrows == 1, "tridiag: householder must have at least one row");
+	if (A.nrows == 1)
+		return;
+	Staged<T> a(view<T>(A), true, true);
+	Staged<T> h(view<T>(Hh), true, true); // only the block upper triangles are written
+	tridiag_dev<T>(a.dev, h.dev);
+}
+
 // qr/col_pivoting/factor.rs:356-395
 template <typename T, typename I> FaerColPivQrStatus colpiv_qr_api(FaerMatMut A, FaerMatMut Q, FaerSliceMut pf, FaerSliceMut pb)
 {
@@ -1351,6 +1366,9 @@ size_t faer_hip_debug_llt_plan(size_t n, size_t tail_rows, size_t nb2, size_t *s
 	return J.size();
 }
 void faer_hip_debug_dump_timing(void) { trsm_dump_timing(); }
+
+void faer_hip_tridiag_in_place_f64(FaerMatMut A, FaerMatMut householder) { tridiag_api<double>(A, householder); }
+void faer_hip_tridiag_in_place_f32(FaerMatMut A, FaerMatMut householder) { tridiag_api<float>(A, householder); }
 
 int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, int resident_workgroups)
 {

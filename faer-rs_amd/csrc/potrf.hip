@@ -372,7 +372,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 	// one tall left-looking panel + ONE trailing update per step.
 	// Look-ahead pays from ~10k rows upwards (measured, N = 8192: 13.3 ms sequential against 13.8 ms); below that and
 	// for the last `tail_rows` rows of a large matrix the steps run back to back on the caller's stream.
-	const idx_t tail_rows = getenv("FAER_HIP_LLT_TAIL") ? atol(getenv("FAER_HIP_LLT_TAIL")) : (n < 10 * LA_NB ? n : 4 * LA_NB);
+	const idx_t tail_rows = getenv("FAER_HIP_LLT_TAIL") ? atol(getenv("FAER_HIP_LLT_TAIL")) : (n < 10 * LA_NB ? n : 3 * LA_NB);
 	// Step widths of the look-ahead part: the FIRST step is LA_NB wide (its diagonal block is factored with the rest
 	// of the chip idle), the following ones LA_NB2 (wider steps: K = LA_NB2 trailing updates run closer to the dense
 	// rate and there are fewer launch boundaries per factorization) while at least 2 * LA_NB2 rows remain.

@@ -1246,6 +1246,309 @@ template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, 
 template long colpiv_qr_dev<double>(MatV<double>, MatV<double>, idx_t *, idx_t *);
 template long colpiv_qr_dev<float>(MatV<float>, MatV<float>, idx_t *, idx_t *);
 
+// ------------------------------------------------------------------------------------------------
+// Tridiagonalization of a self-adjoint matrix -- faer/src/linalg/evd/tridiag.rs:274-535.
+// A level-2, HBM-bound algorithm like the reference's: per column ONE pass over the remaining lower triangle that
+// applies the symmetric rank-2 update of the previous reflector and multiplies the updated matrix by the new one
+// (tridiag_fused_op, :36-272), between two short vector phases.  Three launches per column, no host synchronisation (running the
+// vector phase in the last workgroup of the row pass instead -- release fence, ticket, acquire fence -- measured 2.4x
+// SLOWER: an agent-scope fence per workgroup writes the L2 back):
+//   td_step_kernel(k)   one workgroup: finishes y of step k-1 (:484-511), brings column k up to date (:300-318), makes
+//                       its reflector (:330-336, householder.rs:59-107), updates column k+1 (:348-359), w <- y
+//   td_colpass_kernel(k) / td_rowpass_kernel(k)  one workgroup per 16 columns / rows of A22 = A[k+2.., k+2..]: the column
+//                       pass sums striu(A22^H) x over the tiles below the diagonal one with the update applied on the
+//                       fly (read only), the row pass then writes A22 -= u w^H + w u^H back tile row by tile row and
+//                       sums tril(A22) x -- every y_i is COMPLETE inside one workgroup of each pass: no partial sums, no
+//                       atomics, a fixed summation order.  Price: the strictly lower tiles are read twice.  (One kernel
+//                       doing both passes would race: a row panel's write-back against another panel's column reads.)
+// ------------------------------------------------------------------------------------------------
+struct TdState {
+	double tau_inv;
+};
+template <typename T> struct TdArgs {
+	T *A;
+	idx_t rs, cs;
+	int n, k;
+	T *y, *w, *ysum, *taus;
+	double *csum;
+	TdState *st;
+};
+constexpr int TD_NT = 1024; // td_step_kernel
+constexpr int TD_PW = 16;   // panel width of td_fused_kernel
+
+// sums CNT doubles over the 1024 threads; every thread may read s_red afterwards
+template <int CNT> static __device__ __forceinline__ void td_block_sum(double (&v)[CNT], double *s_part, double *s_red)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+	for (int c = 0; c < CNT; ++c) {
+		const double sv = wave_sum(v[c]);
+		if (lane == 0)
+			s_part[wave * CNT + c] = sv;
+	}
+	__syncthreads();
+	if (tid < CNT) {
+		double t = 0.0;
+		for (int wv = 0; wv < TD_NT / 64; ++wv)
+			t += s_part[wv * CNT + tid];
+		s_red[tid] = t;
+	}
+	__syncthreads();
+}
+
+template <typename T> static __device__ __forceinline__ void td_step_body(const TdArgs<T> &a, const int k)
+{
+	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
+	const int tid = threadIdx.x, n = a.n;
+	auto at = [&](int i, int j) -> T & { return a.A[(idx_t) i * a.rs + (idx_t) j * a.cs]; };
+	T nacc[3] = {0, 0, 0}; // scaled sums of the tail of column k (reductions/norm_l2.rs:6-45)
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	if (k > 0) {
+		// ---- y of step k - 1 (:484-511): x = the reflector in column k-1 (rows k+1..), ysum = sym(A22) x from the fused pass
+		const T tau_inv = (T) a.st->tau_inv;
+		double d[2] = {0.0, 0.0};
+		for (int i = k + 1 + tid; i < n; i += TD_NT) {
+			const T aik = at(i, k), xi = at(i, k - 1);
+			T yv = tau_inv * a.ysum[i];
+			yv += aik * tau_inv;
+			a.y[i] = yv;
+			d[0] += (double) aik * (double) xi;
+			d[1] += (double) xi * (double) yv;
+		}
+		td_block_sum<2>(d, s_part, s_red);
+		T y1 = (at(k, k) + (T) s_red[0]) * tau_inv;
+		const T b = ((y1 + (T) s_red[1]) * (T) 0.5) * tau_inv;
+		y1 -= b;
+		__syncthreads(); // at(k, k) was read by everyone
+		// ---- y -= b x, then column k receives the rest of the rank-2 update (:300-318), norm of its tail on the way
+		for (int i = k + 1 + tid; i < n; i += TD_NT) {
+			const T xi = at(i, k - 1);
+			const T yi = a.y[i] - b * xi;
+			a.y[i] = yi;
+			const T v = at(i, k) - (y1 * xi + yi);
+			at(i, k) = v;
+			if (i >= k + 2) {
+				nacc[0] += (v * sml) * (v * sml);
+				nacc[1] += v * v;
+				nacc[2] += (v * big) * (v * big);
+			}
+		}
+		if (tid == 0) {
+			a.y[k] = y1;
+			at(k, k) -= y1 + y1;
+		}
+	} else {
+		for (int i = 2 + tid; i < n; i += TD_NT) {
+			const T v = at(i, 0);
+			nacc[0] += (v * sml) * (v * sml);
+			nacc[1] += v * v;
+			nacc[2] += (v * big) * (v * big);
+		}
+	}
+	if (k + 1 >= n)
+		return;
+	// ---- reflector of column k below the diagonal (:330-336)
+	double accd[3] = {(double) nacc[0], (double) nacc[1], (double) nacc[2]};
+	td_block_sum<3>(accd, s_part, s_red); // (its barriers also publish the column written above)
+	const T tail_norm = norm_from3<T>(s_red);
+	T head = at(k + 1, k);
+	T head_norm = fabs(head);
+	if (head_norm < Lim<T>::minpos) {
+		head = (T) 0;
+		head_norm = (T) 0;
+	}
+	T tau, hinv = (T) 0;
+	bool scale_tail = false;
+	if (tail_norm < Lim<T>::minpos) {
+		tau = std::numeric_limits<T>::infinity();
+	} else {
+		const T norm = (T) hypot((double) head_norm, (double) tail_norm);
+		const T sign = head_norm != (T) 0 ? head * ((T) 1 / head_norm) : (T) 1;
+		const T signed_norm = sign * norm;
+		hinv = (T) 1 / (head + signed_norm);
+		head = -signed_norm;
+		const T tn = tail_norm * fabs(hinv);
+		tau = (T) 0.5 * ((T) 1 + tn * tn);
+		scale_tail = true;
+	}
+	__syncthreads(); // everyone has read the old head
+	const T u1 = k > 0 ? at(k + 1, k - 1) : (T) 0, y1n = k > 0 ? a.y[k + 1] : (T) 0;
+	for (int i = k + 2 + tid; i < n; i += TD_NT) {
+		if (scale_tail)
+			at(i, k) *= hinv;
+		if (k > 0) { // :348-359
+			const T yi = a.y[i];
+			at(i, k + 1) -= at(i, k - 1) * y1n + yi * u1;
+			a.w[i] = yi;
+		}
+	}
+	if (tid == 0) {
+		at(k + 1, k) = head;
+		a.taus[k] = tau;
+		a.st->tau_inv = (double) ((T) 1 / tau);
+		if (k > 0)
+			at(k + 1, k + 1) -= u1 * y1n + y1n * u1;
+	}
+}
+
+template <typename T> __global__ __launch_bounds__(TD_NT) void td_step_kernel(const TdArgs<T> a) { td_step_body<T>(a, a.k); }
+
+// columns i0 .. i0+15 of A22, rows below the diagonal tile: column sums striu(A22^H) x of the matrix AFTER the rank-2
+// update, which is applied on the fly and not written (nobody writes A22 while this kernel runs) -> csum.
+// 16 wavefronts, one column each, lanes along the rows (512-byte loads), four independent loads in flight per lane.
+template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel(const TdArgs<T> a)
+{
+	const int tid = threadIdx.x, k = a.k;
+	const int base = k + 2, r = a.n - base; // A22 = A[base.., base..], r x r
+	const int i0 = blockIdx.x * TD_PW;
+	const bool upd = k > 0;
+	const T *u = a.A + (idx_t) base * a.rs + (idx_t) (k > 0 ? k - 1 : 0) * a.cs; // u[i * rs]
+	const T *x = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;
+	const T *w = a.w + base;
+	const T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
+	const int lane = tid & 63, j = i0 + (tid >> 6);
+	if (j >= r)
+		return;
+	const T wj = upd ? w[j] : (T) 0, uj = upd ? u[(idx_t) j * a.rs] : (T) 0;
+	const T *col = A22 + (idx_t) j * a.cs;
+	double acc = 0.0;
+	for (int p0 = i0 + TD_PW + lane; p0 < r; p0 += 256) {
+		T v[4], xp[4], up[4], wp[4];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const int pr = p0 + 64 * q;
+			const bool in = pr < r;
+			const idx_t o = in ? (idx_t) pr * a.rs : (idx_t) 0;
+			v[q] = col[o];
+			xp[q] = in ? x[o] : (T) 0;
+			up[q] = (in && upd) ? u[o] : (T) 0;
+			wp[q] = (in && upd) ? w[in ? pr : 0] : (T) 0;
+		}
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			T t = v[q];
+			if (upd) {
+				t = fh_fma(-up[q], wj, t);
+				t = fh_fma(-wp[q], uj, t);
+			}
+			acc += (double) t * (double) xp[q]; // xp == 0 beyond the last row
+		}
+	}
+	const double sv = wave_sum(acc);
+	if (lane == 0)
+		a.csum[base + j] = sv;
+}
+
+// rows i0 .. i0+15 of A22, columns 0 .. i: the rank-2 update written back (every entry belongs to exactly one
+// workgroup), row sums tril(A22) x, plus the strictly lower part of the diagonal tile and csum -> ysum.
+// Thread (ri, cj): row ri of the panel, columns cj, cj + 64, ...; four independent loads in flight per thread.
+template <typename T> __global__ __launch_bounds__(TD_NT) void td_rowpass_kernel(const TdArgs<T> a)
+{
+	constexpr int NC = TD_NT / TD_PW; // 64 column threads per row
+	__shared__ T tile[TD_PW][TD_PW + 1];
+	__shared__ double red[TD_PW][NC + 1];
+	const int tid = threadIdx.x, k = a.k;
+	const int base = k + 2, r = a.n - base;
+	const int i0 = blockIdx.x * TD_PW;
+	const bool upd = k > 0;
+	const T *u = a.A + (idx_t) base * a.rs + (idx_t) (k > 0 ? k - 1 : 0) * a.cs;
+	const T *x = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;
+	const T *w = a.w + base;
+	T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
+	{
+		const int ri = tid & (TD_PW - 1), cj = tid >> 4;
+		const int gi = i0 + ri;
+		const bool vi = gi < r;
+		const T ui = (vi && upd) ? u[(idx_t) gi * a.rs] : (T) 0, wi = (vi && upd) ? w[gi] : (T) 0;
+		const int jend = min(i0 + TD_PW, r);
+		T *row = A22 + (idx_t) (vi ? gi : 0) * a.rs;
+		double acc = 0.0;
+		for (int j0 = cj; j0 < jend; j0 += 4 * NC) {
+			T v[4], xj[4], wj[4], uj[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int j = j0 + NC * q;
+				const bool in = vi && j <= gi; // (j <= gi < jend)
+				const int jc = in ? j : 0;
+				v[q] = row[(idx_t) jc * a.cs];
+				xj[q] = in ? x[(idx_t) jc * a.rs] : (T) 0;
+				wj[q] = upd ? w[jc] : (T) 0;
+				uj[q] = upd ? u[(idx_t) jc * a.rs] : (T) 0;
+			}
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int j = j0 + NC * q;
+				if (vi && j <= gi) {
+					T t = v[q];
+					if (upd) {
+						t = fh_fma(-ui, wj[q], t);
+						t = fh_fma(-wi, uj[q], t);
+						row[(idx_t) j * a.cs] = t;
+					}
+					acc += (double) t * (double) xj[q];
+					if (j >= i0)
+						tile[ri][j - i0] = t;
+				}
+			}
+		}
+		red[ri][cj] = acc;
+	}
+	__syncthreads();
+	if (tid < TD_PW && i0 + tid < r) {
+		double rs_ = 0.0;
+		for (int c = 0; c < NC; ++c)
+			rs_ += red[tid][c];
+		double dc = 0.0; // strictly lower part of the diagonal tile, column tid
+		for (int ri = tid + 1; ri < TD_PW && i0 + ri < r; ++ri)
+			dc += (double) tile[ri][tid] * (double) x[(idx_t) (i0 + ri) * a.rs];
+		const double below = i0 + TD_PW < r ? a.csum[base + i0 + tid] : 0.0;
+		a.ysum[base + i0 + tid] = (T) (rs_ + (dc + below));
+	}
+}
+
+// A: n x n (lower triangle used), H: block_size x (n - 1)
+template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
+{
+	const idx_t n = A.nrows;
+	FH_CHECK(A.ncols == n, "tridiag: the matrix must be square");
+	FH_CHECK(H.nrows > 0 && H.ncols == (n > 0 ? n - 1 : 0), "tridiag: householder must be block_size x (n - 1)");
+	FH_CHECK(n < (1L << 30), "tridiag: matrix too large");
+	if (n <= 1)
+		return;
+	hipStream_t s = ctx().stream;
+	Scratch vb((size_t) (4 * n) * sizeof(T) + 256), cb((size_t) n * sizeof(double)), stb(sizeof(TdState));
+	TdArgs<T> a;
+	a.A = A.p;
+	a.rs = A.rs;
+	a.cs = A.cs;
+	a.n = (int) n;
+	a.y = vb.as<T>();
+	a.w = a.y + n;
+	a.ysum = a.w + n;
+	a.taus = a.ysum + n;
+	a.csum = cb.as<double>();
+	a.st = stb.as<TdState>();
+	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (4 * n) * sizeof(T), s));
+	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(TdState), s));
+	for (idx_t k = 0; k < n; ++k) {
+		a.k = (int) k;
+		hipLaunchKernelGGL(td_step_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
+		const idx_t r = n - k - 2;
+		if (r > 0) {
+			const unsigned g = (unsigned) ((r + TD_PW - 1) / TD_PW);
+			if (r > TD_PW)
+				hipLaunchKernelGGL(td_colpass_kernel<T>, dim3(g - 1), dim3(TD_NT), 0, s, a); // the last panel has no rows below
+			hipLaunchKernelGGL(td_rowpass_kernel<T>, dim3(g), dim3(TD_NT), 0, s, a);
+		}
+	}
+	FH_HIP(hipGetLastError());
+	// block Householder factors of A.submatrix(1, 0, n - 1, n - 1) (:516-533)
+	qr_t_blocks_from_taus<T>(A.sub(1, 0, n - 1, n - 1), H, n - 1, a.taus);
+	FH_HIP(hipStreamSynchronize(s)); // the scratch vectors above are released on return
+}
+template void tridiag_dev<double>(MatV<double>, MatV<double>);
+template void tridiag_dev<float>(MatV<float>, MatV<float>);
+
 // Backup copy of A for the fast path, fused with the range guard of the fp64 fast path: the cooperative leaf
 // accumulates PLAIN squares and dot products in fp64 (exact for fp32 data, whose squares cannot leave the fp64
 // range), whereas the reference's norm_l2 keeps three differently scaled accumulators

@@ -546,6 +546,18 @@ FAER_HIP_API size_t faer_hip_dist_llt_ws_scalars(size_t n, size_t nb, FaerHipDTy
 FAER_HIP_API FaerLltStatus faer_hip_dist_llt_f64(FaerMatMut A_local, size_t n_global, size_t nb, FaerLltRegularization regularization, FaerHipComm comm, void *panel_ws);
 FAER_HIP_API FaerLltStatus faer_hip_dist_llt_f32(FaerMatMut A_local, size_t n_global, size_t nb, FaerLltRegularization regularization, FaerHipComm comm, void *panel_ws);
 
+/* ------------------------------------------------------------------------------------------------
+ * Reduction to condensed form, first member: tridiagonalization of a self-adjoint
+ * matrix, faer::linalg::evd::tridiag::tridiag_in_place (faer/src/linalg/evd/tridiag.rs:274; the FFI of the reference
+ * reaches it only inside self_adjoint_evd, so this entry point is an extension with the Rust function's argument
+ * meaning).  A: n x n, only the lower triangle is read or written.  On return its diagonal and subdiagonal hold the
+ * tridiagonal T with A = Q T Q^H, the essential parts of the Householder reflectors sit below the subdiagonal and
+ * `householder` (block_size x (n - 1), block_size >= 1) holds the block Householder factors of
+ * A.submatrix(1, 0, n - 1, n - 1) -- what apply_block_householder_sequence_* consumes (tridiag.rs:516-533, :561-585).
+ * Level-2, HBM-bound like the reference (csrc/qr.hip, "Tridiagonalization").  Host or device operands. */
+FAER_HIP_API void faer_hip_tridiag_in_place_f64(FaerMatMut A, FaerMatMut householder);
+FAER_HIP_API void faer_hip_tridiag_in_place_f32(FaerMatMut A, FaerMatMut householder);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1125,6 +1125,101 @@ void FN(oracle_apply_householder_sequence_left)(const T *v, long m, long n, long
 	}
 }
 
+/* ------------------------------------------------ tridiagonalization (evd) */
+/* evd/tridiag.rs:174-272 (tridiag_fused_op_fallback; the SIMD variant :36-139 computes the same quantities in a
+ * different summation order).  A: r x r, only the lower triangle is read / written.
+ *   A(lower) -= u w^H + w u^H ;  z = f * tril(A) x ;  y = f * striu(A^H) x   (the caller adds z to y) */
+static void FN(tridiag_fused_op)(FN(mat) A, T *y2, T *z2, const T *w2, const T *u2, const T *x2, T f)
+{
+	long r = A.ncols;
+	FN(mat) U = {(T *)u2, r, 1, 1, r}, W = {(T *)w2, r, 1, 1, r}, X = {(T *)x2, r, 1, 1, r};
+	FN(mat) Z = {z2, r, 1, 1, r}, Y = {y2, r, 1, 1, r};
+	FN(matmul_triangular)(A, 1, 1, U, 0, FN(tr)(W), 0, (T)-1); /* :189-198 */
+	FN(matmul_triangular)(A, 1, 1, W, 0, FN(tr)(U), 0, (T)-1); /* :199-209 */
+	FN(matmul_triangular)(Z, 0, 0, A, 1, X, 0, f);            /* :226-236 */
+	FN(matmul_triangular)(Y, 0, 0, FN(tr)(A), 4, X, 0, f);    /* :237-247 */
+}
+
+/* evd/tridiag.rs:274-535 (Par::Seq), real scalars.  a: n x n self-adjoint (lower triangle used), h: bs x (n - 1).
+ * On return the diagonal and subdiagonal of a hold T, the essential parts of the reflectors sit below the
+ * subdiagonal, h holds the block Householder factors of A.submatrix(1, 0, n - 1, n - 1). */
+long FN(oracle_tridiag_in_place)(T *a, long n, long rs, long cs, T *h, long bs, long hrs, long hcs)
+{
+	if (n == 0)
+		return 0;
+	FN(mat) A = {a, n, n, rs, cs};
+	FN(mat) H = {h, bs, n - 1, hrs, hcs};
+	T *y = (T *)calloc((size_t)n, sizeof(T)), *w = (T *)calloc((size_t)n, sizeof(T)), *z = (T *)calloc((size_t)n, sizeof(T));
+	T *xc = (T *)calloc((size_t)n, sizeof(T)), *uc = (T *)calloc((size_t)n, sizeof(T));
+	for (long k = 0; k < n; k++) {
+		/* :300-318 column k receives the rest of the rank-2 update of step k - 1 */
+		if (k > 0) {
+			T y1 = y[k];
+			AT(A, k, k) -= y1 + y1;
+			for (long i = k + 1; i < n; i++)
+				AT(A, i, k) -= y1 * AT(A, i, k - 1) + y[i];
+		}
+		if (k + 1 == n)
+			break;
+		long k1 = k + 1, r = n - k - 2; /* r: rows below the reflector's head */
+		/* :330-336 reflector of column k below the diagonal */
+		FN(hinfo) hi = FN(make_householder)(&AT(A, k1, k), &AT(A, k + 2, k), rs, &AT(A, k + 2, k), rs, r);
+		T tau_inv = (T)1 / hi.tau;
+		AT(H, 0, k) = hi.tau;
+		T *y1p = &y[k1], *y2 = y + k + 2, *w2 = w + k + 2, *z2 = z + k + 2;
+		for (long i = 0; i < r; i++)
+			xc[i] = AT(A, k + 2 + i, k);
+		FN(mat) A22 = FN(sub)(A, k + 2, k + 2, r, r);
+		if (k > 0) {
+			/* :348-359 */
+			T u1 = AT(A, k1, k - 1);
+			AT(A, k1, k1) -= u1 * (*y1p) + (*y1p) * u1;
+			for (long i = 0; i < r; i++) {
+				uc[i] = AT(A, k + 2 + i, k - 1);
+				AT(A, k + 2 + i, k1) -= uc[i] * (*y1p) + y2[i] * u1;
+			}
+			for (long i = 0; i < r; i++)
+				w2[i] = y2[i];
+			FN(tridiag_fused_op)(A22, y2, z2, w2, uc, xc, tau_inv); /* :362-376 */
+			for (long i = 0; i < r; i++)
+				y2[i] += z2[i]; /* :377-379 */
+		} else {
+			/* :461-483 */
+			FN(mat) X = {xc, r, 1, 1, r}, Y = {y2, r, 1, 1, r};
+			FN(matmul_triangular)(Y, 0, 0, A22, 1, X, 0, tau_inv);
+			FN(matmul_triangular)(Y, 0, 1, FN(tr)(A22), 4, X, 0, tau_inv);
+		}
+		/* :484-511 */
+		for (long i = 0; i < r; i++)
+			y2[i] += AT(A, k + 2 + i, k1) * tau_inv;
+		*y1p = (AT(A, k1, k1) + FN(dot)(&AT(A, k + 2, k1), rs, xc, 1, r)) * tau_inv;
+		T b = ((*y1p + FN(dot)(xc, 1, y2, 1, r)) * (T)0.5) * tau_inv;
+		*y1p -= b;
+		for (long i = 0; i < r; i++)
+			y2[i] -= b * xc[i];
+	}
+	/* :516-533 block Householder factors */
+	if (n > 1) {
+		long m = n - 1;
+		FN(mat) V = FN(sub)(A, 1, 0, m, m);
+		long j = 0;
+		while (j < m) {
+			long b = bs < m - j ? bs : m - j;
+			FN(mat) Hb = FN(sub)(H, 0, j, b, b);
+			for (long q = 0; q < b; q++)
+				AT(Hb, q, q) = AT(Hb, 0, q);
+			FN(upgrade_householder_factor)(Hb, FN(sub)(V, j, j, m - j, b), b, 1);
+			j += b;
+		}
+	}
+	free(y);
+	free(w);
+	free(z);
+	free(xc);
+	free(uc);
+	return 0;
+}
+
 /* --------------------------------------------------------- exported shims */
 void FN(oracle_matmul)(T *c, long m, long n, long crs, long ccs, int accum_add, const T *a, long k, long ars,
 		       long acs, const T *b, long brs, long bcs, T alpha)

@@ -171,6 +171,16 @@ def qr_in_place(a, h, blocking_threshold=48 * 48):
                                                       C.c_long(bs), *_st(h), C.c_long(blocking_threshold))
 
 
+def tridiag_in_place(a, h):
+    """evd/tridiag.rs:274: a (n x n, self-adjoint, lower triangle used) -> T on the diagonal / subdiagonal, reflectors
+    below; h: block_size x (n - 1) block Householder factors"""
+    suf, _ = _suf(a)
+    n = a.shape[0]
+    assert a.shape == (n, n) and h.shape[1] == max(n - 1, 0) and h.dtype == a.dtype
+    getattr(lib(), f"oracle_tridiag_in_place_{suf}")(_p(a), C.c_long(n), *_st(a), _p(h), C.c_long(h.shape[0]), *_st(h))
+    return a, h
+
+
 def apply_householder_sequence_left(v, h, mat, transpose):
     suf, _ = _suf(mat)
     m, n = v.shape
