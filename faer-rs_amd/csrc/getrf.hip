@@ -1054,6 +1054,94 @@ __global__ __launch_bounds__(256) void laswp_small_kernel(T *B, idx_t rs, idx_t 
 	}
 }
 
+// The same with the net permutation prepared ONCE (laswp_compose_list_kernel): the look-ahead driver applies a panel's
+// 512 interchanges to up to four column ranges, each with thousands of workgroups -- rebuilding the permutation in every
+// workgroup (512 dependent steps per entry) was most of those launches' time (profiles/r02_lu_timeline.txt).
+__global__ __launch_bounds__(1024) void laswp_compose_list_kernel(const int *__restrict__ piv, int nt, int row_base, int *dst, int *src)
+{
+	__shared__ int s_piv[LASWP_SMALL_NT];
+	const int tid = threadIdx.x;
+	for (int j = tid; j < nt; j += 1024)
+		s_piv[j] = piv[j] - row_base;
+	__syncthreads();
+	for (int e = tid; e < 2 * nt; e += 1024) {
+		const int d = e < nt ? e : s_piv[e - nt];
+		int pos = -1;
+		if (e < nt || d >= nt) {
+			pos = d;
+			for (int j = nt - 1; j >= 0; --j) {
+				const int pj = s_piv[j];
+				pos = pos == j ? pj : (pos == pj ? j : pos);
+			}
+			if (pos == d)
+				pos = -1; // row stays where it is
+		}
+		dst[e] = d;
+		src[e] = pos;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void laswp_list_kernel(T *B, idx_t rs, idx_t cs, int ncols, const int *__restrict__ dst,
+							 const int *__restrict__ src, int ne)
+{
+	__shared__ int s_dst[2 * LASWP_SMALL_NT], s_src[2 * LASWP_SMALL_NT];
+	__shared__ T tmp[LASWP_CC * 2 * LASWP_SMALL_NT];
+	const int tid = threadIdx.x;
+	for (int e = tid; e < ne; e += 256) {
+		s_dst[e] = dst[e];
+		s_src[e] = src[e];
+	}
+	__syncthreads();
+	const int c0 = blockIdx.x * LASWP_CC;
+	const int nc = min(LASWP_CC, ncols - c0);
+	for (int idx0 = tid; idx0 < nc * ne; idx0 += 256 * 8) {
+		T v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int idx = idx0 + u * 256;
+			const bool in = idx < nc * ne;
+			const int c = in ? idx / ne : 0, e = in ? idx - c * ne : 0;
+			const int sr = in ? s_src[e] : -1;
+			v[u] = B[sr >= 0 ? (idx_t) sr * rs + (idx_t) (c0 + c) * cs : (idx_t) 0]; // unconditional load, clamped address
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int idx = idx0 + u * 256;
+			if (idx < nc * ne)
+				tmp[idx] = v[u];
+		}
+	}
+	__syncthreads();
+	for (int idx = tid; idx < nc * ne; idx += 256) {
+		const int c = idx / ne, e = idx - c * ne;
+		if (s_src[e] >= 0)
+			B[(idx_t) s_dst[e] * rs + (idx_t) (c0 + c) * cs] = tmp[idx];
+	}
+}
+
+struct LaswpList {
+	int *dst = nullptr, *src = nullptr; // 2 * nt entries each (device)
+	int nt = 0;
+};
+static void laswp_compose_list(const int *piv, int nt, int row_base, LaswpList &l)
+{
+	FH_CHECK(nt <= LASWP_SMALL_NT, "laswp list: too many interchanges");
+	l.nt = nt;
+	if (nt == 0)
+		return;
+	hipLaunchKernelGGL(laswp_compose_list_kernel, dim3(1), dim3(1024), 0, ctx().stream, piv, nt, row_base, l.dst, l.src);
+	FH_HIP(hipGetLastError());
+}
+template <typename T> static void laswp_list_dev(MatV<T> B, const LaswpList &l)
+{
+	if (B.nrows == 0 || B.ncols == 0 || l.nt == 0)
+		return;
+	hipLaunchKernelGGL(laswp_list_kernel<T>, dim3((unsigned) ((B.ncols + LASWP_CC - 1) / LASWP_CC)), dim3(256), 0, ctx().stream, B.p, B.rs, B.cs,
+			   (int) B.ncols, l.dst, l.src, 2 * l.nt);
+	FH_HIP(hipGetLastError());
+}
+
 // Applies the transpositions (j <-> piv[j] - row_base), j < nt, to all columns of B (B's row 0 is the
 // row the first transposition refers to).
 template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, int row_base)
@@ -1284,17 +1372,37 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	stream_wait(c.la_bulk, e0);
 	stream_wait(c.la_panel, e0);
 	hipEvent_t ev_panel;
+	// net row permutation of every panel, composed once on the panel stream right behind the panel and shared by all the
+	// interchange launches of the bulk stream for it (two buffers: the bulk stream still applies panel k while the panel
+	// stream finishes panel k + 1)
+	static_assert(LU_LA_NB <= LASWP_SMALL_NT, "panel interchange list");
+	Scratch listb((size_t) 2 * 2 * 2 * LU_LA_NB * sizeof(int));
+	LaswpList lists[2];
+	for (int q = 0; q < 2; ++q) {
+		lists[q].dst = listb.as<int>() + (size_t) q * 4 * LU_LA_NB;
+		lists[q].src = lists[q].dst + 2 * LU_LA_NB;
+	}
+	static const bool use_lists = !(getenv("FAER_HIP_LU_LISTS") && atoi(getenv("FAER_HIP_LU_LISTS")) == 0); // A/B switch
 	{
 		StreamScope sc(c.la_panel);
 		const idx_t w0 = LU_LA_NB < n ? LU_LA_NB : n;
 		getrf_rec<T>(A.sub(0, 0, m, w0), 0, 0, wk);
+		if (use_lists)
+			laswp_compose_list(wk.piv, (int) w0, 0, lists[0]);
 		ev_panel = c.next_event();
 		FH_HIP(hipEventRecord(ev_panel, c.la_panel));
 	}
-	// brings the columns [c0, c0 + nc) up to date with panel [j0, j0 + w): swaps, solve, update
-	auto update = [&](idx_t j0, idx_t w, idx_t c0, idx_t nc) {
-		const idx_t rows = m - j0, j1 = j0 + w;
-		laswp_dev<T>(A.sub(j0, c0, rows, nc), wk.piv + j0, (int) w, (int) j0);
+	// the interchanges of panel k (pivots [j0, j0 + w)) on the columns [c0, c0 + nc), rows j0 ..
+	auto swaps = [&](idx_t k, idx_t j0, idx_t w, idx_t c0, idx_t nc) {
+		if (use_lists)
+			laswp_list_dev<T>(A.sub(j0, c0, m - j0, nc), lists[k & 1]);
+		else
+			laswp_dev<T>(A.sub(j0, c0, m - j0, nc), wk.piv + j0, (int) w, (int) j0);
+	};
+	// brings the columns [c0, c0 + nc) up to date with panel k = [j0, j0 + w): swaps, solve, update
+	auto update = [&](idx_t k, idx_t j0, idx_t w, idx_t c0, idx_t nc) {
+		const idx_t j1 = j0 + w;
+		swaps(k, j0, w, c0, nc);
 		MatV<T> U = A.sub(j0, c0, w, nc);
 		trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, U);
 		if (m > j1)
@@ -1315,17 +1423,17 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 				// date, the other columns of the panel follow while that leaf runs
 				static const bool nosplit = getenv("FAER_HIP_LU_SPLIT") && atoi(getenv("FAER_HIP_LU_SPLIT")) == 0; // A/B switch
 				const idx_t wa = (w2 < LU_W || nosplit) ? w2 : (idx_t) LU_W;
-				update(j0, w, j1, wa);
+				update(k, j0, w, j1, wa);
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
 				if (w2 > wa) {
-					update(j0, w, j1 + wa, w2 - wa);
+					update(k, j0, w, j1 + wa, w2 - wa);
 					ev_next2 = c.next_event();
 					FH_HIP(hipEventRecord(ev_next2, c.la_bulk));
 				}
 			}
 			if (j2 < n)
-				update(j0, w, j2, n - j2);
+				update(k, j0, w, j2, n - j2);
 			// factor.rs:127-185: the panel's transpositions act on the columns to its left as well.  Nothing reads those
 			// columns again during the factorization, so the interchanges of `defer` consecutive panels are applied
 			// TOGETHER, as one composed row permutation per target block (one gather pass over the left part per group of
@@ -1340,8 +1448,12 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			if (k + 1 == nsteps || (k + 1) % defer == 0) {
 				const idx_t jg0 = grp0 * LU_LA_NB;
 				const idx_t gend = j1 < size_all ? j1 : size_all; // pivots [jg0, gend) belong to the group
-				if (jg0 > 0)
-					laswp_dev<T>(A.sub(jg0, 0, m - jg0, jg0), wk.piv + jg0, (int) (gend - jg0), (int) jg0);
+				if (jg0 > 0) {
+					if (defer == 1)
+						swaps(k, jg0, gend - jg0, 0, jg0);
+					else
+						laswp_dev<T>(A.sub(jg0, 0, m - jg0, jg0), wk.piv + jg0, (int) (gend - jg0), (int) jg0);
+				}
 				for (idx_t kb = grp0; kb < k; ++kb) { // inside the group: block kb gets the interchanges of the panels after it
 					const idx_t c0 = kb * LU_LA_NB, r0 = c0 + LU_LA_NB;
 					laswp_dev<T>(A.sub(r0, c0, m - r0, LU_LA_NB), wk.piv + r0, (int) (gend - r0), (int) r0);
@@ -1353,6 +1465,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			stream_wait(c.la_panel, ev_next);
 			wk.after_leaf = ev_next2;
 			getrf_rec<T>(A.sub(j1, j1, m - j1, w2), (int) j1, (int) j1, wk);
+			if (use_lists)
+				laswp_compose_list(wk.piv + j1, (int) w2, (int) j1, lists[(k + 1) & 1]);
 			ev_panel = c.next_event();
 			FH_HIP(hipEventRecord(ev_panel, c.la_panel));
 		}

@@ -568,19 +568,23 @@ template <typename T> static void trsm_leaf128_launch(const T *img, MatV<T> X, M
 	}
 }
 
-template <typename T> static void trsm_rec(MatV<const T> L, MatV<T> X, const T *W, idx_t b0)
+// W == nullptr: the leaves pack their diagonal block themselves (DIRECT), `unit` says how to read its diagonal
+template <typename T> static void trsm_rec(MatV<const T> L, MatV<T> X, const T *W, idx_t b0, bool unit = false)
 {
 	const idx_t n = L.nrows, k = X.ncols;
 	if (n <= TRSM_IB) {
-		trsm_leaf128_launch<T>(W + (size_t) b0 * TriPack<T>::SIZE, X);
+		if (W)
+			trsm_leaf128_launch<T>(W + (size_t) b0 * TriPack<T>::SIZE, X);
+		else
+			trsm_leaf128_launch<T>(nullptr, X, L, unit);
 		return;
 	}
 	const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
 	const idx_t top = (nblk / 2) * TRSM_IB;
 	MatV<T> Xt = X.sub(0, 0, top, k), Xb = X.sub(top, 0, n - top, k);
-	trsm_rec<T>(L.sub(0, 0, top, top), Xt, W, b0);
+	trsm_rec<T>(L.sub(0, 0, top, top), Xt, W, b0, unit);
 	gemm_dev<T>(Xb, DST_FULL, true, L.sub(top, 0, n - top, top), Xt.c(), (T) -1);
-	trsm_rec<T>(L.sub(top, top, n - top, n - top), Xb, W, b0 + top / TRSM_IB);
+	trsm_rec<T>(L.sub(top, top, n - top, n - top), Xb, W, b0 + top / TRSM_IB, unit);
 }
 
 // X <- L^-1 X with the packed images of L's 128 x 128 diagonal blocks already in W (block i at
@@ -619,11 +623,18 @@ template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X)
 		trsm_leaf128_launch<T>(nullptr, X, L, unit);
 		return;
 	}
-	if (n > 64 || k >= 64) { // packed diagonal blocks + substitution leaves + MFMA products off the diagonal
-		const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
-		Scratch wb((size_t) nblk * TriPack<T>::BYTES);
-		trsm_pack_dev<T>(L, unit, wb.as<T>());
-		trsm_rec<T>(L, X, wb.as<T>(), 0);
+	if (n > 64 || k >= 64) { // substitution leaves on the diagonal blocks + MFMA products off the diagonal
+		// every leaf packs its own diagonal block from the triangle (as fast as copying a prepared image, and one launch
+		// less on a chain that is all launches); FAER_HIP_TRSM_PACK=1: separate packing launch (A/B switch)
+		static const bool prepack = getenv("FAER_HIP_TRSM_PACK") && atoi(getenv("FAER_HIP_TRSM_PACK")) == 1;
+		if (prepack) {
+			const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
+			Scratch wb((size_t) nblk * TriPack<T>::BYTES);
+			trsm_pack_dev<T>(L, unit, wb.as<T>());
+			trsm_rec<T>(L, X, wb.as<T>(), 0);
+		} else {
+			trsm_rec<T>(L, X, nullptr, 0, unit);
+		}
 		return;
 	}
 	// tiny solve: one wavefront stages the triangle itself (a single launch)
