@@ -87,15 +87,16 @@ def test_driver_planning_logic_needs_no_gpu():
         cnt = lib.faer_hip_debug_llt_plan(C.c_size_t(n), C.c_size_t(tail), C.c_size_t(nb2), buf, C.c_size_t(64))
         return [int(buf[i]) for i in range(cnt)]
 
-    # N = 16384, look-ahead until 4096 rows remain: 12 steps of 1024, tail from column 12288
-    assert plan(16384, 4096) == [1024 * i for i in range(13)]
+    # N = 16384, look-ahead until at most 4096 rows remain: the first step is ONE 128-block (the whole chip waits for the
+    # first diagonal block), then steps of 1024; tail from column 12416
+    assert plan(16384, 4096) == [0] + [128 + 1024 * i for i in range(13)]
     # everything to the tail when the matrix is not larger than the tail threshold
     assert plan(8192, 8192) == [0]
     # ragged size: steps stop when the next panel would reach the end
-    assert plan(5197, 2048) == [0, 1024, 2048, 3072, 4096]
-    assert plan(5197, 0) == [0, 1024, 2048, 3072, 4096, 5120]  # the last 77 columns are the tail
-    # wider later steps: first step 1024, then 2048 while 2 * 2048 rows remain behind them, 1024 again at the end
-    assert plan(16384, 4096, 2048) == [0, 1024, 3072, 5120, 7168, 9216, 11264, 12288]
+    assert plan(5197, 2048) == [0, 128, 1152, 2176, 3200]
+    assert plan(5197, 0) == [0, 128, 1152, 2176, 3200, 4224]  # the last 973 columns are the tail
+    # wider later steps: first step 128, then 2048 while 2 * 2048 rows remain behind them, 1024 again at the end
+    assert plan(16384, 4096, 2048) == [0, 128, 2176, 4224, 6272, 8320, 10368, 11392, 12416]
     for n in (2049, 3000, 10240, 16384, 20000):
         for tail in (0, 1024, 4096, 1 << 30):
             j = plan(n, tail)
