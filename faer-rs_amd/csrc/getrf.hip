@@ -156,6 +156,23 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 		}
 	if (!(bv > 0.0))
 		br = INT_MAX; // zero / NaN-only chunk: no candidate
+	// Data-tagged granules (xwg.h, recipe R2): every 8-byte word carries {epoch tag, 32 payload bits} and is written by
+	// ONE write-through store, so it needs neither a store drain nor a flag: a consumer that reads the expected tag has
+	// the data.  The HEADER of this workgroup's record (candidate value and row) goes out at once: the other workgroups
+	// only need the headers to pick the winner, so that round trip runs while the candidate row is still being parked
+	// and published (only the winner's row is fetched, one round trip later): LU N = 16384 124.7 -> 120.9 ms.
+	// Going further -- updating the NEXT column first, publishing its header in the middle of this step and finishing
+	// the rank-1 update while it travels (in-panel look-ahead) -- was built and measured 11 % SLOWER: the restructured
+	// step needs ~30 registers more than the 256 a 512-thread workgroup leaves per lane and spills to scratch
+	// (163 vs 146 ms in one visit on a slow box).
+	const unsigned tag = (unsigned) (a.epoch_base + (xwg_u64) (J + 1));
+	xwg_u64 *sg = a.gran + ((size_t) q * G + g) * LU2_GSLOT;
+	if (G > 1 && tid == 0) {
+		const xwg_u64 vb = (xwg_u64) __double_as_longlong(bv);
+		xwg_store_gran(sg + 0, tag, (unsigned) br);
+		xwg_store_gran(sg + 1, tag, (unsigned) (vb >> 32));
+		xwg_store_gran(sg + 2, tag, (unsigned) vb);
+	}
 	// the owners of the candidate row and (workgroup 0) of row J park them in LDS (rotated order)
 #pragma unroll
 	for (int i = 0; i < RPT; ++i) {
@@ -179,14 +196,8 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 			// is written by ONE write-through store, so it needs neither a store drain nor a flag: a consumer that
 			// reads the expected tag has the data.  Two round trips per column (records, then the winner's row)
 			// instead of four (drain, flag, records, row).  Lane c handles register position c.
-			const unsigned tag = (unsigned) (a.epoch_base + (xwg_u64) (J + 1));
-			xwg_u64 *sg = a.gran + ((size_t) q * G + g) * LU2_GSLOT;
-			if (lane == 0) {
-				const xwg_u64 vb = (xwg_u64) __double_as_longlong(bv);
-				xwg_store_gran(sg + 0, tag, (unsigned) br);
-				xwg_store_gran(sg + 1, tag, (unsigned) (vb >> 32));
-				xwg_store_gran(sg + 2, tag, (unsigned) vb);
-			}
+			// Two round trips per column (record headers, then the winner's row) instead of four (drain, flag, records,
+			// row).  Lane c handles register position c.
 			if (lane < W && br != INT_MAX) {
 				const xwg_u64 cb = (xwg_u64) __double_as_longlong((double) sh.cand[lane]);
 				xwg_store_gran(sg + 4 + 2 * lane, tag, (unsigned) (cb >> 32));
