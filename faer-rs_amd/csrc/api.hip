@@ -1330,7 +1330,7 @@ void faer_hip_set_device(int device)
 	Ctx &c = ctx();
 	c.device = device;
 }
-void faer_hip_set_stream(void *s) { ctx().stream = static_cast<hipStream_t>(s); }
+void faer_hip_set_stream(void *s) { ctx().set_stream(static_cast<hipStream_t>(s)); }
 void *faer_hip_get_stream(void) { return ctx().stream; }
 void faer_hip_synchronize(void) { ctx().sync(); }
 void faer_hip_shutdown(void) { fh::ctx_shutdown(); }

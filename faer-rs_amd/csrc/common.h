@@ -90,6 +90,7 @@ struct Ctx {
 	void *alloc(size_t bytes); // returns a device buffer valid until release()
 	void release(void *p);
 	void sync() { FH_HIP(hipStreamSynchronize(stream)); }
+	void set_stream(hipStream_t s); // the caller's stream (faer_hip_set_stream); internal code switches `stream` directly
 	// after a point where every internal stream has been joined AND the caller's stream synchronised: free
 	// buffers may be handed to any stream again
 	void quiesce();

@@ -188,6 +188,47 @@ void *Ctx::alloc(size_t bytes)
 		pool[best].owner = stream;
 		return pool[best].p;
 	}
+	// No buffer free on THIS stream.  Free buffers last used on OTHER streams become reusable once that work has
+	// finished: poll (never wait) before growing the pool, so that a caller that changes streams
+	// (faer_hip_set_stream) or paths that never reach quiesce() do not accumulate one set of buffers per stream.
+	{
+		std::vector<hipStream_t> idle, busy;
+		for (auto &b : pool) {
+			if (b.used || b.owner == stream || b.owner == ANY_STREAM)
+				continue;
+			// only streams this library knows to be alive are polled here: its own two and the null stream (a stream of
+			// the caller may have been destroyed since; those are polled in set_stream(), while the caller still holds them)
+			if (!(b.owner == nullptr || (la_state > 0 && (b.owner == la_bulk || b.owner == la_panel))))
+				continue;
+			bool known = false, is_idle = false;
+			for (hipStream_t q : idle)
+				if (q == b.owner)
+					known = is_idle = true;
+			for (hipStream_t q : busy)
+				if (q == b.owner)
+					known = true;
+			if (!known) {
+				const hipError_t qe = hipStreamQuery(b.owner);
+				if (qe != hipSuccess && qe != hipErrorNotReady)
+					(void) hipGetLastError(); // e.g. a stream the caller destroyed: leave its buffers alone
+				is_idle = qe == hipSuccess;
+				(is_idle ? idle : busy).push_back(b.owner);
+			}
+			if (is_idle)
+				b.owner = ANY_STREAM;
+		}
+		if (!idle.empty()) {
+			best = -1;
+			for (size_t i = 0; i < pool.size(); ++i)
+				if (!pool[i].used && pool[i].owner == ANY_STREAM && pool[i].bytes >= bytes && (best < 0 || pool[i].bytes < pool[best].bytes))
+					best = (int) i;
+			if (best >= 0 && pool[best].bytes <= 2 * bytes + (1 << 20)) {
+				pool[best].used = true;
+				pool[best].owner = stream;
+				return pool[best].p;
+			}
+		}
+	}
 	void *p = nullptr;
 	hipError_t e = hipMalloc(&p, bytes);
 	if (e != hipSuccess) {
@@ -204,6 +245,27 @@ void *Ctx::alloc(size_t bytes)
 	}
 	pool.push_back(Buf{p, bytes, true, stream});
 	return p;
+}
+
+// the caller moves to another stream: its free buffers can be handed to any stream as soon as the old stream is idle
+// (polled, never waited for; the caller still owns `stream` at this point, so the query is safe)
+void Ctx::set_stream(hipStream_t s)
+{
+	if (s == stream)
+		return;
+	if (device >= 0) {
+		bool any = false;
+		for (auto &b : pool)
+			any = any || (!b.used && b.owner == stream);
+		if (any && hipStreamQuery(stream) == hipSuccess) {
+			for (auto &b : pool)
+				if (!b.used && b.owner == stream)
+					b.owner = ANY_STREAM;
+		} else {
+			(void) hipGetLastError();
+		}
+	}
+	stream = s;
 }
 
 void Ctx::quiesce()

@@ -1274,7 +1274,10 @@ template <typename T> struct TdArgs {
 	TdState *st;
 };
 constexpr int TD_NT = 1024; // td_step_kernel
-constexpr int TD_PW = 16;   // panel width of td_fused_kernel
+constexpr int TD_PW = 16;   // panel width of the two matrix passes
+constexpr int TD_RNT = 1024; // row pass (512 threads x 8 loads in flight: no spills, same time in fp64, 20 % slower in fp32)
+constexpr int TD_RUNR = 4;
+constexpr int TD_UNR = 4;   // independent loads in flight per thread in the matrix passes (8 spills: 128 registers per lane at 1024 threads)
 
 // sums CNT doubles over the 1024 threads; every thread may read s_red afterwards
 template <int CNT> static __device__ __forceinline__ void td_block_sum(double (&v)[CNT], double *s_part, double *s_red)
@@ -1395,7 +1398,7 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_step_kernel(co
 
 // columns i0 .. i0+15 of A22, rows below the diagonal tile: column sums striu(A22^H) x of the matrix AFTER the rank-2
 // update, which is applied on the fly and not written (nobody writes A22 while this kernel runs) -> csum.
-// 16 wavefronts, one column each, lanes along the rows (512-byte loads), four independent loads in flight per lane.
+// 16 wavefronts, one column each, lanes along the rows (512-byte loads), TD_UNR independent loads in flight per lane.
 template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel(const TdArgs<T> a)
 {
 	const int tid = threadIdx.x, k = a.k;
@@ -1412,10 +1415,10 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel
 	const T wj = upd ? w[j] : (T) 0, uj = upd ? u[(idx_t) j * a.rs] : (T) 0;
 	const T *col = A22 + (idx_t) j * a.cs;
 	double acc = 0.0;
-	for (int p0 = i0 + TD_PW + lane; p0 < r; p0 += 256) {
-		T v[4], xp[4], up[4], wp[4];
+	for (int p0 = i0 + TD_PW + lane; p0 < r; p0 += 64 * TD_UNR) {
+		T v[TD_UNR], xp[TD_UNR], up[TD_UNR], wp[TD_UNR];
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
+		for (int q = 0; q < TD_UNR; ++q) {
 			const int pr = p0 + 64 * q;
 			const bool in = pr < r;
 			const idx_t o = in ? (idx_t) pr * a.rs : (idx_t) 0;
@@ -1425,7 +1428,7 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel
 			wp[q] = (in && upd) ? w[in ? pr : 0] : (T) 0;
 		}
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
+		for (int q = 0; q < TD_UNR; ++q) {
 			T t = v[q];
 			if (upd) {
 				t = fh_fma(-up[q], wj, t);
@@ -1441,10 +1444,10 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel
 
 // rows i0 .. i0+15 of A22, columns 0 .. i: the rank-2 update written back (every entry belongs to exactly one
 // workgroup), row sums tril(A22) x, plus the strictly lower part of the diagonal tile and csum -> ysum.
-// Thread (ri, cj): row ri of the panel, columns cj, cj + 64, ...; four independent loads in flight per thread.
-template <typename T> __global__ __launch_bounds__(TD_NT) void td_rowpass_kernel(const TdArgs<T> a)
+// Thread (ri, cj): row ri of the panel, columns cj, cj + NC, ...; TD_RUNR independent loads in flight per thread.
+template <typename T> __global__ __launch_bounds__(TD_RNT) void td_rowpass_kernel(const TdArgs<T> a)
 {
-	constexpr int NC = TD_NT / TD_PW; // 64 column threads per row
+	constexpr int NC = TD_RNT / TD_PW; // column threads per row
 	__shared__ T tile[TD_PW][TD_PW + 1];
 	__shared__ double red[TD_PW][NC + 1];
 	const int tid = threadIdx.x, k = a.k;
@@ -1463,10 +1466,10 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_rowpass_kernel
 		const int jend = min(i0 + TD_PW, r);
 		T *row = A22 + (idx_t) (vi ? gi : 0) * a.rs;
 		double acc = 0.0;
-		for (int j0 = cj; j0 < jend; j0 += 4 * NC) {
-			T v[4], xj[4], wj[4], uj[4];
+		for (int j0 = cj; j0 < jend; j0 += TD_RUNR * NC) {
+			T v[TD_RUNR], xj[TD_RUNR], wj[TD_RUNR], uj[TD_RUNR];
 #pragma unroll
-			for (int q = 0; q < 4; ++q) {
+			for (int q = 0; q < TD_RUNR; ++q) {
 				const int j = j0 + NC * q;
 				const bool in = vi && j <= gi; // (j <= gi < jend)
 				const int jc = in ? j : 0;
@@ -1476,7 +1479,7 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_rowpass_kernel
 				uj[q] = upd ? u[(idx_t) jc * a.rs] : (T) 0;
 			}
 #pragma unroll
-			for (int q = 0; q < 4; ++q) {
+			for (int q = 0; q < TD_RUNR; ++q) {
 				const int j = j0 + NC * q;
 				if (vi && j <= gi) {
 					T t = v[q];
@@ -1538,7 +1541,7 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 			const unsigned g = (unsigned) ((r + TD_PW - 1) / TD_PW);
 			if (r > TD_PW)
 				hipLaunchKernelGGL(td_colpass_kernel<T>, dim3(g - 1), dim3(TD_NT), 0, s, a); // the last panel has no rows below
-			hipLaunchKernelGGL(td_rowpass_kernel<T>, dim3(g), dim3(TD_NT), 0, s, a);
+			hipLaunchKernelGGL(td_rowpass_kernel<T>, dim3(g), dim3(TD_RNT), 0, s, a);
 		}
 	}
 	FH_HIP(hipGetLastError());
