@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native dense backend for faer.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gemm|llt|lu|qr|gemv|fplu|cpqr|tridiag] [--no-extras] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gemm|llt|lu|qr|gemv|fplu|cpqr|tridiag|bidiag] [--no-extras] [--no-cpu]
 
 Metric (BASELINE.json): achieved fp64 GFLOP/s.  A "step" is one pass of the hot path over one batch of
 synthetic input that is already resident in HBM when the timed region starts:
@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="gemm", choices=["gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag"])
+    ap.add_argument("--workload", default="gemm", choices=["gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag"])
     ap.add_argument("--n", type=int, default=0, help="override the matrix size (testing only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -251,6 +251,20 @@ def main():
                 F.tridiag_in_place(work, h)
 
             return step, 4.0 * n ** 3 / 3.0, lambda: work.copy_(a), f"tridiag_f64_n{n}", "f64"
+        if name == "bidiag":
+            # bidiagonalization (svd/bidiag.rs:47), HBM bound: per column the trailing matrix is
+            # read + written once and read once more (8 n^3 / 3 flop in total for a square matrix)
+            n = n_override or 4096
+            a = colmajor(n, n, torch.float64, 9)
+            work = a.clone()
+            hl = torch.zeros((n, 32), dtype=torch.float64, device=dev).t()
+            hr = torch.zeros((n - 1, 32), dtype=torch.float64, device=dev).t()
+
+            def step():
+                work.copy_(a)
+                F.bidiag_in_place(work, hl, hr)
+
+            return step, 8.0 * n ** 3 / 3.0, lambda: work.copy_(a), f"bidiag_f64_n{n}", "f64"
         raise ValueError(name)
 
     def timed(fn, steps, warmup):
@@ -339,7 +353,7 @@ def main():
             others = {}
             del step
             torch.cuda.empty_cache()
-            for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag"):
+            for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag"):
                 if name == args.workload:
                     continue
                 try:
@@ -380,6 +394,11 @@ def main():
                     if name == "tridiag":  # HBM bound: the remaining lower triangle is read and written once per column
                         nn = 4096
                         gbs = sum((nn - k - 2) ** 2 * 8.0 for k in range(nn - 2)) * 3 / t / 1e9
+                        others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3), "GB/s_algorithmic": round(gbs, 1),
+                                      "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                    if name == "bidiag":  # HBM bound: the trailing matrix is read + written once and read once more per column
+                        nn = 4096
+                        gbs = sum(3.0 * (nn - k - 1) ** 2 * 8.0 for k in range(nn)) * 3 / t / 1e9
                         others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3), "GB/s_algorithmic": round(gbs, 1),
                                       "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
                     if name == "qr":  # also HBM bound as specified: algorithmic bytes 2 m n sizeof(f32)

@@ -426,6 +426,17 @@ def tridiag_in_place(a, householder):
     return a, householder
 
 
+def bidiag_in_place(a, h_left, h_right):
+    """faer::linalg::svd::bidiag::bidiag_in_place (svd/bidiag.rs:47), nrows >= ncols: `a` -> the upper bidiagonal B on its
+    diagonal / superdiagonal (a = U B V^H), left reflectors below the diagonal (block factors h_left: bl x n), right
+    reflectors right of the superdiagonal (block factors h_right: br x (n - 1))"""
+    suf, _, _ = _dtype_suffix(a)
+    fn = getattr(lib(), f"faer_hip_bidiag_in_place_{suf}")
+    fn.restype = None
+    fn(_mat(a, MatMut), _mat(h_left, MatMut), _mat(h_right, MatMut))
+    return a, h_left, h_right
+
+
 def colpiv_qr_solve_in_place(qr, q_coeff, col_fwd, col_bwd, rhs, mode="lstsq", par=PAR_SEQ):
     """qr/col_pivoting/solve.rs; mode: 'lstsq' (m >= n, solution in the first n rows), 'solve' (square), 'transpose'"""
     suf, _, _ = _dtype_suffix(qr)

@@ -512,6 +512,19 @@ template <typename T> void tridiag_api(FaerMatMut A, FaerMatMut Hh)
 	tridiag_dev<T>(a.dev, h.dev);
 }
 
+// svd/bidiag.rs:47-66
+template <typename T> void bidiag_api(FaerMatMut A, FaerMatMut Hl, FaerMatMut Hr)
+{
+	const size_t size = A.nrows < A.ncols ? A.nrows : A.ncols;
+	FH_CHECK(A.nrows >= A.ncols, "bidiag: nrows >= ncols required");
+	FH_CHECK(Hl.ncols == size && Hr.ncols == (size > 0 ? size - 1 : 0), "bidiag: H_left / H_right must have min(m, n) and min(m, n) - 1 columns"); // :60-61
+	if (size == 0)
+		return;
+	Staged<T> a(view<T>(A), true, true);
+	Staged<T> hl(view<T>(Hl), true, true), hr(view<T>(Hr), true, true); // only the block upper triangles are written
+	bidiag_dev<T>(a.dev, hl.dev, hr.dev);
+}
+
 // qr/col_pivoting/factor.rs:356-395
 template <typename T, typename I> FaerColPivQrStatus colpiv_qr_api(FaerMatMut A, FaerMatMut Q, FaerSliceMut pf, FaerSliceMut pb)
 {
@@ -1369,6 +1382,8 @@ void faer_hip_debug_dump_timing(void) { trsm_dump_timing(); }
 
 void faer_hip_tridiag_in_place_f64(FaerMatMut A, FaerMatMut householder) { tridiag_api<double>(A, householder); }
 void faer_hip_tridiag_in_place_f32(FaerMatMut A, FaerMatMut householder) { tridiag_api<float>(A, householder); }
+void faer_hip_bidiag_in_place_f64(FaerMatMut A, FaerMatMut Hl, FaerMatMut Hr) { bidiag_api<double>(A, Hl, Hr); }
+void faer_hip_bidiag_in_place_f32(FaerMatMut A, FaerMatMut Hl, FaerMatMut Hr) { bidiag_api<float>(A, Hl, Hr); }
 
 int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, int resident_workgroups)
 {

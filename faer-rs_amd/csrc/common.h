@@ -322,6 +322,8 @@ template <typename T> void laswp_rows_dev(MatV<T> B, const int *piv_dev, int nt)
 template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold);
 // evd/tridiag.rs:274: A (self-adjoint, lower triangle used) -> T + reflectors, H: block Householder factors (qr.hip)
 template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H);
+// svd/bidiag.rs:47 (m >= n): A -> upper bidiagonal + reflectors, Hl / Hr: block Householder factors (qr.hip)
+template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr);
 template <typename T>
 void apply_householder_sequence_left_dev(MatV<const T> V, MatV<const T> H, MatV<T> M, bool transpose);
 

@@ -1552,6 +1552,323 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 template void tridiag_dev<double>(MatV<double>, MatV<double>);
 template void tridiag_dev<float>(MatV<float>, MatV<float>);
 
+// ------------------------------------------------------------------------------------------------
+// Bidiagonalization -- faer/src/linalg/svd/bidiag.rs:47-255, m >= n.
+// The reference's unblocked level-2 algorithm: per column k (i) column k and row k receive the rest of the previous
+// step's rank-2 update (:80-98), (ii) the left reflector of column k (:99-102), (iii) ONE pass over A22 that applies
+// A22 -= up y2 + z2 vp and forms y2 = u^H A22 (bidiag_fused_op, :257-301), (iv) y2, row k and its norm (:156-164),
+// (v) z2 = A22 A12^H (:165-172), (vi) the right reflector of the normalised row and the correction of z2 (:176-213).
+// Four launches per column, no host synchronisation in the loop:
+//   bd_pre_kernel(k)      one workgroup: (vi)'s correction of z for step k-1, then (i) and (ii)
+//   bd_colpass_kernel(k)  one wavefront per column of A22, lanes along the rows: (iii), written back; y sums complete per
+//                         wavefront (columns are independent: no race, fixed summation order)
+//   bd_mid_kernel(k)      one workgroup: (iv), a copy of the normalised row for (v), then the reflector part of (vi)
+//   bd_rowpass_kernel(k)  one workgroup per 16 rows of A22 (read only): (v)
+// Algorithmic bytes: A22 read + written once and read once more per column, sum_k 3 (m-k-1)(n-k-1) sizeof(T).
+// ------------------------------------------------------------------------------------------------
+struct BdState {
+	double tl_inv;			  // left reflector of the current step
+	double tr_inv, beta, hinv, b, norm; // right reflector of the current step (consumed by the next bd_pre_kernel)
+	int hinv_inf, pad;
+};
+template <typename T> struct BdArgs {
+	T *A;
+	idx_t rs, cs;
+	int m, n, size, k;
+	T *y, *z, *ysum, *zsum, *vrow, *taul, *taur;
+	BdState *st;
+};
+
+// make_householder_imp (householder.rs:59-107) from the head and the scaled sums of the tail; returns tau, sets
+// head <- beta, hinv (0 if the tail is negligible: nothing is scaled), inf_flag
+template <typename T> static __device__ __forceinline__ T bd_householder(T &head, T tail_norm, T &hinv, bool &negligible)
+{
+	T head_norm = fabs(head);
+	if (head_norm < Lim<T>::minpos) {
+		head = (T) 0;
+		head_norm = (T) 0;
+	}
+	negligible = tail_norm < Lim<T>::minpos;
+	hinv = (T) 0;
+	if (negligible)
+		return std::numeric_limits<T>::infinity();
+	const T norm = (T) hypot((double) head_norm, (double) tail_norm);
+	const T sign = head_norm != (T) 0 ? head * ((T) 1 / head_norm) : (T) 1;
+	const T signed_norm = sign * norm;
+	hinv = (T) 1 / (head + signed_norm);
+	head = -signed_norm;
+	const T tn = tail_norm * fabs(hinv);
+	return (T) 0.5 * ((T) 1 + tn * tn);
+}
+
+template <typename T> __global__ __launch_bounds__(TD_NT) void bd_pre_kernel(const BdArgs<T> a)
+{
+	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
+	const int tid = threadIdx.x, k = a.k, m = a.m, n = a.n;
+	auto at = [&](int i, int j) -> T & { return a.A[(idx_t) i * a.rs + (idx_t) j * a.cs]; };
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	T nacc[3] = {0, 0, 0};
+	if (k > 0) {
+		// ---- z of step k-1 (:186-213): zsum = A22 A12^H of that step, u = its left reflector (column k-1), A22_a = column k
+		const T beta = (T) a.st->beta, hinv = (T) a.st->hinv, b = (T) a.st->b, tr_inv = (T) a.st->tr_inv;
+		const bool inf = a.st->hinv_inf != 0;
+		auto fix = [&](T zs, T a22a, T u) -> T {
+			T w;
+			if (!inf) {
+				w = zs - a22a * beta;
+				w = w * hinv;
+				w = w - u * b;
+			} else {
+				w = a22a - u * b;
+			}
+			return w * tr_inv;
+		};
+		const T up0 = at(k, k - 1), y1 = a.y[k];
+		const T z1 = fix(a.zsum[k], at(k, k), up0);
+		__syncthreads(); // everyone has read a_kk
+		// ---- (i): the rest of the previous rank-2 update on column k, row k and a_kk (:80-98)
+		if (tid == 0) {
+			a.z[k] = z1;
+			at(k, k) -= up0 * y1 + z1;
+		}
+		for (int i = k + 1 + tid; i < m; i += TD_NT) {
+			const T u = at(i, k - 1), old = at(i, k);
+			const T zf = fix(a.zsum[i], old, u);
+			a.z[i] = zf;
+			const T v = old - (u * y1 + zf);
+			at(i, k) = v;
+			nacc[0] += (v * sml) * (v * sml);
+			nacc[1] += v * v;
+			nacc[2] += (v * big) * (v * big);
+		}
+		for (int j = k + 1 + tid; j < n; j += TD_NT)
+			at(k, j) -= up0 * a.y[j] + z1 * at(k - 1, j);
+	} else {
+		for (int i = 1 + tid; i < m; i += TD_NT) {
+			const T v = at(i, 0);
+			nacc[0] += (v * sml) * (v * sml);
+			nacc[1] += v * v;
+			nacc[2] += (v * big) * (v * big);
+		}
+	}
+	// ---- (ii) left reflector of column k (:99-102)
+	double accd[3] = {(double) nacc[0], (double) nacc[1], (double) nacc[2]};
+	td_block_sum<3>(accd, s_part, s_red);
+	const T tail_norm = norm_from3<T>(s_red);
+	T head = at(k, k), hinv;
+	bool negligible;
+	const T tau = bd_householder<T>(head, tail_norm, hinv, negligible);
+	__syncthreads(); // everyone has read the old head
+	if (!negligible)
+		for (int i = k + 1 + tid; i < m; i += TD_NT)
+			at(i, k) *= hinv;
+	if (tid == 0) {
+		at(k, k) = head;
+		a.taul[k] = tau;
+		a.st->tl_inv = (double) ((T) 1 / tau);
+	}
+}
+
+template <typename T> __global__ __launch_bounds__(TD_NT) void bd_colpass_kernel(const BdArgs<T> a)
+{
+	const int tid = threadIdx.x, k = a.k, m = a.m;
+	const int lane = tid & 63, j = k + 1 + blockIdx.x * (TD_NT / 64) + (tid >> 6);
+	if (j >= a.n)
+		return;
+	const bool upd = k > 0;
+	const T yj = upd ? a.y[j] : (T) 0, vpj = upd ? a.A[(idx_t) (k - 1) * a.rs + (idx_t) j * a.cs] : (T) 0;
+	T *col = a.A + (idx_t) j * a.cs;
+	const T *ucol = a.A + (idx_t) k * a.cs, *upcol = a.A + (idx_t) (upd ? k - 1 : 0) * a.cs;
+	double acc = 0.0;
+	for (int i0 = k + 1 + lane; i0 < m; i0 += 64 * TD_UNR) {
+		T v[TD_UNR], u[TD_UNR], up[TD_UNR], z[TD_UNR];
+#pragma unroll
+		for (int q = 0; q < TD_UNR; ++q) {
+			const int i = i0 + 64 * q;
+			const bool in = i < m;
+			const idx_t o = (idx_t) (in ? i : k) * a.rs;
+			v[q] = col[o];
+			u[q] = in ? ucol[o] : (T) 0;
+			up[q] = (in && upd) ? upcol[o] : (T) 0;
+			z[q] = (in && upd) ? a.z[in ? i : 0] : (T) 0;
+		}
+#pragma unroll
+		for (int q = 0; q < TD_UNR; ++q) {
+			const int i = i0 + 64 * q;
+			if (i < m) {
+				T t = v[q];
+				if (upd) {
+					t = fh_fma(-up[q], yj, t);  // A22 -= up y2 (:292)
+					t = fh_fma(-z[q], vpj, t);  // A22 -= z2 vp (:293)
+					col[(idx_t) i * a.rs] = t;
+				}
+				acc += (double) u[q] * (double) t; // y2 = u^H A22 (:294-300)
+			}
+		}
+	}
+	const double sv = wave_sum(acc);
+	if (lane == 0)
+		a.ysum[j] = (T) sv;
+}
+
+template <typename T> __global__ __launch_bounds__(TD_NT) void bd_mid_kernel(const BdArgs<T> a)
+{
+	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
+	const int tid = threadIdx.x, k = a.k, n = a.n;
+	auto row = [&](int j) -> T & { return a.A[(idx_t) k * a.rs + (idx_t) j * a.cs]; };
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	const T tl_inv = (T) a.st->tl_inv;
+	// ---- (iv) y2 = (y2 + A12) / tau_l, A12 -= y2, norm of A12 (:156-164)
+	T nacc[3] = {0, 0, 0};
+	for (int j = k + 1 + tid; j < n; j += TD_NT) {
+		const T yv = (a.ysum[j] + row(j)) * tl_inv;
+		a.y[j] = yv;
+		const T v = row(j) - yv;
+		row(j) = v;
+		nacc[0] += (v * sml) * (v * sml);
+		nacc[1] += v * v;
+		nacc[2] += (v * big) * (v * big);
+	}
+	double accd[3] = {(double) nacc[0], (double) nacc[1], (double) nacc[2]};
+	td_block_sum<3>(accd, s_part, s_red);
+	const T norm = norm_from3<T>(s_red);
+	const T norm_inv = (T) 1 / norm;
+	T tacc[3] = {0, 0, 0};
+	for (int j = k + 1 + tid; j < n; j += TD_NT) {
+		T v = row(j);
+		if (norm != (T) 0) {
+			v *= norm_inv;
+			row(j) = v;
+		}
+		a.vrow[j] = v; // (v) multiplies by the normalised row as it is BEFORE the right reflector touches it
+		if (j >= k + 2) {
+			tacc[0] += (v * sml) * (v * sml);
+			tacc[1] += v * v;
+			tacc[2] += (v * big) * (v * big);
+		}
+	}
+	if (k + 1 >= a.size)
+		return;
+	// ---- (vi) right reflector of the normalised row (:176-185) and b (:186-193)
+	double tad[3] = {(double) tacc[0], (double) tacc[1], (double) tacc[2]};
+	td_block_sum<3>(tad, s_part, s_red); // (its barriers publish the row written above)
+	const T tail_norm = norm_from3<T>(s_red);
+	T head = row(k + 1), hinv;
+	bool negligible;
+	const T tau = bd_householder<T>(head, tail_norm, hinv, negligible);
+	__syncthreads(); // everyone has read the old head
+	double d[1] = {0.0};
+	for (int j = k + 2 + tid; j < n; j += TD_NT) {
+		T v = row(j);
+		if (!negligible) {
+			v *= hinv;
+			row(j) = v;
+		}
+		d[0] += (double) a.y[j] * (double) v;
+	}
+	td_block_sum<1>(d, s_part, s_red);
+	if (tid == 0) {
+		const T b = a.y[k + 1] + (T) s_red[0];
+		row(k + 1) = head * norm; // beta, rescaled (:183-184)
+		a.taur[k] = tau;
+		a.st->tr_inv = (double) ((T) 1 / tau);
+		a.st->beta = (double) head;
+		a.st->hinv = (double) hinv;
+		a.st->hinv_inf = negligible ? 1 : 0;
+		a.st->b = (double) b;
+		a.st->norm = (double) norm;
+	}
+}
+
+// z2 = A22 A12^H with the normalised row (vrow), read only; rows i0 .. i0+15 per workgroup, thread (ri, cj) takes the
+// columns cj, cj + NC, ...
+template <typename T> __global__ __launch_bounds__(TD_NT) void bd_rowpass_kernel(const BdArgs<T> a)
+{
+	constexpr int NC = TD_NT / TD_PW;
+	__shared__ double red[TD_PW][NC + 1];
+	const int tid = threadIdx.x, k = a.k;
+	const int ri = tid & (TD_PW - 1), cj = tid >> 4;
+	const int i = k + 1 + blockIdx.x * TD_PW + ri;
+	const bool vi = i < a.m;
+	const T *rowp = a.A + (idx_t) (vi ? i : k + 1) * a.rs;
+	double acc = 0.0;
+	for (int j0 = k + 1 + cj; j0 < a.n; j0 += TD_UNR * NC) {
+		T v[TD_UNR], x[TD_UNR];
+#pragma unroll
+		for (int q = 0; q < TD_UNR; ++q) {
+			const int j = j0 + NC * q;
+			const bool in = vi && j < a.n;
+			v[q] = rowp[(idx_t) (in ? j : k + 1) * a.cs];
+			x[q] = in ? a.vrow[j] : (T) 0;
+		}
+#pragma unroll
+		for (int q = 0; q < TD_UNR; ++q)
+			acc += (double) v[q] * (double) x[q];
+	}
+	red[ri][cj] = acc;
+	__syncthreads();
+	if (tid < TD_PW) {
+		const int io = k + 1 + blockIdx.x * TD_PW + tid;
+		if (io < a.m) {
+			double t = 0.0;
+			for (int c = 0; c < NC; ++c)
+				t += red[tid][c];
+			a.zsum[io] = (T) t;
+		}
+	}
+}
+
+// A: m x n, m >= n; Hl: bl x n, Hr: br x (n - 1)
+template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
+{
+	const idx_t m = A.nrows, n = A.ncols;
+	FH_CHECK(m >= n, "bidiag: the matrix must have at least as many rows as columns (the reference's SVD transposes wide inputs)");
+	const idx_t size = n;
+	FH_CHECK(Hl.ncols == size && Hr.ncols == (size > 0 ? size - 1 : 0), "bidiag: householder factors must have n and n - 1 columns");
+	FH_CHECK((Hl.nrows > 0 || size == 0) && (Hr.nrows > 0 || size <= 1), "bidiag: householder factors need at least one row");
+	FH_CHECK(m < (1L << 30), "bidiag: matrix too large");
+	if (size == 0)
+		return;
+	hipStream_t s = ctx().stream;
+	Scratch vb((size_t) (3 * n + 2 * m + 2 * n) * sizeof(T) + 256), stb(sizeof(BdState));
+	BdArgs<T> a;
+	a.A = A.p;
+	a.rs = A.rs;
+	a.cs = A.cs;
+	a.m = (int) m;
+	a.n = (int) n;
+	a.size = (int) size;
+	a.y = vb.as<T>();
+	a.ysum = a.y + n;
+	a.vrow = a.ysum + n;
+	a.z = a.vrow + n;
+	a.zsum = a.z + m;
+	a.taul = a.zsum + m;
+	a.taur = a.taul + n;
+	a.st = stb.as<BdState>();
+	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (3 * n + 2 * m + 2 * n) * sizeof(T), s));
+	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(BdState), s));
+	for (idx_t k = 0; k < size; ++k) {
+		a.k = (int) k;
+		const idx_t rr = m - k - 1, cc = n - k - 1;
+		hipLaunchKernelGGL(bd_pre_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
+		if (cc > 0) {
+			hipLaunchKernelGGL(bd_colpass_kernel<T>, dim3((unsigned) ((cc + TD_NT / 64 - 1) / (TD_NT / 64))), dim3(TD_NT), 0, s, a);
+			hipLaunchKernelGGL(bd_mid_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
+			if (k + 1 < size && rr > 0)
+				hipLaunchKernelGGL(bd_rowpass_kernel<T>, dim3((unsigned) ((rr + TD_PW - 1) / TD_PW)), dim3(TD_NT), 0, s, a);
+		}
+	}
+	FH_HIP(hipGetLastError());
+	// block Householder factors (:216-254): the left ones are in the QR layout, the right ones in its transpose
+	qr_t_blocks_from_taus<T>(A, Hl, size, a.taul);
+	if (size > 1)
+		qr_t_blocks_from_taus<T>(A.sub(0, 1, size - 1, n - 1).t(), Hr, size - 1, a.taur);
+	FH_HIP(hipStreamSynchronize(s)); // the scratch vectors above are released on return
+}
+template void bidiag_dev<double>(MatV<double>, MatV<double>, MatV<double>);
+template void bidiag_dev<float>(MatV<float>, MatV<float>, MatV<float>);
+
 // Backup copy of A for the fast path, fused with the range guard of the fp64 fast path: the cooperative leaf
 // accumulates PLAIN squares and dot products in fp64 (exact for fp32 data, whose squares cannot leave the fp64
 // range), whereas the reference's norm_l2 keeps three differently scaled accumulators

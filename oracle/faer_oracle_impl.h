@@ -660,6 +660,7 @@ T FN(oracle_norm_l2)(const T *x, long n, long stride)
  * to `out` (stride os); in==out for the in-place variant. */
 typedef struct {
 	T tau, norm;
+	T hinv; /* head_with_beta_inv (householder.rs:46-47); +inf when the tail is negligible (:73-77) */
 } FN(hinfo);
 static FN(hinfo) FN(make_householder)(T *head, T *out, long os, const T *in, long is, long len)
 {
@@ -672,6 +673,7 @@ static FN(hinfo) FN(make_householder)(T *head, T *out, long os, const T *in, lon
 	}
 	if (tail_norm < TMIN) {
 		r.tau = (T)INFINITY;
+		r.hinv = (T)INFINITY;
 		r.norm = head_norm;
 		return r;
 	}
@@ -686,6 +688,7 @@ static FN(hinfo) FN(make_householder)(T *head, T *out, long os, const T *in, lon
 	T t = tail_norm * FABS(hinv);
 	r.tau = (T)0.5 * ((T)1 + t * t);
 	r.norm = norm;
+	r.hinv = hinv;
 	return r;
 }
 
@@ -1217,6 +1220,118 @@ long FN(oracle_tridiag_in_place)(T *a, long n, long rs, long cs, T *h, long bs, 
 	free(z);
 	free(xc);
 	free(uc);
+	return 0;
+}
+
+/* ----------------------------------------------- bidiagonalization (svd) */
+/* svd/bidiag.rs:47-255 (Par::Seq; bidiag_fused_op_fallback :282-301), real scalars, m >= n (the reference's SVD
+ * only calls it on tall matrices, and so do its tests :380-500).  a: m x n -> upper bidiagonal B on the diagonal and
+ * superdiagonal with A = U B V^H; the left reflectors below the diagonal (block factors hl: bl x n), the right
+ * reflectors right of the superdiagonal (block factors hr: br x (n - 1)). */
+long FN(oracle_bidiag_in_place)(T *a, long m, long n, long rs, long cs, T *hl, long bl, long hlrs, long hlcs, T *hr, long br, long hrrs,
+				long hrcs)
+{
+	long size = m < n ? m : n;
+	if (size == 0)
+		return 0;
+	FN(mat) A = {a, m, n, rs, cs};
+	FN(mat) Hl = {hl, bl, size, hlrs, hlcs};
+	FN(mat) Hr = {hr, br, size - 1, hrrs, hrcs};
+	T *y = (T *)calloc((size_t)n + 1, sizeof(T)), *z = (T *)calloc((size_t)m + 1, sizeof(T));
+	for (long k = 0; k < size; k++) {
+		long k1 = k - 1, rr = m - k - 1, cc = n - k - 1; /* A22 is rr x cc */
+		T *y2 = y + k + 1, *z2 = z + k + 1;
+		if (k > 0) { /* :80-98 */
+			T y1 = y[k], z1 = z[k], up0 = AT(A, k, k1);
+			AT(A, k, k) -= up0 * y1 + z1;
+			for (long i = 0; i < rr; i++)
+				AT(A, k + 1 + i, k) -= AT(A, k + 1 + i, k1) * y1 + z2[i];
+			for (long j = 0; j < cc; j++)
+				AT(A, k, k + 1 + j) -= up0 * y2[j] + z1 * AT(A, k1, k + 1 + j);
+		}
+		/* :99-102 left reflector */
+		FN(hinfo) hi = FN(make_householder)(&AT(A, k, k), &AT(A, k + 1, k), rs, &AT(A, k + 1, k), rs, rr);
+		T tl_inv = (T)1 / hi.tau;
+		AT(Hl, 0, k) = hi.tau;
+		if (k > 0) { /* bidiag_fused_op_fallback :292-300 */
+			for (long j = 0; j < cc; j++)
+				for (long i = 0; i < rr; i++) {
+					T acc = AT(A, k + 1 + i, k1) * y2[j];
+					AT(A, k + 1 + i, k + 1 + j) = FMA((T)-1, acc, AT(A, k + 1 + i, k + 1 + j));
+				}
+			for (long j = 0; j < cc; j++)
+				for (long i = 0; i < rr; i++) {
+					T acc = z2[i] * AT(A, k1, k + 1 + j);
+					AT(A, k + 1 + i, k + 1 + j) = FMA((T)-1, acc, AT(A, k + 1 + i, k + 1 + j));
+				}
+		}
+		for (long j = 0; j < cc; j++) { /* y2 = u^H A22 (:293-300 / :147-154) */
+			T acc = 0;
+			for (long i = 0; i < rr; i++)
+				acc = FMA(AT(A, k + 1 + i, k), AT(A, k + 1 + i, k + 1 + j), acc);
+			y2[j] = acc;
+		}
+		for (long j = 0; j < cc; j++) { /* :156-159 */
+			y2[j] = (y2[j] + AT(A, k, k + 1 + j)) * tl_inv;
+			AT(A, k, k + 1 + j) -= y2[j];
+		}
+		T norm = FN(oracle_norm_l2)(&AT(A, k, k + 1), cc, cs); /* :160-164 */
+		T norm_inv = (T)1 / norm;
+		if (norm != 0)
+			for (long j = 0; j < cc; j++)
+				AT(A, k, k + 1 + j) *= norm_inv;
+		for (long i = 0; i < rr; i++) { /* z2 = A22 A12^H :165-172 */
+			T acc = 0;
+			for (long j = 0; j < cc; j++)
+				acc = FMA(AT(A, k + 1 + i, k + 1 + j), AT(A, k, k + 1 + j), acc);
+			z2[i] = acc;
+		}
+		if (k + 1 == size)
+			break;
+		/* :176-213 right reflector of the (normalised) row */
+		FN(hinfo) hr_ = FN(make_householder)(&AT(A, k, k + 1), &AT(A, k, k + 2), cs, &AT(A, k, k + 2), cs, cc - 1);
+		T tr_inv = (T)1 / hr_.tau;
+		AT(Hr, 0, k) = hr_.tau;
+		T beta = AT(A, k, k + 1);
+		AT(A, k, k + 1) = beta * norm;
+		T b = y2[0] + FN(dot)(y2 + 1, 1, &AT(A, k, k + 2), cs, cc - 1);
+		if (hr_.hinv != (T)INFINITY) {
+			for (long i = 0; i < rr; i++) {
+				T w = z2[i] - AT(A, k + 1 + i, k + 1) * beta;
+				w = w * hr_.hinv;
+				w = w - AT(A, k + 1 + i, k) * b;
+				z2[i] = w * tr_inv;
+			}
+		} else {
+			for (long i = 0; i < rr; i++) {
+				T w = AT(A, k + 1 + i, k + 1) - AT(A, k + 1 + i, k) * b;
+				z2[i] = w * tr_inv;
+			}
+		}
+	}
+	/* :216-254 block Householder factors */
+	for (long j = 0; j < size;) {
+		long b = bl < size - j ? bl : size - j;
+		FN(mat) Hb = FN(sub)(Hl, 0, j, b, b);
+		for (long q = 0; q < b; q++)
+			AT(Hb, q, q) = AT(Hb, 0, q);
+		FN(upgrade_householder_factor)(Hb, FN(sub)(A, j, j, m - j, b), b, 1);
+		j += b;
+	}
+	if (size > 1) {
+		long sz = size - 1;
+		FN(mat) At = FN(tr)(FN(sub)(A, 0, 1, sz, n - 1)); /* (n - 1) x sz */
+		for (long j = 0; j < sz;) {
+			long b = br < sz - j ? br : sz - j;
+			FN(mat) Hb = FN(sub)(Hr, 0, j, b, b);
+			for (long q = 0; q < b; q++)
+				AT(Hb, q, q) = AT(Hb, 0, q);
+			FN(upgrade_householder_factor)(Hb, FN(sub)(At, j, j, n - 1 - j, b), b, 1);
+			j += b;
+		}
+	}
+	free(y);
+	free(z);
 	return 0;
 }
 
