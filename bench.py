@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native dense backend for faer.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gemm|llt|lu|qr|gemv|fplu|cpqr|tridiag|bidiag] [--no-extras] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gemm|llt|lu|qr|gemv|fplu|cpqr|tridiag|bidiag|hess] [--no-extras] [--no-cpu]
 
 Metric (BASELINE.json): achieved fp64 GFLOP/s.  A "step" is one pass of the hot path over one batch of
 synthetic input that is already resident in HBM when the timed region starts:
@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="gemm", choices=["gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag"])
+    ap.add_argument("--workload", default="gemm", choices=["gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess"])
     ap.add_argument("--n", type=int, default=0, help="override the matrix size (testing only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -265,6 +265,19 @@ def main():
                 F.bidiag_in_place(work, hl, hr)
 
             return step, 8.0 * n ** 3 / 3.0, lambda: work.copy_(a), f"bidiag_f64_n{n}", "f64"
+        if name == "hess":
+            # Hessenberg reduction (evd/hessenberg.rs:549), HBM bound: per column A22 is read +
+            # written + read and the rows above are read twice + written (10 n^3 / 3 flop in total)
+            n = n_override or 4096
+            a = colmajor(n, n, torch.float64, 10)
+            work = a.clone()
+            h = torch.zeros((n - 1, 32), dtype=torch.float64, device=dev).t()
+
+            def step():
+                work.copy_(a)
+                F.hessenberg_in_place(work, h)
+
+            return step, 10.0 * n ** 3 / 3.0, lambda: work.copy_(a), f"hessenberg_f64_n{n}", "f64"
         raise ValueError(name)
 
     def timed(fn, steps, warmup):
@@ -353,7 +366,7 @@ def main():
             others = {}
             del step
             torch.cuda.empty_cache()
-            for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag"):
+            for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess"):
                 if name == args.workload:
                     continue
                 try:
@@ -399,6 +412,11 @@ def main():
                     if name == "bidiag":  # HBM bound: the trailing matrix is read + written once and read once more per column
                         nn = 4096
                         gbs = sum(3.0 * (nn - k - 1) ** 2 * 8.0 for k in range(nn)) * 3 / t / 1e9
+                        others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3), "GB/s_algorithmic": round(gbs, 1),
+                                      "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                    if name == "hess":  # HBM bound: A22 read + written + read, the k + 1 rows above read twice + written, per column
+                        nn = 4096
+                        gbs = sum(3.0 * ((nn - k - 1) ** 2 + (k + 1) * (nn - k - 1)) * 8.0 for k in range(nn)) * 3 / t / 1e9
                         others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3), "GB/s_algorithmic": round(gbs, 1),
                                       "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
                     if name == "qr":  # also HBM bound as specified: algorithmic bytes 2 m n sizeof(f32)

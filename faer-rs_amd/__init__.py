@@ -426,6 +426,17 @@ def tridiag_in_place(a, householder):
     return a, householder
 
 
+def hessenberg_in_place(a, householder):
+    """faer::linalg::evd::hessenberg::hessenberg_in_place (evd/hessenberg.rs:549): `a` (n x n) -> the upper Hessenberg H on and
+    above its subdiagonal (a = Q H Q^H), the reflectors of Q below it, their block factors in `householder`
+    (block_size x (n - 1))"""
+    suf, _, _ = _dtype_suffix(a)
+    fn = getattr(lib(), f"faer_hip_hessenberg_in_place_{suf}")
+    fn.restype = None
+    fn(_mat(a, MatMut), _mat(householder, MatMut))
+    return a, householder
+
+
 def bidiag_in_place(a, h_left, h_right):
     """faer::linalg::svd::bidiag::bidiag_in_place (svd/bidiag.rs:47), nrows >= ncols: `a` -> the upper bidiagonal B on its
     diagonal / superdiagonal (a = U B V^H), left reflectors below the diagonal (block factors h_left: bl x n), right

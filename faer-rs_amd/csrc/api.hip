@@ -512,6 +512,18 @@ template <typename T> void tridiag_api(FaerMatMut A, FaerMatMut Hh)
 	tridiag_dev<T>(a.dev, h.dev);
 }
 
+// evd/hessenberg.rs:549-566
+template <typename T> void hessenberg_api(FaerMatMut A, FaerMatMut Hh)
+{
+	FH_CHECK(A.nrows == A.ncols, "hessenberg: the matrix must be square");
+	FH_CHECK(Hh.ncols == (A.nrows > 0 ? A.nrows - 1 : 0), "hessenberg: householder must have n - 1 columns"); // :557-560
+	if (A.nrows <= 1)
+		return;
+	Staged<T> a(view<T>(A), true, true);
+	Staged<T> h(view<T>(Hh), true, true); // only the block upper triangles are written
+	hessenberg_dev<T>(a.dev, h.dev);
+}
+
 // svd/bidiag.rs:47-66
 template <typename T> void bidiag_api(FaerMatMut A, FaerMatMut Hl, FaerMatMut Hr)
 {
@@ -1384,6 +1396,8 @@ void faer_hip_tridiag_in_place_f64(FaerMatMut A, FaerMatMut householder) { tridi
 void faer_hip_tridiag_in_place_f32(FaerMatMut A, FaerMatMut householder) { tridiag_api<float>(A, householder); }
 void faer_hip_bidiag_in_place_f64(FaerMatMut A, FaerMatMut Hl, FaerMatMut Hr) { bidiag_api<double>(A, Hl, Hr); }
 void faer_hip_bidiag_in_place_f32(FaerMatMut A, FaerMatMut Hl, FaerMatMut Hr) { bidiag_api<float>(A, Hl, Hr); }
+void faer_hip_hessenberg_in_place_f64(FaerMatMut A, FaerMatMut householder) { hessenberg_api<double>(A, householder); }
+void faer_hip_hessenberg_in_place_f32(FaerMatMut A, FaerMatMut householder) { hessenberg_api<float>(A, householder); }
 
 int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, int resident_workgroups)
 {

@@ -324,6 +324,8 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H);
 // svd/bidiag.rs:47 (m >= n): A -> upper bidiagonal + reflectors, Hl / Hr: block Householder factors (qr.hip)
 template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr);
+// evd/hessenberg.rs:549: A -> upper Hessenberg + reflectors, H: block Householder factors (qr.hip)
+template <typename T> void hessenberg_dev(MatV<T> A, MatV<T> H);
 template <typename T>
 void apply_householder_sequence_left_dev(MatV<const T> V, MatV<const T> H, MatV<T> M, bool transpose);
 

@@ -1869,6 +1869,231 @@ template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
 template void bidiag_dev<double>(MatV<double>, MatV<double>, MatV<double>);
 template void bidiag_dev<float>(MatV<float>, MatV<float>, MatV<float>);
 
+// ------------------------------------------------------------------------------------------------
+// Hessenberg reduction -- faer/src/linalg/evd/hessenberg.rs:230-408 (hessenberg_rearranged_unblocked; SURVEY.md section
+// 8f item 4).  The reference switches to a blocked variant (hessenberg_gqvdg_blocked, :568-736) for n >= 256: the same
+// reflectors of the same columns in another order of operations; this path runs the level-2 variant at every size (its
+// passes are HBM streams here, not cache-blocked loops) and agrees with either up to rounding.
+// Per column k: (i) row k, column k and a_kk receive the rest of the previous two-sided update (:266-281), (ii) the
+// reflector of column k below the subdiagonal, head = 1 while the step runs (:294-305), (iii) ONE pass over A22 applying
+// A22 -= u2 y2 + z2 u2^H and forming x^H A22 and A22 x (hessenberg_fused_op, :149-193), (iv) y2, z2 (:342-357), (v) the
+// reflector from the right on row k and the rows above it (:358-378).  Four launches per column:
+//   hs_pre_kernel(k)      one workgroup: (iv) of step k-1, restores its beta, (i), (ii)
+//   hs_colpass_kernel(k)  one wavefront per column of A22: the update written back, x^H A22 complete per wavefront
+//   hs_rowpass_kernel(k)  one workgroup per 16 rows of ALL n rows, columns k+1..: row sums with x (read only) = A22 x for
+//                         the rows below k, and for the rows 0..k the sums ARE the w of (v): those rows are updated at once
+// Algorithmic bytes per column: A22 read + written + read, the k+1 rows above read twice + written.
+// ------------------------------------------------------------------------------------------------
+struct HsState {
+	double tau_inv, beta;
+};
+template <typename T> struct HsArgs {
+	T *A;
+	idx_t rs, cs;
+	int n, k;
+	T *y, *z, *ysum, *zsum, *taus;
+	HsState *st;
+};
+
+template <typename T> __global__ __launch_bounds__(TD_NT) void hs_pre_kernel(const HsArgs<T> a)
+{
+	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
+	const int tid = threadIdx.x, k = a.k, n = a.n;
+	auto at = [&](int i, int j) -> T & { return a.A[(idx_t) i * a.rs + (idx_t) j * a.cs]; };
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	T nacc[3] = {0, 0, 0};
+	if (k > 0) {
+		// ---- (iv) of step k-1 (:342-357): x = [1; A[k+1.., k-1]] (its head is still 1 in memory), zsum = A22 x, ysum = x^H A22
+		const T tau_inv = (T) a.st->tau_inv;
+		double d[1] = {0.0};
+		for (int i = k + tid; i < n; i += TD_NT)
+			d[0] += (double) at(i, k - 1) * (double) a.zsum[i];
+		td_block_sum<1>(d, s_part, s_red);
+		const T b = ((T) s_red[0] * (T) 0.5) * tau_inv;
+		const T x0 = at(k, k - 1); // == 1
+		const T y1 = (a.ysum[k] - b * x0) * tau_inv, z1 = (a.zsum[k] - b * x0) * tau_inv;
+		__syncthreads(); // everyone has read the head of the previous reflector
+		// ---- (i) (:266-281) fused with the rest of (iv)
+		if (tid == 0) {
+			at(k, k - 1) = (T) a.st->beta; // (:379) the previous reflector's head goes back to beta
+			a.y[k] = y1;
+			a.z[k] = z1;
+			at(k, k) -= y1 + z1;
+		}
+		for (int i = k + 1 + tid; i < n; i += TD_NT) {
+			const T u = at(i, k - 1);
+			const T yi = (a.ysum[i] - b * u) * tau_inv, zi = (a.zsum[i] - b * u) * tau_inv;
+			a.y[i] = yi;
+			a.z[i] = zi;
+			at(k, i) -= yi + z1 * u;	    // row k: A12 -= y2 + z1 u2^H
+			const T v = at(i, k) - (u * y1 + zi); // column k: A21 -= u2 y1 + z2
+			at(i, k) = v;
+			if (i >= k + 2) {
+				nacc[0] += (v * sml) * (v * sml);
+				nacc[1] += v * v;
+				nacc[2] += (v * big) * (v * big);
+			}
+		}
+	} else {
+		for (int i = 2 + tid; i < n; i += TD_NT) {
+			const T v = at(i, 0);
+			nacc[0] += (v * sml) * (v * sml);
+			nacc[1] += v * v;
+			nacc[2] += (v * big) * (v * big);
+		}
+	}
+	if (k + 1 >= n)
+		return;
+	// ---- (ii) reflector of column k below the subdiagonal (:294-305)
+	double accd[3] = {(double) nacc[0], (double) nacc[1], (double) nacc[2]};
+	td_block_sum<3>(accd, s_part, s_red);
+	const T tail_norm = norm_from3<T>(s_red);
+	T head = at(k + 1, k), hinv;
+	bool negligible;
+	const T tau = bd_householder<T>(head, tail_norm, hinv, negligible);
+	__syncthreads(); // everyone has read the old head
+	if (!negligible)
+		for (int i = k + 2 + tid; i < n; i += TD_NT)
+			at(i, k) *= hinv;
+	if (tid == 0) {
+		at(k + 1, k) = (T) 1; // head of x while the step runs; beta comes back in the next hs_pre_kernel
+		a.taus[k] = tau;
+		a.st->tau_inv = (double) ((T) 1 / tau);
+		a.st->beta = (double) head;
+	}
+}
+
+template <typename T> __global__ __launch_bounds__(TD_NT) void hs_colpass_kernel(const HsArgs<T> a)
+{
+	const int tid = threadIdx.x, k = a.k, n = a.n;
+	const int lane = tid & 63, j = k + 1 + blockIdx.x * (TD_NT / 64) + (tid >> 6);
+	if (j >= n)
+		return;
+	const bool upd = k > 0;
+	const T *upcol = a.A + (idx_t) (upd ? k - 1 : 0) * a.cs; // u2 = previous reflector (rows k+1..: its tail)
+	const T yj = upd ? a.y[j] : (T) 0, uj = upd ? upcol[(idx_t) j * a.rs] : (T) 0;
+	T *col = a.A + (idx_t) j * a.cs;
+	const T *xcol = a.A + (idx_t) k * a.cs;
+	double acc = 0.0;
+	for (int i0 = k + 1 + lane; i0 < n; i0 += 64 * TD_UNR) {
+		T v[TD_UNR], x[TD_UNR], u[TD_UNR], z[TD_UNR];
+#pragma unroll
+		for (int q = 0; q < TD_UNR; ++q) {
+			const int i = i0 + 64 * q;
+			const bool in = i < n;
+			const idx_t o = (idx_t) (in ? i : k + 1) * a.rs;
+			v[q] = col[o];
+			x[q] = in ? xcol[o] : (T) 0;
+			u[q] = (in && upd) ? upcol[o] : (T) 0;
+			z[q] = (in && upd) ? a.z[in ? i : 0] : (T) 0;
+		}
+#pragma unroll
+		for (int q = 0; q < TD_UNR; ++q) {
+			const int i = i0 + 64 * q;
+			if (i < n) {
+				T t = v[q];
+				if (upd) {
+					t = fh_fma(-u[q], yj, t); // A22 -= u2 y2      (:160-167)
+					t = fh_fma(-z[q], uj, t); // A22 -= z2 u2^H    (:168-175)
+					col[(idx_t) i * a.rs] = t;
+				}
+				acc += (double) x[q] * (double) t; // l_out = x^H A22 (:184-191)
+			}
+		}
+	}
+	const double sv = wave_sum(acc);
+	if (lane == 0)
+		a.ysum[j] = (T) sv;
+}
+
+template <typename T> __global__ __launch_bounds__(TD_NT) void hs_rowpass_kernel(const HsArgs<T> a)
+{
+	constexpr int NC = TD_NT / TD_PW;
+	__shared__ double red[TD_PW][NC + 1];
+	__shared__ T s_w[TD_PW];
+	const int tid = threadIdx.x, k = a.k, n = a.n;
+	const int ri = tid & (TD_PW - 1), cj = tid >> 4;
+	const int i = blockIdx.x * TD_PW + ri;
+	const bool vi = i < n;
+	T *rowp = a.A + (idx_t) (vi ? i : 0) * a.rs;
+	const T *xcol = a.A + (idx_t) k * a.cs; // x[j] = A[j, k], j > k (head = 1 in memory)
+	double acc = 0.0;
+	for (int j0 = k + 1 + cj; j0 < n; j0 += TD_UNR * NC) {
+		T v[TD_UNR], x[TD_UNR];
+#pragma unroll
+		for (int q = 0; q < TD_UNR; ++q) {
+			const int j = j0 + NC * q;
+			const bool in = vi && j < n;
+			v[q] = rowp[(idx_t) (in ? j : k + 1) * a.cs];
+			x[q] = in ? xcol[(idx_t) j * a.rs] : (T) 0;
+		}
+#pragma unroll
+		for (int q = 0; q < TD_UNR; ++q)
+			acc += (double) v[q] * (double) x[q];
+	}
+	red[ri][cj] = acc;
+	__syncthreads();
+	if (tid < TD_PW) {
+		const int io = blockIdx.x * TD_PW + tid;
+		double t = 0.0;
+		for (int c = 0; c < NC; ++c)
+			t += red[tid][c];
+		if (io < n && io > k)
+			a.zsum[io] = (T) t; // r_out = A22 x (:176-183)
+		s_w[tid] = (T) t;
+	}
+	// rows 0 .. k: the sum is the w of (:358-378), the row receives the reflector from the right at once
+	if (blockIdx.x * TD_PW > k)
+		return; // (uniform) no such row in this panel
+	__syncthreads();
+	if (vi && i <= k) {
+		const T dw = s_w[ri] * (T) a.st->tau_inv;
+		for (int j = k + 1 + cj; j < n; j += NC)
+			rowp[(idx_t) j * a.cs] -= dw * xcol[(idx_t) j * a.rs];
+	}
+}
+
+// A: n x n, H: block_size x (n - 1)
+template <typename T> void hessenberg_dev(MatV<T> A, MatV<T> H)
+{
+	const idx_t n = A.nrows;
+	FH_CHECK(A.ncols == n, "hessenberg: the matrix must be square");
+	FH_CHECK(H.ncols == (n > 0 ? n - 1 : 0), "hessenberg: householder must be block_size x (n - 1)");
+	FH_CHECK(n < (1L << 30), "hessenberg: matrix too large");
+	if (n <= 1)
+		return;
+	FH_CHECK(H.nrows > 0, "hessenberg: householder needs at least one row");
+	hipStream_t s = ctx().stream;
+	Scratch vb((size_t) (5 * n) * sizeof(T) + 256), stb(sizeof(HsState));
+	HsArgs<T> a;
+	a.A = A.p;
+	a.rs = A.rs;
+	a.cs = A.cs;
+	a.n = (int) n;
+	a.y = vb.as<T>();
+	a.z = a.y + n;
+	a.ysum = a.z + n;
+	a.zsum = a.ysum + n;
+	a.taus = a.zsum + n;
+	a.st = stb.as<HsState>();
+	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (5 * n) * sizeof(T), s));
+	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(HsState), s));
+	for (idx_t k = 0; k < n; ++k) {
+		a.k = (int) k;
+		hipLaunchKernelGGL(hs_pre_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
+		const idx_t r = n - k - 1;
+		if (r > 0) {
+			hipLaunchKernelGGL(hs_colpass_kernel<T>, dim3((unsigned) ((r + TD_NT / 64 - 1) / (TD_NT / 64))), dim3(TD_NT), 0, s, a);
+			hipLaunchKernelGGL(hs_rowpass_kernel<T>, dim3((unsigned) ((n + TD_PW - 1) / TD_PW)), dim3(TD_NT), 0, s, a);
+		}
+	}
+	FH_HIP(hipGetLastError());
+	qr_t_blocks_from_taus<T>(A.sub(1, 0, n - 1, n - 1), H, n - 1, a.taus); // (:382-406)
+	FH_HIP(hipStreamSynchronize(s)); // the scratch vectors above are released on return
+}
+template void hessenberg_dev<double>(MatV<double>, MatV<double>);
+template void hessenberg_dev<float>(MatV<float>, MatV<float>);
+
 // Backup copy of A for the fast path, fused with the range guard of the fp64 fast path: the cooperative leaf
 // accumulates PLAIN squares and dot products in fp64 (exact for fp32 data, whose squares cannot leave the fp64
 // range), whereas the reference's norm_l2 keeps three differently scaled accumulators

@@ -567,6 +567,16 @@ FAER_HIP_API void faer_hip_tridiag_in_place_f32(FaerMatMut A, FaerMatMut househo
 FAER_HIP_API void faer_hip_bidiag_in_place_f64(FaerMatMut A, FaerMatMut H_left, FaerMatMut H_right);
 FAER_HIP_API void faer_hip_bidiag_in_place_f32(FaerMatMut A, FaerMatMut H_left, FaerMatMut H_right);
 
+/* Third member: reduction to upper Hessenberg form, faer::linalg::evd::hessenberg::hessenberg_in_place
+ * (faer/src/linalg/evd/hessenberg.rs:549).  A: n x n.  On return the part of A on and above the subdiagonal holds H with
+ * A = Q H Q^H, the essential parts of the reflectors sit below the subdiagonal, `householder` (block_size x (n - 1)) holds
+ * the block Householder factors of A.submatrix(1, 0, n - 1, n - 1) (hessenberg.rs:382-406, :758-783).  The reference picks
+ * an unblocked variant below n = 256 and a blocked one above; both compute the same reflectors in different orders of
+ * operations and this entry point agrees with either up to rounding (csrc/qr.hip, "Hessenberg reduction").  Level-2,
+ * HBM-bound.  Host or device operands. */
+FAER_HIP_API void faer_hip_hessenberg_in_place_f64(FaerMatMut A, FaerMatMut householder);
+FAER_HIP_API void faer_hip_hessenberg_in_place_f32(FaerMatMut A, FaerMatMut householder);
+
 #ifdef __cplusplus
 }
 #endif

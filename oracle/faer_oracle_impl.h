@@ -1335,6 +1335,117 @@ long FN(oracle_bidiag_in_place)(T *a, long m, long n, long rs, long cs, T *hl, l
 	return 0;
 }
 
+/* ------------------------------------------------- Hessenberg reduction (evd) */
+/* evd/hessenberg.rs:230-408 (hessenberg_rearranged_unblocked, Par::Seq; fused op :149-193), real scalars.  The reference
+ * runs this variant for n * n < 65536 and hessenberg_gqvdg_blocked (:568-736) above: the same Householder reflectors of
+ * the same columns, applied in another order of operations -- equal up to rounding, and the reference's own tests pin
+ * both variants by the same property (:740-900).
+ * a: n x n -> upper Hessenberg H (a = Q H Q^H) on and above the subdiagonal, the essential parts of the reflectors below
+ * it; h: bs x (n - 1) block Householder factors of A.submatrix(1, 0, n - 1, n - 1). */
+long FN(oracle_hessenberg_in_place)(T *a, long n, long rs, long cs, T *h, long bs, long hrs, long hcs)
+{
+	if (n == 0)
+		return 0;
+	FN(mat) A = {a, n, n, rs, cs};
+	FN(mat) H = {h, bs, n - 1, hrs, hcs};
+	T *y = (T *)calloc((size_t)n, sizeof(T)), *z = (T *)calloc((size_t)n, sizeof(T));
+	T *v = (T *)calloc((size_t)n, sizeof(T)), *w = (T *)calloc((size_t)n, sizeof(T));
+	for (long k = 0; k < n; k++) {
+		long r = n - k - 1; /* A22 is r x r */
+		T *y2 = y + k + 1, *z2 = z + k + 1, *v2 = v + k + 1, *w2 = w + k + 1;
+		if (k > 0) { /* :266-281 */
+			T y1 = y[k], z1 = z[k];
+			long p = k - 1;
+			AT(A, k, k) -= y1 + z1;
+			for (long j = 0; j < r; j++)
+				AT(A, k, k + 1 + j) -= y2[j] + z1 * AT(A, k + 1 + j, p);
+			for (long i = 0; i < r; i++)
+				AT(A, k + 1 + i, k) -= AT(A, k + 1 + i, p) * y1 + z2[i];
+		}
+		if (k + 1 == n)
+			break;
+		/* :294-305 reflector of column k below the subdiagonal; its head is 1 while the step runs */
+		FN(hinfo) hi = FN(make_householder)(&AT(A, k + 1, k), &AT(A, k + 2, k), rs, &AT(A, k + 2, k), rs, r - 1);
+		T tau_inv = (T)1 / hi.tau;
+		T beta = AT(A, k + 1, k);
+		AT(A, k + 1, k) = (T)1;
+		AT(H, 0, k) = hi.tau;
+		/* x2 = A[k+1.., k] */
+		if (k > 0) { /* hessenberg_fused_op_fallback :160-192 */
+			long p = k - 1;
+			for (long j = 0; j < r; j++)
+				for (long i = 0; i < r; i++) {
+					T acc = AT(A, k + 1 + i, p) * y2[j];
+					AT(A, k + 1 + i, k + 1 + j) = FMA((T)-1, acc, AT(A, k + 1 + i, k + 1 + j));
+				}
+			for (long j = 0; j < r; j++)
+				for (long i = 0; i < r; i++) {
+					T acc = z2[i] * AT(A, k + 1 + j, p);
+					AT(A, k + 1 + i, k + 1 + j) = FMA((T)-1, acc, AT(A, k + 1 + i, k + 1 + j));
+				}
+		}
+		for (long i = 0; i < r; i++) { /* w2 = A22 x2 */
+			T acc = 0;
+			for (long j = 0; j < r; j++)
+				acc = FMA(AT(A, k + 1 + i, k + 1 + j), AT(A, k + 1 + j, k), acc);
+			w2[i] = acc;
+		}
+		for (long j = 0; j < r; j++) { /* v2 = x2^H A22 */
+			T acc = 0;
+			for (long i = 0; i < r; i++)
+				acc = FMA(AT(A, k + 1 + i, k), AT(A, k + 1 + i, k + 1 + j), acc);
+			v2[j] = acc;
+		}
+		for (long i = 0; i < r; i++) { /* :322-323 / :325-340 */
+			y2[i] = v2[i];
+			z2[i] = w2[i];
+		}
+		/* :342-357 */
+		T b = (FN(dot)(&AT(A, k + 1, k), rs, z2, 1, r) * (T)0.5) * tau_inv;
+		for (long i = 0; i < r; i++) {
+			T u = AT(A, k + 1 + i, k);
+			y2[i] = (y2[i] - b * u) * tau_inv;
+			z2[i] = (z2[i] - b * u) * tau_inv;
+		}
+		/* :358-362 row k right of the diagonal, :363-378 the rows above it: reflector applied from the right */
+		{
+			T d = FN(dot)(&AT(A, k, k + 1), cs, &AT(A, k + 1, k), rs, r) * tau_inv;
+			for (long j = 0; j < r; j++)
+				AT(A, k, k + 1 + j) -= d * AT(A, k + 1 + j, k);
+		}
+		for (long i = 0; i < k; i++) {
+			T acc = 0;
+			for (long j = 0; j < r; j++)
+				acc = FMA(AT(A, i, k + 1 + j), AT(A, k + 1 + j, k), acc);
+			w[i] = acc;
+		}
+		for (long j = 0; j < r; j++)
+			for (long i = 0; i < k; i++) {
+				T acc = w[i] * AT(A, k + 1 + j, k);
+				AT(A, i, k + 1 + j) = FMA(-tau_inv, acc, AT(A, i, k + 1 + j));
+			}
+		AT(A, k + 1, k) = beta; /* :379 */
+	}
+	if (n > 1) { /* :382-406 */
+		long m = n - 1;
+		FN(mat) V = FN(sub)(A, 1, 0, m, m);
+		long j = 0;
+		while (j < m) {
+			long b = bs < m - j ? bs : m - j;
+			FN(mat) Hb = FN(sub)(H, 0, j, b, b);
+			for (long q = 0; q < b; q++)
+				AT(Hb, q, q) = AT(Hb, 0, q);
+			FN(upgrade_householder_factor)(Hb, FN(sub)(V, j, j, m - j, b), b, 1);
+			j += b;
+		}
+	}
+	free(y);
+	free(z);
+	free(v);
+	free(w);
+	return 0;
+}
+
 /* --------------------------------------------------------- exported shims */
 void FN(oracle_matmul)(T *c, long m, long n, long crs, long ccs, int accum_add, const T *a, long k, long ars,
 		       long acs, const T *b, long brs, long bcs, T alpha)

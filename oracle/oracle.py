@@ -181,6 +181,16 @@ def tridiag_in_place(a, h):
     return a, h
 
 
+def hessenberg_in_place(a, h):
+    """evd/hessenberg.rs:549 (the unblocked variant :230): a (n x n) -> upper Hessenberg H with a = Q H Q^H, reflectors
+    below the subdiagonal; h: block_size x (n - 1) block Householder factors"""
+    suf, _ = _suf(a)
+    n = a.shape[0]
+    assert a.shape == (n, n) and h.shape[1] == max(n - 1, 0) and h.dtype == a.dtype
+    getattr(lib(), f"oracle_hessenberg_in_place_{suf}")(_p(a), C.c_long(n), *_st(a), _p(h), C.c_long(h.shape[0]), *_st(h))
+    return a, h
+
+
 def bidiag_in_place(a, hl, hr):
     """svd/bidiag.rs:47 (m >= n): a -> upper bidiagonal B on the diagonal / superdiagonal (a = U B V^H), left reflectors
     below the diagonal (block factors hl: bl x n), right reflectors right of the superdiagonal (hr: br x (n - 1))"""

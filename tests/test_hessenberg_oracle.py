@@ -1,0 +1,47 @@
+"""The CPU oracle's Hessenberg reduction (oracle_hessenberg_in_place, restating faer/src/linalg/evd/hessenberg.rs:230-408)
+pinned the way the reference pins its own (hessenberg.rs:740-793, test_hessenberg_real): Q^H A Q through the block
+Householder sequence of (V, H) equals the upper Hessenberg part of the output."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from test_tridiag_oracle import qh_a_q
+
+
+def hess_of(v):
+    return np.triu(v, -1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,b", [(3, 3), (4, 3), (8, 3), (16, 3), (2, 1), (50, 8), (129, 32), (200, 1)])
+def test_oracle_hessenberg_reference_property(n, b, dtype):
+    rng = np.random.default_rng(n * 5 + b)
+    a = np.asarray(rng.standard_normal((n, n)), dtype=dtype, order="F")
+    v = a.copy(order="F")
+    h = np.zeros((b, n - 1), dtype=dtype, order="F")
+    O.hessenberg_in_place(v, h)
+    hs = hess_of(v)
+    got = qh_a_q(a, v, h)
+    eps = np.finfo(dtype).eps
+    scale = np.linalg.norm(a.astype(np.float64), 2) * n
+    assert np.abs(got - hs).max() <= 64 * eps * scale
+    # similarity: same spectrum (compared through the characteristic polynomial's symmetric functions is overkill:
+    # sorted eigenvalues of a random matrix are well separated at these sizes)
+    ev_a = np.sort_complex(np.linalg.eigvals(a.astype(np.float64)))
+    ev_h = np.sort_complex(np.linalg.eigvals(hs.astype(np.float64)))
+    assert np.abs(ev_a - ev_h).max() <= (1e-6 if dtype == np.float64 else 5e-2) * scale
+
+
+def test_oracle_hessenberg_edge_cases():
+    a = np.array([[2.5]], order="F")
+    O.hessenberg_in_place(a, np.zeros((1, 0), order="F"))
+    assert a[0, 0] == 2.5
+    O.hessenberg_in_place(np.zeros((0, 0), order="F"), np.zeros((1, 0), order="F"))
+    # already upper Hessenberg: all tails are zero, tau = +inf, the matrix is unchanged
+    n = 6
+    rng = np.random.default_rng(1)
+    hmat = np.triu(rng.standard_normal((n, n)), -1)
+    v, h = np.array(hmat, order="F"), np.zeros((2, n - 1), order="F")
+    O.hessenberg_in_place(v, h)
+    assert np.allclose(v, hmat)
+    assert all(np.isinf(h[j % 2, j]) for j in range(n - 1))
