@@ -40,10 +40,10 @@ sys.path.insert(0, ROOT)
 DOMINANT = {
     "llt": {"bound": "mfma", "kernel": "fh::gemm_kernel_p<double,128,128,16,2,2,false,false,1> (trailing SYRK / panel products)",
             "share": 0.55, "source": "profiles/r02_llt_kernel_stats.csv (share of the library's kernel time per factorization)"},
-    "lu": {"bound": "mfma", "kernel": "fh::getrf_panel2_kernel<double,64,1> (cross-workgroup pivot exchange, latency bound) ahead of the MFMA GEMM (0.29)",
-           "share": 0.40, "source": "profiles/r02_lu_kernel_stats.csv"},
+    "lu": {"bound": "mfma", "kernel": "fh::getrf_panel2_kernel<double,64,1> (cross-workgroup pivot exchange, latency bound) ahead of the MFMA GEMM (0.30)",
+           "share": 0.38, "source": "profiles/r02_lu_kernel_stats.csv"},
     "qr": {"bound": "mfma", "kernel": "fh::qr_panel2_kernel<float,8> (per-column all-reduce, latency bound)",
-           "share": 0.43, "source": "profiles/r02_qr_kernel_stats.csv"},
+           "share": 0.38, "source": "profiles/r02_qr_kernel_stats.csv"},
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet), dense
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
