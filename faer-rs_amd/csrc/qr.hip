@@ -1255,12 +1255,14 @@ template long colpiv_qr_dev<float>(MatV<float>, MatV<float>, idx_t *, idx_t *);
 // SLOWER: an agent-scope fence per workgroup writes the L2 back):
 //   td_step_kernel(k)   one workgroup: finishes y of step k-1 (:484-511), brings column k up to date (:300-318), makes
 //                       its reflector (:330-336, householder.rs:59-107), updates column k+1 (:348-359), w <- y
-//   td_colpass_kernel(k) / td_rowpass_kernel(k)  one workgroup per 16 columns / rows of A22 = A[k+2.., k+2..]: the column
-//                       pass sums striu(A22^H) x over the tiles below the diagonal one with the update applied on the
-//                       fly (read only), the row pass then writes A22 -= u w^H + w u^H back tile row by tile row and
-//                       sums tril(A22) x -- every y_i is COMPLETE inside one workgroup of each pass: no partial sums, no
-//                       atomics, a fixed summation order.  Price: the strictly lower tiles are read twice.  (One kernel
-//                       doing both passes would race: a row panel's write-back against another panel's column reads.)
+//   td_colpass_kernel(k)  one wavefront per column of the lower triangle of A22 = A[k+2.., k+2..], lanes along the rows:
+//                       A22 -= u w^H + w u^H written back (coalesced; every entry belongs to one wavefront) and the column
+//                       sum striu(A22^H) x, complete per wavefront
+//   td_rowpass_kernel(k)  one workgroup per 16 rows, read only: the row sums tril(A22) x of the UPDATED triangle
+//                       Every y_i is complete inside one wavefront / workgroup: no partial sums, no atomics, a fixed
+//                       summation order.  Price: the triangle is read twice.  (The first version wrote back in the
+//                       16-row pass and read in the column pass: 253 ms at N = 4096 against this one's time in DESIGN.md;
+//                       one kernel doing both races -- a write-back against another workgroup's reads.)
 // ------------------------------------------------------------------------------------------------
 struct TdState {
 	double tau_inv;
@@ -1275,8 +1277,6 @@ template <typename T> struct TdArgs {
 };
 constexpr int TD_NT = 1024; // td_step_kernel
 constexpr int TD_PW = 16;   // panel width of the two matrix passes
-constexpr int TD_RNT = 1024; // row pass (512 threads x 8 loads in flight: no spills, same time in fp64, 20 % slower in fp32)
-constexpr int TD_RUNR = 4;
 constexpr int TD_UNR = 4;   // independent loads in flight per thread in the matrix passes (8 spills: 128 registers per lane at 1024 threads)
 
 // sums CNT doubles over the 1024 threads; every thread may read s_red afterwards
@@ -1396,45 +1396,47 @@ template <typename T> static __device__ __forceinline__ void td_step_body(const 
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void td_step_kernel(const TdArgs<T> a) { td_step_body<T>(a, a.k); }
 
-// columns i0 .. i0+15 of A22, rows below the diagonal tile: column sums striu(A22^H) x of the matrix AFTER the rank-2
-// update, which is applied on the fly and not written (nobody writes A22 while this kernel runs) -> csum.
-// 16 wavefronts, one column each, lanes along the rows (512-byte loads), TD_UNR independent loads in flight per lane.
+// Column j of the lower triangle of A22 (one wavefront per column, lanes along the rows: 512-byte accesses): the rank-2
+// update A22 -= u w^H + w u^H WRITTEN BACK (every entry belongs to exactly one wavefront) and the column sum
+// striu(A22^H) x over the rows below the diagonal -> csum[j], complete per wavefront.
 template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel(const TdArgs<T> a)
 {
 	const int tid = threadIdx.x, k = a.k;
 	const int base = k + 2, r = a.n - base; // A22 = A[base.., base..], r x r
-	const int i0 = blockIdx.x * TD_PW;
+	const int lane = tid & 63, j = blockIdx.x * (TD_NT / 64) + (tid >> 6);
+	if (j >= r)
+		return;
 	const bool upd = k > 0;
 	const T *u = a.A + (idx_t) base * a.rs + (idx_t) (k > 0 ? k - 1 : 0) * a.cs; // u[i * rs]
 	const T *x = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;
 	const T *w = a.w + base;
-	const T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
-	const int lane = tid & 63, j = i0 + (tid >> 6);
-	if (j >= r)
-		return;
 	const T wj = upd ? w[j] : (T) 0, uj = upd ? u[(idx_t) j * a.rs] : (T) 0;
-	const T *col = A22 + (idx_t) j * a.cs;
+	T *col = a.A + (idx_t) base * a.rs + (idx_t) (base + j) * a.cs;
 	double acc = 0.0;
-	for (int p0 = i0 + TD_PW + lane; p0 < r; p0 += 64 * TD_UNR) {
+	for (int p0 = j + lane; p0 < r; p0 += 64 * TD_UNR) {
 		T v[TD_UNR], xp[TD_UNR], up[TD_UNR], wp[TD_UNR];
 #pragma unroll
 		for (int q = 0; q < TD_UNR; ++q) {
 			const int pr = p0 + 64 * q;
 			const bool in = pr < r;
-			const idx_t o = in ? (idx_t) pr * a.rs : (idx_t) 0;
+			const idx_t o = (idx_t) (in ? pr : j) * a.rs;
 			v[q] = col[o];
-			xp[q] = in ? x[o] : (T) 0;
+			xp[q] = (in && pr > j) ? x[o] : (T) 0; // the diagonal entry is not part of the strictly-upper product
 			up[q] = (in && upd) ? u[o] : (T) 0;
 			wp[q] = (in && upd) ? w[in ? pr : 0] : (T) 0;
 		}
 #pragma unroll
 		for (int q = 0; q < TD_UNR; ++q) {
-			T t = v[q];
-			if (upd) {
-				t = fh_fma(-up[q], wj, t);
-				t = fh_fma(-wp[q], uj, t);
+			const int pr = p0 + 64 * q;
+			if (pr < r) {
+				T t = v[q];
+				if (upd) {
+					t = fh_fma(-up[q], wj, t);
+					t = fh_fma(-wp[q], uj, t);
+					col[(idx_t) pr * a.rs] = t;
+				}
+				acc += (double) t * (double) xp[q];
 			}
-			acc += (double) t * (double) xp[q]; // xp == 0 beyond the last row
 		}
 	}
 	const double sv = wave_sum(acc);
@@ -1442,57 +1444,37 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel
 		a.csum[base + j] = sv;
 }
 
-// rows i0 .. i0+15 of A22, columns 0 .. i: the rank-2 update written back (every entry belongs to exactly one
-// workgroup), row sums tril(A22) x, plus the strictly lower part of the diagonal tile and csum -> ysum.
-// Thread (ri, cj): row ri of the panel, columns cj, cj + NC, ...; TD_RUNR independent loads in flight per thread.
-template <typename T> __global__ __launch_bounds__(TD_RNT) void td_rowpass_kernel(const TdArgs<T> a)
+// Rows i0 .. i0+15 of the (already updated) lower triangle of A22, read only: row sums tril(A22) x, plus csum -> ysum.
+// Thread (ri, cj): row ri of the panel, columns cj, cj + NC, ...; TD_UNR independent loads in flight per thread.
+template <typename T> __global__ __launch_bounds__(TD_NT) void td_rowpass_kernel(const TdArgs<T> a)
 {
-	constexpr int NC = TD_RNT / TD_PW; // column threads per row
-	__shared__ T tile[TD_PW][TD_PW + 1];
+	constexpr int NC = TD_NT / TD_PW;
 	__shared__ double red[TD_PW][NC + 1];
 	const int tid = threadIdx.x, k = a.k;
 	const int base = k + 2, r = a.n - base;
 	const int i0 = blockIdx.x * TD_PW;
-	const bool upd = k > 0;
-	const T *u = a.A + (idx_t) base * a.rs + (idx_t) (k > 0 ? k - 1 : 0) * a.cs;
 	const T *x = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;
-	const T *w = a.w + base;
-	T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
+	const T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
 	{
 		const int ri = tid & (TD_PW - 1), cj = tid >> 4;
 		const int gi = i0 + ri;
 		const bool vi = gi < r;
-		const T ui = (vi && upd) ? u[(idx_t) gi * a.rs] : (T) 0, wi = (vi && upd) ? w[gi] : (T) 0;
 		const int jend = min(i0 + TD_PW, r);
-		T *row = A22 + (idx_t) (vi ? gi : 0) * a.rs;
+		const T *row = A22 + (idx_t) (vi ? gi : 0) * a.rs;
 		double acc = 0.0;
-		for (int j0 = cj; j0 < jend; j0 += TD_RUNR * NC) {
-			T v[TD_RUNR], xj[TD_RUNR], wj[TD_RUNR], uj[TD_RUNR];
+		for (int j0 = cj; j0 < jend; j0 += TD_UNR * NC) {
+			T v[TD_UNR], xj[TD_UNR];
 #pragma unroll
-			for (int q = 0; q < TD_RUNR; ++q) {
+			for (int q = 0; q < TD_UNR; ++q) {
 				const int j = j0 + NC * q;
 				const bool in = vi && j <= gi; // (j <= gi < jend)
 				const int jc = in ? j : 0;
 				v[q] = row[(idx_t) jc * a.cs];
 				xj[q] = in ? x[(idx_t) jc * a.rs] : (T) 0;
-				wj[q] = upd ? w[jc] : (T) 0;
-				uj[q] = upd ? u[(idx_t) jc * a.rs] : (T) 0;
 			}
 #pragma unroll
-			for (int q = 0; q < TD_RUNR; ++q) {
-				const int j = j0 + NC * q;
-				if (vi && j <= gi) {
-					T t = v[q];
-					if (upd) {
-						t = fh_fma(-ui, wj[q], t);
-						t = fh_fma(-wi, uj[q], t);
-						row[(idx_t) j * a.cs] = t;
-					}
-					acc += (double) t * (double) xj[q];
-					if (j >= i0)
-						tile[ri][j - i0] = t;
-				}
-			}
+			for (int q = 0; q < TD_UNR; ++q)
+				acc += (double) v[q] * (double) xj[q];
 		}
 		red[ri][cj] = acc;
 	}
@@ -1501,11 +1483,7 @@ template <typename T> __global__ __launch_bounds__(TD_RNT) void td_rowpass_kerne
 		double rs_ = 0.0;
 		for (int c = 0; c < NC; ++c)
 			rs_ += red[tid][c];
-		double dc = 0.0; // strictly lower part of the diagonal tile, column tid
-		for (int ri = tid + 1; ri < TD_PW && i0 + ri < r; ++ri)
-			dc += (double) tile[ri][tid] * (double) x[(idx_t) (i0 + ri) * a.rs];
-		const double below = i0 + TD_PW < r ? a.csum[base + i0 + tid] : 0.0;
-		a.ysum[base + i0 + tid] = (T) (rs_ + (dc + below));
+		a.ysum[base + i0 + tid] = (T) (rs_ + a.csum[base + i0 + tid]);
 	}
 }
 
@@ -1538,10 +1516,8 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 		hipLaunchKernelGGL(td_step_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
 		const idx_t r = n - k - 2;
 		if (r > 0) {
-			const unsigned g = (unsigned) ((r + TD_PW - 1) / TD_PW);
-			if (r > TD_PW)
-				hipLaunchKernelGGL(td_colpass_kernel<T>, dim3(g - 1), dim3(TD_NT), 0, s, a); // the last panel has no rows below
-			hipLaunchKernelGGL(td_rowpass_kernel<T>, dim3(g), dim3(TD_RNT), 0, s, a);
+			hipLaunchKernelGGL(td_colpass_kernel<T>, dim3((unsigned) ((r + TD_NT / 64 - 1) / (TD_NT / 64))), dim3(TD_NT), 0, s, a);
+			hipLaunchKernelGGL(td_rowpass_kernel<T>, dim3((unsigned) ((r + TD_PW - 1) / TD_PW)), dim3(TD_NT), 0, s, a);
 		}
 	}
 	FH_HIP(hipGetLastError());
