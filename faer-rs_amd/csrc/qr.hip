@@ -846,20 +846,89 @@ __global__ void qr_finalize_kernel(T *H, idx_t hrs, idx_t hcs, int bs, int size,
 
 // T blocks over the first `rank` reflectors from their taus: striu(V^H V) (householder.rs:185-209), diagonal = tau;
 // the columns from `rank` on get the zero / +inf pattern of factor.rs:287-299
+// striu(V_b^H V_b) of EVERY block of reflectors in one launch (one workgroup per block): the blocks are independent, and
+// one block is a 32 x 32 .. 64 x 64 Gram matrix over up to m rows -- as separate split-K GEMM launches they were 127 x
+// 118 us = 15 ms of every N = 4096 reduction to condensed form.  Rows in chunks through LDS with the unit-lower structure
+// applied on the way in (zeros above the diagonal, 1 on it), sums in fp64 in ascending row order.
+constexpr int TB_MAXW = 64, TB_ROWS = 32, TB_NT = 256;
+template <typename T>
+__global__ __launch_bounds__(TB_NT) void qr_tblock_gram_kernel(const T *V, idx_t vrs, idx_t vcs, int m, int rank, int bs, T *H, idx_t hrs, idx_t hcs)
+{
+	__shared__ T L[TB_ROWS][TB_MAXW + 1];
+	const int tid = threadIdx.x;
+	const int c0 = blockIdx.x * bs;
+	const int wb = min(bs, rank - c0);
+	const int npairs = wb * (wb - 1) / 2;
+	constexpr int MAXP = (TB_MAXW * (TB_MAXW - 1) / 2 + TB_NT - 1) / TB_NT;
+	double acc[MAXP];
+	int pi[MAXP], pj[MAXP];
+#pragma unroll
+	for (int q = 0; q < MAXP; ++q) {
+		acc[q] = 0.0;
+		const int p = tid + q * TB_NT;
+		// pair p -> (i < j), enumerated column by column: j = 1: (0,1); j = 2: (0,2), (1,2); ...
+		int j = 1;
+		if (p < npairs) {
+			j = (int) ((1.0f + sqrtf(1.0f + 8.0f * (float) p)) * 0.5f);
+			while (j * (j - 1) / 2 > p)
+				--j;
+			while ((j + 1) * j / 2 <= p)
+				++j;
+		}
+		pj[q] = j;
+		pi[q] = p < npairs ? p - j * (j - 1) / 2 : 0;
+	}
+	const int rows = m - c0; // rows of this block's reflectors
+	for (int r0 = 0; r0 < rows; r0 += TB_ROWS) {
+		__syncthreads();
+		for (int e = tid; e < TB_ROWS * wb; e += TB_NT) {
+			const int c = e / TB_ROWS, rr = e - c * TB_ROWS, r = r0 + rr; // lanes along the rows (unit stride for column-major V)
+			T v = (T) 0;
+			if (r < rows)
+				v = r < c ? (T) 0 : (r == c ? (T) 1 : V[(idx_t) (c0 + r) * vrs + (idx_t) (c0 + c) * vcs]);
+			L[rr][c] = v;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < MAXP; ++q) {
+			if (tid + q * TB_NT < npairs) {
+				double t = acc[q];
+#pragma unroll 8
+				for (int rr = 0; rr < TB_ROWS; ++rr)
+					t += (double) L[rr][pi[q]] * (double) L[rr][pj[q]];
+				acc[q] = t;
+			}
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < MAXP; ++q)
+		if (tid + q * TB_NT < npairs)
+			H[(idx_t) pi[q] * hrs + (idx_t) (c0 + pj[q]) * hcs] = (T) acc[q];
+}
+
 template <typename T> static void qr_t_blocks_from_taus(MatV<T> A, MatV<T> H, idx_t rank, const T *taus)
 {
 	const idx_t m = A.nrows, n = A.ncols, bs = H.nrows;
 	const idx_t size = m < n ? m : n;
-	for (idx_t c0 = 0; c0 < rank; c0 += bs) {
-		const idx_t wb = bs < rank - c0 ? bs : rank - c0;
-		MatV<T> Tb = H.sub(0, c0, wb, wb);
-		MatV<const T> Vtop = A.sub(c0, c0, wb, wb).c();
-		matmul_triangular_dev<T>(Tb, 6, false, Vtop.t(), 6, Vtop, 5, (T) 1);
-		if (m - c0 > wb) {
-			MatV<const T> Vbot = A.sub(c0 + wb, c0, m - c0 - wb, wb).c();
-			GemmExtra<T> ex;
-			ex.dst_strict = true;
-			gemm_dev<T>(Tb, DST_UPPER, true, Vbot.t(), Vbot, (T) 1, &ex);
+	static const bool batched = !(getenv("FAER_HIP_TBLOCK_BATCHED") && atoi(getenv("FAER_HIP_TBLOCK_BATCHED")) == 0); // A/B switch
+	if (batched && bs <= TB_MAXW && rank > 0) {
+		if (bs > 1) {
+			hipLaunchKernelGGL(qr_tblock_gram_kernel<T>, dim3((unsigned) ((rank + bs - 1) / bs)), dim3(TB_NT), 0, ctx().stream, A.p, A.rs, A.cs, (int) m,
+					   (int) rank, (int) bs, H.p, H.rs, H.cs);
+			FH_HIP(hipGetLastError());
+		}
+	} else {
+		for (idx_t c0 = 0; c0 < rank; c0 += bs) {
+			const idx_t wb = bs < rank - c0 ? bs : rank - c0;
+			MatV<T> Tb = H.sub(0, c0, wb, wb);
+			MatV<const T> Vtop = A.sub(c0, c0, wb, wb).c();
+			matmul_triangular_dev<T>(Tb, 6, false, Vtop.t(), 6, Vtop, 5, (T) 1);
+			if (m - c0 > wb) {
+				MatV<const T> Vbot = A.sub(c0 + wb, c0, m - c0 - wb, wb).c();
+				GemmExtra<T> ex;
+				ex.dst_strict = true;
+				gemm_dev<T>(Tb, DST_UPPER, true, Vbot.t(), Vbot, (T) 1, &ex);
+			}
 		}
 	}
 	hipLaunchKernelGGL(qr_finalize_kernel<T>, dim3((unsigned) ((size + 255) / 256)), dim3(256), 0, ctx().stream, H.p, H.rs, H.cs, (int) bs,
