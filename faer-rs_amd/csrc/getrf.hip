@@ -173,42 +173,50 @@ static __device__ __forceinline__ bool panel2_step(const Panel2Args<T> &a, T (&x
 		xwg_store_gran(sg + 1, tag, (unsigned) (vb >> 32));
 		xwg_store_gran(sg + 2, tag, (unsigned) vb);
 	}
-	// the owners of the candidate row and (workgroup 0) of row J park them in LDS (rotated order)
+	// The WAVE that owns the candidate row (and, in workgroup 0, the one that owns row J) parks it in LDS and publishes it
+	// ITSELF: lane c of that wave stores register position c.  Wave 0 does not wait for it -- there is no workgroup barrier
+	// between the arg-max and the exchange any more -- it goes straight to polling the record headers, and only the
+	// winner's row is fetched one round trip later, long after its owner's stores.  (G == 1: the rows are read from LDS
+	// behind the barrier below.)
 #pragma unroll
 	for (int i = 0; i < RPT; ++i) {
 		const int gr = r0 + tid + i * LU2_NT;
-		if (gr == br) {
+		const bool mine_c = gr == br, mine_d = gr == J;
+		if (__any(mine_c)) { // wave uniform
+			if (mine_c) {
 #pragma unroll
-			for (int c = 0; c < W; ++c)
-				sh.cand[c] = x[i][c];
-		}
-		if (gr == J) {
-#pragma unroll
-			for (int c = 0; c < W; ++c)
-				sh.drow[c] = x[i][c];
-		}
-	}
-	__syncthreads();
-	// ---- 2. wave 0: exchange and winner selection
-	if (G > 1) {
-		if (wave == 0) {
-			// Data-tagged granules (xwg.h, recipe R2): every 8-byte word carries {epoch tag, 32 payload bits} and
-			// is written by ONE write-through store, so it needs neither a store drain nor a flag: a consumer that
-			// reads the expected tag has the data.  Two round trips per column (records, then the winner's row)
-			// instead of four (drain, flag, records, row).  Lane c handles register position c.
-			// Two round trips per column (record headers, then the winner's row) instead of four (drain, flag, records,
-			// row).  Lane c handles register position c.
-			if (lane < W && br != INT_MAX) {
+				for (int c = 0; c < W; ++c)
+					sh.cand[c] = x[i][c];
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (G > 1 && lane < W) {
 				const xwg_u64 cb = (xwg_u64) __double_as_longlong((double) sh.cand[lane]);
 				xwg_store_gran(sg + 4 + 2 * lane, tag, (unsigned) (cb >> 32));
 				xwg_store_gran(sg + 5 + 2 * lane, tag, (unsigned) cb);
 			}
-			if (g == 0 && lane < W) {
+		}
+		if (__any(mine_d)) { // (only in the workgroup that holds row J)
+			if (mine_d) {
+#pragma unroll
+				for (int c = 0; c < W; ++c)
+					sh.drow[c] = x[i][c];
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (G > 1 && lane < W) {
 				const xwg_u64 db = (xwg_u64) __double_as_longlong((double) sh.drow[lane]);
 				xwg_u64 *dg = a.gran_diag + (size_t) q * 2 * LU_WMAX + 2 * lane;
 				xwg_store_gran(dg, tag, (unsigned) (db >> 32));
 				xwg_store_gran(dg + 1, tag, (unsigned) db);
 			}
+		}
+	}
+	if (G == 1)
+		__syncthreads();
+	// ---- 2. wave 0: exchange and winner selection
+	if (G > 1) {
+		if (wave == 0) {
+			// Two round trips per column (record headers, then the winner's row) instead of four (drain, flag, records,
+			// row).  Lane c handles register position c.
 			// ---- records of all producers (lane t reads producer t, strided for G > 64)
 			int ok = 0;
 			double v = 0.0;
