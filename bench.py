@@ -43,7 +43,7 @@ DOMINANT = {
     "lu": {"bound": "mfma", "kernel": "fh::getrf_panel2_kernel<double,64,1> (cross-workgroup pivot exchange, latency bound) ahead of the MFMA GEMM (0.30)",
            "share": 0.38, "source": "profiles/r02_lu_kernel_stats.csv"},
     "qr": {"bound": "mfma", "kernel": "fh::qr_panel2_kernel<float,8> (per-column all-reduce, latency bound)",
-           "share": 0.38, "source": "profiles/r02_qr_kernel_stats.csv"},
+           "share": 0.37, "source": "profiles/r02_qr_kernel_stats.csv"},
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet), dense
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table

@@ -28,6 +28,23 @@ def test_trsm(oracle, n, k, upper, unit, order):
     assert np.abs(got - ref).max() <= 64 * n * EPS[np.dtype(np.float64)] * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,k,order", [(128, 20000, "F"), (100, 17000, "C"), (300, 16500, "F")])
+def test_trsm_many_right_hand_sides(oracle, n, k, order, dtype):
+    """more right-hand sides than 16 per wavefront x one workgroup per CU: the substitution leaf runs with 32 right-hand
+    sides per wavefront (trsm.hip, trsm_leaf128_launch); ragged last workgroup, both stride orders, multi-block triangle"""
+    F = init_gpu()
+    rng = np.random.default_rng(n + k)
+    t = np.asarray(np.tril(rnd(rng, n, n)) / n + np.eye(n), dtype=dtype)
+    b = rnd(rng, n, k, dtype)
+    dx = to_dev(b, order)
+    F.solve_lower_triangular_in_place(to_dev(t, order), dx)
+    got = to_host(dx)
+    ref = b.copy(order="F")
+    oracle.trsm(t, ref, upper=False, unit=False)
+    assert np.abs(got - ref).max() <= 64 * n * EPS[np.dtype(dtype)] * max(1.0, np.abs(ref).max())
+
+
 # ------------------------------------------------------------------------------------------- llt
 @pytest.mark.parametrize("n", [1, 2, 4, 8, 31, 64, 65, 127, 128, 129, 240, 300, 1024])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

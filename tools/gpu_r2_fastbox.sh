@@ -5,9 +5,9 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 probe=$(timeout 200 python tools/gpu_exp_one.py lu 16384 2>&1 | grep -o "lu n=16384: [0-9.]*" | grep -o "[0-9.]*$")
 echo "probe lu = $probe ms"
-slow=$(python -c "print(1 if float('$probe' or 999) > 134 else 0)")
+slow=$(python -c "print(1 if float('$probe' or 999) > 130 else 0)")
 if [ "$slow" = "1" ]; then echo "SLOW BOX"; exit 0; fi
-tag=r02f
+tag=r02h
 timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"
 cat gpurun_out/${tag}_bench.json
 for wl in llt lu qr; do
