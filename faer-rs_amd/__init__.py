@@ -438,9 +438,9 @@ def hessenberg_in_place(a, householder):
 
 
 def bidiag_in_place(a, h_left, h_right):
-    """faer::linalg::svd::bidiag::bidiag_in_place (svd/bidiag.rs:47), nrows >= ncols: `a` -> the upper bidiagonal B on its
-    diagonal / superdiagonal (a = U B V^H), left reflectors below the diagonal (block factors h_left: bl x n), right
-    reflectors right of the superdiagonal (block factors h_right: br x (n - 1))"""
+    """faer::linalg::svd::bidiag::bidiag_in_place (svd/bidiag.rs:47): `a` -> the upper bidiagonal B on its diagonal /
+    superdiagonal (a = U B V^H for nrows >= ncols, the shape the reference's SVD uses), left reflectors below the diagonal
+    (block factors h_left: bl x min(m, n)), right reflectors right of the superdiagonal (h_right: br x (min(m, n) - 1))"""
     suf, _, _ = _dtype_suffix(a)
     fn = getattr(lib(), f"faer_hip_bidiag_in_place_{suf}")
     fn.restype = None

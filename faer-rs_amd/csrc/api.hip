@@ -528,7 +528,6 @@ template <typename T> void hessenberg_api(FaerMatMut A, FaerMatMut Hh)
 template <typename T> void bidiag_api(FaerMatMut A, FaerMatMut Hl, FaerMatMut Hr)
 {
 	const size_t size = A.nrows < A.ncols ? A.nrows : A.ncols;
-	FH_CHECK(A.nrows >= A.ncols, "bidiag: nrows >= ncols required");
 	FH_CHECK(Hl.ncols == size && Hr.ncols == (size > 0 ? size - 1 : 0), "bidiag: H_left / H_right must have min(m, n) and min(m, n) - 1 columns"); // :60-61
 	if (size == 0)
 		return;

@@ -322,7 +322,7 @@ template <typename T> void laswp_rows_dev(MatV<T> B, const int *piv_dev, int nt)
 template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold);
 // evd/tridiag.rs:274: A (self-adjoint, lower triangle used) -> T + reflectors, H: block Householder factors (qr.hip)
 template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H);
-// svd/bidiag.rs:47 (m >= n): A -> upper bidiagonal + reflectors, Hl / Hr: block Householder factors (qr.hip)
+// svd/bidiag.rs:47: A -> upper bidiagonal + reflectors, Hl / Hr: block Householder factors (qr.hip)
 template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr);
 // evd/hessenberg.rs:549: A -> upper Hessenberg + reflectors, H: block Householder factors (qr.hip)
 template <typename T> void hessenberg_dev(MatV<T> A, MatV<T> H);

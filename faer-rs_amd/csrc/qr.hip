@@ -1598,7 +1598,7 @@ template void tridiag_dev<double>(MatV<double>, MatV<double>);
 template void tridiag_dev<float>(MatV<float>, MatV<float>);
 
 // ------------------------------------------------------------------------------------------------
-// Bidiagonalization -- faer/src/linalg/svd/bidiag.rs:47-255, m >= n.
+// Bidiagonalization -- faer/src/linalg/svd/bidiag.rs:47-255.
 // The reference's unblocked level-2 algorithm: per column k (i) column k and row k receive the rest of the previous
 // step's rank-2 update (:80-98), (ii) the left reflector of column k (:99-102), (iii) ONE pass over A22 that applies
 // A22 -= up y2 + z2 vp and forms y2 = u^H A22 (bidiag_fused_op, :257-301), (iv) y2, row k and its norm (:156-164),
@@ -1863,12 +1863,13 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void bd_rowpass_kernel
 	}
 }
 
-// A: m x n, m >= n; Hl: bl x n, Hr: br x (n - 1)
+// A: m x n; Hl: bl x min(m, n), Hr: br x (min(m, n) - 1)
 template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
 {
 	const idx_t m = A.nrows, n = A.ncols;
-	FH_CHECK(m >= n, "bidiag: the matrix must have at least as many rows as columns (the reference's SVD transposes wide inputs)");
-	const idx_t size = n;
+	// (m < n runs like the reference does -- svd/bidiag.rs loops over min(m, n) columns and leaves the last row of a wide
+	// matrix normalised, without its right reflector; its SVD only ever passes tall matrices)
+	const idx_t size = m < n ? m : n;
 	FH_CHECK(Hl.ncols == size && Hr.ncols == (size > 0 ? size - 1 : 0), "bidiag: householder factors must have n and n - 1 columns");
 	FH_CHECK((Hl.nrows > 0 || size == 0) && (Hr.nrows > 0 || size <= 1), "bidiag: householder factors need at least one row");
 	FH_CHECK(m < (1L << 30), "bidiag: matrix too large");

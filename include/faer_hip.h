@@ -558,11 +558,12 @@ FAER_HIP_API FaerLltStatus faer_hip_dist_llt_f32(FaerMatMut A_local, size_t n_gl
 FAER_HIP_API void faer_hip_tridiag_in_place_f64(FaerMatMut A, FaerMatMut householder);
 FAER_HIP_API void faer_hip_tridiag_in_place_f32(FaerMatMut A, FaerMatMut householder);
 
-/* Second member: bidiagonalization, faer::linalg::svd::bidiag::bidiag_in_place (faer/src/linalg/svd/bidiag.rs:47), for
- * nrows >= ncols (the shape the reference's SVD calls it with; it transposes wide inputs first).  On return the diagonal
- * and superdiagonal of A hold the upper bidiagonal B with A = U B V^H; the left reflectors sit below the diagonal with
- * their block factors in H_left (bl x ncols), the right reflectors right of the superdiagonal with their block factors in
- * H_right (br x (ncols - 1)) -- the layout apply_block_householder_sequence_* consumes (bidiag.rs:216-254, :404-428).
+/* Second member: bidiagonalization, faer::linalg::svd::bidiag::bidiag_in_place (faer/src/linalg/svd/bidiag.rs:47).  On
+ * return the diagonal and superdiagonal of A hold the upper bidiagonal B with A = U B V^H; the left reflectors sit below
+ * the diagonal with their block factors in H_left (bl x min(m, n)), the right reflectors right of the superdiagonal with
+ * their block factors in H_right (br x (min(m, n) - 1)) -- the layout apply_block_householder_sequence_* consumes
+ * (bidiag.rs:216-254, :404-428).  The reference's SVD only calls it with nrows >= ncols; a wide matrix is processed the
+ * way the reference processes it (min(m, n) columns, the last row left normalised without a right reflector).
  * Level-2, HBM-bound like the reference (csrc/qr.hip, "Bidiagonalization").  Host or device operands. */
 FAER_HIP_API void faer_hip_bidiag_in_place_f64(FaerMatMut A, FaerMatMut H_left, FaerMatMut H_right);
 FAER_HIP_API void faer_hip_bidiag_in_place_f32(FaerMatMut A, FaerMatMut H_left, FaerMatMut H_right);

@@ -192,11 +192,12 @@ def hessenberg_in_place(a, h):
 
 
 def bidiag_in_place(a, hl, hr):
-    """svd/bidiag.rs:47 (m >= n): a -> upper bidiagonal B on the diagonal / superdiagonal (a = U B V^H), left reflectors
+    """svd/bidiag.rs:47: a -> upper bidiagonal B on the diagonal / superdiagonal (a = U B V^H), left reflectors
     below the diagonal (block factors hl: bl x n), right reflectors right of the superdiagonal (hr: br x (n - 1))"""
     suf, _ = _suf(a)
     m, n = a.shape
-    assert m >= n and hl.shape[1] == n and hr.shape[1] == max(n - 1, 0) and hl.dtype == a.dtype == hr.dtype
+    size = min(m, n)
+    assert hl.shape[1] == size and hr.shape[1] == max(size - 1, 0) and hl.dtype == a.dtype == hr.dtype
     getattr(lib(), f"oracle_bidiag_in_place_{suf}")(_p(a), C.c_long(m), C.c_long(n), *_st(a), _p(hl), C.c_long(hl.shape[0]), *_st(hl), _p(hr),
                                                    C.c_long(hr.shape[0]), *_st(hr))
     return a, hl, hr

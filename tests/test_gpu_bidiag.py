@@ -64,6 +64,24 @@ def test_bidiag_reference_property(m, n, bl, br, dtype):
     assert np.abs(sv_a - sv_b).max() <= 64 * eps * scale
 
 
+@pytest.mark.parametrize("m,n", [(4, 8), (17, 40), (1, 5), (64, 65)])
+def test_bidiag_wide_matrix_like_the_reference(m, n):
+    """m < n: the reference loops over min(m, n) columns and leaves the last row normalised (bidiag.rs:173-175 breaks
+    before the right reflector); its SVD never passes such a matrix, the entry point reproduces the behaviour anyway"""
+    F = init_gpu()
+    rng = np.random.default_rng(m * 3 + n)
+    a = np.asarray(rng.standard_normal((m, n)), order="F")
+    uo, hlo, hro = a.copy(order="F"), np.zeros((2, m), order="F"), np.zeros((2, m - 1), order="F")
+    O.bidiag_in_place(uo, hlo, hro)
+    ud, hld, hrd = to_dev(a), to_dev(np.zeros((2, m), order="F")), to_dev(np.zeros((2, m - 1), order="F"))
+    F.bidiag_in_place(ud, hld, hrd)
+    tol = 1e-10 * max(1.0, np.abs(uo).max())
+    assert np.abs(to_host(ud) - uo).max() <= tol
+    for h, ho in ((to_host(hld), hlo), (to_host(hrd), hro)):
+        fin = np.isfinite(ho)
+        assert np.array_equal(np.isfinite(h), fin) and np.abs(h[fin] - ho[fin]).max(initial=0.0) <= tol
+
+
 def test_bidiag_singular_values_n1500():
     F = init_gpu()
     m, n = 2500, 1500
