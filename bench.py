@@ -196,12 +196,13 @@ def main():
                 F.partial_piv_lu_factor_in_place(work)
 
             return step, 2.0 * n ** 3 / 3.0, lambda: work.copy_(a), f"lu_f64_n{n}", "f64"
-        if name == "qr":
+        if name in ("qr", "qrmax"):
             # BASELINE config Q says 1e6 x 256, but faer's own rank test rejects every fp32 column once
             # 16 * eps * nrows >= 1 (nrows >= 524288; qr/no_pivoting/factor.rs:52-58), i.e. the reference does no
             # factorization there (rank 0, reproduced by our library and covered by tests).  The rate is therefore
             # quoted on the largest round tall-skinny shape the reference really factors.
-            m, n = (n_override or 500000), 256
+            # ("qrmax": 524287 rows, the LARGEST height the reference's rank test still accepts in fp32)
+            m, n = (n_override or (524287 if name == "qrmax" else 500000)), 256
             a = colmajor(m, n, torch.float32, 5)
             work = a.clone()
             bs = F.qr_recommended_block_size(m, n, np.float32)
@@ -366,7 +367,7 @@ def main():
             others = {}
             del step
             torch.cuda.empty_cache()
-            for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess"):
+            for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess", "qrmax"):
                 if name == args.workload:
                     continue
                 try:
@@ -380,7 +381,7 @@ def main():
                     peak = FP64_MFMA_PEAK_TFLOPS if dn == "f64" else FP32_MFMA_PEAK_TFLOPS
                     others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3),
                                   "frac_of_mfma_peak": round(rate / 1e3 / peak, 4), "reps": reps}
-                    if name in DOMINANT:
+                    if name in DOMINANT and name != "qrmax":
                         # per-workload roofline object: the factorizations are chains of launches, so `achieved` is the
                         # whole-factorization rate against the bound of their dominant kernel; which kernel dominates and
                         # its share of the device time come from the committed kernel trace named in `source`
@@ -419,8 +420,8 @@ def main():
                         gbs = sum(3.0 * ((nn - k - 1) ** 2 + (k + 1) * (nn - k - 1)) * 8.0 for k in range(nn)) * 3 / t / 1e9
                         others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3), "GB/s_algorithmic": round(gbs, 1),
                                       "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-                    if name == "qr":  # also HBM bound as specified: algorithmic bytes 2 m n sizeof(f32)
-                        gbs = 2.0 * 500000 * 256 * 4 * 3 / t / 1e9
+                    if name in ("qr", "qrmax"):  # also HBM bound as specified: algorithmic bytes 2 m n sizeof(f32)
+                        gbs = 2.0 * (524287 if name == "qrmax" else 500000) * 256 * 4 * 3 / t / 1e9
                         others[lb]["GB/s_algorithmic"] = round(gbs, 1)
                     del st, ov
                     torch.cuda.empty_cache()
