@@ -87,14 +87,19 @@ template <typename S> struct DeviceBackend {
 		stream_wait(ctx().la_panel, ev0);
 		ctx().stream = ctx().la_panel;
 	}
+	hipEvent_t ev_ahead = nullptr;
 	void ahead_end()
 	{
 		if (!two)
 			return;
-		hipEvent_t e = ctx().next_event();
-		FH_HIP(hipEventRecord(e, ctx().la_panel));
+		ev_ahead = ctx().next_event();
+		FH_HIP(hipEventRecord(ev_ahead, ctx().la_panel));
 		ctx().stream = caller;
-		stream_wait(caller, e); // the broadcast of the new panel is ordered behind it
+	}
+	void ahead_join()
+	{
+		if (two && ev_ahead)
+			stream_wait(caller, ev_ahead); // the broadcast of the new panel is ordered behind it
 	}
 	void run_end()
 	{

@@ -30,7 +30,7 @@ namespace fh {
 //   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)
 //                                                        -- collective on the backend's memory space; may be
 //                                                           asynchronous (slot = 0 / 1, at most one in flight each)
-//   void step_begin() / void rest_begin() / rest_end() / ahead_begin() / ahead_end()
+//   void step_begin() / void rest_begin() / rest_end() / ahead_begin() / ahead_end() / ahead_join()
 //                                                        -- scheduling hooks (no-ops for a synchronous backend): the
 //                                                           device backend runs the "rest" updates of a step on the
 //                                                           bulk stream and the look-ahead part (update + panel of
@@ -41,8 +41,8 @@ namespace fh {
 // Look-ahead: the owner of block column k+1 brings that column up to date with panel k and factors it FIRST, then
 // starts its broadcast; every rank posts the receive before it runs the rest of update k, so the transfer of
 // panel k+1 and the latency-bound panel factorization on its owner overlap with the trailing updates of step k.
-// On the owner itself the REST of update k is issued first (an asynchronous backend queues it on its bulk stream) and
-// the look-ahead part second (on its panel stream): the two run concurrently inside the rank, exactly like the two
+// On the owner itself the look-ahead part is issued first (an asynchronous backend queues it on its panel stream) and
+// the REST of update k second (on its bulk stream): the two run concurrently inside the rank, exactly like the two
 // streams of the single-GPU driver (getrf.hip, getrf_lookahead).
 // Two panel buffers alternate; the pivots stay in the backend's memory until the end (no host synchronisation
 // inside the loop).
@@ -144,11 +144,18 @@ template <class B> struct DistLu {
 				be.rest_end();
 			};
 			if (ahead && rank == next_owner) {
-				rest(); // queued first: runs beside the panel below on an asynchronous backend
+				// The look-ahead part is ISSUED first: it is a chain of latency-bound launches that has to start at once,
+				// while issuing the rest of the update (dozens of launches per owned block column) keeps the host busy for
+				// as long as the panel runs (profiles/r02_dist_overlap.txt: issued the other way round, the panel stream only
+				// started when the host had finished queueing the rest -- the two streams ran one after the other).  The
+				// caller's stream joins the panel stream only AFTER the rest has been queued, so a blocking transport that
+				// synchronises in bcast_begin does not hold the rest back either.
 				be.ahead_begin();
 				update(k, k + 1);
 				factor_and_pack(k + 1);
 				be.ahead_end();
+				rest(); // runs beside the panel on an asynchronous backend
+				be.ahead_join();
 				be.bcast_begin(piv_of(k + 1), bytes_of(k + 1), next_owner, (int) ((k + 1) & 1));
 			} else {
 				if (ahead) // post the receive before the updates: the transfer overlaps them

@@ -106,6 +106,7 @@ struct HostBackend {
 	void rest_end() {}
 	void ahead_begin() {}
 	void ahead_end() {}
+	void ahead_join() {}
 	void run_end() {}
 	void copy_ints(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
 	void zero_ints(int *p, size_t n) { std::memset(p, 0, n * sizeof(int)); }

@@ -2,6 +2,7 @@
 and the largest kernels (used to see which stream bounds LLT / LU).  usage: trace_timeline.py <csv> [iteration]"""
 import csv
 import collections
+import os
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -20,6 +21,10 @@ for r in rows:
 if cur:
     runs.append(cur)
 runs = [x for x in runs if len(x) > 50]
+if os.environ.get("TL_WHOLE"):  # the whole trace as one run (drivers whose steps contain copy kernels, e.g. the distributed LU);
+    # TL_WHOLE=2: the trace holds two identical runs (cold + warm), analyse the second
+    allk = [r for r in rows if r["fh"]]
+    runs = [allk[len(allk) // 2:]] if os.environ["TL_WHOLE"] == "2" else [allk]
 print("factorizations found:", len(runs), [len(x) for x in runs])
 it = int(sys.argv[2]) if len(sys.argv) > 2 else len(runs) - 1
 run = runs[it]
