@@ -44,37 +44,52 @@ template <typename S> struct DeviceBackend {
 	}
 	// ---- two-stream schedule inside the rank (dist_lu.h): the rest of update k on the bulk stream, the look-ahead part
 	// (update of block column k+1 + its panel factorization, cooperative leaves on the reserved CUs) on the panel stream
-	bool two = false;
+	bool two = false;     // the two internal streams are available
+	bool two_now = false; // ... and used in the current step
+	long two_min_work = 100000000; // trailing entries (rows x local columns right of the panel) from which a step uses both streams
 	hipStream_t caller = nullptr;
-	hipEvent_t ev0 = nullptr, ev_bulk = nullptr;
+	hipEvent_t ev0 = nullptr, ev_bulk = nullptr, ev_ahead = nullptr;
 	void streams_init()
 	{
 		caller = ctx().stream;
 		two = !getenv("FAER_HIP_DIST_ONE_STREAM") && ctx().lookahead_streams();
+		if (const char *e = getenv("FAER_HIP_DIST_TWO_MIN"))
+			two_min_work = atol(e);
 		if (two)
 			ctx().reset_events();
 	}
-	void step_begin()
+	// The panel stream owns 32 CUs: a panel factored there takes ~0.75 ms longer per 8192 rows than on the whole chip
+	// (its products, solves and interchanges run on 1/8 of the CUs), which only pays when the rest of the update it
+	// overlaps with is longer than that.  Measured on one rank (profiles/r02_dist_overlap.txt): N = 8192 (at most 6.3e7
+	// trailing entries per step) runs 57.2 ms on one stream, 59.7 ms with the two streams in every step; the single-GPU
+	// driver's N = 16384 (2.5e8 entries in the first step) needs them (121 vs 193 ms).  Steps with fewer than 1e8 trailing
+	// entries on this rank run on the caller's stream (FAER_HIP_DIST_TWO_MIN overrides; the count only shrinks).
+	void step_begin(long local_trailing_entries)
 	{
 		if (!two)
 			return;
 		// the bulk stream's reads of the panel buffer that the next receive overwrites, and its writes to the columns the
 		// look-ahead part touches, are older than everything issued from here on
-		if (ev_bulk)
+		if (ev_bulk) {
 			stream_wait(caller, ev_bulk);
+			ev_bulk = nullptr;
+		}
+		two_now = local_trailing_entries >= two_min_work;
+		if (!two_now)
+			return;
 		ev0 = ctx().next_event();
 		FH_HIP(hipEventRecord(ev0, caller));
 	}
 	void rest_begin()
 	{
-		if (!two)
+		if (!two_now)
 			return;
 		stream_wait(ctx().la_bulk, ev0);
 		ctx().stream = ctx().la_bulk;
 	}
 	void rest_end()
 	{
-		if (!two)
+		if (!two_now)
 			return;
 		ev_bulk = ctx().next_event();
 		FH_HIP(hipEventRecord(ev_bulk, ctx().la_bulk));
@@ -82,15 +97,14 @@ template <typename S> struct DeviceBackend {
 	}
 	void ahead_begin()
 	{
-		if (!two)
+		if (!two_now)
 			return;
 		stream_wait(ctx().la_panel, ev0);
 		ctx().stream = ctx().la_panel;
 	}
-	hipEvent_t ev_ahead = nullptr;
 	void ahead_end()
 	{
-		if (!two)
+		if (!two_now)
 			return;
 		ev_ahead = ctx().next_event();
 		FH_HIP(hipEventRecord(ev_ahead, ctx().la_panel));
@@ -98,8 +112,10 @@ template <typename S> struct DeviceBackend {
 	}
 	void ahead_join()
 	{
-		if (two && ev_ahead)
+		if (two_now && ev_ahead) {
 			stream_wait(caller, ev_ahead); // the broadcast of the new panel is ordered behind it
+			ev_ahead = nullptr;
+		}
 	}
 	void run_end()
 	{

@@ -30,7 +30,7 @@ namespace fh {
 //   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)
 //                                                        -- collective on the backend's memory space; may be
 //                                                           asynchronous (slot = 0 / 1, at most one in flight each)
-//   void step_begin() / void rest_begin() / rest_end() / ahead_begin() / ahead_end() / ahead_join()
+//   void step_begin(long local_trailing_entries) / void rest_begin() / rest_end() / ahead_begin() / ahead_end() / ahead_join()
 //                                                        -- scheduling hooks (no-ops for a synchronous backend): the
 //                                                           device backend runs the "rest" updates of a step on the
 //                                                           bulk stream and the look-ahead part (update + panel of
@@ -133,14 +133,48 @@ template <class B> struct DistLu {
 		for (long k = 0; k < nblk; ++k) {
 			be.bcast_wait((int) (k & 1));
 			be.copy_ints(piv_all + k * nb, piv_of(k), (size_t) fw(k));
-			be.step_begin();
 			const bool ahead = k + 1 < nblk;
 			const int next_owner = ahead ? (int) ((k + 1) % world) : -1;
+			{ // local columns right of block k x remaining rows: how much trailing work this rank has beside the next panel
+				long right = 0;
+				for (long b = rank; b < nblk_all; b += world)
+					if (b > k)
+						right += (b * nb + nb <= n) ? nb : n - b * nb;
+				be.step_begin((m - k * nb) * right); // entries of the trailing matrix this rank updates in this step
+			}
+			// The rest of update k on ALL the local block columns at once: the columns of the blocks left of the panel are one
+			// contiguous range of A_local (interchanges only), those of the blocks right of it another one (interchanges, ONE
+			// triangular solve, ONE product) -- three operations per step instead of three per owned block column: fewer,
+			// larger launches (the host was the bottleneck of a rank with many block columns, profiles/r02_dist_overlap.txt),
+			// and the product runs on the large tiles.  Per column the arithmetic is the same as block by block.
 			auto rest = [&]() {
 				be.rest_begin();
-				for (long b = rank; b < nblk_all; b += world)
-					if (!(ahead && b == k + 1))
-						update(k, b);
+				const bool skip_next = ahead && rank == next_owner; // block k + 1 is brought up to date by the look-ahead part
+				long cl = 0, cr = 0, ctot = 0;			    // local columns: left of block k / up to the right range / all
+				for (long b = rank; b < nblk_all; b += world) {
+					const long bw = (b * nb + nb <= n) ? nb : n - b * nb;
+					if (b < k)
+						cl += bw;
+					if (b <= k || (skip_next && b == k + 1))
+						cr += bw;
+					ctot += bw;
+				}
+				const long j0 = k * nb, w = fw(k), rows = m - j0;
+				const int *piv = piv_of(k);
+				View Lp{panel_of(k), rows, w, 1, rows};
+				if (cl > 0)
+					be.laswp(view(j0, 0, rows, cl), piv, (int) w); // factor.rs:127-185
+				if (k % world == rank)
+					update(k, k); // (only a block wider than its factored part has anything left to do)
+				if (ctot > cr) {
+					View Bk = view(j0, cr, rows, ctot - cr);
+					be.laswp(Bk, piv, (int) w);
+					View top{Bk.p, w, Bk.ncols, Bk.rs, Bk.cs};
+					be.trsm_unit_lower(View{Lp.p, w, w, Lp.rs, Lp.cs}, top); // A01 <- L00^-1 A01 (factor.rs:98-107)
+					if (rows > w)
+						be.gemm_sub(View{Bk.p + w * Bk.rs, rows - w, Bk.ncols, Bk.rs, Bk.cs},
+							    View{Lp.p + w * Lp.rs, rows - w, w, Lp.rs, Lp.cs}, top); // A11 -= A10 A01 (:108-117)
+				}
 				be.rest_end();
 			};
 			if (ahead && rank == next_owner) {

@@ -75,7 +75,9 @@ def run(tmp_path, what, n, nb, use_async):
     port = 33000 + (os.getpid() + n + nb) % 2000
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # FAER_HIP_DIST_TWO_MIN=0: every step of the LU on the bulk + panel streams (by default steps with little trailing
+        # work run on the caller's stream alone), so the two-stream schedule is what the two ranks exercise
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FAER_HIP_DIST_TWO_MIN="0")
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT, what, str(n), str(nb), str(tmp_path), "1" if use_async else "0"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]

@@ -385,11 +385,15 @@ def test_full_piv_lu_singular_trailing_block_and_size_property():
 
 # -------------------------------------------------------------------------------------------- distributed lu
 @pytest.mark.gpu
+@pytest.mark.parametrize("two_min", ["0", None])
 @pytest.mark.parametrize("m,n,nb", [(512, 512, 64), (1000, 1000, 128), (700, 500, 96), (300, 420, 64)])
-def test_dist_lu_device_backend_single_rank(oracle, m, n, nb):
+def test_dist_lu_device_backend_single_rank(oracle, m, n, nb, two_min, monkeypatch):
     """the device backend of the distributed LU (csrc/dist.hip) on ONE rank (the broadcast is the identity):
     same pivots as the oracle, factors within tolerance, exactly one broadcast per block column.  The multi-rank
-    control flow of the same template is covered on CPU by tests/test_dist_lu.py (gloo, world_size 2 and 3)."""
+    control flow of the same template is covered on CPU by tests/test_dist_lu.py (gloo, world_size 2 and 3).
+    two_min = "0": every step on the bulk + panel streams (by default steps with little trailing work run on one stream)"""
+    if two_min is not None:
+        monkeypatch.setenv("FAER_HIP_DIST_TWO_MIN", two_min)
     F = init_gpu()
     rng = np.random.default_rng(21)
     a = rnd(rng, m, n)
