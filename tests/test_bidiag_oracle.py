@@ -49,3 +49,23 @@ def test_oracle_bidiag_reference_property(m, n, bl, br, dtype):
     sv_a = np.linalg.svd(a.astype(np.float64), compute_uv=False)
     sv_b = np.linalg.svd(b.astype(np.float64), compute_uv=False)
     assert np.abs(sv_a - sv_b).max() <= 64 * eps * scale
+
+
+def test_oracle_bidiag_edge_cases():
+    # a zero matrix: every reflector is the identity (tau = +inf, householder.rs:70-77), the output is zero
+    uv, hl, hr = np.zeros((5, 3), order="F"), np.zeros((2, 3), order="F"), np.zeros((2, 2), order="F")
+    O.bidiag_in_place(uv, hl, hr)
+    assert np.all(uv == 0) and np.isinf(hl[0, 0]) and np.isinf(hr[0, 0])
+    # an already upper bidiagonal matrix keeps its entries up to sign
+    n = 6
+    b = np.diag(np.arange(1.0, n + 1)) + np.diag(np.full(n - 1, 0.5), 1)
+    uv, hl, hr = np.array(b, order="F"), np.zeros((2, n), order="F"), np.zeros((2, n - 1), order="F")
+    O.bidiag_in_place(uv, hl, hr)
+    assert np.allclose(np.abs(bidiag_of(uv)), np.abs(b))
+    # a wide matrix is processed over min(m, n) columns; the last row is left normalised (bidiag.rs:173-175 breaks before
+    # the right reflector of the last step): documented behaviour of the reference, reproduced literally
+    rng = np.random.default_rng(2)
+    a = np.asarray(rng.standard_normal((3, 7)), order="F")
+    uv, hl, hr = a.copy(order="F"), np.zeros((1, 3), order="F"), np.zeros((1, 2), order="F")
+    O.bidiag_in_place(uv, hl, hr)
+    assert abs(np.linalg.norm(uv[2, 3:]) - 1.0) <= 1e-14
