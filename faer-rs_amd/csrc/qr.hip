@@ -2164,7 +2164,7 @@ __global__ void copy_guard_kernel(T *d, idx_t drs, idx_t dcs, const T *s, idx_t 
 		atomicExch(flag, 1);
 }
 
-template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold)
+template <typename T> static long geqrf_classic(MatV<T> A, MatV<T> H, idx_t blocking_threshold)
 {
 	(void) blocking_threshold; // the GPU recursion always blocks; leaves are 8 columns wide
 	const idx_t m = A.nrows, n = A.ncols;
@@ -2249,6 +2249,56 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 		FH_HIP(hipStreamSynchronize(s)); // taus scratch is released on return
 	}
 	return rank;
+}
+
+// tsqr.hip: the one-pass path for tall fp32 matrices
+bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs);
+idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason);
+
+template <typename T> __global__ void qr_taus_from_blocks_kernel(const T *H, idx_t hrs, idx_t hcs, int bs, int count, T *taus)
+{
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < count)
+		taus[j] = H[(idx_t) (j % bs) * hrs + (idx_t) j * hcs];
+}
+
+// Tall fp32 matrices take the one-pass path (tsqr.hip).  It stops in front of the first 64-column panel it cannot
+// take (ill conditioned, a column failing the reference's rank test, ...) with every earlier reflector applied to
+// everything on its right -- the state qr_in_place_blocked (factor.rs:137-256) is in at that column -- so the classic
+// path simply factors the remaining submatrix and the T blocks are rebuilt from V and the taus.
+template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold)
+{
+	if constexpr (std::is_same<T, float>::value) {
+		const idx_t m = A.nrows, n = A.ncols, bs = H.nrows;
+		const idx_t size = m < n ? m : n;
+		const bool ref_rejects_all = (double) Lim<T>::eps * 16.0 * (double) m >= 1.0;
+		if (size > 0 && bs > 0 && H.ncols == size && !ref_rejects_all && tsqr_applicable(m, n, A.rs, A.cs, bs)) {
+			Scratch taus((size_t) size * sizeof(T));
+			int reason = 0;
+			const idx_t done = tsqr_factor(A, H, taus.as<T>(), &reason);
+			if (done == size)
+				return (long) size;
+			static const bool verbose = getenv("FAER_HIP_VERBOSE") != nullptr;
+			if (verbose)
+				fprintf(stderr, "faer_hip: qr: one-pass path stopped at column %ld (reason %d); classic path for the rest\n", (long) done, reason);
+			MatV<T> B = A.sub(done, done, m - done, n - done);
+			const idx_t size2 = size - done;
+			Scratch h2((size_t) bs * (size_t) size2 * sizeof(T));
+			MatV<T> H2{h2.as<T>(), bs, size2, 1, bs};
+			fill_dev<T>(H2, DST_FULL, (T) 0);
+			const long r2 = geqrf_classic<T>(B, H2, blocking_threshold);
+			if (r2 > 0) {
+				hipLaunchKernelGGL(qr_taus_from_blocks_kernel<T>, dim3((unsigned) ((r2 + 255) / 256)), dim3(256), 0, ctx().stream, H2.p, H2.rs, H2.cs,
+						   (int) bs, (int) r2, taus.as<T>() + done);
+				FH_HIP(hipGetLastError());
+			}
+			const long rank = (long) done + r2;
+			qr_t_blocks_from_taus<T>(A, H, rank, taus.as<T>());
+			FH_HIP(hipStreamSynchronize(ctx().stream)); // scratch is released on return
+			return rank;
+		}
+	}
+	return geqrf_classic<T>(A, H, blocking_threshold);
 }
 
 template long geqrf_dev<double>(MatV<double>, MatV<double>, idx_t);

@@ -134,6 +134,121 @@ def test_qr_tall_skinny_property():
     assert ((torch.triu(VtV, 1) - torch.triu(T, 1)).abs().max()).item() < 1e-2
 
 
+def thin_q(F, dqr, dh, m, n):
+    """the first n columns of Q (fp64 on the host)"""
+    q = to_dev(np.eye(m, n, dtype=np.float32))
+    F.apply_block_householder_sequence_on_the_left_in_place(dqr, dh, q, transpose=False)
+    return to_host(q).astype(np.float64)
+
+
+def _tall_vs_oracle(oracle, F, a, bs, lead=None):
+    """one-pass path (csrc/tsqr.hip) against the oracle's Householder QR: R within 64 eps max|R|, V within 16 eps
+    (its entries are O(1 / sqrt(m))), T within 64 eps max|T| -- the differences measured on the CPU prototype
+    (tools/proto_tsqr.py) are 1-4 eps; the generic bound 64 max(m, n) eps would be ~1 here and say nothing"""
+    import torch
+
+    m, n = a.shape
+    if lead is None:
+        dqr = to_dev(a)
+    else:  # a view with a leading dimension that is not a multiple of 4 (scalar loads in every kernel)
+        buf = torch.zeros((n, lead), dtype=torch.float32, device="cuda")
+        buf[:, :m] = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+        dqr = buf.t()[:m, :]
+    dh = to_dev(np.zeros((bs, n), dtype=np.float32))
+    assert F.qr_factor_in_place(dqr, dh) == n
+    qr, h = to_host(dqr), to_host(dh)
+    ref, rh = a.copy(order="F"), np.zeros((bs, n), dtype=np.float32, order="F")
+    assert oracle.qr_in_place(ref, rh) == n
+    e = float(np.finfo(np.float32).eps)
+    up = np.triu(np.ones((m, n), bool))
+    d = np.abs(qr.astype(np.float64) - ref)
+    assert d[up].max() <= 64 * e * np.abs(ref[up]).max(), ("R", d[up].max() / e / np.abs(ref[up]).max())
+    assert d[~up].max() <= 16 * e, ("V", d[~up].max() / e)
+    tu = np.zeros((bs, n), bool)
+    for j0 in range(0, n, bs):
+        w = min(bs, n - j0)
+        tu[:w, j0:j0 + w] = np.triu(np.ones((w, w), bool))
+    assert np.isfinite(h).all()
+    dt = np.abs(h.astype(np.float64) - rh)[tu].max()
+    assert dt <= 64 * e * np.abs(rh[tu]).max(), ("T", dt / e / np.abs(rh[tu]).max())
+    return qr, h
+
+
+@pytest.mark.parametrize("m,n,bs", [(20000, 64, 64), (20000, 64, 32), (16384, 130, 1), (40000, 100, None), (30000, 200, 16),
+                                    (65536, 256, None), (50000, 256, 256), (24000, 192, 192), (200000, 64, None), (16500, 17, 1)])
+def test_qr_tall_one_pass_vs_oracle(oracle, m, n, bs):
+    """qr/no_pivoting/factor.rs:137-256 on the one-pass path: whole and ragged panels, blocks of Q_coeff narrower than,
+    equal to and wider than a 64-column panel (the wider ones need the cross-panel blocks of T)"""
+    F = init_gpu()
+    rng = np.random.default_rng(m + n)
+    a = rnd(rng, m, n, np.float32)
+    if bs is None:
+        bs = F.qr_recommended_block_size(m, n, np.float32)
+        assert bs == oracle.qr_recommended_block_size(m, n, np.float32)
+    _tall_vs_oracle(oracle, F, a, bs)
+
+
+def test_qr_tall_one_pass_unaligned_leading_dimension(oracle):
+    F = init_gpu()
+    rng = np.random.default_rng(77)
+    a = rnd(rng, 20001, 70, np.float32)
+    _tall_vs_oracle(oracle, F, a, 64, lead=20003)
+
+
+@pytest.mark.parametrize("m", [500000])
+def test_qr_tall_config_q_vs_oracle(oracle, m):
+    """BASELINE config Q at the height the reference really factors (see test_qr_fp32_reference_rank_test_limit): the whole
+    5e5 x 256 factorization against the oracle (about a minute of CPU)"""
+    F = init_gpu()
+    rng = np.random.default_rng(m)
+    a = rnd(rng, m, 256, np.float32)
+    _tall_vs_oracle(oracle, F, a, 256)
+
+
+def test_qr_tall_falls_back_per_panel(oracle):
+    """panels the one-pass path must refuse (tsqr.hip): an ill-conditioned panel in the middle (two nearly equal columns),
+    a column that is zero below the diagonal (the reference's tau = +inf) and a rank-deficient matrix; the classic path
+    takes over from that panel and the result is the oracle's"""
+    F = init_gpu()
+    rng = np.random.default_rng(5)
+    m, n = 20000, 192
+    e = float(np.finfo(np.float32).eps)
+    # (1) columns 70 and 71 agree to 1e-5: cond of the second panel ~ 1e5
+    a = rnd(rng, m, n, np.float32)
+    a[:, 71] = a[:, 70] + 1e-5 * a[:, 71]
+    dqr, dh = to_dev(a), to_dev(np.zeros((64, n), dtype=np.float32))
+    assert F.qr_factor_in_place(dqr, dh) == n
+    q = thin_q(F, dqr, dh, m, n)
+    R = np.triu(to_host(dqr)[:n]).astype(np.float64)
+    assert np.abs(q @ R - a).max() <= 64 * np.sqrt(m) * e * np.abs(a).max()
+    assert np.abs(q.T @ q - np.eye(n)).max() <= 64 * np.sqrt(m) * e
+    ref, rh = a.copy(order="F"), np.zeros((64, n), dtype=np.float32, order="F")
+    assert oracle.qr_in_place(ref, rh) == n
+    assert np.abs(np.abs(np.diag(R)) - np.abs(np.diag(ref[:n]))).max() <= 1e-3 * np.abs(np.diag(ref[:n])).max()
+    # (2) the first panel lives in the top 64 rows only (its reflectors leave the rows below alone), the second one is
+    #     upper triangular from row 64 down: every tail of the second panel is exactly zero
+    b = np.zeros((m, 128), dtype=np.float32, order="F")
+    b[:64, :64] = 10 * np.eye(64, dtype=np.float32) + 0.1 * rnd(rng, 64, 64, np.float32)
+    b[:64, 64:] = rnd(rng, 64, 64, np.float32)
+    b[64:128, 64:] = np.triu(rnd(rng, 64, 64, np.float32)) + 3 * np.eye(64, dtype=np.float32)
+    ref, rh = b.copy(order="F"), np.zeros((64, 128), dtype=np.float32, order="F")
+    rk = oracle.qr_in_place(ref, rh)
+    dqr, dh = to_dev(b), to_dev(np.zeros((64, 128), dtype=np.float32))
+    assert F.qr_factor_in_place(dqr, dh) == rk
+    h = to_host(dh)
+    assert np.array_equal(np.isinf(h), np.isinf(rh))
+    assert np.abs(to_host(dqr) - ref).max() <= 64 * np.sqrt(m) * e * np.abs(ref).max()
+    # (3) rank 100 of 192 columns
+    c = (rnd(rng, m, 100, np.float64) @ rnd(rng, 100, n, np.float64)).astype(np.float32)
+    ref, rh = c.copy(order="F"), np.zeros((64, n), dtype=np.float32, order="F")
+    rk = oracle.qr_in_place(ref, rh)
+    dqr, dh = to_dev(c), to_dev(np.zeros((64, n), dtype=np.float32))
+    got = F.qr_factor_in_place(dqr, dh)
+    assert 100 <= got <= n and abs(got - rk) <= 2
+    q = thin_q(F, dqr, dh, m, n)
+    assert np.abs(q @ np.triu(to_host(dqr)[:n]).astype(np.float64) - c).max() <= 256 * np.sqrt(m) * e * np.abs(c).max()
+
+
 def test_qr_1e6_rows_fp32_matches_reference_semantics():
     """BASELINE config Q literally (1e6 x 256 fp32): the reference's rank test yields rank 0"""
     import torch
