@@ -200,62 +200,73 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(con
 	}
 }
 
-// fixed-order sums of the per-workgroup partials: G (4096 entries), C (64 x tp -> C[a * ldc + coff + b]), column squares
+// Sums of the per-workgroup partials in a FIXED order, two levels: workgroup (x, g) adds the partials g, g + TQ_NG, ... of
+// 256 entries into slice g of the output; the consumers (panel / y kernels) add the TQ_NG slices, again in a fixed order.
+// One level (every entry summed over 512 partials by one thread) took 40-120 us per launch: 64 workgroups, 512 dependent
+// strided loads each.
+constexpr int TQ_NG = 8;
 __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const float *Cp, const float *Sp, int nb, int tp, int want_g,
 							 int want_sq, double *G, double *C, int ldc, int coff, double *S, const int *stat)
 {
 	if (stat[0])
 		return;
 	const int e = blockIdx.x * 256 + threadIdx.x;
+	const int g = blockIdx.y;
 	const int ng = want_g ? 4096 : 0, nc = 64 * tp, ns = want_sq ? 256 : 0;
 	if (e < ng) {
-		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-		int b = 0;
-		for (; b + 4 <= nb; b += 4) {
+		double s0 = 0, s1 = 0;
+		int b = g;
+		for (; b + TQ_NG < nb; b += 2 * TQ_NG) {
 			s0 += Gp[(long) b * 4096 + e];
-			s1 += Gp[(long) (b + 1) * 4096 + e];
-			s2 += Gp[(long) (b + 2) * 4096 + e];
-			s3 += Gp[(long) (b + 3) * 4096 + e];
+			s1 += Gp[(long) (b + TQ_NG) * 4096 + e];
 		}
-		for (; b < nb; ++b)
+		if (b < nb)
 			s0 += Gp[(long) b * 4096 + e];
-		G[e] = (s0 + s1) + (s2 + s3);
+		G[(long) g * 4096 + e] = s0 + s1;
 	} else if (e < ng + nc) {
 		const int idx = e - ng;
-		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-		int b = 0;
-		for (; b + 4 <= nb; b += 4) {
+		double s0 = 0, s1 = 0;
+		int b = g;
+		for (; b + TQ_NG < nb; b += 2 * TQ_NG) {
 			s0 += (double) Cp[(long) b * nc + idx];
-			s1 += (double) Cp[(long) (b + 1) * nc + idx];
-			s2 += (double) Cp[(long) (b + 2) * nc + idx];
-			s3 += (double) Cp[(long) (b + 3) * nc + idx];
+			s1 += (double) Cp[(long) (b + TQ_NG) * nc + idx];
 		}
-		for (; b < nb; ++b)
+		if (b < nb)
 			s0 += (double) Cp[(long) b * nc + idx];
 		const int arow = idx / tp, bcol = idx - arow * tp;
-		C[(long) arow * ldc + coff + bcol] = (s0 + s1) + (s2 + s3);
+		C[((long) g * 64 + arow) * ldc + coff + bcol] = s0 + s1;
 	} else if (e < ng + nc + ns) {
 		const int idx = e - ng - nc;
-		double s = 0;
-		for (int b = 0; b < nb; ++b)
-			s += (double) Sp[(long) b * 256 + idx];
-		S[idx] = s;
+		double s0 = 0;
+		for (int b = g; b < nb; b += TQ_NG)
+			s0 += (double) Sp[(long) b * 256 + idx];
+		S[(long) g * 256 + idx] = s0;
 	}
 }
 
 // ------------------------------------------------------------------------------------------------
-// panel: everything 64 x 64, fp64, one workgroup
+// panel: everything 64 x 64, fp64, one workgroup of 384 threads.
+//
+// Two right-looking eliminations of 64 steps each on REGISTER-resident rows, one barrier per step (the column / row of
+// the step travels through a double-buffered LDS line), the step loop unrolled so that every register index is static:
+//   A. Cholesky of G extended by the rows of A1 and of the identity: the same column operations turn G into L
+//      (R~ = L^T), A1 into Q1~ = A1 R~^-1 and I into R~^-1 -- no separate triangular solves.
+//   B. the sign-choosing LU of I - Q1~ S on its linear part W (column j of I - W S is e_j - s_j W_j), extended by identity
+//      COLUMNS (row operations applied to I give V1^-1) and identity ROWS (their multipliers are the rows of U^-1).
+// The first version of this kernel ran the same algebra as barrier-separated loops over LDS-resident matrices plus three
+// column-parallel substitutions on 64 threads: 314 us per panel, 1.25 of the 3.4 ms of a 5e5 x 256 factorization.
 // ------------------------------------------------------------------------------------------------
 struct TqPanelArgs {
 	float *A;
 	long ld;
 	int m, r0, c0, w, n;
-	const double *G;   // reduced Gram matrix, row major 64 x 64 (w x w valid)
-	const double *S;   // column squares of the first launch (checked when check_range != 0): [0, 64) panel, [64, ..) trailing
-	int check_range, range_cols; // number of staged trailing columns covered by S
+	const double *G;   // TQ_NG slices of the Gram matrix, row major 64 x 64 (w x w valid)
+	const double *S;   // TQ_NG slices of the column squares of the first launch: [0, 64) panel, [64, ..) trailing
+	int check_range, range_cols;
 	double *abv;	   // per global column: sum of squares of the R entries above the current block row
-	double *N1, *N2;   // out: R^-T, R^-1 U^-1 V1^-1 (row major 64 x 64)
+	double *N1, *N2, *N3; // out: R^-T, R^-1 U^-1 V1^-1, V1^-1 (row major 64 x 64)
 	float *Mn;	   // out: M = -(U R)^-1, row major 64 x 64
+	double *Md, *Td;   // out: M and T of this panel in fp64 (cross-panel blocks of T)
 	float *H;
 	long hrs, hcs;
 	int bs;
@@ -263,187 +274,252 @@ struct TqPanelArgs {
 	int *stat;
 };
 
-__global__ __launch_bounds__(256) void tq_panel_kernel(const TqPanelArgs a)
+// The two eliminations of tq_panel_kernel.  The step loop stays a real loop (two steps per iteration, one per column
+// parity) and the rows ROTATE left by one position per iteration, so the column being eliminated is always register
+// position 0 and every register index is static: position k of a thread with parity `par` holds column 2 (k + jb) + par.
+// (A fully unrolled 64-step body -- `#pragma unroll` or template recursion -- left x[] in scratch or spilled 1500 registers.)
+static __device__ __forceinline__ int tq_chol_loop(double (&x)[32], double *cbuf, double *Lm, double *Wm, double *Ri, int hr, int par)
 {
-	__shared__ double Gs[64 * TQ_DP]; // G -> L (lower Cholesky factor, R~ = L^T) -> M
-	__shared__ double Ws[64 * TQ_DP]; // A1 -> Q1~ -> [V1 strictly lower | U upper]
+#pragma unroll 1
+	for (int jb = 0; jb < 32; ++jb) {
+#pragma unroll
+		for (int pj = 0; pj < 2; ++pj) {
+			const int J = 2 * jb + pj;
+			double *cb = cbuf + pj * 192;
+			if (par == pj)
+				cb[hr] = x[0];
+			__syncthreads();
+			const double piv = cb[J];
+			if (!(piv > 0.0) || !(piv < 1e300))
+				return TQ_FAIL_CHOL;
+			const double rd = sqrt(piv), rinv = 1.0 / rd;
+			const double mine = cb[hr] * rinv;
+			if (par == pj) {
+				if (hr < 64) {
+					if (hr >= J)
+						Lm[hr * TQ_DP + J] = hr == J ? rd : mine;
+				} else if (hr < 128) {
+					Wm[(hr - 64) * TQ_DP + J] = mine;
+				} else {
+					Ri[(hr - 128) * TQ_DP + J] = mine;
+				}
+			}
+			const double lr = (hr < 64 && hr <= J) ? 0.0 : mine;
+			const int kmax = 32 - jb; // positions k < kmax hold columns <= 63
+#pragma unroll
+			for (int k = 0; k < 32; ++k) {
+				const int c = 2 * (k + jb) + par;
+				if (k < kmax && c > J)
+					x[k] -= lr * (cb[c] * rinv);
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 31; ++k)
+			x[k] = x[k + 1];
+		x[31] = 0.0;
+	}
+	return 0;
+}
+
+static __device__ __forceinline__ int tq_lu_loop(double (&x)[32], double *cbuf, double *rbw, double *rbe, double *Wm, double *UL, double *sgn,
+						 int hr, int par, int w)
+{
+	const bool etype = hr >= 64 && hr < 128; // identity columns of rows 0..63: not rotated (their live columns are c <= J)
+#pragma unroll 1
+	for (int jb = 0; jb < 32; ++jb) {
+#pragma unroll
+		for (int pj = 0; pj < 2; ++pj) {
+			const int J = 2 * jb + pj;
+			double *cb = cbuf + pj * 192, *rw = rbw + pj * 64, *re = rbe + pj * 64;
+			if (par == pj && hr < 64)
+				cb[hr] = x[0]; // W[r][J]
+			if (par == pj && hr >= 128)
+				cb[hr - 64] = x[0]; // z[k][J]
+			if (hr == J) {
+#pragma unroll
+				for (int k = 0; k < 32; ++k)
+					if (k + jb < 32)
+						rw[2 * (k + jb) + par] = x[k];
+			}
+			if (hr == 64 + J) {
+#pragma unroll
+				for (int k = 0; k < 32; ++k)
+					re[2 * k + par] = x[k];
+			}
+			__syncthreads();
+			const double alpha = cb[J];
+			const double sj = alpha >= 0.0 ? -1.0 : 1.0;
+			const double piv = 1.0 + fabs(alpha);
+			if (J < w && !(1.0 - fabs(alpha) >= TQ_TAIL_MIN))
+				return TQ_FAIL_TAIL;
+			const double pinv = 1.0 / piv;
+			double mult;
+			if (hr < 128) {
+				const int r = hr & 63;
+				mult = r > J ? -sj * cb[r] * pinv : 0.0;
+				if (hr < 64 && par == pj && r > J)
+					Wm[r * TQ_DP + J] = mult; // V1[r][J]
+			} else {
+				const int kz = hr - 128;
+				mult = ((kz == J ? 1.0 : 0.0) - sj * cb[64 + kz]) * pinv;
+				if (par == pj && kz <= J)
+					UL[kz * TQ_DP + J] = mult; // U^-1[kz][J]
+			}
+			if (threadIdx.x == 0)
+				sgn[J] = sj;
+			// row J of the linear part is final: keep it (U[J][c] = delta - s_c W[J][c] once every sign is known)
+			if (threadIdx.x < 64 && (int) threadIdx.x >= J)
+				Wm[J * TQ_DP + threadIdx.x] = rw[threadIdx.x];
+			if (etype) {
+#pragma unroll
+				for (int k = 0; k < 32; ++k)
+					if (2 * k <= J)
+						x[k] -= mult * re[2 * k + par];
+			} else {
+				const int kmax = 32 - jb;
+#pragma unroll
+				for (int k = 0; k < 32; ++k) {
+					const int c = 2 * (k + jb) + par;
+					if (k < kmax && c > J)
+						x[k] -= mult * rw[c];
+				}
+			}
+		}
+		if (!etype) {
+#pragma unroll
+			for (int k = 0; k < 31; ++k)
+				x[k] = x[k + 1];
+			x[31] = 0.0;
+		}
+	}
+	return 0;
+}
+
+constexpr int TQ_PT = 384;
+__global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
+{
+	__shared__ double Lm[64 * TQ_DP]; // L (lower Cholesky factor, R~ = L^T), later M
+	__shared__ double Wm[64 * TQ_DP]; // Q1~, later [V1 strictly lower | U upper]
 	__shared__ double Ri[64 * TQ_DP]; // R~^-1 (upper)
 	__shared__ double UL[64 * TQ_DP]; // U^-1 (upper incl. diagonal) | V1^-1 (strictly lower, unit diagonal implied)
+	__shared__ double cbuf[2][192];
+	__shared__ double rbw[2][64], rbe[2][64];
 	__shared__ double sgn[64];
-	__shared__ double dg[64];
 	__shared__ int s_fail;
 	if (a.stat[0])
 		return;
 	const int tid = threadIdx.x, w = a.w;
-	const int ti = tid & 63, tg = tid >> 6;
+	const int hr = tid % 192, par = tid / 192; // (half-)row, column parity: this thread holds columns 2 k + par, k = 0 .. 31
 	if (tid == 0)
 		s_fail = 0;
-	for (int e = tid; e < 4096; e += 256) {
-		const int i = e >> 6, j = e & 63;
-		double g = (i == j) ? 1.0 : 0.0, x = 0.0;
-		if (i < w && j < w) {
-			g = a.G[e];
-			x = (double) a.A[(long) (a.c0 + j) * a.ld + a.r0 + i];
+	auto fail = [&](int why) {
+		if (tid == 0) {
+			a.stat[1] = a.c0;
+			a.stat[2] = why;
+			a.stat[0] = 1;
 		}
-		Gs[i * TQ_DP + j] = g;
-		Ws[i * TQ_DP + j] = x;
-		Ri[i * TQ_DP + j] = 0.0;
-		UL[i * TQ_DP + j] = 0.0;
-	}
-	__syncthreads();
+	};
 	if (a.check_range) {
 		// fp32 products of the C sums underflow / overflow for columns far from unit scale: rms outside [1e-12, 1e12]
 		const double lo = 1e-24 * (double) (a.m - a.r0), hi = 1e24 * (double) (a.m - a.r0);
 		bool bad = false;
-		for (int c = tid; c < 64 + a.range_cols; c += 256) {
+		for (int c = tid; c < 64 + a.range_cols; c += TQ_PT) {
 			if (c < 64 && c >= w)
 				continue;
-			const double s = a.S[c];
-			bad = bad || !(s >= lo && s <= hi);
+			double sq = 0.0;
+			for (int g = 0; g < TQ_NG; ++g)
+				sq += a.S[g * 256 + c];
+			bad = bad || !(sq >= lo && sq <= hi);
 		}
 		if (bad)
 			s_fail = TQ_FAIL_RANGE;
 		__syncthreads();
 		if (s_fail) {
-			if (tid == 0) {
-				a.stat[1] = a.c0;
-				a.stat[2] = s_fail;
-				a.stat[0] = 1;
-			}
+			fail(TQ_FAIL_RANGE);
 			return;
 		}
 	}
-	// ---- Cholesky, right looking, in place in the lower triangle; the roots of the pivots go to dg[] first
-	for (int j = 0; j < 64; ++j) {
-		__syncthreads(); // the update of step j - 1 is complete
-		const double d = Gs[j * TQ_DP + j];
-		if (!(d > 0.0) || !(d < 1e300)) {
-			if (tid == 0) {
-				a.stat[1] = a.c0;
-				a.stat[2] = TQ_FAIL_CHOL;
-				a.stat[0] = 1;
+	// ---- A. rows 0..63: G (identity beyond w), 64..127: A1 (zero beyond w), 128..191: I
+	double x[32];
+#pragma unroll
+	for (int k = 0; k < 32; ++k) {
+		const int c = 2 * k + par;
+		double v;
+		if (hr < 64) {
+			v = hr == c ? 1.0 : 0.0;
+			if (hr < w && c < w) {
+				v = 0.0;
+				for (int g = 0; g < TQ_NG; ++g)
+					v += a.G[g * 4096 + hr * 64 + c];
 			}
+		} else if (hr < 128) {
+			const int r = hr - 64;
+			v = (r < w && c < w) ? (double) a.A[(long) (a.c0 + c) * a.ld + a.r0 + r] : 0.0;
+		} else {
+			v = hr - 128 == c ? 1.0 : 0.0;
+		}
+		x[k] = v;
+	}
+	{
+		const int why = tq_chol_loop(x, cbuf[0], Lm, Wm, Ri, hr, par);
+		if (why) {
+			fail(why);
 			return; // uniform: every thread read the same pivot
 		}
-		const double rd = sqrt(d);
-		if (tid == 0)
-			dg[j] = rd;
-		if (tid > j && tid < 64)
-			Gs[tid * TQ_DP + j] /= rd;
-		__syncthreads();
-		if (ti > j) {
-			const double lij = Gs[ti * TQ_DP + j];
-			for (int c = j + 1 + tg; c <= ti; c += 4)
-				Gs[ti * TQ_DP + c] -= lij * Gs[c * TQ_DP + j];
-		}
 	}
 	__syncthreads();
-	if (tid < 64)
-		Gs[tid * TQ_DP + tid] = dg[tid];
-	__syncthreads();
-	// ---- Ri = R~^-1 (R~[i][l] = Gs[l][i]); thread c solves R~ x = e_c, uniform loops
-	if (tid < 64) {
-		const int c = tid;
-		for (int i = 63; i >= 0; --i) {
-			double acc = (i == c) ? 1.0 : 0.0;
-			for (int l = i + 1; l < 64; ++l)
-				acc -= Gs[l * TQ_DP + i] * Ri[l * TQ_DP + c];
-			Ri[i * TQ_DP + c] = acc / Gs[i * TQ_DP + i];
-		}
+	// ---- B. half-rows 0..63: W (linear part of I - W S), 64..127: identity columns of the same rows, 128..191: identity ROWS
+#pragma unroll
+	for (int k = 0; k < 32; ++k) {
+		const int c = 2 * k + par;
+		x[k] = hr < 64 ? Wm[hr * TQ_DP + c] : (hr < 128 ? (hr - 64 == c ? 1.0 : 0.0) : 0.0);
 	}
+	for (int e = tid; e < 64 * TQ_DP; e += TQ_PT)
+		UL[e] = 0.0;
 	__syncthreads();
-	// ---- Q1~ = A1 Ri
 	{
-		double wv[16];
-#pragma unroll
-		for (int u = 0; u < 16; ++u) {
-			const int j = tg + 4 * u;
-			double acc = 0.0;
-			for (int l = 0; l <= j; ++l)
-				acc += Ws[ti * TQ_DP + l] * Ri[l * TQ_DP + j];
-			wv[u] = acc;
-		}
-		__syncthreads();
-#pragma unroll
-		for (int u = 0; u < 16; ++u)
-			Ws[ti * TQ_DP + tg + 4 * u] = wv[u];
-	}
-	__syncthreads();
-	// ---- sign-choosing LU of I - Q1~ S on the linear part (column j of I - W S is e_j - s_j W_j)
-	for (int j = 0; j < 64; ++j) {
-		__syncthreads(); // the update of step j - 1 is complete
-		const double alpha = Ws[j * TQ_DP + j];
-		const double sj = alpha >= 0.0 ? -1.0 : 1.0;
-		const double piv = 1.0 + fabs(alpha);
-		if (j < w && !(1.0 - fabs(alpha) >= TQ_TAIL_MIN)) {
-			if (tid == 0) {
-				a.stat[1] = a.c0;
-				a.stat[2] = TQ_FAIL_TAIL;
-				a.stat[0] = 1;
-			}
+		const int why = tq_lu_loop(x, cbuf[0], rbw[0], rbe[0], Wm, UL, sgn, hr, par, w);
+		if (why) {
+			fail(why);
 			return; // uniform
 		}
-		if (tid == 0)
-			sgn[j] = sj;
-		if (tid > j && tid < 64)
-			Ws[tid * TQ_DP + j] = -sj * Ws[tid * TQ_DP + j] / piv;
-		__syncthreads();
-		if (ti > j) {
-			const double lij = Ws[ti * TQ_DP + j];
-			for (int c = j + 1 + tg; c < 64; c += 4)
-				Ws[ti * TQ_DP + c] -= lij * Ws[j * TQ_DP + c];
+	}
+	__syncthreads();
+	// U = triu(I - W S) from the rows of W kept by the loop, V1^-1 from the identity columns
+	for (int e = tid; e < 4096; e += TQ_PT) {
+		const int i = e >> 6, c = e & 63;
+		if (c >= i)
+			Wm[i * TQ_DP + c] = (i == c ? 1.0 : 0.0) - sgn[c] * Wm[i * TQ_DP + c];
+	}
+	if (hr >= 64 && hr < 128) {
+#pragma unroll
+		for (int k = 0; k < 32; ++k) {
+			const int c = 2 * k + par;
+			if (c < hr - 64)
+				UL[(hr - 64) * TQ_DP + c] = x[k];
 		}
 	}
 	__syncthreads();
-	for (int e = tid; e < 4096; e += 256) {
-		const int i = e >> 6, j = e & 63;
-		if (j >= i)
-			Ws[i * TQ_DP + j] = (i == j ? 1.0 : 0.0) - sgn[j] * Ws[i * TQ_DP + j];
-	}
-	__syncthreads();
-	// ---- wave 0: U^-1 (upper part of UL); wave 1: V1^-1 (strictly lower part of UL); wave 2: the reference's rank test;
-	//      wave 3: condition estimate.  Uniform loops, predicated reads: the two substitutions never touch each other's half.
-	if (tg == 0) {
-		const int c = ti;
-		for (int i = 63; i >= 0; --i) {
-			double acc = (i == c) ? 1.0 : 0.0;
-			for (int l = i + 1; l < 64; ++l) {
-				const double x = l <= c ? UL[l * TQ_DP + c] : 0.0;
-				acc -= Ws[i * TQ_DP + l] * x;
-			}
-			if (i <= c)
-				UL[i * TQ_DP + c] = acc / Ws[i * TQ_DP + i];
-		}
-	} else if (tg == 1) {
-		// column c of V1^-1: x_c = 1 (implied), x_i = -V1[i][c] - sum_{c < l < i} V1[i][l] x_l
-		const int c = ti;
-		for (int i = 1; i < 64; ++i) {
-			double acc = -Ws[i * TQ_DP + c];
-			for (int l = 1; l < i; ++l) {
-				const double x = l > c ? UL[l * TQ_DP + c] : 0.0;
-				acc -= Ws[i * TQ_DP + l] * x;
-			}
-			if (i > c)
-				UL[i * TQ_DP + c] = acc;
-		}
-	} else if (tg == 2) {
+	// ---- the reference's rank test (wave 0), condition estimate (wave 1)
+	if (tid < 64) {
 		// factor.rs:52-64: |R_jj| > eps * 16 * (m - row) * hypot(|R_jj|, |R[0 .. j, j]|)
-		const int j = ti;
+		const int j = tid;
 		if (j < w) {
 			double ab = a.abv[a.c0 + j];
 			for (int l = 0; l < j; ++l)
-				ab += Gs[j * TQ_DP + l] * Gs[j * TQ_DP + l];
-			const double rjj = Gs[j * TQ_DP + j];
+				ab += Lm[j * TQ_DP + l] * Lm[j * TQ_DP + l];
+			const double rjj = Lm[j * TQ_DP + j];
 			const double full = sqrt(rjj * rjj + ab);
 			const double thr = (double) 1.1920928955078125e-07f * 16.0 * (double) (a.m - a.c0 - j) * full;
 			if (!(rjj > thr))
 				atomicMax(&s_fail, (int) TQ_FAIL_RANK);
 		}
-	} else {
+	} else if (tid < 128) {
+		const int ti = tid - 64;
 		double f1 = 0.0, f2 = 0.0;
 		for (int l = 0; l < 64; ++l) {
-			f1 += l <= ti ? Gs[ti * TQ_DP + l] * Gs[ti * TQ_DP + l] : 0.0;
-			f2 += Ri[l * TQ_DP + ti] * Ri[l * TQ_DP + ti];
+			f1 += l <= ti ? Lm[ti * TQ_DP + l] * Lm[ti * TQ_DP + l] : 0.0;
+			f2 += l <= ti ? Ri[l * TQ_DP + ti] * Ri[l * TQ_DP + ti] : 0.0;
 		}
 		for (int o = 32; o > 0; o >>= 1) {
 			f1 += __shfl_xor(f1, o);
@@ -454,59 +530,53 @@ __global__ __launch_bounds__(256) void tq_panel_kernel(const TqPanelArgs a)
 	}
 	__syncthreads();
 	if (s_fail) {
-		if (tid == 0) {
-			a.stat[1] = a.c0;
-			a.stat[2] = s_fail;
-			a.stat[0] = 1;
-		}
+		fail(s_fail);
 		return;
 	}
-	// ---- outputs that read L: the top block of A (R = S R~ on and above the diagonal, V1 below), N1 = R^-T
-	for (int e = tid; e < 4096; e += 256) {
+	// ---- outputs that read L: the top block of A (R = S R~ on and above the diagonal, V1 below), N1 = R^-T, N3 = V1^-1
+	for (int e = tid; e < 4096; e += TQ_PT) {
 		const int i = e >> 6, j = e & 63;
 		if (i < w && j < w)
-			a.A[(long) (a.c0 + j) * a.ld + a.r0 + i] = (float) (i <= j ? sgn[i] * Gs[j * TQ_DP + i] : Ws[i * TQ_DP + j]);
-		// R^-1 = Ri S  =>  N1[i][l] = R^-1[l][i] = Ri[l][i] * s_i
-		a.N1[e] = Ri[j * TQ_DP + i] * sgn[i];
+			a.A[(long) (a.c0 + j) * a.ld + a.r0 + i] = (float) (i <= j ? sgn[i] * Lm[j * TQ_DP + i] : Wm[i * TQ_DP + j]);
+		// R^-1 = R~^-1 S  =>  N1[i][l] = R^-1[l][i] = Ri[l][i] * s_i  (Ri holds only its upper triangle)
+		a.N1[e] = j <= i ? Ri[j * TQ_DP + i] * sgn[i] : 0.0;
+		a.N3[e] = i == j ? 1.0 : (j < i ? UL[i * TQ_DP + j] : 0.0);
 	}
-	// ---- M = -Ri S U^-1 (upper) into registers, then into Gs
-	{
-		double mv[16];
-#pragma unroll
-		for (int u = 0; u < 16; ++u) {
-			const int j = tg + 4 * u, k = ti;
-			double acc = 0.0;
-			for (int l = k; l <= j; ++l)
-				acc += Ri[k * TQ_DP + l] * sgn[l] * UL[l * TQ_DP + j];
-			mv[u] = k <= j ? -acc : 0.0;
-		}
-		__syncthreads(); // all reads of L are done
-#pragma unroll
-		for (int u = 0; u < 16; ++u) {
-			const int j = tg + 4 * u;
-			Gs[ti * TQ_DP + j] = mv[u];
-			a.Mn[ti * 64 + j] = (float) mv[u];
-		}
+	__syncthreads(); // all reads of L are done
+	// ---- M = -R~^-1 S U^-1 (upper) into Lm
+	for (int e = tid; e < 4096; e += TQ_PT) {
+		const int k = e >> 6, j = e & 63;
+		double acc = 0.0;
+		for (int l = k; l <= j; ++l)
+			acc += Ri[k * TQ_DP + l] * sgn[l] * UL[l * TQ_DP + j];
+		const double mv = k <= j ? -acc : 0.0;
+		Lm[k * TQ_DP + j] = mv;
+		a.Mn[e] = (float) mv;
+		a.Md[e] = mv;
 	}
 	__syncthreads();
 	// ---- N2 = -M V1^-1,  T = triu(V1^T U^-1)
-	for (int u = 0; u < 16; ++u) {
-		const int j = tg + 4 * u, k = ti;
-		// V1^-1[l][j]: 1 on the diagonal, UL[l][j] for l > j, 0 above
-		double acc = Gs[k * TQ_DP + j];
-		for (int l = j + 1; l < 64; ++l)
-			acc += Gs[k * TQ_DP + l] * UL[l * TQ_DP + j];
-		a.N2[k * 64 + j] = -acc;
-		if (k <= j && j < w) {
-			double tt = UL[k * TQ_DP + j]; // l = k term: V1[k][k] = 1
+	for (int e = tid; e < 4096; e += TQ_PT) {
+		const int k = e >> 6, j = e & 63;
+		// V1^-1[l][j]: 1 on the diagonal, UL[l][j] for l > j, 0 above; M upper: l >= k
+		double acc = k <= j ? Lm[k * TQ_DP + j] : 0.0;
+		for (int l = (k > j + 1 ? k : j + 1); l < 64; ++l)
+			acc += Lm[k * TQ_DP + l] * UL[l * TQ_DP + j];
+		a.N2[e] = -acc;
+		double tt = 0.0;
+		if (k <= j) {
+			tt = UL[k * TQ_DP + j]; // l = k term: V1[k][k] = 1
 			for (int l = k + 1; l <= j; ++l)
-				tt += Ws[l * TQ_DP + k] * UL[l * TQ_DP + j];
-			const int gi = a.c0 + k, gj = a.c0 + j;
-			if (gi / a.bs == gj / a.bs)
-				a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) tt;
-			if (k == j)
-				a.taus[gj] = (float) tt;
+				tt += Wm[l * TQ_DP + k] * UL[l * TQ_DP + j];
+			if (j < w) {
+				const int gi = a.c0 + k, gj = a.c0 + j;
+				if (gi / a.bs == gj / a.bs)
+					a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) tt;
+				if (k == j)
+					a.taus[gj] = (float) tt;
+			}
 		}
+		a.Td[e] = tt;
 	}
 }
 
@@ -517,32 +587,40 @@ struct TqYArgs {
 	float *A;
 	long ld;
 	int r0, cx, w, t;
-	const double *C; // reduced, row major 64 x ldc
+	const double *C; // TQ_NG slices, each row major 64 x ldc
 	int ldc;
-	const double *N1, *N2;
+	const double *N1, *N2, *N3;
 	double *abv;
 	float *Yn; // out: -Y, row major 64 x typ
 	int typ;
+	double *Z; // out: Z = -V1^-1 (D - X_top) = T^-H V^H X, row major 64 x ldz, column index = GLOBAL column
+	int ldz;
 	const int *stat;
 };
 
 __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 {
-	__shared__ double n1[64 * TQ_DP], n2[64 * TQ_DP];
+	__shared__ double n1[64 * TQ_DP], n2[64 * TQ_DP], n3[64 * TQ_DP];
 	__shared__ double v[64 * 17];
+	__shared__ double sred[256];
 	if (a.stat[0])
 		return;
 	const int tid = threadIdx.x;
 	for (int e = tid; e < 4096; e += 256) {
 		n1[(e >> 6) * TQ_DP + (e & 63)] = a.N1[e];
 		n2[(e >> 6) * TQ_DP + (e & 63)] = a.N2[e];
+		n3[(e >> 6) * TQ_DP + (e & 63)] = a.N3[e];
 	}
 	const int bl = tid & 15, ig = tid >> 4; // column, row group: rows ig, ig + 16, ig + 32, ig + 48
 	const int b = blockIdx.x * 16 + bl;
 	const bool colok = b < a.t;
 	for (int u = 0; u < 4; ++u) {
 		const int i = ig + 16 * u;
-		v[i * 17 + bl] = colok ? a.C[(long) i * a.ldc + b] : 0.0;
+		double c = 0.0;
+		if (colok)
+			for (int g = 0; g < TQ_NG; ++g)
+				c += a.C[((long) g * 64 + i) * a.ldc + b];
+		v[i * 17 + bl] = c;
 	}
 	__syncthreads();
 	double d[4], e4[4];
@@ -566,9 +644,7 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 	for (int u = 0; u < 4; ++u)
 		v[(ig + 16 * u) * 17 + bl] = e4[u];
 	// column norms of the R rows just produced (rank test of the later panels)
-	double ss = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
-	__shared__ double sred[256];
-	sred[tid] = ss;
+	sred[tid] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
 	__syncthreads();
 	if (ig == 0 && colok) {
 		double s = 0.0;
@@ -579,11 +655,15 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 #pragma unroll
 	for (int u = 0; u < 4; ++u) {
 		const int k = ig + 16 * u;
-		double acc = 0.0;
-		for (int l = 0; l < 64; ++l)
+		double acc = 0.0, zz = 0.0;
+		for (int l = 0; l < 64; ++l) {
 			acc += n2[k * TQ_DP + l] * v[l * 17 + bl];
+			zz += l <= k ? n3[k * TQ_DP + l] * v[l * 17 + bl] : 0.0;
+		}
 		if (b < a.typ)
 			a.Yn[(long) k * a.typ + b] = colok ? (float) -acc : 0.f;
+		if (colok)
+			a.Z[(long) k * a.ldz + a.cx + b] = -zz;
 	}
 }
 
@@ -731,34 +811,157 @@ template <bool VEC> __global__ __launch_bounds__(256, 1) void tq_update_kernel(c
 }
 
 // ------------------------------------------------------------------------------------------------
-// cross-panel blocks of T inside one block of Q_coeff: T[k-panel cols, l-panel cols] = V_k^T V_l, k < l
-// C (reduced) = V_l^T [V_first .. V_{l-1}] over the rows below panel l's top block; the top block's rows are added here
+// cross-panel blocks of T inside one block of Q_coeff, from small matrices only (no pass over V).
+// After the block reflector of panel k has been applied,  V_k^T X' = -T_k Z_k  (T_k + T_k^T = V_k^T V_k), and every
+// later reflector changes it by  -(V_k^T V_j) Z_j = -T_kj Z_j.  With V_l = (A~_l - [R_l; 0]) M_l below row c_l and zero above:
+//   T_kl = V_k^T V_l = ( B_l - V_k[c_k : c_l + w_l, :]^T R[c_k : c_l + w_l, cols of l] ) M_l,
+//   B = V_k^T X over all rows >= c_k:  B := -T_k Z_k after step k,  B[:, cols > l] -= T_kl Z_l[:, cols > l] after step l.
+// (checked against the Gram matrix of the stored V in tools/proto_tsqr.py: 0.1 eps.)  One workgroup per panel k, the
+// blocks l = k + 1, ... of its block of Q_coeff in sequence; 64 x 64 x 64 products on the fp64 matrix cores.
+// The first version computed these blocks as Gram products over V: three more passes, 0.46 of 3.4 ms.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tq_tcross_kernel(const float *A, long ld, int m, int cfirst, int cl, int wl, const double *C, int ldc,
-							 float *H, long hrs, long hcs, int bs, const int *stat)
+struct TqTxArgs {
+	const float *A;
+	long ld;
+	int n, bs;
+	const double *Td, *Md; // per panel 64 x 64
+	const double *Z;       // per panel 64 x ldz
+	int ldz;
+	double *B; // scratch per panel 64 x ldz
+	float *H;
+	long hrs, hcs;
+	const int *stat;
+};
+
+// acc[jb] (rows 16 wv .. + 15, columns 16 jb .. + 15) += A (64 x 64, LDS) * B (64 x 64, LDS)
+static __device__ __forceinline__ void tq_mm64(f64x4 (&acc)[4], const double *Am, const double *Bm, int wv, int lane)
 {
-	if (stat[0])
-		return;
-	const int e = blockIdx.x * 256 + threadIdx.x;
-	const int nk = cl - cfirst; // columns of the earlier panels
-	if (e >= nk * wl)
-		return;
-	const int i = e % nk, j = e / nk; // i: column cfirst + i of an earlier panel, j: column cl + j of panel l
-	double acc = C[(long) j * ldc + i];
-	// rows cl .. cl + wl - 1: V_l's top block is unit lower triangular
-	for (int r = j; r < wl && cl + r < m; ++r) {
-		const double vl = r == j ? 1.0 : (double) A[(long) (cl + j) * ld + cl + r];
-		acc += (double) A[(long) (cfirst + i) * ld + cl + r] * vl;
+#pragma unroll 4
+	for (int k0 = 0; k0 < 64; k0 += 4) {
+		const double av = Am[(16 * wv + (lane & 15)) * TQ_DP + k0 + (lane >> 4)];
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb) {
+			const double bv = Bm[(k0 + (lane >> 4)) * TQ_DP + 16 * jb + (lane & 15)];
+			acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[jb], 0, 0, 0);
+		}
 	}
-	const int gi = cfirst + i, gj = cl + j;
-	H[(long) (gi % bs) * hrs + (long) gj * hcs] = (float) acc;
 }
 
-__global__ void tq_zero_kernel(double *p, int n)
+__global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
 {
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i < n)
-		p[i] = 0.0;
+	__shared__ double Am[64 * TQ_DP], Bm[64 * TQ_DP], Tm[64 * TQ_DP];
+	if (a.stat[0])
+		return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int k = blockIdx.x;
+	const int ck = k * TQ_PW;
+	const int bend = min(a.n, (ck / a.bs + 1) * a.bs); // end of the block of Q_coeff that holds panel k
+	const int l1 = k + 1, lend = (bend + TQ_PW - 1) / TQ_PW; // panels l1 .. lend - 1 share the block
+	if (l1 >= lend)
+		return;
+	double *Bk = a.B + (long) k * 64 * a.ldz;
+	auto zero_acc = [](f64x4 (&acc)[4]) {
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+			acc[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
+	};
+	// f64 16x16x4 result map: col = lane & 15, row = (lane >> 4) + 4 * reg
+	// ---- B := -T_k Z_k on the columns of the later panels of the block
+	for (int e = tid; e < 4096; e += 256)
+		Am[(e >> 6) * TQ_DP + (e & 63)] = a.Td[(long) k * 4096 + e];
+	for (int l = l1; l < lend; ++l) {
+		const int cl = l * TQ_PW;
+		__syncthreads();
+		for (int e = tid; e < 4096; e += 256) {
+			const int i = e >> 6, j = e & 63;
+			Bm[i * TQ_DP + j] = cl + j < a.n ? a.Z[((long) k * 64 + i) * a.ldz + cl + j] : 0.0;
+		}
+		__syncthreads();
+		f64x4 acc[4];
+		zero_acc(acc);
+		tq_mm64(acc, Am, Bm, wv, lane);
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				Bk[(long) (16 * wv + (lane >> 4) + 4 * r) * a.ldz + cl + 16 * jb + (lane & 15)] = -acc[jb][r];
+	}
+	for (int l = l1; l < lend; ++l) {
+		const int cl = l * TQ_PW;
+		const int wl = min(TQ_PW, a.n - cl);
+		// ---- acc = V_k[c_k : c_l + w_l, :]^T R[c_k : c_l + w_l, cols of l], 64 rows at a time
+		f64x4 acc[4];
+		zero_acc(acc);
+		for (int r0 = ck; r0 < cl + wl; r0 += 64) {
+			__syncthreads();
+			for (int e = tid; e < 4096; e += 256) {
+				const int i = e & 63, r = e >> 6; // Am[i][r] = V_k[r0 + r][i]: lanes along the rows of A (unit stride)
+				const int gr = r0 + (e & 63), ii = e >> 6;
+				// (transposed fill: thread e handles row gr, column ii -- consecutive threads read consecutive rows)
+				double vv = 0.0;
+				if (gr < cl + wl) {
+					const int rr = gr - ck; // row inside V_k
+					vv = rr < ii ? 0.0 : (rr == ii ? 1.0 : (double) a.A[(long) (ck + ii) * a.ld + gr]);
+				}
+				Am[ii * TQ_DP + (gr - r0)] = vv;
+				double rv = 0.0;
+				if (gr < cl + wl && ii < wl) {
+					const bool below = gr - cl > ii; // strictly below the diagonal of R_l: holds V_l, not R
+					rv = below ? 0.0 : (double) a.A[(long) (cl + ii) * a.ld + gr];
+				}
+				Bm[(gr - r0) * TQ_DP + ii] = rv;
+				(void) i;
+				(void) r;
+			}
+			__syncthreads();
+			tq_mm64(acc, Am, Bm, wv, lane);
+		}
+		// ---- Tm = B_l - acc, then T_kl = Tm M_l
+		__syncthreads();
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int i = 16 * wv + (lane >> 4) + 4 * r, j = 16 * jb + (lane & 15);
+				Am[i * TQ_DP + j] = Bk[(long) i * a.ldz + cl + j] - acc[jb][r];
+			}
+		for (int e = tid; e < 4096; e += 256)
+			Bm[(e >> 6) * TQ_DP + (e & 63)] = a.Md[(long) l * 4096 + e];
+		__syncthreads();
+		zero_acc(acc);
+		tq_mm64(acc, Am, Bm, wv, lane);
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int i = 16 * wv + (lane >> 4) + 4 * r, j = 16 * jb + (lane & 15);
+				Tm[i * TQ_DP + j] = acc[jb][r];
+				if (j < wl) {
+					const int gi = ck + i, gj = cl + j;
+					a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) acc[jb][r];
+				}
+			}
+		// ---- B[:, later panels] -= T_kl Z_l[:, later panels]
+		for (int l2 = l + 1; l2 < lend; ++l2) {
+			const int c2 = l2 * TQ_PW;
+			__syncthreads();
+			for (int e = tid; e < 4096; e += 256) {
+				const int i = e >> 6, j = e & 63;
+				Bm[i * TQ_DP + j] = c2 + j < a.n ? a.Z[((long) l * 64 + i) * a.ldz + c2 + j] : 0.0;
+			}
+			__syncthreads();
+			zero_acc(acc);
+			tq_mm64(acc, Tm, Bm, wv, lane);
+#pragma unroll
+			for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const long o = (long) (16 * wv + (lane >> 4) + 4 * r) * a.ldz + c2 + 16 * jb + (lane & 15);
+					Bk[o] -= acc[jb][r];
+				}
+		}
+		__syncthreads(); // Bk written by this workgroup is read by it in the next round (workgroup-scope visibility)
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -791,8 +994,8 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 	else
 		hipLaunchKernelGGL(tq_gram_kernel<false>, dim3(nb), dim3(256), 0, s, g);
 	const int total = (want_g ? 4096 : 0) + 64 * g.tp + (want_sq ? 256 : 0);
-	hipLaunchKernelGGL(tq_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, Gp, Cp, Sp, nb, g.tp, (int) want_g, (int) want_sq, G, C, ldc,
-			   coff, S, stat);
+	hipLaunchKernelGGL(tq_reduce_kernel, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, Gp, Cp, Sp, nb, g.tp, (int) want_g, (int) want_sq, G, C,
+			   ldc, coff, S, stat);
 	FH_HIP(hipGetLastError());
 }
 
@@ -817,18 +1020,26 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	hipStream_t s = ctx().stream;
 	const bool vec = (ld % 4 == 0) && ((uintptr_t) A.p % 16 == 0);
 	const int npan = (int) ((n + TQ_PW - 1) / TQ_PW);
-	const int tmax = (int) n; // trailing width bound
-	const int ldc = (tmax + 63) & ~63;
-	const int typ = ldc;
+	const int ldc = ((int) n + 63) & ~63;
+	const int typ = ldc, ldz = ldc;
 	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * 4), sp((size_t) TQ_NB * 256 * 4);
-	Scratch small((size_t) (4096 * 3 + 64 * ldc + 512 + 2 * n + 64) * 8 + (size_t) (4096 + 64 * typ) * 4 + 256);
+	// fp64 workspace: G (NG x 4096), N1, N2, N3 (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64),
+	//                 Td, Md (npan x 4096 each), Z, B (npan x 64 x ldz each); then fp32: Mn (4096), Yn (64 x typ); then the status words
+	const size_t nd = (size_t) TQ_NG * 4096 + 3 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
+			  (size_t) 2 * npan * 64 * ldz;
+	Scratch small(nd * 8 + (size_t) (4096 + 64 * typ) * 4 + 256);
 	double *G = small.as<double>();
-	double *N1 = G + 4096, *N2 = N1 + 4096, *C = N2 + 4096, *S = C + (size_t) 64 * ldc, *abv = S + 512;
-	float *Mn = reinterpret_cast<float *>(abv + 2 * n + 64);
+	double *N1 = G + (size_t) TQ_NG * 4096, *N2 = N1 + 4096, *N3 = N2 + 4096, *C = N3 + 4096;
+	double *S = C + (size_t) TQ_NG * 64 * ldc, *abv = S + (size_t) TQ_NG * 256;
+	double *Td = abv + n + 64, *Md = Td + (size_t) npan * 4096, *Z = Md + (size_t) npan * 4096, *Bx = Z + (size_t) npan * 64 * ldz;
+	float *Mn = reinterpret_cast<float *>(Bx + (size_t) npan * 64 * ldz);
 	float *Yn = Mn + 4096;
 	int *stat = reinterpret_cast<int *>(Yn + (size_t) 64 * typ);
 	FH_HIP(hipMemsetAsync(stat, 0, 64, s));
-	FH_HIP(hipMemsetAsync(abv, 0, (size_t) (2 * n + 64) * 8, s));
+	FH_HIP(hipMemsetAsync(abv, 0, (size_t) (n + 64) * 8, s));
+	const bool cross = bs > TQ_PW && npan > 1;
+	if (cross)
+		FH_HIP(hipMemsetAsync(Z, 0, (size_t) npan * 64 * ldz * 8, s));
 	auto launch_gram = [&](int c0, int w, bool first) {
 		// G of panel [c0, c0 + w) and C against everything right of it, rows from c0 down, strips of <= 192 columns
 		const int t = (int) n - c0 - w;
@@ -865,14 +1076,17 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		pa.abv = abv;
 		pa.N1 = N1;
 		pa.N2 = N2;
+		pa.N3 = N3;
 		pa.Mn = Mn;
+		pa.Md = Md + (size_t) k * 4096;
+		pa.Td = Td + (size_t) k * 4096;
 		pa.H = H.p;
 		pa.hrs = H.rs;
 		pa.hcs = H.cs;
 		pa.bs = (int) bs;
 		pa.taus = taus;
 		pa.stat = stat;
-		hipLaunchKernelGGL(tq_panel_kernel, dim3(1), dim3(256), 0, s, pa);
+		hipLaunchKernelGGL(tq_panel_kernel, dim3(1), dim3(TQ_PT), 0, s, pa);
 		if (t > 0) {
 			TqYArgs ya;
 			ya.A = A.p;
@@ -885,9 +1099,12 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			ya.ldc = ldc;
 			ya.N1 = N1;
 			ya.N2 = N2;
+			ya.N3 = N3;
 			ya.abv = abv;
 			ya.Yn = Yn;
 			ya.typ = typ;
+			ya.Z = Z + (size_t) k * 64 * ldz;
+			ya.ldz = ldz;
 			ya.stat = stat;
 			hipLaunchKernelGGL(tq_y_kernel, dim3((t + 15) / 16), dim3(256), 0, s, ya);
 		}
@@ -908,12 +1125,13 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			if (nwg > TQ_NB)
 				nwg = TQ_NB;
 			const int nstrip = (t + TQ_TS - 1) / TQ_TS;
+			const bool v2 = vec && r1 % 4 == 0;
 			for (int st = 0; st < nstrip || (st == 0 && nstrip == 0); ++st) {
 				ua.coff = st * TQ_TS;
 				ua.ts = nstrip == 0 ? 0 : (t - ua.coff < TQ_TS ? t - ua.coff : TQ_TS);
 				ua.X = A.p + (long) (c0 + w + ua.coff) * ld + r1;
 				ua.do_v = nstrip <= 1; // V overwrites P: only when no other launch still reads the panel
-				if (vec && r1 % 4 == 0)
+				if (v2)
 					hipLaunchKernelGGL(tq_update_kernel<true>, dim3(nwg), dim3(256), 0, s, ua);
 				else
 					hipLaunchKernelGGL(tq_update_kernel<false>, dim3(nwg), dim3(256), 0, s, ua);
@@ -923,7 +1141,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 				ua.ts = 0;
 				ua.X = ua.P;
 				ua.do_v = 1;
-				if (vec && r1 % 4 == 0)
+				if (v2)
 					hipLaunchKernelGGL(tq_update_kernel<true>, dim3(nwg), dim3(256), 0, s, ua);
 				else
 					hipLaunchKernelGGL(tq_update_kernel<false>, dim3(nwg), dim3(256), 0, s, ua);
@@ -935,28 +1153,22 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		}
 		FH_HIP(hipGetLastError());
 	}
-	// cross-panel blocks of T (blocks of Q_coeff wider than one panel)
-	if (bs > TQ_PW) {
-		for (int l = 1; l < npan; ++l) {
-			const int cl = l * TQ_PW;
-			const int cfirst = (int) ((cl / bs) * bs);
-			if (cfirst == cl)
-				continue; // panel l starts a block of Q_coeff
-			const int wl = (int) (n - cl < TQ_PW ? n - cl : TQ_PW);
-			const int nk = cl - cfirst;
-			const int r1 = cl + wl;
-			const int rows = (int) (m - r1);
-			for (int off = 0; off < nk; off += TQ_TS) {
-				const int ts = nk - off < TQ_TS ? nk - off : TQ_TS;
-				if (rows > 0)
-					tq_gram(A.p + (long) cl * ld + r1, A.p + (long) (cfirst + off) * ld + r1, ld, rows, wl, ts, false, false, vec && r1 % 4 == 0,
-						gp.as<double>(), cp.as<float>(), sp.as<float>(), G, C, ldc, off, S, stat);
-				else
-					hipLaunchKernelGGL(tq_zero_kernel, dim3((64 * ldc + 255) / 256), dim3(256), 0, s, C, 64 * ldc);
-			}
-			hipLaunchKernelGGL(tq_tcross_kernel, dim3((nk * wl + 255) / 256), dim3(256), 0, s, A.p, ld, (int) m, cfirst, cl, wl, C, ldc, H.p,
-					   H.rs, H.cs, (int) bs, stat);
-		}
+	if (cross) {
+		TqTxArgs ta;
+		ta.A = A.p;
+		ta.ld = ld;
+		ta.n = (int) n;
+		ta.bs = (int) bs;
+		ta.Td = Td;
+		ta.Md = Md;
+		ta.Z = Z;
+		ta.ldz = ldz;
+		ta.B = Bx;
+		ta.H = H.p;
+		ta.hrs = H.rs;
+		ta.hcs = H.cs;
+		ta.stat = stat;
+		hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
 		FH_HIP(hipGetLastError());
 	}
 	int st[4];

@@ -96,5 +96,77 @@ def main():
               f"fp32 oracle vs fp64 oracle: R {dR32 / e:.2f}, V {dV32 / e:.2f}, T {dT32 / e:.2f}")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def tsqr_algebraic_t(a):
+    """same factorization; the cross-panel blocks of T from small matrices only (no pass over V):
+    T_kl = -( T_k Z_k[:, l] + sum_{k<j<l} T_kj Z_j[:, l] + V_k[c_k : c_{l+1}]^T R[c_k : c_{l+1}, l] ) M_l,
+    with Z_k = -V1^-1 (D - X_top) of step k (V_k^T X' = -T_k Z_k after the block reflector has been applied)."""
+    dt = np.float32
+    A = a.astype(dt).copy()
+    m, n = A.shape
+    npan = (n + PW - 1) // PW
+    T = np.zeros((n, n))
+    Z = [None] * npan
+    Ms = [None] * npan
+    for k in range(npan):
+        c0 = k * PW
+        w = min(PW, n - c0)
+        P = A[c0:, c0:c0 + w]
+        X = A[c0:, c0 + w:]
+        G = P.astype(np.float64).T @ P.astype(np.float64)
+        C = (P.T @ X).astype(np.float64)
+        R, V1, U, M, Tk, s = panel_small(G, P[:w].astype(np.float64))
+        T[c0:c0 + w, c0:c0 + w] = Tk
+        Ms[k] = M
+        if X.shape[1]:
+            D = np.linalg.solve(R.T, C)
+            E = D - X[:w].astype(np.float64)
+            Zk = -np.linalg.solve(V1, E)
+            Z[k] = np.zeros((w, n))
+            Z[k][:, c0 + w:] = Zk
+            Y = np.linalg.solve(R, np.linalg.solve(U, -Zk))
+            X[w:] = X[w:] - P[w:] @ Y.astype(dt)
+            X[:w] = D.astype(dt)
+        P[w:] = P[w:] @ M.astype(dt)
+        P[:w] = (np.triu(R) + np.tril(V1, -1)).astype(dt)
+    A64 = A.astype(np.float64)
+    for k in range(npan):
+        ck = k * PW
+        for l in range(k + 1, npan):
+            cl = l * PW
+            wl = min(PW, n - cl)
+            cols = slice(cl, cl + wl)
+            acc = T[ck:ck + PW, ck:ck + PW] @ Z[k][:, cols]
+            for j in range(k + 1, l):
+                cj = j * PW
+                acc += T[ck:ck + PW, cj:cj + PW] @ Z[j][:, cols]
+            Vk = np.tril(A64[ck:cl + wl, ck:ck + PW], -1)
+            Vk[np.arange(PW), np.arange(PW)] = 1.0
+            Rl = A64[ck:cl + wl, cols].copy()
+            Rl[cl - ck:] = np.triu(Rl[cl - ck:])
+            acc += Vk.T @ Rl
+            T[ck:ck + PW, cols] = -acc @ Ms[l]
+    return A, T
+
+
+def check_algebraic():
+    rng = np.random.default_rng(1)
+    for (m, n) in [(20000, 256), (9000, 200)]:
+        a = rng.standard_normal((m, n)).astype(np.float32)
+        got, T = tsqr_algebraic_t(a)
+        V = np.tril(got.astype(np.float64), -1)[:, :n]
+        V[np.arange(n), np.arange(n)] = 1.0
+        VtV = V.T @ V
+        ref64 = a.astype(np.float64).copy(order="F")
+        rh64 = np.zeros((n, n), order="F")
+        oracle.qr_in_place(ref64, rh64)
+        e = np.finfo(np.float32).eps
+        print(f"{m}x{n}: algebraic T vs Gram of the stored V: {np.abs(np.triu(T, 1) - np.triu(VtV, 1)).max() / e:.2f} eps; "
+              f"vs fp64 oracle T: {np.abs(np.triu(T) - np.triu(rh64)).max() / e:.2f} eps (max |T| {np.abs(rh64).max():.2f})")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "algebraic":
+    check_algebraic()
