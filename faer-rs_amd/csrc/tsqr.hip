@@ -245,16 +245,17 @@ __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// panel: everything 64 x 64, fp64, one workgroup of 384 threads.
+// panel: everything 64 x 64, fp64, one workgroup of 256 threads.
 //
-// Two right-looking eliminations of 64 steps each on REGISTER-resident rows, one barrier per step (the column / row of
-// the step travels through a double-buffered LDS line), the step loop unrolled so that every register index is static:
+// Two right-looking eliminations of 64 steps each on REGISTER-resident rows (tq_a_block / tq_b_block below):
 //   A. Cholesky of G extended by the rows of A1 and of the identity: the same column operations turn G into L
 //      (R~ = L^T), A1 into Q1~ = A1 R~^-1 and I into R~^-1 -- no separate triangular solves.
 //   B. the sign-choosing LU of I - Q1~ S on its linear part W (column j of I - W S is e_j - s_j W_j), extended by identity
 //      COLUMNS (row operations applied to I give V1^-1) and identity ROWS (their multipliers are the rows of U^-1).
-// The first version of this kernel ran the same algebra as barrier-separated loops over LDS-resident matrices plus three
-// column-parallel substitutions on 64 threads: 314 us per panel, 1.25 of the 3.4 ms of a 5e5 x 256 factorization.
+// History (profiles/r03_qr_panel_phases.txt): barrier-separated loops over LDS-resident matrices plus three column-parallel
+// substitutions on 64 threads: 314 us per panel (1.25 of the 3.4 ms of a 5e5 x 256 factorization); rows in registers with one
+// workgroup barrier per column: 267 us (2 750 / 5 900 cycles per column in A / B: six wavefronts of dependent fp64
+// instructions between two barriers); one wavefront per kind of row with v_readlane broadcasts: see tq_a_block.
 // ------------------------------------------------------------------------------------------------
 struct TqPanelArgs {
 	float *A;
@@ -272,144 +273,238 @@ struct TqPanelArgs {
 	int bs;
 	float *taus;
 	int *stat;
+	long long *dbg; // phase stamps (timing build only)
 };
 
-// The two eliminations of tq_panel_kernel.  The step loop stays a real loop (two steps per iteration, one per column
-// parity) and the rows ROTATE left by one position per iteration, so the column being eliminated is always register
-// position 0 and every register index is static: position k of a thread with parity `par` holds column 2 (k + jb) + par.
-// (A fully unrolled 64-step body -- `#pragma unroll` or template recursion -- left x[] in scratch or spilled 1500 registers.)
-static __device__ __forceinline__ int tq_chol_loop(double (&x)[32], double *cbuf, double *Lm, double *Wm, double *Ri, int hr, int par)
+// 1 / a and 1 / sqrt(a) in fp64 from the hardware estimates and two Newton steps (the IEEE division / square-root
+// sequences are ~40 dependent instructions each, on the critical path of every elimination step)
+static __device__ __forceinline__ double tq_rcp(double a)
 {
-#pragma unroll 1
-	for (int jb = 0; jb < 32; ++jb) {
-#pragma unroll
-		for (int pj = 0; pj < 2; ++pj) {
-			const int J = 2 * jb + pj;
-			double *cb = cbuf + pj * 192;
-			if (par == pj)
-				cb[hr] = x[0];
-			__syncthreads();
-			const double piv = cb[J];
-			if (!(piv > 0.0) || !(piv < 1e300))
-				return TQ_FAIL_CHOL;
-			const double rd = sqrt(piv), rinv = 1.0 / rd;
-			const double mine = cb[hr] * rinv;
-			if (par == pj) {
-				if (hr < 64) {
-					if (hr >= J)
-						Lm[hr * TQ_DP + J] = hr == J ? rd : mine;
-				} else if (hr < 128) {
-					Wm[(hr - 64) * TQ_DP + J] = mine;
-				} else {
-					Ri[(hr - 128) * TQ_DP + J] = mine;
-				}
-			}
-			const double lr = (hr < 64 && hr <= J) ? 0.0 : mine;
-			const int kmax = 32 - jb; // positions k < kmax hold columns <= 63
-#pragma unroll
-			for (int k = 0; k < 32; ++k) {
-				const int c = 2 * (k + jb) + par;
-				if (k < kmax && c > J)
-					x[k] -= lr * (cb[c] * rinv);
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < 31; ++k)
-			x[k] = x[k + 1];
-		x[31] = 0.0;
-	}
-	return 0;
+#ifdef TQ_EXACT_DIV
+	return 1.0 / a;
+#endif
+	double r = __builtin_amdgcn_rcp(a);
+	r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+	r = __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+	return r;
+}
+static __device__ __forceinline__ double tq_rsq(double a)
+{
+#ifdef TQ_EXACT_DIV
+	return 1.0 / sqrt(a);
+#endif
+	double r = __builtin_amdgcn_rsq(a);
+	r = __builtin_fma(__builtin_fma(-0.5 * a * r, r, 0.5), r, r);
+	r = __builtin_fma(__builtin_fma(-0.5 * a * r, r, 0.5), r, r);
+	return r;
 }
 
-static __device__ __forceinline__ int tq_lu_loop(double (&x)[32], double *cbuf, double *rbw, double *rbe, double *Wm, double *UL, double *sgn,
-						 int hr, int par, int w)
+static __device__ __forceinline__ double tq_rl(double v, int l)
 {
-	const bool etype = hr >= 64 && hr < 128; // identity columns of rows 0..63: not rotated (their live columns are c <= J)
-#pragma unroll 1
-	for (int jb = 0; jb < 32; ++jb) {
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+	return __hiloint2double(hi, lo);
+}
+
+// The two eliminations of tq_panel_kernel, one WAVEFRONT per kind of row, lane r = row, the 64 columns of the row in
+// registers.  The sequential part -- the 64 pivots -- runs inside wavefront 0 without a workgroup barrier: the pivot comes
+// from its own lanes through v_readlane, the multipliers of the other columns / the pivot row go to LDS (they are part of
+// the result anyway) and come back as wave-uniform broadcast reads, one read + one FMA per entry.  Wavefronts 1 and 2
+// repeat the same column operations on their rows ONE BLOCK of TQ_NJ columns behind, from what wavefront 0 published:
+// 64 / TQ_NJ + 1 workgroup barriers per elimination instead of 64.  Rows rotate left by TQ_NJ positions per block, so the
+// column being eliminated sits at a static position jj < TQ_NJ.
+// What was measured on the way (profiles/r03_qr_panel_phases.txt):
+//   * v_readlane per entry (two per fp64 value, then an FMA on the scalar pair) is a dependent SALU -> readlane -> FMA
+//     chain: ~20 cycles per instruction;
+//   * a write by ONE lane followed by a wave-uniform read of the same LDS word needs a fence + wave barrier in between --
+//     without it the read was hoisted above the masked store (V1^-1 lost its second-order terms, 4e-5);
+//   * the block body must stay SMALL: with 8 columns unrolled per kind (~16 KB each) the first pass through each body cost
+//     60 000 - 90 000 cycles of instruction-cache misses against ~10 000 for every later pass.  One body for all kinds,
+//     TQ_NJ = 4 columns per pass.
+constexpr int TQ_NJ = 4;
+
+static __device__ __forceinline__ void tq_lds_order()
+{
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// x[k] -= a * src[k * stride] for the positions k >= k0 (k0 <= TQ_NJ, an unrolled-loop constant) of the live groups of 8:
+// the broadcast reads of a group are issued together, then its FMAs
+static __device__ __forceinline__ void tq_axpy_from(int k0, double (&x)[64], double a, const double *src, int stride, int live)
+{
 #pragma unroll
-		for (int pj = 0; pj < 2; ++pj) {
-			const int J = 2 * jb + pj;
-			double *cb = cbuf + pj * 192, *rw = rbw + pj * 64, *re = rbe + pj * 64;
-			if (par == pj && hr < 64)
-				cb[hr] = x[0]; // W[r][J]
-			if (par == pj && hr >= 128)
-				cb[hr - 64] = x[0]; // z[k][J]
-			if (hr == J) {
+	for (int g = 0; g < 8; ++g) {
+		if (8 * g < live) { // wave uniform
+			double m[8];
 #pragma unroll
-				for (int k = 0; k < 32; ++k)
-					if (k + jb < 32)
-						rw[2 * (k + jb) + par] = x[k];
+			for (int q = 0; q < 8; ++q)
+				m[q] = src[(8 * g + q) * stride];
+#pragma unroll
+			for (int q = 0; q < 8; ++q)
+				if (8 * g + q >= k0)
+					x[8 * g + q] = __builtin_fma(-a, m[q], x[8 * g + q]);
+		}
+	}
+}
+
+// A: Cholesky of G (kind 0) -> L in Lm (junk above the diagonal), reciprocal roots in dinv; kinds 1 / 2: the rows of A1 / of
+//    I under the same column operations -> Q1~ = A1 R~^-1 in Wm, R~^-1 in Ri.  Block b = columns TQ_NJ b .. + TQ_NJ - 1.
+static __device__ __forceinline__ bool tq_a_block(double (&x)[64], int kind, int b, int r, double *Lm, double *dinv, double *out)
+{
+	const int live = 64 - TQ_NJ * b; // positions < live hold columns <= 63 (dead positions of the last group read junk: unused)
+	bool bad = false;
+#pragma unroll
+	for (int jj = 0; jj < TQ_NJ; ++jj) {
+		const int J = TQ_NJ * b + jj;
+		double a;
+		if (kind == 0) {
+			const double d = tq_rl(x[jj], J);
+			bad = bad || !(d > 0.0) || !(d < 1e300); // wave uniform
+			const double rinv = tq_rsq(d);
+			a = x[jj] * rinv;	  // lane J: the root of the pivot; lanes < J: junk above the diagonal
+			Lm[r * TQ_DP + J] = a; // read back below by this wavefront
+			if (r == J)
+				dinv[J] = rinv;
+			tq_lds_order();
+		} else {
+			a = x[jj] * dinv[J];
+			out[r * TQ_DP + J] = a;
+		}
+		tq_axpy_from(jj + 1, x, a, Lm + (TQ_NJ * b) * TQ_DP + J, TQ_DP, live); // L[NJ b + k][J]: wave-uniform addresses
+	}
+	return bad;
+}
+
+// B: the sign-choosing LU of I - Q1~ S on its linear part W (column j of I - W S is e_j - s_j W_j): kind 0 eliminates the rows
+//    of W (V1 below the diagonal of Wm, the raw rows of U on and above it, signs and reciprocal pivots in sgn / pinvs);
+//    kind 2 carries identity ROWS through the elimination: their multipliers are the rows of U^-1.
+static __device__ __forceinline__ bool tq_b_block02(double (&x)[64], int kind, int b, int r, int w, double *Wm, double *UL, double *sgn,
+						    double *pinvs)
+{
+	const int live = 64 - TQ_NJ * b;
+	bool bad = false;
+#pragma unroll
+	for (int jj = 0; jj < TQ_NJ; ++jj) {
+		const int J = TQ_NJ * b + jj;
+		double *wrow = Wm + J * TQ_DP + TQ_NJ * b; // W[J][NJ b + k]
+		double mult;
+		if (kind == 0) {
+			// row J is final: lane J publishes it (U[J][c] = delta - s_c W[J][c] once every sign is known)
+			if (r == J) {
+#pragma unroll
+				for (int k = jj; k < 64; ++k)
+					if (k < live)
+						wrow[k] = x[k];
 			}
-			if (hr == 64 + J) {
-#pragma unroll
-				for (int k = 0; k < 32; ++k)
-					re[2 * k + par] = x[k];
-			}
-			__syncthreads();
-			const double alpha = cb[J];
+			const double alpha = tq_rl(x[jj], J);
+			bad = bad || (J < w && !(1.0 - fabs(alpha) >= TQ_TAIL_MIN)); // wave uniform
 			const double sj = alpha >= 0.0 ? -1.0 : 1.0;
-			const double piv = 1.0 + fabs(alpha);
-			if (J < w && !(1.0 - fabs(alpha) >= TQ_TAIL_MIN))
-				return TQ_FAIL_TAIL;
-			const double pinv = 1.0 / piv;
-			double mult;
-			if (hr < 128) {
-				const int r = hr & 63;
-				mult = r > J ? -sj * cb[r] * pinv : 0.0;
-				if (hr < 64 && par == pj && r > J)
-					Wm[r * TQ_DP + J] = mult; // V1[r][J]
-			} else {
-				const int kz = hr - 128;
-				mult = ((kz == J ? 1.0 : 0.0) - sj * cb[64 + kz]) * pinv;
-				if (par == pj && kz <= J)
-					UL[kz * TQ_DP + J] = mult; // U^-1[kz][J]
-			}
-			if (threadIdx.x == 0)
+			const double pinv = tq_rcp(1.0 + fabs(alpha));
+			mult = r > J ? -sj * x[jj] * pinv : 0.0;
+			if (r > J)
+				Wm[r * TQ_DP + J] = mult; // V1[r][J]
+			if (r == J) {
 				sgn[J] = sj;
-			// row J of the linear part is final: keep it (U[J][c] = delta - s_c W[J][c] once every sign is known)
-			if (threadIdx.x < 64 && (int) threadIdx.x >= J)
-				Wm[J * TQ_DP + threadIdx.x] = rw[threadIdx.x];
-			if (etype) {
-#pragma unroll
-				for (int k = 0; k < 32; ++k)
-					if (2 * k <= J)
-						x[k] -= mult * re[2 * k + par];
-			} else {
-				const int kmax = 32 - jb;
-#pragma unroll
-				for (int k = 0; k < 32; ++k) {
-					const int c = 2 * (k + jb) + par;
-					if (k < kmax && c > J)
-						x[k] -= mult * rw[c];
-				}
+				pinvs[J] = pinv;
 			}
+			tq_lds_order();
+		} else {
+			const double sj = sgn[J], pinv = pinvs[J];
+			mult = ((r == J ? 1.0 : 0.0) - sj * x[jj]) * pinv;
+			if (r <= J)
+				UL[r * TQ_DP + J] = mult; // U^-1[r][J]
 		}
-		if (!etype) {
-#pragma unroll
-			for (int k = 0; k < 31; ++k)
-				x[k] = x[k + 1];
-			x[31] = 0.0;
-		}
+		tq_axpy_from(jj + 1, x, mult, wrow, 1, live);
 	}
-	return 0;
+	return bad;
 }
 
-constexpr int TQ_PT = 384;
+//    kind 1: V1^-1 by forward substitution, one COLUMN per lane (x[k] = row NJ b + k of column r of the inverse): once
+//    row J of the inverse is final its entries sit at position jj of every lane, and the rows below take
+//    -V1[row][J] x[jj] -- the multipliers are wave-uniform reads of column J of V1, no lane has to publish anything.
+static __device__ __forceinline__ void tq_b_block1(double (&x)[64], int b, int r, double *Wm, double *UL)
+{
+	const int live = 64 - TQ_NJ * b;
+#pragma unroll
+	for (int jj = 0; jj < TQ_NJ; ++jj) {
+		const int J = TQ_NJ * b + jj;
+		const double a = x[jj]; // V1^-1[J][r]
+		if (r < J)
+			UL[J * TQ_DP + r] = a;
+		tq_axpy_from(jj + 1, x, a, Wm + (TQ_NJ * b) * TQ_DP + J, TQ_DP, live); // V1[NJ b + k][J], k > jj
+	}
+}
+
+static __device__ __forceinline__ void tq_rot(double (&x)[64])
+{
+#pragma unroll
+	for (int k = 0; k < 64 - TQ_NJ; ++k)
+		x[k] = x[k + TQ_NJ];
+#pragma unroll
+	for (int k = 64 - TQ_NJ; k < 64; ++k)
+		x[k] = 0.0;
+}
+
+// acc[jb] (rows 16 wv .. + 15, columns 16 jb .. + 15) = A * B, both 64 x 64 in LDS, read through a structure mask:
+//   AM 0: A[i][k] as stored;  1: the transpose of the unit lower triangle of the array (V1^T)
+//   BM 0: as stored;  1: upper triangle, row k scaled by sc[k];  2: unit lower triangle;  3: upper triangle
+template <int AM, int BM>
+static __device__ __forceinline__ void tq_mm64m(f64x4 (&acc)[4], const double *Am, const double *Bm, const double *sc, int wv, int lane)
+{
+#pragma unroll
+	for (int jb = 0; jb < 4; ++jb)
+		acc[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
+	const int i = 16 * wv + (lane & 15);
+#pragma unroll 4
+	for (int k0 = 0; k0 < 64; k0 += 4) {
+		const int k = k0 + (lane >> 4);
+		double av;
+		if (AM == 0)
+			av = Am[i * TQ_DP + k];
+		else
+			av = k > i ? Am[k * TQ_DP + i] : (k == i ? 1.0 : 0.0);
+		const double rs = BM == 1 ? sc[k] : 1.0;
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb) {
+			const int j = 16 * jb + (lane & 15);
+			double bv = Bm[k * TQ_DP + j];
+			if (BM == 1)
+				bv = k <= j ? rs * bv : 0.0;
+			else if (BM == 2)
+				bv = k > j ? bv : (k == j ? 1.0 : 0.0);
+			else if (BM == 3)
+				bv = k <= j ? bv : 0.0;
+			acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[jb], 0, 0, 0);
+		}
+	}
+}
+
+#ifdef FH_TQ_TIMING
+#define TQ_STAMP(i)                                                                                                      \
+	do {                                                                                                             \
+		if (threadIdx.x == 0)                                                                                    \
+			a.dbg[i] = (long long) __builtin_readcyclecounter();                                             \
+	} while (0)
+#else
+#define TQ_STAMP(i)                                                                                                      \
+	do {                                                                                                             \
+	} while (0)
+#endif
+constexpr int TQ_PT = 256;
 __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 {
-	__shared__ double Lm[64 * TQ_DP]; // L (lower Cholesky factor, R~ = L^T), later M
-	__shared__ double Wm[64 * TQ_DP]; // Q1~, later [V1 strictly lower | U upper]
+	__shared__ double Lm[64 * TQ_DP]; // G, then L (lower Cholesky factor, R~ = L^T), later M
+	__shared__ double Wm[64 * TQ_DP]; // A1, then Q1~, then [V1 strictly lower | U upper]
 	__shared__ double Ri[64 * TQ_DP]; // R~^-1 (upper)
 	__shared__ double UL[64 * TQ_DP]; // U^-1 (upper incl. diagonal) | V1^-1 (strictly lower, unit diagonal implied)
-	__shared__ double cbuf[2][192];
-	__shared__ double rbw[2][64], rbe[2][64];
-	__shared__ double sgn[64];
+	__shared__ double sgn[64], dinv[64], pinvs[64];
 	__shared__ int s_fail;
 	if (a.stat[0])
 		return;
 	const int tid = threadIdx.x, w = a.w;
-	const int hr = tid % 192, par = tid / 192; // (half-)row, column parity: this thread holds columns 2 k + par, k = 0 .. 31
+	const int r = tid & 63;
+	const int kind = __builtin_amdgcn_readfirstlane(tid >> 6); // wavefront = kind of row (3: only the cooperative phases)
+	TQ_STAMP(0);
 	if (tid == 0)
 		s_fail = 0;
 	auto fail = [&](int why) {
@@ -431,6 +526,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 				sq += a.S[g * 256 + c];
 			bad = bad || !(sq >= lo && sq <= hi);
 		}
+		__syncthreads();
 		if (bad)
 			s_fail = TQ_FAIL_RANGE;
 		__syncthreads();
@@ -439,67 +535,138 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 			return;
 		}
 	}
-	// ---- A. rows 0..63: G (identity beyond w), 64..127: A1 (zero beyond w), 128..191: I
-	double x[32];
-#pragma unroll
-	for (int k = 0; k < 32; ++k) {
-		const int c = 2 * k + par;
-		double v;
-		if (hr < 64) {
-			v = hr == c ? 1.0 : 0.0;
-			if (hr < w && c < w) {
-				v = 0.0;
-				for (int g = 0; g < TQ_NG; ++g)
-					v += a.G[g * 4096 + hr * 64 + c];
-			}
-		} else if (hr < 128) {
-			const int r = hr - 64;
-			v = (r < w && c < w) ? (double) a.A[(long) (a.c0 + c) * a.ld + a.r0 + r] : 0.0;
-		} else {
-			v = hr - 128 == c ? 1.0 : 0.0;
+	// ---- G (the sum of its TQ_NG slices, identity beyond w) and A1 (zero beyond w) through LDS, coalesced
+	for (int e = tid; e < 4096; e += TQ_PT) {
+		const int i = e >> 6, j = e & 63;
+		double g = i == j ? 1.0 : 0.0, v = 0.0;
+		if (i < w && j < w) {
+			g = 0.0;
+			for (int q = 0; q < TQ_NG; ++q)
+				g += a.G[q * 4096 + e];
+			v = (double) a.A[(long) (a.c0 + i) * a.ld + a.r0 + j]; // transposed fill: lanes along the rows of A
 		}
-		x[k] = v;
-	}
-	{
-		const int why = tq_chol_loop(x, cbuf[0], Lm, Wm, Ri, hr, par);
-		if (why) {
-			fail(why);
-			return; // uniform: every thread read the same pivot
-		}
+		Lm[i * TQ_DP + j] = g;
+		Wm[j * TQ_DP + i] = v;
 	}
 	__syncthreads();
-	// ---- B. half-rows 0..63: W (linear part of I - W S), 64..127: identity columns of the same rows, 128..191: identity ROWS
+	double x[64];
+	if (kind == 0) {
 #pragma unroll
-	for (int k = 0; k < 32; ++k) {
-		const int c = 2 * k + par;
-		x[k] = hr < 64 ? Wm[hr * TQ_DP + c] : (hr < 128 ? (hr - 64 == c ? 1.0 : 0.0) : 0.0);
+		for (int k = 0; k < 64; ++k)
+			x[k] = Lm[r * TQ_DP + k];
+	} else if (kind == 1) {
+#pragma unroll
+		for (int k = 0; k < 64; ++k)
+			x[k] = Wm[r * TQ_DP + k];
+	} else {
+#pragma unroll
+		for (int k = 0; k < 64; ++k)
+			x[k] = r == k ? 1.0 : 0.0;
+	}
+	__syncthreads(); // Lm / Wm are rewritten by the elimination
+	TQ_STAMP(1);
+	constexpr int NBLK = 64 / TQ_NJ;
+#pragma unroll 1
+	for (int it = 0; it <= NBLK; ++it) {
+		const int blk = kind == 0 ? it : it - 1;
+		if (kind < 3 && blk >= 0 && blk < NBLK) {
+			if (tq_a_block(x, kind, blk, r, Lm, dinv, kind == 1 ? Wm : Ri) && r == 0)
+				s_fail = TQ_FAIL_CHOL;
+			tq_rot(x);
+		}
+		__syncthreads();
+		if (s_fail) {
+			fail(s_fail);
+			return;
+		}
+	}
+	TQ_STAMP(2);
+	// ---- B
+	if (kind == 0) {
+#pragma unroll
+		for (int k = 0; k < 64; ++k)
+			x[k] = Wm[r * TQ_DP + k];
+	} else if (kind == 1) {
+#pragma unroll
+		for (int k = 0; k < 64; ++k)
+			x[k] = r == k ? 1.0 : 0.0;
+	} else {
+#pragma unroll
+		for (int k = 0; k < 64; ++k)
+			x[k] = 0.0;
 	}
 	for (int e = tid; e < 64 * TQ_DP; e += TQ_PT)
 		UL[e] = 0.0;
 	__syncthreads();
-	{
-		const int why = tq_lu_loop(x, cbuf[0], rbw[0], rbe[0], Wm, UL, sgn, hr, par, w);
-		if (why) {
-			fail(why);
-			return; // uniform
+#pragma unroll 1
+	for (int it = 0; it <= NBLK; ++it) {
+		const int blk = kind == 0 ? it : it - 1;
+		if (kind < 3 && blk >= 0 && blk < NBLK) {
+			if (kind == 1) {
+				tq_b_block1(x, blk, r, Wm, UL);
+			} else {
+				if (tq_b_block02(x, kind, blk, r, w, Wm, UL, sgn, pinvs) && r == 0)
+					s_fail = TQ_FAIL_TAIL;
+			}
+			tq_rot(x);
+		}
+		__syncthreads();
+		if (s_fail) {
+			fail(s_fail);
+			return;
 		}
 	}
-	__syncthreads();
-	// U = triu(I - W S) from the rows of W kept by the loop, V1^-1 from the identity columns
+	TQ_STAMP(3);
+	// U = triu(I - W S) from the raw rows kept by the elimination, V1^-1 from the identity columns
 	for (int e = tid; e < 4096; e += TQ_PT) {
 		const int i = e >> 6, c = e & 63;
 		if (c >= i)
 			Wm[i * TQ_DP + c] = (i == c ? 1.0 : 0.0) - sgn[c] * Wm[i * TQ_DP + c];
 	}
-	if (hr >= 64 && hr < 128) {
-#pragma unroll
-		for (int k = 0; k < 32; ++k) {
-			const int c = 2 * k + par;
-			if (c < hr - 64)
-				UL[(hr - 64) * TQ_DP + c] = x[k];
+	__syncthreads();
+#ifdef FH_TQ_TIMING
+	{
+		// debug build: residuals of the three inverses, max over the workgroup -> dbg[9..11] (as doubles)
+		__shared__ double s_res[3];
+		if (tid < 3)
+			s_res[tid] = 0.0;
+		__syncthreads();
+		double r1 = 0.0, r2 = 0.0, r3 = 0.0;
+		for (int e = tid; e < 4096; e += TQ_PT) {
+			const int i = e >> 6, j = e & 63;
+			double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+			for (int l = 0; l < 64; ++l) {
+				const double v1 = i > l ? Wm[i * TQ_DP + l] : (i == l ? 1.0 : 0.0);    // V1[i][l]
+				const double li = l > j ? UL[l * TQ_DP + j] : (l == j ? 1.0 : 0.0);   // V1^-1[l][j]
+				a1 += v1 * li;
+				const double u = l >= i ? Wm[i * TQ_DP + l] : 0.0;                     // U[i][l]
+				const double ui = l <= j ? UL[l * TQ_DP + j] : 0.0;                    // U^-1[l][j]
+				a2 += u * ui;
+				const double rt = l >= i ? Lm[l * TQ_DP + i] : 0.0;                    // R~[i][l] = L[l][i]
+				const double ri = l <= j ? Ri[l * TQ_DP + j] : 0.0;
+				a3 += rt * ri;
+			}
+			const double d = i == j ? 1.0 : 0.0;
+			r1 = fmax(r1, fabs(a1 - d));
+			r2 = fmax(r2, fabs(a2 - d));
+			r3 = fmax(r3, fabs(a3 - d));
+		}
+		for (int q = 0; q < TQ_PT; ++q) {
+			if (tid == q) {
+				s_res[0] = fmax(s_res[0], r1);
+				s_res[1] = fmax(s_res[1], r2);
+				s_res[2] = fmax(s_res[2], r3);
+			}
+			__syncthreads();
+		}
+		if (tid == 0) {
+			a.dbg[9] = __double_as_longlong(s_res[0]);
+			a.dbg[10] = __double_as_longlong(s_res[1]);
+			a.dbg[11] = __double_as_longlong(s_res[2]);
 		}
 	}
-	__syncthreads();
+#endif
+	TQ_STAMP(4);
 	// ---- the reference's rank test (wave 0), condition estimate (wave 1)
 	if (tid < 64) {
 		// factor.rs:52-64: |R_jj| > eps * 16 * (m - row) * hypot(|R_jj|, |R[0 .. j, j]|)
@@ -533,6 +700,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 		fail(s_fail);
 		return;
 	}
+	TQ_STAMP(5);
 	// ---- outputs that read L: the top block of A (R = S R~ on and above the diagonal, V1 below), N1 = R^-T, N3 = V1^-1
 	for (int e = tid; e < 4096; e += TQ_PT) {
 		const int i = e >> 6, j = e & 63;
@@ -543,41 +711,54 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 		a.N3[e] = i == j ? 1.0 : (j < i ? UL[i * TQ_DP + j] : 0.0);
 	}
 	__syncthreads(); // all reads of L are done
-	// ---- M = -R~^-1 S U^-1 (upper) into Lm
-	for (int e = tid; e < 4096; e += TQ_PT) {
-		const int k = e >> 6, j = e & 63;
-		double acc = 0.0;
-		for (int l = k; l <= j; ++l)
-			acc += Ri[k * TQ_DP + l] * sgn[l] * UL[l * TQ_DP + j];
-		const double mv = k <= j ? -acc : 0.0;
-		Lm[k * TQ_DP + j] = mv;
-		a.Mn[e] = (float) mv;
-		a.Md[e] = mv;
+	TQ_STAMP(6);
+	// ---- the three 64 x 64 x 64 products on the fp64 matrix cores (waves 0..3, 16 rows each); as scalar dot products of
+	//      triangular length out of LDS they were 120 000 cycles of this kernel
+	const int lane = tid & 63, wv = kind;
+	f64x4 acc[4];
+	// M = -R~^-1 S U^-1 (upper) into Lm
+	if (wv < 4) {
+		tq_mm64m<0, 1>(acc, Ri, UL, sgn, wv, lane);
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int k = 16 * wv + (lane >> 4) + 4 * r, j = 16 * jb + (lane & 15);
+				const double mv = k <= j ? -acc[jb][r] : 0.0;
+				Lm[k * TQ_DP + j] = mv;
+				a.Mn[k * 64 + j] = (float) mv;
+				a.Md[k * 64 + j] = mv;
+			}
 	}
 	__syncthreads();
-	// ---- N2 = -M V1^-1,  T = triu(V1^T U^-1)
-	for (int e = tid; e < 4096; e += TQ_PT) {
-		const int k = e >> 6, j = e & 63;
-		// V1^-1[l][j]: 1 on the diagonal, UL[l][j] for l > j, 0 above; M upper: l >= k
-		double acc = k <= j ? Lm[k * TQ_DP + j] : 0.0;
-		for (int l = (k > j + 1 ? k : j + 1); l < 64; ++l)
-			acc += Lm[k * TQ_DP + l] * UL[l * TQ_DP + j];
-		a.N2[e] = -acc;
-		double tt = 0.0;
-		if (k <= j) {
-			tt = UL[k * TQ_DP + j]; // l = k term: V1[k][k] = 1
-			for (int l = k + 1; l <= j; ++l)
-				tt += Wm[l * TQ_DP + k] * UL[l * TQ_DP + j];
-			if (j < w) {
-				const int gi = a.c0 + k, gj = a.c0 + j;
-				if (gi / a.bs == gj / a.bs)
-					a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) tt;
-				if (k == j)
-					a.taus[gj] = (float) tt;
+	TQ_STAMP(7);
+	if (wv < 4) {
+		// N2 = -M V1^-1
+		tq_mm64m<0, 2>(acc, Lm, UL, sgn, wv, lane);
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				a.N2[(16 * wv + (lane >> 4) + 4 * r) * 64 + 16 * jb + (lane & 15)] = -acc[jb][r];
+		// T = triu(V1^T U^-1)
+		tq_mm64m<1, 3>(acc, Wm, UL, sgn, wv, lane);
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int k = 16 * wv + (lane >> 4) + 4 * r, j = 16 * jb + (lane & 15);
+				const double tt = k <= j ? acc[jb][r] : 0.0;
+				if (k <= j && j < w) {
+					const int gi = a.c0 + k, gj = a.c0 + j;
+					if (gi / a.bs == gj / a.bs)
+						a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) tt;
+					if (k == j)
+						a.taus[gj] = (float) tt;
+				}
+				a.Td[k * 64 + j] = tt;
 			}
-		}
-		a.Td[e] = tt;
 	}
+	TQ_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1027,7 +1208,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	//                 Td, Md (npan x 4096 each), Z, B (npan x 64 x ldz each); then fp32: Mn (4096), Yn (64 x typ); then the status words
 	const size_t nd = (size_t) TQ_NG * 4096 + 3 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
 			  (size_t) 2 * npan * 64 * ldz;
-	Scratch small(nd * 8 + (size_t) (4096 + 64 * typ) * 4 + 256);
+	Scratch small(nd * 8 + (size_t) (4096 + 64 * typ) * 4 + 2048);
 	double *G = small.as<double>();
 	double *N1 = G + (size_t) TQ_NG * 4096, *N2 = N1 + 4096, *N3 = N2 + 4096, *C = N3 + 4096;
 	double *S = C + (size_t) TQ_NG * 64 * ldc, *abv = S + (size_t) TQ_NG * 256;
@@ -1035,7 +1216,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	float *Mn = reinterpret_cast<float *>(Bx + (size_t) npan * 64 * ldz);
 	float *Yn = Mn + 4096;
 	int *stat = reinterpret_cast<int *>(Yn + (size_t) 64 * typ);
-	FH_HIP(hipMemsetAsync(stat, 0, 64, s));
+	FH_HIP(hipMemsetAsync(stat, 0, 2048, s));
 	FH_HIP(hipMemsetAsync(abv, 0, (size_t) (n + 64) * 8, s));
 	const bool cross = bs > TQ_PW && npan > 1;
 	if (cross)
@@ -1086,6 +1267,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		pa.bs = (int) bs;
 		pa.taus = taus;
 		pa.stat = stat;
+		pa.dbg = reinterpret_cast<long long *>(stat + 16);
 		hipLaunchKernelGGL(tq_panel_kernel, dim3(1), dim3(TQ_PT), 0, s, pa);
 		if (t > 0) {
 			TqYArgs ya;
@@ -1174,6 +1356,17 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	int st[4];
 	FH_HIP(hipMemcpyAsync(st, stat, sizeof(st), hipMemcpyDeviceToHost, s));
 	FH_HIP(hipStreamSynchronize(s));
+#ifdef FH_TQ_TIMING
+	{
+		long long d[32];
+		FH_HIP(hipMemcpy(d, stat + 16, sizeof(d), hipMemcpyDeviceToHost));
+		fprintf(stderr, "tq_panel phases (shader cycles): start %lld: load %lld chol %lld reload %lld lu %lld finish %lld tests %lld out %lld M %lld N2/T %lld\n",
+			d[0], d[1] - d[0], d[2] - d[1], 0LL, d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[8] - d[7]);
+		double res[3];
+		memcpy(res, d + 9, sizeof(res));
+		fprintf(stderr, "tq_panel residuals of the last panel: |V1 V1^-1 - I| %.3e  |U U^-1 - I| %.3e  |R~ R~^-1 - I| %.3e\n", res[0], res[1], res[2]);
+	}
+#endif
 	*reason = st[0] ? st[2] : TQ_OK;
 	return st[0] ? (idx_t) st[1] : n;
 }
