@@ -72,10 +72,10 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(con
 	const int quad = tid & 15, cg = tid >> 4;
 	const int ncol = TQ_PW + a.tp;
 	const int ntile = 2 * (a.tp >> 5);
-	f64x4 gacc[4];
+	f64x4 gacc[3];
 	f32x16 cacc[3];
 #pragma unroll
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < 3; ++i)
 		gacc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
 	for (int i = 0; i < 3; ++i)
@@ -128,17 +128,24 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(con
 		if (ch + (int) gridDim.x < a.nchunks)
 			load_chunk(ch + gridDim.x); // in flight during the products
 		if (a.want_g) {
-			// wave wv: the 16 x 64 block row wv of G; lane: A[i = l & 15][k = l >> 4], four k-slices per 16-byte read
+			// the 10 lower 16 x 16 tiles of G (the panel kernel reads the lower triangle only), three per wavefront:
+			// lane: A[i = l & 15][k = l >> 4], four k-slices per 16-byte read
+			const int t0 = wv == 0 ? 0x30 : (wv == 1 ? 0x33 : (wv == 2 ? 0x22 : 0x00)); // (ia << 4) | ib
+			const int t1 = wv == 0 ? 0x31 : (wv == 1 ? 0x20 : (wv == 2 ? 0x10 : -1));
+			const int t2 = wv == 0 ? 0x32 : (wv == 1 ? 0x21 : (wv == 2 ? 0x11 : -1));
 #pragma unroll
 			for (int s = 0; s < 4; ++s) {
 				const int roff = 16 * s + 4 * (lane >> 4);
-				const f32x4 av = *reinterpret_cast<const f32x4 *>(&sm[(16 * wv + (lane & 15)) * TQ_LP + roff]);
 #pragma unroll
-				for (int ib = 0; ib < 4; ++ib) {
-					const f32x4 bv = *reinterpret_cast<const f32x4 *>(&sm[(16 * ib + (lane & 15)) * TQ_LP + roff]);
+				for (int u = 0; u < 3; ++u) {
+					const int tt = u == 0 ? t0 : (u == 1 ? t1 : t2);
+					if (tt >= 0) { // wave uniform
+						const f32x4 av = *reinterpret_cast<const f32x4 *>(&sm[(16 * (tt >> 4) + (lane & 15)) * TQ_LP + roff]);
+						const f32x4 bv = *reinterpret_cast<const f32x4 *>(&sm[(16 * (tt & 15) + (lane & 15)) * TQ_LP + roff]);
 #pragma unroll
-					for (int q = 0; q < 4; ++q)
-						gacc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64((double) av[q], (double) bv[q], gacc[ib], 0, 0, 0);
+						for (int q = 0; q < 4; ++q)
+							gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double) av[q], (double) bv[q], gacc[u], 0, 0, 0);
+					}
 				}
 			}
 		}
@@ -166,12 +173,19 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(con
 	}
 	const long blk = blockIdx.x;
 	if (a.want_g) {
-		// f64 16x16x4 result map: col = lane & 15, row = (lane >> 4) + 4 * reg
+		// f64 16x16x4 result map: col = lane & 15, row = (lane >> 4) + 4 * reg; tiles above the diagonal are never written
+		const int t0 = wv == 0 ? 0x30 : (wv == 1 ? 0x33 : (wv == 2 ? 0x22 : 0x00));
+		const int t1 = wv == 0 ? 0x31 : (wv == 1 ? 0x20 : (wv == 2 ? 0x10 : -1));
+		const int t2 = wv == 0 ? 0x32 : (wv == 1 ? 0x21 : (wv == 2 ? 0x11 : -1));
 #pragma unroll
-		for (int ib = 0; ib < 4; ++ib)
+		for (int u = 0; u < 3; ++u) {
+			const int tt = u == 0 ? t0 : (u == 1 ? t1 : t2);
+			if (tt >= 0) {
 #pragma unroll
-			for (int r = 0; r < 4; ++r)
-				a.Gp[blk * 4096 + (16 * wv + (lane >> 4) + 4 * r) * 64 + 16 * ib + (lane & 15)] = gacc[ib][r];
+				for (int r = 0; r < 4; ++r)
+					a.Gp[blk * 4096 + (16 * (tt >> 4) + (lane >> 4) + 4 * r) * 64 + 16 * (tt & 15) + (lane & 15)] = gacc[u][r];
+			}
+		}
 	}
 #pragma unroll
 	for (int u = 0; u < 3; ++u) {
@@ -541,8 +555,9 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 		double g = i == j ? 1.0 : 0.0, v = 0.0;
 		if (i < w && j < w) {
 			g = 0.0;
+			const int el = i >= j ? e : j * 64 + i; // the Gram kernel writes the lower 16 x 16 tiles only
 			for (int q = 0; q < TQ_NG; ++q)
-				g += a.G[q * 4096 + e];
+				g += a.G[q * 4096 + el];
 			v = (double) a.A[(long) (a.c0 + i) * a.ld + a.r0 + j]; // transposed fill: lanes along the rows of A
 		}
 		Lm[i * TQ_DP + j] = g;
@@ -942,6 +957,7 @@ template <bool VEC> __global__ __launch_bounds__(256, 1) void tq_update_kernel(c
 				pr[i] = tq_ld4<VEC>(Pb + (long) kc * a.ld, lam, rows);
 		}
 		// one wavefront per SIMD (512 registers): the next strip of X is fetched while the matrix cores work on this one
+		// (two wavefronts per SIMD without the prefetch registers spill and measured 10 % slower)
 		f32x4 xn[16];
 #pragma unroll
 		for (int r = 0; r < 16; ++r) {
@@ -1028,7 +1044,183 @@ static __device__ __forceinline__ void tq_mm64(f64x4 (&acc)[4], const double *Am
 	}
 }
 
+// The sequence of 64 x 64 x 64 products of one workgroup (panel k), in order; operands that come from global memory are
+// fetched into registers one product ahead (the first version staged them behind two barriers per product and kept B in
+// global memory: ~13 us per product, 238 us per factorization, all of it dependent memory round trips).
+struct TqTxUnit {
+	int type; // 0: B_l = -T_k Z_k[:, l];  1: acc += V_k^T chunk * R chunk;  2: T_kl = (B_l - acc) M_l;  3: B_l2 -= T_kl Z_l[:, l2];  4: done
+	int l, x; // x: first row of the chunk (type 1) / l2 (type 3)
+};
+
+constexpr int TQ_TX_MAXL = 3; // later panels of one block of Q_coeff kept in registers (blocks of Q_coeff up to 256 columns)
+
 __global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
+{
+	__shared__ double Am[64 * TQ_DP], Bm[64 * TQ_DP], Tm[64 * TQ_DP];
+	if (a.stat[0])
+		return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int k = blockIdx.x;
+	const int ck = k * TQ_PW;
+	const int bend = min(a.n, (ck / a.bs + 1) * a.bs); // end of the block of Q_coeff that holds panel k
+	const int l1 = k + 1, lend = (bend + TQ_PW - 1) / TQ_PW; // panels l1 .. lend - 1 share the block
+	if (l1 >= lend)
+		return;
+	auto next = [&](TqTxUnit u) {
+		const int cl = u.l * TQ_PW, wl = min(TQ_PW, a.n - cl);
+		if (u.type == 0) {
+			if (u.l + 1 < lend)
+				return TqTxUnit{0, u.l + 1, 0};
+			return TqTxUnit{1, l1, ck};
+		}
+		if (u.type == 1) {
+			if (u.x + 64 < cl + wl)
+				return TqTxUnit{1, u.l, u.x + 64};
+			return TqTxUnit{2, u.l, 0};
+		}
+		if (u.type == 2) {
+			if (u.l + 1 < lend)
+				return TqTxUnit{3, u.l, u.l + 1};
+			return TqTxUnit{4, 0, 0};
+		}
+		if (u.x + 1 < lend)
+			return TqTxUnit{3, u.l, u.x + 1};
+		return TqTxUnit{1, u.l + 1, ck};
+	};
+	// element (i, j) = (e >> 6, e & 63), e = tid + 256 q, of the operands of a product.  Only what comes from global memory
+	// is fetched ahead: the fp64 B operand of types 0 / 2 / 3 (rb) or the two fp32 chunks of type 1 (fa, fb); the A operand of
+	// type 0 (T_k) is loaded once, those of types 2 / 3 are written to LDS by the previous epilogue
+	auto fetch = [&](const TqTxUnit &u, double (&rb)[16], float (&fa)[16], float (&fb)[16]) {
+		const int cl = u.l * TQ_PW, wl = min(TQ_PW, a.n - cl);
+		if (u.type == 1) {
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {
+				// transposed fill: this thread handles row gr = x + (e & 63) of A and column ii = e >> 6 (lanes along the rows)
+				const int e = tid + 256 * q, gr = u.x + (e & 63), ii = e >> 6;
+				float va = 0.f, vb = 0.f;
+				if (gr < cl + wl) {
+					const int rr = gr - ck; // row inside V_k: unit lower trapezoid
+					va = rr < ii ? 0.f : (rr == ii ? 1.f : a.A[(long) (ck + ii) * a.ld + gr]);
+					if (ii < wl && !(gr - cl > ii)) // strictly below the diagonal of R_l the array holds V_l
+						vb = a.A[(long) (cl + ii) * a.ld + gr];
+				}
+				fa[q] = va;
+				fb[q] = vb;
+			}
+		} else {
+			const double *pb;
+			long ldb;
+			int ncol = 64;
+			if (u.type == 2) {
+				pb = a.Md + (long) u.l * 4096;
+				ldb = 64;
+			} else {
+				const int c0 = (u.type == 0 ? u.l : u.x) * TQ_PW;
+				pb = a.Z + (long) (u.type == 0 ? k : u.l) * 64 * a.ldz + c0;
+				ldb = a.ldz;
+				ncol = a.n - c0;
+			}
+#pragma unroll
+			for (int q = 0; q < 16; ++q) {
+				const int e = tid + 256 * q, i = e >> 6, j = e & 63;
+				rb[q] = j < ncol ? pb[(long) i * ldb + j] : 0.0;
+			}
+		}
+	};
+	auto stage = [&](const TqTxUnit &u, const double (&rb)[16], const float (&fa)[16], const float (&fb)[16]) {
+#pragma unroll
+		for (int q = 0; q < 16; ++q) {
+			const int e = tid + 256 * q, i = e >> 6, j = e & 63;
+			if (u.type == 1) { // Am[ii][row], Bm[row][ii]
+				Am[i * TQ_DP + j] = (double) fa[q];
+				Bm[j * TQ_DP + i] = (double) fb[q];
+			} else {
+				Bm[i * TQ_DP + j] = rb[q];
+			}
+		}
+	};
+	for (int e = tid; e < 4096; e += 256)
+		Am[(e >> 6) * TQ_DP + (e & 63)] = a.Td[(long) k * 4096 + e]; // T_k: the A operand of the type-0 products
+	f64x4 Bacc[TQ_TX_MAXL][4]; // B_l for the later panels: rows 16 wv .. + 15 (f64 16x16x4 result map: col = lane & 15, row = (lane >> 4) + 4 reg)
+	f64x4 acc[4], vr[4];
+#pragma unroll
+	for (int li = 0; li < TQ_TX_MAXL; ++li)
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+			Bacc[li][jb] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int jb = 0; jb < 4; ++jb)
+		vr[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
+	double rb[16];
+	float fa[16], fb[16];
+	TqTxUnit u{0, l1, 0};
+	fetch(u, rb, fa, fb);
+	while (u.type != 4) {
+		__syncthreads(); // the previous product has read its operands
+		stage(u, rb, fa, fb);
+		__syncthreads();
+		const TqTxUnit un = next(u);
+		if (un.type != 4)
+			fetch(un, rb, fa, fb); // in flight during the product
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+			acc[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
+		tq_mm64(acc, u.type == 3 ? Tm : Am, Bm, wv, lane);
+		const int li = u.l - l1;
+		if (u.type == 0) {
+#pragma unroll
+			for (int q = 0; q < TQ_TX_MAXL; ++q)
+				if (q == li)
+#pragma unroll
+					for (int jb = 0; jb < 4; ++jb)
+						Bacc[q][jb] = -acc[jb];
+		} else if (u.type == 1) {
+#pragma unroll
+			for (int jb = 0; jb < 4; ++jb)
+				vr[jb] += acc[jb];
+			if (un.type == 2) {
+				// Am = B_l - V_k^T R (this wavefront's 16 rows: read by tq_mm64 of the next product after its barrier)
+				__syncthreads(); // every wavefront has finished reading Am
+#pragma unroll
+				for (int q = 0; q < TQ_TX_MAXL; ++q)
+					if (q == li)
+#pragma unroll
+						for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+							for (int r = 0; r < 4; ++r)
+								Am[(16 * wv + (lane >> 4) + 4 * r) * TQ_DP + 16 * jb + (lane & 15)] = Bacc[q][jb][r] - vr[jb][r];
+#pragma unroll
+				for (int jb = 0; jb < 4; ++jb)
+					vr[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
+			}
+		} else if (u.type == 2) {
+			const int cl = u.l * TQ_PW, wl = min(TQ_PW, a.n - cl);
+#pragma unroll
+			for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const int i = 16 * wv + (lane >> 4) + 4 * r, j = 16 * jb + (lane & 15);
+					Tm[i * TQ_DP + j] = acc[jb][r]; // read as the A operand of the type-3 products (behind their barriers)
+					if (j < wl) {
+						const int gi = ck + i, gj = cl + j;
+						a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) acc[jb][r];
+					}
+				}
+		} else {
+			const int l2i = u.x - l1;
+#pragma unroll
+			for (int q = 0; q < TQ_TX_MAXL; ++q)
+				if (q == l2i)
+#pragma unroll
+					for (int jb = 0; jb < 4; ++jb)
+						Bacc[q][jb] -= acc[jb];
+		}
+		u = un;
+	}
+}
+
+// General form (any number of later panels in the block of Q_coeff): B in global memory, operands staged per product.
+__global__ __launch_bounds__(256) void tq_tx_general_kernel(const TqTxArgs a)
 {
 	__shared__ double Am[64 * TQ_DP], Bm[64 * TQ_DP], Tm[64 * TQ_DP];
 	if (a.stat[0])
@@ -1148,6 +1340,15 @@ __global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
 // ------------------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------------------
+static void tq_launch_update(bool vec, int nwg, const TqUpdArgs &ua)
+{
+	hipStream_t s = ctx().stream;
+	if (vec)
+		hipLaunchKernelGGL(tq_update_kernel<true>, dim3(nwg), dim3(256), 0, s, ua);
+	else
+		hipLaunchKernelGGL(tq_update_kernel<false>, dim3(nwg), dim3(256), 0, s, ua);
+}
+
 static void tq_gram(const float *P, const float *X, long ld, int rows, int w, int t, bool want_g, bool want_sq, bool vec, double *Gp, float *Cp,
 		    float *Sp, double *G, double *C, int ldc, int coff, double *S, const int *stat)
 {
@@ -1303,9 +1504,12 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			ua.nrb = (rows + 127) / 128;
 			ua.stat = stat;
 			ua.P = A.p + (long) c0 * ld + r1;
+			// one persistent workgroup per CU (its registers and LDS allow no second one): 256 measured 5 % ahead of 512 and
+			// 10 % ahead of 1024 workgroups on the 5e5 x 256 factorization
 			int nwg = (ua.nrb + 3) / 4;
-			if (nwg > TQ_NB)
-				nwg = TQ_NB;
+			const int ncu = ctx().stream_cus();
+			if (nwg > ncu)
+				nwg = ncu;
 			const int nstrip = (t + TQ_TS - 1) / TQ_TS;
 			const bool v2 = vec && r1 % 4 == 0;
 			for (int st = 0; st < nstrip || (st == 0 && nstrip == 0); ++st) {
@@ -1313,20 +1517,14 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 				ua.ts = nstrip == 0 ? 0 : (t - ua.coff < TQ_TS ? t - ua.coff : TQ_TS);
 				ua.X = A.p + (long) (c0 + w + ua.coff) * ld + r1;
 				ua.do_v = nstrip <= 1; // V overwrites P: only when no other launch still reads the panel
-				if (v2)
-					hipLaunchKernelGGL(tq_update_kernel<true>, dim3(nwg), dim3(256), 0, s, ua);
-				else
-					hipLaunchKernelGGL(tq_update_kernel<false>, dim3(nwg), dim3(256), 0, s, ua);
+				tq_launch_update(v2, nwg, ua);
 			}
 			if (nstrip > 1) {
 				ua.coff = 0;
 				ua.ts = 0;
 				ua.X = ua.P;
 				ua.do_v = 1;
-				if (v2)
-					hipLaunchKernelGGL(tq_update_kernel<true>, dim3(nwg), dim3(256), 0, s, ua);
-				else
-					hipLaunchKernelGGL(tq_update_kernel<false>, dim3(nwg), dim3(256), 0, s, ua);
+				tq_launch_update(v2, nwg, ua);
 			}
 		}
 		if (t > 0) {
@@ -1350,7 +1548,10 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		ta.hrs = H.rs;
 		ta.hcs = H.cs;
 		ta.stat = stat;
-		hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
+		if (bs <= (TQ_TX_MAXL + 1) * TQ_PW)
+			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
+		else
+			hipLaunchKernelGGL(tq_tx_general_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
 		FH_HIP(hipGetLastError());
 	}
 	int st[4];
