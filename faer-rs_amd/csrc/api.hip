@@ -145,6 +145,8 @@ template <typename T, typename I> FaerPartialPivLuStatus lu_api(FaerMatMut A, Fa
 	{
 		Staged<T> a(view<T>(A), true, true);
 		nt = getrf_dev<T>(a.dev, perm.data(), perm_inv.data());
+		if (nt < 0)
+			a.writeback = false; // Unknown (exchange timeout without room for the rerun): a host operand keeps its input
 	}
 	I *f = static_cast<I *>(pf.ptr), *b = static_cast<I *>(pb.ptr);
 	for (idx_t i = 0; i < m; ++i) {
@@ -1402,6 +1404,11 @@ int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, int resident_
 {
 	return lu_leaf_width((idx_t) nrows, dtype == FaerHipDType_F64 ? 8 : 4, resident_workgroups);
 }
+int faer_hip_debug_dist_two_streams_ok(size_t panel_rows, FaerHipDType dtype, int panel_cus, int all_cus)
+{
+	return dist_two_streams_ok((idx_t) panel_rows, dtype == FaerHipDType_F64 ? 8 : 4, panel_cus, all_cus) ? 1 : 0;
+}
+void faer_hip_debug_lu_force_general(int on) { lu_force_general(on); }
 void *faer_hip_debug_internal_stream(int which)
 {
 	Ctx &c = ctx();

@@ -281,6 +281,8 @@ template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, 
 // pure host planning logic, exported for the CPU tests (faer_hip_debug_*)
 std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2);
 int lu_leaf_width(idx_t m, int elem_bytes, int resident_workgroups);
+bool dist_two_streams_ok(idx_t panel_rows, int elem_bytes, int panel_cus, int all_cus);
+void lu_force_general(int on); // debug: every LU leaf on the non-cooperative path
 // tall-skinny shapes (skinny.hip): streaming kernels; false if the shape / strides do not qualify
 template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV<const T> B, T alpha);
 // C <- [C +] alpha * sum_z ws[z] (slices of nrows x ncols, column major), fixed summation order (gemm.hip)

@@ -64,7 +64,7 @@ template <typename S> struct DeviceBackend {
 	// trailing entries per step) runs 57.2 ms on one stream, 59.7 ms with the two streams in every step; the single-GPU
 	// driver's N = 16384 (2.5e8 entries in the first step) needs them (121 vs 193 ms).  Steps with fewer than 1e8 trailing
 	// entries on this rank run on the caller's stream (FAER_HIP_DIST_TWO_MIN overrides; the count only shrinks).
-	void step_begin(long local_trailing_entries)
+	void step_begin(long local_trailing_entries, long next_panel_rows)
 	{
 		if (!two)
 			return;
@@ -74,7 +74,10 @@ template <typename S> struct DeviceBackend {
 			stream_wait(caller, ev_bulk);
 			ev_bulk = nullptr;
 		}
-		two_now = local_trailing_entries >= two_min_work;
+		// the look-ahead panel is factored on the CU-masked panel stream: its cooperative leaves must fit those CUs at the
+		// width they would have on the whole chip (dist_two_streams_ok, getrf.hip) -- beyond 131072 fp64 rows they do not
+		// fit at all and the leaf would abort
+		two_now = local_trailing_entries >= two_min_work && dist_two_streams_ok(next_panel_rows, (int) sizeof(T), ctx().la_panel_cus, ctx().ncu > 0 ? ctx().ncu : 256);
 		if (!two_now)
 			return;
 		ev0 = ctx().next_event();

@@ -30,7 +30,7 @@ namespace fh {
 //   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)
 //                                                        -- collective on the backend's memory space; may be
 //                                                           asynchronous (slot = 0 / 1, at most one in flight each)
-//   void step_begin(long local_trailing_entries) / void rest_begin() / rest_end() / ahead_begin() / ahead_end() / ahead_join()
+//   void step_begin(long local_trailing_entries, long next_panel_rows) / void rest_begin() / rest_end() / ahead_begin() / ahead_end() / ahead_join()
 //                                                        -- scheduling hooks (no-ops for a synchronous backend): the
 //                                                           device backend runs the "rest" updates of a step on the
 //                                                           bulk stream and the look-ahead part (update + panel of
@@ -140,7 +140,7 @@ template <class B> struct DistLu {
 				for (long b = rank; b < nblk_all; b += world)
 					if (b > k)
 						right += (b * nb + nb <= n) ? nb : n - b * nb;
-				be.step_begin((m - k * nb) * right); // entries of the trailing matrix this rank updates in this step
+				be.step_begin((m - k * nb) * right, m - (k + 1) * nb); // trailing entries this rank updates in this step; rows of the next panel
 			}
 			// The rest of update k on ALL the local block columns at once: the columns of the blocks left of the panel are one
 			// contiguous range of A_local (interchanges only), those of the blocks right of it another one (interchanges, ONE

@@ -26,6 +26,8 @@
 // (getrf_lookahead).
 #include <climits>
 
+#include <atomic>
+
 #include "common.h"
 #include "lds_blocks.h"
 #include "xwg.h"
@@ -1203,6 +1205,7 @@ template <typename T> struct LuWork {
 	xwg_u64 epoch_base; // epochs consumed by earlier leaf launches of this factorization
 	int *status;
 	hipEvent_t after_leaf = nullptr; // look-ahead: the stream waits for this event right after the next leaf launch
+	bool general = false;		 // every leaf on the non-cooperative path (rerun after an exchange timeout, debug switch)
 };
 
 // rows per workgroup of the cooperative kernel for a leaf of w columns (registers: RPT x W scalars per thread)
@@ -1237,11 +1240,168 @@ int lu_leaf_width(idx_t m, int elem_bytes, int cap)
 	}
 	return 0;
 }
-template <typename T> static int leaf_width_for(idx_t m)
+// The distributed driver factors the look-ahead panel on the CU-masked panel stream only when its cooperative leaves keep,
+// on those `panel_cus` CUs, the width they would have on the whole chip (pure host logic: faer_hip_debug_dist_two_streams_ok)
+bool dist_two_streams_ok(idx_t panel_rows, int elem_bytes, int panel_cus, int all_cus)
 {
-	const int w = lu_leaf_width(m, (int) sizeof(T), resident_workgroups());
-	FH_CHECK(w > 0, "partial_piv_lu: more rows than the cooperative panel kernel can keep resident (1,048,576 fp64 / 2,097,152 fp32 rows on 256 CUs)");
-	return w;
+	if (panel_rows <= 0)
+		return true;
+	const int w = lu_leaf_width(panel_rows, elem_bytes, panel_cus);
+	return w > 0 && w == lu_leaf_width(panel_rows, elem_bytes, all_cus);
+}
+// 0: the panel is taller than the cooperative kernel can keep resident -> the non-cooperative leaf (getrf_leaf_general)
+template <typename T> static int leaf_width_for(idx_t m) { return lu_leaf_width(m, (int) sizeof(T), resident_workgroups()); }
+
+static std::atomic<int> g_lu_force_general{0}; // faer_hip_debug_lu_force_general: tests run the whole suite of shapes on the fallback
+void lu_force_general(int on) { g_lu_force_general.store(on); }
+
+// ------------------------------------------------------------------------------------------------
+// Non-cooperative leaf: the same unblocked elimination (factor.rs:19-67: first largest |a| of the column, interchange,
+// reciprocal scaling, rank-1 update with fma(l, -u, dst)) as three plain launches per column -- no workgroup has to be
+// resident together with any other, so it takes ANY number of rows and cannot time out.  It is the fallback of the
+// cooperative panel kernel: panels taller than its residency limit (the reference has no such limit,
+// lu/partial_pivoting/factor.rs:234-295) and the rerun after an exchange timeout (GPU shared with other work).
+// ~3 launches x 64 columns per leaf: slow, by design never on the fast path.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct LugArgs {
+	T *P;
+	idx_t rs, cs;
+	int m, w, j;
+	int *piv;
+	int row_base;
+	double *pv; // per workgroup: best |a| ...
+	int *pr;    // ... and its row
+	int nwg;
+	T *urow; // row j after the interchange (w entries)
+};
+
+template <typename T> __global__ __launch_bounds__(256) void lug_argmax_kernel(const LugArgs<T> a)
+{
+	__shared__ double sv[256];
+	__shared__ int sr[256];
+	const int tid = threadIdx.x;
+	double bv = 0.0;
+	int br = INT_MAX;
+	// ascending rows per thread, strictly greater: the first largest of the thread's rows
+	for (long i = (long) a.j + (long) blockIdx.x * 256 + tid; i < a.m; i += (long) gridDim.x * 256) {
+		const double av = fabs((double) a.P[i * a.rs + (idx_t) a.j * a.cs]);
+		if (av > bv) {
+			bv = av;
+			br = (int) i;
+		}
+	}
+	sv[tid] = bv;
+	sr[tid] = br;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if (tid < o && better(sv[tid + o], sr[tid + o], sv[tid], sr[tid])) {
+			sv[tid] = sv[tid + o];
+			sr[tid] = sr[tid + o];
+		}
+		__syncthreads();
+	}
+	if (tid == 0) {
+		a.pv[blockIdx.x] = sv[0];
+		a.pr[blockIdx.x] = sr[0];
+	}
+}
+
+template <typename T> __global__ __launch_bounds__(256) void lug_pivot_kernel(const LugArgs<T> a)
+{
+	__shared__ double sv[256];
+	__shared__ int sr[256];
+	__shared__ int s_p;
+	const int tid = threadIdx.x;
+	double bv = 0.0;
+	int br = INT_MAX;
+	for (int g = tid; g < a.nwg; g += 256)
+		if (better(a.pv[g], a.pr[g], bv, br)) {
+			bv = a.pv[g];
+			br = a.pr[g];
+		}
+	sv[tid] = bv;
+	sr[tid] = br;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if (tid < o && better(sv[tid + o], sr[tid + o], sv[tid], sr[tid])) {
+			sv[tid] = sv[tid + o];
+			sr[tid] = sr[tid + o];
+		}
+		__syncthreads();
+	}
+	if (tid == 0) {
+		const int p = (sv[0] > 0.0 && sr[0] != INT_MAX) ? sr[0] : a.j; // zero / NaN-only column: no interchange
+		s_p = p;
+		a.piv[a.j] = a.row_base + p;
+	}
+	__syncthreads();
+	const int p = s_p;
+	for (int c = tid; c < a.w; c += 256) {
+		T *xj = a.P + (idx_t) a.j * a.rs + (idx_t) c * a.cs, *xp = a.P + (idx_t) p * a.rs + (idx_t) c * a.cs;
+		const T vj = *xj, vp = *xp;
+		if (p != a.j) {
+			*xj = vp;
+			*xp = vj;
+		}
+		a.urow[c] = vp; // row j after the interchange (p == j: vp == vj)
+	}
+}
+
+template <typename T> __global__ __launch_bounds__(256) void lug_update_kernel(const LugArgs<T> a)
+{
+	__shared__ T su[LU_WMAX];
+	const int tid = threadIdx.x;
+	if (tid < a.w)
+		su[tid] = a.urow[tid];
+	__syncthreads();
+	const T inv = (T) 1 / su[a.j];
+	for (long i = (long) a.j + 1 + (long) blockIdx.x * 256 + tid; i < a.m; i += (long) gridDim.x * 256) {
+		T *row = a.P + i * a.rs;
+		const T l = row[(idx_t) a.j * a.cs] * inv;
+		row[(idx_t) a.j * a.cs] = l;
+		for (int c = a.j + 1; c < a.w; ++c)
+			row[(idx_t) c * a.cs] = fh_fma(l, -su[c], row[(idx_t) c * a.cs]); // rank_update_imp: fma(l_i, -u_c, dst)
+	}
+}
+
+template <typename T> static void getrf_leaf_general(MatV<T> P, int col0, int row_base, LuWork<T> &wk)
+{
+	const idx_t m = P.nrows;
+	const int w = (int) P.ncols;
+	FH_CHECK(w <= LU_WMAX, "getrf leaf: panel too wide");
+	hipStream_t s = ctx().stream;
+	int nwg = (int) ((m + 255) / 256);
+	if (nwg > 1024)
+		nwg = 1024;
+	if (nwg < 1)
+		nwg = 1;
+	// (released on return while the launches may still be queued: the pool hands a buffer back to the SAME stream only)
+	Scratch pvb((size_t) nwg * sizeof(double)), prb((size_t) nwg * sizeof(int)), ub((size_t) LU_WMAX * sizeof(T));
+	LugArgs<T> a;
+	a.P = P.p;
+	a.rs = P.rs;
+	a.cs = P.cs;
+	a.m = (int) m;
+	a.w = w;
+	a.piv = wk.piv + col0;
+	a.row_base = row_base;
+	a.pv = pvb.as<double>();
+	a.pr = prb.as<int>();
+	a.nwg = nwg;
+	a.urow = ub.as<T>();
+	const int steps = w < (int) m ? w : (int) m;
+	for (int j = 0; j < steps; ++j) {
+		a.j = j;
+		hipLaunchKernelGGL(lug_argmax_kernel<T>, dim3(nwg), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(lug_pivot_kernel<T>, dim3(1), dim3(256), 0, s, a);
+		if (j + 1 < (int) m)
+			hipLaunchKernelGGL(lug_update_kernel<T>, dim3(nwg), dim3(256), 0, s, a);
+	}
+	FH_HIP(hipGetLastError());
+	if (wk.after_leaf) {
+		stream_wait(s, wk.after_leaf);
+		wk.after_leaf = nullptr;
+	}
 }
 
 // FAER_HIP_LU_PANEL=3 selects the second-generation panel kernel (one hop per column on the dependent chain, logical
@@ -1284,6 +1444,10 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 	const idx_t m = P.nrows;
 	const int w = (int) P.ncols;
 	int lw = leaf_width_for<T>(m);
+	if (wk.general || lw == 0 || g_lu_force_general.load()) {
+		getrf_leaf_general<T>(P, col0, row_base, wk);
+		return;
+	}
 	FH_CHECK(w <= lw, "getrf leaf: panel too wide");
 	while (lw / 2 >= w && lw > 8)
 		lw /= 2; // a narrower panel fits the narrower (taller) shape just as well: fewer workgroups to synchronise
@@ -1343,9 +1507,13 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 	const idx_t m = P.nrows, n = P.ncols; // n <= m
 	if (n == 0)
 		return;
-	if (n <= leaf_width_for<T>(m)) {
-		getrf_leaf<T>(P, col0, row_base, wk);
-		return;
+	{
+		const int lw = leaf_width_for<T>(m);
+		const bool gen = wk.general || lw == 0 || g_lu_force_general.load(); // non-cooperative leaves: always LU_W columns
+		if (n <= (gen ? LU_W : lw)) {
+			getrf_leaf<T>(P, col0, row_base, wk);
+			return;
+		}
 	}
 	// factor.rs:84-86 split rule
 	const idx_t half = n / 2;
@@ -1518,13 +1686,45 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
 		FH_HIP(hipMemsetAsync(granb.p, 0, gran_bytes + diag_bytes, ctx().stream));
 
+		// The cooperative leaves exchange pivots between RESIDENT workgroups; on a GPU shared with other work a workgroup may
+		// not get its CU within the bounded spin and the exchange times out -- with the panel kernels returning before they
+		// store anything, but with later launches already consuming stale pivots.  The factorization is then redone from a
+		// copy of A on the non-cooperative leaves (getrf_leaf_general), so that a valid input never comes back as
+		// PartialPivLuStatus::Unknown (lu/partial_pivoting/factor.rs:234-295 has no failure mode).  The copy costs one pass
+		// over A (0.8 of ~100 ms at N = 16384); it is skipped -- and Unknown stays possible -- only when it does not fit.
+		const bool force_general = g_lu_force_general.load() != 0;
+		const size_t a_bytes = (size_t) m * (size_t) size * sizeof(T);
+		size_t mem_free = 0, mem_total = 0;
+		bool have_backup = false;
+		if (!force_general && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+			have_backup = a_bytes <= mem_free / 2;
+		Scratch backup(have_backup ? a_bytes : 256);
+		MatV<T> Bk{backup.as<T>(), m, size, 1, m};
+		if (have_backup)
+			copy_dev<T>(Bk, A.sub(0, 0, m, size).c());
+
 		// look-ahead needs every workgroup of a cooperative leaf resident on the CUs reserved for the panel stream
 		const idx_t leaf_r = leaf_rows_per_wg<T>(LU_W);
-		const bool la = size >= 8 * LU_LA_NB && ctx().lookahead_streams() && (m + leaf_r - 1) / leaf_r <= (idx_t) ctx().la_panel_cus;
+		const bool la = !force_general && size >= 8 * LU_LA_NB && ctx().lookahead_streams() && (m + leaf_r - 1) / leaf_r <= (idx_t) ctx().la_panel_cus;
 		if (la)
 			getrf_lookahead<T>(A.sub(0, 0, m, size), wk, ctx().stream);
 		else
 			getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);
+		if (have_backup) {
+			int st2[4] = {0, 0, 0, 0};
+			FH_HIP(hipMemcpyAsync(st2, wk.status, sizeof(st2), hipMemcpyDeviceToHost, ctx().stream));
+			ctx().sync();
+			ctx().quiesce();
+			if (st2[2] != 0) {
+				fprintf(stderr, "faer_hip: partial_piv_lu: the cross-workgroup exchange of the panel kernel timed out (GPU shared with other "
+						"work?); redoing the factorization on the non-cooperative path\n");
+				copy_dev<T>(A.sub(0, 0, m, size), Bk.c());
+				FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
+				wk.general = true;
+				wk.after_leaf = nullptr;
+				getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);
+			}
+		}
 		if (m < n) { // factor.rs:278-285 (+ the swaps of the columns right of the square part)
 			MatV<T> right = A.sub(0, size, m, n - size);
 			laswp_dev<T>(right, wk.piv, (int) size, 0);

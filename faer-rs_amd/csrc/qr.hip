@@ -1872,7 +1872,7 @@ template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
 	const idx_t size = m < n ? m : n;
 	FH_CHECK(Hl.ncols == size && Hr.ncols == (size > 0 ? size - 1 : 0), "bidiag: householder factors must have n and n - 1 columns");
 	FH_CHECK((Hl.nrows > 0 || size == 0) && (Hr.nrows > 0 || size <= 1), "bidiag: householder factors need at least one row");
-	FH_CHECK(m < (1L << 30), "bidiag: matrix too large");
+	FH_CHECK(m < (1L << 30) && n < (1L << 30), "bidiag: matrix too large");
 	if (size == 0)
 		return;
 	hipStream_t s = ctx().stream;

@@ -13,6 +13,8 @@
 //     computed once: x_j <- x_j * (1 / t_jj).
 // Upper triangles are lower triangles on the row/column reversed views (triangular_solve.rs:578-604);
 // every kernel here takes signed strides so the reversal is free.
+#include <atomic>
+
 #include "common.h"
 #include "lds_blocks.h"
 #include "mfma.h"
@@ -524,12 +526,16 @@ template <typename T, int RW> static size_t trsm_leaf128_lds()
 template <typename T, bool DIRECT, int RW>
 static void trsm_leaf128_go(const T *src, idx_t n, MatV<T> X, int along_rhs, idx_t trs, idx_t tcs, int unit)
 {
-	static bool attr_done = false; // raise the dynamic LDS limit once per process and instance
+	// raise the dynamic LDS limit once per DEVICE and instance: the attribute belongs to the device that is current at the
+	// time of the call, and a thread bound to a second GPU must not launch without it (atomic flags: several threads)
+	static std::atomic<unsigned long long> attr_done{0}; // bit d: device d
 	const size_t lds = trsm_leaf128_lds<T, RW>();
-	if (!attr_done) {
+	const int dev = ctx().device;
+	const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+	if (bit == 0 || !(attr_done.load(std::memory_order_acquire) & bit)) {
 		FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_leaf128_kernel<T, DIRECT, RW>), hipFuncAttributeMaxDynamicSharedMemorySize,
 					   (int) lds));
-		attr_done = true;
+		attr_done.fetch_or(bit, std::memory_order_release);
 	}
 	const idx_t k = X.ncols;
 	const dim3 grid((unsigned) ((k + TL_NW * RW - 1) / (TL_NW * RW)));

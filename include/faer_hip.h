@@ -479,6 +479,11 @@ FAER_HIP_API void faer_hip_debug_stream_xcc(int which, int nblocks, unsigned *ou
  * the cooperative LU panel kernel picks for `nrows` rows when `resident_workgroups` workgroups fit the device. */
 FAER_HIP_API size_t faer_hip_debug_llt_plan(size_t n, size_t tail_rows, size_t nb2, size_t *starts, size_t cap);
 FAER_HIP_API int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, int resident_workgroups);
+/* tests: run every leaf of the partial-pivot LU on the non-cooperative path (the fallback for panels taller than the
+ * cooperative kernel can keep resident and for the rerun after an exchange timeout) */
+FAER_HIP_API void faer_hip_debug_lu_force_general(int on);
+/* host logic of the distributed LU: may a step factor its look-ahead panel of `panel_rows` rows on the CU-masked panel stream? */
+FAER_HIP_API int faer_hip_debug_dist_two_streams_ok(size_t panel_rows, FaerHipDType dtype, int panel_cus, int all_cus);
 /* Instrumented builds (make -C csrc timing): prints and resets the in-kernel phase counters; a no-op otherwise. */
 FAER_HIP_API void faer_hip_debug_dump_timing(void);
 /* The internal CU-masked streams themselves (1 = bulk, 2 = panel), for microbenchmarks via faer_hip_set_stream. */

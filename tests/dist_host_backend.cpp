@@ -101,7 +101,7 @@ struct HostBackend {
 	}
 	void bcast_wait(int slot) { ++waited[slot]; }
 	// scheduling hooks of the asynchronous device backend: nothing to do on the host
-	void step_begin(long) {}
+	void step_begin(long, long) {}
 	void rest_begin() {}
 	void rest_end() {}
 	void ahead_begin() {}

@@ -110,6 +110,12 @@ def test_driver_planning_logic_needs_no_gpu():
     assert w(200000, F.DTYPE_F64, 256) == 32 and w(600000, F.DTYPE_F64, 256) == 8
     assert w(1048576, F.DTYPE_F64, 256) == 8 and w(1048577, F.DTYPE_F64, 256) == 0
     assert w(300000, F.DTYPE_F32, 256) == 32 and w(2097152, F.DTYPE_F32, 256) == 8 and w(2097153, F.DTYPE_F32, 256) == 0
+    # distributed LU: the look-ahead panel goes to the 32-CU panel stream only while its leaves keep their whole-chip width
+    # there (beyond 131072 fp64 rows they would not fit at all and the leaf would abort: ADVICE r02)
+    ok = lambda rows, dt: lib.faer_hip_debug_dist_two_streams_ok(C.c_size_t(rows), C.c_int(dt), 32, 256)  # noqa: E731
+    assert ok(16384, F.DTYPE_F64) == 1 and ok(16385, F.DTYPE_F64) == 0 and ok(131072, F.DTYPE_F64) == 0
+    assert ok(200000, F.DTYPE_F64) == 0 and ok(2000000, F.DTYPE_F64) == 0 and ok(0, F.DTYPE_F64) == 1
+    assert ok(32768, F.DTYPE_F32) == 1 and ok(32769, F.DTYPE_F32) == 0
 
 
 def test_header_is_valid_c99_and_cxx17(tmp_path):

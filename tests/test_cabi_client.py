@@ -52,12 +52,13 @@ def test_clients_compile_link_and_run_host_only():
         assert "ok (host-only)" in r.stdout
 
 
-def test_abi_compat_is_up_to_date():
-    """csrc/abi_compat.c is generated from include/faer_hip.h: regenerating it must not change it"""
+def test_abi_compat_is_up_to_date(tmp_path):
+    """csrc/abi_compat.c is generated from include/faer_hip.h: a fresh generation (into a temporary file -- the tracked
+    file is never rewritten by the test run) must be identical"""
     path = os.path.join(LIBDIR, "csrc", "abi_compat.c")
-    before = open(path).read()
-    subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_abi_compat.py")], check=True, capture_output=True)
-    assert open(path).read() == before
+    fresh = str(tmp_path / "abi_compat.c")
+    subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_abi_compat.py"), fresh], check=True, capture_output=True)
+    assert open(fresh).read() == open(path).read()
 
 
 def test_v024_aliases_and_stubs_are_exported():
@@ -79,5 +80,7 @@ def test_clients_compute_on_the_gpu(name):
     if not os.path.exists(b):
         pytest.skip("client binaries are built where the reference tree is available (__graft_entry__.build())")
     r = subprocess.run([b, "compute"], capture_output=True, text=True, timeout=300)
+    if r.returncode == 2 and "no gfx950 device" in (r.stdout + r.stderr):
+        pytest.skip("no gfx950 device visible to the client")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok (compute)" in r.stdout

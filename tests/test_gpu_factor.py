@@ -206,6 +206,46 @@ def test_plu_vs_oracle(oracle, m, n, dtype):
     assert np.abs(lu - ref).max() <= 4 * max(m, n) * e * kappa * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("m,n", [(3, 3), (33, 33), (300, 8), (8, 300), (257, 257), (1000, 700), (2000, 64), (700, 1000)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_plu_non_cooperative_leaves_vs_oracle(oracle, m, n, dtype):
+    """the fallback of the cooperative panel kernel (getrf.hip getrf_leaf_general: taller panels than it can keep resident,
+    rerun after an exchange timeout) forced on for ordinary shapes: identical pivots, factors within the forward error"""
+    F = init_gpu()
+    rng = np.random.default_rng(m * 5 + n)
+    a = rnd(rng, m, n, dtype)
+    ref = a.copy(order="F")
+    rperm, rinv, rnt = oracle.lu_in_place(ref)
+    dlu = to_dev(a)
+    F.lib().faer_hip_debug_lu_force_general(1)
+    try:
+        perm, perm_inv, nt = F.partial_piv_lu_factor_in_place(dlu)
+    finally:
+        F.lib().faer_hip_debug_lu_force_general(0)
+    lu = to_host(dlu)
+    perm = perm.astype(np.int64)
+    size = min(m, n)
+    e = EPS[np.dtype(dtype)]
+    assert (perm == rperm).all() and nt == rnt
+    kappa = np.linalg.cond(a[perm][:size, :size].astype(np.float64))
+    assert np.abs(lu - ref).max() <= 4 * max(m, n) * e * kappa * max(1.0, np.abs(ref).max())
+
+
+def test_plu_taller_than_the_cooperative_limit(oracle):
+    """1 100 000 fp64 rows: more than the cooperative kernel keeps resident on 256 CUs (1 048 576).  The reference has no
+    such limit (lu/partial_pivoting/factor.rs:234-295); round 2 aborted here, now the non-cooperative leaf takes over"""
+    F = init_gpu()
+    m, n = 1100000, 6
+    rng = np.random.default_rng(99)
+    a = rnd(rng, m, n, np.float64)
+    ref = a.copy(order="F")
+    rperm, _, rnt = oracle.lu_in_place(ref)
+    dlu = to_dev(a)
+    perm, _, nt = F.partial_piv_lu_factor_in_place(dlu)
+    assert (perm.astype(np.int64) == rperm).all() and nt == rnt
+    assert np.abs(to_host(dlu) - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
 def test_plu_ties_and_zero_column(oracle):
     """first strictly largest |a_ij| wins; an all-zero column keeps the diagonal (factor.rs:35-43)"""
     F = init_gpu()
