@@ -324,10 +324,29 @@ def main():
     if overhead is not None:  # restoring the input is not part of the factorization
         odt, odt_ev = timed(overhead, args.steps, 1)
         dt, dt_ev = max(dt - odt, 1e-9), max(dt_ev - odt_ev, 1e-9)
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt, dt_ev], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_ev = t[0].item(), t[1].item()
+        if args.workload in ("lu", "llt"):
+            # per rank, from the LAST timed factorization: device time of the call, of the panels the rank owned (the serial
+            # chain of a 1-D block-cyclic factorization) and -- with the built-in transport -- inside ncclBroadcast, plus the
+            # number of ranks RCCL itself reports: what a scaling curve is read against
+            ds = F.dist_last_stats()
+            rs = rccl.stats() if rccl is not None else {"ncclCommCount": -1, "broadcasts": 0, "bytes": 0.0, "bcast_device_ms": 0.0}
+            mine = torch.tensor([ds["total_device_ms"], ds["panel_device_ms"], ds["panels_owned"], rs["ncclCommCount"], rs["broadcasts"],
+                                 rs["bytes"], rs["bcast_device_ms"] / max(args.steps + args.warmup, 1)], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            allr = torch.stack(allr).cpu().numpy()
+            per_rank = {"total_device_ms": [round(float(x), 3) for x in allr[:, 0]],
+                        "panel_device_ms": [round(float(x), 3) for x in allr[:, 1]],
+                        "panels_owned": [int(x) for x in allr[:, 2]],
+                        "update_and_wait_device_ms": [round(float(a - b), 3) for a, b in zip(allr[:, 0], allr[:, 1])],
+                        "ncclCommCount": [int(x) for x in allr[:, 3]],
+                        "bcast_device_ms_per_factorization": [round(float(x), 3) for x in allr[:, 6]],
+                        "transport": args.transport}
     ms_per_step = dt / args.steps * 1e3
     value = flops * world * args.steps / dt / 1e9  # whole-job GFLOP/s
 
@@ -350,6 +369,8 @@ def main():
                        else f"block columns of C over {world} GPUs, no collective")},
     }
 
+    if per_rank is not None:
+        out["per_rank"] = per_rank
     if rank == 0:
         # ---------------------------------------------------------------- roofline of the dominant kernel
         if args.workload == "gemm":

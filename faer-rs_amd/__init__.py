@@ -570,10 +570,25 @@ class RcclTransport:
         self.handle = L.faer_hip_rccl_create((C.c_ubyte * 128).from_buffer_copy(unique_id), int(rank), int(world_size))
         self.comm = L.faer_hip_rccl_comm(C.c_void_p(self.handle))
 
+    def stats(self):
+        """{ranks the communicator reports (ncclCommCount), broadcasts, bytes, device ms inside ncclBroadcast} since the last call"""
+        out = (C.c_double * 4)()
+        L = lib()
+        L.faer_hip_rccl_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.faer_hip_rccl_stats(C.c_void_p(self.handle), out)
+        return {"ncclCommCount": int(out[0]), "broadcasts": int(out[1]), "bytes": float(out[2]), "bcast_device_ms": float(out[3])}
+
     def close(self):
         if self.handle:
             lib().faer_hip_rccl_destroy(C.c_void_p(self.handle))
             self.handle = None
+
+
+def dist_last_stats():
+    """the calling thread's last distributed factorization: device ms of the call, of the panels this rank owned, their count"""
+    out = (C.c_double * 3)()
+    lib().faer_hip_dist_last_stats(out)
+    return {"total_device_ms": float(out[0]), "panel_device_ms": float(out[1]), "panels_owned": int(out[2])}
 
 
 def dist_local_ncols(n, nb, rank, world_size):

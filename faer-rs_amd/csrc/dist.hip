@@ -9,8 +9,44 @@ using namespace fh;
 
 namespace {
 
+// per-thread record of the last distributed factorization (faer_hip_dist_last_stats): device time between its first and last
+// launch on the caller's stream, and the time of the panel factorizations THIS rank owned (timing events on the stream they
+// ran on) -- what bench.py prints per rank so that a scaling curve can be read against the model of DESIGN.md section 4
+struct DistStats {
+	double total_ms = 0, panel_ms = 0;
+	int panels = 0;
+};
+thread_local DistStats g_dist_stats;
+
+struct PhaseTimer {
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+	void begin()
+	{
+		hipEvent_t a, b;
+		FH_HIP(hipEventCreate(&a));
+		FH_HIP(hipEventCreate(&b));
+		FH_HIP(hipEventRecord(a, ctx().stream));
+		ev.emplace_back(a, b);
+	}
+	void end() { FH_HIP(hipEventRecord(ev.back().second, ctx().stream)); }
+	double harvest() // after the run has been synchronised
+	{
+		double ms = 0;
+		for (auto &p : ev) {
+			float t = 0;
+			if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess)
+				ms += t;
+			(void) hipEventDestroy(p.first);
+			(void) hipEventDestroy(p.second);
+		}
+		ev.clear();
+		return ms;
+	}
+};
+
 template <typename S> struct DeviceBackend {
 	typedef S T;
+	PhaseTimer t_panel, t_total;
 	struct View {
 		T *p;
 		long nrows, ncols, rs, cs;
@@ -19,7 +55,12 @@ template <typename S> struct DeviceBackend {
 
 	static MatV<T> mv(View v) { return MatV<T>{v.p, v.nrows, v.ncols, v.rs, v.cs}; }
 	int *lu_status = nullptr; // 16 zeroed device ints: the panel kernels' status words, read once at the end
-	void factor_panel(View P, int *piv_out) { getrf_panel_dev<T>(mv(P), piv_out, lu_status); }
+	void factor_panel(View P, int *piv_out)
+	{
+		t_panel.begin();
+		getrf_panel_dev<T>(mv(P), piv_out, lu_status);
+		t_panel.end();
+	}
 	void laswp(View B, const int *piv, int nt) { laswp_rows_dev<T>(mv(B), piv, nt); }
 	void trsm_unit_lower(View L, View X) { trsm_lower_dev<T>(mv(L).c(), true, mv(X)); }
 	void gemm_sub(View C, View A, View B) { gemm_dev<T>(mv(C), DST_FULL, true, mv(A).c(), mv(B).c(), (T) -1); }
@@ -137,7 +178,12 @@ template <typename S> struct DeviceBackend {
 	}
 	// ---- Cholesky (dist_llt.h)
 	T reg_delta = (T) 0, reg_eps = (T) 0;
-	void potrf_panel(View P, long offset, int *status) { potrf_panel_dev<T>(mv(P), reg_delta, reg_eps, status, (idx_t) offset); }
+	void potrf_panel(View P, long offset, int *status)
+	{
+		t_panel.begin();
+		potrf_panel_dev<T>(mv(P), reg_delta, reg_eps, status, (idx_t) offset);
+		t_panel.end();
+	}
 	void syrk_sub(View C, View A, View Bt) { gemm_dev<T>(mv(C), DST_LOWER, true, mv(A).c(), mv(Bt).t().c(), (T) -1); }
 	void to_host(int *dst, const int *src, size_t n)
 	{
@@ -168,10 +214,15 @@ FaerPartialPivLuStatus dist_lu_api(FaerMatMut A_local, size_t n_global, size_t n
 	typename B::View Av{static_cast<T *>(A_local.ptr), m, (long) A_local.ncols, 1, (long) A_local.col_stride};
 	const long size = m < n ? m : n;
 	std::vector<int> piv((size_t) size);
+	be.t_total.begin();
 	DistLu<B>::run(be, Av, m, n, (long) nb, comm.rank, comm.world_size, static_cast<T *>(panel_ws), piv.data());
+	be.t_total.end();
 	int lst[4] = {0, 0, 0, 0};
 	FH_HIP(hipMemcpyAsync(lst, be.lu_status, sizeof(lst), hipMemcpyDeviceToHost, ctx().stream));
 	ctx().sync(); // the run joined both internal streams into the caller's
+	g_dist_stats.panels = (int) be.t_panel.ev.size();
+	g_dist_stats.panel_ms = be.t_panel.harvest();
+	g_dist_stats.total_ms = be.t_total.harvest();
 	if (be.two)
 		ctx().quiesce();
 	if (lst[2] != 0) { // a cooperative panel kernel of THIS rank gave up waiting for its peers (getrf.hip): factors are garbage
@@ -221,8 +272,13 @@ FaerLltStatus dist_llt_api(FaerMatMut A_local, size_t n_global, size_t nb, FaerL
 	be.reg_delta = reg.dynamic_regularization_delta ? *static_cast<const T *>(reg.dynamic_regularization_delta) : (T) 0;
 	be.reg_eps = reg.dynamic_regularization_epsilon ? *static_cast<const T *>(reg.dynamic_regularization_epsilon) : (T) 0;
 	typename B::View Av{static_cast<T *>(A_local.ptr), n, (long) A_local.ncols, 1, (long) A_local.col_stride};
+	be.t_total.begin();
 	const long r = DistLlt<B>::run(be, Av, n, (long) nb, comm.rank, comm.world_size, static_cast<T *>(panel_ws));
+	be.t_total.end();
 	ctx().sync();
+	g_dist_stats.panels = (int) be.t_panel.ev.size();
+	g_dist_stats.panel_ms = be.t_panel.harvest();
+	g_dist_stats.total_ms = be.t_total.harvest();
 	if (r >= 0) {
 		st.ok.dynamic_regularization_count = (size_t) r;
 	} else {
@@ -235,6 +291,12 @@ FaerLltStatus dist_llt_api(FaerMatMut A_local, size_t n_global, size_t nb, FaerL
 } // namespace
 
 extern "C" {
+void faer_hip_dist_last_stats(double *out3)
+{
+	out3[0] = g_dist_stats.total_ms;
+	out3[1] = g_dist_stats.panel_ms;
+	out3[2] = (double) g_dist_stats.panels;
+}
 size_t faer_hip_dist_llt_ws_scalars(size_t n, size_t nb, FaerHipDType dtype)
 {
 	return dtype == FaerHipDType_F64 ? DistLlt<DeviceBackend<double>>::ws_scalars((long) n, (long) nb)

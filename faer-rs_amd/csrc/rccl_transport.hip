@@ -7,6 +7,9 @@
 // (faer_hip_rccl_unique_id) and the application ships to the other ranks by whatever means it already has.
 #include <dlfcn.h>
 
+#include <utility>
+#include <vector>
+
 #include "common.h"
 
 using namespace fh;
@@ -26,6 +29,7 @@ struct RcclApi {
 	int (*Broadcast)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
 	int (*CommDestroy)(NcclComm) = nullptr;
 	const char *(*GetErrorString)(int) = nullptr;
+	int (*CommCount)(NcclComm, int *) = nullptr;
 };
 
 RcclApi *rccl_api()
@@ -46,6 +50,7 @@ RcclApi *rccl_api()
 			api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(api.handle, "ncclBroadcast"));
 			api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
 			api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+			api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.handle, "ncclCommCount"));
 			if (!api.GetUniqueId || !api.CommInitRank || !api.Broadcast || !api.CommDestroy)
 				api.handle = nullptr;
 		}
@@ -58,6 +63,9 @@ struct Rccl {
 	hipStream_t stream = nullptr;
 	hipEvent_t ready = nullptr, done[3] = {nullptr, nullptr, nullptr}; // slots 0 / 1 of the drivers + the blocking form
 	int rank = 0, world = 1;
+	// statistics since the last faer_hip_rccl_stats: broadcasts issued, bytes, their device time (timing events on `stream`)
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+	double n_bcast = 0, bytes = 0;
 };
 
 void rccl_check(int rc, const char *what)
@@ -76,7 +84,15 @@ void rccl_start(Rccl *r, void *buf, size_t bytes, int root, int slot)
 	hipStream_t cur = ctx().stream;
 	FH_HIP(hipEventRecord(r->ready, cur)); // the panel was packed on the caller's stream
 	FH_HIP(hipStreamWaitEvent(r->stream, r->ready, 0));
+	hipEvent_t t0, t1;
+	FH_HIP(hipEventCreate(&t0));
+	FH_HIP(hipEventCreate(&t1));
+	FH_HIP(hipEventRecord(t0, r->stream));
 	rccl_check(a->Broadcast(buf, buf, bytes, NCCL_CHAR, root, r->comm, r->stream), "ncclBroadcast");
+	FH_HIP(hipEventRecord(t1, r->stream));
+	r->timed.emplace_back(t0, t1);
+	r->n_bcast += 1;
+	r->bytes += (double) bytes;
 	FH_HIP(hipEventRecord(r->done[slot], r->stream));
 }
 
@@ -146,6 +162,34 @@ FaerHipComm faer_hip_rccl_comm(void *handle)
 	c.ibcast = rccl_ibcast;
 	c.wait = rccl_wait;
 	return c;
+}
+
+// out4: {ranks the communicator reports (ncclCommCount), broadcasts, bytes, device milliseconds inside ncclBroadcast} since
+// the previous call; synchronises the transport's stream
+void faer_hip_rccl_stats(void *handle, double *out4)
+{
+	FH_CHECK(handle != nullptr && out4 != nullptr, "rccl transport: NULL argument");
+	Rccl *r = static_cast<Rccl *>(handle);
+	RcclApi *a = rccl_api();
+	int cnt = -1;
+	if (a && a->CommCount && r->comm)
+		(void) a->CommCount(r->comm, &cnt);
+	FH_HIP(hipStreamSynchronize(r->stream));
+	double ms = 0;
+	for (auto &p : r->timed) {
+		float t = 0;
+		if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess)
+			ms += t;
+		(void) hipEventDestroy(p.first);
+		(void) hipEventDestroy(p.second);
+	}
+	r->timed.clear();
+	out4[0] = (double) cnt;
+	out4[1] = r->n_bcast;
+	out4[2] = r->bytes;
+	out4[3] = ms;
+	r->n_bcast = 0;
+	r->bytes = 0;
 }
 
 void faer_hip_rccl_destroy(void *handle)

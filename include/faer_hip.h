@@ -526,6 +526,12 @@ FAER_HIP_API void faer_hip_rccl_destroy(void *handle);
 
 /* Number of block columns of width `nb` owned by `rank` out of n columns distributed block-cyclically. */
 FAER_HIP_API size_t faer_hip_dist_local_ncols(size_t n, size_t nb, int rank, int world_size);
+/* measurement aids (bench.py --gpus N --workload lu|llt): the calling thread's last faer_hip_dist_* factorization --
+ * out3 = {device ms of the whole call, device ms of the panel factorizations this rank owned, their number};
+ * faer_hip_rccl_stats: out4 = {ranks the communicator reports (ncclCommCount), broadcasts, bytes, device ms inside
+ * ncclBroadcast} since the previous call */
+FAER_HIP_API void faer_hip_dist_last_stats(double *out3);
+FAER_HIP_API void faer_hip_rccl_stats(void *handle, double *out4);
 /* Scalars of device scratch the distributed LU needs: all pivots + two broadcast buffers ({pivots, packed panel}). */
 FAER_HIP_API size_t faer_hip_dist_panel_ws_scalars(size_t nrows, size_t nb, FaerHipDType dtype);
 /* Distributed partial-pivot LU of an m x n matrix whose block columns (width nb) are dealt block-cyclically

@@ -29,19 +29,24 @@ def test_bidiag_vs_oracle(m, n, bl, br, dtype):
     # |dx| / |x| when its column moves by dx ~ mx eps ||A||, and |x| is the magnitude of the bidiagonal entry it produces:
     # the O(1) quantities (reflectors, block factors) are compared with that conditioning
     assert np.abs(bidiag_of(u) - bidiag_of(uo)).max() <= 64 * mx * eps * scale
-    bo = bidiag_of(uo)
-    bmin = np.abs(bo[bo != 0]).min(initial=scale)
-    cond = max(1.0, scale / bmin)
-    mask = np.ones((m, n), dtype=bool)
-    for j in range(n):
-        mask[j, j] = False
-        if j + 1 < n:
-            mask[j, j + 1] = False
-    assert np.abs(u[mask] - uo[mask]).max(initial=0.0) <= 64 * mx * eps * cond
-    for h, ho in ((hl, hlo), (hr, hro)):
+    # ... PER REFLECTOR: the left reflector of column j is conditioned by the diagonal entry it produces, the right reflector
+    # of row j by the superdiagonal one -- not by the smallest entry of the whole bidiagonal
+    bo = bidiag_of(uo).astype(np.float64)
+    dg = np.abs(np.diag(bo))[:min(m, n)]
+    sg = np.abs(np.diag(bo, 1))
+    cl = np.maximum(1.0, scale / np.where(dg != 0, dg, scale))
+    cr = np.maximum(1.0, scale / np.where(sg != 0, sg, scale))
+    for j in range(min(m, n)):
+        assert np.abs(u[j + 1:, j] - uo[j + 1:, j]).max(initial=0.0) <= 64 * mx * eps * cl[j], ("left", j)
+        if j + 2 < n:
+            assert np.abs(u[j, j + 2:] - uo[j, j + 2:]).max(initial=0.0) <= 64 * mx * eps * cr[j], ("right", j)
+    for h, ho, cc, bb in ((hl, hlo, cl, bl), (hr, hro, cr, br)):
         fin = np.isfinite(ho)
         assert np.array_equal(np.isfinite(h), fin)
-        assert np.abs(h[fin] - ho[fin]).max(initial=0.0) <= 64 * mx * eps * cond
+        for j in range(ho.shape[1]):  # column j of a block factor couples the reflectors of its block up to j
+            cj = cc[(j // bb) * bb:j + 1].max(initial=1.0)
+            fj = fin[:, j]
+            assert np.abs(h[fj, j] - ho[fj, j]).max(initial=0.0) <= 64 * mx * eps * cj, j
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -27,13 +27,17 @@ def test_hessenberg_vs_oracle(n, b, dtype):
     # H scales with A: same algorithm, another summation order.  A reflector moves by |dx| / |x| when its column moves by
     # dx ~ n eps ||A||, |x| being the subdiagonal entry it produces: the O(1) quantities are compared with that conditioning
     assert np.abs(hess_of(v) - hess_of(vo)).max() <= 64 * n * eps * scale
-    sub = np.abs(np.diag(vo, -1))
-    cond = max(1.0, scale / sub[sub != 0].min(initial=scale))
-    il = np.tril_indices(n, -2)
-    assert np.abs(v[il] - vo[il]).max(initial=0.0) <= 64 * n * eps * cond
+    # ... PER COLUMN: reflector j is conditioned by its own subdiagonal entry, not by the smallest one of the matrix
+    sub = np.abs(np.diag(vo, -1)).astype(np.float64)
+    cond = np.maximum(1.0, scale / np.where(sub != 0, sub, scale))  # one factor per reflector (column j -> entry (j + 1, j))
+    for j in range(n - 2):
+        assert np.abs(v[j + 2:, j] - vo[j + 2:, j]).max(initial=0.0) <= 64 * n * eps * cond[j], j
     fin = np.isfinite(ho)
     assert np.array_equal(np.isfinite(h), fin)
-    assert np.abs(h[fin] - ho[fin]).max(initial=0.0) <= 64 * n * eps * cond
+    for j in range(n - 1):  # column j of a block factor couples the reflectors of its block up to j
+        cj = cond[(j // b) * b:j + 1].max()
+        fj = fin[:, j]
+        assert np.abs(h[fj, j] - ho[fj, j]).max(initial=0.0) <= 64 * n * eps * cj, j
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -246,3 +246,45 @@ def test_matmul_full_size_property():
     rhs = a @ (b @ x)
     scale = (a.abs() @ (b.abs() @ x.abs())).max().item()
     assert (lhs - rhs).abs().max().item() <= 8 * n * 2.3e-16 * scale
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_matmul_config_r_1024_cubed_vs_oracle(oracle, dtype):
+    """BASELINE config R (the reference's own CPU-runnable case: 1024^3 matmul) entry by entry against the oracle"""
+    F = init_gpu()
+    n = 1024
+    rng = np.random.default_rng(1024)
+    a, b, c0 = rnd(rng, n, n, dtype), rnd(rng, n, n, dtype), rnd(rng, n, n, dtype)
+    for accum, alpha in ((F.ACCUM_ADD, -0.5), (F.ACCUM_REPLACE, 1.0)):
+        dc = to_dev(c0 if accum == F.ACCUM_ADD else np.full((n, n), np.nan, dtype=dtype))
+        F.matmul(dc, accum, to_dev(a), to_dev(b), alpha)
+        ref = c0.copy(order="F")
+        oracle.matmul(ref, a, b, alpha=alpha, accum_add=accum == F.ACCUM_ADD)
+        got = to_host(dc)
+        tol = bound(a, b, c0 if accum == F.ACCUM_ADD else 0 * c0, n, dtype, alpha)
+        assert (np.abs(got.astype(np.float64) - ref.astype(np.float64)) <= tol).all()
+
+
+def test_matmul_full_size_sampled_rows_vs_oracle(oracle):
+    """BASELINE config G (N = 8192 fp64), the launch bench.py times: 96 sampled rows of C (all 8192 columns, i.e. every tile
+    column and 96 tile rows of the 128 x 128 raster) against the oracle's product of the same rows, 4 K eps (|A||B|)"""
+    import torch
+
+    F = init_gpu()
+    n = 8192
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g).t()
+    b = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g).t()
+    c = torch.empty((n, n), dtype=torch.float64, device="cuda").t()
+    F.matmul(c, F.ACCUM_REPLACE, a, b, 1.0)
+    F.synchronize()
+    rows = np.unique(np.concatenate([np.arange(0, n, 128)[:64] + np.arange(64) % 128, np.array([0, 1, 127, 128, 4095, 4096, n - 1]),
+                                      np.random.default_rng(7).integers(0, n, 25)]))
+    rt = torch.from_numpy(rows).cuda()
+    ah = np.asfortranarray(a[rt].cpu().numpy())
+    bh = np.asfortranarray(b.cpu().numpy())
+    ref = np.zeros((len(rows), n), order="F")
+    oracle.matmul(ref, ah, bh)
+    got = c[rt].cpu().numpy()
+    tol = 4 * n * EPS[np.dtype(np.float64)] * (np.abs(ah) @ np.abs(bh))
+    assert (np.abs(got - ref) <= tol).all(), np.abs(got - ref).max()

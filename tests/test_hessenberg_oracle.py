@@ -45,3 +45,29 @@ def test_oracle_hessenberg_edge_cases():
     O.hessenberg_in_place(v, h)
     assert np.allclose(v, hmat)
     assert all(np.isinf(h[j % 2, j]) for j in range(n - 1))
+
+
+@pytest.mark.parametrize("n", [256, 300, 515])
+def test_unblocked_restatement_agrees_with_a_blocked_reduction(n):
+    """From n = 256 (n^2 >= blocking_threshold) the reference runs hessenberg_gqvdg_blocked (evd/hessenberg.rs:563-565,
+    568-736): the SAME reflectors of the SAME columns (beta = -sign(x_0) |x|, householder.rs:59-107) applied in blocked
+    order.  The oracle restates only hessenberg_rearranged_unblocked (:230-408); this test documents that the variant does
+    not matter beyond rounding by comparing the restatement with an independent BLOCKED reduction of the same sign
+    convention, LAPACK's dgehrd (block reflectors, nb = 32): the Hessenberg matrices agree within c n eps ||A||, reflector j
+    within that bound times ||A|| / |h(j + 1, j)| (a reflector x / (x_0 + sign |x|) moves by |dx| / |x|), and
+    tau_faer = 1 / tau_lapack (H = I - v v^H / tau, :21-23)."""
+    scipy_lapack = pytest.importorskip("scipy.linalg.lapack")
+    rng = np.random.default_rng(n)
+    a = np.asarray(rng.standard_normal((n, n)), order="F")
+    v, h = a.copy(order="F"), np.zeros((1, n - 1), order="F")
+    O.hessenberg_in_place(v, h)
+    ht, tau, info = scipy_lapack.dgehrd(a, lo=0, hi=n - 1)
+    assert info == 0
+    eps = np.finfo(np.float64).eps
+    scale = np.linalg.norm(a, 2)
+    assert np.abs(hess_of(v) - hess_of(ht)).max() <= 64 * n * eps * scale
+    sub = np.abs(np.diag(v, -1))
+    cond = np.maximum(1.0, scale / np.where(sub != 0, sub, scale))
+    for j in range(n - 2):
+        assert np.abs(v[j + 2:, j] - ht[j + 2:, j]).max() <= 64 * n * eps * cond[j], j
+        assert abs(h[0, j] - 1.0 / tau[j]) <= 64 * n * eps * cond[j] * max(1.0, abs(h[0, j])), j
