@@ -59,6 +59,7 @@ template <typename T> struct GemmArgs {
 	int epi_serial;		// 1: accumulate epilogue as one read-modify-write per element (A/B switch, see gemm_kernel_p)
 	int k_trim;		// GemmExtra::k_trim (pipelined kernel only)
 	int tri_off;		// tri_enum: first tile of the enumeration (tiles of the skipped leading rows)
+	int raster_g;		// tile rows per raster group (pipelined kernel)
 };
 
 // FaerBlock membership test (faer/src/linalg/matmul/triangular.rs:906-977)
@@ -440,7 +441,18 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 	{
 		const int nblocks = gridDim.x;
 		const int pid = xcd_remap(blockIdx.x, nblocks) + g.tri_off;
-		if (g.tri_enum) {
+		if (g.tri_enum && BN == 2 * BM) {
+			// lower trapezoid of BM x 2 BM tiles: tile row tm holds tn = 0 .. tm / 2, i.e. rows 2 p and 2 p + 1 hold p + 1
+			// tiles each and p (p + 1) tiles precede row 2 p
+			int q = (int) ((sqrtf(4.0f * (float) pid + 1.0f) - 1.0f) * 0.5f);
+			while ((q + 1) * (q + 2) <= pid)
+				++q;
+			while (q * (q + 1) > pid)
+				--q;
+			const int rem = pid - q * (q + 1);
+			tm = rem < q + 1 ? 2 * q : 2 * q + 1;
+			tn = rem < q + 1 ? rem : rem - (q + 1);
+		} else if (g.tri_enum) {
 			int i = (int) ((sqrtf(8.0f * (float) pid + 1.0f) - 1.0f) * 0.5f);
 			while ((i + 1) * (i + 2) / 2 <= pid)
 				++i;
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 			tm = i;
 			tn = pid - i * (i + 1) / 2;
 		} else {
-			constexpr int G = 8;
+			const int G = g.raster_g;
 			const int per_group = G * g.ntn;
 			const int grp = pid / per_group;
 			const int first_m = grp * G;
@@ -914,13 +926,22 @@ static void launch_cfg(const GemmArgs<T> &g, bool akm, bool bkm, int splits)
 	FH_HIP(hipGetLastError());
 }
 
+// tiles of the lower triangle in the first `rows` tile rows: square tiles, or BM x 2 BM tiles (tile row tm holds tm / 2 + 1)
+static inline int tri_tiles(int rows, bool wide)
+{
+	if (!wide)
+		return rows * (rows + 1) / 2;
+	const int p = rows / 2;
+	return (rows & 1) ? (p + 1) * (p + 1) : p * (p + 1);
+}
+
 // software-pipelined dense kernel (gemm_kernel_p)
 template <typename T, int BM, int BN, int WM, int WN> static void launch_cfg_p(const GemmArgs<T> &g, bool akm, bool bkm, int splits)
 {
 	constexpr int BK = 16;
 	constexpr int PF = (BM * BN >= 128 * 128) ? 1 : 4; // register prefetch depth (tiles)
 	constexpr int NT = WM * WN * 64;
-	int nblocks = g.tri_enum ? g.ntm * (g.ntm + 1) / 2 - g.tri_off : g.ntm * g.ntn;
+	int nblocks = g.tri_enum ? tri_tiles(g.ntm, BN == 2 * BM) - g.tri_off : g.ntm * g.ntn;
 	dim3 grid((unsigned) nblocks, 1, (unsigned) splits), block(NT);
 	hipStream_t s = ctx().stream;
 	if (akm && bkm)
@@ -1017,6 +1038,10 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	g.k_trim = ex.k_trim;
 	g.tri_off = 0;
 	{
+		static const int rg = getenv("FAER_HIP_GEMM_RASTER") ? atoi(getenv("FAER_HIP_GEMM_RASTER")) : 8; // A/B switch
+		g.raster_g = rg > 0 ? rg : 8;
+	}
+	{
 		const char *e = getenv("FAER_HIP_GEMM_EPI");
 		g.epi_serial = e ? (atoi(e) == 0 ? 1 : 0) : 0;
 	}
@@ -1036,10 +1061,24 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	const int variant = ctx().gemm_variant;
 	const idx_t tiles128 = ((m + 127) / 128) * ((n + 127) / 128) / (kind == DST_LOWER ? 2 : 1);
 	bool big = tiles128 >= 256;
-	if (variant == 1 || variant == 11)
+	if (variant == 1 || variant == 11 || variant == 3)
 		big = true;
 	if (variant == 2 || variant == 12)
 		big = false;
+	// Eight wavefronts of 64 x 64 per workgroup (128 x 256 block tile, one workgroup per CU) for large plain FULL products
+	// with a deep K: the A tile is shared by four wavefront columns, the B tile by two rows -- 25 % fewer global loads and
+	// LDS stores per flop than four wavefronts on 128 x 128, same LDS reads per MFMA.  DGEMM N = 8192: 68.6 -> 71.3 TFLOP/s
+	// in one visit (256 x 128: 70.9; raster group sizes 2 .. 32 make no difference; four wavefronts of 128 x 64 on the same
+	// block tile spill in the main loop: 12 TFLOP/s).  One workgroup per CU means nobody covers a workgroup's accumulate
+	// epilogue, so the short-K updates of the factorizations stay on the 128 x 128 tile (tools/gpu_gemm_wide_ab.py:
+	// r = 8192: K = 512 -2 %, K = 2048 +1.4 %, K = 8192 +2.9 %; r = 15360: +-0.3 %), and so does every lower dst (its
+	// 128 x 256 tiles on the diagonal waste more: -5 .. -11 %; the trapezoid enumeration is kept reachable for tests).
+	// variant 3 forces the wide tile (full and square lower), 5 forbids it.
+	const bool plain = !ex.inplace && !ex.diag && !ex.a_struct && !ex.b_struct && !ex.row_idx && !ex.col_idx;
+	const bool wide_ok = plain && (kind == DST_FULL ? !ex.k_trim : (m == n));
+	const idx_t tiles_wide = ((m + 127) / 128) * ((n + 255) / 256);
+	const bool wide_auto = kind == DST_FULL && k >= 2048 && tiles_wide >= 512;
+	const int wide = wide_ok && big && variant != 5 && variant < 10 && (variant == 3 || (variant == 0 && wide_auto)) ? 1 : 0;
 	const bool legacy = variant >= 10;
 	// in-place product (ex.inplace): the aliased operand and dst share rows (transposed orientation: A and C
 	// share their rows, one tile must cover all of N) or columns (B and C share their columns, one tile must
@@ -1076,17 +1115,22 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		bm = bn = 64;
 		shape = 1;
 	}
+	if (wide) {
+		bm = 128;
+		bn = 256;
+		shape = 5;
+	}
 	g.ntm = (int) ((m + bm - 1) / bm);
 	g.ntn = (int) ((n + bn - 1) / bn);
 	g.tri_enum = (g.lower && m == n) ? 1 : 0;
 	if (ex.tri_skip) {
 		FH_CHECK(g.tri_enum && ex.tri_skip % bm == 0 && ex.tri_skip < m, "gemm: tri_skip needs a square lower dst and a tile-aligned skip");
 		const int st = (int) (ex.tri_skip / bm);
-		g.tri_off = st * (st + 1) / 2;
+		g.tri_off = tri_tiles(st, bn == 2 * bm);
 	}
 
 	// split-K for few-tile / deep-K products
-	idx_t tiles = g.tri_enum ? (idx_t) g.ntm * (g.ntm + 1) / 2 - g.tri_off : (idx_t) g.ntm * g.ntn;
+	idx_t tiles = g.tri_enum ? (idx_t) tri_tiles(g.ntm, bn == 2 * bm) - g.tri_off : (idx_t) g.ntm * g.ntn;
 	int splits = 1;
 	// Deep-K products with few output tiles are split along K.  Rectangular outputs (the V^H A / V^H V products of QR:
 	// K = rows of the panel, a few tiles of output) split from K = 1024 in slices of >= 256 (measured: square QR
@@ -1121,6 +1165,8 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		FH_CHECK(splits == 1, "gemm: in-place product cannot be split along K");
 	if (extra_path)
 		launch_cfg<T, 64, 64, 2, 2, true>(g, akm, bkm, splits); // triangular operands / diag scaling
+	else if (shape == 5)
+		launch_cfg_p<T, 128, 256, 2, 4>(g, akm, bkm, splits);
 	else if (shape == 2)
 		launch_cfg_p<T, 32, 128, 1, 4>(g, akm, bkm, splits);
 	else if (shape == 3)

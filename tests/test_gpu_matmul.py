@@ -288,3 +288,31 @@ def test_matmul_full_size_sampled_rows_vs_oracle(oracle):
     got = c[rt].cpu().numpy()
     tol = 4 * n * EPS[np.dtype(np.float64)] * (np.abs(ah) @ np.abs(bh))
     assert (np.abs(got - ref) <= tol).all(), np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind,m,n,k", [("full", 300, 500, 70), ("full", 128, 256, 16), ("full", 1000, 1030, 33), ("full", 257, 513, 129),
+                                        ("lower", 1000, 1000, 90), ("lower", 129, 129, 40), ("lower", 640, 640, 16), ("lower", 1537, 1537, 70)])
+def test_gemm_wide_tile_vs_oracle(oracle, kind, m, n, k, dtype):
+    """the eight-wavefront 128 x 256 tile (gemm.hip: default for large plain products, incl. the trapezoid enumeration of a
+    square lower dst) forced on small ragged shapes: entries within 4 K eps (|A||B|), the strict upper triangle of a lower
+    dst untouched bit for bit"""
+    F = init_gpu()
+    rng = np.random.default_rng(m + n + k)
+    a, b, c0 = rnd(rng, m, k, dtype), rnd(rng, k, n, dtype), rnd(rng, m, n, dtype)
+    F.lib().faer_hip_set_gemm_variant(3)
+    try:
+        dc = to_dev(c0)
+        F.gemm(dc, F.DST_LOWER if kind == "lower" else F.DST_FULL, F.ACCUM_ADD, to_dev(a), to_dev(b), -0.75)
+        got = to_host(dc)
+    finally:
+        F.lib().faer_hip_set_gemm_variant(0)
+    ref = c0.copy(order="F")
+    oracle.matmul(ref, a, b, alpha=-0.75, accum_add=True)
+    tol = bound(a, b, c0, k, dtype, -0.75)
+    if kind == "lower":
+        lo = np.tril(np.ones((m, n), bool))
+        assert (np.abs(got.astype(np.float64) - ref.astype(np.float64))[lo] <= tol[lo]).all()
+        assert np.array_equal(got[~lo], c0[~lo])
+    else:
+        assert (np.abs(got.astype(np.float64) - ref.astype(np.float64)) <= tol).all()
