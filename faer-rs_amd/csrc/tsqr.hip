@@ -279,7 +279,7 @@ struct TqPanelArgs {
 	const double *S;   // TQ_NG slices of the column squares of the first launch: [0, 64) panel, [64, ..) trailing
 	int check_range, range_cols;
 	double *abv;	   // per global column: sum of squares of the R entries above the current block row
-	double *N1, *N2, *N3; // out: R^-T, R^-1 U^-1 V1^-1, V1^-1 (row major 64 x 64)
+	double *N1, *N3; // out: R^-T, V1^-1 (row major 64 x 64); with M they give Y = -M V1^-1 (R^-T C - X_top)
 	float *Mn;	   // out: M = -(U R)^-1, row major 64 x 64
 	double *Md, *Td;   // out: M and T of this panel in fp64 (cross-panel blocks of T)
 	float *H;
@@ -748,13 +748,6 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	__syncthreads();
 	TQ_STAMP(7);
 	if (wv < 4) {
-		// N2 = -M V1^-1
-		tq_mm64m<0, 2>(acc, Lm, UL, sgn, wv, lane);
-#pragma unroll
-		for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-			for (int r = 0; r < 4; ++r)
-				a.N2[(16 * wv + (lane >> 4) + 4 * r) * 64 + 16 * jb + (lane & 15)] = -acc[jb][r];
 		// T = triu(V1^T U^-1)
 		tq_mm64m<1, 3>(acc, Wm, UL, sgn, wv, lane);
 #pragma unroll
@@ -785,7 +778,7 @@ struct TqYArgs {
 	int r0, cx, w, t;
 	const double *C; // TQ_NG slices, each row major 64 x ldc
 	int ldc;
-	const double *N1, *N2, *N3;
+	const double *N1, *N3, *Md; // R^-T, V1^-1, M = -(U R)^-1
 	double *abv;
 	float *Yn; // out: -Y, row major 64 x typ
 	int typ;
@@ -796,7 +789,7 @@ struct TqYArgs {
 
 __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 {
-	__shared__ double n1[64 * TQ_DP], n2[64 * TQ_DP], n3[64 * TQ_DP];
+	__shared__ double n1[64 * TQ_DP], n3[64 * TQ_DP], mm[64 * TQ_DP];
 	__shared__ double v[64 * 17];
 	__shared__ double sred[256];
 	if (a.stat[0])
@@ -804,8 +797,8 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 	const int tid = threadIdx.x;
 	for (int e = tid; e < 4096; e += 256) {
 		n1[(e >> 6) * TQ_DP + (e & 63)] = a.N1[e];
-		n2[(e >> 6) * TQ_DP + (e & 63)] = a.N2[e];
 		n3[(e >> 6) * TQ_DP + (e & 63)] = a.N3[e];
+		mm[(e >> 6) * TQ_DP + (e & 63)] = a.Md[e];
 	}
 	const int bl = tid & 15, ig = tid >> 4; // column, row group: rows ig, ig + 16, ig + 32, ig + 48
 	const int b = blockIdx.x * 16 + bl;
@@ -848,18 +841,31 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 			s += sred[g * 16 + bl];
 		a.abv[a.cx + b] += s;
 	}
+	// zn = V1^-1 (D - X_top) = -Z, then  -Y = M zn  (Y = R^-1 U^-1 V1^-1 (D - X_top), M = -(U R)^-1 upper triangular)
+	double zn[4];
 #pragma unroll
 	for (int u = 0; u < 4; ++u) {
 		const int k = ig + 16 * u;
-		double acc = 0.0, zz = 0.0;
-		for (int l = 0; l < 64; ++l) {
-			acc += n2[k * TQ_DP + l] * v[l * 17 + bl];
-			zz += l <= k ? n3[k * TQ_DP + l] * v[l * 17 + bl] : 0.0;
-		}
-		if (b < a.typ)
-			a.Yn[(long) k * a.typ + b] = colok ? (float) -acc : 0.f;
+		double zz = 0.0;
+		for (int l = 0; l <= k; ++l)
+			zz += n3[k * TQ_DP + l] * v[l * 17 + bl];
+		zn[u] = zz;
 		if (colok)
 			a.Z[(long) k * a.ldz + a.cx + b] = -zz;
+	}
+	__syncthreads(); // every read of D - X_top is done
+#pragma unroll
+	for (int u = 0; u < 4; ++u)
+		v[(ig + 16 * u) * 17 + bl] = zn[u];
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+		const int k = ig + 16 * u;
+		double acc = 0.0;
+		for (int l = k; l < 64; ++l)
+			acc += mm[k * TQ_DP + l] * v[l * 17 + bl];
+		if (b < a.typ)
+			a.Yn[(long) k * a.typ + b] = colok ? (float) acc : 0.f;
 	}
 }
 
@@ -1024,10 +1030,11 @@ struct TqTxArgs {
 	const double *Td, *Md; // per panel 64 x 64
 	const double *Z;       // per panel 64 x ldz
 	int ldz;
-	double *B; // scratch per panel 64 x ldz
+	double *B; // scratch per panel 64 x ldz (general kernel); per panel 2 x 64 x 64: B_L and V^T R between the stages
 	float *H;
 	long hrs, hcs;
 	const int *stat;
+	int stage; // 0: everything; 1: all that does not need the LAST panel's kernel (runs beside it); 2: the rest
 };
 
 // acc[jb] (rows 16 wv .. + 15, columns 16 jb .. + 15) += A (64 x 64, LDS) * B (64 x 64, LDS)
@@ -1153,14 +1160,47 @@ __global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
 		vr[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
 	double rb[16];
 	float fa[16], fb[16];
+	// Two stages: everything up to the last 64-row chunk of V_k^T R for the LAST panel L of the block needs nothing of panel
+	// L's kernel (its R block and M) and runs on a second stream beside it; B_L and the partial V^T R travel through a.B.
+	const int L = lend - 1, cL = L * TQ_PW;
+	auto is_cut = [&](const TqTxUnit &t) { return t.type == 1 && t.l == L && t.x == cL; };
+	double *state = a.B + (long) k * 2 * 4096;
 	TqTxUnit u{0, l1, 0};
+	if (a.stage == 2) {
+		u = TqTxUnit{1, L, cL};
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int o = (16 * wv + (lane >> 4) + 4 * r) * 64 + 16 * jb + (lane & 15);
+				vr[jb][r] = state[4096 + o];
+#pragma unroll
+				for (int q = 0; q < TQ_TX_MAXL; ++q)
+					if (q == L - l1)
+						Bacc[q][jb][r] = state[o];
+			}
+	}
 	fetch(u, rb, fa, fb);
 	while (u.type != 4) {
+		if (a.stage == 1 && is_cut(u)) {
+#pragma unroll
+			for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const int o = (16 * wv + (lane >> 4) + 4 * r) * 64 + 16 * jb + (lane & 15);
+					state[4096 + o] = vr[jb][r];
+#pragma unroll
+					for (int q = 0; q < TQ_TX_MAXL; ++q)
+						if (q == L - l1)
+							state[o] = Bacc[q][jb][r];
+				}
+			return; // (uniform)
+		}
 		__syncthreads(); // the previous product has read its operands
 		stage(u, rb, fa, fb);
 		__syncthreads();
 		const TqTxUnit un = next(u);
-		if (un.type != 4)
+		if (un.type != 4 && !(a.stage == 1 && is_cut(un)))
 			fetch(un, rb, fa, fb); // in flight during the product
 #pragma unroll
 		for (int jb = 0; jb < 4; ++jb)
@@ -1381,6 +1421,24 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 	FH_HIP(hipGetLastError());
 }
 
+// per-thread side stream of the factorization (stage 1 of the cross-panel T blocks)
+struct TqSide {
+	hipStream_t stream = nullptr;
+	hipEvent_t fork = nullptr, done = nullptr;
+	int device = -1;
+};
+static TqSide &tq_side()
+{
+	static thread_local TqSide sd;
+	if (sd.stream == nullptr || sd.device != ctx().device) {
+		FH_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+		FH_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+		FH_HIP(hipEventCreateWithFlags(&sd.done, hipEventDisableTiming));
+		sd.device = ctx().device;
+	}
+	return sd;
+}
+
 bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs)
 {
 	static const bool off = getenv("FAER_HIP_QR_TSQR") && atoi(getenv("FAER_HIP_QR_TSQR")) == 0; // A/B switch
@@ -1405,13 +1463,13 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	const int ldc = ((int) n + 63) & ~63;
 	const int typ = ldc, ldz = ldc;
 	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * 4), sp((size_t) TQ_NB * 256 * 4);
-	// fp64 workspace: G (NG x 4096), N1, N2, N3 (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64),
+	// fp64 workspace: G (NG x 4096), N1, N3 (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64),
 	//                 Td, Md (npan x 4096 each), Z, B (npan x 64 x ldz each); then fp32: Mn (4096), Yn (64 x typ); then the status words
-	const size_t nd = (size_t) TQ_NG * 4096 + 3 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
+	const size_t nd = (size_t) TQ_NG * 4096 + 2 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
 			  (size_t) 2 * npan * 64 * ldz;
 	Scratch small(nd * 8 + (size_t) (4096 + 64 * typ) * 4 + 2048);
 	double *G = small.as<double>();
-	double *N1 = G + (size_t) TQ_NG * 4096, *N2 = N1 + 4096, *N3 = N2 + 4096, *C = N3 + 4096;
+	double *N1 = G + (size_t) TQ_NG * 4096, *N3 = N1 + 4096, *C = N3 + 4096;
 	double *S = C + (size_t) TQ_NG * 64 * ldc, *abv = S + (size_t) TQ_NG * 256;
 	double *Td = abv + n + 64, *Md = Td + (size_t) npan * 4096, *Z = Md + (size_t) npan * 4096, *Bx = Z + (size_t) npan * 64 * ldz;
 	float *Mn = reinterpret_cast<float *>(Bx + (size_t) npan * 64 * ldz);
@@ -1438,6 +1496,28 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 				cp.as<float>(), sp.as<float>(), G, C, ldc, off, S, stat);
 		}
 	};
+	auto tx_args = [&]() {
+		TqTxArgs ta;
+		ta.A = A.p;
+		ta.ld = ld;
+		ta.n = (int) n;
+		ta.bs = (int) bs;
+		ta.Td = Td;
+		ta.Md = Md;
+		ta.Z = Z;
+		ta.ldz = ldz;
+		ta.B = Bx;
+		ta.H = H.p;
+		ta.hrs = H.rs;
+		ta.hcs = H.cs;
+		ta.stat = stat;
+		ta.stage = 0;
+		return ta;
+	};
+	// one block of Q_coeff over all panels (the tall-skinny case): the cross-panel blocks of T in two stages
+	const bool two_stage = cross && bs >= n && bs <= (TQ_TX_MAXL + 1) * TQ_PW && npan >= 2;
+	TqSide &side = tq_side();
+	bool stage2_on_side = false;
 	launch_gram(0, (int) (n < TQ_PW ? n : TQ_PW), true);
 	for (int k = 0; k < npan; ++k) {
 		const int c0 = k * TQ_PW;
@@ -1457,7 +1537,6 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		pa.range_cols = t < TQ_TS ? t : TQ_TS;
 		pa.abv = abv;
 		pa.N1 = N1;
-		pa.N2 = N2;
 		pa.N3 = N3;
 		pa.Mn = Mn;
 		pa.Md = Md + (size_t) k * 4096;
@@ -1481,8 +1560,8 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			ya.C = C;
 			ya.ldc = ldc;
 			ya.N1 = N1;
-			ya.N2 = N2;
 			ya.N3 = N3;
+			ya.Md = Md + (size_t) k * 4096;
 			ya.abv = abv;
 			ya.Yn = Yn;
 			ya.typ = typ;
@@ -1507,7 +1586,18 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			// one persistent workgroup per CU (its registers and LDS allow no second one): 256 measured 5 % ahead of 512 and
 			// 10 % ahead of 1024 workgroups on the 5e5 x 256 factorization
 			int nwg = (ua.nrb + 3) / 4;
-			const int ncu = ctx().stream_cus();
+			int ncu = ctx().stream_cus();
+			if (two_stage && k == npan - 1 && ncu > 8 * npan) {
+				// stage 2 of the cross-panel T blocks needs the panel kernel only: beside this last update, on the CUs it leaves free
+				ncu -= npan - 1;
+				TqTxArgs t2 = tx_args();
+				t2.stage = 2;
+				FH_HIP(hipEventRecord(side.fork, s));
+				FH_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+				hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.stream, t2);
+				FH_HIP(hipEventRecord(side.done, side.stream));
+				stage2_on_side = true;
+			}
 			if (nwg > ncu)
 				nwg = ncu;
 			const int nstrip = (t + TQ_TS - 1) / TQ_TS;
@@ -1527,6 +1617,16 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 				tq_launch_update(v2, nwg, ua);
 			}
 		}
+		if (two_stage && k == npan - 2) {
+			// everything of the cross-panel T blocks that does not depend on the last panel's kernel: on the side stream, beside
+			// the Gram / reduce / panel kernels of the last panel (a single workgroup busy most of that time)
+			TqTxArgs t1 = tx_args();
+			t1.stage = 1;
+			FH_HIP(hipEventRecord(side.fork, s));
+			FH_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.stream, t1);
+			FH_HIP(hipEventRecord(side.done, side.stream));
+		}
 		if (t > 0) {
 			const int wn = t < TQ_PW ? t : TQ_PW;
 			launch_gram(c0 + w, wn, false);
@@ -1534,24 +1634,18 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		FH_HIP(hipGetLastError());
 	}
 	if (cross) {
-		TqTxArgs ta;
-		ta.A = A.p;
-		ta.ld = ld;
-		ta.n = (int) n;
-		ta.bs = (int) bs;
-		ta.Td = Td;
-		ta.Md = Md;
-		ta.Z = Z;
-		ta.ldz = ldz;
-		ta.B = Bx;
-		ta.H = H.p;
-		ta.hrs = H.rs;
-		ta.hcs = H.cs;
-		ta.stat = stat;
-		if (bs <= (TQ_TX_MAXL + 1) * TQ_PW)
+		TqTxArgs ta = tx_args();
+		if (two_stage) {
+			FH_HIP(hipStreamWaitEvent(s, side.done, 0)); // stage 1 ran beside the last panel's kernels
+			if (!stage2_on_side) {
+				ta.stage = 2;
+				hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
+			}
+		} else if (bs <= (TQ_TX_MAXL + 1) * TQ_PW) {
 			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
-		else
+		} else {
 			hipLaunchKernelGGL(tq_tx_general_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
+		}
 		FH_HIP(hipGetLastError());
 	}
 	int st[4];
@@ -1561,7 +1655,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	{
 		long long d[32];
 		FH_HIP(hipMemcpy(d, stat + 16, sizeof(d), hipMemcpyDeviceToHost));
-		fprintf(stderr, "tq_panel phases (shader cycles): start %lld: load %lld chol %lld reload %lld lu %lld finish %lld tests %lld out %lld M %lld N2/T %lld\n",
+		fprintf(stderr, "tq_panel phases (shader cycles): start %lld: load %lld chol %lld reload %lld lu %lld finish %lld tests %lld out %lld M %lld T %lld\n",
 			d[0], d[1] - d[0], d[2] - d[1], 0LL, d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[8] - d[7]);
 		double res[3];
 		memcpy(res, d + 9, sizeof(res));
