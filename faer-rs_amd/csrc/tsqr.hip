@@ -47,6 +47,15 @@ constexpr double TQ_COND_MAX = 64.0 * 512.0; // |R|_F |R^-1|_F (>= 64 for any pa
 constexpr double TQ_TAIL_MIN = 1e-9;	     // 1 - |head| / |column| below this: the tail is numerically zero
 enum { TQ_OK = 0, TQ_FAIL_CHOL = 1, TQ_FAIL_TAIL = 2, TQ_FAIL_RANK = 3, TQ_FAIL_COND = 4, TQ_FAIL_RANGE = 5 };
 
+// Status word 0 of a factorization: 0, or 1 + the number of columns completed when a panel was rejected.  The kernels of
+// the steps before the rejected panel still run (some of them beside the panel kernel that rejects), all later ones
+// return at once: `c0` is the first column of the panel a launch belongs to.
+static __device__ __forceinline__ bool tq_skip(const int *stat, int c0)
+{
+	const int s = *reinterpret_cast<const volatile int *>(stat);
+	return s != 0 && c0 >= s - 1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // gram
 // ------------------------------------------------------------------------------------------------
@@ -61,12 +70,13 @@ struct TqGramArgs {
 	float *Cp;  // [grid][64 * tp]
 	float *Sp;  // [grid][256] per-column sums of squares of the staged columns (range guard of the first launch)
 	const int *stat;
+	int c0; // first column of the panel (tq_skip)
 };
 
 template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(const TqGramArgs a)
 {
 	__shared__ float sm[(TQ_PW + TQ_TS) * TQ_LP];
-	if (a.stat[0])
+	if (tq_skip(a.stat, a.c0))
 		return;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int quad = tid & 15, cg = tid >> 4;
@@ -220,9 +230,9 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(con
 // strided loads each.
 constexpr int TQ_NG = 8;
 __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const float *Cp, const float *Sp, int nb, int tp, int want_g,
-							 int want_sq, double *G, double *C, int ldc, int coff, double *S, const int *stat)
+							 int want_sq, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0)
 {
-	if (stat[0])
+	if (tq_skip(stat, c0))
 		return;
 	const int e = blockIdx.x * 256 + threadIdx.x;
 	const int g = blockIdx.y;
@@ -281,6 +291,8 @@ struct TqPanelArgs {
 	double *abv;	   // per global column: sum of squares of the R entries above the current block row
 	double *N1, *N3; // out: R^-T, V1^-1 (row major 64 x 64); with M they give Y = -M V1^-1 (R^-T C - X_top)
 	float *Mn;	   // out: M = -(U R)^-1, row major 64 x 64
+	float *top;	   // out: the panel's top block (R on and above the diagonal, V1 below), row major 64 x 64 -- NOT written
+			   // into A here: the Gram launch of this panel's trailing columns may still be reading those rows
 	double *Md, *Td;   // out: M and T of this panel in fp64 (cross-panel blocks of T)
 	float *H;
 	long hrs, hcs;
@@ -525,7 +537,8 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 		if (tid == 0) {
 			a.stat[1] = a.c0;
 			a.stat[2] = why;
-			a.stat[0] = 1;
+			__threadfence();
+			*reinterpret_cast<volatile int *>(a.stat) = a.c0 + 1;
 		}
 	};
 	if (a.check_range) {
@@ -549,19 +562,36 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 			return;
 		}
 	}
-	// ---- G (the sum of its TQ_NG slices, identity beyond w) and A1 (zero beyond w) through LDS, coalesced
-	for (int e = tid; e < 4096; e += TQ_PT) {
-		const int i = e >> 6, j = e & 63;
-		double g = i == j ? 1.0 : 0.0, v = 0.0;
-		if (i < w && j < w) {
-			g = 0.0;
+	// ---- G (the sum of its TQ_NG slices, identity beyond w) and A1 (zero beyond w) through LDS, coalesced; the loads of four
+	//      entries (36 of them) are in flight together: one entry at a time this was 36 000 cycles of dependent round trips
+#pragma unroll 1
+	for (int e0 = tid; e0 < 4096; e0 += 4 * TQ_PT) {
+		double gs[4][TQ_NG];
+		float av[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int e = e0 + u * TQ_PT;
+			const int i = e >> 6, j = e & 63;
+			const bool in = i < w && j < w;
 			const int el = i >= j ? e : j * 64 + i; // the Gram kernel writes the lower 16 x 16 tiles only
+#pragma unroll
 			for (int q = 0; q < TQ_NG; ++q)
-				g += a.G[q * 4096 + el];
-			v = (double) a.A[(long) (a.c0 + i) * a.ld + a.r0 + j]; // transposed fill: lanes along the rows of A
+				gs[u][q] = in ? a.G[q * 4096 + el] : 0.0;
+			av[u] = in ? a.A[(long) (a.c0 + i) * a.ld + a.r0 + j] : 0.f; // transposed fill: lanes along the rows of A
 		}
-		Lm[i * TQ_DP + j] = g;
-		Wm[j * TQ_DP + i] = v;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int e = e0 + u * TQ_PT;
+			const int i = e >> 6, j = e & 63;
+			double g = 0.0;
+#pragma unroll
+			for (int q = 0; q < TQ_NG; ++q)
+				g += gs[u][q];
+			if (!(i < w && j < w))
+				g = i == j ? 1.0 : 0.0;
+			Lm[i * TQ_DP + j] = g;
+			Wm[j * TQ_DP + i] = (double) av[u];
+		}
 	}
 	__syncthreads();
 	double x[64];
@@ -719,8 +749,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	// ---- outputs that read L: the top block of A (R = S R~ on and above the diagonal, V1 below), N1 = R^-T, N3 = V1^-1
 	for (int e = tid; e < 4096; e += TQ_PT) {
 		const int i = e >> 6, j = e & 63;
-		if (i < w && j < w)
-			a.A[(long) (a.c0 + j) * a.ld + a.r0 + i] = (float) (i <= j ? sgn[i] * Lm[j * TQ_DP + i] : Wm[i * TQ_DP + j]);
+		a.top[e] = (float) (i <= j ? sgn[i] * Lm[j * TQ_DP + i] : Wm[i * TQ_DP + j]);
 		// R^-1 = R~^-1 S  =>  N1[i][l] = R^-1[l][i] = Ri[l][i] * s_i  (Ri holds only its upper triangle)
 		a.N1[e] = j <= i ? Ri[j * TQ_DP + i] * sgn[i] : 0.0;
 		a.N3[e] = i == j ? 1.0 : (j < i ? UL[i * TQ_DP + j] : 0.0);
@@ -784,17 +813,36 @@ struct TqYArgs {
 	int typ;
 	double *Z; // out: Z = -V1^-1 (D - X_top) = T^-H V^H X, row major 64 x ldz, column index = GLOBAL column
 	int ldz;
+	const float *top; // the panel's top block as the panel kernel left it (workgroup 0 stores it into A)
 	const int *stat;
 };
+
+// the panel's top block from its staging copy into A (once every reader of the original rows is done)
+static __device__ __forceinline__ void tq_store_top(float *A, long ld, int r0, int c0, int w, const float *top, int tid)
+{
+	for (int e = tid; e < 4096; e += 256) {
+		const int i = e >> 6, j = e & 63;
+		if (i < w && j < w)
+			A[(long) (c0 + j) * ld + r0 + i] = top[e];
+	}
+}
+__global__ __launch_bounds__(256) void tq_top_kernel(float *A, long ld, int r0, int c0, int w, const float *top, const int *stat)
+{
+	if (tq_skip(stat, c0))
+		return;
+	tq_store_top(A, ld, r0, c0, w, top, threadIdx.x);
+}
 
 __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 {
 	__shared__ double n1[64 * TQ_DP], n3[64 * TQ_DP], mm[64 * TQ_DP];
 	__shared__ double v[64 * 17];
 	__shared__ double sred[256];
-	if (a.stat[0])
+	if (tq_skip(a.stat, a.r0))
 		return;
 	const int tid = threadIdx.x;
+	if (blockIdx.x == 0)
+		tq_store_top(a.A, a.ld, a.r0, a.cx - a.w, a.w, a.top, tid);
 	for (int e = tid; e < 4096; e += 256) {
 		n1[(e >> 6) * TQ_DP + (e & 63)] = a.N1[e];
 		n3[(e >> 6) * TQ_DP + (e & 63)] = a.N3[e];
@@ -883,6 +931,7 @@ struct TqUpdArgs {
 	int do_v;
 	int nrb; // 128-row blocks
 	const int *stat;
+	int c0; // first column of the panel (tq_skip)
 };
 
 template <bool VEC> static __device__ __forceinline__ f32x4 tq_ld4(const float *col, int lam, int rows)
@@ -934,7 +983,7 @@ template <bool VEC> __global__ __launch_bounds__(256, 1) void tq_update_kernel(c
 {
 	constexpr int PITCH = TQ_TS + 64;
 	__shared__ float Ys[64 * PITCH];
-	if (a.stat[0])
+	if (tq_skip(a.stat, a.c0))
 		return;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	for (int e = tid; e < 64 * PITCH; e += 256) {
@@ -1390,7 +1439,7 @@ static void tq_launch_update(bool vec, int nwg, const TqUpdArgs &ua)
 }
 
 static void tq_gram(const float *P, const float *X, long ld, int rows, int w, int t, bool want_g, bool want_sq, bool vec, double *Gp, float *Cp,
-		    float *Sp, double *G, double *C, int ldc, int coff, double *S, const int *stat)
+		    float *Sp, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0)
 {
 	hipStream_t s = ctx().stream;
 	TqGramArgs g;
@@ -1408,6 +1457,7 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 	g.Cp = Cp;
 	g.Sp = Sp;
 	g.stat = stat;
+	g.c0 = c0;
 	const int nb = g.nchunks < TQ_NB ? g.nchunks : TQ_NB;
 	if (nb <= 0)
 		return;
@@ -1417,23 +1467,25 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 		hipLaunchKernelGGL(tq_gram_kernel<false>, dim3(nb), dim3(256), 0, s, g);
 	const int total = (want_g ? 4096 : 0) + 64 * g.tp + (want_sq ? 256 : 0);
 	hipLaunchKernelGGL(tq_reduce_kernel, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, Gp, Cp, Sp, nb, g.tp, (int) want_g, (int) want_sq, G, C,
-			   ldc, coff, S, stat);
+			   ldc, coff, S, stat, c0);
 	FH_HIP(hipGetLastError());
 }
 
-// per-thread side stream of the factorization (stage 1 of the cross-panel T blocks)
+// per-thread side streams of the factorization: the panel kernel of step k + 1 (one workgroup) beside the rest of step k's
+// update, and the cross-panel T blocks beside the last steps
 struct TqSide {
-	hipStream_t stream = nullptr;
-	hipEvent_t fork = nullptr, done = nullptr;
+	hipStream_t panel = nullptr, tx = nullptr;
+	hipEvent_t pfork = nullptr, pdone = nullptr, xfork = nullptr, xdone = nullptr;
 	int device = -1;
 };
 static TqSide &tq_side()
 {
 	static thread_local TqSide sd;
-	if (sd.stream == nullptr || sd.device != ctx().device) {
-		FH_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
-		FH_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
-		FH_HIP(hipEventCreateWithFlags(&sd.done, hipEventDisableTiming));
+	if (sd.panel == nullptr || sd.device != ctx().device) {
+		FH_HIP(hipStreamCreateWithFlags(&sd.panel, hipStreamNonBlocking));
+		FH_HIP(hipStreamCreateWithFlags(&sd.tx, hipStreamNonBlocking));
+		for (hipEvent_t *e : {&sd.pfork, &sd.pdone, &sd.xfork, &sd.xdone})
+			FH_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
 		sd.device = ctx().device;
 	}
 	return sd;
@@ -1464,36 +1516,38 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	const int typ = ldc, ldz = ldc;
 	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * 4), sp((size_t) TQ_NB * 256 * 4);
 	// fp64 workspace: G (NG x 4096), N1, N3 (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64),
-	//                 Td, Md (npan x 4096 each), Z, B (npan x 64 x ldz each); then fp32: Mn (4096), Yn (64 x typ); then the status words
+	//                 Td, Md (npan x 4096 each), Z, B (npan x 64 x ldz each); then fp32: Mn (npan x 4096), top (4096), Yn (64 x typ); then the status words
 	const size_t nd = (size_t) TQ_NG * 4096 + 2 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
 			  (size_t) 2 * npan * 64 * ldz;
-	Scratch small(nd * 8 + (size_t) (4096 + 64 * typ) * 4 + 2048);
+	Scratch small(nd * 8 + ((size_t) npan * 4096 + 4096 + (size_t) 64 * typ) * 4 + 2048);
 	double *G = small.as<double>();
 	double *N1 = G + (size_t) TQ_NG * 4096, *N3 = N1 + 4096, *C = N3 + 4096;
 	double *S = C + (size_t) TQ_NG * 64 * ldc, *abv = S + (size_t) TQ_NG * 256;
 	double *Td = abv + n + 64, *Md = Td + (size_t) npan * 4096, *Z = Md + (size_t) npan * 4096, *Bx = Z + (size_t) npan * 64 * ldz;
-	float *Mn = reinterpret_cast<float *>(Bx + (size_t) npan * 64 * ldz);
-	float *Yn = Mn + 4096;
+	float *Mn = reinterpret_cast<float *>(Bx + (size_t) npan * 64 * ldz); // one per panel: V of step k is formed beside panel k + 1
+	float *top = Mn + (size_t) npan * 4096;
+	float *Yn = top + 4096;
 	int *stat = reinterpret_cast<int *>(Yn + (size_t) 64 * typ);
 	FH_HIP(hipMemsetAsync(stat, 0, 2048, s));
 	FH_HIP(hipMemsetAsync(abv, 0, (size_t) (n + 64) * 8, s));
 	const bool cross = bs > TQ_PW && npan > 1;
 	if (cross)
 		FH_HIP(hipMemsetAsync(Z, 0, (size_t) npan * 64 * ldz * 8, s));
-	auto launch_gram = [&](int c0, int w, bool first) {
-		// G of panel [c0, c0 + w) and C against everything right of it, rows from c0 down, strips of <= 192 columns
-		const int t = (int) n - c0 - w;
+	// Gram launches of panel [c0, c0 + w), rows from c0 down: G (want_g) and / or C against the columns [cx, cx + t) in strips
+	// of <= 192
+	auto launch_gram = [&](int c0, int w, bool want_g, int cx, int t, bool first) {
 		const float *P = A.p + (long) c0 * ld + c0;
 		const int rows = (int) (m - c0);
 		if (t == 0) {
-			tq_gram(P, P, ld, rows, w, 0, true, first, vec, gp.as<double>(), cp.as<float>(), sp.as<float>(), G, C, ldc, 0, S, stat);
+			if (want_g)
+				tq_gram(P, P, ld, rows, w, 0, true, first, vec, gp.as<double>(), cp.as<float>(), sp.as<float>(), G, C, ldc, 0, S, stat, c0);
 			return;
 		}
 		for (int off = 0; off < t; off += TQ_TS) {
 			const int ts = t - off < TQ_TS ? t - off : TQ_TS;
 			// the range guard covers the first strip only (n <= 256); wider matrices check the rest per panel through G
-			tq_gram(P, A.p + (long) (c0 + w + off) * ld + c0, ld, rows, w, ts, off == 0, first && off == 0, vec, gp.as<double>(),
-				cp.as<float>(), sp.as<float>(), G, C, ldc, off, S, stat);
+			tq_gram(P, A.p + (long) (cx + off) * ld + c0, ld, rows, w, ts, want_g && off == 0, first && off == 0, vec, gp.as<double>(),
+				cp.as<float>(), sp.as<float>(), G, C, ldc, cx + off - (c0 + w), S, stat, c0);
 		}
 	};
 	auto tx_args = [&]() {
@@ -1514,12 +1568,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		ta.stage = 0;
 		return ta;
 	};
-	// one block of Q_coeff over all panels (the tall-skinny case): the cross-panel blocks of T in two stages
-	const bool two_stage = cross && bs >= n && bs <= (TQ_TX_MAXL + 1) * TQ_PW && npan >= 2;
-	TqSide &side = tq_side();
-	bool stage2_on_side = false;
-	launch_gram(0, (int) (n < TQ_PW ? n : TQ_PW), true);
-	for (int k = 0; k < npan; ++k) {
+	auto launch_panel = [&](int k, hipStream_t ps) {
 		const int c0 = k * TQ_PW;
 		const int w = (int) (n - c0 < TQ_PW ? n - c0 : TQ_PW);
 		const int t = (int) n - c0 - w;
@@ -1538,7 +1587,8 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		pa.abv = abv;
 		pa.N1 = N1;
 		pa.N3 = N3;
-		pa.Mn = Mn;
+		pa.Mn = Mn + (size_t) k * 4096;
+		pa.top = top;
 		pa.Md = Md + (size_t) k * 4096;
 		pa.Td = Td + (size_t) k * 4096;
 		pa.H = H.p;
@@ -1548,7 +1598,33 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		pa.taus = taus;
 		pa.stat = stat;
 		pa.dbg = reinterpret_cast<long long *>(stat + 16);
-		hipLaunchKernelGGL(tq_panel_kernel, dim3(1), dim3(TQ_PT), 0, s, pa);
+		hipLaunchKernelGGL(tq_panel_kernel, dim3(1), dim3(TQ_PT), 0, ps, pa);
+	};
+	// one block of Q_coeff over all panels (the tall-skinny case): the cross-panel blocks of T in two stages beside the last steps
+	const bool two_stage = cross && bs >= n && bs <= (TQ_TX_MAXL + 1) * TQ_PW && npan >= 2;
+	// look-ahead: the columns of the next panel are updated first, its Gram matrix and its panel kernel (ONE workgroup, ~150 us)
+	// follow at once, and the rest of the update + the products against the next panel run beside that kernel
+	// Measured on 5e5 x 256 (profiles/r03_qr_lookahead.txt): beside the streaming kernels the panel kernel takes 270-370 us
+	// instead of 205 and the split launches read both panels twice -- 2.50 ms against 2.39 ms without.  It is on where the
+	// rest of the update is long enough to cover that (>= 192 more trailing columns); FAER_HIP_QR_TSQR_LA = 1 / 0 forces it.
+	static const int la_env = getenv("FAER_HIP_QR_TSQR_LA") ? atoi(getenv("FAER_HIP_QR_TSQR_LA")) : -1; // A/B switch
+	TqSide &side = tq_side();
+	const int ncu_all = ctx().stream_cus();
+	int cus_taken = 0; // CUs held by side-stream kernels while the persistent update kernels run
+	bool tx_on_side = false;
+	launch_gram(0, (int) (n < TQ_PW ? n : TQ_PW), true, (int) (n < TQ_PW ? n : TQ_PW), (int) (n < TQ_PW ? 0 : n - TQ_PW), true);
+	launch_panel(0, s);
+	bool panel_on_side = false;
+	for (int k = 0; k < npan; ++k) {
+		const int c0 = k * TQ_PW;
+		const int w = (int) (n - c0 < TQ_PW ? n - c0 : TQ_PW);
+		const int t = (int) n - c0 - w;
+		const int wn = t < TQ_PW ? t : TQ_PW; // width of the next panel
+		if (panel_on_side) {
+			FH_HIP(hipStreamWaitEvent(s, side.pdone, 0));
+			panel_on_side = false;
+			cus_taken -= 1;
+		}
 		if (t > 0) {
 			TqYArgs ya;
 			ya.A = A.p;
@@ -1567,80 +1643,98 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			ya.typ = typ;
 			ya.Z = Z + (size_t) k * 64 * ldz;
 			ya.ldz = ldz;
+			ya.top = top;
 			ya.stat = stat;
 			hipLaunchKernelGGL(tq_y_kernel, dim3((t + 15) / 16), dim3(256), 0, s, ya);
+		} else {
+			hipLaunchKernelGGL(tq_top_kernel, dim3(1), dim3(256), 0, s, A.p, ld, c0, c0, w, top, stat);
+		}
+		if (two_stage && k == npan - 1 && tx_on_side) {
+			// stage 2 needs this panel's kernel and the V rows the last update wrote: beside the update below
+			TqTxArgs t2 = tx_args();
+			t2.stage = 2;
+			FH_HIP(hipEventRecord(side.xfork, s));
+			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
+			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.tx, t2);
 		}
 		const int r1 = c0 + w;
 		const int rows = (int) (m - r1);
-		if (rows > 0) {
-			TqUpdArgs ua;
-			ua.ld = ld;
-			ua.rows = rows;
-			ua.w = w;
-			ua.Yn = Yn;
-			ua.typ = typ;
-			ua.Mn = Mn;
-			ua.nrb = (rows + 127) / 128;
-			ua.stat = stat;
-			ua.P = A.p + (long) c0 * ld + r1;
+		TqUpdArgs ua;
+		ua.ld = ld;
+		ua.rows = rows;
+		ua.w = w;
+		ua.Yn = Yn;
+		ua.typ = typ;
+		ua.Mn = Mn + (size_t) k * 4096;
+		ua.nrb = (rows + 127) / 128;
+		ua.stat = stat;
+		ua.c0 = c0;
+		ua.P = A.p + (long) c0 * ld + r1;
+		const bool v2 = vec && r1 % 4 == 0;
+		// columns [from, to) of the trailing matrix in strips of <= 192; with_v: V = P M afterwards (it overwrites the panel:
+		// in the same launch only when no other launch still reads the panel)
+		auto update = [&](int from, int to, bool with_v) {
+			if (rows <= 0)
+				return;
 			// one persistent workgroup per CU (its registers and LDS allow no second one): 256 measured 5 % ahead of 512 and
-			// 10 % ahead of 1024 workgroups on the 5e5 x 256 factorization
+			// 10 % ahead of 1024 workgroups on the 5e5 x 256 factorization; the side-stream kernels keep their CUs
 			int nwg = (ua.nrb + 3) / 4;
-			int ncu = ctx().stream_cus();
-			if (two_stage && k == npan - 1 && ncu > 8 * npan) {
-				// stage 2 of the cross-panel T blocks needs the panel kernel only: beside this last update, on the CUs it leaves free
-				ncu -= npan - 1;
-				TqTxArgs t2 = tx_args();
-				t2.stage = 2;
-				FH_HIP(hipEventRecord(side.fork, s));
-				FH_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
-				hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.stream, t2);
-				FH_HIP(hipEventRecord(side.done, side.stream));
-				stage2_on_side = true;
-			}
+			const int ncu = ncu_all - cus_taken > 8 ? ncu_all - cus_taken : ncu_all;
 			if (nwg > ncu)
 				nwg = ncu;
-			const int nstrip = (t + TQ_TS - 1) / TQ_TS;
-			const bool v2 = vec && r1 % 4 == 0;
-			for (int st = 0; st < nstrip || (st == 0 && nstrip == 0); ++st) {
-				ua.coff = st * TQ_TS;
-				ua.ts = nstrip == 0 ? 0 : (t - ua.coff < TQ_TS ? t - ua.coff : TQ_TS);
+			const int nstrip = (to - from + TQ_TS - 1) / TQ_TS;
+			for (int st = 0; st < nstrip; ++st) {
+				ua.coff = from + st * TQ_TS;
+				ua.ts = to - ua.coff < TQ_TS ? to - ua.coff : TQ_TS;
 				ua.X = A.p + (long) (c0 + w + ua.coff) * ld + r1;
-				ua.do_v = nstrip <= 1; // V overwrites P: only when no other launch still reads the panel
+				ua.do_v = with_v && nstrip == 1;
 				tq_launch_update(v2, nwg, ua);
 			}
-			if (nstrip > 1) {
+			if (with_v && nstrip != 1) {
 				ua.coff = 0;
 				ua.ts = 0;
 				ua.X = ua.P;
 				ua.do_v = 1;
 				tq_launch_update(v2, nwg, ua);
 			}
+		};
+		if (t == 0) {
+			update(0, 0, true);
+		} else if (!(la_env >= 0 ? la_env != 0 : t - wn >= TQ_TS)) {
+			update(0, t, true);
+			launch_gram(c0 + w, wn, true, c0 + w + wn, t - wn, false);
+			launch_panel(k + 1, s);
+		} else {
+			update(0, wn, false);
+			launch_gram(c0 + w, wn, true, c0 + w + wn, 0, false);
+			FH_HIP(hipEventRecord(side.pfork, s));
+			FH_HIP(hipStreamWaitEvent(side.panel, side.pfork, 0));
+			launch_panel(k + 1, side.panel);
+			FH_HIP(hipEventRecord(side.pdone, side.panel));
+			panel_on_side = true;
+			cus_taken += 1;
+			update(wn, t, true);
+			launch_gram(c0 + w, wn, false, c0 + w + wn, t - wn, false);
 		}
 		if (two_stage && k == npan - 2) {
-			// everything of the cross-panel T blocks that does not depend on the last panel's kernel: on the side stream, beside
-			// the Gram / reduce / panel kernels of the last panel (a single workgroup busy most of that time)
+			// everything of the cross-panel T blocks that does not depend on the last panel's kernel: beside the Gram / reduce /
+			// panel kernels of the last panel (a single workgroup busy most of that time), one CU per panel
 			TqTxArgs t1 = tx_args();
 			t1.stage = 1;
-			FH_HIP(hipEventRecord(side.fork, s));
-			FH_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
-			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.stream, t1);
-			FH_HIP(hipEventRecord(side.done, side.stream));
-		}
-		if (t > 0) {
-			const int wn = t < TQ_PW ? t : TQ_PW;
-			launch_gram(c0 + w, wn, false);
+			FH_HIP(hipEventRecord(side.xfork, s));
+			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
+			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.tx, t1);
+			tx_on_side = true;
+			if (ncu_all > 8 * npan)
+				cus_taken += npan - 1;
 		}
 		FH_HIP(hipGetLastError());
 	}
 	if (cross) {
 		TqTxArgs ta = tx_args();
-		if (two_stage) {
-			FH_HIP(hipStreamWaitEvent(s, side.done, 0)); // stage 1 ran beside the last panel's kernels
-			if (!stage2_on_side) {
-				ta.stage = 2;
-				hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
-			}
+		if (tx_on_side) {
+			FH_HIP(hipEventRecord(side.xdone, side.tx));
+			FH_HIP(hipStreamWaitEvent(s, side.xdone, 0));
 		} else if (bs <= (TQ_TX_MAXL + 1) * TQ_PW) {
 			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
 		} else {

@@ -19,6 +19,10 @@ for sec in "$@"; do
       for sw in 1 0; do
         FAER_HIP_QR_TSQR=$sw timeout 300 python bench.py --workload qr --steps 10 --warmup 2 --no-extras --no-cpu 2>&1 | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/tsqr=$sw /"
       done ;;
+    qrla)
+      for sw in 1 0 1 0; do
+        FAER_HIP_QR_TSQR_LA=$sw timeout 300 python bench.py --workload qr --steps 10 --warmup 2 --no-extras --no-cpu 2>&1 | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/lookahead=$sw /"
+      done ;;
     qrprof)
       rm -rf gpurun_out/prof_${tag}_qr
       timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_qr -o qr -- python bench.py --workload qr --steps 10 --warmup 2 --no-extras --no-cpu > gpurun_out/prof_${tag}_qr.log 2>&1; echo "prof qr rc=$?"
