@@ -71,6 +71,7 @@ struct TqGramArgs {
 	float *Sp;  // [grid][256] per-column sums of squares of the staged columns (range guard of the first launch)
 	const int *stat;
 	int c0; // first column of the panel (tq_skip)
+	float *A1s; // want_g: the panel's top 64 x 64 block, column major, for the panel kernel (see there)
 };
 
 template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(const TqGramArgs a)
@@ -127,6 +128,11 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(con
 		load_chunk(ch);
 	for (; ch < a.nchunks; ch += gridDim.x) {
 		__syncthreads(); // the previous chunk has been consumed
+		if (ch == 0 && a.want_g) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				*reinterpret_cast<f32x4 *>(a.A1s + (i * 16 + cg) * 64 + quad * 4) = st[i];
+		}
 #pragma unroll
 		for (int i = 0; i < 16; ++i)
 			if (i * 16 < ncol) {
@@ -291,6 +297,7 @@ struct TqPanelArgs {
 	double *abv;	   // per global column: sum of squares of the R entries above the current block row
 	double *N1, *N3; // out: R^-T, V1^-1 (row major 64 x 64); with M they give Y = -M V1^-1 (R^-T C - X_top)
 	float *Mn;	   // out: M = -(U R)^-1, row major 64 x 64
+	const float *A1s;  // the panel's top block before the factorization, column major 64 x 64 (written by the Gram kernel)
 	float *top;	   // out: the panel's top block (R on and above the diagonal, V1 below), row major 64 x 64 -- NOT written
 			   // into A here: the Gram launch of this panel's trailing columns may still be reading those rows
 	double *Md, *Td;   // out: M and T of this panel in fp64 (cross-panel blocks of T)
@@ -545,9 +552,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 		// fp32 products of the C sums underflow / overflow for columns far from unit scale: rms outside [1e-12, 1e12]
 		const double lo = 1e-24 * (double) (a.m - a.r0), hi = 1e24 * (double) (a.m - a.r0);
 		bool bad = false;
-		for (int c = tid; c < 64 + a.range_cols; c += TQ_PT) {
-			if (c < 64 && c >= w)
-				continue;
+		for (int c = tid; c < w; c += TQ_PT) { // the trailing columns: tq_y_kernel of this step
 			double sq = 0.0;
 			for (int g = 0; g < TQ_NG; ++g)
 				sq += a.S[g * 256 + c];
@@ -562,6 +567,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 			return;
 		}
 	}
+	TQ_STAMP(12);
 	// ---- G (the sum of its TQ_NG slices, identity beyond w) and A1 (zero beyond w) through LDS, coalesced; the loads of four
 	//      entries (36 of them) are in flight together: one entry at a time this was 36 000 cycles of dependent round trips
 #pragma unroll 1
@@ -577,7 +583,9 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 #pragma unroll
 			for (int q = 0; q < TQ_NG; ++q)
 				gs[u][q] = in ? a.G[q * 4096 + el] : 0.0;
-			av[u] = in ? a.A[(long) (a.c0 + i) * a.ld + a.r0 + j] : 0.f; // transposed fill: lanes along the rows of A
+			// the top block as the Gram kernel's first workgroup copied it: read from A it is 64 columns on 64 different
+			// pages (2 MB apart at m = 5e5), and this single workgroup waited for every one of the address translations
+			av[u] = in ? a.A1s[e] : 0.f;
 		}
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
@@ -593,7 +601,9 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 			Wm[j * TQ_DP + i] = (double) av[u];
 		}
 	}
+	TQ_STAMP(13);
 	__syncthreads();
+	TQ_STAMP(14);
 	double x[64];
 	if (kind == 0) {
 #pragma unroll
@@ -613,6 +623,8 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	constexpr int NBLK = 64 / TQ_NJ;
 #pragma unroll 1
 	for (int it = 0; it <= NBLK; ++it) {
+		if (it < 8)
+			TQ_STAMP(16 + it);
 		const int blk = kind == 0 ? it : it - 1;
 		if (kind < 3 && blk >= 0 && blk < NBLK) {
 			if (tq_a_block(x, kind, blk, r, Lm, dinv, kind == 1 ? Wm : Ri) && r == 0)
@@ -645,6 +657,8 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	__syncthreads();
 #pragma unroll 1
 	for (int it = 0; it <= NBLK; ++it) {
+		if (it < 8)
+			TQ_STAMP(24 + it);
 		const int blk = kind == 0 ? it : it - 1;
 		if (kind < 3 && blk >= 0 && blk < NBLK) {
 			if (kind == 1) {
@@ -814,7 +828,9 @@ struct TqYArgs {
 	double *Z; // out: Z = -V1^-1 (D - X_top) = T^-H V^H X, row major 64 x ldz, column index = GLOBAL column
 	int ldz;
 	const float *top; // the panel's top block as the panel kernel left it (workgroup 0 stores it into A)
-	const int *stat;
+	int *stat;
+	const double *Sr; // first step only (check_range): TQ_NG slices of the column squares, trailing columns at [64, 64 + range_cols)
+	int check_range, range_cols, mrows;
 };
 
 // the panel's top block from its staging copy into A (once every reader of the original rows is done)
@@ -841,6 +857,27 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 	if (tq_skip(a.stat, a.r0))
 		return;
 	const int tid = threadIdx.x;
+	if (a.check_range) {
+		// fp32 products of the C sums underflow / overflow for columns far from unit scale: rms outside [1e-12, 1e12] (the
+		// panel kernel checked its own columns).  Every workgroup evaluates the same sums; nothing has been written yet.
+		const double lo = 1e-24 * (double) a.mrows, hi = 1e24 * (double) a.mrows;
+		int bad = 0;
+		if (tid < a.range_cols) {
+			double sq = 0.0;
+			for (int g = 0; g < TQ_NG; ++g)
+				sq += a.Sr[g * 256 + 64 + tid];
+			bad = !(sq >= lo && sq <= hi);
+		}
+		if (__syncthreads_or(bad)) {
+			if (blockIdx.x == 0 && tid == 0) {
+				a.stat[1] = a.r0;
+				a.stat[2] = TQ_FAIL_RANGE;
+				__threadfence();
+				*reinterpret_cast<volatile int *>(a.stat) = a.r0 + 1;
+			}
+			return;
+		}
+	}
 	if (blockIdx.x == 0)
 		tq_store_top(a.A, a.ld, a.r0, a.cx - a.w, a.w, a.top, tid);
 	for (int e = tid; e < 4096; e += 256) {
@@ -1439,10 +1476,11 @@ static void tq_launch_update(bool vec, int nwg, const TqUpdArgs &ua)
 }
 
 static void tq_gram(const float *P, const float *X, long ld, int rows, int w, int t, bool want_g, bool want_sq, bool vec, double *Gp, float *Cp,
-		    float *Sp, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0)
+		    float *Sp, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0, float *A1s)
 {
 	hipStream_t s = ctx().stream;
 	TqGramArgs g;
+	g.A1s = A1s;
 	g.P = P;
 	g.X = X;
 	g.ld = ld;
@@ -1515,18 +1553,19 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	const int ldc = ((int) n + 63) & ~63;
 	const int typ = ldc, ldz = ldc;
 	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * 4), sp((size_t) TQ_NB * 256 * 4);
-	// fp64 workspace: G (NG x 4096), N1, N3 (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64),
-	//                 Td, Md (npan x 4096 each), Z, B (npan x 64 x ldz each); then fp32: Mn (npan x 4096), top (4096), Yn (64 x typ); then the status words
-	const size_t nd = (size_t) TQ_NG * 4096 + 2 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
+	// fp64 workspace: G (NG x 4096), N1, N3 (4096 each), C (NG x 64 x ldc), S, S2 (NG x 256 each), abv (n + 64),
+	//                 Td, Md (npan x 4096 each), Z, B (npan x 64 x ldz each); then fp32: Mn (npan x 4096), top, A1s (4096 each), Yn (64 x typ); then the status words
+	const size_t nd = (size_t) TQ_NG * 4096 + 2 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) 2 * TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
 			  (size_t) 2 * npan * 64 * ldz;
-	Scratch small(nd * 8 + ((size_t) npan * 4096 + 4096 + (size_t) 64 * typ) * 4 + 2048);
+	Scratch small(nd * 8 + ((size_t) npan * 4096 + 2 * 4096 + (size_t) 64 * typ) * 4 + 2048);
 	double *G = small.as<double>();
 	double *N1 = G + (size_t) TQ_NG * 4096, *N3 = N1 + 4096, *C = N3 + 4096;
-	double *S = C + (size_t) TQ_NG * 64 * ldc, *abv = S + (size_t) TQ_NG * 256;
+	double *S = C + (size_t) TQ_NG * 64 * ldc, *S2 = S + (size_t) TQ_NG * 256, *abv = S2 + (size_t) TQ_NG * 256;
 	double *Td = abv + n + 64, *Md = Td + (size_t) npan * 4096, *Z = Md + (size_t) npan * 4096, *Bx = Z + (size_t) npan * 64 * ldz;
 	float *Mn = reinterpret_cast<float *>(Bx + (size_t) npan * 64 * ldz); // one per panel: V of step k is formed beside panel k + 1
 	float *top = Mn + (size_t) npan * 4096;
-	float *Yn = top + 4096;
+	float *A1s = top + 4096;
+	float *Yn = A1s + 4096;
 	int *stat = reinterpret_cast<int *>(Yn + (size_t) 64 * typ);
 	FH_HIP(hipMemsetAsync(stat, 0, 2048, s));
 	FH_HIP(hipMemsetAsync(abv, 0, (size_t) (n + 64) * 8, s));
@@ -1535,19 +1574,19 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		FH_HIP(hipMemsetAsync(Z, 0, (size_t) npan * 64 * ldz * 8, s));
 	// Gram launches of panel [c0, c0 + w), rows from c0 down: G (want_g) and / or C against the columns [cx, cx + t) in strips
 	// of <= 192
-	auto launch_gram = [&](int c0, int w, bool want_g, int cx, int t, bool first) {
+	auto launch_gram = [&](int c0, int w, bool want_g, int cx, int t, bool first, double *Sd) {
 		const float *P = A.p + (long) c0 * ld + c0;
 		const int rows = (int) (m - c0);
 		if (t == 0) {
 			if (want_g)
-				tq_gram(P, P, ld, rows, w, 0, true, first, vec, gp.as<double>(), cp.as<float>(), sp.as<float>(), G, C, ldc, 0, S, stat, c0);
+				tq_gram(P, P, ld, rows, w, 0, true, first, vec, gp.as<double>(), cp.as<float>(), sp.as<float>(), G, C, ldc, 0, Sd, stat, c0, A1s);
 			return;
 		}
 		for (int off = 0; off < t; off += TQ_TS) {
 			const int ts = t - off < TQ_TS ? t - off : TQ_TS;
 			// the range guard covers the first strip only (n <= 256); wider matrices check the rest per panel through G
 			tq_gram(P, A.p + (long) (cx + off) * ld + c0, ld, rows, w, ts, want_g && off == 0, first && off == 0, vec, gp.as<double>(),
-				cp.as<float>(), sp.as<float>(), G, C, ldc, cx + off - (c0 + w), S, stat, c0);
+				cp.as<float>(), sp.as<float>(), G, C, ldc, cx + off - (c0 + w), Sd, stat, c0, A1s);
 		}
 	};
 	auto tx_args = [&]() {
@@ -1589,6 +1628,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		pa.N3 = N3;
 		pa.Mn = Mn + (size_t) k * 4096;
 		pa.top = top;
+		pa.A1s = A1s;
 		pa.Md = Md + (size_t) k * 4096;
 		pa.Td = Td + (size_t) k * 4096;
 		pa.H = H.p;
@@ -1606,15 +1646,39 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	// follow at once, and the rest of the update + the products against the next panel run beside that kernel
 	// Measured on 5e5 x 256 (profiles/r03_qr_lookahead.txt): beside the streaming kernels the panel kernel takes 270-370 us
 	// instead of 205 and the split launches read both panels twice -- 2.50 ms against 2.39 ms without.  It is on where the
-	// rest of the update is long enough to cover that (>= 192 more trailing columns); FAER_HIP_QR_TSQR_LA = 1 / 0 forces it.
+	// rest of the update is long enough to cover that (>= 192 more trailing columns).  Otherwise only the Gram launch is
+	// split (gram_and_panel below).  FAER_HIP_QR_TSQR_LA = 0 / 1 / 2: neither / always the first / always the second.
 	static const int la_env = getenv("FAER_HIP_QR_TSQR_LA") ? atoi(getenv("FAER_HIP_QR_TSQR_LA")) : -1; // A/B switch
 	TqSide &side = tq_side();
 	const int ncu_all = ctx().stream_cus();
 	int cus_taken = 0; // CUs held by side-stream kernels while the persistent update kernels run
 	bool tx_on_side = false;
-	launch_gram(0, (int) (n < TQ_PW ? n : TQ_PW), true, (int) (n < TQ_PW ? n : TQ_PW), (int) (n < TQ_PW ? 0 : n - TQ_PW), true);
-	launch_panel(0, s);
 	bool panel_on_side = false;
+	const double *s_trailing = S; // where the first step's squares of the trailing columns are
+	// Gram products and panel kernel of panel p.  The panel kernel needs G only: with enough trailing columns the products
+	// against them (C) are a second launch that runs BESIDE the panel kernel (the panel columns are read twice)
+	auto gram_and_panel = [&](int p, bool first) {
+		const int pc0 = p * TQ_PW;
+		const int pw = (int) (n - pc0 < TQ_PW ? n - pc0 : TQ_PW);
+		const int pt = (int) n - pc0 - pw;
+		const bool split = la_env >= 0 ? la_env == 2 && pt > 0 : pt >= 2 * TQ_PW;
+		if (!split) {
+			launch_gram(pc0, pw, true, pc0 + pw, pt, first, S);
+			launch_panel(p, s);
+			return;
+		}
+		launch_gram(pc0, pw, true, pc0 + pw, 0, first, S);
+		FH_HIP(hipEventRecord(side.pfork, s));
+		FH_HIP(hipStreamWaitEvent(side.panel, side.pfork, 0));
+		launch_panel(p, side.panel);
+		FH_HIP(hipEventRecord(side.pdone, side.panel));
+		panel_on_side = true;
+		cus_taken += 1;
+		launch_gram(pc0, pw, false, pc0 + pw, pt, first, S2);
+		if (first)
+			s_trailing = S2;
+	};
+	gram_and_panel(0, true);
 	for (int k = 0; k < npan; ++k) {
 		const int c0 = k * TQ_PW;
 		const int w = (int) (n - c0 < TQ_PW ? n - c0 : TQ_PW);
@@ -1645,6 +1709,10 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			ya.ldz = ldz;
 			ya.top = top;
 			ya.stat = stat;
+			ya.Sr = s_trailing;
+			ya.check_range = k == 0;
+			ya.range_cols = t < TQ_TS ? t : TQ_TS;
+			ya.mrows = (int) m;
 			hipLaunchKernelGGL(tq_y_kernel, dim3((t + 15) / 16), dim3(256), 0, s, ya);
 		} else {
 			hipLaunchKernelGGL(tq_top_kernel, dim3(1), dim3(256), 0, s, A.p, ld, c0, c0, w, top, stat);
@@ -1700,13 +1768,12 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		};
 		if (t == 0) {
 			update(0, 0, true);
-		} else if (!(la_env >= 0 ? la_env != 0 : t - wn >= TQ_TS)) {
+		} else if (!(la_env >= 0 ? la_env == 1 : t - wn >= TQ_TS)) {
 			update(0, t, true);
-			launch_gram(c0 + w, wn, true, c0 + w + wn, t - wn, false);
-			launch_panel(k + 1, s);
+			gram_and_panel(k + 1, false);
 		} else {
 			update(0, wn, false);
-			launch_gram(c0 + w, wn, true, c0 + w + wn, 0, false);
+			launch_gram(c0 + w, wn, true, c0 + w + wn, 0, false, S);
 			FH_HIP(hipEventRecord(side.pfork, s));
 			FH_HIP(hipStreamWaitEvent(side.panel, side.pfork, 0));
 			launch_panel(k + 1, side.panel);
@@ -1714,7 +1781,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			panel_on_side = true;
 			cus_taken += 1;
 			update(wn, t, true);
-			launch_gram(c0 + w, wn, false, c0 + w + wn, t - wn, false);
+			launch_gram(c0 + w, wn, false, c0 + w + wn, t - wn, false, S);
 		}
 		if (two_stage && k == npan - 2) {
 			// everything of the cross-panel T blocks that does not depend on the last panel's kernel: beside the Gram / reduce /
@@ -1751,6 +1818,13 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		FH_HIP(hipMemcpy(d, stat + 16, sizeof(d), hipMemcpyDeviceToHost));
 		fprintf(stderr, "tq_panel phases (shader cycles): start %lld: load %lld chol %lld reload %lld lu %lld finish %lld tests %lld out %lld M %lld T %lld\n",
 			d[0], d[1] - d[0], d[2] - d[1], 0LL, d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[8] - d[7]);
+		fprintf(stderr, "  load: range %lld loads %lld barrier %lld fill %lld | A iterations:", d[12] - d[0], d[13] - d[12], d[14] - d[13], d[1] - d[14]);
+		for (int i = 0; i < 7; ++i)
+			fprintf(stderr, " %lld", d[17 + i] - d[16 + i]);
+		fprintf(stderr, " | B iterations:");
+		for (int i = 0; i < 7; ++i)
+			fprintf(stderr, " %lld", d[25 + i] - d[24 + i]);
+		fprintf(stderr, "\n");
 		double res[3];
 		memcpy(res, d + 9, sizeof(res));
 		fprintf(stderr, "tq_panel residuals of the last panel: |V1 V1^-1 - I| %.3e  |U U^-1 - I| %.3e  |R~ R~^-1 - I| %.3e\n", res[0], res[1], res[2]);

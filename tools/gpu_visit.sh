@@ -20,7 +20,7 @@ for sec in "$@"; do
         FAER_HIP_QR_TSQR=$sw timeout 300 python bench.py --workload qr --steps 10 --warmup 2 --no-extras --no-cpu 2>&1 | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/tsqr=$sw /"
       done ;;
     qrla)
-      for sw in 1 0 1 0; do
+      for sw in 2 0 2 0; do
         FAER_HIP_QR_TSQR_LA=$sw timeout 300 python bench.py --workload qr --steps 10 --warmup 2 --no-extras --no-cpu 2>&1 | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/lookahead=$sw /"
       done ;;
     qrprof)
