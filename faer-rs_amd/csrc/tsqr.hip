@@ -236,13 +236,46 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(con
 // strided loads each.
 constexpr int TQ_NG = 8;
 __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const float *Cp, const float *Sp, int nb, int tp, int want_g,
-							 int want_sq, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0)
+							 int want_sq, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0,
+							 double *Gf, int *cnt)
 {
+	__shared__ int s_last;
 	if (tq_skip(stat, c0))
 		return;
 	const int e = blockIdx.x * 256 + threadIdx.x;
 	const int g = blockIdx.y;
 	const int ng = want_g ? 4096 : 0, nc = 64 * tp, ns = want_sq ? 256 : 0;
+	if (blockIdx.x * 256 < ng) { // (4096 = 16 x 256: a workgroup is all G or not at all)
+		double s0 = 0, s1 = 0;
+		int b = g;
+		for (; b + TQ_NG < nb; b += 2 * TQ_NG) {
+			s0 += Gp[(long) b * 4096 + e];
+			s1 += Gp[(long) (b + TQ_NG) * 4096 + e];
+		}
+		if (b < nb)
+			s0 += Gp[(long) b * 4096 + e];
+		G[(long) g * 4096 + e] = s0 + s1;
+		// The slices of G are added up here as well, by whichever of the TQ_NG workgroups of these 256 entries finishes last
+		// (fixed order of the slices): the panel kernel -- ONE workgroup -- then reads 32 KB instead of 256 KB, which took
+		// it 35 000 cycles.  The counters return to zero by themselves.
+		__threadfence();
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const int old = atomicAdd(&cnt[blockIdx.x], 1);
+			s_last = old == TQ_NG - 1;
+			if (s_last)
+				cnt[blockIdx.x] = 0;
+		}
+		__syncthreads();
+		if (s_last) {
+			__threadfence();
+			double sum = 0.0;
+			for (int q = 0; q < TQ_NG; ++q)
+				sum += __builtin_nontemporal_load(&G[(long) q * 4096 + e]);
+			Gf[e] = sum;
+		}
+		return;
+	}
 	if (e < ng) {
 		double s0 = 0, s1 = 0;
 		int b = g;
@@ -291,7 +324,7 @@ struct TqPanelArgs {
 	float *A;
 	long ld;
 	int m, r0, c0, w, n;
-	const double *G;   // TQ_NG slices of the Gram matrix, row major 64 x 64 (w x w valid)
+	const double *G;   // the Gram matrix (sum of the TQ_NG slices), row major 64 x 64 (w x w valid, lower 16 x 16 tiles)
 	const double *S;   // TQ_NG slices of the column squares of the first launch: [0, 64) panel, [64, ..) trailing
 	int check_range, range_cols;
 	double *abv;	   // per global column: sum of squares of the R entries above the current block row
@@ -338,177 +371,252 @@ static __device__ __forceinline__ double tq_rl(double v, int l)
 	return __hiloint2double(hi, lo);
 }
 
-// The two eliminations of tq_panel_kernel, one WAVEFRONT per kind of row, lane r = row, the 64 columns of the row in
-// registers.  The sequential part -- the 64 pivots -- runs inside wavefront 0 without a workgroup barrier: the pivot comes
-// from its own lanes through v_readlane, the multipliers of the other columns / the pivot row go to LDS (they are part of
-// the result anyway) and come back as wave-uniform broadcast reads, one read + one FMA per entry.  Wavefronts 1 and 2
-// repeat the same column operations on their rows ONE BLOCK of TQ_NJ columns behind, from what wavefront 0 published:
-// 64 / TQ_NJ + 1 workgroup barriers per elimination instead of 64.  Rows rotate left by TQ_NJ positions per block, so the
-// column being eliminated sits at a static position jj < TQ_NJ.
-// What was measured on the way (profiles/r03_qr_panel_phases.txt):
-//   * v_readlane per entry (two per fp64 value, then an FMA on the scalar pair) is a dependent SALU -> readlane -> FMA
-//     chain: ~20 cycles per instruction;
+// The small-matrix work of tq_panel_kernel is BLOCKED by 16 columns: only the 16 x 16 diagonal blocks are eliminated column
+// by column (inside ONE wavefront, rows in lanes, the 16 columns of the block in registers, pivots and pivot rows through
+// v_readlane); everything else -- the blocks below / right of a diagonal block (a triangular substitution per lane), the
+// trailing updates and the three triangular inverses (16 x 16 x 16 products on the fp64 matrix cores) -- has no per-column
+// synchronisation at all.  The first version eliminated all 64 columns one after the other with every row in registers
+// (one wavefront per kind of row, multipliers through LDS): 1 400 (Cholesky) and 2 750 (LU) cycles per column, 270 000 of
+// the kernel's 470 000 cycles (profiles/r03_qr_panel_phases.txt).
+// What was measured on the way (same file):
 //   * a write by ONE lane followed by a wave-uniform read of the same LDS word needs a fence + wave barrier in between --
-//     without it the read was hoisted above the masked store (V1^-1 lost its second-order terms, 4e-5);
-//   * the block body must stay SMALL: with 8 columns unrolled per kind (~16 KB each) the first pass through each body cost
-//     60 000 - 90 000 cycles of instruction-cache misses against ~10 000 for every later pass.  One body for all kinds,
-//     TQ_NJ = 4 columns per pass.
-constexpr int TQ_NJ = 4;
-
+//     without it the read was hoisted above the masked store;
+//   * code that runs once costs ~3.5 cycles per byte (instruction fetch, one cache line per L2 round trip): the kernel is
+//     ONE workgroup that starts cold every launch, so unrolled bodies are kept to what is re-used by the four block steps.
 static __device__ __forceinline__ void tq_lds_order()
 {
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	__builtin_amdgcn_wave_barrier();
 }
 
-// x[k] -= a * src[k * stride] for the positions k >= k0 (k0 <= TQ_NJ, an unrolled-loop constant) of the live groups of 8:
-// the broadcast reads of a group are issued together, then its FMAs
-static __device__ __forceinline__ void tq_axpy_from(int k0, double (&x)[64], double a, const double *src, int stride, int live)
+// A 64 x 64 fp64 matrix in LDS seen through strides (a transposed view swaps them) and a structure mask in LOGICAL
+// coordinates: 0 as stored, 1 lower incl. diagonal, 2 unit lower (the stored strictly lower part, ones on the diagonal),
+// 3 upper incl. diagonal, 4 unit upper; rsc (optional): row r is scaled by rsc[r].
+struct TqMat {
+	const double *p;
+	int rs, cs, mode;
+	const double *rsc;
+};
+static __device__ __forceinline__ double tq_get(const TqMat &M, int r, int c)
+{
+	double v = M.p[r * M.rs + c * M.cs];
+	if (M.mode == 1)
+		v = c <= r ? v : 0.0;
+	else if (M.mode == 2)
+		v = c < r ? v : (c == r ? 1.0 : 0.0);
+	else if (M.mode == 3)
+		v = r <= c ? v : 0.0;
+	else if (M.mode == 4)
+		v = r < c ? v : (c == r ? 1.0 : 0.0);
+	if (M.rsc)
+		v *= M.rsc[r];
+	return v;
+}
+// acc += A(tile ti, tile kt) * B(tile kt, tile tj); acc[q]: row (lane >> 4) + 4 q, column lane & 15 of the 16 x 16 tile
+static __device__ __forceinline__ void tq_tile_mac(f64x4 &acc, const TqMat &A, int ti, const TqMat &B, int tj, int kt, int lane)
 {
 #pragma unroll
-	for (int g = 0; g < 8; ++g) {
-		if (8 * g < live) { // wave uniform
-			double m[8];
-#pragma unroll
-			for (int q = 0; q < 8; ++q)
-				m[q] = src[(8 * g + q) * stride];
-#pragma unroll
-			for (int q = 0; q < 8; ++q)
-				if (8 * g + q >= k0)
-					x[8 * g + q] = __builtin_fma(-a, m[q], x[8 * g + q]);
-		}
+	for (int s4 = 0; s4 < 4; ++s4) {
+		const int k = 16 * kt + 4 * s4 + (lane >> 4);
+		const double av = tq_get(A, 16 * ti + (lane & 15), k);
+		const double bv = tq_get(B, k, 16 * tj + (lane & 15));
+		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
 	}
 }
 
-// A: Cholesky of G (kind 0) -> L in Lm (junk above the diagonal), reciprocal roots in dinv; kinds 1 / 2: the rows of A1 / of
-//    I under the same column operations -> Q1~ = A1 R~^-1 in Wm, R~^-1 in Ri.  Block b = columns TQ_NJ b .. + TQ_NJ - 1.
-static __device__ __forceinline__ bool tq_a_block(double (&x)[64], int kind, int b, int r, double *Lm, double *dinv, double *out)
+// The three column-by-column routines below work on FOUR columns per pass of a loop and then rotate the 16 registers by
+// four positions, so that the columns in hand sit at the static positions 0 .. 3: one loop body of a quarter of the fully
+// unrolled size (6 KB each, and the kernel runs at the speed of its instruction fetch) at nearly its speed (rotating by
+// one position per column measured 2 000 cycles per column against 800).  In pass b position k holds column 4 b + k
+// (mod 16); the positions with 4 b + k >= 16 are finished columns.
+static __device__ __forceinline__ void tq_rot16(double (&x)[16])
 {
-	const int live = 64 - TQ_NJ * b; // positions < live hold columns <= 63 (dead positions of the last group read junk: unused)
-	bool bad = false;
+	double t[4];
 #pragma unroll
-	for (int jj = 0; jj < TQ_NJ; ++jj) {
-		const int J = TQ_NJ * b + jj;
-		double a;
-		if (kind == 0) {
-			const double d = tq_rl(x[jj], J);
-			bad = bad || !(d > 0.0) || !(d < 1e300); // wave uniform
-			const double rinv = tq_rsq(d);
-			a = x[jj] * rinv;	  // lane J: the root of the pivot; lanes < J: junk above the diagonal
-			Lm[r * TQ_DP + J] = a; // read back below by this wavefront
-			if (r == J)
-				dinv[J] = rinv;
-			tq_lds_order();
-		} else {
-			a = x[jj] * dinv[J];
-			out[r * TQ_DP + J] = a;
+	for (int k = 0; k < 4; ++k)
+		t[k] = x[k];
+#pragma unroll
+	for (int k = 0; k < 12; ++k)
+		x[k] = x[k + 4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+		x[12 + k] = t[k];
+}
+
+// Forward substitution with a 16 x 16 lower triangular block T (T[i][l] at T + i * trs + l * tcs, the same for every lane
+// of a group), one right-hand side per lane in z:  z <- T^-1 z.  dinv: reciprocals of the diagonal, used by the lanes
+// with `scaled` (the others have a unit diagonal).
+// UNR = 4 (rotation by four) where the call is repeated per block step, 1 (a quarter of the code) where it runs once.
+template <int UNR>
+static __device__ __forceinline__ void tq_subst16(double (&z)[16], const double *T, int trs, int tcs, const double *dinv, bool scaled)
+{
+	if (UNR == 1) {
+#pragma unroll 1
+		for (int l = 0; l < 16; ++l) {
+			const double dv = dinv[l];
+			z[0] *= scaled ? dv : 1.0;
+			const double *col = T + l * tcs + l * trs; // T[l + k][l] at col[k * trs]
+#pragma unroll
+			for (int k = 1; k < 16; ++k) {
+				const double t = l + k < 16 ? col[k * trs] : 0.0; // wave uniform
+				z[k] = __builtin_fma(-t, z[0], z[k]);
+			}
+			const double t0 = z[0];
+#pragma unroll
+			for (int k = 0; k < 15; ++k)
+				z[k] = z[k + 1];
+			z[15] = t0;
 		}
-		tq_axpy_from(jj + 1, x, a, Lm + (TQ_NJ * b) * TQ_DP + J, TQ_DP, live); // L[NJ b + k][J]: wave-uniform addresses
+		return;
+	}
+#pragma unroll 1
+	for (int b = 0; b < 4; ++b) {
+#pragma unroll
+		for (int jj = 0; jj < 4; ++jj) {
+			const int l = 4 * b + jj;
+			const double dv = dinv[l];
+			z[jj] *= scaled ? dv : 1.0;
+			const double *col = T + l * tcs + (4 * b) * trs; // T[4 b + k][l] at col[k * trs]
+			// all the reads first, unconditionally (beyond the block they land in the next rows of the LDS arrays and are
+			// discarded): guarded one by one they were issued one by one, a full LDS latency each
+			double t[16];
+#pragma unroll
+			for (int k = jj + 1; k < 16; ++k)
+				t[k] = col[k * trs];
+#pragma unroll
+			for (int k = jj + 1; k < 16; ++k) {
+				const double tk = 4 * b + k < 16 ? t[k] : 0.0; // wave uniform
+				z[k] = __builtin_fma(-tk, z[jj], z[k]);
+			}
+		}
+		tq_rot16(z);
+	}
+}
+
+// Cholesky of the 16 x 16 block D (row i in lane i & 15, lanes >= 16 repeat the rows): x <- the lower factor, zeros above
+// the diagonal; dinv16[J] <- 1 / L[J][J].  Returns true if a pivot is not positive (wave uniform).
+static __device__ __forceinline__ bool tq_chol16(double (&x)[16], int lane, double *dinv16)
+{
+	const int i = lane & 15;
+	bool bad = false;
+#pragma unroll 1
+	for (int b = 0; b < 4; ++b) {
+#pragma unroll
+		for (int jj = 0; jj < 4; ++jj) {
+			const int J = 4 * b + jj;
+			const double d = tq_rl(x[jj], J);
+			bad = bad || !(d > 0.0) || !(d < 1e300);
+			const double rinv = tq_rsq(d);
+			const double a = x[jj] * rinv; // lane i >= J: L[i][J]
+			x[jj] = i >= J ? a : 0.0;
+			if (lane == J)
+				dinv16[J] = rinv;
+			// L[4 b + k][J] from lane (4 b + k) mod 16: for a finished column that lane is < J and holds the zero written above
+#pragma unroll
+			for (int k = jj + 1; k < 16; ++k)
+				x[k] = __builtin_fma(-a, tq_rl(x[jj], (4 * b + k) & 15), x[k]);
+		}
+		tq_rot16(x);
 	}
 	return bad;
 }
 
-// B: the sign-choosing LU of I - Q1~ S on its linear part W (column j of I - W S is e_j - s_j W_j): kind 0 eliminates the rows
-//    of W (V1 below the diagonal of Wm, the raw rows of U on and above it, signs and reciprocal pivots in sgn / pinvs);
-//    kind 2 carries identity ROWS through the elimination: their multipliers are the rows of U^-1.
-static __device__ __forceinline__ bool tq_b_block02(double (&x)[64], int kind, int b, int r, int w, double *Wm, double *UL, double *sgn,
-						    double *pinvs)
+// The sign-choosing elimination (I - Q1~ S = V1 U on its linear part W, column j of I - W S is e_j - s_j W_j) of the 16
+// columns c0 .. c0 + 15 of W, row r in lane r, the 16 entries of the row in x: afterwards x holds the multipliers V1[r][c]
+// below the diagonal and the raw rows of U (U[j][c] = delta - s_c W[j][c] once every sign is known) on and above it.
+// Returns true if the tail of a column is numerically zero (wave uniform).
+static __device__ __forceinline__ bool tq_lu16(double (&x)[16], int r, int c0, int w, double *sgn, double *pinvs)
 {
-	const int live = 64 - TQ_NJ * b;
 	bool bad = false;
+#pragma unroll 1
+	for (int b = 0; b < 4; ++b) {
 #pragma unroll
-	for (int jj = 0; jj < TQ_NJ; ++jj) {
-		const int J = TQ_NJ * b + jj;
-		double *wrow = Wm + J * TQ_DP + TQ_NJ * b; // W[J][NJ b + k]
-		double mult;
-		if (kind == 0) {
-			// row J is final: lane J publishes it (U[J][c] = delta - s_c W[J][c] once every sign is known)
-			if (r == J) {
-#pragma unroll
-				for (int k = jj; k < 64; ++k)
-					if (k < live)
-						wrow[k] = x[k];
-			}
-			const double alpha = tq_rl(x[jj], J);
-			bad = bad || (J < w && !(1.0 - fabs(alpha) >= TQ_TAIL_MIN)); // wave uniform
+		for (int jj = 0; jj < 4; ++jj) {
+			const int gJ = c0 + 4 * b + jj;
+			const double alpha = tq_rl(x[jj], gJ);
+			bad = bad || (gJ < w && !(1.0 - fabs(alpha) >= TQ_TAIL_MIN));
 			const double sj = alpha >= 0.0 ? -1.0 : 1.0;
 			const double pinv = tq_rcp(1.0 + fabs(alpha));
-			mult = r > J ? -sj * x[jj] * pinv : 0.0;
-			if (r > J)
-				Wm[r * TQ_DP + J] = mult; // V1[r][J]
-			if (r == J) {
-				sgn[J] = sj;
-				pinvs[J] = pinv;
+			const double mult = r > gJ ? -sj * x[jj] * pinv : 0.0;
+			if (r > gJ)
+				x[jj] = mult; // V1[r][gJ]
+			if (r == gJ) {
+				sgn[gJ] = sj;
+				pinvs[gJ] = pinv;
 			}
-			tq_lds_order();
-		} else {
-			const double sj = sgn[J], pinv = pinvs[J];
-			mult = ((r == J ? 1.0 : 0.0) - sj * x[jj]) * pinv;
-			if (r <= J)
-				UL[r * TQ_DP + J] = mult; // U^-1[r][J]
+			// the pivot row from lane gJ, zero for the finished columns (selected on the scalar side: no branches)
+#pragma unroll
+			for (int k = jj + 1; k < 16; ++k) {
+				int lo = __builtin_amdgcn_readlane(__double2loint(x[k]), gJ), hi = __builtin_amdgcn_readlane(__double2hiint(x[k]), gJ);
+				const bool live = 4 * b + k < 16;
+				lo = live ? lo : 0;
+				hi = live ? hi : 0;
+				x[k] = __builtin_fma(-mult, __hiloint2double(hi, lo), x[k]);
+			}
 		}
-		tq_axpy_from(jj + 1, x, mult, wrow, 1, live);
+		tq_rot16(x);
 	}
 	return bad;
 }
 
-//    kind 1: V1^-1 by forward substitution, one COLUMN per lane (x[k] = row NJ b + k of column r of the inverse): once
-//    row J of the inverse is final its entries sit at position jj of every lane, and the rows below take
-//    -V1[row][J] x[jj] -- the multipliers are wave-uniform reads of column J of V1, no lane has to publish anything.
-static __device__ __forceinline__ void tq_b_block1(double (&x)[64], int b, int r, double *Wm, double *UL)
+// One matrix of tq_trinv_levels: T lower triangular (logical), X = T^-1 read back through `X` (logical lower), written
+// through (out, ors, ocs): X[r][c] at out[r * ors + c * ocs].  The diagonal blocks of X are already there.
+struct TqInvJob {
+	TqMat T, X;
+	double *out;
+	int ors, ocs;
+};
+// Off-diagonal blocks of the inverses of `nm` lower triangular matrices, block diagonal by block diagonal:
+// X(i, j) = -X(i, i) sum_{k = j}^{i - 1} T(i, k) X(k, j); one workgroup barrier per diagonal.
+static __device__ __forceinline__ void tq_trinv_levels(const TqInvJob &job0, const TqInvJob &job1, int nm, double *Pt, int wv, int lane)
 {
-	const int live = 64 - TQ_NJ * b;
+#pragma unroll 1
+	for (int d = 1; d < 4; ++d) {
+		const int per = 4 - d;
+#pragma unroll 1
+		for (int t = wv; t < nm * per; t += 4) {
+			const bool second = t >= per;
+			TqInvJob jb; // (a run-time index into an array of jobs would put them into scratch memory)
+			jb.T.p = second ? job1.T.p : job0.T.p;
+			jb.T.rs = second ? job1.T.rs : job0.T.rs;
+			jb.T.cs = second ? job1.T.cs : job0.T.cs;
+			jb.T.mode = second ? job1.T.mode : job0.T.mode;
+			jb.X.p = second ? job1.X.p : job0.X.p;
+			jb.X.rs = second ? job1.X.rs : job0.X.rs;
+			jb.X.cs = second ? job1.X.cs : job0.X.cs;
+			jb.X.mode = second ? job1.X.mode : job0.X.mode;
+			jb.T.rsc = nullptr;
+			jb.X.rsc = nullptr;
+			jb.out = second ? job1.out : job0.out;
+			jb.ors = second ? job1.ors : job0.ors;
+			jb.ocs = second ? job1.ocs : job0.ocs;
+			const int j = second ? t - per : t, i = j + d;
+			f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+			for (int k = j; k < i; ++k)
+				tq_tile_mac(acc, jb.T, i, jb.X, j, k, lane);
 #pragma unroll
-	for (int jj = 0; jj < TQ_NJ; ++jj) {
-		const int J = TQ_NJ * b + jj;
-		const double a = x[jj]; // V1^-1[J][r]
-		if (r < J)
-			UL[J * TQ_DP + r] = a;
-		tq_axpy_from(jj + 1, x, a, Wm + (TQ_NJ * b) * TQ_DP + J, TQ_DP, live); // V1[NJ b + k][J], k > jj
-	}
-}
-
-static __device__ __forceinline__ void tq_rot(double (&x)[64])
-{
+			for (int q = 0; q < 4; ++q)
+				Pt[((lane >> 4) + 4 * q) * 17 + (lane & 15)] = acc[q];
+			tq_lds_order();
+			const TqMat Pm = {Pt, 17, 1, 0, nullptr};
+			f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
+			// Pm is a single tile: rows 16 kt + .. with kt = 0 -- shift X instead
+			{
 #pragma unroll
-	for (int k = 0; k < 64 - TQ_NJ; ++k)
-		x[k] = x[k + TQ_NJ];
+				for (int s4 = 0; s4 < 4; ++s4) {
+					const int k = 4 * s4 + (lane >> 4);
+					const double av = tq_get(jb.X, 16 * i + (lane & 15), 16 * i + k);
+					const double bv = Pm.p[k * 17 + (lane & 15)];
+					acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc2, 0, 0, 0);
+				}
+			}
 #pragma unroll
-	for (int k = 64 - TQ_NJ; k < 64; ++k)
-		x[k] = 0.0;
-}
-
-// acc[jb] (rows 16 wv .. + 15, columns 16 jb .. + 15) = A * B, both 64 x 64 in LDS, read through a structure mask:
-//   AM 0: A[i][k] as stored;  1: the transpose of the unit lower triangle of the array (V1^T)
-//   BM 0: as stored;  1: upper triangle, row k scaled by sc[k];  2: unit lower triangle;  3: upper triangle
-template <int AM, int BM>
-static __device__ __forceinline__ void tq_mm64m(f64x4 (&acc)[4], const double *Am, const double *Bm, const double *sc, int wv, int lane)
-{
-#pragma unroll
-	for (int jb = 0; jb < 4; ++jb)
-		acc[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
-	const int i = 16 * wv + (lane & 15);
-#pragma unroll 4
-	for (int k0 = 0; k0 < 64; k0 += 4) {
-		const int k = k0 + (lane >> 4);
-		double av;
-		if (AM == 0)
-			av = Am[i * TQ_DP + k];
-		else
-			av = k > i ? Am[k * TQ_DP + i] : (k == i ? 1.0 : 0.0);
-		const double rs = BM == 1 ? sc[k] : 1.0;
-#pragma unroll
-		for (int jb = 0; jb < 4; ++jb) {
-			const int j = 16 * jb + (lane & 15);
-			double bv = Bm[k * TQ_DP + j];
-			if (BM == 1)
-				bv = k <= j ? rs * bv : 0.0;
-			else if (BM == 2)
-				bv = k > j ? bv : (k == j ? 1.0 : 0.0);
-			else if (BM == 3)
-				bv = k <= j ? bv : 0.0;
-			acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[jb], 0, 0, 0);
+			for (int q = 0; q < 4; ++q)
+				jb.out[(16 * i + (lane >> 4) + 4 * q) * jb.ors + (16 * j + (lane & 15)) * jb.ocs] = -acc2[q];
+			tq_lds_order(); // Pt is reused by this wavefront's next task
 		}
+		__syncthreads();
 	}
 }
 
@@ -531,6 +639,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	__shared__ double Ri[64 * TQ_DP]; // R~^-1 (upper)
 	__shared__ double UL[64 * TQ_DP]; // U^-1 (upper incl. diagonal) | V1^-1 (strictly lower, unit diagonal implied)
 	__shared__ double sgn[64], dinv[64], pinvs[64];
+	__shared__ double Pt[4 * 16 * 17]; // one scratch tile per wavefront
 	__shared__ int s_fail;
 	if (a.stat[0])
 		return;
@@ -572,7 +681,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	//      entries (36 of them) are in flight together: one entry at a time this was 36 000 cycles of dependent round trips
 #pragma unroll 1
 	for (int e0 = tid; e0 < 4096; e0 += 4 * TQ_PT) {
-		double gs[4][TQ_NG];
+		double gs[4];
 		float av[4];
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
@@ -580,9 +689,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 			const int i = e >> 6, j = e & 63;
 			const bool in = i < w && j < w;
 			const int el = i >= j ? e : j * 64 + i; // the Gram kernel writes the lower 16 x 16 tiles only
-#pragma unroll
-			for (int q = 0; q < TQ_NG; ++q)
-				gs[u][q] = in ? a.G[q * 4096 + el] : 0.0;
+			gs[u] = in ? a.G[el] : 0.0;
 			// the top block as the Gram kernel's first workgroup copied it: read from A it is 64 columns on 64 different
 			// pages (2 MB apart at m = 5e5), and this single workgroup waited for every one of the address translations
 			av[u] = in ? a.A1s[e] : 0.f;
@@ -591,98 +698,219 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 		for (int u = 0; u < 4; ++u) {
 			const int e = e0 + u * TQ_PT;
 			const int i = e >> 6, j = e & 63;
-			double g = 0.0;
-#pragma unroll
-			for (int q = 0; q < TQ_NG; ++q)
-				g += gs[u][q];
+			double g = gs[u];
 			if (!(i < w && j < w))
 				g = i == j ? 1.0 : 0.0;
 			Lm[i * TQ_DP + j] = g;
 			Wm[j * TQ_DP + i] = (double) av[u];
+			Ri[i * TQ_DP + j] = 0.0; // the blocks below its diagonal are never written, and the products read all of it
 		}
 	}
 	TQ_STAMP(13);
 	__syncthreads();
 	TQ_STAMP(14);
-	double x[64];
-	if (kind == 0) {
-#pragma unroll
-		for (int k = 0; k < 64; ++k)
-			x[k] = Lm[r * TQ_DP + k];
-	} else if (kind == 1) {
-#pragma unroll
-		for (int k = 0; k < 64; ++k)
-			x[k] = Wm[r * TQ_DP + k];
-	} else {
-#pragma unroll
-		for (int k = 0; k < 64; ++k)
-			x[k] = r == k ? 1.0 : 0.0;
-	}
-	__syncthreads(); // Lm / Wm are rewritten by the elimination
 	TQ_STAMP(1);
-	constexpr int NBLK = 64 / TQ_NJ;
+	const int lane = tid & 63, wv = kind;
+	double *Ptw = Pt + wv * (16 * 17); // this wavefront's scratch tile
+	// ---- A1: Cholesky G = L L^T (R~ = L^T), 16 columns per step: diagonal block and the rows below it in wavefront 0,
+	//      the trailing update on the matrix cores
 #pragma unroll 1
-	for (int it = 0; it <= NBLK; ++it) {
-		if (it < 8)
-			TQ_STAMP(16 + it);
-		const int blk = kind == 0 ? it : it - 1;
-		if (kind < 3 && blk >= 0 && blk < NBLK) {
-			if (tq_a_block(x, kind, blk, r, Lm, dinv, kind == 1 ? Wm : Ri) && r == 0)
+	for (int jb = 0; jb < 4; ++jb) {
+		if (jb < 4)
+			TQ_STAMP(16 + 2 * jb);
+		const int c0 = 16 * jb;
+		if (wv == 0) {
+			double x[16];
+			const int i = lane & 15;
+#pragma unroll
+			for (int c = 0; c < 16; ++c)
+				x[c] = Lm[(c0 + i) * TQ_DP + c0 + c];
+			if (tq_chol16(x, lane, dinv + c0) && lane == 0)
 				s_fail = TQ_FAIL_CHOL;
-			tq_rot(x);
-		}
-		__syncthreads();
-		if (s_fail) {
-			fail(s_fail);
-			return;
-		}
-	}
-	TQ_STAMP(2);
-	// ---- B
-	if (kind == 0) {
+			if (lane < 16) {
 #pragma unroll
-		for (int k = 0; k < 64; ++k)
-			x[k] = Wm[r * TQ_DP + k];
-	} else if (kind == 1) {
-#pragma unroll
-		for (int k = 0; k < 64; ++k)
-			x[k] = r == k ? 1.0 : 0.0;
-	} else {
-#pragma unroll
-		for (int k = 0; k < 64; ++k)
-			x[k] = 0.0;
-	}
-	for (int e = tid; e < 64 * TQ_DP; e += TQ_PT)
-		UL[e] = 0.0;
-	__syncthreads();
-#pragma unroll 1
-	for (int it = 0; it <= NBLK; ++it) {
-		if (it < 8)
-			TQ_STAMP(24 + it);
-		const int blk = kind == 0 ? it : it - 1;
-		if (kind < 3 && blk >= 0 && blk < NBLK) {
-			if (kind == 1) {
-				tq_b_block1(x, blk, r, Wm, UL);
-			} else {
-				if (tq_b_block02(x, kind, blk, r, w, Wm, UL, sgn, pinvs) && r == 0)
-					s_fail = TQ_FAIL_TAIL;
+				for (int c = 0; c < 16; ++c)
+					Lm[(c0 + i) * TQ_DP + c0 + c] = x[c];
 			}
-			tq_rot(x);
+			tq_lds_order();
+			// rows below: x L_d^T = b, one row per lane (at most 48); lanes 48 .. 63: the columns of L_d^-1, i.e. the
+			// diagonal block of R~^-1 = L^-T -- the same substitution on unit vectors
+			const int row = c0 + 16 + lane;
+			const bool inv = lane >= 48, act = row < 64;
+			const int j = lane - 48;
+			double z[16];
+#pragma unroll
+			for (int c = 0; c < 16; ++c)
+				z[c] = inv ? (c == j ? 1.0 : 0.0) : Lm[(act ? row : 63) * TQ_DP + c0 + c];
+			tq_subst16<4>(z, Lm + c0 * TQ_DP + c0, TQ_DP, 1, dinv + c0, true);
+			if (inv) {
+#pragma unroll
+				for (int c = 0; c < 16; ++c)
+					Ri[(c0 + j) * TQ_DP + c0 + c] = z[c]; // L_d^-1[c][j], zero for c < j
+			} else if (act) {
+#pragma unroll
+				for (int c = 0; c < 16; ++c)
+					Lm[row * TQ_DP + c0 + c] = z[c];
+			}
 		}
 		__syncthreads();
 		if (s_fail) {
 			fail(s_fail);
 			return;
+		}
+		if (jb < 4)
+			TQ_STAMP(17 + 2 * jb);
+		if (jb < 3) {
+			// G(ti, tj) -= L(ti, jb) L(tj, jb)^T for jb < tj <= ti
+			const TqMat La = {Lm, TQ_DP, 1, 0, nullptr}, Lt = {Lm, 1, TQ_DP, 0, nullptr};
+			int t = 0;
+#pragma unroll 1
+			for (int ti = jb + 1; ti < 4; ++ti)
+#pragma unroll 1
+				for (int tj = jb + 1; tj <= ti; ++tj, ++t) {
+					if ((t & 3) != wv)
+						continue;
+					f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+					tq_tile_mac(acc, La, ti, Lt, tj, jb, lane);
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+						Lm[(16 * ti + (lane >> 4) + 4 * q) * TQ_DP + 16 * tj + (lane & 15)] -= acc[q];
+				}
+			__syncthreads();
+		}
+	}
+	// ---- A2: the blocks of R~^-1 = L^-T above its diagonal blocks, on the matrix cores
+	{
+		TqInvJob job;
+		job.T = TqMat{Lm, TQ_DP, 1, 1, nullptr};
+		job.X = TqMat{Ri, 1, TQ_DP, 1, nullptr};
+		job.out = Ri;
+		job.ors = 1;
+		job.ocs = TQ_DP;
+		tq_trinv_levels(job, job, 1, Ptw, wv, lane);
+	}
+	// ---- A3: Q1~ = A1 R~^-1 in place (row block wv is read and written by wavefront wv only)
+	{
+		// output block (wv, tj) overwrites an input of the blocks right of it only: right to left
+		const TqMat Am = {Wm, TQ_DP, 1, 0, nullptr}, Rm = {Ri, TQ_DP, 1, 3, nullptr};
+#pragma unroll 1
+		for (int tj = 3; tj >= 0; --tj) {
+			f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+			for (int kt = 0; kt <= tj; ++kt)
+				tq_tile_mac(acc, Am, wv, Rm, tj, kt, lane);
+			tq_lds_order();
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+				Wm[(16 * wv + (lane >> 4) + 4 * q) * TQ_DP + 16 * tj + (lane & 15)] = acc[q];
+			tq_lds_order();
+		}
+	}
+	__syncthreads();
+	TQ_STAMP(2);
+	// ---- B1: the sign-choosing LU of W, 16 columns per step
+#pragma unroll 1
+	for (int jb = 0; jb < 4; ++jb) {
+		TQ_STAMP(24 + 2 * jb);
+		const int c0 = 16 * jb;
+		if (wv == 0) {
+			double x[16];
+#pragma unroll
+			for (int c = 0; c < 16; ++c)
+				x[c] = Wm[lane * TQ_DP + c0 + c];
+			if (tq_lu16(x, lane, c0, w, sgn, pinvs) && lane == 0)
+				s_fail = TQ_FAIL_TAIL;
+			if (lane >= c0) {
+#pragma unroll
+				for (int c = 0; c < 16; ++c)
+					Wm[lane * TQ_DP + c0 + c] = x[c];
+			}
+			tq_lds_order();
+			// the 16 rows of U right of the block: V1_d u = w, one column per lane (at most 48); lanes 48 .. 63: the columns
+			// of V1_d^-1 (diagonal block of V1^-1)
+			const int col = c0 + 16 + lane;
+			const bool inv = lane >= 48, act = col < 64;
+			const int j = lane - 48;
+			double z[16];
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				z[i] = inv ? (i == j ? 1.0 : 0.0) : Wm[(c0 + i) * TQ_DP + (act ? col : 63)];
+			tq_subst16<4>(z, Wm + c0 * TQ_DP + c0, TQ_DP, 1, pinvs, false);
+			if (inv) {
+#pragma unroll
+				for (int i = 0; i < 16; ++i)
+					if (i > j)
+						UL[(c0 + i) * TQ_DP + c0 + j] = z[i];
+			} else if (act) {
+#pragma unroll
+				for (int i = 0; i < 16; ++i)
+					Wm[(c0 + i) * TQ_DP + col] = z[i];
+			}
+		}
+		__syncthreads();
+		if (s_fail) {
+			fail(s_fail);
+			return;
+		}
+		TQ_STAMP(25 + 2 * jb);
+		if (jb < 3) {
+			// W(ti, tj) -= V1(ti, jb) U(jb, tj) for ti, tj > jb
+			const TqMat Wa = {Wm, TQ_DP, 1, 0, nullptr};
+			int t = 0;
+#pragma unroll 1
+			for (int ti = jb + 1; ti < 4; ++ti)
+#pragma unroll 1
+				for (int tj = jb + 1; tj < 4; ++tj, ++t) {
+					if ((t & 3) != wv)
+						continue;
+					f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+					tq_tile_mac(acc, Wa, ti, Wa, tj, jb, lane);
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+						Wm[(16 * ti + (lane >> 4) + 4 * q) * TQ_DP + 16 * tj + (lane & 15)] -= acc[q];
+				}
+			__syncthreads();
 		}
 	}
 	TQ_STAMP(3);
-	// U = triu(I - W S) from the raw rows kept by the elimination, V1^-1 from the identity columns
+	// U = triu(I - W S) from the raw rows kept by the elimination
 	for (int e = tid; e < 4096; e += TQ_PT) {
 		const int i = e >> 6, c = e & 63;
 		if (c >= i)
 			Wm[i * TQ_DP + c] = (i == c ? 1.0 : 0.0) - sgn[c] * Wm[i * TQ_DP + c];
 	}
 	__syncthreads();
+	// ---- B2: U^-1 (upper, into the upper part of UL) and V1^-1 (unit lower, strictly lower part of UL; its diagonal blocks
+	//      are there).  Diagonal block wv of U^-1 in wavefront wv: lane j < 16 solves for column j of (U_d^T)^-1
+	if (lane < 16) {
+		const int j = lane, d0 = 16 * wv;
+		double z[16];
+#pragma unroll
+		for (int c = 0; c < 16; ++c)
+			z[c] = c == j ? 1.0 : 0.0;
+		// U^T: T[i][l] = U[l][i]; the reciprocal diagonal of U is pinvs (U_jj = 1 + |alpha_j|)
+		tq_subst16<1>(z, Wm + d0 * TQ_DP + d0, 1, TQ_DP, pinvs + d0, true);
+#pragma unroll
+		for (int c = 0; c < 16; ++c)
+			if (c >= j)
+				UL[(d0 + j) * TQ_DP + d0 + c] = z[c]; // U^-1[j][c] = (U^T)^-1[c][j]
+	}
+	__syncthreads();
+	{
+		TqInvJob jobs[2];
+		jobs[0].T = TqMat{Wm, 1, TQ_DP, 1, nullptr}; // U^T
+		jobs[0].X = TqMat{UL, 1, TQ_DP, 1, nullptr};
+		jobs[0].out = UL;
+		jobs[0].ors = 1;
+		jobs[0].ocs = TQ_DP;
+		jobs[1].T = TqMat{Wm, TQ_DP, 1, 2, nullptr}; // V1
+		jobs[1].X = TqMat{UL, TQ_DP, 1, 2, nullptr};
+		jobs[1].out = UL;
+		jobs[1].ors = TQ_DP;
+		jobs[1].ocs = 1;
+		tq_trinv_levels(jobs[0], jobs[1], 2, Ptw, wv, lane);
+	}
+	TQ_STAMP(15);
 #ifdef FH_TQ_TIMING
 	{
 		// debug build: residuals of the three inverses, max over the workgroup -> dbg[9..11] (as doubles)
@@ -770,44 +998,50 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	}
 	__syncthreads(); // all reads of L are done
 	TQ_STAMP(6);
-	// ---- the three 64 x 64 x 64 products on the fp64 matrix cores (waves 0..3, 16 rows each); as scalar dot products of
-	//      triangular length out of LDS they were 120 000 cycles of this kernel
-	const int lane = tid & 63, wv = kind;
-	f64x4 acc[4];
-	// M = -R~^-1 S U^-1 (upper) into Lm
-	if (wv < 4) {
-		tq_mm64m<0, 1>(acc, Ri, UL, sgn, wv, lane);
+	// ---- M = -R~^-1 S U^-1 and T = triu(V1^T U^-1), both upper triangular, on the fp64 matrix cores: wavefront wv owns the
+	//      block row wv (as scalar dot products of triangular length out of LDS they were 120 000 cycles of this kernel);
+	//      one loop body for both products
+#pragma unroll 1
+	for (int pass = 0; pass < 2; ++pass) {
+		TqMat Am, Bm;
+		Am.p = pass ? Wm : Ri;
+		Am.rs = pass ? 1 : TQ_DP;
+		Am.cs = pass ? TQ_DP : 1;
+		Am.mode = pass ? 4 : 3; // V1^T (unit upper) : R~^-1 (upper)
+		Am.rsc = nullptr;
+		Bm.p = UL;
+		Bm.rs = TQ_DP;
+		Bm.cs = 1;
+		Bm.mode = 3;
+		Bm.rsc = pass ? nullptr : sgn; // S U^-1
+#pragma unroll 1
+		for (int tj = 0; tj < 4; ++tj) {
+			f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+			for (int kt = wv; kt <= tj; ++kt)
+				tq_tile_mac(acc, Am, wv, Bm, tj, kt, lane);
 #pragma unroll
-		for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				const int k = 16 * wv + (lane >> 4) + 4 * r, j = 16 * jb + (lane & 15);
-				const double mv = k <= j ? -acc[jb][r] : 0.0;
-				Lm[k * TQ_DP + j] = mv;
-				a.Mn[k * 64 + j] = (float) mv;
-				a.Md[k * 64 + j] = mv;
-			}
-	}
-	__syncthreads();
-	TQ_STAMP(7);
-	if (wv < 4) {
-		// T = triu(V1^T U^-1)
-		tq_mm64m<1, 3>(acc, Wm, UL, sgn, wv, lane);
-#pragma unroll
-		for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				const int k = 16 * wv + (lane >> 4) + 4 * r, j = 16 * jb + (lane & 15);
-				const double tt = k <= j ? acc[jb][r] : 0.0;
-				if (k <= j && j < w) {
-					const int gi = a.c0 + k, gj = a.c0 + j;
-					if (gi / a.bs == gj / a.bs)
-						a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) tt;
-					if (k == j)
-						a.taus[gj] = (float) tt;
+			for (int q = 0; q < 4; ++q) {
+				const int k = 16 * wv + (lane >> 4) + 4 * q, j = 16 * tj + (lane & 15);
+				if (pass == 0) {
+					const double mv = k <= j ? -acc[q] : 0.0;
+					a.Mn[k * 64 + j] = (float) mv;
+					a.Md[k * 64 + j] = mv;
+				} else {
+					const double tt = k <= j ? acc[q] : 0.0;
+					if (k <= j && j < w) {
+						const int gi = a.c0 + k, gj = a.c0 + j;
+						if (gi / a.bs == gj / a.bs)
+							a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) tt;
+						if (k == j)
+							a.taus[gj] = (float) tt;
+					}
+					a.Td[k * 64 + j] = tt;
 				}
-				a.Td[k * 64 + j] = tt;
 			}
+		}
+		if (pass == 0)
+			TQ_STAMP(7);
 	}
 	TQ_STAMP(8);
 }
@@ -1476,7 +1710,7 @@ static void tq_launch_update(bool vec, int nwg, const TqUpdArgs &ua)
 }
 
 static void tq_gram(const float *P, const float *X, long ld, int rows, int w, int t, bool want_g, bool want_sq, bool vec, double *Gp, float *Cp,
-		    float *Sp, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0, float *A1s)
+		    float *Sp, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0, float *A1s, double *Gf, int *cnt)
 {
 	hipStream_t s = ctx().stream;
 	TqGramArgs g;
@@ -1505,7 +1739,7 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 		hipLaunchKernelGGL(tq_gram_kernel<false>, dim3(nb), dim3(256), 0, s, g);
 	const int total = (want_g ? 4096 : 0) + 64 * g.tp + (want_sq ? 256 : 0);
 	hipLaunchKernelGGL(tq_reduce_kernel, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, Gp, Cp, Sp, nb, g.tp, (int) want_g, (int) want_sq, G, C,
-			   ldc, coff, S, stat, c0);
+			   ldc, coff, S, stat, c0, Gf, cnt);
 	FH_HIP(hipGetLastError());
 }
 
@@ -1553,13 +1787,13 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	const int ldc = ((int) n + 63) & ~63;
 	const int typ = ldc, ldz = ldc;
 	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * 4), sp((size_t) TQ_NB * 256 * 4);
-	// fp64 workspace: G (NG x 4096), N1, N3 (4096 each), C (NG x 64 x ldc), S, S2 (NG x 256 each), abv (n + 64),
+	// fp64 workspace: G (NG x 4096), N1, N3, Gf (4096 each), C (NG x 64 x ldc), S, S2 (NG x 256 each), abv (n + 64),
 	//                 Td, Md (npan x 4096 each), Z, B (npan x 64 x ldz each); then fp32: Mn (npan x 4096), top, A1s (4096 each), Yn (64 x typ); then the status words
-	const size_t nd = (size_t) TQ_NG * 4096 + 2 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) 2 * TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
+	const size_t nd = (size_t) TQ_NG * 4096 + 3 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) 2 * TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
 			  (size_t) 2 * npan * 64 * ldz;
 	Scratch small(nd * 8 + ((size_t) npan * 4096 + 2 * 4096 + (size_t) 64 * typ) * 4 + 2048);
 	double *G = small.as<double>();
-	double *N1 = G + (size_t) TQ_NG * 4096, *N3 = N1 + 4096, *C = N3 + 4096;
+	double *N1 = G + (size_t) TQ_NG * 4096, *N3 = N1 + 4096, *Gf = N3 + 4096, *C = Gf + 4096;
 	double *S = C + (size_t) TQ_NG * 64 * ldc, *S2 = S + (size_t) TQ_NG * 256, *abv = S2 + (size_t) TQ_NG * 256;
 	double *Td = abv + n + 64, *Md = Td + (size_t) npan * 4096, *Z = Md + (size_t) npan * 4096, *Bx = Z + (size_t) npan * 64 * ldz;
 	float *Mn = reinterpret_cast<float *>(Bx + (size_t) npan * 64 * ldz); // one per panel: V of step k is formed beside panel k + 1
@@ -1579,14 +1813,14 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		const int rows = (int) (m - c0);
 		if (t == 0) {
 			if (want_g)
-				tq_gram(P, P, ld, rows, w, 0, true, first, vec, gp.as<double>(), cp.as<float>(), sp.as<float>(), G, C, ldc, 0, Sd, stat, c0, A1s);
+				tq_gram(P, P, ld, rows, w, 0, true, first, vec, gp.as<double>(), cp.as<float>(), sp.as<float>(), G, C, ldc, 0, Sd, stat, c0, A1s, Gf, stat + 128);
 			return;
 		}
 		for (int off = 0; off < t; off += TQ_TS) {
 			const int ts = t - off < TQ_TS ? t - off : TQ_TS;
 			// the range guard covers the first strip only (n <= 256); wider matrices check the rest per panel through G
 			tq_gram(P, A.p + (long) (cx + off) * ld + c0, ld, rows, w, ts, want_g && off == 0, first && off == 0, vec, gp.as<double>(),
-				cp.as<float>(), sp.as<float>(), G, C, ldc, cx + off - (c0 + w), Sd, stat, c0, A1s);
+				cp.as<float>(), sp.as<float>(), G, C, ldc, cx + off - (c0 + w), Sd, stat, c0, A1s, Gf, stat + 128);
 		}
 	};
 	auto tx_args = [&]() {
@@ -1619,7 +1853,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		pa.c0 = c0;
 		pa.w = w;
 		pa.n = (int) n;
-		pa.G = G;
+		pa.G = Gf;
 		pa.S = S;
 		pa.check_range = k == 0;
 		pa.range_cols = t < TQ_TS ? t : TQ_TS;
@@ -1655,13 +1889,14 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	bool tx_on_side = false;
 	bool panel_on_side = false;
 	const double *s_trailing = S; // where the first step's squares of the trailing columns are
-	// Gram products and panel kernel of panel p.  The panel kernel needs G only: with enough trailing columns the products
-	// against them (C) are a second launch that runs BESIDE the panel kernel (the panel columns are read twice)
+	// Gram products and panel kernel of panel p.  The panel kernel needs G only: the products against the trailing columns (C)
+	// can be a second launch that runs BESIDE the panel kernel (the panel columns are read twice).  Beside a streaming kernel
+	// the panel kernel -- bound by its instruction fetch -- took twice as long (137 -> 283 us): 2.17 ms against 2.07 ms.
 	auto gram_and_panel = [&](int p, bool first) {
 		const int pc0 = p * TQ_PW;
 		const int pw = (int) (n - pc0 < TQ_PW ? n - pc0 : TQ_PW);
 		const int pt = (int) n - pc0 - pw;
-		const bool split = la_env >= 0 ? la_env == 2 && pt > 0 : pt >= 2 * TQ_PW;
+		const bool split = la_env == 2 && pt > 0; // measured slower (profiles/r03_qr_lookahead.txt): only on request
 		if (!split) {
 			launch_gram(pc0, pw, true, pc0 + pw, pt, first, S);
 			launch_panel(p, s);
@@ -1818,7 +2053,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		FH_HIP(hipMemcpy(d, stat + 16, sizeof(d), hipMemcpyDeviceToHost));
 		fprintf(stderr, "tq_panel phases (shader cycles): start %lld: load %lld chol %lld reload %lld lu %lld finish %lld tests %lld out %lld M %lld T %lld\n",
 			d[0], d[1] - d[0], d[2] - d[1], 0LL, d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[8] - d[7]);
-		fprintf(stderr, "  load: range %lld loads %lld barrier %lld fill %lld | A iterations:", d[12] - d[0], d[13] - d[12], d[14] - d[13], d[1] - d[14]);
+		fprintf(stderr, "  load: range %lld loads %lld barrier %lld fill %lld | U, U^-1, V1^-1: %lld | A iterations:", d[12] - d[0], d[13] - d[12], d[14] - d[13], d[1] - d[14], d[15] - d[3]);
 		for (int i = 0; i < 7; ++i)
 			fprintf(stderr, " %lld", d[17 + i] - d[16 + i]);
 		fprintf(stderr, " | B iterations:");
