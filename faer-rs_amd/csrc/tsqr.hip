@@ -527,34 +527,26 @@ static __device__ __forceinline__ bool tq_chol16(double (&x)[16], int lane, doub
 // Returns true if the tail of a column is numerically zero (wave uniform).
 static __device__ __forceinline__ bool tq_lu16(double (&x)[16], int r, int c0, int w, double *sgn, double *pinvs)
 {
+	// (fully unrolled: with the rotation scheme every column updated all 15 other positions, finished ones with a zero
+	// factor selected on the scalar side -- 19 600 cycles per call against 9 700; the 3 KB of extra code cost less)
 	bool bad = false;
-#pragma unroll 1
-	for (int b = 0; b < 4; ++b) {
 #pragma unroll
-		for (int jj = 0; jj < 4; ++jj) {
-			const int gJ = c0 + 4 * b + jj;
-			const double alpha = tq_rl(x[jj], gJ);
-			bad = bad || (gJ < w && !(1.0 - fabs(alpha) >= TQ_TAIL_MIN));
-			const double sj = alpha >= 0.0 ? -1.0 : 1.0;
-			const double pinv = tq_rcp(1.0 + fabs(alpha));
-			const double mult = r > gJ ? -sj * x[jj] * pinv : 0.0;
-			if (r > gJ)
-				x[jj] = mult; // V1[r][gJ]
-			if (r == gJ) {
-				sgn[gJ] = sj;
-				pinvs[gJ] = pinv;
-			}
-			// the pivot row from lane gJ, zero for the finished columns (selected on the scalar side: no branches)
-#pragma unroll
-			for (int k = jj + 1; k < 16; ++k) {
-				int lo = __builtin_amdgcn_readlane(__double2loint(x[k]), gJ), hi = __builtin_amdgcn_readlane(__double2hiint(x[k]), gJ);
-				const bool live = 4 * b + k < 16;
-				lo = live ? lo : 0;
-				hi = live ? hi : 0;
-				x[k] = __builtin_fma(-mult, __hiloint2double(hi, lo), x[k]);
-			}
+	for (int J = 0; J < 16; ++J) {
+		const int gJ = c0 + J;
+		const double alpha = tq_rl(x[J], gJ);
+		bad = bad || (gJ < w && !(1.0 - fabs(alpha) >= TQ_TAIL_MIN));
+		const double sj = alpha >= 0.0 ? -1.0 : 1.0;
+		const double pinv = tq_rcp(1.0 + fabs(alpha));
+		const double mult = r > gJ ? -sj * x[J] * pinv : 0.0;
+		if (r > gJ)
+			x[J] = mult; // V1[r][gJ]
+		if (r == gJ) {
+			sgn[gJ] = sj;
+			pinvs[gJ] = pinv;
 		}
-		tq_rot16(x);
+#pragma unroll
+		for (int k = J + 1; k < 16; ++k)
+			x[k] = __builtin_fma(-mult, tq_rl(x[k], gJ), x[k]); // the pivot row from lane gJ
 	}
 	return bad;
 }
@@ -820,31 +812,51 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 				x[c] = Wm[lane * TQ_DP + c0 + c];
 			if (tq_lu16(x, lane, c0, w, sgn, pinvs) && lane == 0)
 				s_fail = TQ_FAIL_TAIL;
-			if (lane >= c0) {
-#pragma unroll
-				for (int c = 0; c < 16; ++c)
-					Wm[lane * TQ_DP + c0 + c] = x[c];
-			}
 			tq_lds_order();
-			// the 16 rows of U right of the block: V1_d u = w, one column per lane (at most 48); lanes 48 .. 63: the columns
-			// of V1_d^-1 (diagonal block of V1^-1)
+			// the signs of these 16 columns are known: U[r][c] = delta - s_c W[r][c] for every row r <= c of the column block
+			// (the rows above the diagonal block hold what the earlier steps left there; nothing reads them raw any more)
+#pragma unroll
+			for (int c = 0; c < 16; ++c) {
+				const double sc = sgn[c0 + c];
+				if (c0 + c >= lane)
+					x[c] = (c0 + c == lane ? 1.0 : 0.0) - sc * x[c];
+			}
+#pragma unroll
+			for (int c = 0; c < 16; ++c)
+				Wm[lane * TQ_DP + c0 + c] = x[c];
+			tq_lds_order();
+			// One substitution call per step, the lanes doing different things with it:
+			//   lanes < 48 - 16 jb: the 16 rows of U right of the block, V1_d u = w, one column per lane;
+			//   the others: the diagonal blocks of V1^-1 and of U^-1 (unit vectors as right-hand sides; U^-1 through U_d^T,
+			//   whose reciprocal diagonal is pinvs: U_jj = 1 + |alpha_j|) -- of block jb - 1 in lanes 32 .. 63, and in the
+			//   last step also of block 3 in lanes 0 .. 31
+			const int nU = 48 - c0;
+			const bool isU12 = lane < nU;
+			const bool invl = !isU12 && (jb == 3 || (jb >= 1 && lane >= 32));
+			const int bi = lane >= 32 ? jb - 1 : 3;	// block of the inverse lanes
+			const bool uinv = (lane & 16) != 0;	// lanes 16-31 / 48-63: U^-1, lanes 0-15 / 32-47: V1^-1
+			const int j = lane & 15, d0 = invl ? 16 * bi : c0;
 			const int col = c0 + 16 + lane;
-			const bool inv = lane >= 48, act = col < 64;
-			const int j = lane - 48;
+			const int trs = invl && uinv ? 1 : TQ_DP, tcs = invl && uinv ? TQ_DP : 1;
 			double z[16];
 #pragma unroll
 			for (int i = 0; i < 16; ++i)
-				z[i] = inv ? (i == j ? 1.0 : 0.0) : Wm[(c0 + i) * TQ_DP + (act ? col : 63)];
-			tq_subst16<4>(z, Wm + c0 * TQ_DP + c0, TQ_DP, 1, pinvs, false);
-			if (inv) {
-#pragma unroll
-				for (int i = 0; i < 16; ++i)
-					if (i > j)
-						UL[(c0 + i) * TQ_DP + c0 + j] = z[i];
-			} else if (act) {
+				z[i] = isU12 ? Wm[(c0 + i) * TQ_DP + col] : (i == j ? 1.0 : 0.0);
+			tq_subst16<4>(z, Wm + d0 * TQ_DP + d0, trs, tcs, pinvs + d0, invl && uinv);
+			if (isU12) {
 #pragma unroll
 				for (int i = 0; i < 16; ++i)
 					Wm[(c0 + i) * TQ_DP + col] = z[i];
+			} else if (invl) {
+#pragma unroll
+				for (int i = 0; i < 16; ++i) {
+					if (uinv) {
+						if (i >= j)
+							UL[(d0 + j) * TQ_DP + d0 + i] = z[i]; // U^-1[j][i] = (U^T)^-1[i][j]
+					} else if (i > j) {
+						UL[(d0 + i) * TQ_DP + d0 + j] = z[i]; // V1^-1[i][j]
+					}
+				}
 			}
 		}
 		__syncthreads();
@@ -873,29 +885,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 		}
 	}
 	TQ_STAMP(3);
-	// U = triu(I - W S) from the raw rows kept by the elimination
-	for (int e = tid; e < 4096; e += TQ_PT) {
-		const int i = e >> 6, c = e & 63;
-		if (c >= i)
-			Wm[i * TQ_DP + c] = (i == c ? 1.0 : 0.0) - sgn[c] * Wm[i * TQ_DP + c];
-	}
-	__syncthreads();
-	// ---- B2: U^-1 (upper, into the upper part of UL) and V1^-1 (unit lower, strictly lower part of UL; its diagonal blocks
-	//      are there).  Diagonal block wv of U^-1 in wavefront wv: lane j < 16 solves for column j of (U_d^T)^-1
-	if (lane < 16) {
-		const int j = lane, d0 = 16 * wv;
-		double z[16];
-#pragma unroll
-		for (int c = 0; c < 16; ++c)
-			z[c] = c == j ? 1.0 : 0.0;
-		// U^T: T[i][l] = U[l][i]; the reciprocal diagonal of U is pinvs (U_jj = 1 + |alpha_j|)
-		tq_subst16<1>(z, Wm + d0 * TQ_DP + d0, 1, TQ_DP, pinvs + d0, true);
-#pragma unroll
-		for (int c = 0; c < 16; ++c)
-			if (c >= j)
-				UL[(d0 + j) * TQ_DP + d0 + c] = z[c]; // U^-1[j][c] = (U^T)^-1[c][j]
-	}
-	__syncthreads();
+	// ---- B2: the blocks of U^-1 (upper part of UL) and V1^-1 (strictly lower part) off their diagonal blocks
 	{
 		TqInvJob jobs[2];
 		jobs[0].T = TqMat{Wm, 1, TQ_DP, 1, nullptr}; // U^T
@@ -1001,6 +991,9 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	// ---- M = -R~^-1 S U^-1 and T = triu(V1^T U^-1), both upper triangular, on the fp64 matrix cores: wavefront wv owns the
 	//      block row wv (as scalar dot products of triangular length out of LDS they were 120 000 cycles of this kernel);
 	//      one loop body for both products
+	const bool big_bs = a.bs >= TQ_PW;
+	const float bs_rcp = 1.0f / (float) a.bs;
+	const int hrow0 = big_bs ? a.c0 % a.bs : 0; // row of H that holds T's row 0
 #pragma unroll 1
 	for (int pass = 0; pass < 2; ++pass) {
 		TqMat Am, Bm;
@@ -1030,11 +1023,13 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 				} else {
 					const double tt = k <= j ? acc[q] : 0.0;
 					if (k <= j && j < w) {
-						const int gi = a.c0 + k, gj = a.c0 + j;
-						if (gi / a.bs == gj / a.bs)
-							a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) tt;
+						// rows / columns k, j < 64 of a panel that starts at a multiple of 64; the block size of Q_coeff is a
+						// multiple of 64 or divides it (tsqr_applicable): no integer division per entry
+						const int kb = big_bs ? 0 : (int) (((float) k + 0.5f) * bs_rcp), jbk = big_bs ? 0 : (int) (((float) j + 0.5f) * bs_rcp);
+						if (kb == jbk)
+							a.H[(long) (hrow0 + k - kb * a.bs) * a.hrs + (long) (a.c0 + j) * a.hcs] = (float) tt;
 						if (k == j)
-							a.taus[gj] = (float) tt;
+							a.taus[a.c0 + j] = (float) tt;
 					}
 					a.Td[k * 64 + j] = tt;
 				}
