@@ -258,8 +258,12 @@ template <typename T> struct GemmExtra {
 	//   is zero for k > m -- each tile stops its K loop at the end of its diagonal block instead of multiplying zeros;
 	//   tri_skip (DST_LOWER, square): the first `tri_skip` rows of the lower triangle (a multiple of 128) are left
 	//   untouched, i.e. one launch covers "block column below the leading block + remaining lower square".
+	//   stair_nb / stair_gap (DST_LOWER, any shape): the "diagonal" is a staircase -- column n of dst stands for column
+	//   n + (n / stair_nb) * stair_gap of the matrix it is a part of (the owned block columns of a 1-D block-cyclic
+	//   partition next to each other: dist_llt.h), entries above it are left untouched.
 	int k_trim = 0;
 	idx_t tri_skip = 0;
+	idx_t stair_nb = 0, stair_gap = 0;
 };
 
 // dst(kind) <- [dst +] alpha * A * diag * B        (gemm.hip)

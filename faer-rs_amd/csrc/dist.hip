@@ -44,6 +44,16 @@ struct PhaseTimer {
 	}
 };
 
+// dst(c, k) = P(c + (c / nb) * gap, k): the rows of the received panel that belong to the owned block columns, contiguous
+// (the rhs of the staircase product of dist_llt.h); dst column major with leading dimension ncols
+template <typename T> __global__ void gather_stair_kernel(const T *P, long prs, long pcs, long ncols, long w, long nb, long gap, T *dst)
+{
+	const long c = (long) blockIdx.x * blockDim.x + threadIdx.x;
+	const long k = blockIdx.y;
+	if (c < ncols)
+		dst[k * ncols + c] = P[(c + (c / nb) * gap) * prs + k * pcs];
+}
+
 template <typename S> struct DeviceBackend {
 	typedef S T;
 	PhaseTimer t_panel, t_total;
@@ -185,6 +195,21 @@ template <typename S> struct DeviceBackend {
 		t_panel.end();
 	}
 	void syrk_sub(View C, View A, View Bt) { gemm_dev<T>(mv(C), DST_LOWER, true, mv(A).c(), mv(Bt).t().c(), (T) -1); }
+	void gather_stair(View P, long ncols, long nb, long gap, T *dst)
+	{
+		if (ncols <= 0 || P.ncols <= 0)
+			return;
+		hipLaunchKernelGGL(gather_stair_kernel<T>, dim3((unsigned) ((ncols + 255) / 256), (unsigned) P.ncols), dim3(256), 0, ctx().stream, P.p, P.rs,
+				   P.cs, ncols, P.ncols, nb, gap, dst);
+		FH_HIP(hipGetLastError());
+	}
+	void syrk_stair_sub(View C, View A, View Bt, long nb, long gap)
+	{
+		GemmExtra<T> ex;
+		ex.stair_nb = (idx_t) nb;
+		ex.stair_gap = (idx_t) gap;
+		gemm_dev<T>(mv(C), DST_LOWER, true, mv(A).c(), mv(Bt).t().c(), (T) -1, &ex);
+	}
 	void to_host(int *dst, const int *src, size_t n)
 	{
 		FH_HIP(hipMemcpyAsync(dst, src, n * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));

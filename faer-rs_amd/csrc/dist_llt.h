@@ -7,6 +7,13 @@
 // Look-ahead: the owner of block column k+1 updates and factors that column FIRST and starts its broadcast; every
 // rank posts the receive before it runs the rest of update k, so the transfer of panel k+1 (and the latency-bound
 // panel factorization on its owner) overlaps with the trailing updates of step k.  Two panel buffers alternate.
+// On the owner the look-ahead part is issued first (an asynchronous backend queues it on its panel stream) and the
+// rest of the update second (bulk stream): the two run concurrently inside the rank, as in dist_lu.h.
+//
+// The rest of update k is ONE product per rank, not one per owned block column: the owned block columns right of the
+// panel lie next to each other in A_local, the rows of the panel that belong to them are gathered into a contiguous
+// operand, and the product writes the lower part under a STAIRCASE (block column i of the range starts `world` blocks
+// further down than block column i - 1).  Per entry the arithmetic is that of the block-by-block update.
 //
 // Template over a backend like dist_lu.h (device backend in dist.hip, host backend under tests/).  Backend B:
 //   typedef scalar T;  struct View { T *p; long nrows, ncols, rs, cs; };
@@ -15,6 +22,13 @@
 //                                                           status (backend memory): [0] = first failing global index
 //                                                           + 1 (kept if already set), [1] += regularisation count
 //   void syrk_sub(View C, View A, View Bt)               -- C -= A * Bt^T; rows 0..C.ncols-1 of C: lower part only
+//   void gather_stair(View P, long ncols, long nb, long gap, T *dst)
+//                                                        -- dst (ncols x P.ncols, column major, ld = ncols) <- the rows
+//                                                           c + (c / nb) * gap of P, c < ncols
+//   void syrk_stair_sub(View C, View A, View Bt, long nb, long gap)
+//                                                        -- C(i, c) -= (A Bt^T)(i, c) for i >= c + (c / nb) * gap
+//   void step_begin(long local_trailing_entries, long next_panel_rows) / rest_begin() / rest_end() / ahead_begin() /
+//        ahead_end() / ahead_join() / run_end()          -- scheduling hooks as in dist_lu.h
 //   void pack(View src, T *dst)                          -- contiguous column-major copy into the panel buffer
 //   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)
 //   void bcast(void *buf, size_t bytes, int root)        -- blocking (status exchange at the end)
@@ -32,8 +46,8 @@ template <class B> struct DistLlt {
 
 	static size_t hdr_scalars() { return (4 * sizeof(int) + sizeof(T) - 1) / sizeof(T); }
 	static size_t buf_scalars(long n, long nb) { return (size_t) n * (size_t) nb; }
-	// [status: 4 ints][panel buffer 0][panel buffer 1]
-	static size_t ws_scalars(long n, long nb) { return hdr_scalars() + 2 * buf_scalars(n, nb); }
+	// [status: 4 ints][panel buffer 0][panel buffer 1][gathered panel rows of the owned block columns]
+	static size_t ws_scalars(long n, long nb) { return hdr_scalars() + 3 * buf_scalars(n, nb); }
 
 	// A_local: n x local_ncols (this rank's block columns in increasing global order, full height; only the lower
 	// triangle of the global matrix is referenced or written).  Returns -(index + 1) for the first non-positive
@@ -66,24 +80,57 @@ template <class B> struct DistLlt {
 			View P{buf(k), rows, w, 1, rows};
 			be.syrk_sub(view(bc0, lc, n - bc0, bw), View{P.p + off, rows - off, w, 1, rows}, View{P.p + off, bw, w, 1, rows});
 		};
+		T *gbuf = bufs + 2 * bsz;
+		// the rest of update k: all owned block columns right of the panel (without block k + 1 if this rank brings it up
+		// to date in the look-ahead part) in one staircase product
+		auto rest = [&](long k, bool skip_next) {
+			be.rest_begin();
+			long b0 = -1, c_first = 0, c_all = 0; // first block of the range, its first local column, local columns in all
+			for (long b = rank; b < nblk; b += world) {
+				if (b0 < 0 && b > k && !(skip_next && b == k + 1)) {
+					b0 = b;
+					c_first = c_all;
+				}
+				c_all += width(b);
+			}
+			if (b0 >= 0) {
+				const long j0 = k * nb, w = width(k), rows = n - j0, off = b0 * nb - j0, nc = c_all - c_first;
+				View Pk{buf(k) + off, rows - off, w, 1, rows};
+				be.gather_stair(Pk, nc, nb, (world - 1) * nb, gbuf);
+				be.syrk_stair_sub(view(b0 * nb, c_first, n - b0 * nb, nc), Pk, View{gbuf, nc, w, 1, nc}, nb, (world - 1) * nb);
+			}
+			be.rest_end();
+		};
 		be.zero_ints(status, 4);
 		if (rank == 0 % world)
 			factor_and_pack(0);
 		be.bcast_begin(buf(0), (size_t) n * (size_t) width(0) * sizeof(T), 0, 0);
 		for (long k = 0; k < nblk; ++k) {
 			be.bcast_wait((int) (k & 1));
-			if (k + 1 < nblk) {
-				const int next_owner = (int) ((k + 1) % world);
-				if (rank == next_owner) {
-					update(k, k + 1);
-					factor_and_pack(k + 1);
-				}
-				be.bcast_begin(buf(k + 1), (size_t) (n - (k + 1) * nb) * (size_t) width(k + 1) * sizeof(T), next_owner, (int) ((k + 1) & 1));
+			const bool ahead = k + 1 < nblk;
+			const int next_owner = ahead ? (int) ((k + 1) % world) : -1;
+			{ // trailing entries this rank updates in this step, rows of the next panel: does the step use both streams?
+				long right = 0;
+				for (long b = rank; b < nblk; b += world)
+					if (b > k)
+						right += width(b);
+				be.step_begin((n - k * nb) * right / 2, n - (k + 1) * nb);
 			}
-			for (long b = rank; b < nblk; b += world)
-				if (b > k + 1)
-					update(k, b);
+			if (ahead && rank == next_owner) {
+				be.ahead_begin();
+				update(k, k + 1);
+				factor_and_pack(k + 1);
+				be.ahead_end();
+				rest(k, true); // runs beside the panel on an asynchronous backend
+				be.ahead_join();
+				be.bcast_begin(buf(k + 1), (size_t) (n - (k + 1) * nb) * (size_t) width(k + 1) * sizeof(T), next_owner, (int) ((k + 1) & 1));
+			} else {
+				if (ahead) // post the receive before the updates: the transfer overlaps them
+					be.bcast_begin(buf(k + 1), (size_t) (n - (k + 1) * nb) * (size_t) width(k + 1) * sizeof(T), next_owner, (int) ((k + 1) & 1));
+				rest(k, false);
+			}
 		}
+		be.run_end();
 		// ---- outcome: every rank knows only about the panels it factored; combine (first failure, summed count)
 		int mine[4] = {0, 0, 0, 0};
 		be.to_host(mine, status, 4);

@@ -60,7 +60,14 @@ template <typename T> struct GemmArgs {
 	int k_trim;		// GemmExtra::k_trim (pipelined kernel only)
 	int tri_off;		// tri_enum: first tile of the enumeration (tiles of the skipped leading rows)
 	int raster_g;		// tile rows per raster group (pipelined kernel)
+	int stair_nb, stair_gap; // GemmExtra::stair_*: "lower" is tested against the column n + (n / stair_nb) * stair_gap
 };
+
+// column index the lower-part test of dst uses (GemmExtra::stair_nb: a staircase instead of a diagonal)
+template <typename G> static __device__ __forceinline__ int lower_col(const G &g, int n)
+{
+	return g.stair_nb ? n + (n / g.stair_nb) * g.stair_gap : n;
+}
 
 // FaerBlock membership test (faer/src/linalg/matmul/triangular.rs:906-977)
 static __device__ __forceinline__ bool in_block(int s, int i, int j)
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		}
 	}
 	const int m_off = tm * BM, n_off = tn * BN;
-	if (g.lower && m_off + BM - 1 < n_off)
+	if (g.lower && m_off + BM - 1 < lower_col(g, n_off))
 		return; // tile entirely above the diagonal
 
 	int k_begin = blockIdx.z * g.k_per_split;
@@ -335,11 +342,12 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		for (int r = 0; r < 4; ++r) {
 			const int n = n_off + wn * WTN + j * 16 + Mfma<T>::row(r, lhi);
 			const bool n_ok = n < g.N;
+			const int nlow = lower_col(g, n);
 			const idx_t ncol = (n_ok && g.col_idx) ? load_idx(g.col_idx, g.idx64, n) : (idx_t) n;
 #pragma unroll
 			for (int i = 0; i < TM; ++i) {
 				const int m = m_off + wm * WTM + i * 16 + l15;
-				const bool ok = n_ok && m < g.M && !(g.lower && (m < n || (g.dst_strict && m == n)));
+				const bool ok = n_ok && m < g.M && !(g.lower && (m < nlow || (g.dst_strict && m == nlow)));
 				const idx_t mrow = (ok && g.row_idx) ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
 				ptr[r][i] = !ok ? g.dst : g.atomic == 2 ? g.ws + ((size_t) blockIdx.z * g.N + n) * g.M + m : g.dst + mrow * g.drs + ncol * g.dcs;
 				okmask |= (unsigned) ok << (r * TM + i);
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		}
 	}
 	const int m_off = tm * BM, n_off = tn * BN;
-	if (g.lower && m_off + BM - 1 < n_off)
+	if (g.lower && m_off + BM - 1 < lower_col(g, n_off))
 		return; // tile entirely above the diagonal
 
 	const int k_begin = blockIdx.z * g.k_per_split;
@@ -758,11 +766,12 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		for (int r = 0; r < 4; ++r) {
 			const int n = n_off + wn * WTN + j * 16 + Mfma<T>::row(r, lhi);
 			const bool n_ok = n < g.N;
+			const int nlow = lower_col(g, n);
 			const idx_t ncol = (n_ok && g.col_idx) ? load_idx(g.col_idx, g.idx64, n) : (idx_t) n;
 #pragma unroll
 			for (int i = 0; i < TM; ++i) {
 				const int m = m_off + wm * WTM + i * 16 + l15;
-				const bool ok = n_ok && m < g.M && !(g.lower && (m < n || (g.dst_strict && m == n)));
+				const bool ok = n_ok && m < g.M && !(g.lower && (m < nlow || (g.dst_strict && m == nlow)));
 				const idx_t mrow = (ok && g.row_idx) ? load_idx(g.row_idx, g.idx64, m) : (idx_t) m;
 				ptr[r][i] = !ok ? g.dst : g.atomic == 2 ? g.ws + ((size_t) blockIdx.z * g.N + n) * g.M + m : g.dst + mrow * g.drs + ncol * g.dcs;
 				okmask |= (unsigned) ok << (r * TM + i);
@@ -1037,6 +1046,8 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	g.dst_strict = ex.dst_strict ? 1 : 0;
 	g.k_trim = ex.k_trim;
 	g.tri_off = 0;
+	g.stair_nb = (int) ex.stair_nb;
+	g.stair_gap = (int) ex.stair_gap;
 	{
 		static const int rg = getenv("FAER_HIP_GEMM_RASTER") ? atoi(getenv("FAER_HIP_GEMM_RASTER")) : 8; // A/B switch
 		g.raster_g = rg > 0 ? rg : 8;
@@ -1046,8 +1057,10 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		g.epi_serial = e ? (atoi(e) == 0 ? 1 : 0) : 0;
 	}
 	const bool extra_path = ex.diag || ex.a_struct || ex.b_struct;
-	if (ex.k_trim || ex.tri_skip)
-		FH_CHECK(!extra_path && !indexed && !ex.inplace && ctx().gemm_variant < 10, "gemm: k_trim / tri_skip need the plain dense kernel");
+	if (ex.k_trim || ex.tri_skip || ex.stair_nb)
+		FH_CHECK(!extra_path && !indexed && !ex.inplace && ctx().gemm_variant < 10, "gemm: k_trim / tri_skip / stair_nb need the plain dense kernel");
+	if (ex.stair_nb)
+		FH_CHECK(g.lower && !transpose && ex.stair_nb > 0 && ex.stair_gap >= 0, "gemm: stair_nb needs a lower, untransposed dst");
 
 	// loader shapes: K-major when the k stride is the unit one (and the mn stride is not)
 	const bool akm = iabs(A.cs) == 1 && iabs(A.rs) != 1;
@@ -1122,7 +1135,7 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	}
 	g.ntm = (int) ((m + bm - 1) / bm);
 	g.ntn = (int) ((n + bn - 1) / bn);
-	g.tri_enum = (g.lower && m == n) ? 1 : 0;
+	g.tri_enum = (g.lower && m == n && !ex.stair_nb) ? 1 : 0;
 	if (ex.tri_skip) {
 		FH_CHECK(g.tri_enum && ex.tri_skip % bm == 0 && ex.tri_skip < m, "gemm: tri_skip needs a square lower dst and a tile-aligned skip");
 		const int st = (int) (ex.tri_skip / bm);
@@ -1139,7 +1152,7 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	static const idx_t splitk_mink = getenv("FAER_HIP_SPLITK_MINK") ? atol(getenv("FAER_HIP_SPLITK_MINK")) : 1024;
 	static const idx_t splitk_chunk = getenv("FAER_HIP_SPLITK_CHUNK") ? atol(getenv("FAER_HIP_SPLITK_CHUNK")) : 256;
 	const idx_t mink = kind == DST_FULL ? splitk_mink : 4096, chunk = kind == DST_FULL ? splitk_chunk : 1024;
-	if (tiles < 256 && k >= mink && !indexed && !ex.k_trim) {
+	if (tiles < 256 && k >= mink && !indexed && !ex.k_trim && !ex.stair_nb) {
 		splits = (int) ((512 + tiles - 1) / tiles);
 		idx_t max_splits = k / chunk;
 		if (splits > max_splits)

@@ -134,6 +134,22 @@ struct HostBackend {
 			}
 		}
 	}
+	void gather_stair(View P, long ncols, long nb, long gap, double *dst)
+	{
+		for (long k = 0; k < P.ncols; ++k)
+			for (long c = 0; c < ncols; ++c)
+				dst[k * ncols + c] = at(P, c + (c / nb) * gap, k);
+	}
+	void syrk_stair_sub(View C, View A, View Bt, long nb, long gap)
+	{
+		for (long c = 0; c < C.ncols; ++c)
+			for (long i = c + (c / nb) * gap; i < C.nrows; ++i) {
+				double s = 0.0;
+				for (long k = 0; k < A.ncols; ++k)
+					s += at(A, i, k) * at(Bt, c, k);
+				at(C, i, c) -= s;
+			}
+	}
 	void syrk_sub(View C, View A, View Bt)
 	{
 		for (long j = 0; j < C.ncols; ++j)

@@ -53,9 +53,13 @@ if what == "lu":
     F.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cols=np.array(cols), loc=loc.cpu().numpy(), fwd=fwd, cnt=cnt)
 else:
+    loc0 = loc.clone()
     cnt = F.dist_llt(loc, n, nb, rank, world, bcast, ibcast=ibcast if use_async else None)
     F.synchronize()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cols=np.array(cols), loc=loc.cpu().numpy(), cnt=cnt)
+    # only the lower triangle of the global matrix may be written (the grouped update masks a staircase)
+    above = torch.arange(n, device="cuda")[:, None] < torch.tensor(cols, device="cuda")[None, :]
+    upper_untouched = bool(torch.equal(loc[above], loc0[above]))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cols=np.array(cols), loc=loc.cpu().numpy(), cnt=cnt, upper_untouched=upper_untouched)
 if rank == 0:  # single-GPU reference by the same library
     ref = a.clone()
     if what == "lu":
@@ -96,12 +100,13 @@ def test_two_rank_lu_equals_single_gpu(tmp_path, n, nb, use_async):
     assert np.abs(got - ref["ref"]).max() <= 256 * n * 2.3e-16 * max(1.0, np.abs(ref["ref"]).max())
 
 
-@pytest.mark.parametrize("n,nb,use_async", [(1024, 128, True), (1000, 192, False)])
+@pytest.mark.parametrize("n,nb,use_async", [(1024, 128, True), (1000, 192, False), (2500, 128, True)])
 def test_two_rank_llt_equals_single_gpu(tmp_path, n, nb, use_async):
     res, ref = run(tmp_path, "llt", n, nb, use_async)
     got = np.zeros((n, n))
     for r in res:
         assert int(r["cnt"]) == 0
+        assert bool(r["upper_untouched"])
         got[:, r["cols"]] = r["loc"]
     il = np.tril_indices(n)
     assert np.abs(got[il] - ref["ref"][il]).max() <= 256 * n * 2.3e-16 * np.abs(ref["ref"][il]).max()
