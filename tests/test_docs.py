@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def referenced_paths(md):
     text = open(os.path.join(ROOT, md)).read()
     pats = re.findall(r"`((?:profiles|tools|tests|oracle|include|faer-rs_amd)/[A-Za-z0-9_./\-]+\.[a-z]+)`", text)
-    pats += [f"profiles/{p}" for p in re.findall(r"`(r0[12]_[A-Za-z0-9_/]+\.(?:txt|csv|json))`", text)]
+    pats += [f"profiles/{p}" for p in re.findall(r"`(r0[123]_[A-Za-z0-9_/]+\.(?:txt|csv|json))`", text)]
     return sorted(set(pats))
 
 
@@ -28,7 +28,7 @@ def test_referenced_files_exist():
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r01_final_bench_line.json", "r02_bench_line.json"])
+@pytest.mark.parametrize("name", ["r01_final_bench_line.json", "r02_bench_line.json", "r03_bench_line.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = json.load(open(os.path.join(ROOT, "profiles", name)))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
