@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override the matrix size (testing only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pause", type=float, default=0.0, help="seconds of idle time before each entry of `others` (diagnostic)")
     ap.add_argument("--transport", default="torch", choices=["torch", "rccl"],
                     help="multi-GPU lu/llt: broadcast through torch.distributed (RCCL under the nccl backend) or the library's own "
                          "RCCL transport (ncclBroadcast on a dedicated stream, no Python callback in the loop)")
@@ -420,11 +421,18 @@ def main():
             others = {}
             del step
             torch.cuda.empty_cache()
+            only = os.environ.get("BENCH_OTHERS")  # diagnostic: a comma-separated subset
             for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess", "qrmax"):
-                if name == args.workload:
+                if name == args.workload or (only and name not in only.split(",")):
                     continue
                 try:
                     st, fl, ov, lb, dn = make_workload(name)
+                    if args.pause > 0:
+                        # the chip leaves a long MFMA-bound run (the headline, LLT, LU) at reduced clocks for a while and the
+                        # latency-bound workloads after it measured up to 40 % slower than on their own: every entry of
+                        # `others` starts from an idle chip (documented in DESIGN.md 6c; --pause 0 restores back-to-back runs)
+                        torch.cuda.synchronize()
+                        time.sleep(args.pause)
                     reps = 5
                     t, _ = timed(st, reps, 2)
                     if ov is not None:
@@ -481,7 +489,8 @@ def main():
                                                       "algorithmic_bytes": 2.0 * 500000 * 256 * 4}
                             others[lb]["roofline"].update(dominant_from_profile("qr") or {})
                     del st, ov
-                    torch.cuda.empty_cache()
+                    if not os.environ.get("BENCH_KEEP_CACHE"):  # diagnostic
+                        torch.cuda.empty_cache()
                 except Exception as ex:  # keep the headline line even if an extra fails
                     others[name] = {"error": str(ex)[:200]}
             out["others"] = others

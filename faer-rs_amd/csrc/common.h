@@ -81,6 +81,13 @@ struct Ctx {
 	std::vector<hipEvent_t> la_events;
 	size_t la_next_event = 0;
 	bool lookahead_streams(); // creates the streams on first use; false if the runtime refuses
+	// Plain side stream + events of the one-pass QR (tsqr.hip): ONE stream for both of its roles, created before the two
+	// CU-masked streams above.  The runtime maps streams onto 4 hardware queues by default; as the 4th and 5th stream of the
+	// process the QR's side streams made every kernel of the QR -- on the caller's stream too -- 1.3-6x slower (bench.py:
+	// QR after an LLT in the same process 2.78 ms against 2.04; profiles/r03_qr_stream_order.txt).
+	hipStream_t qr_side[2] = {nullptr, nullptr};
+	hipEvent_t qr_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	void qr_side_streams();
 	hipEvent_t next_event();  // timing-disabled events, recycled per factorization (reset_events)
 	void reset_events() { la_next_event = 0; }
 	int ncu = 0;

@@ -64,10 +64,24 @@ void Ctx::ensure_device()
 	device = d;
 }
 
+void Ctx::qr_side_streams()
+{
+	if (qr_side[0])
+		return;
+	// ONE stream for both roles: with the caller's stream and the two CU-masked ones that makes four -- a fifth stream
+	// shares a hardware queue with another one (the runtime maps streams onto 4 of them by default) and whatever was
+	// created last ran 1.3 - 6 x slower, on every stream (profiles/r03_qr_stream_order.txt)
+	FH_HIP(hipStreamCreateWithFlags(&qr_side[0], hipStreamNonBlocking));
+	qr_side[1] = qr_side[0];
+	for (hipEvent_t &e : qr_ev)
+		FH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+}
+
 bool Ctx::lookahead_streams()
 {
 	if (la_state != 0)
 		return la_state > 0;
+	qr_side_streams(); // (see common.h: the order of creation matters)
 	la_state = -1;
 	if (getenv("FAER_HIP_NO_LOOKAHEAD"))
 		return false;

@@ -1738,24 +1738,17 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 	FH_HIP(hipGetLastError());
 }
 
-// per-thread side streams of the factorization: the panel kernel of step k + 1 (one workgroup) beside the rest of step k's
-// update, and the cross-panel T blocks beside the last steps
+// side streams of the factorization (owned by the per-thread context, ctx.hip): the panel kernel of step k + 1 (one
+// workgroup) beside the rest of step k's update, and the cross-panel T blocks beside the last steps
 struct TqSide {
-	hipStream_t panel = nullptr, tx = nullptr;
-	hipEvent_t pfork = nullptr, pdone = nullptr, xfork = nullptr, xdone = nullptr;
-	int device = -1;
+	hipStream_t panel, tx;
+	hipEvent_t pfork, pdone, xfork, xdone;
 };
-static TqSide &tq_side()
+static TqSide tq_side()
 {
-	static thread_local TqSide sd;
-	if (sd.panel == nullptr || sd.device != ctx().device) {
-		FH_HIP(hipStreamCreateWithFlags(&sd.panel, hipStreamNonBlocking));
-		FH_HIP(hipStreamCreateWithFlags(&sd.tx, hipStreamNonBlocking));
-		for (hipEvent_t *e : {&sd.pfork, &sd.pdone, &sd.xfork, &sd.xdone})
-			FH_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-		sd.device = ctx().device;
-	}
-	return sd;
+	Ctx &c = ctx();
+	c.qr_side_streams();
+	return TqSide{c.qr_side[0], c.qr_side[1], c.qr_ev[0], c.qr_ev[1], c.qr_ev[2], c.qr_ev[3]};
 }
 
 bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs)
@@ -1878,7 +1871,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	// rest of the update is long enough to cover that (>= 192 more trailing columns).  Otherwise only the Gram launch is
 	// split (gram_and_panel below).  FAER_HIP_QR_TSQR_LA = 0 / 1 / 2: neither / always the first / always the second.
 	static const int la_env = getenv("FAER_HIP_QR_TSQR_LA") ? atoi(getenv("FAER_HIP_QR_TSQR_LA")) : -1; // A/B switch
-	TqSide &side = tq_side();
+	const TqSide side = tq_side();
 	const int ncu_all = ctx().stream_cus();
 	int cus_taken = 0; // CUs held by side-stream kernels while the persistent update kernels run
 	bool tx_on_side = false;
