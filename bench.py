@@ -34,6 +34,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime maps streams onto 4 hardware queues by default.  A rank of the distributed LU / Cholesky has the caller's
+# stream, the library's two CU-masked look-ahead streams, the transport's stream and torch.distributed's own: streams that
+# share a queue serialise (profiles/r03_qr_stream_order.txt: whatever was created fifth ran 1.3-6x slower).  Read by the
+# runtime at its first call, i.e. after this line; measured neutral on one GPU (LLT 39.06 / 38.74, LU 123.6 / 123.2, QR
+# 2.016 / 2.015 ms with 4 / 8).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 # The factorizations are chains of launches.  Which kernel dominates, its share of the library's kernel time, its average
 # launch duration and its launch count are PARSED at run time from the committed rocprofv3 kernel trace of
