@@ -395,7 +395,9 @@ def main():
                     pmc_src = f"profiles/pmc_gemm_latest.json ({pj.get('recorded', 'round 1')}; rocprofv3 --pmc, not this run)"
                 except Exception:
                     pmc = None
-            out["roofline"] = {"bound": "mfma", "kernel": "fh::gemm_kernel_p<double,128,128,16,2,2,false,true,1>",
+            # the kernel's name (tile shape) from the committed kernel trace of this same command, like the other workloads
+            kname = (dominant_from_profile("gemm") or {}).get("dominant_kernel", "fh::gemm_kernel_p<double, 128, 256, 16, 2, 4, false, true, 1>")
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": pmc, "traffic_source": pmc_src,
                                "algorithmic_flops_per_launch": flops, "launch_ms": round(launch_s * 1e3, 4)}

@@ -70,8 +70,9 @@ struct Ctx {
 		hipStream_t owner; // stream whose work last used the buffer: reuse is stream ordered only on that stream
 	};
 	std::vector<Buf> pool;
-	int *status = nullptr; // 16 ints of device status words (pinned-host readable copy below)
-	int *status_host = nullptr;
+	int *status = nullptr; // 16 ints of device status words
+	int *host_ints = nullptr; // 16 pinned host ints: read-back target of the drivers that return a status per call
+	int *pinned_ints();
 	// Look-ahead execution (factorizations): two internal streams on DISJOINT sets of CUs
 	// (hipExtStreamCreateWithCUMask): `la_bulk` runs the trailing-matrix GEMMs on most of the chip, `la_panel`
 	// the latency-bound diagonal-block / panel work on a few reserved CUs, so neither queue can starve the other.

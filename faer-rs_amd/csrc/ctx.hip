@@ -64,6 +64,13 @@ void Ctx::ensure_device()
 	device = d;
 }
 
+int *Ctx::pinned_ints()
+{
+	if (!host_ints)
+		FH_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_ints), 16 * sizeof(int), hipHostMallocDefault));
+	return host_ints;
+}
+
 void Ctx::qr_side_streams()
 {
 	if (qr_side[0])

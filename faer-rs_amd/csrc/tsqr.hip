@@ -258,9 +258,11 @@ __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const 
 		// The slices of G are added up here as well, by whichever of the TQ_NG workgroups of these 256 entries finishes last
 		// (fixed order of the slices): the panel kernel -- ONE workgroup -- then reads 32 KB instead of 256 KB, which took
 		// it 35 000 cycles.  The counters return to zero by themselves.
-		__threadfence();
+		// (the barrier waits for every wavefront's stores; ONE release fence behind it publishes them all -- a fence per
+		// thread made this kernel 19 -> 33 us)
 		__syncthreads();
 		if (threadIdx.x == 0) {
+			__threadfence();
 			const int old = atomicAdd(&cnt[blockIdx.x], 1);
 			s_last = old == TQ_NG - 1;
 			if (s_last)
@@ -1109,10 +1111,15 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 	}
 	if (blockIdx.x == 0)
 		tq_store_top(a.A, a.ld, a.r0, a.cx - a.w, a.w, a.top, tid);
+	// only the triangles the products below read (a single workgroup loads at ~7 B / cycle: 96 KB were 6 us)
 	for (int e = tid; e < 4096; e += 256) {
-		n1[(e >> 6) * TQ_DP + (e & 63)] = a.N1[e];
-		n3[(e >> 6) * TQ_DP + (e & 63)] = a.N3[e];
-		mm[(e >> 6) * TQ_DP + (e & 63)] = a.Md[e];
+		const int i = e >> 6, j = e & 63;
+		if (j <= i) {
+			n1[i * TQ_DP + j] = a.N1[e];
+			n3[i * TQ_DP + j] = a.N3[e];
+		}
+		if (j >= i)
+			mm[i * TQ_DP + j] = a.Md[e];
 	}
 	const int bl = tid & 15, ig = tid >> 4; // column, row group: rows ig, ig + 16, ig + 32, ig + 48
 	const int b = blockIdx.x * 16 + bl;
@@ -2032,8 +2039,8 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		}
 		FH_HIP(hipGetLastError());
 	}
-	int st[4];
-	FH_HIP(hipMemcpyAsync(st, stat, sizeof(st), hipMemcpyDeviceToHost, s));
+	int *st = ctx().pinned_ints(); // (a pageable target makes the copy a staged, blocking one)
+	FH_HIP(hipMemcpyAsync(st, stat, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
 	FH_HIP(hipStreamSynchronize(s));
 #ifdef FH_TQ_TIMING
 	{
