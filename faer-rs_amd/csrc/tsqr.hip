@@ -1111,15 +1111,10 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 	}
 	if (blockIdx.x == 0)
 		tq_store_top(a.A, a.ld, a.r0, a.cx - a.w, a.w, a.top, tid);
-	// only the triangles the products below read (a single workgroup loads at ~7 B / cycle: 96 KB were 6 us)
 	for (int e = tid; e < 4096; e += 256) {
-		const int i = e >> 6, j = e & 63;
-		if (j <= i) {
-			n1[i * TQ_DP + j] = a.N1[e];
-			n3[i * TQ_DP + j] = a.N3[e];
-		}
-		if (j >= i)
-			mm[i * TQ_DP + j] = a.Md[e];
+		n1[(e >> 6) * TQ_DP + (e & 63)] = a.N1[e];
+		n3[(e >> 6) * TQ_DP + (e & 63)] = a.N3[e];
+		mm[(e >> 6) * TQ_DP + (e & 63)] = a.Md[e];
 	}
 	const int bl = tid & 15, ig = tid >> 4; // column, row group: rows ig, ig + 16, ig + 32, ig + 48
 	const int b = blockIdx.x * 16 + bl;
