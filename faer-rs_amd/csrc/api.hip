@@ -1409,6 +1409,7 @@ int faer_hip_debug_dist_two_streams_ok(size_t panel_rows, FaerHipDType dtype, in
 	return dist_two_streams_ok((idx_t) panel_rows, dtype == FaerHipDType_F64 ? 8 : 4, panel_cus, all_cus) ? 1 : 0;
 }
 void faer_hip_debug_lu_force_general(int on) { lu_force_general(on); }
+long faer_hip_debug_qr_one_pass_columns(void) { return qr_last_one_pass_columns(); }
 void *faer_hip_debug_internal_stream(int which)
 {
 	Ctx &c = ctx();

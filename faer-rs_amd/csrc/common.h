@@ -295,6 +295,7 @@ std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2);
 int lu_leaf_width(idx_t m, int elem_bytes, int resident_workgroups);
 bool dist_two_streams_ok(idx_t panel_rows, int elem_bytes, int panel_cus, int all_cus);
 void lu_force_general(int on); // debug: every LU leaf on the non-cooperative path
+long qr_last_one_pass_columns(); // debug: columns the one-pass QR path completed in this thread's last factorization (-1: not taken)
 // tall-skinny shapes (skinny.hip): streaming kernels; false if the shape / strides do not qualify
 template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV<const T> B, T alpha);
 // C <- [C +] alpha * sum_z ws[z] (slices of nrows x ncols, column major), fixed summation order (gemm.hip)

@@ -2266,8 +2266,12 @@ template <typename T> __global__ void qr_taus_from_blocks_kernel(const T *H, idx
 // take (ill conditioned, a column failing the reference's rank test, ...) with every earlier reflector applied to
 // everything on its right -- the state qr_in_place_blocked (factor.rs:137-256) is in at that column -- so the classic
 // path simply factors the remaining submatrix and the T blocks are rebuilt from V and the taus.
+static thread_local long g_qr_one_pass_columns = -1; // of this thread's last QR: columns the one-pass path completed, -1 = not taken
+long qr_last_one_pass_columns() { return g_qr_one_pass_columns; }
+
 template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold)
 {
+	g_qr_one_pass_columns = -1;
 	if constexpr (std::is_same<T, float>::value) {
 		const idx_t m = A.nrows, n = A.ncols, bs = H.nrows;
 		const idx_t size = m < n ? m : n;
@@ -2276,6 +2280,7 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 			Scratch taus((size_t) size * sizeof(T));
 			int reason = 0;
 			const idx_t done = tsqr_factor(A, H, taus.as<T>(), &reason);
+			g_qr_one_pass_columns = (long) done;
 			if (done == size)
 				return (long) size;
 			static const bool verbose = getenv("FAER_HIP_VERBOSE") != nullptr;

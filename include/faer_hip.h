@@ -482,6 +482,10 @@ FAER_HIP_API int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, 
 /* tests: run every leaf of the partial-pivot LU on the non-cooperative path (the fallback for panels taller than the
  * cooperative kernel can keep resident and for the rerun after an exchange timeout) */
 FAER_HIP_API void faer_hip_debug_lu_force_general(int on);
+/* tests: how many columns the one-pass tall-skinny QR path (csrc/tsqr.hip) completed in the calling thread's last
+ * qr_factor_in_place (== ncols: the whole factorization; fewer: a panel was rejected and the classic path finished; -1: the
+ * path was not applicable) */
+FAER_HIP_API long faer_hip_debug_qr_one_pass_columns(void);
 /* host logic of the distributed LU: may a step factor its look-ahead panel of `panel_rows` rows on the CU-masked panel stream? */
 FAER_HIP_API int faer_hip_debug_dist_two_streams_ok(size_t panel_rows, FaerHipDType dtype, int panel_cus, int all_cus);
 /* Instrumented builds (make -C csrc timing): prints and resets the in-kernel phase counters; a no-op otherwise. */

@@ -1,5 +1,6 @@
 """GPU parity: Householder QR through the C-ABI vs the CPU oracle and the reference's known-answer test
 (test_qr, test_rank_deficient (shape), qr::tests::test_example)."""
+import ctypes as C
 import json
 import os
 
@@ -156,6 +157,8 @@ def _tall_vs_oracle(oracle, F, a, bs, lead=None):
         dqr = buf.t()[:m, :]
     dh = to_dev(np.zeros((bs, n), dtype=np.float32))
     assert F.qr_factor_in_place(dqr, dh) == n
+    F.lib().faer_hip_debug_qr_one_pass_columns.restype = C.c_long
+    assert F.lib().faer_hip_debug_qr_one_pass_columns() == n  # the whole factorization ran on the one-pass path
     qr, h = to_host(dqr), to_host(dh)
     ref, rh = a.copy(order="F"), np.zeros((bs, n), dtype=np.float32, order="F")
     assert oracle.qr_in_place(ref, rh) == n
@@ -179,6 +182,21 @@ def _tall_vs_oracle(oracle, F, a, bs, lead=None):
 def test_qr_tall_one_pass_vs_oracle(oracle, m, n, bs):
     """qr/no_pivoting/factor.rs:137-256 on the one-pass path: whole and ragged panels, blocks of Q_coeff narrower than,
     equal to and wider than a 64-column panel (the wider ones need the cross-panel blocks of T)"""
+    F = init_gpu()
+    rng = np.random.default_rng(m + n)
+    a = rnd(rng, m, n, np.float32)
+    if bs is None:
+        bs = F.qr_recommended_block_size(m, n, np.float32)
+        assert bs == oracle.qr_recommended_block_size(m, n, np.float32)
+    _tall_vs_oracle(oracle, F, a, bs)
+
+
+@pytest.mark.parametrize("m,n,bs", [(40000, 512, 512), (33000, 384, 128), (50000, 320, None), (36000, 448, 64), (20000, 512, 256),
+                                    (30001, 300, 64)])
+def test_qr_tall_one_pass_wide_panels_vs_oracle(oracle, m, n, bs):
+    """256 < n <= 512 on the one-pass path: trailing matrices wider than one 192-column strip (several Gram / update launches
+    per panel), the look-ahead of the panel kernel (on by itself from 192 more trailing columns), blocks of Q_coeff wider than
+    256 columns (the general kernel of the cross-panel T blocks) and several blocks of Q_coeff of 2 - 4 panels each"""
     F = init_gpu()
     rng = np.random.default_rng(m + n)
     a = rnd(rng, m, n, np.float32)
@@ -220,6 +238,8 @@ def test_qr_tall_falls_back_per_panel(oracle):
     assert oracle.qr_in_place(ref, rh) == n
     dqr, dh = to_dev(a), to_dev(np.zeros((64, n), dtype=np.float32))
     assert F.qr_factor_in_place(dqr, dh) == n
+    F.lib().faer_hip_debug_qr_one_pass_columns.restype = C.c_long
+    assert F.lib().faer_hip_debug_qr_one_pass_columns() == 64  # the first panel on the one-pass path, the graded one refused
     q = thin_q(F, dqr, dh, m, n)
     R = np.triu(to_host(dqr)[:n]).astype(np.float64)
     assert np.abs(q @ R - a).max() <= 64 * np.sqrt(m) * e * np.abs(a).max()
@@ -235,6 +255,7 @@ def test_qr_tall_falls_back_per_panel(oracle):
     rk = oracle.qr_in_place(ref, rh)
     dqr, dh = to_dev(b), to_dev(np.zeros((64, 128), dtype=np.float32))
     assert F.qr_factor_in_place(dqr, dh) == rk
+    assert 0 <= F.lib().faer_hip_debug_qr_one_pass_columns() < 128
     h = to_host(dh)
     assert np.array_equal(np.isinf(h), np.isinf(rh))
     assert np.abs(to_host(dqr) - ref).max() <= 64 * np.sqrt(m) * e * np.abs(ref).max()
