@@ -107,16 +107,8 @@ Ctx &ctx();
 void debug_stream_xcc(int which, int nblocks, unsigned *out_host); // which: 0 caller's stream, 1 bulk, 2 panel
 void ctx_shutdown(); // releases the calling thread's look-ahead streams / events; safe without a device
 
-// stream `s` waits for event `e`; with FAER_HIP_LA_HOSTSYNC set the HOST waits instead (debugging aid that
-// takes hipStreamWaitEvent out of the picture)
-inline void stream_wait(hipStream_t s, hipEvent_t e)
-{
-	static const bool hostsync = getenv("FAER_HIP_LA_HOSTSYNC") != nullptr;
-	if (hostsync)
-		FH_HIP(hipEventSynchronize(e));
-	else
-		FH_HIP(hipStreamWaitEvent(s, e, 0));
-}
+// stream `s` waits for event `e`
+inline void stream_wait(hipStream_t s, hipEvent_t e) { FH_HIP(hipStreamWaitEvent(s, e, 0)); }
 
 // RAII: run the enclosed launches on another stream
 struct StreamScope {

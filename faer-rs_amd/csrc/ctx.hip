@@ -100,16 +100,12 @@ bool Ctx::lookahead_streams()
 		la_panel_cus = atoi(e);
 	if (la_panel_cus < 8 || la_panel_cus > ncu / 2 || ncu > 1024)
 		return false;
-	// CU i of the mask is enabled by bit i.  FAER_HIP_PANEL_MASK picks the layout: "tail" (default) = the last
-	// `la_panel_cus` bits, "head" = the first ones, "mod8" = bits i with i % 8 == 7 (ncu / 8 of them).
-	// Measured (profiles/r01_exp_masks.txt): workgroups of a masked stream still land on all 8 XCDs for every
-	// layout -- the dispatcher deals workgroups to the XCDs round robin and the mask only selects CUs inside each,
-	// so a stream cannot be confined to one XCD (and its L2); "mod8" leaves XCDs without panel / bulk CUs and is
-	// 20 % slower, "head" == "tail".
-	const char *mode = getenv("FAER_HIP_PANEL_MASK");
-	const int layout = !mode ? 0 : !strcmp(mode, "head") ? 1 : !strcmp(mode, "mod8") ? 2 : 0;
-	if (layout == 2)
-		la_panel_cus = ncu / 8;
+	// CU i of the mask is enabled by bit i; the panel stream gets the LAST `la_panel_cus` CUs.  Measured
+	// (profiles/r01_exp_masks.txt): workgroups of a masked stream still land on all 8 XCDs for every layout -- the
+	// dispatcher deals workgroups to the XCDs round robin and the mask only selects CUs inside each, so a stream cannot be
+	// confined to one XCD (and its L2); every 8th CU instead leaves XCDs without panel / bulk CUs and is 20 % slower, the
+	// first CUs instead of the last ones make no difference.
+	const int layout = 0;
 	uint32_t mb[32], mp[32];
 	memset(mb, 0, sizeof(mb));
 	memset(mp, 0, sizeof(mp));
@@ -120,12 +116,6 @@ bool Ctx::lookahead_streams()
 	}
 	const uint32_t words = (uint32_t) ((ncu + 31) / 32);
 	hipStream_t b = nullptr, p = nullptr;
-	if (getenv("FAER_HIP_LA_SAME")) { // debugging aid: ONE internal stream for both roles (no concurrency at all)
-		FH_HIP(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
-		la_bulk = la_panel = b;
-		la_state = 1;
-		return true;
-	}
 	if (getenv("FAER_HIP_NO_CUMASK")) { // debugging aid: plain streams, no CU partition
 		FH_HIP(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
 		FH_HIP(hipStreamCreateWithFlags(&p, hipStreamNonBlocking));

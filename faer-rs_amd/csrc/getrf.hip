@@ -1011,7 +1011,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		lists[q].dst = listb.as<int>() + (size_t) q * 4 * LU_LA_NB;
 		lists[q].src = lists[q].dst + 2 * LU_LA_NB;
 	}
-	static const bool use_lists = !(getenv("FAER_HIP_LU_LISTS") && atoi(getenv("FAER_HIP_LU_LISTS")) == 0); // A/B switch
+	const bool use_lists = true; // (the per-workgroup rebuild of the permutation was 4 % slower: DESIGN.md 3.4)
 	{
 		StreamScope sc(c.la_panel);
 		const idx_t w0 = LU_LA_NB < n ? LU_LA_NB : n;
@@ -1072,7 +1072,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// Default 1 (every panel at once): with 8 the composed passes moved ~8 ms off the bulk stream's per-panel
 			// scattered passes but cost as much again in compose_perm / gather / scatter launches and a serial tail
 			// (142.6 vs 145.1 ms at N = 16384, profiles/r02_exp_lu_panel.txt).
-			static const idx_t defer = getenv("FAER_HIP_LU_LEFT_DEFER") ? atol(getenv("FAER_HIP_LU_LEFT_DEFER")) : 1;
+			const idx_t defer = 1;
 			const idx_t grp0 = (k / defer) * defer; // first panel of this group
 			if (k + 1 == nsteps || (k + 1) % defer == 0) {
 				const idx_t jg0 = grp0 * LU_LA_NB;

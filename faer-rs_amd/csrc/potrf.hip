@@ -349,9 +349,8 @@ constexpr idx_t LA_NB = 1024;
 std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2)
 {
 	// width of the first look-ahead step: the whole chip waits for the first diagonal block, so it is ONE 128-block (a
-	// leaf, ~55 us) instead of a 1024-wide one (~1.05 ms): 41.1 -> 40.1 ms at N = 16384 (FAER_HIP_LLT_FIRST overrides, a
-	// multiple of 128)
-	static const idx_t first = getenv("FAER_HIP_LLT_FIRST") ? atol(getenv("FAER_HIP_LLT_FIRST")) / POTRF_NB * POTRF_NB : POTRF_NB;
+	// leaf, ~55 us) instead of a 1024-wide one (~1.05 ms): 41.1 -> 40.1 ms at N = 16384
+	const idx_t first = POTRF_NB;
 	std::vector<idx_t> J;
 	J.push_back(0);
 	while (true) {
@@ -382,8 +381,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 	// Step widths of the look-ahead part: the FIRST step is LA_NB wide (its diagonal block is factored with the rest
 	// of the chip idle), the following ones LA_NB2 (wider steps: K = LA_NB2 trailing updates run closer to the dense
 	// rate and there are fewer launch boundaries per factorization) while at least 2 * LA_NB2 rows remain.
-	const idx_t nb2 = getenv("FAER_HIP_LLT_NB2") ? atol(getenv("FAER_HIP_LLT_NB2")) : LA_NB;
-	FH_CHECK(nb2 >= LA_NB && nb2 % POTRF_NB == 0 && nb2 <= 4096, "potrf: FAER_HIP_LLT_NB2 must be a multiple of 128 in [1024, 4096]");
+	const idx_t nb2 = LA_NB; // (wider later steps measured no gain in round 2)
 	const std::vector<idx_t> J = llt_plan(n, tail_rows, nb2); // look-ahead steps: panel columns [J[k], J[k + 1])
 	idx_t ks = (idx_t) J.size() - 1; // look-ahead steps
 	if (ks > 0 && !c.lookahead_streams())
@@ -405,7 +403,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		}
 		// trailing size from which the update of the next diagonal block runs on the panel stream (it has slack to
 		// spare while the trailing matrix is large, and the bulk stream then issues fewer launches per step)
-		const idx_t dpanel_rmin = getenv("FAER_HIP_LLT_DPANEL") ? atol(getenv("FAER_HIP_LLT_DPANEL")) : 8192;
+		const idx_t dpanel_rmin = 8192;
 		for (idx_t k = 0; k < ks; ++k) {
 			const idx_t j0 = J[(size_t) k], j1 = J[(size_t) k + 1], w = j1 - j0; // panel columns [j0, j1)
 			const idx_t r = n - j1;						       // rows below

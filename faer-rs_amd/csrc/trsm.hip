@@ -556,11 +556,7 @@ template <typename T> static void trsm_leaf128_launch(const T *img, MatV<T> X, M
 	FH_CHECK(n <= TP_NB && k < (1L << 31), "trsm leaf: shape");
 	auto ab = [](idx_t v) { return v < 0 ? -v : v; };
 	const int along_rhs = ab(X.cs) <= ab(X.rs) ? 1 : 0;
-	static const int force = []() {
-		const char *e = getenv("FAER_HIP_TRSM_RW"); // 16 / 32: A/B switch
-		return e ? atoi(e) : 0;
-	}();
-	const bool narrow = force ? force == 16 : (k + TL_NW * 16 - 1) / (TL_NW * 16) <= (idx_t) ctx().stream_cus();
+	const bool narrow = (k + TL_NW * 16 - 1) / (TL_NW * 16) <= (idx_t) ctx().stream_cus();
 	if (img) {
 		if (narrow)
 			trsm_leaf128_go<T, false, 16>(img, n, X, along_rhs, 0, 0, 0);
@@ -631,8 +627,8 @@ template <typename T> void trsm_lower_dev(MatV<const T> L, bool unit, MatV<T> X)
 	}
 	if (n > 64 || k >= 64) { // substitution leaves on the diagonal blocks + MFMA products off the diagonal
 		// every leaf packs its own diagonal block from the triangle (as fast as copying a prepared image, and one launch
-		// less on a chain that is all launches); FAER_HIP_TRSM_PACK=1: separate packing launch (A/B switch)
-		static const bool prepack = getenv("FAER_HIP_TRSM_PACK") && atoi(getenv("FAER_HIP_TRSM_PACK")) == 1;
+		// less on a chain that is all launches) (a separate packing launch is kept as the other branch)
+		const bool prepack = false;
 		if (prepack) {
 			const idx_t nblk = (n + TRSM_IB - 1) / TRSM_IB;
 			Scratch wb((size_t) nblk * TriPack<T>::BYTES);
