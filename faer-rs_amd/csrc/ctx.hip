@@ -32,6 +32,19 @@ void ctx_shutdown()
 		c.la_bulk = c.la_panel = nullptr;
 	}
 	c.la_state = 0;
+	if (c.qr_side[0]) {
+		(void) hipStreamSynchronize(c.qr_side[0]);
+		(void) hipStreamDestroy(c.qr_side[0]);
+		c.qr_side[0] = c.qr_side[1] = nullptr;
+		for (hipEvent_t &e : c.qr_ev) {
+			(void) hipEventDestroy(e);
+			e = nullptr;
+		}
+	}
+	if (c.host_ints) {
+		(void) hipHostFree(c.host_ints);
+		c.host_ints = nullptr;
+	}
 }
 
 int Ctx::stream_cus()
