@@ -989,17 +989,27 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 // ------------------------------------------------------------------------------------------------
 constexpr idx_t LU_LA_NB = 512;
 
-template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipStream_t caller)
+// `backup` (optional, m x n): receives a copy of A as it is on entry -- the first panel's columns on the caller's stream,
+// the rest on the bulk stream BESIDE the first panel (that stream has nothing else to do until the panel is done; copied up
+// front the 2 GB of N = 16384 were 0.75 ms of every factorization, profiles/r03_lu_timeline.txt).
+template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipStream_t caller, const MatV<T> *backup = nullptr)
 {
 	Ctx &c = ctx();
 	const idx_t m = A.nrows, n = A.ncols; // n <= m
 	const idx_t size_all = n;		      // every column is a pivot column (n <= m)
 	const idx_t nsteps = (n + LU_LA_NB - 1) / LU_LA_NB;
 	c.reset_events();
+	const idx_t wb = LU_LA_NB < n ? LU_LA_NB : n;
+	if (backup)
+		copy_dev<T>(backup->sub(0, 0, m, wb), A.sub(0, 0, m, wb).c());
 	hipEvent_t e0 = c.next_event();
 	FH_HIP(hipEventRecord(e0, caller));
 	stream_wait(c.la_bulk, e0);
 	stream_wait(c.la_panel, e0);
+	if (backup && n > wb) {
+		StreamScope sc(c.la_bulk);
+		copy_dev<T>(backup->sub(0, wb, m, n - wb), A.sub(0, wb, m, n - wb).c());
+	}
 	hipEvent_t ev_panel;
 	// net row permutation of every panel, composed once on the panel stream right behind the panel and shared by all the
 	// interchange launches of the bulk stream for it (two buffers: the bulk stream still applies panel k while the panel
@@ -1132,8 +1142,9 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		// not get its CU within the bounded spin and the exchange times out -- with the panel kernels returning before they
 		// store anything, but with later launches already consuming stale pivots.  The factorization is then redone from a
 		// copy of A on the non-cooperative leaves (getrf_leaf_general), so that a valid input never comes back as
-		// PartialPivLuStatus::Unknown (lu/partial_pivoting/factor.rs:234-295 has no failure mode).  The copy costs one pass
-		// over A (0.8 of ~100 ms at N = 16384); it is skipped -- and Unknown stays possible -- only when it does not fit.
+		// PartialPivLuStatus::Unknown (lu/partial_pivoting/factor.rs:234-295 has no failure mode).  The copy is one pass over
+		// A (the look-ahead driver hides it beside its first panel); it is skipped -- and Unknown stays possible -- only when
+		// it does not fit.
 		const bool force_general = g_lu_force_general.load() != 0;
 		const size_t a_bytes = (size_t) m * (size_t) size * sizeof(T);
 		size_t mem_free = 0, mem_total = 0;
@@ -1142,14 +1153,13 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 			have_backup = a_bytes <= mem_free / 2;
 		Scratch backup(have_backup ? a_bytes : 256);
 		MatV<T> Bk{backup.as<T>(), m, size, 1, m};
-		if (have_backup)
-			copy_dev<T>(Bk, A.sub(0, 0, m, size).c());
-
 		// look-ahead needs every workgroup of a cooperative leaf resident on the CUs reserved for the panel stream
 		const idx_t leaf_r = leaf_rows_per_wg<T>(LU_W);
 		const bool la = !force_general && size >= 8 * LU_LA_NB && ctx().lookahead_streams() && (m + leaf_r - 1) / leaf_r <= (idx_t) ctx().la_panel_cus;
+		if (have_backup && !la)
+			copy_dev<T>(Bk, A.sub(0, 0, m, size).c());
 		if (la)
-			getrf_lookahead<T>(A.sub(0, 0, m, size), wk, ctx().stream);
+			getrf_lookahead<T>(A.sub(0, 0, m, size), wk, ctx().stream, have_backup ? &Bk : nullptr);
 		else
 			getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);
 		if (have_backup) {
