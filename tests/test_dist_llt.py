@@ -65,7 +65,7 @@ def run_world(tmp_path, world, n, nb, seed, bad=-1):
     return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
 
 
-@pytest.mark.parametrize("world,n,nb", [(2, 96, 16), (2, 100, 16), (3, 90, 8), (2, 64, 64), (3, 50, 16), (2, 7, 16)])
+@pytest.mark.parametrize("world,n,nb", [(2, 96, 16), (2, 100, 16), (3, 90, 8), (2, 64, 64), (3, 50, 16), (2, 7, 16), (4, 130, 16), (3, 200, 32)])
 def test_dist_llt_matches_single_process_oracle(tmp_path, oracle, world, n, nb):
     seed = 11
     res = run_world(tmp_path, world, n, nb, seed)
