@@ -829,37 +829,46 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 			tq_lds_order();
 			// One substitution call per step, the lanes doing different things with it:
 			//   lanes < 48 - 16 jb: the 16 rows of U right of the block, V1_d u = w, one column per lane;
-			//   the others: the diagonal blocks of V1^-1 and of U^-1 (unit vectors as right-hand sides; U^-1 through U_d^T,
-			//   whose reciprocal diagonal is pinvs: U_jj = 1 + |alpha_j|) -- of block jb - 1 in lanes 32 .. 63, and in the
-			//   last step also of block 3 in lanes 0 .. 31
+			//   lanes 48 .. 63: the diagonal block of V1^-1 (unit vectors as right-hand sides) -- the same triangle, so every
+			//   read of it stays wave uniform;
+			//   last step only, lanes 0 .. 15: the diagonal block of U^-1 through U_d^T, whose reciprocal diagonal is pinvs
+			//   (U_jj = 1 + |alpha_j|).  The other diagonal blocks of U^-1 are wavefront 1's, one step behind (below).
 			const int nU = 48 - c0;
-			const bool isU12 = lane < nU;
-			const bool invl = !isU12 && (jb == 3 || (jb >= 1 && lane >= 32));
-			const int bi = lane >= 32 ? jb - 1 : 3;	// block of the inverse lanes
-			const bool uinv = (lane & 16) != 0;	// lanes 16-31 / 48-63: U^-1, lanes 0-15 / 32-47: V1^-1
-			const int j = lane & 15, d0 = invl ? 16 * bi : c0;
+			const bool isU12 = lane < nU, v1l = lane >= 48, u3 = jb == 3 && lane < 16;
+			const int j = lane & 15;
 			const int col = c0 + 16 + lane;
-			const int trs = invl && uinv ? 1 : TQ_DP, tcs = invl && uinv ? TQ_DP : 1;
 			double z[16];
 #pragma unroll
 			for (int i = 0; i < 16; ++i)
 				z[i] = isU12 ? Wm[(c0 + i) * TQ_DP + col] : (i == j ? 1.0 : 0.0);
-			tq_subst16<4>(z, Wm + d0 * TQ_DP + d0, trs, tcs, pinvs + d0, invl && uinv);
+			tq_subst16<4>(z, Wm + c0 * TQ_DP + c0, u3 ? 1 : TQ_DP, u3 ? TQ_DP : 1, pinvs + c0, u3);
 			if (isU12) {
 #pragma unroll
 				for (int i = 0; i < 16; ++i)
 					Wm[(c0 + i) * TQ_DP + col] = z[i];
-			} else if (invl) {
+			} else if (v1l) {
 #pragma unroll
-				for (int i = 0; i < 16; ++i) {
-					if (uinv) {
-						if (i >= j)
-							UL[(d0 + j) * TQ_DP + d0 + i] = z[i]; // U^-1[j][i] = (U^T)^-1[i][j]
-					} else if (i > j) {
-						UL[(d0 + i) * TQ_DP + d0 + j] = z[i]; // V1^-1[i][j]
-					}
-				}
+				for (int i = 0; i < 16; ++i)
+					if (i > j)
+						UL[(c0 + i) * TQ_DP + c0 + j] = z[i]; // V1^-1[i][j]
+			} else if (u3) {
+#pragma unroll
+				for (int i = 0; i < 16; ++i)
+					if (i >= j)
+						UL[(c0 + j) * TQ_DP + c0 + i] = z[i]; // U^-1[j][i] = (U^T)^-1[i][j]
 			}
+		} else if (wv == 1 && jb >= 1 && lane < 16) {
+			// beside wavefront 0: the diagonal block jb - 1 of U^-1 (that block of U is final since the last barrier)
+			const int d0 = c0 - 16;
+			double z[16];
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				z[i] = i == lane ? 1.0 : 0.0;
+			tq_subst16<4>(z, Wm + d0 * TQ_DP + d0, 1, TQ_DP, pinvs + d0, true);
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				if (i >= lane)
+					UL[(d0 + lane) * TQ_DP + d0 + i] = z[i];
 		}
 		__syncthreads();
 		if (s_fail) {
