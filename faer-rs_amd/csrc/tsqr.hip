@@ -310,17 +310,18 @@ __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// panel: everything 64 x 64, fp64, one workgroup of 256 threads.
-//
-// Two right-looking eliminations of 64 steps each on REGISTER-resident rows (tq_a_block / tq_b_block below):
-//   A. Cholesky of G extended by the rows of A1 and of the identity: the same column operations turn G into L
-//      (R~ = L^T), A1 into Q1~ = A1 R~^-1 and I into R~^-1 -- no separate triangular solves.
-//   B. the sign-choosing LU of I - Q1~ S on its linear part W (column j of I - W S is e_j - s_j W_j), extended by identity
-//      COLUMNS (row operations applied to I give V1^-1) and identity ROWS (their multipliers are the rows of U^-1).
-// History (profiles/r03_qr_panel_phases.txt): barrier-separated loops over LDS-resident matrices plus three column-parallel
-// substitutions on 64 threads: 314 us per panel (1.25 of the 3.4 ms of a 5e5 x 256 factorization); rows in registers with one
-// workgroup barrier per column: 267 us (2 750 / 5 900 cycles per column in A / B: six wavefronts of dependent fp64
-// instructions between two barriers); one wavefront per kind of row with v_readlane broadcasts: see tq_a_block.
+// panel: everything 64 x 64, fp64, one workgroup of 256 threads (four wavefronts), blocked by 16 columns:
+//   A1. Cholesky G = L L^T (R~ = L^T): diagonal block + the rows below it in wavefront 0 (tq_chol16, tq_subst16, which also
+//       yields the diagonal block of L^-1 in its spare lanes), trailing update on the fp64 matrix cores;
+//   A2. the rest of R~^-1 = L^-T block diagonal by block diagonal (tq_trinv_levels);   A3. Q1~ = A1 R~^-1 (products);
+//   B1. the sign-choosing LU of I - Q1~ S = V1 U on its linear part W (column j of I - W S is e_j - s_j W_j): tq_lu16 on the
+//       64 x 16 block column, U formed as soon as the block's signs are known, the 16 rows of U right of the block and the
+//       diagonal block of V1^-1 by substitution, the Schur complement on the matrix cores; wavefront 1 inverts the
+//       diagonal block of U one step behind;
+//   B2. the rest of U^-1 and V1^-1 (tq_trinv_levels);   then the reference's rank test, the condition guard, the outputs.
+// History (profiles/r03_qr_panel_phases.txt): barrier-separated loops over LDS-resident matrices: 314 us per panel (1.25 of
+// the 3.4 ms of a 5e5 x 256 factorization at the time); every row in registers, one wavefront per kind of row, one workgroup
+// barrier per 4 columns: 146 us; this version ~110 us.
 // ------------------------------------------------------------------------------------------------
 struct TqPanelArgs {
 	float *A;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 		return;
 	const int tid = threadIdx.x, w = a.w;
 	const int r = tid & 63;
-	const int kind = __builtin_amdgcn_readfirstlane(tid >> 6); // wavefront = kind of row (3: only the cooperative phases)
+	const int kind = __builtin_amdgcn_readfirstlane(tid >> 6); // wavefront index, as a scalar
 	TQ_STAMP(0);
 	if (tid == 0)
 		s_fail = 0;
