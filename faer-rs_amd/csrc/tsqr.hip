@@ -24,7 +24,7 @@
 //
 // Accuracy: R comes from an fp64 Cholesky factor of an exactly accumulated Gram matrix: relative error
 // ~ cond(panel)^2 * 2^-53, i.e. below fp32 rounding for cond(panel) < ~1e4 (measured on the CPU prototype
-// tools/proto_tsqr.py: closer to an fp64 Householder QR than the fp32 Householder QR is).  V = P M and D = R^-T C
+// tests/diag/proto_tsqr.py: closer to an fp64 Householder QR than the fp32 Householder QR is).  V = P M and D = R^-T C
 // amplify fp32 rounding by cond(panel), so the panel kernel REFUSES a panel whose Frobenius condition estimate exceeds
 // TQ_COND_MAX, whose updated column is (numerically) zero below the diagonal (the reference's tau = +inf case) or whose
 // column fails the reference's rank test (factor.rs:52-64, evaluated from R): nothing of that panel has been written
@@ -1346,7 +1346,7 @@ template <bool VEC> __global__ __launch_bounds__(256, 1) void tq_update_kernel(c
 // later reflector changes it by  -(V_k^T V_j) Z_j = -T_kj Z_j.  With V_l = (A~_l - [R_l; 0]) M_l below row c_l and zero above:
 //   T_kl = V_k^T V_l = ( B_l - V_k[c_k : c_l + w_l, :]^T R[c_k : c_l + w_l, cols of l] ) M_l,
 //   B = V_k^T X over all rows >= c_k:  B := -T_k Z_k after step k,  B[:, cols > l] -= T_kl Z_l[:, cols > l] after step l.
-// (checked against the Gram matrix of the stored V in tools/proto_tsqr.py: 0.1 eps.)  One workgroup per panel k, the
+// (checked against the Gram matrix of the stored V in tests/diag/proto_tsqr.py: 0.1 eps.)  One workgroup per panel k, the
 // blocks l = k + 1, ... of its block of Q_coeff in sequence; 64 x 64 x 64 products on the fp64 matrix cores.
 // The first version computed these blocks as Gram products over V: three more passes, 0.46 of 3.4 ms.
 // ------------------------------------------------------------------------------------------------

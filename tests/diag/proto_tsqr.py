@@ -5,14 +5,14 @@ Checks, against the oracle's Householder QR (test infrastructure), that
   R = S R~, M = -(U R)^-1, V = (P - [R; 0]) M, T = V1^T U^-1,
   trailing: D = R^-T (P^T X) (new top rows), Y = R^-1 (V1 U)^-1 (D - X_top), X' = X - P Y below the top block
 reproduce faer's (V, T, R) (householder.rs:59-107, qr/no_pivoting/factor.rs:137-256) up to rounding.
-Run: python tools/proto_tsqr.py
+Run: python tests/diag/proto_tsqr.py
 """
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle  # noqa: E402
 
 PW = 64

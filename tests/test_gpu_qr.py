@@ -145,7 +145,7 @@ def thin_q(F, dqr, dh, m, n):
 def _tall_vs_oracle(oracle, F, a, bs, lead=None):
     """one-pass path (csrc/tsqr.hip) against the oracle's Householder QR: R within 64 eps max|R|, V within 16 eps
     (its entries are O(1 / sqrt(m))), T within 64 eps max|T| -- the differences measured on the CPU prototype
-    (tools/proto_tsqr.py) are 1-4 eps; the generic bound 64 max(m, n) eps would be ~1 here and say nothing"""
+    (tests/diag/proto_tsqr.py) are 1-4 eps; the generic bound 64 max(m, n) eps would be ~1 here and say nothing"""
     import torch
 
     m, n = a.shape

@@ -1,5 +1,5 @@
 """CPU check of the algebra of the one-pass tall-skinny QR (csrc/tsqr.hip) through its numpy prototype
-(tools/proto_tsqr.py): Gram matrix -> Cholesky -> sign-choosing LU -> Householder vectors / T blocks reproduce the
+(tests/diag/proto_tsqr.py): Gram matrix -> Cholesky -> sign-choosing LU -> Householder vectors / T blocks reproduce the
 oracle's Householder QR (faer qr/no_pivoting/factor.rs:137-256, householder.rs:59-107), including the cross-panel blocks
 of T computed from small matrices only.  Test infrastructure: nothing here is on the product path."""
 import importlib.util
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle  # noqa: E402
 
-_spec = importlib.util.spec_from_file_location("proto_tsqr", os.path.join(ROOT, "tools", "proto_tsqr.py"))
+_spec = importlib.util.spec_from_file_location("proto_tsqr", os.path.join(ROOT, "tests", "diag", "proto_tsqr.py"))
 proto = importlib.util.module_from_spec(_spec)
 _argv = sys.argv
 sys.argv = ["proto_tsqr", "--import-only"]  # (the module runs its demo only without arguments / with "algebraic")
