@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(256) void tq_top_kernel(float *A, long ld, int r0, 
 __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 {
 	__shared__ double n1[64 * TQ_DP], n3[64 * TQ_DP], mm[64 * TQ_DP];
-	__shared__ double v[64 * 17];
+	__shared__ double v[64 * 17], v2[64 * 17];
 	__shared__ double sred[256];
 	if (tq_skip(a.stat, a.r0))
 		return;
@@ -1129,6 +1129,9 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 	const int bl = tid & 15, ig = tid >> 4; // column, row group: rows ig, ig + 16, ig + 32, ig + 48
 	const int b = blockIdx.x * 16 + bl;
 	const bool colok = b < a.t;
+	// (the loops over the four rows of a thread stay rolled and hand their results on through LDS: the kernel runs ~20 us,
+	// a third of it was the first pass through 7 KB of unrolled code)
+#pragma unroll 1
 	for (int u = 0; u < 4; ++u) {
 		const int i = ig + 16 * u;
 		double c = 0.0;
@@ -1138,28 +1141,24 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 		v[i * 17 + bl] = c;
 	}
 	__syncthreads();
-	double d[4], e4[4];
-#pragma unroll
+	double dsq = 0.0;
+#pragma unroll 1
 	for (int u = 0; u < 4; ++u) {
 		const int i = ig + 16 * u;
 		double acc = 0.0;
 		for (int l = 0; l <= i; ++l)
 			acc += n1[i * TQ_DP + l] * v[l * 17 + bl];
-		d[u] = acc;
+		dsq += acc * acc;
 		float *xp = a.A + (long) (a.cx + b) * a.ld + a.r0 + i;
 		double xt = 0.0;
 		if (colok && i < a.w) {
 			xt = (double) *xp;
 			*xp = (float) acc;
 		}
-		e4[u] = acc - xt;
+		v2[i * 17 + bl] = acc - xt; // E = D - X_top
 	}
-	__syncthreads();
-#pragma unroll
-	for (int u = 0; u < 4; ++u)
-		v[(ig + 16 * u) * 17 + bl] = e4[u];
 	// column norms of the R rows just produced (rank test of the later panels)
-	sred[tid] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+	sred[tid] = dsq;
 	__syncthreads();
 	if (ig == 0 && colok) {
 		double s = 0.0;
@@ -1168,23 +1167,18 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 		a.abv[a.cx + b] += s;
 	}
 	// zn = V1^-1 (D - X_top) = -Z, then  -Y = M zn  (Y = R^-1 U^-1 V1^-1 (D - X_top), M = -(U R)^-1 upper triangular)
-	double zn[4];
-#pragma unroll
+#pragma unroll 1
 	for (int u = 0; u < 4; ++u) {
 		const int k = ig + 16 * u;
 		double zz = 0.0;
 		for (int l = 0; l <= k; ++l)
-			zz += n3[k * TQ_DP + l] * v[l * 17 + bl];
-		zn[u] = zz;
+			zz += n3[k * TQ_DP + l] * v2[l * 17 + bl];
+		v[k * 17 + bl] = zz; // (every read of the C sums in v is behind the barrier above)
 		if (colok)
 			a.Z[(long) k * a.ldz + a.cx + b] = -zz;
 	}
-	__syncthreads(); // every read of D - X_top is done
-#pragma unroll
-	for (int u = 0; u < 4; ++u)
-		v[(ig + 16 * u) * 17 + bl] = zn[u];
 	__syncthreads();
-#pragma unroll
+#pragma unroll 1
 	for (int u = 0; u < 4; ++u) {
 		const int k = ig + 16 * u;
 		double acc = 0.0;
