@@ -246,15 +246,19 @@ __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const 
 	const int g = blockIdx.y;
 	const int ng = want_g ? 4096 : 0, nc = 64 * tp, ns = want_sq ? 256 : 0;
 	if (blockIdx.x * 256 < ng) { // (4096 = 16 x 256: a workgroup is all G or not at all)
-		double s0 = 0, s1 = 0;
+		// four independent sums (fixed assignment of the partials to them): eight loads in flight instead of two -- the loop is
+		// a chain of memory round trips
+		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 		int b = g;
-		for (; b + TQ_NG < nb; b += 2 * TQ_NG) {
+		for (; b + 3 * TQ_NG < nb; b += 4 * TQ_NG) {
 			s0 += Gp[(long) b * 4096 + e];
 			s1 += Gp[(long) (b + TQ_NG) * 4096 + e];
+			s2 += Gp[(long) (b + 2 * TQ_NG) * 4096 + e];
+			s3 += Gp[(long) (b + 3 * TQ_NG) * 4096 + e];
 		}
-		if (b < nb)
+		for (; b < nb; b += TQ_NG)
 			s0 += Gp[(long) b * 4096 + e];
-		G[(long) g * 4096 + e] = s0 + s1;
+		G[(long) g * 4096 + e] = (s0 + s1) + (s2 + s3);
 		// The slices of G are added up here as well, by whichever of the TQ_NG workgroups of these 256 entries finishes last
 		// (fixed order of the slices): the panel kernel -- ONE workgroup -- then reads 32 KB instead of 256 KB, which took
 		// it 35 000 cycles.  The counters return to zero by themselves.
@@ -279,27 +283,33 @@ __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const 
 		return;
 	}
 	if (e < ng) {
-		double s0 = 0, s1 = 0;
+		// four independent sums (fixed assignment of the partials to them): eight loads in flight instead of two -- the loop is
+		// a chain of memory round trips
+		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 		int b = g;
-		for (; b + TQ_NG < nb; b += 2 * TQ_NG) {
+		for (; b + 3 * TQ_NG < nb; b += 4 * TQ_NG) {
 			s0 += Gp[(long) b * 4096 + e];
 			s1 += Gp[(long) (b + TQ_NG) * 4096 + e];
+			s2 += Gp[(long) (b + 2 * TQ_NG) * 4096 + e];
+			s3 += Gp[(long) (b + 3 * TQ_NG) * 4096 + e];
 		}
-		if (b < nb)
+		for (; b < nb; b += TQ_NG)
 			s0 += Gp[(long) b * 4096 + e];
-		G[(long) g * 4096 + e] = s0 + s1;
+		G[(long) g * 4096 + e] = (s0 + s1) + (s2 + s3);
 	} else if (e < ng + nc) {
 		const int idx = e - ng;
-		double s0 = 0, s1 = 0;
+		double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 		int b = g;
-		for (; b + TQ_NG < nb; b += 2 * TQ_NG) {
+		for (; b + 3 * TQ_NG < nb; b += 4 * TQ_NG) {
 			s0 += (double) Cp[(long) b * nc + idx];
 			s1 += (double) Cp[(long) (b + TQ_NG) * nc + idx];
+			s2 += (double) Cp[(long) (b + 2 * TQ_NG) * nc + idx];
+			s3 += (double) Cp[(long) (b + 3 * TQ_NG) * nc + idx];
 		}
-		if (b < nb)
+		for (; b < nb; b += TQ_NG)
 			s0 += (double) Cp[(long) b * nc + idx];
 		const int arow = idx / tp, bcol = idx - arow * tp;
-		C[((long) g * 64 + arow) * ldc + coff + bcol] = s0 + s1;
+		C[((long) g * 64 + arow) * ldc + coff + bcol] = (s0 + s1) + (s2 + s3);
 	} else if (e < ng + nc + ns) {
 		const int idx = e - ng - nc;
 		double s0 = 0;
