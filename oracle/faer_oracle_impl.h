@@ -1337,9 +1337,9 @@ long FN(oracle_bidiag_in_place)(T *a, long m, long n, long rs, long cs, T *hl, l
 
 /* ------------------------------------------------- Hessenberg reduction (evd) */
 /* evd/hessenberg.rs:230-408 (hessenberg_rearranged_unblocked, Par::Seq; fused op :149-193), real scalars.  The reference
- * runs this variant for n * n < 65536 and hessenberg_gqvdg_blocked (:568-736) above: the same Householder reflectors of
- * the same columns, applied in another order of operations -- equal up to rounding, and the reference's own tests pin
- * both variants by the same property (:740-900).
+ * runs this variant for n * n < 65536 and hessenberg_gqvdg_blocked (:568-736, restated further down) above: the same
+ * Householder reflectors of the same columns, applied in another order of operations -- equal up to rounding, and the
+ * reference's own tests pin both variants by the same property (:740-900).
  * a: n x n -> upper Hessenberg H (a = Q H Q^H) on and above the subdiagonal, the essential parts of the reflectors below
  * it; h: bs x (n - 1) block Householder factors of A.submatrix(1, 0, n - 1, n - 1). */
 long FN(oracle_hessenberg_in_place)(T *a, long n, long rs, long cs, T *h, long bs, long hrs, long hcs)
@@ -1447,6 +1447,110 @@ long FN(oracle_hessenberg_in_place)(T *a, long n, long rs, long cs, T *h, long b
 }
 
 /* --------------------------------------------------------- exported shims */
+/* evd/hessenberg.rs:409-548 (hessenberg_gqvdg_unblocked): one block of b reflectors of the n x n matrix A (the caller's
+ * trailing submatrix), left-looking -- column k is brought up to date with the k reflectors before it from both sides, then
+ * its reflector is made; Z[:, k] = A[:, k+1:] u_k and the column k of the block's T factor come out of the same step.
+ * While the block runs every reflector's head is 1 in memory; the subdiagonal entries are kept in beta. */
+static void FN(hess_gqvdg_unblocked)(FN(mat) A, FN(mat) Z, FN(mat) H, T *beta)
+{
+	long n = A.nrows, b = H.nrows;
+	T *xbuf = (T *)calloc((size_t)(n > 0 ? n : 1), sizeof(T));
+	for (long k = 0; k < b; k++) {
+		FN(mat) x0 = {xbuf, k, 1, 1, k > 0 ? k : 1};
+		FN(mat) T00 = FN(sub)(H, 0, 0, k, k);
+		FN(mat) U0 = FN(sub)(A, 0, 0, n, k);
+		FN(mat) A1 = FN(sub)(A, 0, k, n, 1), A2 = FN(sub)(A, 0, k + 1, n, n - k - 1);
+		FN(mat) Z0 = FN(sub)(Z, 0, 0, n, k), Z1 = FN(sub)(Z, 0, k, n, 1);
+		FN(mat) U00 = FN(sub)(U0, 0, 0, k, k), U10 = FN(sub)(U0, k, 0, 1, k), U20 = FN(sub)(U0, k + 1, 0, n - k - 1, k);
+		for (long i = 0; i < k; i++) /* :438 x0 = U10^H */
+			xbuf[i] = AT(U10, 0, i);
+		FN(trsm_upper)(T00, 0, x0);		 /* :439-443 */
+		FN(gemm)(A1, 1, Z0, x0, (T)-1);		 /* :444-451 A1 -= Z0 x0 */
+		FN(mat) A01 = FN(sub)(A1, 0, 0, k, 1), A21 = FN(sub)(A1, k + 1, 0, n - k - 1, 1);
+		T *A11 = &AT(A1, k, 0);
+		/* :455-476 x0 = U00^H (strict upper) A01 + A11 conj(U10^T) + U20^H A21 */
+		FN(matmul_triangular)(x0, 0, 0, FN(tr)(U00), 4, A01, 0, (T)1);
+		for (long i = 0; i < k; i++)
+			xbuf[i] += (*A11) * AT(U10, 0, i);
+		FN(gemm)(x0, 1, FN(tr)(U20), A21, (T)1);
+		FN(trsm_lower)(FN(tr)(T00), 0, x0);	 /* :478-484 x0 <- T00^-H x0 */
+		/* :485-505 */
+		FN(matmul_triangular)(A01, 0, 1, U00, 3, x0, 0, (T)-1);
+		*A11 -= FN(dot)(&AT(U10, 0, 0), U10.cs, xbuf, 1, k);
+		FN(gemm)(A21, 1, U20, x0, (T)-1);
+		T *t11 = &AT(H, k, k);
+		if (k + 1 < n) { /* :506-513 */
+			T *head = &AT(A21, 0, 0);
+			FN(hinfo) hi = FN(make_householder)(head, &AT(A21, 1, 0), A21.rs, &AT(A21, 1, 0), A21.rs, n - k - 2);
+			beta[k] = *head;
+			*head = (T)1;
+			*t11 = hi.tau;
+		} else {
+			*t11 = (T)INFINITY;
+		}
+		FN(gemm)(Z1, 0, A2, A21, (T)1);				      /* :517-524 Z1 = A2 A21 */
+		FN(gemm)(FN(sub)(H, 0, k, k, 1), 0, FN(tr)(U20), A21, (T)1); /* :525-532 T01 = U20^H A21 */
+	}
+	free(xbuf);
+}
+
+/* evd/hessenberg.rs:568-736 (hessenberg_gqvdg_blocked): the variant the reference runs for n * n >= blocking_threshold
+ * (256 * 256 by default, :21).  Per block of b = h.nrows columns: the block's reflectors and T factor (above), then the
+ * block reflector applied from the right to the rows above the block (X0) and -- through Z = A U -- to the rows of the
+ * block, and from the left to the columns right of the block.  a, h as in oracle_hessenberg_in_place. */
+long FN(oracle_hessenberg_blocked_in_place)(T *a, long n, long rs, long cs, T *h, long b, long hrs, long hcs)
+{
+	if (n == 0)
+		return 0;
+	FN(mat) A = {a, n, n, rs, cs};
+	FN(mat) H = {h, b, n - 1, hrs, hcs};
+	T *zbuf = (T *)calloc((size_t)n * (size_t)b, sizeof(T)), *xb = (T *)calloc((size_t)n * (size_t)b, sizeof(T));
+	T *beta = (T *)calloc((size_t)b, sizeof(T));
+	FN(mat) Z = {zbuf, n, b, 1, n};
+	long j = 0;
+	while (j < n) {
+		long bs = b < n - j ? b : n - j;
+		long bu = bs < n - j - 1 ? bs : n - j - 1; /* bs_u */
+		FN(mat) T1 = FN(sub)(H, 0, j, bu, bu);
+		FN(hess_gqvdg_unblocked)(FN(sub)(A, j, j, n - j, n - j), FN(sub)(Z, j, 0, n - j, bs), T1, beta);
+		{
+			long r2 = n - j - bu; /* rows / columns after the block */
+			FN(mat) X = {xb, n, bu, 1, n};
+			FN(mat) X0 = FN(sub)(X, 0, 0, j, bu), X2 = FN(sub)(X, j + bu, 0, r2, bu);
+			FN(mat) Z1 = FN(sub)(Z, j, 0, bu, bu), Z2 = FN(sub)(Z, j + bu, 0, r2, bu);
+			FN(mat) A01 = FN(sub)(A, 0, j, j, bu), A02 = FN(sub)(A, 0, j + bu, j, r2);
+			FN(mat) U1 = FN(sub)(A, j, j, bu, bu), A12 = FN(sub)(A, j, j + bu, bu, r2);
+			FN(mat) U2 = FN(sub)(A, j + bu, j, r2, bu), A22 = FN(sub)(A, j + bu, j + bu, r2, r2);
+			/* :610-649 rows above the block: X0 = [A01 A02] [U1; U2] T1^-1, [A01 A02] -= X0 [U1; U2]^H */
+			FN(matmul_triangular)(X0, 0, 0, A01, 0, U1, 3, (T)1);
+			FN(gemm)(X0, 1, A02, U2, (T)1);
+			FN(trsm_lower)(FN(tr)(T1), 0, FN(tr)(X0));
+			FN(matmul_triangular)(A01, 0, 1, X0, 0, FN(tr)(U1), 4, (T)-1);
+			FN(gemm)(A02, 1, X0, FN(tr)(U2), (T)-1);
+			/* :650-675 rows of the block and below: Z <- Z T1^-1, [A12; A22] -= Z U2^H */
+			FN(trsm_lower)(FN(tr)(T1), 0, FN(tr)(Z1));
+			FN(trsm_lower)(FN(tr)(T1), 0, FN(tr)(Z2));
+			FN(gemm)(A12, 1, Z1, FN(tr)(U2), (T)-1);
+			FN(gemm)(A22, 1, Z2, FN(tr)(U2), (T)-1);
+			/* :676-723 from the left: X = T1^-H [U1; U2]^H [A12; A22], [A12; A22] -= [U1; U2] X */
+			FN(mat) Xt = FN(tr)(X2);
+			FN(matmul_triangular)(Xt, 0, 0, FN(tr)(U1), 4, A12, 0, (T)1);
+			FN(gemm)(Xt, 1, FN(tr)(U2), A22, (T)1);
+			FN(trsm_lower)(FN(tr)(T1), 0, Xt);
+			FN(matmul_triangular)(A12, 0, 1, U1, 3, Xt, 0, (T)-1);
+			FN(gemm)(A22, 1, U2, Xt, (T)-1);
+		}
+		for (long k = 0; k < bs; k++) /* :725-733 the subdiagonal back in place of the reflector heads */
+			if (k + 1 < n - j)
+				AT(A, j + k + 1, j + k) = beta[k];
+		j += bs;
+	}
+	free(zbuf);
+	free(xb);
+	free(beta);
+	return 0;
+}
+
 void FN(oracle_matmul)(T *c, long m, long n, long crs, long ccs, int accum_add, const T *a, long k, long ars,
 		       long acs, const T *b, long brs, long bcs, T alpha)
 {

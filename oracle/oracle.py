@@ -191,6 +191,22 @@ def hessenberg_in_place(a, h):
     return a, h
 
 
+def hessenberg_blocked_in_place(a, h):
+    """evd/hessenberg.rs:568-736 (hessenberg_gqvdg_blocked + hessenberg_gqvdg_unblocked :409-548): the variant the
+    reference runs for n * n >= blocking_threshold; same arguments and output layout as hessenberg_in_place"""
+    suf, _ = _suf(a)
+    n = a.shape[0]
+    assert a.shape == (n, n) and h.shape[1] == max(n - 1, 0) and h.dtype == a.dtype
+    getattr(lib(), f"oracle_hessenberg_blocked_in_place_{suf}")(_p(a), C.c_long(n), *_st(a), _p(h), C.c_long(h.shape[0]), *_st(h))
+    return a, h
+
+
+def hessenberg_reference_in_place(a, h, blocking_threshold=256 * 256):
+    """evd/hessenberg.rs:549-567: the dispatch of hessenberg_in_place (HessenbergParams::auto, :17-24)"""
+    n = a.shape[0]
+    return hessenberg_in_place(a, h) if n * n < blocking_threshold else hessenberg_blocked_in_place(a, h)
+
+
 def bidiag_in_place(a, hl, hr):
     """svd/bidiag.rs:47: a -> upper bidiagonal B on the diagonal / superdiagonal (a = U B V^H), left reflectors
     below the diagonal (block factors hl: bl x n), right reflectors right of the superdiagonal (hr: br x (n - 1))"""

@@ -11,14 +11,12 @@ from test_tridiag_oracle import qh_a_q
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("n,b", [(2, 1), (3, 3), (4, 3), (8, 3), (16, 3), (17, 1), (33, 8), (50, 8), (129, 32), (300, 16), (700, 32)])
-def test_hessenberg_vs_oracle(n, b, dtype):
+def _vs_oracle(n, b, dtype, oracle_fn):
     F = init_gpu()
     rng = np.random.default_rng(n * 5 + b)
     a = np.asarray(rng.standard_normal((n, n)), dtype=dtype, order="F")
     vo, ho = a.copy(order="F"), np.zeros((b, n - 1), dtype=dtype, order="F")
-    O.hessenberg_in_place(vo, ho)
+    oracle_fn(vo, ho)
     vd, hd = to_dev(a), to_dev(np.zeros((b, n - 1), dtype=dtype, order="F"))
     F.hessenberg_in_place(vd, hd)
     v, h = to_host(vd), to_host(hd)
@@ -38,6 +36,22 @@ def test_hessenberg_vs_oracle(n, b, dtype):
         cj = cond[(j // b) * b:j + 1].max()
         fj = fin[:, j]
         assert np.abs(h[fj, j] - ho[fj, j]).max(initial=0.0) <= 64 * n * eps * cj, j
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,b", [(2, 1), (3, 3), (4, 3), (8, 3), (16, 3), (17, 1), (33, 8), (50, 8), (129, 32), (300, 16), (700, 32)])
+def test_hessenberg_vs_oracle(n, b, dtype):
+    """against the restatement of hessenberg_rearranged_unblocked (evd/hessenberg.rs:230-408) at every size"""
+    _vs_oracle(n, b, dtype, O.hessenberg_in_place)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,b", [(256, 32), (300, 16), (515, 32), (700, 8)])
+def test_hessenberg_vs_the_variant_the_reference_runs(n, b, dtype):
+    """n * n >= 256 * 256: the reference runs hessenberg_gqvdg_blocked (evd/hessenberg.rs:562-566, 568-736); the oracle
+    restates that variant too (oracle_hessenberg_blocked_in_place) and the GPU path -- which runs the level-2 algorithm at
+    every size -- is held to the same per-reflector bounds against it"""
+    _vs_oracle(n, b, dtype, O.hessenberg_reference_in_place)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
