@@ -1391,7 +1391,11 @@ size_t faer_hip_debug_llt_plan(size_t n, size_t tail_rows, size_t nb2, size_t *s
 		starts[i] = (size_t) J[i];
 	return J.size();
 }
-void faer_hip_debug_dump_timing(void) { trsm_dump_timing(); }
+void faer_hip_debug_dump_timing(void)
+{
+	trsm_dump_timing();
+	lu_dump_timing();
+}
 
 void faer_hip_tridiag_in_place_f64(FaerMatMut A, FaerMatMut householder) { tridiag_api<double>(A, householder); }
 void faer_hip_tridiag_in_place_f32(FaerMatMut A, FaerMatMut householder) { tridiag_api<float>(A, householder); }

@@ -31,15 +31,12 @@
 #include "common.h"
 #include "lds_blocks.h"
 #include "xwg.h"
+#include "lu_wpanel.h"
 
 namespace fh {
 
 constexpr int LU_W = 64; // leaf width of the recursion
 
-static __device__ __forceinline__ bool better(double av, int ar, double bv, int br)
-{
-	return av > bv || (av == bv && ar < br);
-}
 // ------------------------------------------------------------------------------------------------
 // Register-resident cooperative panel kernel.  Phase timing of its LDS-resident predecessor
 // (profiles/r01_lu_panel_phase_timing.txt) showed that only ~1.6 us of ~6.4 us per column was the
@@ -79,36 +76,6 @@ template <typename T, int W> struct Panel2Shared {
 	int p;	   // winning row (global)
 	int flag;
 };
-
-// Wave-wide arg-max of (|a|, row) with the smaller row winning ties, on the DPP network instead of LDS-crossbar
-// shuffles: quad_perm + row_half_mirror + row_mirror reduce each row of 16 lanes, row_bcast:15 / row_bcast:31
-// carry the partial results across the four rows, lane 63 ends up with the wave result and broadcasts it.
-// (six data-parallel steps of ~7 VALU instructions each instead of eighteen ds_bpermute round trips.)
-static __device__ __forceinline__ void wave_argmax2(double &v, int &r)
-{
-#define FH_DPP_STEP(ctrl, rmask)                                                                                         \
-	do {                                                                                                             \
-		const int lo_ = __double2loint(v), hi_ = __double2hiint(v);                                              \
-		const int olo_ = __builtin_amdgcn_update_dpp(lo_, lo_, ctrl, rmask, 0xf, false);                         \
-		const int ohi_ = __builtin_amdgcn_update_dpp(hi_, hi_, ctrl, rmask, 0xf, false);                         \
-		const int or_ = __builtin_amdgcn_update_dpp(r, r, ctrl, rmask, 0xf, false);                              \
-		const double ov_ = __hiloint2double(ohi_, olo_);                                                         \
-		if (better(ov_, or_, v, r)) {                                                                            \
-			v = ov_;                                                                                         \
-			r = or_;                                                                                         \
-		}                                                                                                        \
-	} while (0)
-	FH_DPP_STEP(0xB1, 0xf);	 // quad_perm [1,0,3,2]
-	FH_DPP_STEP(0x4E, 0xf);	 // quad_perm [2,3,0,1]
-	FH_DPP_STEP(0x141, 0xf); // row_half_mirror
-	FH_DPP_STEP(0x140, 0xf); // row_mirror: every lane of a row now holds the row's best
-	FH_DPP_STEP(0x142, 0xa); // row_bcast:15 into rows 1 and 3
-	FH_DPP_STEP(0x143, 0xc); // row_bcast:31 into rows 2 and 3
-#undef FH_DPP_STEP
-	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-	v = __hiloint2double(hi, lo);
-	r = __builtin_amdgcn_readlane(r, 63);
-}
 
 static __device__ __forceinline__ double gran_pair_to_double(xwg_u64 h, xwg_u64 l)
 {
@@ -672,6 +639,7 @@ template <typename T> struct LuWork {
 	xwg_u64 *gran;	    // [LU2_NSLOT][LU2_GMAX][LU2_GSLOT] tagged granules (zeroed once per factorization)
 	xwg_u64 *gran_diag; // [LU2_NSLOT][2 * LU_W]
 	xwg_u64 epoch_base; // epochs consumed by earlier leaf launches of this factorization
+	unsigned char *wws = nullptr; // LW_WS_BYTES of getrf_wpanel_kernel's exchange records (zeroed once per factorization)
 	int *status;
 	hipEvent_t after_leaf = nullptr; // look-ahead: the stream waits for this event right after the next leaf launch
 	bool general = false;		 // every leaf on the non-cooperative path (rerun after an exchange timeout, debug switch)
@@ -881,6 +849,41 @@ template <typename T, int W> static void launch_leaf(int G, hipStream_t s, const
 	hipLaunchKernelGGL((getrf_panel2_kernel<T, W, (sizeof(T) == 8 ? 64 : 128) / W>), dim3(G), dim3(LU2_NT), 0, s, a);
 }
 
+// A/B switch of the round (removed once the old kernel is only the fallback): FAER_HIP_LU_PANEL=2 keeps getrf_panel2_kernel
+static bool wpanel_enabled()
+{
+	static const bool on = !(getenv("FAER_HIP_LU_PANEL") && atoi(getenv("FAER_HIP_LU_PANEL")) == 2);
+	return on;
+}
+// timing build: 16 device words that receive the per-phase tick sums of the panel kernel (lu_dump_timing)
+static unsigned long long *g_lu_phase = nullptr;
+static unsigned long long *lu_phase_words()
+{
+#ifdef FH_LU_TIMING
+	if (!g_lu_phase) {
+		FH_HIP(hipMalloc(&g_lu_phase, 16 * sizeof(unsigned long long)));
+		FH_HIP(hipMemset(g_lu_phase, 0, 16 * sizeof(unsigned long long)));
+	}
+#endif
+	return g_lu_phase;
+}
+void lu_dump_timing()
+{
+#ifdef FH_LU_TIMING
+	if (!g_lu_phase)
+		return;
+	unsigned long long h[16];
+	FH_HIP(hipDeviceSynchronize());
+	FH_HIP(hipMemcpy(h, g_lu_phase, sizeof(h), hipMemcpyDeviceToHost));
+	FH_HIP(hipMemset(g_lu_phase, 0, sizeof(h)));
+	const double n = h[8] ? (double) h[8] : 1.0;
+	fprintf(stderr,
+		"wpanel phases (s_memtime ticks per column, wg 0 / wave 0, %llu columns): sweep %.0f | relabel+scale+col J+1 %.0f | candidate+combine+publish %.0f | "
+		"row record wait+correct %.0f | rank-1 update %.0f || per 8 columns: rotate %.0f\n",
+		h[8], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, 8.0 * h[5] / n);
+#endif
+}
+
 template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, LuWork<T> &wk)
 {
 	const idx_t m = P.nrows;
@@ -891,6 +894,40 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 		return;
 	}
 	FH_CHECK(w <= lw, "getrf leaf: panel too wide");
+	if (lw == LU_W && w <= m && wk.wws && wpanel_enabled()) {
+		// round-4 kernel (lu_wpanel.h): one exchange per column.  64 x RPT rows per wavefront; four wavefronts per workgroup
+		// (one per SIMD) while that many workgroups are resident, else eight
+		constexpr int RPT = sizeof(T) == 8 ? 1 : 2;
+		const int cap = resident_workgroups();
+		const int g4 = (int) ((m + 256 * RPT - 1) / (256 * RPT)), g8 = (int) ((m + 512 * RPT - 1) / (512 * RPT));
+		const bool four = g4 <= cap && g4 <= LW_GMAX;
+		if (four || g8 <= LW_GMAX) { // (g8 <= cap: that is what lw == LU_W says)
+			WPanelArgs<T> a;
+			a.P = P.p;
+			a.rs = P.rs;
+			a.cs = P.cs;
+			a.m = (int) m;
+			a.w = w;
+			a.piv = wk.piv + col0;
+			a.row_base = row_base;
+			a.ws = wk.wws;
+			a.epoch_base = (unsigned) wk.epoch_base;
+			a.status = wk.status;
+			a.phase = lu_phase_words();
+			hipStream_t s = ctx().stream;
+			if (four)
+				hipLaunchKernelGGL((getrf_wpanel_kernel<T, RPT, 4>), dim3(g4), dim3(256), 0, s, a);
+			else
+				hipLaunchKernelGGL((getrf_wpanel_kernel<T, RPT, 8>), dim3(g8), dim3(512), 0, s, a);
+			FH_HIP(hipGetLastError());
+			wk.epoch_base += (xwg_u64) (((w < (int) m ? w : (int) m) + 7) & ~7); // the kernel runs whole groups of 8 column steps
+			if (wk.after_leaf) {
+				stream_wait(s, wk.after_leaf);
+				wk.after_leaf = nullptr;
+			}
+			return;
+		}
+	}
 	while (lw / 2 >= w && lw > 8)
 		lw /= 2; // a narrower panel fits the narrower (taller) shape just as well: fewer workgroups to synchronise
 	const int R = leaf_rows_per_wg<T>(lw);
@@ -1129,7 +1166,10 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		const size_t gran_bytes = (size_t) LU2_NSLOT * LU2_GMAX * LU2_GSLOT * sizeof(xwg_u64), diag_bytes = (size_t) LU2_NSLOT * 2 * LU_WMAX * sizeof(xwg_u64);
 		Scratch granb(gran_bytes + diag_bytes);
 		Scratch misc(256);
+		Scratch wwsb(LW_WS_BYTES);
 		LuWork<T> wk;
+		wk.wws = wwsb.as<unsigned char>();
+		FH_HIP(hipMemsetAsync(wwsb.p, 0, LW_WS_BYTES, ctx().stream));
 		wk.piv = pivb.as<int>();
 		wk.gran = granb.as<xwg_u64>();
 		wk.gran_diag = wk.gran + (size_t) LU2_NSLOT * LU2_GMAX * LU2_GSLOT;
@@ -1226,7 +1266,10 @@ template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev, int *status_
 	// released on return while the kernels may still be queued: the pool hands a buffer back to the SAME stream only
 	Scratch granb(gran_bytes + diag_bytes);
 	Scratch misc(256);
+	Scratch wwsb(LW_WS_BYTES);
 	LuWork<T> wk;
+	wk.wws = wwsb.as<unsigned char>();
+	FH_HIP(hipMemsetAsync(wwsb.p, 0, LW_WS_BYTES, ctx().stream));
 	wk.piv = piv_dev;
 	wk.gran = granb.as<xwg_u64>();
 	wk.gran_diag = wk.gran + (size_t) LU2_NSLOT * LU2_GMAX * LU2_GSLOT;
