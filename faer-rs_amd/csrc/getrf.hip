@@ -878,9 +878,9 @@ void lu_dump_timing()
 	FH_HIP(hipMemset(g_lu_phase, 0, sizeof(h)));
 	const double n = h[8] ? (double) h[8] : 1.0;
 	fprintf(stderr,
-		"wpanel phases (s_memtime ticks per column, wg 0 / wave 0, %llu columns): sweep %.0f | relabel+scale+col J+1 %.0f | candidate+combine+publish %.0f | "
-		"row record wait+correct %.0f | rank-1 update %.0f || per 8 columns: rotate %.0f\n",
-		h[8], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, 8.0 * h[5] / n);
+		"wpanel phases (s_memtime ticks per column, wg 0 / wave 0, %llu columns): sweep %.0f | barrier+result %.0f | relabel+scale+col J+1 %.0f | candidate+combine+publish %.0f | "
+		"row record wait+correct %.0f | rank-1 update %.0f || per 8 columns: rotate %.0f || header sweeps checked per column %.2f\n",
+		h[8], h[0] / n, h[7] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, 8.0 * h[5] / n, h[6] / n);
 #endif
 }
 
@@ -901,7 +901,7 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 		const int cap = resident_workgroups();
 		const int g4 = (int) ((m + 256 * RPT - 1) / (256 * RPT)), g8 = (int) ((m + 512 * RPT - 1) / (512 * RPT));
 		const bool four = g4 <= cap && g4 <= LW_GMAX;
-		if (four || g8 <= LW_GMAX) { // (g8 <= cap: that is what lw == LU_W says)
+		if (four || g8 <= LW_GMAX) { // (g8 <= cap: that is what lw == LU_W says; more than LW_GMAX workgroups: the old kernel)
 			WPanelArgs<T> a;
 			a.P = P.p;
 			a.rs = P.rs;
@@ -916,9 +916,9 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 			a.phase = lu_phase_words();
 			hipStream_t s = ctx().stream;
 			if (four)
-				hipLaunchKernelGGL((getrf_wpanel_kernel<T, RPT, 4>), dim3(g4), dim3(256), 0, s, a);
+				hipLaunchKernelGGL((getrf_wpanel_kernel<T, RPT, 4, 2>), dim3(g4), dim3(256), 0, s, a);
 			else
-				hipLaunchKernelGGL((getrf_wpanel_kernel<T, RPT, 8>), dim3(g8), dim3(512), 0, s, a);
+				hipLaunchKernelGGL((getrf_wpanel_kernel<T, RPT, 8, 2>), dim3(g8), dim3(512), 0, s, a);
 			FH_HIP(hipGetLastError());
 			wk.epoch_base += (xwg_u64) (((w < (int) m ? w : (int) m) + 7) & ~7); // the kernel runs whole groups of 8 column steps
 			if (wk.after_leaf) {
@@ -1094,11 +1094,32 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		{
 			StreamScope sc(c.la_bulk);
 			stream_wait(c.la_bulk, ev_panel);
-			if (w2 > 0) {
-				// the next panel starts with a leaf on its first LU_W columns: release it as soon as those are up to
+			// Every solve U = L_kk^-1 A is a dependent chain of ~8 launches whose length does not depend on the number of columns
+			// (profiles/r04_lu_v4_timeline.txt: ~240 us per chain, three chains per step -- the first 64 columns of the next panel,
+			// its other 448, the rest -- were 20 of the bulk stream's 87 ms).  How the columns right of the panel are grouped:
+			//   mode 2 (while the bulk stream is the critical one: its trailing product takes longer than a panel): ONE chain of
+			//          interchanges + solve for all of them, then the product on the next panel's columns (-> released), then on
+			//          the rest;
+			//   mode 1 (afterwards, the panel chain is critical): the next panel's columns first (all 512: with the round-4 leaf
+			//          the old split "first 64, then 448" made the panel wait for the second chain), then the rest;
+			//   mode 0: the three chains of rounds 1-3 (A/B switch FAER_HIP_LU_CHAIN).
+			static const int chain_env = getenv("FAER_HIP_LU_CHAIN") ? atoi(getenv("FAER_HIP_LU_CHAIN")) : -1;
+			static const idx_t one_chain_rows = getenv("FAER_HIP_LU_CHAIN_ROWS") ? atol(getenv("FAER_HIP_LU_CHAIN_ROWS")) : 10240;
+			const int mode = chain_env >= 0 ? (chain_env == 3 ? (m - j1 >= one_chain_rows ? 2 : 1) : chain_env) : (m - j1 >= one_chain_rows ? 2 : 1);
+			if (w2 > 0 && mode == 2) {
+				swaps(k, j0, w, j1, n - j1);
+				MatV<T> U = A.sub(j0, j1, w, n - j1);
+				trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, U);
+				if (m > j1)
+					gemm_dev<T>(A.sub(j1, j1, m - j1, w2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), U.sub(0, 0, w, w2).c(), (T) -1);
+				ev_next = c.next_event();
+				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
+				if (j2 < n && m > j1)
+					gemm_dev<T>(A.sub(j1, j2, m - j1, n - j2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), U.sub(0, w2, w, n - j2).c(), (T) -1);
+			} else if (w2 > 0) {
+				// mode 0: the next panel starts with a leaf on its first LU_W columns: release it as soon as those are up to
 				// date, the other columns of the panel follow while that leaf runs
-				static const bool nosplit = getenv("FAER_HIP_LU_SPLIT") && atoi(getenv("FAER_HIP_LU_SPLIT")) == 0; // A/B switch
-				const idx_t wa = (w2 < LU_W || nosplit) ? w2 : (idx_t) LU_W;
+				const idx_t wa = (w2 < LU_W || mode == 1) ? w2 : (idx_t) LU_W;
 				update(k, j0, w, j1, wa);
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
@@ -1107,9 +1128,9 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 					ev_next2 = c.next_event();
 					FH_HIP(hipEventRecord(ev_next2, c.la_bulk));
 				}
+				if (j2 < n)
+					update(k, j0, w, j2, n - j2);
 			}
-			if (j2 < n)
-				update(k, j0, w, j2, n - j2);
 			// factor.rs:127-185: the panel's transpositions act on the columns to its left as well.  Nothing reads those
 			// columns again during the factorization, so the interchanges of `defer` consecutive panels are applied
 			// TOGETHER, as one composed row permutation per target block (one gather pass over the left part per group of

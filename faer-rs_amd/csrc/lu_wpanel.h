@@ -114,7 +114,7 @@ template <int STEPS> static __device__ __forceinline__ void lw_argmax(double v, 
 }
 
 constexpr int LW_W = 64;	    // leaf width = wavefront size: lane c <-> register position c of a published row
-constexpr int LW_GMAX = 256;	    // workgroups per panel
+constexpr int LW_GMAX = 32;	    // workgroups per panel = two rounds of a header sweep (taller panels: getrf_panel2_kernel)
 constexpr int LW_HDR_BYTES = 64;    // {label}, {a}, {s}, {l}: four 16-byte granule pairs
 constexpr int LW_ROW_BYTES = LW_W * 16;
 constexpr int LW_NSH = 2; // header slots (column parity)
@@ -141,6 +141,8 @@ template <typename T> struct WPanelArgs {
 template <int NW> struct WPanelShared {
 	double cv[2][NW]; // the wavefronts' candidates of the current column, slots alternate with the column parity
 	int lab[2][NW];
+	double res_a[2], res_s[2], res_l[2]; // what wavefront 0 found in the headers of the current column
+	int res_p[2], res_gw[2], res_flags[2];
 	double trans[NW][LW_W]; // per wavefront: the candidate row on its way from one lane's registers to 64 lanes
 };
 
@@ -185,58 +187,147 @@ static __device__ __forceinline__ void lw_store(lw_u32x4 q, __amdgpu_buffer_rsrc
 	} while (0)
 #endif
 
-// Sweep of the G headers of column J by one wavefront (lane t reads workgroups t, t + 64, ...): winner's label p,
-// workgroup gw and header values; false if nobody has a candidate (then there is no row record either).  A timeout sets `dead` (wave uniform): the kernel then runs to its end without waiting
-// for anything and without storing anything -- no early exits, the eight step bodies stay one straight line of code.
-static __device__ __forceinline__ bool lw_sweep(__amdgpu_buffer_rsrc_t hr, int G, unsigned tag, int J, int lane, bool &dead, int &p, int &gw, double &a,
-						double &s, double &l)
+// One sweep over the G <= 16 RND headers of a column as ONE wavefront reads it: lane 4 t + k holds piece k ({label}, {a},
+// {s}, {l}) of the records t, t + 16, ... -- 16 bytes per lane and round, four adjacent lanes per 64-byte record, so a round is
+// 16 full cache lines (a lane per record and four loads per lane asked for every line four times: with all 256 wavefronts of
+// a panel sweeping, three sweeps deep, the 2 KB of headers became a hot spot that slowed every memory access of the kernel --
+// profiles/r04_lu_panel_phases_v2_all_waves_poll_3_deep.txt).  Only wavefront 0 of a workgroup sweeps; the others execute the
+// SAME load instructions on one line of their own workgroup's record (`voff`) and never look at the result: with the number
+// of memory instructions per step fixed, the compiler's counted waits (s_waitcnt vmcnt(N)) let a sweep stay in flight across
+// the other waits of a step -- behind a wave-uniform branch every wait in its shadow became vmcnt(0), i.e. a full round trip
+// (profiles/r04_lu_panel_phases_v3_one_sweeper_branchy.txt).
+template <int RND> struct LwSweep { // (plain members, not an array: an indexed array inside the struct is kept in scratch memory)
+	lw_u32x4 r0, r1;
+};
+template <int RND> static __device__ __forceinline__ void lw_sweep_issue(LwSweep<RND> &w, __amdgpu_buffer_rsrc_t hr, int G, int J, unsigned voff)
 {
-	double bcv, ba, bs, bl;
-	int blab, bg;
-	for (int spin = 0;; ++spin) {
-		bool ok = true;
-		bcv = -1.0;
-		blab = INT_MAX;
-		ba = bs = bl = 0.0;
-		bg = 0;
-		for (int t = lane; t < G; t += 64) {
-			const unsigned voff = (unsigned) (t * LW_HDR_BYTES), soff = (unsigned) ((J & 1) * G * LW_HDR_BYTES);
-			const lw_u32x4 h0 = lw_load(hr, voff, soff), h1 = lw_load(hr, voff + 16, soff), h2 = lw_load(hr, voff + 32, soff),
-				       h3 = lw_load(hr, voff + 48, soff);
-			ok = ok && lw_ok(h0, tag) && lw_ok(h1, tag) && lw_ok(h2, tag) && lw_ok(h3, tag);
-			const int lb = (int) h0.y;
-			const double av = lw_unpack(h1), fa = fabs(av);
-			// a published candidate is a real one (|a| > 0) or the diagonal row of a zero / NaN-only column (factor.rs:35-43)
-			const double cv = lb == INT_MAX ? -1.0 : (fa > 0.0 ? fa : 0.0);
-			if (better(cv, lb, bcv, blab)) {
-				bcv = cv;
-				blab = lb;
-				ba = av;
-				bs = lw_unpack(h2);
-				bl = lw_unpack(h3);
-				bg = t;
+	const unsigned soff = (unsigned) ((J & 1) * G * LW_HDR_BYTES);
+	w.r0 = lw_load(hr, voff, soff);
+	w.r1 = lw_load(hr, voff + 1024u, soff);
+	static_assert(RND == 2, "two rounds of 16 records");
+}
+template <int RND> static __device__ __forceinline__ bool lw_sweep_ok(const LwSweep<RND> &w, unsigned tag, int G, int lane)
+{
+	const int t = lane >> 2;
+	bool ok = (t >= G || lw_ok(w.r0, tag)) && (t + 16 >= G || lw_ok(w.r1, tag));
+	return ok;
+}
+// "The old contents of this sweep are used here": placed right before a sweep's registers are re-issued, it keeps the register
+// allocator from handing them to something else while a stale re-issued load may still be in flight (the compiler then waits
+// for that load before the FIRST write to the register -- a full round trip right behind the successful check,
+// profiles/r04_lu_panel_phases_v3_one_sweeper_branchy.txt); here the old load has long returned and the wait is free.
+template <int RND> static __device__ __forceinline__ void lw_sweep_retire(const LwSweep<RND> &w)
+{
+	asm volatile("" ::"v"(w.r0), "v"(w.r1));
+}
+// value of quad lane Q (0..3) in every lane of the quad
+template <int Q> static __device__ __forceinline__ unsigned lw_quad(unsigned v)
+{
+	return (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, Q * 0x55, 0xf, 0xf, true);
+}
+
+// The sweep of column J, by wavefront 0 of every workgroup: winner's label p, workgroup gw and header values; false if nobody
+// has a candidate (then there is no row record either).  THREE sweeps are in flight when it starts -- A, B, C were issued by
+// the previous step behind its row-record wait, in the middle of and behind its rank-1 update -- so a header is seen a
+// fraction of a memory round trip after it lands instead of a whole one later.  A timeout sets `dead` (wave
+// uniform): the kernel then runs to its end without waiting for anything and without storing anything -- no early exits, the
+// eight step bodies stay one straight line of code.
+template <int RND>
+static __device__ __forceinline__ bool lw_sweep(__amdgpu_buffer_rsrc_t hr, int G, unsigned tag, int J, int lane, bool &dead, LwSweep<RND> &A,
+						LwSweep<RND> &B, LwSweep<RND> &C, int &p, int &gw, double &a, double &s, double &l
+#ifdef FH_LU_TIMING
+						,
+						unsigned long long &nsweeps
+#endif
+)
+{
+	const unsigned voff = (unsigned) (lane * 16);
+	// A, B, C are only ever written by the UNCONDITIONAL issues of lw_step: re-issued inside a branch here they would become
+	// phi values, and the register copies at the join READ -- i.e. wait for -- the sweeps that are still in flight
+	// (profiles/r04_lu_panel_phases_v3_one_sweeper_branchy.txt).  A sweep that comes back stale is simply dropped; if all three
+	// are stale (a slow workgroup), a plain load-check loop on its own register pair takes over.
+	// The sweep that succeeded is copied member by member inside its own branch: a select over A, B, C would read the two
+	// that are still in flight as well, and a struct assignment sends all of them to scratch memory.
+	lw_u32x4 q0, q1;
+#define FH_LW_TAKE(S)                                                                                                    \
+	do {                                                                                                             \
+		q0 = S.r0;                                                                                               \
+		q1 = S.r1;                                                                                               \
+		/* (opaque to the optimizer: it would merge the three copies into ONE load through a pointer phi, which */   \
+		/* keeps the sweeps in scratch memory) */                                                                  \
+		asm volatile("" : "+v"(q0), "+v"(q1));                                                                   \
+	} while (0)
+#ifdef FH_LU_TIMING
+	nsweeps += 1;
+#endif
+	if (dead || __all(lw_sweep_ok<RND>(A, tag, G, lane))) {
+		FH_LW_TAKE(A);
+	} else {
+#ifdef FH_LU_TIMING
+		nsweeps += 1;
+#endif
+		if (__all(lw_sweep_ok<RND>(B, tag, G, lane))) {
+			FH_LW_TAKE(B);
+		} else {
+#ifdef FH_LU_TIMING
+			nsweeps += 1;
+#endif
+			if (__all(lw_sweep_ok<RND>(C, tag, G, lane))) {
+				FH_LW_TAKE(C);
+			} else {
+				LwSweep<RND> S;
+				for (int spin = 0;; ++spin) {
+#ifdef FH_LU_TIMING
+					nsweeps += 1;
+#endif
+					lw_sweep_issue<RND>(S, hr, G, J, voff);
+					if (__all(lw_sweep_ok<RND>(S, tag, G, lane)))
+						break;
+					if (spin >= LW_SPIN_MAX) {
+						dead = true;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(1);
+				}
+				FH_LW_TAKE(S);
 			}
 		}
-		if (dead || __all(ok))
-			break;
-		if (spin >= LW_SPIN_MAX) {
-			dead = true;
-			break;
-		}
-		__builtin_amdgcn_s_sleep(1);
 	}
+#undef FH_LW_TAKE
+	// per quad: the best of its (up to RND) records; every lane keeps ITS piece of that record
+	double bcv = -1.0;
+	int blab = INT_MAX, bg = 0;
+	unsigned phi = 0u, plo = 0u;
+	const int t = lane >> 2;
+#define FH_LW_ROUND(q, off)                                                                                              \
+	if (t + off < G) {                                                                                               \
+		const int lb = (int) lw_quad<0>(q.y);                                                                    \
+		const double av = __hiloint2double((int) lw_quad<1>(q.y), (int) lw_quad<1>(q.w)), fa = fabs(av);         \
+		/* a published candidate is a real one (|a| > 0) or the diagonal row of a zero / NaN-only column (factor.rs:35-43) */ \
+		const double cv = lb == INT_MAX ? -1.0 : (fa > 0.0 ? fa : 0.0);                                          \
+		if (better(cv, lb, bcv, blab)) {                                                                         \
+			bcv = cv;                                                                                        \
+			blab = lb;                                                                                       \
+			bg = t + off;                                                                                    \
+			phi = q.y;                                                                                       \
+			plo = q.w;                                                                                       \
+		}                                                                                                        \
+	}
+	FH_LW_ROUND(q0, 0)
+	FH_LW_ROUND(q1, 16)
+#undef FH_LW_ROUND
 	double wv;
 	int wl;
 	lw_argmax<6>(bcv, blab, wv, wl);
 	// (no candidate at all: cannot happen for J < m, the row labelled J is always one; the padded steps J >= m keep the diagonal)
 	const bool any = wv >= 0.0;
 	const unsigned long long bal = (unsigned long long) __ballot(blab == wl && bcv == wv);
-	const int wlane = any && bal != 0ull ? __builtin_amdgcn_readfirstlane((int) __ffsll(bal) - 1) : 0;
+	const int qb = any && bal != 0ull ? (__builtin_amdgcn_readfirstlane((int) __ffsll(bal) - 1) & ~3) : 0;
 	p = any ? wl : J;
-	gw = any ? __builtin_amdgcn_readlane(bg, wlane) : 0;
-	a = lane_bcast(ba, wlane);
-	s = lane_bcast(bs, wlane);
-	l = lane_bcast(bl, wlane);
+	gw = any ? __builtin_amdgcn_readlane(bg, qb) : 0;
+	a = __hiloint2double(__builtin_amdgcn_readlane((int) phi, qb + 1), __builtin_amdgcn_readlane((int) plo, qb + 1));
+	s = __hiloint2double(__builtin_amdgcn_readlane((int) phi, qb + 2), __builtin_amdgcn_readlane((int) plo, qb + 2));
+	l = __hiloint2double(__builtin_amdgcn_readlane((int) phi, qb + 3), __builtin_amdgcn_readlane((int) plo, qb + 3));
 	return any;
 }
 
@@ -331,9 +422,10 @@ static __device__ __forceinline__ void lw_publish(const WPanelArgs<T> &a, __amdg
 
 // One column step (column J = 8 grp + JJ at register position JJ).  Steps J >= steps (a leaf narrower than a multiple of 8
 // columns) run like any other on the zero padding and store nothing.
-template <typename T, int RPT, int NW, int JJ>
+template <typename T, int RPT, int NW, int RND, int JJ>
 static __device__ __forceinline__ void lw_step(const WPanelArgs<T> &a, __amdgpu_buffer_rsrc_t hr, __amdgpu_buffer_rsrc_t rr, T (&x)[RPT][LW_W],
-					       int (&lab)[RPT], T &uprev, WPanelShared<NW> &sh, int grp, int G, int steps, int nsteps, bool &dead
+					       int (&lab)[RPT], T &uprev, WPanelShared<NW> &sh, int grp, int G, int steps, int nsteps, bool &dead, unsigned svoff,
+					       LwSweep<RND> &A, LwSweep<RND> &B, LwSweep<RND> &C
 #ifdef FH_LU_TIMING
 					       ,
 					       unsigned long long (&tk)[8], unsigned long long &t_last
@@ -345,11 +437,34 @@ static __device__ __forceinline__ void lw_step(const WPanelArgs<T> &a, __amdgpu_
 	const int rot = grp * 8;
 	const int lim = LW_W - rot; // positions < lim hold unfinished columns
 	const unsigned tag = a.epoch_base + (unsigned) J + 1u;
-	// ---- 1. the headers of column J
-	int p, gw;
-	double da, ds, dl;
-	const bool any = lw_sweep(hr, G, tag, J, lane, dead, p, gw, da, ds, dl);
+	// ---- 1. the headers of column J: wavefront 0 sweeps, the others wait for its result at the barrier
+	const int wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+	const int rpar = J & 1;
+	if (wave0) {
+		int p0, gw0;
+		double a0, s0, l0;
+#ifdef FH_LU_TIMING
+		const bool any0 = lw_sweep<RND>(hr, G, tag, J, lane, dead, A, B, C, p0, gw0, a0, s0, l0, tk[6]);
+#else
+		const bool any0 = lw_sweep<RND>(hr, G, tag, J, lane, dead, A, B, C, p0, gw0, a0, s0, l0);
+#endif
+		if (lane == 0) {
+			sh.res_p[rpar] = p0;
+			sh.res_gw[rpar] = gw0;
+			sh.res_flags[rpar] = (any0 ? 1 : 0) | (dead ? 2 : 0);
+			sh.res_a[rpar] = a0;
+			sh.res_s[rpar] = s0;
+			sh.res_l[rpar] = l0;
+		}
+	}
 	LW_TICK(0);
+	__syncthreads();
+	const int p = __builtin_amdgcn_readfirstlane(sh.res_p[rpar]), gw = __builtin_amdgcn_readfirstlane(sh.res_gw[rpar]);
+	const int rflags = __builtin_amdgcn_readfirstlane(sh.res_flags[rpar]);
+	const bool any = (rflags & 1) != 0;
+	dead = dead || (rflags & 2) != 0;
+	const double da = sh.res_a[rpar], ds = sh.res_s[rpar], dl = sh.res_l[rpar];
+	LW_TICK(7);
 	// ---- 2. the winner's row record is fetched while the next header is prepared (used in 5.)
 	const unsigned rvoff = (unsigned) (((lane + rot) & 63) * 16), rsoff = (unsigned) (((J & 3) * G + gw) * LW_ROW_BYTES);
 	lw_u32x4 rv = lw_load(rr, rvoff, rsoff);
@@ -367,15 +482,16 @@ static __device__ __forceinline__ void lw_step(const WPanelArgs<T> &a, __amdgpu_
 	T l[RPT];
 #pragma unroll
 	for (int i = 0; i < RPT; ++i) {
-		const bool act = lab[i] > J;
-		const T li = x[i][JJ] * inv;
-		l[i] = act ? li : (T) 0;
-		x[i][JJ] = act ? li : x[i][JJ];
-		const T nx = fh_fma(li, -uJ1, x[i][JJ + 1]);
-		x[i][JJ + 1] = act && JJ + 1 < lim ? nx : x[i][JJ + 1];
+		l[i] = (T) 0;
+		if (lab[i] > J) {
+			l[i] = x[i][JJ] * inv;
+			x[i][JJ] = l[i];
+			if (JJ + 1 < lim)
+				x[i][JJ + 1] = fh_fma(l[i], -uJ1, x[i][JJ + 1]);
+		}
 	}
 	LW_TICK(1);
-	// ---- 4. candidate of column J + 1, header and row record on their way
+	// ---- 4. candidate of column J + 1, header and row record on their way; the first sweep of the next column follows them
 	if (J + 1 < nsteps)
 		lw_publish<T, RPT, NW, JJ + 1>(a, hr, rr, x, lab, l, sh, J + 1, rot, G);
 	LW_TICK(2);
@@ -391,11 +507,19 @@ static __device__ __forceinline__ void lw_step(const WPanelArgs<T> &a, __amdgpu_
 		rv = lw_load(rr, rvoff, rsoff);
 	}
 	const T ucur = fh_fma(lp, -uprev, (T) lw_unpack(rv));
+	// the first sweep of column J + 1 (every wavefront issues it, see LwSweep); the other two follow inside / behind the update
+	lw_sweep_retire<RND>(A);
+	lw_sweep_issue<RND>(A, hr, G, J + 1, svoff);
 	LW_TICK(3);
 	// ---- 6. rank-1 update of the columns >= J + 2 (positions in blocks of 8, a block takes part while it holds unfinished
-	//         columns; the multipliers of the pivot row reach the FMAs through the scalar unit, as in getrf_panel2_kernel)
+	//         columns; the multipliers of the pivot row reach the FMAs through the scalar unit, as in getrf_panel2_kernel;
+	//         rows labelled <= J stay bitwise untouched: l * u could be NaN for an infinite u)
 #pragma unroll
 	for (int cb = 0; cb < LW_W / 8; ++cb) {
+		if (cb == 4) {
+			lw_sweep_retire<RND>(B);
+			lw_sweep_issue<RND>(B, hr, G, J + 1, svoff);
+		}
 		if (cb * 8 + 7 > JJ + 1 && cb * 8 < lim) {
 			T u[8];
 #pragma unroll
@@ -403,22 +527,23 @@ static __device__ __forceinline__ void lw_step(const WPanelArgs<T> &a, __amdgpu_
 				u[k] = lane_bcast(ucur, cb * 8 + k);
 #pragma unroll
 			for (int i = 0; i < RPT; ++i) {
-				const bool act = lab[i] > J;
+				if (lab[i] > J) {
 #pragma unroll
-				for (int k = 0; k < 8; ++k)
-					if (cb * 8 + k > JJ + 1) {
-						const T nx = fh_fma(l[i], -u[k], x[i][cb * 8 + k]);
-						x[i][cb * 8 + k] = act ? nx : x[i][cb * 8 + k];
-					}
+					for (int k = 0; k < 8; ++k)
+						if (cb * 8 + k > JJ + 1)
+							x[i][cb * 8 + k] = fh_fma(l[i], -u[k], x[i][cb * 8 + k]);
+				}
 			}
 		}
 	}
+	lw_sweep_retire<RND>(C);
+	lw_sweep_issue<RND>(C, hr, G, J + 1, svoff);
 	uprev = ucur;
 	LW_TICK(4);
 }
 
-// grid = G workgroups of NW wavefronts, all resident; wavefront v of workgroup g owns the rows [(g NW + v) 64 RPT, +64 RPT)
-template <typename T, int RPT, int NW> __global__ __launch_bounds__(NW * 64) void getrf_wpanel_kernel(const WPanelArgs<T> a)
+// grid = G <= 16 RND workgroups of NW wavefronts, all resident; wavefront v of workgroup g owns the rows [(g NW + v) 64 RPT, +64 RPT)
+template <typename T, int RPT, int NW, int RND> __global__ __launch_bounds__(NW * 64) void getrf_wpanel_kernel(const WPanelArgs<T> a)
 {
 	__shared__ WPanelShared<NW> sh;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -458,16 +583,22 @@ template <typename T, int RPT, int NW> __global__ __launch_bounds__(NW * 64) voi
 			l0[i] = (T) 0;
 		lw_publish<T, RPT, NW, 0>(a, hr, rr, x, lab, l0, sh, 0, 0, G);
 	}
+	// wavefront 0 sweeps all headers; the others issue the same loads on their own workgroup's record and ignore them (LwSweep)
+	const unsigned svoff = wave == 0 ? (unsigned) (lane * 16) : (unsigned) (blockIdx.x * LW_HDR_BYTES + (lane & 3) * 16);
+	LwSweep<RND> A, B, C;
+	lw_sweep_issue<RND>(A, hr, G, 0, svoff);
+	lw_sweep_issue<RND>(B, hr, G, 0, svoff);
+	lw_sweep_issue<RND>(C, hr, G, 0, svoff);
 	int rot = 0;
 	for (int grp = 0; grp * 8 < steps; ++grp) {
-		lw_step<T, RPT, NW, 0>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead LW_TARGS);
-		lw_step<T, RPT, NW, 1>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead LW_TARGS);
-		lw_step<T, RPT, NW, 2>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead LW_TARGS);
-		lw_step<T, RPT, NW, 3>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead LW_TARGS);
-		lw_step<T, RPT, NW, 4>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead LW_TARGS);
-		lw_step<T, RPT, NW, 5>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead LW_TARGS);
-		lw_step<T, RPT, NW, 6>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead LW_TARGS);
-		lw_step<T, RPT, NW, 7>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead LW_TARGS);
+		lw_step<T, RPT, NW, RND, 0>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
+		lw_step<T, RPT, NW, RND, 1>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
+		lw_step<T, RPT, NW, RND, 2>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
+		lw_step<T, RPT, NW, RND, 3>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
+		lw_step<T, RPT, NW, RND, 4>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
+		lw_step<T, RPT, NW, RND, 5>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
+		lw_step<T, RPT, NW, RND, 6>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
+		lw_step<T, RPT, NW, RND, 7>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
 		// rotate every row left by 8: the finished columns go to the tail
 #pragma unroll
 		for (int i = 0; i < RPT; ++i) {
