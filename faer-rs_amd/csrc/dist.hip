@@ -296,11 +296,14 @@ FaerLltStatus dist_llt_api(FaerMatMut A_local, size_t n_global, size_t nb, FaerL
 	be.comm = comm;
 	be.reg_delta = reg.dynamic_regularization_delta ? *static_cast<const T *>(reg.dynamic_regularization_delta) : (T) 0;
 	be.reg_eps = reg.dynamic_regularization_epsilon ? *static_cast<const T *>(reg.dynamic_regularization_epsilon) : (T) 0;
+	be.streams_init(); // the two-stream schedule of the LU (step_begin / ahead_* / rest_*: no-ops without it -- ADVICE r03)
 	typename B::View Av{static_cast<T *>(A_local.ptr), n, (long) A_local.ncols, 1, (long) A_local.col_stride};
 	be.t_total.begin();
 	const long r = DistLlt<B>::run(be, Av, n, (long) nb, comm.rank, comm.world_size, static_cast<T *>(panel_ws));
 	be.t_total.end();
-	ctx().sync();
+	ctx().sync(); // the run joined both internal streams into the caller's
+	if (be.two)
+		ctx().quiesce();
 	g_dist_stats.panels = (int) be.t_panel.ev.size();
 	g_dist_stats.panel_ms = be.t_panel.harvest();
 	g_dist_stats.total_ms = be.t_total.harvest();

@@ -1210,7 +1210,10 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		const size_t a_bytes = (size_t) m * (size_t) size * sizeof(T);
 		size_t mem_free = 0, mem_total = 0;
 		bool have_backup = false;
-		if (!force_general && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+		// (a panel of one workgroup exchanges with nobody and cannot time out: small matrices skip the copy, the memory query
+		// and the extra synchronisation -- ADVICE r03)
+		const bool one_workgroup = m <= (idx_t) 256 * (sizeof(T) == 8 ? 1 : 2);
+		if (!force_general && !one_workgroup && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
 			have_backup = a_bytes <= mem_free / 2;
 		Scratch backup(have_backup ? a_bytes : 256);
 		MatV<T> Bk{backup.as<T>(), m, size, 1, m};

@@ -596,6 +596,7 @@ template <typename T> struct GqArgs {
 	double *dots; // n entries
 	double *kvec; // n entries
 	T *taus;      // size entries
+	int top;      // rows of a parent matrix ABOVE A(0, :) that belong to the columns as well (they count in the rank test)
 };
 
 template <typename T> static __device__ __forceinline__ double scale_sml() { return sqrt((double) Lim<T>::minpos); }
@@ -610,7 +611,8 @@ template <typename T> __global__ void gq_norms_kernel(const GqArgs<T> a)
 		return;
 	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
 	T acc[6] = {0, 0, 0, 0, 0, 0};
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.m; i += gridDim.x * blockDim.x) {
+	// (i < 0: the column's entries in the parent's rows above this submatrix -- factor.rs:26,52-58 takes the norm of ALL rows above)
+	for (int i = -a.top + (int) (blockIdx.x * blockDim.x + threadIdx.x); i < a.m; i += gridDim.x * blockDim.x) {
 		if (i == row)
 			continue;
 		const T x = a.A[(idx_t) i * a.rs + (idx_t) a.col * a.cs];
@@ -761,7 +763,7 @@ __global__ void gq_advance_kernel(GqState *st)
 		st->row += 1;
 }
 
-template <typename T> static long qr_general(MatV<T> A, T *taus_dev)
+template <typename T> static long qr_general(MatV<T> A, T *taus_dev, idx_t top = 0)
 {
 	const idx_t m = A.nrows, n = A.ncols;
 	const idx_t size = m < n ? m : n;
@@ -784,6 +786,7 @@ template <typename T> static long qr_general(MatV<T> A, T *taus_dev)
 	a.dots = dotsb.as<double>();
 	a.kvec = kb.as<double>();
 	a.taus = taus_dev;
+	a.top = (int) top;
 	int rb = (int) ((m + 255) / 256);
 	if (rb > 1024)
 		rb = 1024;
@@ -2164,7 +2167,10 @@ __global__ void copy_guard_kernel(T *d, idx_t drs, idx_t dcs, const T *s, idx_t 
 		atomicExch(flag, 1);
 }
 
-template <typename T> static long geqrf_classic(MatV<T> A, MatV<T> H, idx_t blocking_threshold)
+// `off` > 0: A is the trailing part parent(off:, off:) of a matrix whose first `off` columns are finished reflectors (the
+// one-pass path stopped there).  The reference's rank test looks at a column's entries in ALL rows above the current one
+// (factor.rs:26,52-58), so the `off` parent rows above A count: both paths below read them through negative row offsets.
+template <typename T> static long geqrf_classic(MatV<T> A, MatV<T> H, idx_t blocking_threshold, idx_t off = 0)
 {
 	(void) blocking_threshold; // the GPU recursion always blocks; leaves are 8 columns wide
 	const idx_t m = A.nrows, n = A.ncols;
@@ -2221,14 +2227,14 @@ template <typename T> static long geqrf_classic(MatV<T> A, MatV<T> H, idx_t bloc
 		wk.gran_head = wk.gran + (size_t) 2 * QR_GMAX * 2 * QR_PW;
 		wk.epoch_base = 0;
 		wk.status = status;
-		wk.a_top = A.p;
+		wk.a_top = A.p - off * A.rs - off * A.cs; // origin of the parent
 		wk.rs = A.rs;
 		wk.cs = A.cs;
 		for (idx_t c0 = 0; c0 < size; c0 += bs) {
 			const idx_t wb = bs < size - c0 ? bs : size - c0;
 			MatV<T> P = A.sub(c0, c0, m - c0, wb);
 			MatV<T> Tb = H.sub(0, c0, wb, wb);
-			qr_rec<T>(P, Tb, c0, c0, wk);
+			qr_rec<T>(P, Tb, off + c0, off + c0, wk);
 			if (c0 + wb < n) // factor.rs:241-249: apply Q_k^H to everything on the right
 				apply_block_householder_dev<T>(P.c(), Tb.c(), A.sub(c0, c0 + wb, m - c0, n - c0 - wb), true);
 		}
@@ -2244,7 +2250,7 @@ template <typename T> static long geqrf_classic(MatV<T> A, MatV<T> H, idx_t bloc
 	}
 	if (rank < 0) {
 		Scratch taus((size_t) size * sizeof(T));
-		rank = qr_general<T>(A, taus.as<T>());
+		rank = qr_general<T>(A, taus.as<T>(), off);
 		qr_t_blocks_from_taus<T>(A, H, rank, taus.as<T>());
 		FH_HIP(hipStreamSynchronize(s)); // taus scratch is released on return
 	}
@@ -2291,7 +2297,7 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 			Scratch h2((size_t) bs * (size_t) size2 * sizeof(T));
 			MatV<T> H2{h2.as<T>(), bs, size2, 1, bs};
 			fill_dev<T>(H2, DST_FULL, (T) 0);
-			const long r2 = geqrf_classic<T>(B, H2, blocking_threshold);
+			const long r2 = geqrf_classic<T>(B, H2, blocking_threshold, done);
 			if (r2 > 0) {
 				hipLaunchKernelGGL(qr_taus_from_blocks_kernel<T>, dim3((unsigned) ((r2 + 255) / 256)), dim3(256), 0, ctx().stream, H2.p, H2.rs, H2.cs,
 						   (int) bs, (int) r2, taus.as<T>() + done);

@@ -63,9 +63,28 @@ struct Rccl {
 	hipStream_t stream = nullptr;
 	hipEvent_t ready = nullptr, done[3] = {nullptr, nullptr, nullptr}; // slots 0 / 1 of the drivers + the blocking form
 	int rank = 0, world = 1;
-	// statistics since the last faer_hip_rccl_stats: broadcasts issued, bytes, their device time (timing events on `stream`)
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+	// statistics since the last faer_hip_rccl_stats: broadcasts issued, bytes, their device time.  The timing events are a
+	// fixed ring, created on first use and destroyed with the transport: a caller that never asks for statistics holds at
+	// most 2 * TIMED events however many panels it broadcasts (one pair per broadcast was an unbounded leak: ADVICE r03).
+	static constexpr int TIMED = 64;
+	hipEvent_t t0[TIMED] = {}, t1[TIMED] = {};
+	bool pending[TIMED] = {};
+	int next_timed = 0;
+	double timed_ms = 0;
 	double n_bcast = 0, bytes = 0;
+	// folds the pair in slot i into timed_ms if its broadcast has finished (never waits)
+	void harvest(int i)
+	{
+		if (!pending[i])
+			return;
+		float t = 0;
+		const hipError_t e = hipEventElapsedTime(&t, t0[i], t1[i]);
+		if (e == hipSuccess)
+			timed_ms += t;
+		else
+			(void) hipGetLastError(); // not finished yet: this broadcast stays untimed
+		pending[i] = false;
+	}
 };
 
 void rccl_check(int rc, const char *what)
@@ -84,13 +103,17 @@ void rccl_start(Rccl *r, void *buf, size_t bytes, int root, int slot)
 	hipStream_t cur = ctx().stream;
 	FH_HIP(hipEventRecord(r->ready, cur)); // the panel was packed on the caller's stream
 	FH_HIP(hipStreamWaitEvent(r->stream, r->ready, 0));
-	hipEvent_t t0, t1;
-	FH_HIP(hipEventCreate(&t0));
-	FH_HIP(hipEventCreate(&t1));
-	FH_HIP(hipEventRecord(t0, r->stream));
+	const int ti = r->next_timed;
+	r->next_timed = (ti + 1) % Rccl::TIMED;
+	r->harvest(ti); // the slot's previous broadcast (TIMED broadcasts ago)
+	if (!r->t0[ti]) {
+		FH_HIP(hipEventCreate(&r->t0[ti]));
+		FH_HIP(hipEventCreate(&r->t1[ti]));
+	}
+	FH_HIP(hipEventRecord(r->t0[ti], r->stream));
 	rccl_check(a->Broadcast(buf, buf, bytes, NCCL_CHAR, root, r->comm, r->stream), "ncclBroadcast");
-	FH_HIP(hipEventRecord(t1, r->stream));
-	r->timed.emplace_back(t0, t1);
+	FH_HIP(hipEventRecord(r->t1[ti], r->stream));
+	r->pending[ti] = true;
 	r->n_bcast += 1;
 	r->bytes += (double) bytes;
 	FH_HIP(hipEventRecord(r->done[slot], r->stream));
@@ -175,15 +198,10 @@ void faer_hip_rccl_stats(void *handle, double *out4)
 	if (a && a->CommCount && r->comm)
 		(void) a->CommCount(r->comm, &cnt);
 	FH_HIP(hipStreamSynchronize(r->stream));
-	double ms = 0;
-	for (auto &p : r->timed) {
-		float t = 0;
-		if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess)
-			ms += t;
-		(void) hipEventDestroy(p.first);
-		(void) hipEventDestroy(p.second);
-	}
-	r->timed.clear();
+	for (int i = 0; i < Rccl::TIMED; ++i)
+		r->harvest(i);
+	const double ms = r->timed_ms;
+	r->timed_ms = 0;
 	out4[0] = (double) cnt;
 	out4[1] = r->n_bcast;
 	out4[2] = r->bytes;
@@ -204,6 +222,11 @@ void faer_hip_rccl_destroy(void *handle)
 	(void) hipEventDestroy(r->ready);
 	for (hipEvent_t e : r->done)
 		(void) hipEventDestroy(e);
+	for (int i = 0; i < Rccl::TIMED; ++i)
+		if (r->t0[i]) {
+			(void) hipEventDestroy(r->t0[i]);
+			(void) hipEventDestroy(r->t1[i]);
+		}
 	(void) hipStreamDestroy(r->stream);
 	delete r;
 }

@@ -43,7 +43,7 @@ constexpr int TQ_LP = 68;   // LDS pitch (floats) of one staged column of a 64-r
 constexpr int TQ_TS = 192;  // widest strip of trailing columns per launch (LDS: 256 staged columns)
 constexpr int TQ_NB = 512;  // workgroups (= partial sums) of a Gram launch: two per CU
 constexpr int TQ_DP = 65;   // pitch of the fp64 64 x 64 matrices in LDS
-constexpr double TQ_COND_MAX = 64.0 * 512.0; // |R|_F |R^-1|_F (>= 64 for any panel): cond_2(panel) below ~512
+constexpr double TQ_COND_MAX = 64.0 * 512.0; // |R D|_F |(R D)^-1|_F of the equilibrated panel (>= 64 for any panel): cond_2 below ~512
 constexpr double TQ_TAIL_MIN = 1e-9;	     // 1 - |head| / |column| below this: the tail is numerically zero
 enum { TQ_OK = 0, TQ_FAIL_CHOL = 1, TQ_FAIL_TAIL = 2, TQ_FAIL_RANK = 3, TQ_FAIL_COND = 4, TQ_FAIL_RANGE = 5 };
 
@@ -981,17 +981,22 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 				atomicMax(&s_fail, (int) TQ_FAIL_RANK);
 		}
 	} else if (tid < 128) {
+		// The estimate is taken on the EQUILIBRATED panel P D, D = diag(1 / |column|): its factor is R~ D (row ti of L scaled
+		// to unit length, |R~ D|_F^2 = 64) and (R~ D)^-1 = D^-1 R~^-1.  What the one-pass path loses to rounding -- the
+		// Cholesky factorization of G, V = P M, the trailing rows of R -- is invariant under column scaling, so a panel whose
+		// columns merely differ in scale stays here; the unscaled estimate of round 3 sent it to the classic path.
 		const int ti = tid - 64;
-		double f1 = 0.0, f2 = 0.0;
+		double g2 = 0.0; // |column ti|^2 = G_ii = |row ti of L|^2
+		for (int l = 0; l < 64; ++l)
+			g2 += l <= ti ? Lm[ti * TQ_DP + l] * Lm[ti * TQ_DP + l] : 0.0;
+		double f2 = 0.0;
 		for (int l = 0; l < 64; ++l) {
-			f1 += l <= ti ? Lm[ti * TQ_DP + l] * Lm[ti * TQ_DP + l] : 0.0;
-			f2 += l <= ti ? Ri[l * TQ_DP + ti] * Ri[l * TQ_DP + ti] : 0.0;
+			const double gl = __shfl(g2, l);
+			f2 += l <= ti ? Ri[l * TQ_DP + ti] * Ri[l * TQ_DP + ti] * gl : 0.0;
 		}
-		for (int o = 32; o > 0; o >>= 1) {
-			f1 += __shfl_xor(f1, o);
+		for (int o = 32; o > 0; o >>= 1)
 			f2 += __shfl_xor(f2, o);
-		}
-		if (!(sqrt(f1 * f2) <= TQ_COND_MAX))
+		if (!(sqrt(64.0 * f2) <= TQ_COND_MAX))
 			atomicMax(&s_fail, (int) TQ_FAIL_COND);
 	}
 	__syncthreads();
@@ -1767,6 +1772,37 @@ static TqSide tq_side()
 	return TqSide{c.qr_side[0], c.qr_side[1], c.qr_ev[0], c.qr_ev[1], c.qr_ev[2], c.qr_ev[3]};
 }
 
+// Range guard of the columns the first step's Gram launches do not cover (n > 256: the squares of the first 64 + 192
+// columns come out of those launches, tq_panel_kernel / tq_y_kernel check them): one workgroup per column, BEFORE anything is
+// written -- a column whose rms is outside [1e-12, 1e12] would be updated by the first steps with flushed or overflowed fp32
+// products, and a later rejection could not undo that.  One more read of those columns (n <= 512).
+__global__ __launch_bounds__(256) void tq_range_rest_kernel(const float *A, long ld, int m, int c_first, int *stat)
+{
+	__shared__ double red[256];
+	const float *col = A + (long) (c_first + (int) blockIdx.x) * ld;
+	double sq = 0.0;
+	for (int i = threadIdx.x; i < m; i += 256) {
+		const double v = (double) col[i];
+		sq += v * v;
+	}
+	red[threadIdx.x] = sq;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int) threadIdx.x < o)
+			red[threadIdx.x] += red[threadIdx.x + o];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		const double lo = 1e-24 * (double) m, hi = 1e24 * (double) m;
+		if (!(red[0] >= lo && red[0] <= hi)) {
+			stat[1] = 0;
+			stat[2] = TQ_FAIL_RANGE;
+			__threadfence();
+			atomicExch(stat, 1); // "stopped in front of column 0": every later kernel returns at once
+		}
+	}
+}
+
 bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs)
 {
 	static const bool off = getenv("FAER_HIP_QR_TSQR") && atoi(getenv("FAER_HIP_QR_TSQR")) == 0; // A/B switch
@@ -1791,14 +1827,14 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	const int ldc = ((int) n + 63) & ~63;
 	const int typ = ldc, ldz = ldc;
 	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * 4), sp((size_t) TQ_NB * 256 * 4);
-	// fp64 workspace: G (NG x 4096), N1, N3, Gf (4096 each), C (NG x 64 x ldc), S, S2 (NG x 256 each), abv (n + 64),
+	// fp64 workspace: G (NG x 4096), N1, N3, Gf (4096 each), C (NG x 64 x ldc), S (NG x 256; a second slab of that size is unused padding), abv (n + 64),
 	//                 Td, Md (npan x 4096 each), Z, B (npan x 64 x ldz each); then fp32: Mn (npan x 4096), top, A1s (4096 each), Yn (64 x typ); then the status words
 	const size_t nd = (size_t) TQ_NG * 4096 + 3 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) 2 * TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
 			  (size_t) 2 * npan * 64 * ldz;
 	Scratch small(nd * 8 + ((size_t) npan * 4096 + 2 * 4096 + (size_t) 64 * typ) * 4 + 2048);
 	double *G = small.as<double>();
 	double *N1 = G + (size_t) TQ_NG * 4096, *N3 = N1 + 4096, *Gf = N3 + 4096, *C = Gf + 4096;
-	double *S = C + (size_t) TQ_NG * 64 * ldc, *S2 = S + (size_t) TQ_NG * 256, *abv = S2 + (size_t) TQ_NG * 256;
+	double *S = C + (size_t) TQ_NG * 64 * ldc, *abv = S + (size_t) 2 * TQ_NG * 256;
 	double *Td = abv + n + 64, *Md = Td + (size_t) npan * 4096, *Z = Md + (size_t) npan * 4096, *Bx = Z + (size_t) npan * 64 * ldz;
 	float *Mn = reinterpret_cast<float *>(Bx + (size_t) npan * 64 * ldz); // one per panel: V of step k is formed beside panel k + 1
 	float *top = Mn + (size_t) npan * 4096;
@@ -1822,7 +1858,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		}
 		for (int off = 0; off < t; off += TQ_TS) {
 			const int ts = t - off < TQ_TS ? t - off : TQ_TS;
-			// the range guard covers the first strip only (n <= 256); wider matrices check the rest per panel through G
+			// the range guard of these launches covers the first strip only (n <= 256); tq_range_rest_kernel checks the others
 			tq_gram(P, A.p + (long) (cx + off) * ld + c0, ld, rows, w, ts, want_g && off == 0, first && off == 0, vec, gp.as<double>(),
 				cp.as<float>(), sp.as<float>(), G, C, ldc, cx + off - (c0 + w), Sd, stat, c0, A1s, Gf, stat + 128);
 		}
@@ -1880,43 +1916,28 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	};
 	// one block of Q_coeff over all panels (the tall-skinny case): the cross-panel blocks of T in two stages beside the last steps
 	const bool two_stage = cross && bs >= n && bs <= (TQ_TX_MAXL + 1) * TQ_PW && npan >= 2;
-	// look-ahead: the columns of the next panel are updated first, its Gram matrix and its panel kernel (ONE workgroup, ~150 us)
-	// follow at once, and the rest of the update + the products against the next panel run beside that kernel
-	// Measured on 5e5 x 256 (profiles/r03_qr_lookahead.txt): beside the streaming kernels the panel kernel takes 270-370 us
-	// instead of 205 and the split launches read both panels twice -- 2.50 ms against 2.39 ms without.  It is on where the
-	// rest of the update is long enough to cover that (>= 192 more trailing columns).  Otherwise only the Gram launch is
-	// split (gram_and_panel below).  FAER_HIP_QR_TSQR_LA = 0 / 1 / 2: neither / always the first / always the second.
-	static const int la_env = getenv("FAER_HIP_QR_TSQR_LA") ? atoi(getenv("FAER_HIP_QR_TSQR_LA")) : -1; // A/B switch
+	// look-ahead: the columns of the next panel are updated first, its Gram matrix and its panel kernel (ONE workgroup, ~110 us)
+	// follow at once, and the rest of the update + the products against the next panel run beside that kernel.  It is on where
+	// the rest of the update is long enough to cover what the panel kernel loses beside streaming kernels (>= 192 more trailing
+	// columns).  Two variants that forced it (always / a split Gram launch beside the panel kernel) measured slower and are
+	// gone: profiles/r03_qr_lookahead.txt keeps the record.
 	const TqSide side = tq_side();
 	const int ncu_all = ctx().stream_cus();
 	int cus_taken = 0; // CUs held by side-stream kernels while the persistent update kernels run
 	bool tx_on_side = false;
 	bool panel_on_side = false;
-	const double *s_trailing = S; // where the first step's squares of the trailing columns are
-	// Gram products and panel kernel of panel p.  The panel kernel needs G only: the products against the trailing columns (C)
-	// can be a second launch that runs BESIDE the panel kernel (the panel columns are read twice).  Beside a streaming kernel
-	// the panel kernel -- bound by its instruction fetch -- took twice as long (137 -> 283 us): 2.17 ms against 2.07 ms.
+	// Gram products and panel kernel of panel p
 	auto gram_and_panel = [&](int p, bool first) {
 		const int pc0 = p * TQ_PW;
 		const int pw = (int) (n - pc0 < TQ_PW ? n - pc0 : TQ_PW);
 		const int pt = (int) n - pc0 - pw;
-		const bool split = la_env == 2 && pt > 0; // measured slower (profiles/r03_qr_lookahead.txt): only on request
-		if (!split) {
-			launch_gram(pc0, pw, true, pc0 + pw, pt, first, S);
-			launch_panel(p, s);
-			return;
-		}
-		launch_gram(pc0, pw, true, pc0 + pw, 0, first, S);
-		FH_HIP(hipEventRecord(side.pfork, s));
-		FH_HIP(hipStreamWaitEvent(side.panel, side.pfork, 0));
-		launch_panel(p, side.panel);
-		FH_HIP(hipEventRecord(side.pdone, side.panel));
-		panel_on_side = true;
-		cus_taken += 1;
-		launch_gram(pc0, pw, false, pc0 + pw, pt, first, S2);
-		if (first)
-			s_trailing = S2;
+		launch_gram(pc0, pw, true, pc0 + pw, pt, first, S);
+		launch_panel(p, s);
 	};
+	if (n > TQ_PW + TQ_TS) {
+		hipLaunchKernelGGL(tq_range_rest_kernel, dim3((unsigned) (n - (TQ_PW + TQ_TS))), dim3(256), 0, s, A.p, (long) ld, (int) m, TQ_PW + TQ_TS, stat);
+		FH_HIP(hipGetLastError());
+	}
 	gram_and_panel(0, true);
 	for (int k = 0; k < npan; ++k) {
 		const int c0 = k * TQ_PW;
@@ -1948,7 +1969,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			ya.ldz = ldz;
 			ya.top = top;
 			ya.stat = stat;
-			ya.Sr = s_trailing;
+			ya.Sr = S;
 			ya.check_range = k == 0;
 			ya.range_cols = t < TQ_TS ? t : TQ_TS;
 			ya.mrows = (int) m;
@@ -2007,7 +2028,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		};
 		if (t == 0) {
 			update(0, 0, true);
-		} else if (!(la_env >= 0 ? la_env == 1 : t - wn >= TQ_TS)) {
+		} else if (t - wn < TQ_TS) {
 			update(0, t, true);
 			gram_and_panel(k + 1, false);
 		} else {

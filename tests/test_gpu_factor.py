@@ -109,7 +109,7 @@ def test_llt_host_pointer():
     assert np.abs(L @ L.T - a).max() < 1e-10 * np.abs(a).max()
 
 
-def test_llt_full_size_property():
+def test_llt_full_size_property(oracle):
     """BASELINE config C (N = 16384 fp64): ||L L^T x - A x|| via matvecs, no oracle"""
     import torch
 
@@ -125,6 +125,13 @@ def test_llt_full_size_property():
     x = torch.randn((n, 4), dtype=torch.float64, device="cuda", generator=g)
     r = L @ (L.t() @ x) - a @ x
     assert r.abs().max().item() <= 64 * n * 2.3e-16 * (a.abs() @ x.abs()).max().item()
+    # sampled parity at the BASELINE size: the leading k x k block of L is the Cholesky factor of the leading block of A
+    # whatever follows it (cholesky/ldlt/factor.rs:367-498) -- compared entry by entry with the oracle's factorization
+    k = 2048
+    ref = np.asfortranarray(a[:k, :k].cpu().numpy())
+    assert oracle.llt_in_place(ref) == ("ok", 0)
+    d = np.abs(np.tril(l[:k, :k].cpu().numpy()) - np.tril(ref)).max()
+    assert d <= 64 * k * 2.3e-16 * np.abs(np.tril(ref)).max(), d
 
 
 @pytest.mark.parametrize("n,tail", [(4096, 0), (4363, 0), (5120 + 77, 2048), (5120 + 77, 1 << 20), (6144, 3000), (3072 + 5, 1024)])
@@ -267,7 +274,7 @@ def test_plu_ties_and_zero_column(oracle):
     assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.allclose(got[~np.isnan(got)], ref[~np.isnan(ref)])
 
 
-def test_plu_full_size_property():
+def test_plu_full_size_property(oracle):
     """BASELINE config L on one GPU (N = 16384 fp64): ||L U x - P A x||, |L| <= 1"""
     import torch
 
@@ -286,6 +293,18 @@ def test_plu_full_size_property():
     r = L @ (torch.triu(lu) @ x) - a[p] @ x
     scale = (L.abs() @ (torch.triu(lu).abs() @ x.abs())).max().item()
     assert r.abs().max().item() <= 64 * n * 2.3e-16 * scale
+    # sampled parity at the BASELINE size: the first k columns (pivots, L panel, leading block of U) depend on the first k
+    # columns of A only (lu/partial_pivoting/factor.rs:68-187) -- compared with the oracle's factorization of that panel.  Rows
+    # below k are moved again by later interchanges: row i of the final L is the oracle's row of the same ORIGINAL row.
+    k = 512
+    ref = np.asfortranarray(a[:, :k].cpu().numpy())
+    rperm, rinv, _ = oracle.lu_in_place(ref)
+    perm64 = perm.astype(np.int64)
+    assert (perm64[:k] == rperm[:k]).all()  # identical pivots, column by column
+    got = lu[:, :k].cpu().numpy()
+    want = ref[rinv.astype(np.int64)[perm64], :]
+    kappa = np.linalg.cond(a[p][:k, :k].cpu().numpy())
+    assert np.abs(got - want).max() <= 4 * n * 2.3e-16 * kappa * max(1.0, np.abs(want).max()), np.abs(got - want).max()
 
 
 @pytest.mark.parametrize("m,n", [(4096, 4096), (4500, 4321), (6000, 5000)])

@@ -142,10 +142,11 @@ def thin_q(F, dqr, dh, m, n):
     return to_host(q).astype(np.float64)
 
 
-def _tall_vs_oracle(oracle, F, a, bs, lead=None):
-    """one-pass path (csrc/tsqr.hip) against the oracle's Householder QR: R within 64 eps max|R|, V within 16 eps
-    (its entries are O(1 / sqrt(m))), T within 64 eps max|T| -- the differences measured on the CPU prototype
-    (tests/diag/proto_tsqr.py) are 1-4 eps; the generic bound 64 max(m, n) eps would be ~1 here and say nothing"""
+def _tall_vs_oracle(oracle, F, a, bs, lead=None, tol=(8.0, 2.0, 8.0)):
+    """one-pass path (csrc/tsqr.hip) against the oracle's Householder QR: every column of R within tol[0] eps of that column's
+    largest entry, V within tol[1] eps (its entries are O(1 / sqrt(m))), T within tol[2] eps max|T|.  Measured on well
+    conditioned panels: 2-4 / 0.1-0.6 / 2-4 eps (DESIGN.md section 3.5a, tests/diag/gpu_qr_tall_fuzz.py), hence 8 / 2 / 8;
+    conditioned panels pass cond-scaled tolerances.  The generic bound 64 max(m, n) eps would be ~1 here and say nothing"""
     import torch
 
     m, n = a.shape
@@ -165,16 +166,89 @@ def _tall_vs_oracle(oracle, F, a, bs, lead=None):
     e = float(np.finfo(np.float32).eps)
     up = np.triu(np.ones((m, n), bool))
     d = np.abs(qr.astype(np.float64) - ref)
-    assert d[up].max() <= 64 * e * np.abs(ref[up]).max(), ("R", d[up].max() / e / np.abs(ref[up]).max())
-    assert d[~up].max() <= 16 * e, ("V", d[~up].max() / e)
+    dr = np.where(up, d, 0.0).max(axis=0) / np.where(up, np.abs(ref), 0.0).max(axis=0)  # per column of R
+    assert dr.max() <= tol[0] * e, ("R", dr.max() / e)
+    assert d[~up].max() <= tol[1] * e, ("V", d[~up].max() / e)
     tu = np.zeros((bs, n), bool)
     for j0 in range(0, n, bs):
         w = min(bs, n - j0)
         tu[:w, j0:j0 + w] = np.triu(np.ones((w, w), bool))
     assert np.isfinite(h).all()
     dt = np.abs(h.astype(np.float64) - rh)[tu].max()
-    assert dt <= 64 * e * np.abs(rh[tu]).max(), ("T", dt / e / np.abs(rh[tu]).max())
-    return qr, h
+    assert dt <= tol[2] * e * np.abs(rh[tu]).max(), ("T", dt / e / np.abs(rh[tu]).max())
+    return dqr, dh, qr, h
+
+
+def _q_properties(F, dqr, dh, a, c=16.0):
+    """the condition-independent properties of a Householder QR: |Q^T Q - I| and |Q R - A| at c sqrt(m) eps"""
+    m, n = a.shape
+    e = float(np.finfo(np.float32).eps)
+    q = thin_q(F, dqr, dh, m, n)
+    R = np.triu(to_host(dqr)[:n]).astype(np.float64)
+    assert np.abs(q.T @ q - np.eye(n)).max() <= c * np.sqrt(m) * e, ("QtQ", np.abs(q.T @ q - np.eye(n)).max() / (np.sqrt(m) * e))
+    res = np.abs(q @ R - a).max(axis=0) / np.abs(a).max(axis=0)  # per column: scaled columns must not hide behind the largest one
+    assert res.max() <= c * np.sqrt(m) * e, ("QR-A", res.max() / (np.sqrt(m) * e))
+
+
+def _conditioned(rng, m, n, cond):
+    """m x n fp32 matrix, entries O(1), whose 64-column panels each have singular values graded from 1 to 1 / cond (independent
+    random subspaces: a panel keeps that conditioning after the earlier panels' reflectors have been applied)"""
+    blocks = []
+    for c0 in range(0, n, 64):
+        w = min(64, n - c0)
+        q1, _ = np.linalg.qr(rng.standard_normal((m, w)))
+        q2, _ = np.linalg.qr(rng.standard_normal((w, w)))
+        blocks.append((q1 * np.logspace(0.0, -np.log10(cond), w)) @ q2.T * np.sqrt(m))
+    return np.asfortranarray(np.hstack(blocks).astype(np.float32))
+
+
+@pytest.mark.parametrize("cond", [10.0, 100.0, 400.0])
+@pytest.mark.parametrize("m,n,bs", [(20000, 64, 64), (30000, 128, 128)])
+def test_qr_tall_one_pass_conditioned_panels(oracle, m, n, bs, cond):
+    """accepted panels between the Gaussian case (cond ~ 1.2) and the guard (cond_2 ~ 512, tsqr.hip TQ_COND_MAX): V = P M and
+    the trailing rows of R amplify fp32 rounding by cond(panel), so the factors are compared at cond-scaled tolerances
+    (householder.rs:59-107, factor.rs:52-64 semantics unchanged) AND through the properties that do not depend on it"""
+    F = init_gpu()
+    rng = np.random.default_rng(int(m + n + cond))
+    a = _conditioned(rng, m, n, cond)
+    first = np.linalg.cond(a[:, :64].astype(np.float64))
+    assert cond * 0.99 <= first <= cond * 1.01  # the case is what it claims to be
+    dqr, dh, _, _ = _tall_vs_oracle(oracle, F, a, bs, tol=(16.0 * cond, 4.0 * cond, 16.0 * cond))
+    _q_properties(F, dqr, dh, a)
+
+
+@pytest.mark.parametrize("decades", [3, 6])
+def test_qr_tall_one_pass_badly_scaled_columns(oracle, decades):
+    """well-conditioned directions, column scales spread over 2 x `decades` decades: the guard looks at the EQUILIBRATED panel
+    (a Cholesky factorization of D G D is as accurate as that of G), so these stay on the one-pass path at the Gaussian
+    tolerances -- R compared column by column"""
+    F = init_gpu()
+    rng = np.random.default_rng(decades)
+    m, n = 24000, 128
+    a = rnd(rng, m, n, np.float32)
+    a *= (10.0 ** rng.uniform(-decades, decades, n)).astype(np.float32)[None, :]
+    dqr, dh, _, _ = _tall_vs_oracle(oracle, F, np.asfortranarray(a), 64)
+    _q_properties(F, dqr, dh, a)
+
+
+def test_qr_tall_range_guard_covers_every_column(oracle):
+    """256 < n <= 512: a column beyond the first 256 whose scale is outside the fp32-safe range [1e-12, 1e12] must stop the
+    one-pass path BEFORE anything is written (tq_range_rest_kernel); the classic path then factors the matrix"""
+    F = init_gpu()
+    rng = np.random.default_rng(9)
+    m, n = 20000, 320
+    a = rnd(rng, m, n, np.float32)
+    a[:, 300] *= np.float32(1e-20)
+    ref, rh = a.copy(order="F"), np.zeros((64, n), dtype=np.float32, order="F")
+    rk = oracle.qr_in_place(ref, rh)
+    dqr, dh = to_dev(a), to_dev(np.zeros((64, n), dtype=np.float32))
+    assert F.qr_factor_in_place(dqr, dh) == rk
+    F.lib().faer_hip_debug_qr_one_pass_columns.restype = C.c_long
+    assert F.lib().faer_hip_debug_qr_one_pass_columns() == 0
+    e = float(np.finfo(np.float32).eps)
+    d = np.abs(to_host(dqr).astype(np.float64) - ref)
+    scale = np.maximum(np.abs(ref).max(axis=0), 1e-30)
+    assert (d.max(axis=0) / scale).max() <= 64 * np.sqrt(m) * e
 
 
 @pytest.mark.parametrize("m,n,bs", [(20000, 64, 64), (20000, 64, 32), (16384, 130, 1), (40000, 100, None), (30000, 200, 16),
@@ -231,20 +305,25 @@ def test_qr_tall_falls_back_per_panel(oracle):
     rng = np.random.default_rng(5)
     m, n = 20000, 192
     e = float(np.finfo(np.float32).eps)
-    # (1) the columns of the second panel are graded over four decades: cond ~ 1e4, every column passes the rank test
+    # (1) the second panel is ill conditioned (not merely badly scaled): 64 columns spanning a 40-dimensional space plus noise
+    #     at 1e-5 -- cond ~ 1e5, every column still passes the rank test
     a = rnd(rng, m, n, np.float32)
-    a[:, 64:128] *= np.logspace(0, -4, 64, dtype=np.float32)[None, :]
+    a[:, 64:128] = (rnd(rng, m, 40, np.float64) @ rnd(rng, 40, 64, np.float64) / 6.0 + 1e-5 * rnd(rng, m, 64, np.float64)).astype(np.float32)
     ref, rh = a.copy(order="F"), np.zeros((64, n), dtype=np.float32, order="F")
     assert oracle.qr_in_place(ref, rh) == n
     dqr, dh = to_dev(a), to_dev(np.zeros((64, n), dtype=np.float32))
     assert F.qr_factor_in_place(dqr, dh) == n
     F.lib().faer_hip_debug_qr_one_pass_columns.restype = C.c_long
-    assert F.lib().faer_hip_debug_qr_one_pass_columns() == 64  # the first panel on the one-pass path, the graded one refused
+    assert F.lib().faer_hip_debug_qr_one_pass_columns() == 64  # the first panel on the one-pass path, the ill-conditioned one refused
     q = thin_q(F, dqr, dh, m, n)
     R = np.triu(to_host(dqr)[:n]).astype(np.float64)
     assert np.abs(q @ R - a).max() <= 64 * np.sqrt(m) * e * np.abs(a).max()
     assert np.abs(q.T @ q - np.eye(n)).max() <= 64 * np.sqrt(m) * e
-    assert np.abs(np.abs(np.diag(R)) - np.abs(np.diag(ref[:n]))).max() <= 1e-3 * np.abs(np.diag(ref[:n])).max()
+    # (1b) the same panel graded over four decades but well conditioned after equilibration: stays on the one-pass path
+    a = rnd(rng, m, n, np.float32)
+    a[:, 64:128] *= np.logspace(0, -4, 64, dtype=np.float32)[None, :]
+    dq2, dh2, _, _ = _tall_vs_oracle(oracle, F, np.asfortranarray(a), 64)
+    _q_properties(F, dq2, dh2, a)
     # (2) the first panel lives in the top 64 rows only (its reflectors leave the rows below alone), the second one is
     #     upper triangular from row 64 down: every tail of the second panel is exactly zero
     b = np.zeros((m, 128), dtype=np.float32, order="F")
@@ -265,7 +344,7 @@ def test_qr_tall_falls_back_per_panel(oracle):
     rk = oracle.qr_in_place(ref, rh)
     dqr, dh = to_dev(c), to_dev(np.zeros((64, n), dtype=np.float32))
     got = F.qr_factor_in_place(dqr, dh)
-    assert 100 <= got <= n and abs(got - rk) <= 2
+    assert got == rk  # the rank test sees the whole column above the diagonal (geqrf_classic `off`)
     q = thin_q(F, dqr, dh, m, n)
     assert np.abs(q @ np.triu(to_host(dqr)[:n]).astype(np.float64) - c).max() <= 256 * np.sqrt(m) * e * np.abs(c).max()
 
