@@ -1051,10 +1051,7 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	{
 		g.raster_g = 8; // (2 ... 32 measured within 0.3 % of each other at N = 8192: DESIGN.md 3.1)
 	}
-	{
-		const char *e = getenv("FAER_HIP_GEMM_EPI");
-		g.epi_serial = e ? (atoi(e) == 0 ? 1 : 0) : 0;
-	}
+	g.epi_serial = 0; // (1: one read-modify-write per element, the pre-round-1-fix epilogue; kept for the record, profiles/r01_exp_syrk_rates.txt)
 	const bool extra_path = ex.diag || ex.a_struct || ex.b_struct;
 	if (ex.k_trim || ex.tri_skip || ex.stair_nb)
 		FH_CHECK(!extra_path && !indexed && !ex.inplace && ctx().gemm_variant < 10, "gemm: k_trim / tri_skip / stair_nb need the plain dense kernel");
@@ -1148,8 +1145,7 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	// K = rows of the panel, a few tiles of output) split from K = 1024 in slices of >= 256 (measured: square QR
 	// N = 4096 99.6 -> 80.2 ms); triangular outputs (the diagonal-block updates of the blocked Cholesky, which sit
 	// on its critical chain) keep the coarser rule, the finer one cost the N = 16384 factorization 0.6 ms.
-	static const idx_t splitk_mink = getenv("FAER_HIP_SPLITK_MINK") ? atol(getenv("FAER_HIP_SPLITK_MINK")) : 1024;
-	static const idx_t splitk_chunk = getenv("FAER_HIP_SPLITK_CHUNK") ? atol(getenv("FAER_HIP_SPLITK_CHUNK")) : 256;
+	const idx_t splitk_mink = 1024, splitk_chunk = 256;
 	const idx_t mink = kind == DST_FULL ? splitk_mink : 4096, chunk = kind == DST_FULL ? splitk_chunk : 1024;
 	if (tiles < 256 && k >= mink && !indexed && !ex.k_trim && !ex.stair_nb) {
 		splits = (int) ((512 + tiles - 1) / tiles);

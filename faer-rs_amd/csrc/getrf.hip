@@ -641,7 +641,6 @@ template <typename T> struct LuWork {
 	xwg_u64 epoch_base; // epochs consumed by earlier leaf launches of this factorization
 	unsigned char *wws = nullptr; // LW_WS_BYTES of getrf_wpanel_kernel's exchange records (zeroed once per factorization)
 	int *status;
-	hipEvent_t after_leaf = nullptr; // look-ahead: the stream waits for this event right after the next leaf launch
 	bool general = false;		 // every leaf on the non-cooperative path (rerun after an exchange timeout, debug switch)
 };
 
@@ -835,10 +834,6 @@ template <typename T> static void getrf_leaf_general(MatV<T> P, int col0, int ro
 			hipLaunchKernelGGL(lug_update_kernel<T>, dim3(nwg), dim3(256), 0, s, a);
 	}
 	FH_HIP(hipGetLastError());
-	if (wk.after_leaf) {
-		stream_wait(s, wk.after_leaf);
-		wk.after_leaf = nullptr;
-	}
 }
 
 // (A second-generation panel kernel -- one hop per column on the dependent chain, logical row indices instead of physical
@@ -849,12 +844,6 @@ template <typename T, int W> static void launch_leaf(int G, hipStream_t s, const
 	hipLaunchKernelGGL((getrf_panel2_kernel<T, W, (sizeof(T) == 8 ? 64 : 128) / W>), dim3(G), dim3(LU2_NT), 0, s, a);
 }
 
-// A/B switch of the round (removed once the old kernel is only the fallback): FAER_HIP_LU_PANEL=2 keeps getrf_panel2_kernel
-static bool wpanel_enabled()
-{
-	static const bool on = !(getenv("FAER_HIP_LU_PANEL") && atoi(getenv("FAER_HIP_LU_PANEL")) == 2);
-	return on;
-}
 // timing build: 16 device words that receive the per-phase tick sums of the panel kernel (lu_dump_timing)
 static unsigned long long *g_lu_phase = nullptr;
 static unsigned long long *lu_phase_words()
@@ -894,7 +883,7 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 		return;
 	}
 	FH_CHECK(w <= lw, "getrf leaf: panel too wide");
-	if (lw == LU_W && w <= m && wk.wws && wpanel_enabled()) {
+	if (lw == LU_W && w <= m && wk.wws) {
 		// round-4 kernel (lu_wpanel.h): one exchange per column.  64 x RPT rows per wavefront; four wavefronts per workgroup
 		// (one per SIMD) while that many workgroups are resident, else eight
 		constexpr int RPT = sizeof(T) == 8 ? 1 : 2;
@@ -921,10 +910,6 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 				hipLaunchKernelGGL((getrf_wpanel_kernel<T, RPT, 8, 2>), dim3(g8), dim3(512), 0, s, a);
 			FH_HIP(hipGetLastError());
 			wk.epoch_base += (xwg_u64) (((w < (int) m ? w : (int) m) + 7) & ~7); // the kernel runs whole groups of 8 column steps
-			if (wk.after_leaf) {
-				stream_wait(s, wk.after_leaf);
-				wk.after_leaf = nullptr;
-			}
 			return;
 		}
 	}
@@ -966,10 +951,6 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 	const int steps = w < (int) m ? w : (int) m;
 	if (G > 1)
 		wk.epoch_base += (xwg_u64) steps;
-	if (wk.after_leaf) { // the columns right of this leaf are brought up to date by another stream: join it now
-		stream_wait(s, wk.after_leaf);
-		wk.after_leaf = nullptr;
-	}
 }
 
 static idx_t next_pow2(idx_t n)
@@ -1090,7 +1071,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		const idx_t j1 = j0 + w;
 		const idx_t w2 = j1 < n ? (LU_LA_NB < n - j1 ? LU_LA_NB : n - j1) : 0;
 		const idx_t j2 = j1 + w2;
-		hipEvent_t ev_next = nullptr, ev_next2 = nullptr;
+		hipEvent_t ev_next = nullptr;
 		{
 			StreamScope sc(c.la_bulk);
 			stream_wait(c.la_bulk, ev_panel);
@@ -1101,11 +1082,10 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			//          interchanges + solve for all of them, then the product on the next panel's columns (-> released), then on
 			//          the rest;
 			//   mode 1 (afterwards, the panel chain is critical): the next panel's columns first (all 512: with the round-4 leaf
-			//          the old split "first 64, then 448" made the panel wait for the second chain), then the rest;
-			//   mode 0: the three chains of rounds 1-3 (A/B switch FAER_HIP_LU_CHAIN).
-			static const int chain_env = getenv("FAER_HIP_LU_CHAIN") ? atoi(getenv("FAER_HIP_LU_CHAIN")) : -1;
-			static const idx_t one_chain_rows = getenv("FAER_HIP_LU_CHAIN_ROWS") ? atol(getenv("FAER_HIP_LU_CHAIN_ROWS")) : 10240;
-			const int mode = chain_env >= 0 ? (chain_env == 3 ? (m - j1 >= one_chain_rows ? 2 : 1) : chain_env) : (m - j1 >= one_chain_rows ? 2 : 1);
+			//          the split "first 64, then 448" of rounds 1-3 made the panel wait for the second chain), then the rest.
+			// Measured in one visit (profiles/r04_exp_lu_chain_grouping.txt, N = 16384): three chains 107.9 ms, mode 1 everywhere
+			// 102.4, mode 2 everywhere 101.6, mode 2 down to 10240 remaining rows 100.7.
+			const int mode = m - j1 >= 10240 ? 2 : 1;
 			if (w2 > 0 && mode == 2) {
 				swaps(k, j0, w, j1, n - j1);
 				MatV<T> U = A.sub(j0, j1, w, n - j1);
@@ -1117,17 +1097,9 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 				if (j2 < n && m > j1)
 					gemm_dev<T>(A.sub(j1, j2, m - j1, n - j2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), U.sub(0, w2, w, n - j2).c(), (T) -1);
 			} else if (w2 > 0) {
-				// mode 0: the next panel starts with a leaf on its first LU_W columns: release it as soon as those are up to
-				// date, the other columns of the panel follow while that leaf runs
-				const idx_t wa = (w2 < LU_W || mode == 1) ? w2 : (idx_t) LU_W;
-				update(k, j0, w, j1, wa);
+				update(k, j0, w, j1, w2);
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
-				if (w2 > wa) {
-					update(k, j0, w, j1 + wa, w2 - wa);
-					ev_next2 = c.next_event();
-					FH_HIP(hipEventRecord(ev_next2, c.la_bulk));
-				}
 				if (j2 < n)
 					update(k, j0, w, j2, n - j2);
 			}
@@ -1160,7 +1132,6 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		if (w2 > 0) {
 			StreamScope sc(c.la_panel);
 			stream_wait(c.la_panel, ev_next);
-			wk.after_leaf = ev_next2;
 			getrf_rec<T>(A.sub(j1, j1, m - j1, w2), (int) j1, (int) j1, wk);
 			if (use_lists)
 				laswp_compose_list(wk.piv + j1, (int) w2, (int) j1, lists[(k + 1) & 1]);
@@ -1237,7 +1208,6 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 				copy_dev<T>(A.sub(0, 0, m, size), Bk.c());
 				FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
 				wk.general = true;
-				wk.after_leaf = nullptr;
 				getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);
 			}
 		}

@@ -175,7 +175,7 @@ template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV
 	if (off)
 		return false;
 	idx_t m = C.nrows, n = C.ncols, k = A.ncols;
-	static const idx_t LONG = getenv("FAER_HIP_SKINNY_MIN") ? atol(getenv("FAER_HIP_SKINNY_MIN")) : 256;
+	const idx_t LONG = 256;
 	// ---- update, possibly on the transposed problem (C^T = B^T A^T)
 	if (n >= LONG && m <= 32 && k <= 16 && iabs3(C.cs) == 1 && iabs3(B.cs) == 1) {
 		MatV<T> Ct = C.t();
@@ -189,17 +189,17 @@ template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV
 	if (m >= LONG && m < (1L << 31) && n <= 32 && k <= 16 && iabs3(C.rs) == 1 && iabs3(A.rs) == 1) {
 		// rows per thread: few -- the launch needs thousands of workgroups in flight to cover the HBM latency
 		// (measured at 5e5 rows: 8 rows per thread = 245 workgroups ran at 1.5 TB/s)
-		static const int rsel = getenv("FAER_HIP_SKINNY_R") ? atoi(getenv("FAER_HIP_SKINNY_R")) : 2;
+		// (2 rows per thread: 1 and 4 measured slower in round 1)
 		if (k <= 8)
-			rsel == 1 ? launch_update<T, 8, 1>(C, add, A, B, alpha) : rsel == 2 ? launch_update<T, 8, 2>(C, add, A, B, alpha) : launch_update<T, 8, 4>(C, add, A, B, alpha);
+			launch_update<T, 8, 2>(C, add, A, B, alpha);
 		else
-			rsel == 1 ? launch_update<T, 16, 1>(C, add, A, B, alpha) : rsel == 2 ? launch_update<T, 16, 2>(C, add, A, B, alpha) : launch_update<T, 16, 4>(C, add, A, B, alpha);
+			launch_update<T, 16, 2>(C, add, A, B, alpha);
 		return true;
 	}
 	// ---- reduce
 	if (k >= LONG && k < (1L << 31) && m <= 16 && n <= 16 && iabs3(A.cs) == 1 && iabs3(B.rs) == 1) {
 		const idx_t blocks = ((m + 7) / 8) * ((n + 7) / 8);
-		static const idx_t wgs = getenv("FAER_HIP_SKINNY_WGS") ? atol(getenv("FAER_HIP_SKINNY_WGS")) : 512;
+		const idx_t wgs = 512;
 		idx_t slices = wgs / blocks;
 		idx_t kps = (k + slices - 1) / slices;
 		kps = (kps + 511) / 512 * 512;
