@@ -30,6 +30,7 @@
 
 #include "common.h"
 #include "lds_blocks.h"
+#include "mfma.h"
 #include "xwg.h"
 #include "lu_wpanel.h"
 
@@ -454,9 +455,11 @@ __global__ void scatter_rows_kernel(T *B, idx_t rs, idx_t cs, int nrows, int nco
 constexpr int LASWP_SMALL_NT = 512;
 constexpr int LASWP_CC = 8;
 
+// `top_out` (optional, nt x ncols, column major with pitch nt): receives a copy of the rows 0 .. nt-1 AFTER the interchanges
+// (the fused node update below reads the block it overwrites from there).
 template <typename T>
 __global__ __launch_bounds__(256) void laswp_small_kernel(T *B, idx_t rs, idx_t cs, int nrows, int ncols,
-							  const int *__restrict__ piv, int nt, int row_base)
+							  const int *__restrict__ piv, int nt, int row_base, T *top_out)
 {
 	__shared__ int s_piv[LASWP_SMALL_NT];
 	__shared__ int s_dst[2 * LASWP_SMALL_NT], s_src[2 * LASWP_SMALL_NT];
@@ -508,6 +511,126 @@ __global__ __launch_bounds__(256) void laswp_small_kernel(T *B, idx_t rs, idx_t 
 		const int c = idx / ne, e = idx - c * ne;
 		if (s_src[e] >= 0)
 			B[(idx_t) s_dst[e] * rs + (idx_t) (c0 + c) * cs] = tmp[idx];
+	}
+	if (top_out) {
+		for (int idx = tid; idx < nc * nt; idx += 256) {
+			const int c = idx / nt, d = idx - c * nt; // (entry e = d of the lists is row d)
+			top_out[(size_t) (c0 + c) * nt + d] = s_src[d] >= 0 ? tmp[c * ne + d] : B[(idx_t) d * rs + (idx_t) (c0 + c) * cs];
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused update of the right sibling of a 64-column leaf (the 128-column nodes of the recursion, factor.rs:98-117):
+//     A01 <- L00^-1 A01  (64 x nr, unit lower L00),   A11 -= A10 A01  ((m - 64) x nr, K = 64)
+// in ONE launch instead of substitution leaf + product (28 + 45-65 us on the panel stream's 32 CUs, each bound by its own
+// latency): every workgroup solves the 64 x 64 system itself from the copy of the interchanged top block the interchange
+// launch left in `top` (so nobody reads what workgroup 0 overwrites with A01), then updates its own 256 rows on the
+// matrix cores straight from / to memory.
+//   * solve: thread = column c of the block, wavefront w holds the rows 16 w .. 16 w + 15 in registers; four 16-row steps:
+//     the owner substitutes inside its diagonal block (multipliers are LDS broadcasts), writes its rows of U to LDS, the
+//     wavefronts below eliminate against them;
+//   * product: D' = (A10 A01)^T per 16 x 16 tile (mfma.h: operand a = U[k][c], b = -L[r][k]), so that 16 consecutive lanes
+//     hold 16 consecutive rows of a column: 128-byte accesses in the column-major panel.
+// ------------------------------------------------------------------------------------------------
+constexpr int LUN_W = 64;   // left width = rows of the triangular system
+constexpr int LUN_LP = 65;  // LDS pitch of L00 (row major: broadcast reads)
+constexpr int LUN_UP = 80;  // LDS pitch of U (k major; pitch = 16 mod 32 keeps the four k groups of an operand read on disjoint banks)
+constexpr int LUN_ROWS = 256; // rows of A11 per workgroup
+
+template <typename T>
+__global__ __launch_bounds__(256) void lu_node64_kernel(T *P, idx_t cs, int m, int nr, const T *__restrict__ top)
+{
+	typedef typename Mfma<T>::acc_t acc_t;
+	__shared__ T Ls[LUN_W * LUN_LP];
+	__shared__ T Us[LUN_W * LUN_UP];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int l15 = lane & 15, lhi = lane >> 4;
+	T *B = P + (idx_t) LUN_W * cs; // the right block
+	// ---- L00 (strictly lower part is used) and this thread's 16 rows of column c = lane of the interchanged top block
+#pragma unroll
+	for (int j = 0; j < LUN_W / 4; ++j) {
+		const int k = wave + 4 * j;
+		Ls[lane * LUN_LP + k] = P[lane + (idx_t) k * cs];
+	}
+	T u[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		u[i] = lane < nr ? top[(size_t) lane * LUN_W + 16 * wave + i] : (T) 0;
+	__syncthreads();
+	// ---- U = L00^-1 top (factor.rs:104-109 -> triangular_solve.rs: forward substitution, unit diagonal)
+#pragma unroll
+	for (int kb = 0; kb < 4; ++kb) {
+		if (wave == kb) {
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+#pragma unroll
+				for (int i = k + 1; i < 16; ++i)
+					u[i] = fh_fma(-Ls[(16 * kb + i) * LUN_LP + 16 * kb + k], u[k], u[i]);
+			}
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				Us[(16 * kb + i) * LUN_UP + lane] = u[i];
+		}
+		__syncthreads();
+		if (wave > kb) {
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				const T uk = Us[(16 * kb + k) * LUN_UP + lane];
+#pragma unroll
+				for (int i = 0; i < 16; ++i)
+					u[i] = fh_fma(-Ls[(16 * wave + i) * LUN_LP + 16 * kb + k], uk, u[i]);
+			}
+		}
+	}
+	// ---- workgroup 0 stores A01 (lanes along the rows)
+	if (blockIdx.x == 0) {
+		for (int idx = tid; idx < LUN_W * nr; idx += 256) {
+			const int d = idx & (LUN_W - 1), c = idx >> 6;
+			B[d + (idx_t) c * cs] = Us[d * LUN_UP + c];
+		}
+	}
+	// ---- A11 -= A10 A01 on this workgroup's rows: wavefront w takes 64 of them, 16 at a time
+	const int rb = LUN_W + (int) blockIdx.x * LUN_ROWS + wave * 64;
+#pragma unroll 1
+	for (int rt = 0; rt < 4; ++rt) {
+		const int r0 = rb + 16 * rt;
+		if (r0 >= m) // wave uniform
+			break;
+		const int r = r0 + l15;
+		const bool rin = r < m;
+		T bneg[16]; // b operand of step k0 = 4 j: -L[r][4 j + lhi]
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+			const T v = P[(rin ? r : m - 1) + (idx_t) (4 * j + lhi) * cs];
+			bneg[j] = rin ? -v : (T) 0;
+		}
+		acc_t acc[4];
+#pragma unroll
+		for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int c = 16 * ct + Mfma<T>::row(q, lhi);
+				const bool in = rin && c < nr;
+				const T v = B[(in ? r : 0) + (idx_t) (in ? c : 0) * cs];
+				acc[ct][q] = in ? v : (T) 0;
+			}
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+#pragma unroll
+			for (int ct = 0; ct < 4; ++ct) {
+				const T a = Us[(4 * j + lhi) * LUN_UP + 16 * ct + l15];
+				acc[ct] = Mfma<T>::run(a, bneg[j], acc[ct]);
+			}
+		}
+#pragma unroll
+		for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int c = 16 * ct + Mfma<T>::row(q, lhi);
+				if (rin && c < nr)
+					B[r + (idx_t) c * cs] = acc[ct][q];
+			}
 	}
 }
 
@@ -601,7 +724,7 @@ template <typename T> static void laswp_list_dev(MatV<T> B, const LaswpList &l)
 
 // Applies the transpositions (j <-> piv[j] - row_base), j < nt, to all columns of B (B's row 0 is the
 // row the first transposition refers to).
-template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, int row_base)
+template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, int row_base, T *top_out = nullptr)
 {
 	if (B.nrows == 0 || B.ncols == 0 || nt == 0)
 		return;
@@ -609,7 +732,7 @@ template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, i
 	hipStream_t s = ctx().stream;
 	if (nt <= LASWP_SMALL_NT) {
 		hipLaunchKernelGGL(laswp_small_kernel<T>, dim3((unsigned) ((B.ncols + LASWP_CC - 1) / LASWP_CC)), dim3(256), 0, s, B.p,
-				   B.rs, B.cs, nrows, (int) B.ncols, piv, nt, row_base);
+				   B.rs, B.cs, nrows, (int) B.ncols, piv, nt, row_base, top_out);
 		FH_HIP(hipGetLastError());
 		return;
 	}
@@ -640,6 +763,7 @@ template <typename T> struct LuWork {
 	xwg_u64 *gran_diag; // [LU2_NSLOT][2 * LU_W]
 	xwg_u64 epoch_base; // epochs consumed by earlier leaf launches of this factorization
 	unsigned char *wws = nullptr; // LW_WS_BYTES of getrf_wpanel_kernel's exchange records (zeroed once per factorization)
+	T *ttop = nullptr;	      // 64 x 64 scalars: interchanged top block of a 128-column node (lu_node64_kernel)
 	int *status;
 	bool general = false;		 // every leaf on the non-cooperative path (rerun after an exchange timeout, debug switch)
 };
@@ -984,11 +1108,20 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 	MatV<T> left = P.sub(0, 0, m, bs), right = P.sub(0, bs, m, n - bs);
 	getrf_rec<T>(left, col0, row_base, wk);
 	// bring the right half up to date: swaps, A01 <- L00^-1 A01, A11 -= A10 A01 (factor.rs:98-117)
-	laswp_dev<T>(right, wk.piv + col0, (int) bs, row_base);
 	MatV<T> A00 = P.sub(0, 0, bs, bs), A01 = P.sub(0, bs, bs, n - bs), A10 = P.sub(bs, 0, m - bs, bs),
 		A11 = P.sub(bs, bs, m - bs, n - bs);
-	trsm_lower_dev<T>(A00.c(), true, A01);
-	gemm_dev<T>(A11, DST_FULL, true, A10.c(), A01.c(), (T) -1);
+	if (bs == LUN_W && n - bs <= LUN_W && P.rs == 1 && wk.ttop && m < (1L << 30)) {
+		// the 128-column nodes: interchanges (+ a copy of the interchanged top block), then solve and product in one launch
+		laswp_dev<T>(right, wk.piv + col0, (int) bs, row_base, wk.ttop);
+		const idx_t below = m - bs;
+		const unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
+		hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg), dim3(256), 0, ctx().stream, P.p, P.cs, (int) m, (int) (n - bs), (const T *) wk.ttop);
+		FH_HIP(hipGetLastError());
+	} else {
+		laswp_dev<T>(right, wk.piv + col0, (int) bs, row_base);
+		trsm_lower_dev<T>(A00.c(), true, A01);
+		gemm_dev<T>(A11, DST_FULL, true, A10.c(), A01.c(), (T) -1);
+	}
 	getrf_rec<T>(A11, col0 + (int) bs, row_base + (int) bs, wk);
 	// the right half's transpositions act on the rows below bs of the left half (factor.rs:127-185)
 	laswp_dev<T>(A10, wk.piv + col0 + bs, (int) (n - bs < m - bs ? n - bs : m - bs), row_base + (int) bs);
@@ -1159,8 +1292,10 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		Scratch granb(gran_bytes + diag_bytes);
 		Scratch misc(256);
 		Scratch wwsb(LW_WS_BYTES);
+		Scratch ttopb((size_t) LUN_W * LUN_W * sizeof(T));
 		LuWork<T> wk;
 		wk.wws = wwsb.as<unsigned char>();
+		wk.ttop = ttopb.as<T>();
 		FH_HIP(hipMemsetAsync(wwsb.p, 0, LW_WS_BYTES, ctx().stream));
 		wk.piv = pivb.as<int>();
 		wk.gran = granb.as<xwg_u64>();
@@ -1261,8 +1396,10 @@ template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev, int *status_
 	Scratch granb(gran_bytes + diag_bytes);
 	Scratch misc(256);
 	Scratch wwsb(LW_WS_BYTES);
+	Scratch ttopb((size_t) LUN_W * LUN_W * sizeof(T));
 	LuWork<T> wk;
 	wk.wws = wwsb.as<unsigned char>();
+	wk.ttop = ttopb.as<T>();
 	FH_HIP(hipMemsetAsync(wwsb.p, 0, LW_WS_BYTES, ctx().stream));
 	wk.piv = piv_dev;
 	wk.gran = granb.as<xwg_u64>();
