@@ -260,10 +260,11 @@ template <typename T> struct GemmExtra {
 	//   untouched, i.e. one launch covers "block column below the leading block + remaining lower square".
 	//   stair_nb / stair_gap (DST_LOWER, any shape): the "diagonal" is a staircase -- column n of dst stands for column
 	//   n + (n / stair_nb) * stair_gap of the matrix it is a part of (the owned block columns of a 1-D block-cyclic
-	//   partition next to each other: dist_llt.h), entries above it are left untouched.
+	//   partition next to each other: dist_llt.h), entries above it are left untouched.  stair_row0: row 0 of dst is row
+	//   stair_row0 of that picture (a row chunk of the staircase: dst(i, n) is written iff i + stair_row0 >= that column).
 	int k_trim = 0;
 	idx_t tri_skip = 0;
-	idx_t stair_nb = 0, stair_gap = 0;
+	idx_t stair_nb = 0, stair_gap = 0, stair_row0 = 0;
 };
 
 // dst(kind) <- [dst +] alpha * A * diag * B        (gemm.hip)

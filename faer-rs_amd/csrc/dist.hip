@@ -45,13 +45,13 @@ struct PhaseTimer {
 };
 
 // dst(c, k) = P(c + (c / nb) * gap, k): the rows of the received panel that belong to the owned block columns, contiguous
-// (the rhs of the staircase product of dist_llt.h); dst column major with leading dimension ncols
-template <typename T> __global__ void gather_stair_kernel(const T *P, long prs, long pcs, long ncols, long w, long nb, long gap, T *dst)
+// (the rhs of the staircase product of dist_llt.h); dst column major with leading dimension ld
+template <typename T> __global__ void gather_stair_kernel(const T *P, long prs, long pcs, long ncols, long w, long nb, long gap, T *dst, long ld)
 {
 	const long c = (long) blockIdx.x * blockDim.x + threadIdx.x;
 	const long k = blockIdx.y;
 	if (c < ncols)
-		dst[k * ncols + c] = P[(c + (c / nb) * gap) * prs + k * pcs];
+		dst[k * ld + c] = P[(c + (c / nb) * gap) * prs + k * pcs];
 }
 
 template <typename S> struct DeviceBackend {
@@ -88,10 +88,25 @@ template <typename S> struct DeviceBackend {
 		else
 			bcast(buf, bytes, root);
 	}
+	// The transport's wait orders the CURRENT stream of its own world behind the transfer: the built-in RCCL transport that
+	// is ctx().stream, a callback transport (torch.distributed handles) the caller's stream.  Called from the look-ahead or the
+	// rest part (dist_llt.h waits for a chunk where it is first read, on the panel / bulk stream), the wait is therefore taken
+	// on the caller's stream and handed to the internal stream through an event.
 	void bcast_wait(int slot)
 	{
-		if (comm.ibcast && comm.wait)
+		if (!(comm.ibcast && comm.wait))
+			return;
+		hipStream_t cur = ctx().stream;
+		if (caller && cur != caller) {
+			ctx().stream = caller;
 			comm.wait(comm.user, slot);
+			hipEvent_t e = ctx().next_event();
+			FH_HIP(hipEventRecord(e, caller));
+			ctx().stream = cur;
+			stream_wait(cur, e);
+		} else {
+			comm.wait(comm.user, slot);
+		}
 	}
 	// ---- two-stream schedule inside the rank (dist_lu.h): the rest of update k on the bulk stream, the look-ahead part
 	// (update of block column k+1 + its panel factorization, cooperative leaves on the reserved CUs) on the panel stream
@@ -164,6 +179,22 @@ template <typename S> struct DeviceBackend {
 		FH_HIP(hipEventRecord(ev_ahead, ctx().la_panel));
 		ctx().stream = caller;
 	}
+	// inside the look-ahead part (dist_llt.h: the broadcast of a chunk): the caller's stream joins the panel stream's work so
+	// far and takes the next launches / transport calls; the panel stream goes on afterwards
+	void ahead_pause()
+	{
+		if (!two_now)
+			return;
+		hipEvent_t e = ctx().next_event();
+		FH_HIP(hipEventRecord(e, ctx().la_panel));
+		stream_wait(caller, e);
+		ctx().stream = caller;
+	}
+	void ahead_resume()
+	{
+		if (two_now)
+			ctx().stream = ctx().la_panel;
+	}
 	void ahead_join()
 	{
 		if (two_now && ev_ahead) {
@@ -194,20 +225,37 @@ template <typename S> struct DeviceBackend {
 		potrf_panel_dev<T>(mv(P), reg_delta, reg_eps, status, (idx_t) offset);
 		t_panel.end();
 	}
+	// X <- X L^-T (cholesky/ldlt/factor.rs:422-426, expressed like the reference as L \ X^T); counted as panel time
+	void solve_rows(View L, View X)
+	{
+		if (X.nrows <= 0)
+			return;
+		t_panel.begin();
+		trsm_lower_dev<T>(mv(L).c(), false, mv(X).t());
+		t_panel.end();
+	}
 	void syrk_sub(View C, View A, View Bt) { gemm_dev<T>(mv(C), DST_LOWER, true, mv(A).c(), mv(Bt).t().c(), (T) -1); }
-	void gather_stair(View P, long ncols, long nb, long gap, T *dst)
+	void gemm_sub_nt(View C, View A, View Bt)
+	{
+		if (C.nrows > 0 && C.ncols > 0)
+			gemm_dev<T>(mv(C), DST_FULL, true, mv(A).c(), mv(Bt).t().c(), (T) -1);
+	}
+	void gather_stair(View P, long ncols, long nb, long gap, T *dst, long ld)
 	{
 		if (ncols <= 0 || P.ncols <= 0)
 			return;
 		hipLaunchKernelGGL(gather_stair_kernel<T>, dim3((unsigned) ((ncols + 255) / 256), (unsigned) P.ncols), dim3(256), 0, ctx().stream, P.p, P.rs,
-				   P.cs, ncols, P.ncols, nb, gap, dst);
+				   P.cs, ncols, P.ncols, nb, gap, dst, ld);
 		FH_HIP(hipGetLastError());
 	}
-	void syrk_stair_sub(View C, View A, View Bt, long nb, long gap)
+	void syrk_stair_sub(View C, View A, View Bt, long nb, long gap, long row0)
 	{
+		if (C.nrows <= 0 || C.ncols <= 0)
+			return;
 		GemmExtra<T> ex;
 		ex.stair_nb = (idx_t) nb;
 		ex.stair_gap = (idx_t) gap;
+		ex.stair_row0 = (idx_t) row0;
 		gemm_dev<T>(mv(C), DST_LOWER, true, mv(A).c(), mv(Bt).t().c(), (T) -1, &ex);
 	}
 	void to_host(int *dst, const int *src, size_t n)

@@ -1,36 +1,49 @@
 // Distributed Cholesky (lower) over a 1-D block-cyclic column partition: one process per
-// GPU, ONE broadcast per block column -- the factored column panel L[k:, k] from its owner -- and purely local
-// rank-nb updates of the owned block columns.  Same mathematics as the single-GPU driver
-// (cholesky/ldlt/factor.rs:367-498 with is_llt): panel = Cholesky of the diagonal block + solve of the rows below
-// (:407-433), trailing update lower(A11) -= L10 L10^T (:436-446) restricted to the columns a rank owns.
+// GPU, the solved rows L[k+1:, k] of every block column broadcast from its owner, purely local rank-nb updates of the
+// owned block columns.  Same mathematics as the single-GPU driver (cholesky/ldlt/factor.rs:367-498 with is_llt):
+// panel = Cholesky of the diagonal block + solve of the rows below (:407-433), trailing update lower(A11) -= L10 L10^T
+// (:436-446) restricted to the columns a rank owns.
 //
-// Look-ahead: the owner of block column k+1 updates and factors that column FIRST and starts its broadcast; every
-// rank posts the receive before it runs the rest of update k, so the transfer of panel k+1 (and the latency-bound
-// panel factorization on its owner) overlaps with the trailing updates of step k.  Two panel buffers alternate.
+// Round 4: the panel travels in ROW CHUNKS.  Once L_kk is known the rows of A21 L_kk^-T are independent of each other
+// (factor.rs:422-426), so the owner solves, packs and broadcasts the rows below the diagonal block in up to LLT_NCH
+// block-aligned chunks -- chunk c's transfer overlaps chunk c + 1's solve -- and every receiver updates the rows of a
+// chunk as soon as that chunk has arrived: the rows of the panel that multiply an owned column lie in the same or an
+// earlier chunk (lower triangle).  The owner of block column k + 1 does the same in its look-ahead part: diagonal block
+// after chunk 0 of panel k, then chunk by chunk "update rows, solve, pack, start the broadcast".  With the whole panel as
+// ONE message (rounds 2-3) every step carried "panel + transfer of up to 134 MB" on its critical chain; now it carries one
+// diagonal block and one chunk.  The diagonal block itself is needed by nobody else and stays home.
+//
+// Look-ahead: the owner of block column k+1 updates and factors that column FIRST and starts its broadcasts; every
+// rank posts the receives before it runs the rest of update k.  Two panel buffers alternate.
 // On the owner the look-ahead part is issued first (an asynchronous backend queues it on its panel stream) and the
 // rest of the update second (bulk stream): the two run concurrently inside the rank, as in dist_lu.h.
 //
-// The rest of update k is ONE product per rank, not one per owned block column: the owned block columns right of the
-// panel lie next to each other in A_local, the rows of the panel that belong to them are gathered into a contiguous
-// operand, and the product writes the lower part under a STAIRCASE (block column i of the range starts `world` blocks
-// further down than block column i - 1).  Per entry the arithmetic is that of the block-by-block update.
+// The rest of update k is one staircase product per rank AND CHUNK, not one per owned block column: the owned block
+// columns right of the panel lie next to each other in A_local, the rows of the panel that belong to them are gathered
+// into a contiguous operand as their chunks arrive, and the product writes the lower part under a STAIRCASE (block
+// column i of the range starts `world` blocks further down than block column i - 1).  Per entry the arithmetic is that
+// of the block-by-block update.
 //
 // Template over a backend like dist_lu.h (device backend in dist.hip, host backend under tests/).  Backend B:
 //   typedef scalar T;  struct View { T *p; long nrows, ncols, rs, cs; };
-//   void potrf_panel(View P, long offset, int *status)   -- P: rows x w, top w x w block = diagonal block (lower part
-//                                                           referenced); in place: L_kk and the solved rows below.
-//                                                           status (backend memory): [0] = first failing global index
-//                                                           + 1 (kept if already set), [1] += regularisation count
+//   void potrf_panel(View P, long offset, int *status)   -- here: P = the w x w diagonal block (lower part referenced), in
+//                                                           place.  status (backend memory): [0] = first failing global
+//                                                           index + 1 (kept if already set), [1] += regularisation count
+//   void solve_rows(View L, View X)                      -- X <- X L^-T (rows below the diagonal block, any subset)
 //   void syrk_sub(View C, View A, View Bt)               -- C -= A * Bt^T; rows 0..C.ncols-1 of C: lower part only
-//   void gather_stair(View P, long ncols, long nb, long gap, T *dst)
-//                                                        -- dst (ncols x P.ncols, column major, ld = ncols) <- the rows
-//                                                           c + (c / nb) * gap of P, c < ncols
-//   void syrk_stair_sub(View C, View A, View Bt, long nb, long gap)
-//                                                        -- C(i, c) -= (A Bt^T)(i, c) for i >= c + (c / nb) * gap
+//   void gemm_sub_nt(View C, View A, View Bt)            -- C -= A * Bt^T (all of C)
+//   void gather_stair(View P, long ncols, long nb, long gap, T *dst, long ld)
+//                                                        -- dst(c, :) <- row c + (c / nb) * gap of P, c < ncols (dst column
+//                                                           major with leading dimension ld)
+//   void syrk_stair_sub(View C, View A, View Bt, long nb, long gap, long row0)
+//                                                        -- C(i, c) -= (A Bt^T)(i, c) for i + row0 >= c + (c / nb) * gap
 //   void step_begin(long local_trailing_entries, long next_panel_rows) / rest_begin() / rest_end() / ahead_begin() /
 //        ahead_end() / ahead_join() / run_end()          -- scheduling hooks as in dist_lu.h
+//   void ahead_pause() / ahead_resume()                  -- inside the look-ahead part: what follows (a broadcast) is issued
+//                                                           on the caller's context, ordered behind the look-ahead work so far
 //   void pack(View src, T *dst)                          -- contiguous column-major copy into the panel buffer
-//   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)
+//   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)   -- slots 0 .. 2 LLT_NCH - 1;
+//                                                           a slot may be waited for more than once (once per context)
 //   void bcast(void *buf, size_t bytes, int root)        -- blocking (status exchange at the end)
 //   void to_host(int *dst, const int *src, size_t n)     -- synchronising
 //   void zero_ints(int *p, size_t n)
@@ -40,6 +53,8 @@
 
 namespace fh {
 
+constexpr int LLT_NCH = 4; // row chunks of a panel (fewer when fewer block rows remain)
+
 template <class B> struct DistLlt {
 	typedef typename B::T T;
 	typedef typename B::View View;
@@ -48,6 +63,37 @@ template <class B> struct DistLlt {
 	static size_t buf_scalars(long n, long nb) { return (size_t) n * (size_t) nb; }
 	// [status: 4 ints][panel buffer 0][panel buffer 1][gathered panel rows of the owned block columns]
 	static size_t ws_scalars(long n, long nb) { return hdr_scalars() + 3 * buf_scalars(n, nb); }
+
+	// chunks of panel k: the block rows k + 1 .. nblk - 1 in nch nearly equal block-aligned pieces; chunk c = rows [g[c], g[c + 1])
+	struct Plan {
+		int nch;
+		long g[LLT_NCH + 1];
+	};
+	static Plan plan(long k, long nblk, long n, long nb)
+	{
+		Plan p;
+		const long tb = nblk - k - 1;
+		p.nch = (int) (tb < LLT_NCH ? tb : LLT_NCH);
+		for (int c = 0; c <= LLT_NCH; ++c)
+			p.g[c] = n;
+		for (int c = 0; c < p.nch; ++c)
+			p.g[c] = (k + 1 + (c * tb) / p.nch) * nb;
+		return p;
+	}
+	// number of chunk broadcasts and their bytes for an n x n matrix (what the tests expect on the wire)
+	static void wire(long n, long nb, size_t scalar_bytes, long *messages, size_t *bytes)
+	{
+		const long nblk = (n + nb - 1) / nb;
+		*messages = 0;
+		*bytes = 0;
+		for (long k = 0; k < nblk; ++k) {
+			const Plan p = plan(k, nblk, n, nb);
+			const long w = (k + 1) * nb <= n ? nb : n - k * nb;
+			*messages += p.nch;
+			if (p.nch > 0)
+				*bytes += (size_t) (n - p.g[0]) * (size_t) w * scalar_bytes;
+		}
+	}
 
 	// A_local: n x local_ncols (this rank's block columns in increasing global order, full height; only the lower
 	// triangle of the global matrix is referenced or written).  Returns -(index + 1) for the first non-positive
@@ -69,21 +115,42 @@ template <class B> struct DistLlt {
 		auto view = [&](long r0, long c0, long nr, long nc) {
 			return View{A_local.p + r0 * A_local.rs + c0 * A_local.cs, nr, nc, A_local.rs, A_local.cs};
 		};
-		auto factor_and_pack = [&](long k) { // owner of block column k
-			const long j0 = k * nb, w = width(k), rows = n - j0, lc = local_col0(k);
-			be.potrf_panel(view(j0, lc, rows, w), j0, status);
-			be.pack(view(j0, lc, rows, w), buf(k));
+		auto slot = [&](long k, int c) { return (int) ((k & 1) * LLT_NCH + c); };
+		// rows [r0, r1) of panel k inside its chunk c, as packed in the panel buffer (chunk c: column major, ld = its rows)
+		auto chunk_rows = [&](long k, const Plan &p, int c, long r0, long r1) {
+			const long w = width(k), ld = p.g[c + 1] - p.g[c];
+			T *base = buf(k) + (size_t) (p.g[c] - p.g[0]) * (size_t) w;
+			return View{base + (r0 - p.g[c]), r1 - r0, w, 1, ld};
 		};
-		auto update = [&](long k, long b) { // block column b (owned by this rank, b > k) -= panel k
-			const long j0 = k * nb, w = width(k), rows = n - j0;
-			const long bc0 = b * nb, bw = width(b), lc = local_col0(b), off = bc0 - j0;
-			View P{buf(k), rows, w, 1, rows};
-			be.syrk_sub(view(bc0, lc, n - bc0, bw), View{P.p + off, rows - off, w, 1, rows}, View{P.p + off, bw, w, 1, rows});
+		// each (context, chunk) waits for the chunk's transfer at most once: 0 = look-ahead part, 1 = rest of the update
+		bool waited[2][LLT_NCH];
+		auto wait_chunk = [&](long k, int c, int ctx) {
+			if (!waited[ctx][c]) {
+				be.bcast_wait(slot(k, c));
+				waited[ctx][c] = true;
+			}
+		};
+		// owner of block column k, its diagonal block factored: chunk c of the rows below -- solve, pack, start the broadcast
+		auto produce_chunk = [&](long k, const Plan &p, int c) {
+			const long j0 = k * nb, w = width(k), lc = local_col0(k), rows = p.g[c + 1] - p.g[c];
+			be.solve_rows(view(j0, lc, w, w), view(p.g[c], lc, rows, w));
+			View dst = chunk_rows(k, p, c, p.g[c], p.g[c + 1]);
+			be.pack(view(p.g[c], lc, rows, w), dst.p);
+			be.ahead_pause();
+			be.bcast_begin(dst.p, (size_t) rows * (size_t) w * sizeof(T), (int) (k % world), slot(k, c));
+			be.ahead_resume();
+		};
+		auto post_receives = [&](long k) {
+			const Plan p = plan(k, nblk, n, nb);
+			for (int c = 0; c < p.nch; ++c) {
+				View dst = chunk_rows(k, p, c, p.g[c], p.g[c + 1]);
+				be.bcast_begin(dst.p, (size_t) dst.nrows * (size_t) width(k) * sizeof(T), (int) (k % world), slot(k, c));
+			}
 		};
 		T *gbuf = bufs + 2 * bsz;
 		// the rest of update k: all owned block columns right of the panel (without block k + 1 if this rank brings it up
-		// to date in the look-ahead part) in one staircase product
-		auto rest = [&](long k, bool skip_next) {
+		// to date in the look-ahead part), one staircase product per chunk of the panel as the chunks arrive
+		auto rest = [&](long k, const Plan &p, bool skip_next) {
 			be.rest_begin();
 			long b0 = -1, c_first = 0, c_all = 0; // first block of the range, its first local column, local columns in all
 			for (long b = rank; b < nblk; b += world) {
@@ -94,19 +161,44 @@ template <class B> struct DistLlt {
 				c_all += width(b);
 			}
 			if (b0 >= 0) {
-				const long j0 = k * nb, w = width(k), rows = n - j0, off = b0 * nb - j0, nc = c_all - c_first;
-				View Pk{buf(k) + off, rows - off, w, 1, rows};
-				be.gather_stair(Pk, nc, nb, (world - 1) * nb, gbuf);
-				be.syrk_stair_sub(view(b0 * nb, c_first, n - b0 * nb, nc), Pk, View{gbuf, nc, w, 1, nc}, nb, (world - 1) * nb);
+				const long nc = c_all - c_first, gap = (world - 1) * nb;
+				long nc_done = 0, b_next = b0; // gathered columns so far, next owned block to gather
+				for (int c = 0; c < p.nch; ++c) {
+					if (p.g[c + 1] <= b0 * nb)
+						continue; // rows above the first owned column: nothing to update
+					wait_chunk(k, c, 1);
+					// rows of the owned blocks that start inside this chunk
+					long ncols_c = 0;
+					const long b_first = b_next;
+					while (b_next < nblk && b_next * nb < p.g[c + 1]) {
+						ncols_c += width(b_next);
+						b_next += world;
+					}
+					if (ncols_c > 0)
+						be.gather_stair(chunk_rows(k, p, c, b_first * nb, p.g[c + 1]), ncols_c, nb, gap, gbuf + nc_done, nc);
+					nc_done += ncols_c;
+					const long r0 = p.g[c] > b0 * nb ? p.g[c] : b0 * nb;
+					be.syrk_stair_sub(view(r0, c_first, p.g[c + 1] - r0, nc_done), chunk_rows(k, p, c, r0, p.g[c + 1]),
+							  View{gbuf, nc_done, width(k), 1, nc}, nb, gap, r0 - b0 * nb);
+				}
 			}
 			be.rest_end();
 		};
 		be.zero_ints(status, 4);
-		if (rank == 0 % world)
-			factor_and_pack(0);
-		be.bcast_begin(buf(0), (size_t) n * (size_t) width(0) * sizeof(T), 0, 0);
+		{
+			const Plan p0 = plan(0, nblk, n, nb);
+			if (rank == 0 % world) {
+				be.potrf_panel(view(0, local_col0(0), width(0), width(0)), 0, status);
+				for (int c = 0; c < p0.nch; ++c)
+					produce_chunk(0, p0, c);
+			} else {
+				post_receives(0);
+			}
+		}
 		for (long k = 0; k < nblk; ++k) {
-			be.bcast_wait((int) (k & 1));
+			const Plan p = plan(k, nblk, n, nb);
+			for (int c = 0; c < LLT_NCH; ++c)
+				waited[0][c] = waited[1][c] = false;
 			const bool ahead = k + 1 < nblk;
 			const int next_owner = ahead ? (int) ((k + 1) % world) : -1;
 			{ // trailing entries this rank updates in this step, rows of the next panel: does the step use both streams?
@@ -117,18 +209,36 @@ template <class B> struct DistLlt {
 				be.step_begin((n - k * nb) * right / 2, n - (k + 1) * nb);
 			}
 			if (ahead && rank == next_owner) {
+				// look-ahead part: block column k + 1 is brought up to date, factored and sent chunk by chunk
 				be.ahead_begin();
-				update(k, k + 1);
-				factor_and_pack(k + 1);
+				const Plan q = plan(k + 1, nblk, n, nb);
+				const long d0 = (k + 1) * nb, w1 = width(k + 1), lc1 = local_col0(k + 1);
+				wait_chunk(k, 0, 0);
+				View Bt1 = chunk_rows(k, p, 0, d0, d0 + w1); // the rows of panel k that belong to block column k + 1
+				be.syrk_sub(view(d0, lc1, w1, w1), Bt1, Bt1);
+				be.potrf_panel(view(d0, lc1, w1, w1), d0, status);
+				for (int cq = 0; cq < q.nch; ++cq) {
+					for (int c = 0; c < p.nch; ++c) {
+						const long lo = q.g[cq] > p.g[c] ? q.g[cq] : p.g[c], hi = q.g[cq + 1] < p.g[c + 1] ? q.g[cq + 1] : p.g[c + 1];
+						if (lo >= hi)
+							continue;
+						wait_chunk(k, c, 0);
+						be.gemm_sub_nt(view(lo, lc1, hi - lo, w1), chunk_rows(k, p, c, lo, hi), Bt1);
+					}
+					produce_chunk(k + 1, q, cq);
+				}
 				be.ahead_end();
-				rest(k, true); // runs beside the panel on an asynchronous backend
+				rest(k, p, true); // runs beside the panel on an asynchronous backend
 				be.ahead_join();
-				be.bcast_begin(buf(k + 1), (size_t) (n - (k + 1) * nb) * (size_t) width(k + 1) * sizeof(T), next_owner, (int) ((k + 1) & 1));
 			} else {
-				if (ahead) // post the receive before the updates: the transfer overlaps them
-					be.bcast_begin(buf(k + 1), (size_t) (n - (k + 1) * nb) * (size_t) width(k + 1) * sizeof(T), next_owner, (int) ((k + 1) & 1));
-				rest(k, false);
+				if (ahead) // post the receives before the updates: the transfers overlap them
+					post_receives(k + 1);
+				rest(k, p, false);
 			}
+			// every chunk of panel k has been waited for by somebody on this rank before its buffer is reused two steps later
+			for (int c = 0; c < p.nch; ++c)
+				if (!waited[0][c] && !waited[1][c])
+					wait_chunk(k, c, 1);
 		}
 		be.run_end();
 		// ---- outcome: every rank knows only about the panels it factored; combine (first failure, summed count)

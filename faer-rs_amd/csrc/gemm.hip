@@ -60,13 +60,13 @@ template <typename T> struct GemmArgs {
 	int k_trim;		// GemmExtra::k_trim (pipelined kernel only)
 	int tri_off;		// tri_enum: first tile of the enumeration (tiles of the skipped leading rows)
 	int raster_g;		// tile rows per raster group (pipelined kernel)
-	int stair_nb, stair_gap; // GemmExtra::stair_*: "lower" is tested against the column n + (n / stair_nb) * stair_gap
+	int stair_nb, stair_gap, stair_row0; // GemmExtra::stair_*: "lower" is tested against the column n + (n / stair_nb) * stair_gap - stair_row0
 };
 
 // column index the lower-part test of dst uses (GemmExtra::stair_nb: a staircase instead of a diagonal)
 template <typename G> static __device__ __forceinline__ int lower_col(const G &g, int n)
 {
-	return g.stair_nb ? n + (n / g.stair_nb) * g.stair_gap : n;
+	return g.stair_nb ? n + (n / g.stair_nb) * g.stair_gap - g.stair_row0 : n;
 }
 
 // FaerBlock membership test (faer/src/linalg/matmul/triangular.rs:906-977)
@@ -1048,6 +1048,7 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	g.tri_off = 0;
 	g.stair_nb = (int) ex.stair_nb;
 	g.stair_gap = (int) ex.stair_gap;
+	g.stair_row0 = (int) ex.stair_row0;
 	{
 		g.raster_g = 8; // (2 ... 32 measured within 0.3 % of each other at N = 8192: DESIGN.md 3.1)
 	}
@@ -1056,7 +1057,7 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	if (ex.k_trim || ex.tri_skip || ex.stair_nb)
 		FH_CHECK(!extra_path && !indexed && !ex.inplace && ctx().gemm_variant < 10, "gemm: k_trim / tri_skip / stair_nb need the plain dense kernel");
 	if (ex.stair_nb)
-		FH_CHECK(g.lower && !transpose && ex.stair_nb > 0 && ex.stair_gap >= 0, "gemm: stair_nb needs a lower, untransposed dst");
+		FH_CHECK(g.lower && !transpose && ex.stair_nb > 0 && ex.stair_gap >= 0 && ex.stair_row0 >= 0, "gemm: stair_nb needs a lower, untransposed dst");
 
 	// loader shapes: K-major when the k stride is the unit one (and the mn stride is not)
 	const bool akm = iabs(A.cs) == 1 && iabs(A.rs) != 1;

@@ -61,7 +61,8 @@ RcclApi *rccl_api()
 struct Rccl {
 	NcclComm comm = nullptr;
 	hipStream_t stream = nullptr;
-	hipEvent_t ready = nullptr, done[3] = {nullptr, nullptr, nullptr}; // slots 0 / 1 of the drivers + the blocking form
+	static constexpr int SLOTS = 8; // dist_llt.h: two panels x LLT_NCH chunks in flight (dist_lu.h uses slots 0 / 1)
+	hipEvent_t ready = nullptr, done[SLOTS + 1] = {}; // slots of the drivers + the blocking form (index SLOTS)
 	int rank = 0, world = 1;
 	// statistics since the last faer_hip_rccl_stats: broadcasts issued, bytes, their device time.  The timing events are a
 	// fixed ring, created on first use and destroyed with the transport: a caller that never asks for statistics holds at
@@ -121,7 +122,7 @@ void rccl_start(Rccl *r, void *buf, size_t bytes, int root, int slot)
 
 void rccl_ibcast(void *user, void *buf, size_t bytes, int root, int slot)
 {
-	FH_CHECK(slot == 0 || slot == 1, "rccl transport: slot out of range");
+	FH_CHECK(slot >= 0 && slot < Rccl::SLOTS, "rccl transport: slot out of range");
 	rccl_start(static_cast<Rccl *>(user), buf, bytes, root, slot);
 }
 void rccl_wait(void *user, int slot)
@@ -132,8 +133,8 @@ void rccl_wait(void *user, int slot)
 void rccl_bcast(void *user, void *buf, size_t bytes, int root)
 {
 	Rccl *r = static_cast<Rccl *>(user);
-	rccl_start(r, buf, bytes, root, 2);
-	FH_HIP(hipStreamWaitEvent(ctx().stream, r->done[2], 0));
+	rccl_start(r, buf, bytes, root, Rccl::SLOTS);
+	FH_HIP(hipStreamWaitEvent(ctx().stream, r->done[Rccl::SLOTS], 0));
 }
 
 } // namespace

@@ -93,13 +93,22 @@ struct HostBackend {
 	void to_host(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
 	// the look-ahead protocol of the drivers with a blocking transport: begin = the broadcast itself, wait = no-op;
 	// `begun` / `waited` let the tests check that every broadcast is started exactly once and awaited exactly once
-	long begun[2] = {0, 0}, waited[2] = {0, 0};
+	// (slots 0 / 1: dist_lu.h; 0 .. 7: the chunks of dist_llt.h, which may be waited for once per context)
+	long begun[8] = {0, 0, 0, 0, 0, 0, 0, 0}, waited[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	long pending[8] = {0, 0, 0, 0, 0, 0, 0, 0}, waits_without_transfer = 0;
 	void bcast_begin(void *buf, size_t bytes, int root, int slot)
 	{
 		++begun[slot];
+		++pending[slot];
 		bcast(buf, bytes, root);
 	}
-	void bcast_wait(int slot) { ++waited[slot]; }
+	void bcast_wait(int slot)
+	{
+		++waited[slot];
+		if (begun[slot] == 0)
+			++waits_without_transfer; // a wait for a slot nothing was ever started on
+		pending[slot] = 0;
+	}
 	// scheduling hooks of the asynchronous device backend: nothing to do on the host
 	void step_begin(long, long) {}
 	void rest_begin() {}
@@ -107,6 +116,8 @@ struct HostBackend {
 	void ahead_begin() {}
 	void ahead_end() {}
 	void ahead_join() {}
+	void ahead_pause() {}
+	void ahead_resume() {}
 	void run_end() {}
 	void copy_ints(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
 	void zero_ints(int *p, size_t n) { std::memset(p, 0, n * sizeof(int)); }
@@ -134,21 +145,44 @@ struct HostBackend {
 			}
 		}
 	}
-	void gather_stair(View P, long ncols, long nb, long gap, double *dst)
+	// X <- X L^-T, row by row (cholesky/ldlt/factor.rs:422-426)
+	void solve_rows(View L, View X)
+	{
+		for (long i = 0; i < X.nrows; ++i)
+			for (long j = 0; j < X.ncols; ++j) {
+				double s = at(X, i, j);
+				for (long k = 0; k < j; ++k)
+					s -= at(X, i, k) * at(L, j, k);
+				at(X, i, j) = s * (1.0 / at(L, j, j));
+			}
+	}
+	void gemm_sub_nt(View C, View A, View Bt)
+	{
+		for (long j = 0; j < C.ncols; ++j)
+			for (long i = 0; i < C.nrows; ++i) {
+				double s = 0.0;
+				for (long k = 0; k < A.ncols; ++k)
+					s += at(A, i, k) * at(Bt, j, k);
+				at(C, i, j) -= s;
+			}
+	}
+	void gather_stair(View P, long ncols, long nb, long gap, double *dst, long ld)
 	{
 		for (long k = 0; k < P.ncols; ++k)
 			for (long c = 0; c < ncols; ++c)
-				dst[k * ncols + c] = at(P, c + (c / nb) * gap, k);
+				dst[k * ld + c] = at(P, c + (c / nb) * gap, k);
 	}
-	void syrk_stair_sub(View C, View A, View Bt, long nb, long gap)
+	void syrk_stair_sub(View C, View A, View Bt, long nb, long gap, long row0)
 	{
-		for (long c = 0; c < C.ncols; ++c)
-			for (long i = c + (c / nb) * gap; i < C.nrows; ++i) {
+		for (long c = 0; c < C.ncols; ++c) {
+			const long first = c + (c / nb) * gap - row0;
+			for (long i = first > 0 ? first : 0; i < C.nrows; ++i) {
 				double s = 0.0;
 				for (long k = 0; k < A.ncols; ++k)
 					s += at(A, i, k) * at(Bt, c, k);
 				at(C, i, c) -= s;
 			}
+		}
 	}
 	void syrk_sub(View C, View A, View Bt)
 	{
@@ -189,10 +223,18 @@ long test_dist_llt_f64(double *a_local, long n, long local_ncols, long ld, long 
 	std::vector<double> ws(fh::DistLlt<HostBackend>::ws_scalars(n, nb));
 	HostBackend::View A{a_local, n, local_ncols, 1, ld};
 	const long r = fh::DistLlt<HostBackend>::run(be, A, n, nb, rank, world, ws.data());
+	long begun = 0, waited = 0, unawaited = 0;
+	for (int sl = 0; sl < 8; ++sl) {
+		begun += be.begun[sl];
+		waited += be.waited[sl];
+		unawaited += be.pending[sl];
+	}
 	stats[0] = be.bytes_bcast;
 	stats[1] = (unsigned long long) be.n_bcast;
-	stats[2] = (unsigned long long) (be.begun[0] + be.begun[1]);
-	stats[3] = (unsigned long long) (be.waited[0] + be.waited[1]);
+	stats[2] = (unsigned long long) begun;
+	stats[3] = (unsigned long long) waited;
+	stats[4] = (unsigned long long) (unawaited + be.waits_without_transfer); // must be 0: every chunk awaited, no stray waits
+	fh::DistLlt<HostBackend>::wire(n, nb, sizeof(double), reinterpret_cast<long *>(&stats[5]), reinterpret_cast<size_t *>(&stats[6]));
 	return r;
 }
 long test_dist_local_ncols(long n, long nb, int rank, int world) { return (long) fh::DistLu<HostBackend>::local_ncols(n, nb, rank, world); }

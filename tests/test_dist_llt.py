@@ -3,8 +3,9 @@
 The GPU product path instantiates the same template with the device backend (csrc/dist.hip); here it runs with the
 test-only host backend of tests/dist_host_backend.cpp, one process per rank, torch.distributed broadcasts.  Checked
 against the single-process oracle: the gathered lower triangle within tolerance, an untouched strict upper
-triangle, ONE broadcast per block column with exactly the panel's bytes (+ the closing status exchange), the same
-failure index on every rank for a matrix that is not positive definite."""
+triangle, the chunked transfers of every block column -- up to four row chunks of the rows below the diagonal block --
+with exactly the planned message count and bytes (+ the closing status exchange), the same failure index on every rank
+for a matrix that is not positive definite."""
 import os
 import subprocess
 import sys
@@ -39,11 +40,11 @@ def bcast(user, buf, nbytes, root_rank):
     arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(nbytes,))
     dist.broadcast(torch.from_numpy(arr), src=root_rank)
 cb = BCAST(bcast)
-stats = (C.c_ulonglong * 4)()
+stats = (C.c_ulonglong * 8)()
 r = lib.test_dist_llt_f64(a_loc.ctypes.data_as(C.c_void_p), C.c_long(n), C.c_long(a_loc.shape[1]), C.c_long(max(n, 1)), C.c_long(nb),
                           rank, world, cb, None, stats)
 np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cols=np.array(cols, dtype=np.int64), a_loc=a_loc, ret=r, bytes=stats[0], nbc=stats[1],
-         begun=stats[2], waited=stats[3])
+         begun=stats[2], waited=stats[3], stray=stats[4], wire_messages=stats[5], wire_bytes=stats[6])
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -83,13 +84,25 @@ def test_dist_llt_matches_single_process_oracle(tmp_path, oracle, world, n, nb):
     iu = np.triu_indices(n, 1)
     assert (got[iu] == -7.5).all()
     assert np.abs(got[il] - ref[il]).max() <= 200 * n * np.finfo(np.float64).eps * np.abs(ref[il]).max()
-    # ONE broadcast per block column carrying exactly the panel, plus the closing status exchange (world x 16 bytes);
-    # every broadcast begun exactly once and awaited exactly once
+    # The rows below every diagonal block travel in up to four block-aligned row chunks (dist_llt.h, LLT_NCH), the diagonal
+    # block stays with its owner: the chunk count and the bytes on the wire are those of the plan -- recomputed here from the
+    # sizes alone -- plus the closing status exchange (world x 16 bytes); every chunk begun exactly once on every rank,
+    # awaited at least once (the look-ahead part and the rest of the update each wait for the chunks they read), none left
+    # unawaited, no wait for a transfer that was never started
     nblk = (n + nb - 1) // nb
-    expect = sum((n - k * nb) * min(nb, n - k * nb) * 8 for k in range(nblk)) + world * 16
+    messages, payload = 0, 0
+    for k in range(nblk):
+        tb = nblk - k - 1
+        nch = min(4, tb)
+        messages += nch
+        if nch:
+            payload += (n - (k + 1) * nb) * min(nb, n - k * nb) * 8
     for r in res:
-        assert int(r["nbc"]) == nblk + world and int(r["bytes"]) == expect
-        assert int(r["begun"]) == nblk and int(r["waited"]) == nblk
+        assert int(r["wire_messages"]) == messages and int(r["wire_bytes"]) == payload
+        assert int(r["nbc"]) == messages + world and int(r["bytes"]) == payload + world * 16
+        assert int(r["begun"]) == messages and int(r["waited"]) >= messages and int(r["stray"]) == 0
+    if nblk >= 6:
+        assert messages >= 4 * (nblk - 4)  # four chunks per panel while four block rows remain below it
 
 
 @pytest.mark.parametrize("world,n,nb,bad", [(2, 80, 16, 37), (3, 70, 8, 0), (2, 64, 16, 63)])
