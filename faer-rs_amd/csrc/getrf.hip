@@ -1162,32 +1162,35 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		copy_dev<T>(backup->sub(0, wb, m, n - wb), A.sub(0, wb, m, n - wb).c());
 	}
 	hipEvent_t ev_panel;
-	// net row permutation of every panel, composed once on the panel stream right behind the panel and shared by all the
-	// interchange launches of the bulk stream for it (two buffers: the bulk stream still applies panel k while the panel
-	// stream finishes panel k + 1)
+	// net row permutation of a panel's interchanges, composed once (laswp_compose_list_kernel) and shared by all the interchange
+	// launches for it.  Round 4: composed on the BULK stream at the start of the step that applies it (22 us that used to sit
+	// on the panel stream's chain); `half[0 / 1]` are the lists of the first / second 256 interchanges of a panel whose update of
+	// the next panel's columns runs in two stages (below).
 	static_assert(LU_LA_NB <= LASWP_SMALL_NT, "panel interchange list");
-	Scratch listb((size_t) 2 * 2 * 2 * LU_LA_NB * sizeof(int));
-	LaswpList lists[2];
+	Scratch listb((size_t) 3 * 2 * 2 * LU_LA_NB * sizeof(int));
+	LaswpList full, half[2];
+	full.dst = listb.as<int>();
+	full.src = full.dst + 2 * LU_LA_NB;
 	for (int q = 0; q < 2; ++q) {
-		lists[q].dst = listb.as<int>() + (size_t) q * 4 * LU_LA_NB;
-		lists[q].src = lists[q].dst + 2 * LU_LA_NB;
+		half[q].dst = listb.as<int>() + (size_t) (q + 1) * 4 * LU_LA_NB;
+		half[q].src = half[q].dst + 2 * LU_LA_NB;
 	}
-	const bool use_lists = true; // (the per-workgroup rebuild of the permutation was 4 % slower: DESIGN.md 3.4)
+	constexpr idx_t HALF = LU_LA_NB / 2;
+	// remaining rows from which the bulk stream is the critical one (mode 2 below); fewer: the panel chain is
+	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= 10240; };
+	bool staged = false; // the panel about to be applied has already been applied to the next panel's columns with its first half
 	{
 		StreamScope sc(c.la_panel);
 		const idx_t w0 = LU_LA_NB < n ? LU_LA_NB : n;
 		getrf_rec<T>(A.sub(0, 0, m, w0), 0, 0, wk);
-		if (use_lists)
-			laswp_compose_list(wk.piv, (int) w0, 0, lists[0]);
 		ev_panel = c.next_event();
 		FH_HIP(hipEventRecord(ev_panel, c.la_panel));
 	}
 	// the interchanges of panel k (pivots [j0, j0 + w)) on the columns [c0, c0 + nc), rows j0 ..
 	auto swaps = [&](idx_t k, idx_t j0, idx_t w, idx_t c0, idx_t nc) {
-		if (use_lists)
-			laswp_list_dev<T>(A.sub(j0, c0, m - j0, nc), lists[k & 1]);
-		else
-			laswp_dev<T>(A.sub(j0, c0, m - j0, nc), wk.piv + j0, (int) w, (int) j0);
+		(void) k;
+		(void) w;
+		laswp_list_dev<T>(A.sub(j0, c0, m - j0, nc), full);
 	};
 	// brings the columns [c0, c0 + nc) up to date with panel k = [j0, j0 + w): swaps, solve, update
 	auto update = [&](idx_t k, idx_t j0, idx_t w, idx_t c0, idx_t nc) {
@@ -1218,8 +1221,25 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			//          the split "first 64, then 448" of rounds 1-3 made the panel wait for the second chain), then the rest.
 			// Measured in one visit (profiles/r04_exp_lu_chain_grouping.txt, N = 16384): three chains 107.9 ms, mode 1 everywhere
 			// 102.4, mode 2 everywhere 101.6, mode 2 down to 10240 remaining rows 100.7.
-			const int mode = m - j1 >= 10240 ? 2 : 1;
-			if (w2 > 0 && mode == 2) {
+			const int mode = bulk_bound(m - j1) ? 2 : 1;
+			if (!(w2 > 0 && staged)) // (the staged path composes it behind the release of the next panel)
+				laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full);
+			if (w2 > 0 && staged) {
+				// second stage of the two-stage update of the next panel's columns (the first one ran beside the second half of
+				// panel k, see the panel part below): interchanges of the second 256 pivots, U2 = L22^-1 (.), product with K = 256
+				const idx_t jh = j0 + HALF;
+				laswp_compose_list(wk.piv + jh, (int) HALF, (int) jh, half[1]);
+				laswp_list_dev<T>(A.sub(jh, j1, m - jh, w2), half[1]);
+				MatV<T> U2 = A.sub(jh, j1, HALF, w2);
+				trsm_lower_dev<T>(A.sub(jh, jh, HALF, HALF).c(), true, U2);
+				if (m > j1)
+					gemm_dev<T>(A.sub(j1, j1, m - j1, w2), DST_FULL, true, A.sub(j1, jh, m - j1, HALF).c(), U2.c(), (T) -1);
+				ev_next = c.next_event();
+				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
+				laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full);
+				if (j2 < n)
+					update(k, j0, w, j2, n - j2);
+			} else if (w2 > 0 && mode == 2) {
 				swaps(k, j0, w, j1, n - j1);
 				MatV<T> U = A.sub(j0, j1, w, n - j1);
 				trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, U);
@@ -1265,11 +1285,48 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		if (w2 > 0) {
 			StreamScope sc(c.la_panel);
 			stream_wait(c.la_panel, ev_next);
-			getrf_rec<T>(A.sub(j1, j1, m - j1, w2), (int) j1, (int) j1, wk);
-			if (use_lists)
-				laswp_compose_list(wk.piv + j1, (int) w2, (int) j1, lists[(k + 1) & 1]);
+			// While the panel chain is the critical one, what sits between two panels is the bulk stream's chain "interchanges,
+			// solve against the 512 x 512 triangle, product" on the next panel's columns (~330 us, profiles/r04_lu_timeline.txt).
+			// Half of it can run early: as soon as the LEFT 256 columns of panel k + 1 are final, the bulk stream (idle in this
+			// phase) applies them to the columns of panel k + 2 -- interchanges of the first 256 pivots, U1 = L11^-1 (.), product
+			// with K = 256 on all rows below -- beside the right half of the panel; the second stage (above) is then half as
+			// long.  Row interchanges of the second half commute with the first stage (they move whole rows of L and of the
+			// updated columns alike); the panel stream only has to wait for the first stage before it interchanges rows of the
+			// LEFT half's columns (factor.rs:127-185), which the first stage reads.
+			const idx_t w3 = j2 < n ? (LU_LA_NB < n - j2 ? LU_LA_NB : n - j2) : 0;
+			const bool stage = w2 == LU_LA_NB && w3 > 0 && !bulk_bound(m - j2) && m - j1 > LU_LA_NB;
+			if (!stage) {
+				getrf_rec<T>(A.sub(j1, j1, m - j1, w2), (int) j1, (int) j1, wk);
+			} else {
+				const idx_t mp = m - j1;
+				MatV<T> P = A.sub(j1, j1, mp, w2);
+				getrf_rec<T>(P.sub(0, 0, mp, HALF), (int) j1, (int) j1, wk);
+				hipEvent_t ev_half = c.next_event(), ev_s1 = c.next_event();
+				FH_HIP(hipEventRecord(ev_half, c.la_panel));
+				{
+					StreamScope sb(c.la_bulk);
+					stream_wait(c.la_bulk, ev_half);
+					laswp_compose_list(wk.piv + j1, (int) HALF, (int) j1, half[0]);
+					laswp_list_dev<T>(A.sub(j1, j2, mp, w3), half[0]);
+					MatV<T> U1 = A.sub(j1, j2, HALF, w3);
+					trsm_lower_dev<T>(A.sub(j1, j1, HALF, HALF).c(), true, U1);
+					gemm_dev<T>(A.sub(j1 + HALF, j2, mp - HALF, w3), DST_FULL, true, A.sub(j1 + HALF, j1, mp - HALF, HALF).c(), U1.c(), (T) -1);
+					FH_HIP(hipEventRecord(ev_s1, c.la_bulk));
+				}
+				// the top node of the panel's recursion, as in getrf_rec (factor.rs:98-117, :127-185)
+				MatV<T> right = P.sub(0, HALF, mp, HALF);
+				laswp_dev<T>(right, wk.piv + j1, (int) HALF, (int) j1);
+				trsm_lower_dev<T>(P.sub(0, 0, HALF, HALF).c(), true, P.sub(0, HALF, HALF, HALF));
+				gemm_dev<T>(P.sub(HALF, HALF, mp - HALF, HALF), DST_FULL, true, P.sub(HALF, 0, mp - HALF, HALF).c(), P.sub(0, HALF, HALF, HALF).c(), (T) -1);
+				getrf_rec<T>(P.sub(HALF, HALF, mp - HALF, HALF), (int) (j1 + HALF), (int) (j1 + HALF), wk);
+				stream_wait(c.la_panel, ev_s1);
+				laswp_dev<T>(P.sub(HALF, 0, mp - HALF, HALF), wk.piv + j1 + HALF, (int) HALF, (int) (j1 + HALF));
+			}
+			staged = stage;
 			ev_panel = c.next_event();
 			FH_HIP(hipEventRecord(ev_panel, c.la_panel));
+		} else {
+			staged = false;
 		}
 	}
 	hipEvent_t eb = c.next_event();

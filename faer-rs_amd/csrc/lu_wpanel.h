@@ -116,10 +116,13 @@ template <int STEPS> static __device__ __forceinline__ void lw_argmax(double v, 
 constexpr int LW_W = 64;	    // leaf width = wavefront size: lane c <-> register position c of a published row
 constexpr int LW_GMAX = 32;	    // workgroups per panel = two rounds of a header sweep (taller panels: getrf_panel2_kernel)
 constexpr int LW_HDR_BYTES = 64;    // {label}, {a}, {s}, {l}: four 16-byte granule pairs
+#ifndef LW_HDR_STRIDE
+#define LW_HDR_STRIDE 320 // bytes between the header records of consecutive workgroups (64: LU N = 16384 ~0.8 ms slower, 1088 / 4160: no better -- profiles/r04_exp_lu_header_stride.txt)
+#endif
 constexpr int LW_ROW_BYTES = LW_W * 16;
 constexpr int LW_NSH = 2; // header slots (column parity)
 constexpr int LW_NSR = 4; // row-record slots (column modulo 4)
-constexpr size_t LW_HDR_WS = (size_t) LW_NSH * LW_GMAX * LW_HDR_BYTES;
+constexpr size_t LW_HDR_WS = (size_t) LW_NSH * LW_GMAX * LW_HDR_STRIDE;
 constexpr size_t LW_ROW_WS = (size_t) LW_NSR * LW_GMAX * LW_ROW_BYTES;
 constexpr size_t LW_WS_BYTES = LW_HDR_WS + LW_ROW_WS;
 constexpr int LW_SPIN_MAX = 1 << 20;
@@ -201,9 +204,9 @@ template <int RND> struct LwSweep { // (plain members, not an array: an indexed 
 };
 template <int RND> static __device__ __forceinline__ void lw_sweep_issue(LwSweep<RND> &w, __amdgpu_buffer_rsrc_t hr, int G, int J, unsigned voff)
 {
-	const unsigned soff = (unsigned) ((J & 1) * G * LW_HDR_BYTES);
+	const unsigned soff = (unsigned) ((J & 1) * LW_GMAX * LW_HDR_STRIDE);
 	w.r0 = lw_load(hr, voff, soff);
-	w.r1 = lw_load(hr, voff + 1024u, soff);
+	w.r1 = lw_load(hr, voff + 16u * LW_HDR_STRIDE, soff);
 	static_assert(RND == 2, "two rounds of 16 records");
 }
 template <int RND> static __device__ __forceinline__ bool lw_sweep_ok(const LwSweep<RND> &w, unsigned tag, int G, int lane)
@@ -241,7 +244,7 @@ static __device__ __forceinline__ bool lw_sweep(__amdgpu_buffer_rsrc_t hr, int G
 #endif
 )
 {
-	const unsigned voff = (unsigned) (lane * 16);
+	const unsigned voff = (unsigned) ((lane >> 2) * LW_HDR_STRIDE + (lane & 3) * 16);
 	// A, B, C are only ever written by the UNCONDITIONAL issues of lw_step: re-issued inside a branch here they would become
 	// phi values, and the register copies at the join READ -- i.e. wait for -- the sweeps that are still in flight
 	// (profiles/r04_lu_panel_phases_v3_one_sweeper_branchy.txt).  A sweep that comes back stale is simply dropped; if all three
@@ -400,7 +403,7 @@ static __device__ __forceinline__ void lw_publish(const WPanelArgs<T> &a, __amdg
 			q.w = 0u;
 		}
 		if (lane < 4)
-			lw_store(q, hr, (unsigned) (lane * 16), (unsigned) ((par * G + g) * LW_HDR_BYTES));
+			lw_store(q, hr, (unsigned) (lane * 16), (unsigned) ((par * LW_GMAX + g) * LW_HDR_STRIDE));
 	}
 	if (!ghas)
 		return;
@@ -584,7 +587,7 @@ template <typename T, int RPT, int NW, int RND> __global__ __launch_bounds__(NW 
 		lw_publish<T, RPT, NW, 0>(a, hr, rr, x, lab, l0, sh, 0, 0, G);
 	}
 	// wavefront 0 sweeps all headers; the others issue the same loads on their own workgroup's record and ignore them (LwSweep)
-	const unsigned svoff = wave == 0 ? (unsigned) (lane * 16) : (unsigned) (blockIdx.x * LW_HDR_BYTES + (lane & 3) * 16);
+	const unsigned svoff = wave == 0 ? (unsigned) ((lane >> 2) * LW_HDR_STRIDE + (lane & 3) * 16) : (unsigned) (blockIdx.x * LW_HDR_STRIDE + (lane & 3) * 16);
 	LwSweep<RND> A, B, C;
 	lw_sweep_issue<RND>(A, hr, G, 0, svoff);
 	lw_sweep_issue<RND>(B, hr, G, 0, svoff);
