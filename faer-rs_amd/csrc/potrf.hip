@@ -341,6 +341,9 @@ static void potrf_panel_flat(MatV<T> P, int regularize, T eps, T delta, int *sta
 // leaving 255 CUs idle.  Same arithmetic per entry as the reference's right-looking sweep
 // (cholesky/ldlt/factor.rs:367-498) with a larger step.
 constexpr idx_t LA_NB = 1024;
+#ifndef LLT_SIDE_RMIN
+#define LLT_SIDE_RMIN 8192 // rows of the remaining lower square from which the panel solve runs on the side stream
+#endif
 
 // Step plan of the blocked driver (pure host logic, unit tested without a GPU through faer_hip_debug_llt_plan):
 // starts of the look-ahead panels; the last entry is where the sequential tail takes over.  The first step is LA_NB
@@ -404,6 +407,16 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		// trailing size from which the update of the next diagonal block runs on the panel stream (it has slack to
 		// spare while the trailing matrix is large, and the bulk stream then issues fewer launches per step)
 		const idx_t dpanel_rmin = 8192;
+		// Round 4: the panel solve of step k + 1 (a dependent chain of ~15 small launches, ~0.4 ms whatever the number of rows:
+		// 6.4 of the bulk stream's 34 ms, profiles/r03_llt_timeline.txt) no longer sits between two trailing updates on the bulk
+		// stream.  Update k brings block column k + 1 up to date FIRST (its own launch), and while the rest of update k -- the
+		// lower square right of it, which neither reads nor writes that block column -- runs on the bulk stream, a plain side
+		// stream solves P_{k+1} = A_{>k+1,k+1} L_{k+1,k+1}^-T as soon as the panel stream has factored the diagonal block.
+		// Its small kernels find their slots among the product's workgroups (the two launches are independent); towards the
+		// end, where the rest of the update is shorter than the chain, the chain is exposed as before.
+		c.qr_side_streams();
+		hipStream_t side = c.qr_side[0];
+		hipEvent_t ev_solved = nullptr; // P_k solved (recorded on the stream that did it)
 		for (idx_t k = 0; k < ks; ++k) {
 			const idx_t j0 = J[(size_t) k], j1 = J[(size_t) k + 1], w = j1 - j0; // panel columns [j0, j1)
 			const idx_t r = n - j1;						       // rows below
@@ -412,42 +425,70 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 			MatV<T> Pk = A.sub(j1, j0, r, w);
 			MatV<const T> X = Pk.c(), X0 = Pk.sub(0, 0, w1, w).c();
 			const bool d_on_panel = !last && dpanel_rmin > 0 && r >= dpanel_rmin;
-			hipEvent_t ev_upd;
+			// (the side-stream solve pays only while the rest of the update is much longer than the chain it hides)
+			const bool side_solve = !last && r - w1 >= LLT_SIDE_RMIN;
+			hipEvent_t ev_upd, ev_col = nullptr;
 			{
 				StreamScope sc(c.la_bulk);
-				stream_wait(c.la_bulk, ev_diag);
-				// P_k <- P_k L_kk^-T in place (cholesky/ldlt/factor.rs:422-426): the reference's TRSM recursion on the
-				// 128-blocks of L_kk -- substitution leaves against the packed diagonal blocks the panel stream
-				// left in Wbase, MFMA products in between
-				trsm_lower_pre_dev<T>(A.sub(j0, j0, w, w).c(), Pk.t(), Wbase + (size_t) (j0 / POTRF_NB) * TriPack<T>::SIZE);
+				if (ev_solved) {
+					stream_wait(c.la_bulk, ev_solved);
+				} else {
+					stream_wait(c.la_bulk, ev_diag);
+					// P_k <- P_k L_kk^-T in place (cholesky/ldlt/factor.rs:422-426): the reference's TRSM recursion on the
+					// 128-blocks of L_kk -- substitution leaves against the packed diagonal blocks the panel stream
+					// left in Wbase, MFMA products in between
+					trsm_lower_pre_dev<T>(A.sub(j0, j0, w, w).c(), Pk.t(), Wbase + (size_t) (j0 / POTRF_NB) * TriPack<T>::SIZE);
+				}
+				ev_upd = c.next_event(); // P_k is solved
+				FH_HIP(hipEventRecord(ev_upd, c.la_bulk));
 				if (last) {
 					gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1);
-				} else if (!d_on_panel) { // next diagonal block first
-					gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
+				} else if (!side_solve) {
+					if (!d_on_panel) { // next diagonal block first
+						gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
+						ev_col = c.next_event();
+						FH_HIP(hipEventRecord(ev_col, c.la_bulk));
+					}
+					// block column k+1 below its diagonal block + the remaining lower square in ONE launch: the lower
+					// triangle of the whole trailing matrix minus its leading w1 rows
+					GemmExtra<T> ex;
+					ex.tri_skip = w1;
+					gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1, &ex);
+				} else {
+					if (!d_on_panel) // next diagonal block first
+						gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
+					// block column k + 1 below its diagonal block
+					gemm_dev<T>(A.sub(j1 + w1, j1, r - w1, w1), DST_FULL, true, Pk.sub(w1, 0, r - w1, w).c(), X0.t(), (T) -1);
+					ev_col = c.next_event();
+					FH_HIP(hipEventRecord(ev_col, c.la_bulk));
+					// the remaining lower square
+					MatV<const T> X2 = Pk.sub(w1, 0, r - w1, w).c();
+					gemm_dev<T>(A.sub(j1 + w1, j1 + w1, r - w1, r - w1), DST_LOWER, true, X2, X2.t(), (T) -1);
 				}
-				ev_upd = c.next_event();
-				FH_HIP(hipEventRecord(ev_upd, c.la_bulk));
 			}
-			// (the remainder of the trailing update is enqueued BEFORE the panel stream's launches so that the bulk
-			// queue never runs dry while the host is busy enqueuing)
+			ev_solved = nullptr;
 			if (!last) {
-				StreamScope sc(c.la_bulk);
-				// block column k+1 below its diagonal block + the remaining lower square in ONE launch: the lower
-				// triangle of the whole trailing matrix minus its leading w1 rows
-				GemmExtra<T> ex;
-				ex.tri_skip = w1;
-				gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1, &ex);
-			}
-			if (!last) {
-				StreamScope sc(c.la_panel);
-				stream_wait(c.la_panel, ev_upd);
-				if (d_on_panel)
-					gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
-				potrf_panel_flat<T>(A.sub(j1, j1, w1, w1), regularize, eps, delta, status, j1, Wbase);
-				ev_diag = c.next_event();
-				FH_HIP(hipEventRecord(ev_diag, c.la_panel));
+				{
+					StreamScope sc(c.la_panel);
+					stream_wait(c.la_panel, d_on_panel ? ev_upd : ev_col);
+					if (d_on_panel)
+						gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
+					potrf_panel_flat<T>(A.sub(j1, j1, w1, w1), regularize, eps, delta, status, j1, Wbase);
+					ev_diag = c.next_event();
+					FH_HIP(hipEventRecord(ev_diag, c.la_panel));
+				}
+				if (side_solve) {
+					StreamScope sc(side);
+					stream_wait(side, ev_col);
+					stream_wait(side, ev_diag);
+					trsm_lower_pre_dev<T>(A.sub(j1, j1, w1, w1).c(), A.sub(j1 + w1, j1, r - w1, w1).t(), Wbase + (size_t) (j1 / POTRF_NB) * TriPack<T>::SIZE);
+					ev_solved = c.next_event();
+					FH_HIP(hipEventRecord(ev_solved, side));
+				}
 			}
 		}
+		if (ev_solved) // (cannot happen: the last look-ahead step starts no solve; kept for symmetry)
+			stream_wait(caller, ev_solved);
 		// rejoin the caller's stream
 		hipEvent_t eb = c.next_event(), ep = c.next_event();
 		FH_HIP(hipEventRecord(eb, c.la_bulk));
