@@ -29,6 +29,7 @@
 #include <atomic>
 
 #include "common.h"
+#include <functional>
 #include "lds_blocks.h"
 #include "mfma.h"
 #include "xwg.h"
@@ -1164,21 +1165,17 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	hipEvent_t ev_panel;
 	// net row permutation of a panel's interchanges, composed once (laswp_compose_list_kernel) and shared by all the interchange
 	// launches for it.  Round 4: composed on the BULK stream at the start of the step that applies it (22 us that used to sit
-	// on the panel stream's chain); `half[0 / 1]` are the lists of the first / second 256 interchanges of a panel whose update of
-	// the next panel's columns runs in two stages (below).
+	// on the panel stream's chain).
 	static_assert(LU_LA_NB <= LASWP_SMALL_NT, "panel interchange list");
-	Scratch listb((size_t) 3 * 2 * 2 * LU_LA_NB * sizeof(int));
-	LaswpList full, half[2];
+	Scratch listb((size_t) 2 * 2 * LU_LA_NB * sizeof(int));
+	LaswpList full;
 	full.dst = listb.as<int>();
 	full.src = full.dst + 2 * LU_LA_NB;
-	for (int q = 0; q < 2; ++q) {
-		half[q].dst = listb.as<int>() + (size_t) (q + 1) * 4 * LU_LA_NB;
-		half[q].src = half[q].dst + 2 * LU_LA_NB;
-	}
-	constexpr idx_t HALF = LU_LA_NB / 2;
+	c.qr_side_streams();
+	hipStream_t side = c.qr_side[0];
 	// remaining rows from which the bulk stream is the critical one (mode 2 below); fewer: the panel chain is
 	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= 10240; };
-	bool staged = false; // the panel about to be applied has already been applied to the next panel's columns with its first half
+	bool staged = false; // the panel about to be applied has already been applied to the next panel's columns except for its last part
 	{
 		StreamScope sc(c.la_panel);
 		const idx_t w0 = LU_LA_NB < n ? LU_LA_NB : n;
@@ -1200,6 +1197,50 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, U);
 		if (m > j1)
 			gemm_dev<T>(A.sub(j1, c0, m - j1, nc), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), U.c(), (T) -1);
+	};
+	// ---- staged update of the NEXT panel's columns (while the panel chain is the critical one, see the panel part below).
+	// Stage q of panel [jp, jp + 512) on the columns [cx, cx + wx): the interchanges of its pivots [q QW, (q + 1) QW), the solve
+	// against that diagonal block, the product with the QW columns below it -- on the bulk stream.
+	// QW = 256 (two stages): with four stages of 128 the part left between two panels is shorter, but the factorization is 2 - 3 ms
+	// SLOWER at N = 8192 .. 16384 (profiles/r04_exp_lu_stages.txt): twice the small launches beside the latency-bound panel kernel
+	constexpr idx_t QW = 256;
+	hipEvent_t ev_stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	auto stage_update = [&](idx_t jp, idx_t q, idx_t cx, idx_t wx) {
+		const idx_t r0 = jp + q * QW, r1 = r0 + QW;
+		laswp_dev<T>(A.sub(r0, cx, m - r0, wx), wk.piv + r0, (int) QW, (int) r0);
+		MatV<T> U = A.sub(r0, cx, QW, wx);
+		trsm_lower_dev<T>(A.sub(r0, r0, QW, QW).c(), true, U);
+		if (m > r1)
+			gemm_dev<T>(A.sub(r1, cx, m - r1, wx), DST_FULL, true, A.sub(r1, r0, m - r1, QW).c(), U.c(), (T) -1);
+	};
+	// The panel [jp, jp + 512) on the panel stream with the top levels of getrf_rec's recursion written out (factor.rs:84-117,
+	// :127-185), columns [lo, hi) of it: as soon as a QW-column part is final, its stage starts on the bulk stream; the
+	// interchanges a later part makes on that part's columns wait for the stage, which reads them.
+	std::function<void(idx_t, idx_t, idx_t, idx_t, idx_t)> staged_panel = [&](idx_t jp, idx_t cx, idx_t wx, idx_t lo, idx_t hi) {
+		if (hi - lo == QW) {
+			getrf_rec<T>(A.sub(jp + lo, jp + lo, m - jp - lo, QW), (int) (jp + lo), (int) (jp + lo), wk);
+			const idx_t q = lo / QW;
+			if (hi < LU_LA_NB) { // (the last part's stage opens the next step on the bulk stream)
+				hipEvent_t ev_part = c.next_event();
+				FH_HIP(hipEventRecord(ev_part, c.la_panel));
+				StreamScope sb(c.la_bulk);
+				stream_wait(c.la_bulk, ev_part);
+				stage_update(jp, q, cx, wx);
+				ev_stage[q] = c.next_event();
+				FH_HIP(hipEventRecord(ev_stage[q], c.la_bulk));
+			}
+			return;
+		}
+		const idx_t mid = (lo + hi) / 2;
+		staged_panel(jp, cx, wx, lo, mid);
+		const idx_t a = jp + lo, b = jp + mid;
+		laswp_dev<T>(A.sub(a, b, m - a, hi - mid), wk.piv + a, (int) (mid - lo), (int) a);
+		MatV<T> U = A.sub(a, b, mid - lo, hi - mid);
+		trsm_lower_dev<T>(A.sub(a, a, mid - lo, mid - lo).c(), true, U);
+		gemm_dev<T>(A.sub(b, b, m - b, hi - mid), DST_FULL, true, A.sub(b, a, m - b, mid - lo).c(), U.c(), (T) -1);
+		staged_panel(jp, cx, wx, mid, hi);
+		stream_wait(c.la_panel, ev_stage[mid / QW - 1]); // (bulk stream order: the earlier stages are done as well)
+		laswp_dev<T>(A.sub(b, a, m - b, mid - lo), wk.piv + b, (int) (hi - mid), (int) b);
 	};
 	for (idx_t k = 0; k < nsteps; ++k) {
 		const idx_t j0 = k * LU_LA_NB;
@@ -1225,20 +1266,32 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			if (!(w2 > 0 && staged)) // (the staged path composes it behind the release of the next panel)
 				laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full);
 			if (w2 > 0 && staged) {
-				// second stage of the two-stage update of the next panel's columns (the first one ran beside the second half of
-				// panel k, see the panel part below): interchanges of the second 256 pivots, U2 = L22^-1 (.), product with K = 256
-				const idx_t jh = j0 + HALF;
-				laswp_compose_list(wk.piv + jh, (int) HALF, (int) jh, half[1]);
-				laswp_list_dev<T>(A.sub(jh, j1, m - jh, w2), half[1]);
-				MatV<T> U2 = A.sub(jh, j1, HALF, w2);
-				trsm_lower_dev<T>(A.sub(jh, jh, HALF, HALF).c(), true, U2);
-				if (m > j1)
-					gemm_dev<T>(A.sub(j1, j1, m - j1, w2), DST_FULL, true, A.sub(j1, jh, m - j1, HALF).c(), U2.c(), (T) -1);
+				// last stage of the staged update of the next panel's columns (the earlier ones ran beside the rest of panel k,
+				// see the panel part below): interchanges of the last QW pivots, U = L_qq^-1 (.), product with K = QW
+				stage_update(j0, (idx_t) (LU_LA_NB / QW - 1), j1, w2);
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
 				laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full);
 				if (j2 < n)
 					update(k, j0, w, j2, n - j2);
+			} else if (w2 > 0 && mode == 2 && side && j2 < n && m > j1) {
+				// the chain of the columns behind the next panel -- interchanges, solve -- on the side stream, BESIDE the bulk
+				// stream's chain and product for the next panel's columns: both chains are latency bound (a dozen small launches
+				// each), together they keep the chip no busier than one, and the big product starts a chain earlier
+				hipEvent_t ev_list = c.next_event(), ev_side = c.next_event();
+				FH_HIP(hipEventRecord(ev_list, c.la_bulk)); // (the list is composed, everything earlier on these columns is done)
+				{
+					StreamScope ss(side);
+					stream_wait(side, ev_list);
+					swaps(k, j0, w, j2, n - j2);
+					trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, A.sub(j0, j2, w, n - j2));
+					FH_HIP(hipEventRecord(ev_side, side));
+				}
+				update(k, j0, w, j1, w2);
+				ev_next = c.next_event();
+				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
+				stream_wait(c.la_bulk, ev_side);
+				gemm_dev<T>(A.sub(j1, j2, m - j1, n - j2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), A.sub(j0, j2, w, n - j2).c(), (T) -1);
 			} else if (w2 > 0 && mode == 2) {
 				swaps(k, j0, w, j1, n - j1);
 				MatV<T> U = A.sub(j0, j1, w, n - j1);
@@ -1287,40 +1340,18 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			stream_wait(c.la_panel, ev_next);
 			// While the panel chain is the critical one, what sits between two panels is the bulk stream's chain "interchanges,
 			// solve against the 512 x 512 triangle, product" on the next panel's columns (~330 us, profiles/r04_lu_timeline.txt).
-			// Half of it can run early: as soon as the LEFT 256 columns of panel k + 1 are final, the bulk stream (idle in this
-			// phase) applies them to the columns of panel k + 2 -- interchanges of the first 256 pivots, U1 = L11^-1 (.), product
-			// with K = 256 on all rows below -- beside the right half of the panel; the second stage (above) is then half as
-			// long.  Row interchanges of the second half commute with the first stage (they move whole rows of L and of the
-			// updated columns alike); the panel stream only has to wait for the first stage before it interchanges rows of the
-			// LEFT half's columns (factor.rs:127-185), which the first stage reads.
+			// Most of it can run early: as soon as a QW-column part of panel k + 1 is final, the bulk stream (idle in this
+			// phase) applies it to the columns of panel k + 2 -- interchanges of its QW pivots, U = L_qq^-1 (.), product with
+			// K = QW on all rows below -- beside the rest of the panel; only the last part's stage (above) is left between the
+			// panels.  Row interchanges of later parts commute with a stage (they move whole rows of L and of the updated columns
+			// alike); the panel stream only has to wait for a stage before it interchanges rows of that part's columns
+			// (factor.rs:127-185), which the stage reads.
 			const idx_t w3 = j2 < n ? (LU_LA_NB < n - j2 ? LU_LA_NB : n - j2) : 0;
 			const bool stage = w2 == LU_LA_NB && w3 > 0 && !bulk_bound(m - j2) && m - j1 > LU_LA_NB;
 			if (!stage) {
 				getrf_rec<T>(A.sub(j1, j1, m - j1, w2), (int) j1, (int) j1, wk);
 			} else {
-				const idx_t mp = m - j1;
-				MatV<T> P = A.sub(j1, j1, mp, w2);
-				getrf_rec<T>(P.sub(0, 0, mp, HALF), (int) j1, (int) j1, wk);
-				hipEvent_t ev_half = c.next_event(), ev_s1 = c.next_event();
-				FH_HIP(hipEventRecord(ev_half, c.la_panel));
-				{
-					StreamScope sb(c.la_bulk);
-					stream_wait(c.la_bulk, ev_half);
-					laswp_compose_list(wk.piv + j1, (int) HALF, (int) j1, half[0]);
-					laswp_list_dev<T>(A.sub(j1, j2, mp, w3), half[0]);
-					MatV<T> U1 = A.sub(j1, j2, HALF, w3);
-					trsm_lower_dev<T>(A.sub(j1, j1, HALF, HALF).c(), true, U1);
-					gemm_dev<T>(A.sub(j1 + HALF, j2, mp - HALF, w3), DST_FULL, true, A.sub(j1 + HALF, j1, mp - HALF, HALF).c(), U1.c(), (T) -1);
-					FH_HIP(hipEventRecord(ev_s1, c.la_bulk));
-				}
-				// the top node of the panel's recursion, as in getrf_rec (factor.rs:98-117, :127-185)
-				MatV<T> right = P.sub(0, HALF, mp, HALF);
-				laswp_dev<T>(right, wk.piv + j1, (int) HALF, (int) j1);
-				trsm_lower_dev<T>(P.sub(0, 0, HALF, HALF).c(), true, P.sub(0, HALF, HALF, HALF));
-				gemm_dev<T>(P.sub(HALF, HALF, mp - HALF, HALF), DST_FULL, true, P.sub(HALF, 0, mp - HALF, HALF).c(), P.sub(0, HALF, HALF, HALF).c(), (T) -1);
-				getrf_rec<T>(P.sub(HALF, HALF, mp - HALF, HALF), (int) (j1 + HALF), (int) (j1 + HALF), wk);
-				stream_wait(c.la_panel, ev_s1);
-				laswp_dev<T>(P.sub(HALF, 0, mp - HALF, HALF), wk.piv + j1 + HALF, (int) HALF, (int) (j1 + HALF));
+				staged_panel(j1, j2, w3, 0, LU_LA_NB);
 			}
 			staged = stage;
 			ev_panel = c.next_event();
