@@ -4,7 +4,7 @@
 tag=${1:-run}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -3 gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 timeout 300 python tools/gpu_fuzz.py 300 7 2>&1 | tail -1
