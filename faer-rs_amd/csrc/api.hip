@@ -1395,6 +1395,7 @@ void faer_hip_debug_dump_timing(void)
 {
 	trsm_dump_timing();
 	lu_dump_timing();
+	gemm_dump_timing();
 }
 
 void faer_hip_tridiag_in_place_f64(FaerMatMut A, FaerMatMut householder) { tridiag_api<double>(A, householder); }

@@ -309,6 +309,7 @@ template <typename T> void trsm_lower_pre_dev(MatV<const T> L, MatV<T> X, const 
 template <typename T> void trsm_pack_dev(MatV<const T> L, bool unit, T *W);
 void trsm_dump_timing(); // timing build only (no-op otherwise)
 void lu_dump_timing();   // timing build only: per-phase ticks of the LU panel kernel (getrf.hip)
+void gemm_dump_timing(); // timing build only: per-phase ticks of the pipelined GEMM tile (gemm.hip)
 
 // in-place lower Cholesky; returns >=0 regularization count or -(index+1)   (potrf.hip)
 template <typename T> long potrf_lower_dev(MatV<T> A, T reg_delta, T reg_eps);

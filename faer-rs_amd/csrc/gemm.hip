@@ -61,6 +61,9 @@ template <typename T> struct GemmArgs {
 	int tri_off;		// tri_enum: first tile of the enumeration (tiles of the skipped leading rows)
 	int raster_g;		// tile rows per raster group (pipelined kernel)
 	int stair_nb, stair_gap, stair_row0; // GemmExtra::stair_*: "lower" is tested against the column n + (n / stair_nb) * stair_gap - stair_row0
+	// pipelined kernel, interior tiles of a plain column-major dst (see "fast tile I/O" there): 0 = off, 1 = replace (dst = alpha acc),
+	// 2 / 3 = accumulate with alpha == +1 / -1: the accumulators START from the old dst values (-dst for 3, stored negated)
+	int fast_io;
 };
 
 // column index the lower-part test of dst uses (GemmExtra::stair_nb: a staircase instead of a diagonal)
@@ -401,6 +404,47 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 // ------------------------------------------------------------------------------------------------
 #define FH_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
+// timing build (make timing): where a workgroup's time goes, s_memtime stamps of thread 0 -- entry -> first tile in LDS ->
+// end of the K loop -> epilogue's stores issued -> stores acknowledged; sums over all workgroups (gemm_dump_timing)
+#ifdef FH_GEMM_TIMING
+__device__ unsigned long long g_gemm_phase[16];
+#define FH_GT(i)                                                                                                         \
+	do {                                                                                                             \
+		const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                             \
+		gt_acc[i] += now_ - gt_last;                                                                             \
+		gt_last = now_;                                                                                          \
+	} while (0)
+#else
+#define FH_GT(i)                                                                                                         \
+	do {                                                                                                             \
+	} while (0)
+#endif
+
+// Buffer-addressed access to a dst tile: address = descriptor base (SGPRs, per wavefront) + per-lane byte offset (one VGPR,
+// computed once) + wave-uniform byte offset (an SGPR per element, scalar unit) -- no vector ALU instruction per element.
+typedef unsigned int fh_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct TileIO;
+template <> struct TileIO<double> {
+	static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+	{
+		return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int) voff, (int) soff, 0));
+	}
+	static __device__ __forceinline__ void store(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+	{
+		__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fh_u32x2, v), r, (int) voff, (int) soff, 0);
+	}
+};
+template <> struct TileIO<float> {
+	static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+	{
+		return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int) voff, (int) soff, 0));
+	}
+	static __device__ __forceinline__ void store(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+	{
+		__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int) voff, (int) soff, 0);
+	}
+};
+
 // compile-time unrolled interleave pattern for one k-step of NMMA MFMAs (the builtin needs constants):
 // KIND 0: MFMA + fragment ds_read + global loads; KIND 1: MFMA + fragment ds_read; KIND 2: MFMA + LDS stores
 template <int I, int NMMA, int NFR, int NLD, int KIND> struct SgbStep {
@@ -443,6 +487,10 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 	const int lane = tid & 63, wave = tid >> 6;
 	const int wm = wave % WM, wn = wave / WM;
 	const int l15 = lane & 15, lhi = lane >> 4;
+#ifdef FH_GEMM_TIMING
+	unsigned long long gt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long gt_last = __builtin_amdgcn_s_memtime();
+#endif
 
 	// ---- tile coordinates (same mapping as gemm_kernel)
 	int tm, tn;
@@ -594,6 +642,43 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		for (int j = 0; j < TN; ++j)
 			acc[i][j] = (acc_t) (T) 0;
 
+	// ---- fast tile I/O.  The two workgroups of a CU share its SIMDs, and while one of them streams MFMAs every vector ALU
+	// instruction of the OTHER one waits for a gap in that stream (~64 cycles each, profiles/r04_gemm_tile_phases.txt): the
+	// general epilogue below -- 64-bit address arithmetic, masks and an fma per element, ~1500 vector ALU instructions per
+	// wavefront -- took 95 000 (accumulate) to 143 000 (replace) cycles of a K = 1024 tile's 640 000.  Interior tiles of a plain
+	// column-major dst (everything but the edge / diagonal tiles of the products the factorizations issue) address dst through
+	// a buffer descriptor instead (TileIO: no vector ALU per element), and an accumulating product with alpha = +-1 loads the
+	// old tile INTO the accumulators here, so that its epilogue is 64 stores (alpha = -1: from -dst, stored negated -- exact).
+	const bool fast = g.fast_io != 0 && m_off + BM <= g.M && n_off + BN <= g.N && (!g.lower || m_off >= n_off + BN);
+	__amdgpu_buffer_rsrc_t crs;
+	unsigned cvoff = 0;
+	if (fast) {
+		const int wv = __builtin_amdgcn_readfirstlane(wave);
+		T *cbase = g.dst + (idx_t) (m_off + (wv % WM) * WTM) + (idx_t) (n_off + (wv / WM) * WTN) * g.dcs;
+		crs = __builtin_amdgcn_make_buffer_rsrc((void *) cbase, 0, (int) 0x7fffffff, 0x00020000);
+		cvoff = (unsigned) (l15 + Mfma<T>::row(0, lhi) * (int) g.dcs) * (unsigned) sizeof(T);
+		if (g.fast_io >= 2) {
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+#pragma unroll
+					for (int i = 0; i < TM; ++i) {
+						const unsigned soff = (unsigned) ((j * 16 + Mfma<T>::row(r, 0)) * (int) g.dcs + i * 16) * (unsigned) sizeof(T);
+						acc[i][j][r] = TileIO<T>::load(crs, cvoff, soff);
+					}
+			if (g.fast_io == 3) {
+#pragma unroll
+				for (int j = 0; j < TN; ++j)
+#pragma unroll
+					for (int r = 0; r < 4; ++r)
+#pragma unroll
+						for (int i = 0; i < TM; ++i)
+							acc[i][j][r] = -acc[i][j][r];
+			}
+		}
+	}
+
 	// fragment double buffer
 	T fa[2][TM], fb[2][TN];
 	const int a_frag_off = AKM ? (wm * WTM + l15) * SA + lhi : lhi * SA + wm * WTM + l15;
@@ -634,6 +719,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 			store_b(smem + A_SZ, rb[0], bmask[0]);
 		}
 		__syncthreads();
+		FH_GT(0);
 		if (nk > 0)
 			read_frag(smem, 0, 0);
 		int kt = 0;
@@ -749,6 +835,41 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		}
 	}
 
+	FH_GT(1);
+	if (fast) {
+		// (scaled IN PLACE first, then stored straight from the accumulators: a temporary per element makes the compiler wait
+		// for older stores before it reuses the temporary's registers)
+		const T scale = g.fast_io == 1 ? g.alpha : (g.fast_io == 3 ? (T) -1 : (T) 1);
+		if (scale != (T) 1) { // (uniform)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+#pragma unroll
+					for (int i = 0; i < TM; ++i)
+						acc[i][j][r] *= scale;
+		}
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+#pragma unroll
+				for (int i = 0; i < TM; ++i) {
+					const unsigned soff = (unsigned) ((j * 16 + Mfma<T>::row(r, 0)) * (int) g.dcs + i * 16) * (unsigned) sizeof(T);
+					TileIO<T>::store(acc[i][j][r], crs, cvoff, soff);
+				}
+#ifdef FH_GEMM_TIMING
+		FH_GT(2);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		FH_GT(3);
+		if (tid == 0 && PF == 1) {
+			for (int i = 0; i < 8; ++i)
+				atomicAdd(&g_gemm_phase[i], gt_acc[i]);
+			atomicAdd(&g_gemm_phase[8], 1ull);
+		}
+#endif
+		return;
+	}
 	// ---- epilogue: lane (l15, lhi), reg r of acc[i][j] holds C(m_off + wm*WTM + i*16 + l15, n_off + wn*WTN + j*16 +
 	// row(r, lhi)).  Accumulate mode first LOADS the 4 * TM old values of one 16-column group together and only then
 	// stores them (measured: prefetching the next group ahead of the stores is slower again): written as one
@@ -816,7 +937,21 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				else
 					*ptr[r][i] = g.alpha * v;
 			}
+#ifdef FH_GEMM_TIMING
+		if (j < 4)
+			FH_GT(4 + j);
+#endif
 	}
+#ifdef FH_GEMM_TIMING
+	FH_GT(2);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	FH_GT(3);
+	if (tid == 0 && PF == 1) {
+		for (int i = 0; i < 8; ++i)
+			atomicAdd(&g_gemm_phase[i], gt_acc[i]);
+		atomicAdd(&g_gemm_phase[8], 1ull);
+	}
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -890,6 +1025,20 @@ template <typename T> void splitk_reduce_dev(MatV<T> C, const T *ws, int splits,
 }
 template void splitk_reduce_dev<double>(MatV<double>, const double *, int, double, bool);
 template void splitk_reduce_dev<float>(MatV<float>, const float *, int, float, bool);
+
+void gemm_dump_timing()
+{
+#ifdef FH_GEMM_TIMING
+	unsigned long long h[16];
+	FH_HIP(hipDeviceSynchronize());
+	FH_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_phase), sizeof(h)));
+	unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	FH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_phase), z, sizeof(z)));
+	const double n = h[8] ? (double) h[8] : 1.0;
+	fprintf(stderr, "gemm tile phases (shader cycles per workgroup, wave 0; %llu tiles): first tile in LDS %.0f | K loop %.0f | epilogue groups %.0f %.0f %.0f %.0f (+%.0f) | stores acknowledged %.0f\n",
+		h[8], h[0] / n, h[1] / n, h[4] / n, h[5] / n, h[6] / n, h[7] / n, h[2] / n, h[3] / n);
+#endif
+}
 
 template <typename T> static void fill_ext(MatV<T> A, DstKind kind, T value, const GemmExtra<T> *ex)
 {
@@ -1172,6 +1321,19 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 
 	if (ex.inplace)
 		FH_CHECK(splits == 1, "gemm: in-place product cannot be split along K");
+	g.fast_io = 0;
+	{
+		static const int fio = getenv("FAER_HIP_GEMM_FASTIO") ? atoi(getenv("FAER_HIP_GEMM_FASTIO")) : 1; // EXPERIMENT switch
+		// (the wave-uniform byte offsets of a tile, < 64 dcs sizeof(T), and the per-lane ones, < 16 dcs sizeof(T), are 32-bit)
+		if (fio && plain && !legacy && splits == 1 && C.rs == 1 && C.cs > 0 && C.cs < (1L << 21) && !ex.stair_nb) {
+			if (!add)
+				g.fast_io = 1;
+			else if (alpha == (T) 1)
+				g.fast_io = 2;
+			else if (alpha == (T) -1)
+				g.fast_io = 3;
+		}
+	}
 	if (extra_path)
 		launch_cfg<T, 64, 64, 2, 2, true>(g, akm, bkm, splits); // triangular operands / diag scaling
 	else if (shape == 5)
