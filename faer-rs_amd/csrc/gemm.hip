@@ -1323,9 +1323,8 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		FH_CHECK(splits == 1, "gemm: in-place product cannot be split along K");
 	g.fast_io = 0;
 	{
-		static const int fio = getenv("FAER_HIP_GEMM_FASTIO") ? atoi(getenv("FAER_HIP_GEMM_FASTIO")) : 1; // EXPERIMENT switch
 		// (the wave-uniform byte offsets of a tile, < 64 dcs sizeof(T), and the per-lane ones, < 16 dcs sizeof(T), are 32-bit)
-		if (fio && plain && !legacy && splits == 1 && C.rs == 1 && C.cs > 0 && C.cs < (1L << 21) && !ex.stair_nb) {
+		if (plain && !legacy && splits == 1 && C.rs == 1 && C.cs > 0 && C.cs < (1L << 21) && !ex.stair_nb) {
 			if (!add)
 				g.fast_io = 1;
 			else if (alpha == (T) 1)
