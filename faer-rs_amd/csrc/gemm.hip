@@ -657,27 +657,29 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		T *cbase = g.dst + (idx_t) (m_off + (wv % WM) * WTM) + (idx_t) (n_off + (wv / WM) * WTN) * g.dcs;
 		crs = __builtin_amdgcn_make_buffer_rsrc((void *) cbase, 0, (int) 0x7fffffff, 0x00020000);
 		cvoff = (unsigned) (l15 + Mfma<T>::row(0, lhi) * (int) g.dcs) * (unsigned) sizeof(T);
-		if (g.fast_io >= 2) {
-#pragma unroll
-			for (int j = 0; j < TN; ++j)
-#pragma unroll
-				for (int r = 0; r < 4; ++r)
-#pragma unroll
-					for (int i = 0; i < TM; ++i) {
-						const unsigned soff = (unsigned) ((j * 16 + Mfma<T>::row(r, 0)) * (int) g.dcs + i * 16) * (unsigned) sizeof(T);
-						acc[i][j][r] = TileIO<T>::load(crs, cvoff, soff);
-					}
-			if (g.fast_io == 3) {
-#pragma unroll
-				for (int j = 0; j < TN; ++j)
-#pragma unroll
-					for (int r = 0; r < 4; ++r)
-#pragma unroll
-						for (int i = 0; i < TM; ++i)
-							acc[i][j][r] = -acc[i][j][r];
-			}
-		}
 	}
+	// (issued BEHIND the first A / B tile's loads, negated behind that tile's LDS stores: one memory round trip for both)
+	const bool cstart = fast && g.fast_io >= 2;
+	auto load_c_tile = [&]() {
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+#pragma unroll
+				for (int i = 0; i < TM; ++i) {
+					const unsigned soff = (unsigned) ((j * 16 + Mfma<T>::row(r, 0)) * (int) g.dcs + i * 16) * (unsigned) sizeof(T);
+					acc[i][j][r] = TileIO<T>::load(crs, cvoff, soff);
+				}
+	};
+	auto negate_c_tile = [&]() {
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+#pragma unroll
+				for (int i = 0; i < TM; ++i)
+					acc[i][j][r] = -acc[i][j][r];
+	};
 
 	// fragment double buffer
 	T fa[2][TM], fb[2][TN];
@@ -715,8 +717,12 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				load_a(ra[0], amask[0]);
 				load_b(rb[0], bmask[0]);
 			}
+			if (cstart)
+				load_c_tile();
 			store_a(smem, ra[0], amask[0]);
 			store_b(smem + A_SZ, rb[0], bmask[0]);
+			if (cstart && g.fast_io == 3)
+				negate_c_tile();
 		}
 		__syncthreads();
 		FH_GT(0);
@@ -780,6 +786,11 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 		}
 	} else {
 		// ring of PF register sets; pa / pb always point at the next tile to load (tile index `tl`)
+		if (cstart) {
+			load_c_tile();
+			if (g.fast_io == 3)
+				negate_c_tile();
+		}
 		int tl = 0;
 		auto load_next = [&](T (&ra_)[A_CNT], unsigned &amask_, T (&rb_)[B_CNT], unsigned &bmask_) {
 			if (tl == nk - 1) { // last tile: k-checked
