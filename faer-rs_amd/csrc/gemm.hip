@@ -572,21 +572,47 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 	const idx_t a_tile_step = (idx_t) BK * g.acs, b_tile_step = (idx_t) BK * g.brs;
 	const idx_t a_kstep = (idx_t) A_KSTEP * g.acs, b_kstep = (idx_t) B_KSTEP * g.brs; // wave uniform
 
-	// full tile: no k checks
+	// Full tiles (no k checks) are loaded through buffer descriptors: base = a wave-uniform pointer that advances with the K
+	// tile (scalar unit), one per-lane byte offset computed here, a scalar offset per element -- no vector ALU instruction per
+	// load inside the K loop (the 64-bit pointer arithmetic of the pointer form was ~40 of the loop's ~70 per 16 columns of K).
+	// MN-major operands keep the row clamp in the lane offset; the K-major B operand needs no clamp at all: the descriptor ends
+	// where column N begins, columns beyond it read as zero.  (K-major A keeps the pointer form.)  The host routes operands
+	// with negative strides or offsets beyond 32 bits to the non-pipelined kernel (gemm_dev).
+	constexpr unsigned TS = (unsigned) sizeof(T);
+	const T *a_ub = g.a + (idx_t) k_begin * g.acs; // (uniform)
+	const T *b_ub = g.b + (idx_t) k_begin * g.brs + (BKM ? (idx_t) n_off * g.bcs : (idx_t) 0);
+	const unsigned a_vo = AKM ? 0u : (unsigned) ((idx_t) min(a_mn0, g.M - 1) * g.ars + (idx_t) a_k * g.acs) * TS;
+	const unsigned b_vo = BKM ? (unsigned) ((idx_t) b_k * g.brs + (idx_t) b_mn * g.bcs) * TS
+				  : (unsigned) ((idx_t) min(b_mn0, g.N - 1) * g.bcs + (idx_t) b_k * g.brs) * TS;
+	const idx_t b_ext = (idx_t) (g.N - n_off) * g.bcs * (idx_t) TS;
+	const unsigned b_lim = BKM ? (b_ext < (idx_t) 0xfffffff0u ? (unsigned) b_ext : 0xfffffff0u) : 0x7fffffffu;
+	// (the eight-wavefront 128 x 256 tile keeps the pointer form: 71.2 -> 70.0 TFLOP/s with descriptors at N = 8192, while the
+	// four-wavefront tiles gain 3 - 4 %: profiles/r04_gemm_tile_phases.txt)
+	constexpr bool BUF_A = !AKM && WM * WN == 4, BUF_B = WM * WN == 4;
 	auto load_a = [&](T (&ra_)[A_CNT], unsigned &amask_) {
 		amask_ = a_mnmask;
+		if constexpr (!BUF_A) {
 #pragma unroll
-		for (int i = 0; i < A_CNT; ++i) {
-			const T *p = AKM ? pa + (idx_t) min(a_mn0 + i * A_MSTEP, g.M - 1) * g.ars : pa + (idx_t) i * a_kstep;
-			ra_[i] = *p;
+			for (int i = 0; i < A_CNT; ++i)
+				ra_[i] = *(AKM ? pa + (idx_t) min(a_mn0 + i * A_MSTEP, g.M - 1) * g.ars : pa + (idx_t) i * a_kstep);
+		} else {
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) a_ub, 0, (int) 0x7fffffff, 0x00020000);
+#pragma unroll
+			for (int i = 0; i < A_CNT; ++i)
+				ra_[i] = TileIO<T>::load(rs, a_vo, (unsigned) (i * A_KSTEP * (int) g.acs) * TS);
 		}
 	};
 	auto load_b = [&](T (&rb_)[B_CNT], unsigned &bmask_) {
 		bmask_ = b_mnmask;
+		if constexpr (!BUF_B) {
 #pragma unroll
-		for (int i = 0; i < B_CNT; ++i) {
-			const T *p = BKM ? pb + (idx_t) min(b_mn0 + i * B_NSTEP, g.N - 1) * g.bcs : pb + (idx_t) i * b_kstep;
-			rb_[i] = *p;
+			for (int i = 0; i < B_CNT; ++i)
+				rb_[i] = *(BKM ? pb + (idx_t) min(b_mn0 + i * B_NSTEP, g.N - 1) * g.bcs : pb + (idx_t) i * b_kstep);
+		} else {
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) b_ub, 0, (int) b_lim, 0x00020000);
+#pragma unroll
+			for (int i = 0; i < B_CNT; ++i)
+				rb_[i] = TileIO<T>::load(rs, b_vo, (unsigned) (BKM ? i * B_NSTEP * (int) g.bcs : i * B_KSTEP * (int) g.brs) * TS);
 		}
 	};
 	// last (possibly partial) tile starting at k0: k >= k_end is clamped to k_end - 1 and masked
@@ -734,6 +760,8 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 			T *nxt = smem + ((kt + 1) & 1) * STAGE;
 			pa += a_tile_step;
 			pb += b_tile_step;
+			a_ub += a_tile_step;
+			b_ub += b_tile_step;
 			load_a(ra[0], amask[0]);
 			load_b(rb[0], bmask[0]);
 			read_frag(cur, 1, 1);
@@ -759,6 +787,8 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 			T *nxt = smem + ((kt + 1) & 1) * STAGE;
 			pa += a_tile_step;
 			pb += b_tile_step;
+			a_ub += a_tile_step;
+			b_ub += b_tile_step;
 			load_a_tail(ra[0], amask[0], k_begin + (kt + 1) * BK);
 			load_b_tail(rb[0], bmask[0], k_begin + (kt + 1) * BK);
 			read_frag(cur, 1, 1);
@@ -802,6 +832,8 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 			}
 			pa += a_tile_step;
 			pb += b_tile_step;
+			a_ub += a_tile_step;
+			b_ub += b_tile_step;
 			++tl;
 		};
 #pragma unroll
@@ -1244,12 +1276,24 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	// r = 8192: K = 512 -2 %, K = 2048 +1.4 %, K = 8192 +2.9 %; r = 15360: +-0.3 %), and so does every lower dst (its
 	// 128 x 256 tiles on the diagonal waste more: -5 .. -11 %; the trapezoid enumeration is kept reachable for tests).
 	// variant 3 forces the wide tile (full and square lower), 5 forbids it.
+	bool legacy = variant >= 10;
+	{
+		// the pipelined kernel addresses full operand tiles through 32-bit buffer offsets (see its loaders): operands with
+		// negative strides, or whose per-lane / per-element offsets inside a tile row do not fit, go to the non-pipelined kernel
+		const idx_t ts = (idx_t) sizeof(T);
+		const bool a_ok = A.rs >= 0 && A.cs >= 0 && (akm || ((m - 1) * A.rs + 32 * A.cs) * ts < (1L << 31));
+		const bool b_ok = B.rs >= 0 && B.cs >= 0 &&
+				  (bkm ? (16 * B.rs + 520 * B.cs) * ts < (1L << 31) : ((n - 1) * B.cs + 32 * B.rs) * ts < (1L << 31));
+		if (!(a_ok && b_ok) && !legacy) {
+			FH_CHECK(!ex.k_trim && !ex.tri_skip && !ex.stair_nb && !ex.inplace, "gemm: operand strides out of range for this product");
+			legacy = true;
+		}
+	}
 	const bool plain = !ex.inplace && !ex.diag && !ex.a_struct && !ex.b_struct && !ex.row_idx && !ex.col_idx;
 	const bool wide_ok = plain && (kind == DST_FULL ? !ex.k_trim : (m == n));
 	const idx_t tiles_wide = ((m + 127) / 128) * ((n + 255) / 256);
 	const bool wide_auto = kind == DST_FULL && k >= 2048 && tiles_wide >= 512;
-	const int wide = wide_ok && big && variant != 5 && variant < 10 && (variant == 3 || (variant == 0 && wide_auto)) ? 1 : 0;
-	const bool legacy = variant >= 10;
+	const int wide = wide_ok && big && variant != 5 && !legacy && (variant == 3 || (variant == 0 && wide_auto)) ? 1 : 0;
 	// in-place product (ex.inplace): the aliased operand and dst share rows (transposed orientation: A and C
 	// share their rows, one tile must cover all of N) or columns (B and C share their columns, one tile must
 	// cover all of M).  A 32-wide tile along the free dimension keeps the launch wide for skinny panels.
