@@ -586,9 +586,9 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				  : (unsigned) ((idx_t) min(b_mn0, g.N - 1) * g.bcs + (idx_t) b_k * g.brs) * TS;
 	const idx_t b_ext = (idx_t) (g.N - n_off) * g.bcs * (idx_t) TS;
 	const unsigned b_lim = BKM ? (b_ext < (idx_t) 0xfffffff0u ? (unsigned) b_ext : 0xfffffff0u) : 0x7fffffffu;
-	// (the eight-wavefront 128 x 256 tile keeps the pointer form: 71.2 -> 70.0 TFLOP/s with descriptors at N = 8192, while the
-	// four-wavefront tiles gain 3 - 4 %: profiles/r04_gemm_tile_phases.txt)
-	constexpr bool BUF_A = !AKM && WM * WN == 4, BUF_B = WM * WN == 4;
+	// (the eight-wavefront 128 x 256 tile loads only B this way: descriptors for both 71.4 -> 70.0 TFLOP/s at N = 8192, for A alone
+	// 69.8, for B alone 72.0; the four-wavefront tiles gain 4 % with both: profiles/r04_gemm_tile_phases.txt)
+	constexpr bool BUF_A = !AKM && WM * WN == 4, BUF_B = true;
 	auto load_a = [&](T (&ra_)[A_CNT], unsigned &amask_) {
 		amask_ = a_mnmask;
 		if constexpr (!BUF_A) {
