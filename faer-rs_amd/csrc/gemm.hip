@@ -1283,7 +1283,8 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		const idx_t ts = (idx_t) sizeof(T);
 		const bool a_ok = A.rs >= 0 && A.cs >= 0 && (akm || ((m - 1) * A.rs + 32 * A.cs) * ts < (1L << 31));
 		const bool b_ok = B.rs >= 0 && B.cs >= 0 &&
-				  (bkm ? (16 * B.rs + 520 * B.cs) * ts < (1L << 31) : ((n - 1) * B.cs + 32 * B.rs) * ts < (1L << 31));
+				  (bkm ? (16 * B.rs + 256 * B.cs) * ts < (1L << 31) : ((n - 1) * B.cs + 32 * B.rs) * ts < (1L << 31));
+		// (K-major B: lane offset <= 15 brs + 31 bcs, element offsets <= (BN - 16) bcs with BN <= 256)
 		if (!(a_ok && b_ok) && !legacy) {
 			FH_CHECK(!ex.k_trim && !ex.tri_skip && !ex.stair_nb && !ex.inplace, "gemm: operand strides out of range for this product");
 			legacy = true;
