@@ -67,6 +67,31 @@ def test_matmul_negative_and_generic_strides(oracle):
     assert np.abs(to_host(dc) - a[::-1] @ b).max() < 1e-11
 
 
+def test_matmul_device_negative_strides_and_huge_leading_dimension(oracle):
+    """operand views the buffer-addressed loaders of the pipelined kernel cannot express (gemm.hip, gemm_dev: negative device
+    strides, per-tile offsets beyond 32 bits) are routed to the non-pipelined kernel: same results"""
+    import ctypes as C
+    F = init_gpu()
+    rng = np.random.default_rng(15)
+    a, b = rnd(rng, 200, 150), rnd(rng, 150, 130)
+    da, db, dc = to_dev(a), to_dev(b), to_dev(np.zeros((200, 130)))
+    # rows of a reversed, columns of b reversed, through hand-made views (torch has no negative strides)
+    va = F.MatRef(da.data_ptr() + 199 * da.stride(0) * 8, 200, 150, -da.stride(0), da.stride(1))
+    vb = F.MatRef(db.data_ptr() + 129 * db.stride(1) * 8, 150, 130, db.stride(0), -db.stride(1))
+    al = C.c_double(1.0)
+    F.lib().libfaer_v0_23_matmul_f64(F._mat(dc, F.MatMut), C.c_int(F.ACCUM_REPLACE), va, vb, C.byref(al), F.PAR_SEQ)
+    assert np.abs(to_host(dc) - a[::-1] @ b[:, ::-1]).max() < 1e-11
+    # K-major rhs with a leading dimension of 1.2e6 rows (the V^T A products of a very tall QR): C = X^T Y, K = 1.2e6
+    import torch
+    k = 1_200_000
+    x = torch.randn((24, k), dtype=torch.float64, device="cuda").t()  # k x 24, column major
+    y = torch.randn((20, k), dtype=torch.float64, device="cuda").t()
+    c = torch.zeros((20, 24), dtype=torch.float64, device="cuda").t()  # 24 x 20, column major
+    F.matmul(c, F.ACCUM_REPLACE, x.t(), y, 1.0)
+    ref = x.t() @ y
+    assert (c - ref).abs().max().item() <= 64 * k * 2.3e-16 * 16
+
+
 def test_matmul_host_pointers(oracle):
     """host-resident operands (a faer::Mat): staged through device buffers by the library"""
     F = init_gpu()
