@@ -13,10 +13,13 @@ synthetic input that is already resident in HBM when the timed region starts:
   lu   (configs[3], one GPU)                : in-place partial-pivot LU of a 16384^2 matrix
   qr   (configs[4])                         : fp32 Householder QR of a 1e6 x 256 matrix
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the gemm workload is sharded by
-block columns of C with no data-path collective: every rank multiplies the same A by
-its own N x 8192 slice of B => weak scaling; `value` is the whole-job rate (sum of all ranks' flops over the
-slowest rank's time).  Rank 0 prints ONE JSON line.
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) and no --workload the headline is
+BASELINE.json configs[3]: the partial-pivot LU of a 16384^2 matrix, 1-D block-cyclic columns over the N ranks, one
+RCCL broadcast per factored panel through the library's own transport (`resolve_run` below) => strong scaling;
+`value` is the whole-job rate, `per_rank.ncclCommCount` must equal N, `lu_1gpu_same_run` is the single-GPU LU of
+the same size timed on rank 0 in the same run (the N = 1 point of the curve; it is also `others.lu_f64_n16384` of
+the --gpus 1 line).  `others` then carries the collective-free weak-scaling GEMM (every rank multiplies the same
+A by its own N x 8192 slice of B) and the block-cyclic LU at N = 65536.  Rank 0 prints ONE JSON line.
 
 The line also carries
   "roofline":     the dominant kernel (the MFMA GEMM) against the fp64 MFMA peak, timed with HIP events on the
@@ -45,7 +48,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # launch duration and its launch count are PARSED at run time from the committed rocprofv3 kernel trace of
 # `bench.py --workload X --steps 10 --warmup 2` (profiles/rNN_X_kernel_stats.csv, newest round first) -- they describe that
 # recorded run, not this one, and the JSON says so (`source`, `not_measured_this_run`).
-PROFILE_ROUNDS = ("r04", "r03", "r02")
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02")
 BOUND_OF = {  # what bounds the dominant kernel of each chain
     "gemm_kernel": "mfma", "getrf_panel": "latency", "getrf_wpanel": "latency", "qr_panel": "latency", "tq_update": "hbm", "tq_gram": "mfma", "tq_panel": "latency",
     "trsm_leaf": "latency", "potrf_leaf": "latency",
@@ -74,6 +77,32 @@ def dominant_from_profile(workload):
     return None
 
 
+def resolve_run(gpus, workload, transport):
+    """What a command line runs: (workload, transport, defaulted).  One GPU: the DGEMM of BASELINE.json configs[1]; several GPUs
+    and no --workload: configs[3], the block-cyclic LU over the library's RCCL transport (a collective-free GEMM would show
+    N x with zero RCCL traffic and say nothing about the distributed path -- VERDICT r04 item 4)."""
+    defaulted = workload is None
+    if workload is None:
+        workload = "lu" if gpus > 1 else "gemm"
+    if transport is None:
+        transport = "rccl" if (gpus > 1 and defaulted) else "torch"
+    return workload, transport, defaulted
+
+
+def per_rank_dict(allr, transport):
+    """`per_rank` of a distributed lu / llt line from the all-gathered rows {total ms, panel ms, panels owned, ncclCommCount,
+    broadcasts, bytes, broadcast ms per factorization}: what a scaling curve is read against -- with the library's RCCL
+    transport `ncclCommCount` is what RCCL itself reports on every rank and must equal the number of GPUs."""
+    return {"total_device_ms": [round(float(r[0]), 3) for r in allr],
+            "panel_device_ms": [round(float(r[1]), 3) for r in allr],
+            "panels_owned": [int(r[2]) for r in allr],
+            "update_and_wait_device_ms": [round(float(r[0] - r[1]), 3) for r in allr],
+            "ncclCommCount": [int(r[3]) for r in allr],
+            "broadcasts": [int(r[4]) for r in allr],
+            "bcast_device_ms_per_factorization": [round(float(r[6]), 3) for r in allr],
+            "transport": transport}
+
+
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; BASELINE.md), dense
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
@@ -84,15 +113,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="gemm", choices=["gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess"])
+    ap.add_argument("--workload", default=None, choices=["gemm", "sgemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess"],
+                    help="default: gemm on one GPU, the block-cyclic lu (RCCL transport) on several (resolve_run)")
     ap.add_argument("--n", type=int, default=0, help="override the matrix size (testing only)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pause", type=float, default=0.0, help="seconds of idle time before each entry of `others` (diagnostic)")
-    ap.add_argument("--transport", default="torch", choices=["torch", "rccl"],
+    ap.add_argument("--transport", default=None, choices=["torch", "rccl"],
                     help="multi-GPU lu/llt: broadcast through torch.distributed (RCCL under the nccl backend) or the library's own "
                          "RCCL transport (ncclBroadcast on a dedicated stream, no Python callback in the loop)")
     args = ap.parse_args()
+    args.workload, args.transport, defaulted = resolve_run(args.gpus, args.workload, args.transport)
 
     import numpy as np
     import torch
@@ -139,16 +170,18 @@ def main():
     # ------------------------------------------------------------------ workloads
     def make_workload(name, n_override=0):
         """returns (step_fn, flops_per_step, overhead_fn, label, dtype_name)"""
-        if name == "gemm":
-            n = n_override or 8192
-            a = colmajor(n, n, torch.float64, 1)               # replicated on every rank
-            b = colmajor(n, n, torch.float64, 2 + rank)         # this rank's block columns of B
-            c = torch.empty((n, n), dtype=torch.float64, device=dev).t()
+        if name in ("gemm", "gemm4096", "sgemm"):
+            # "gemm4096": the mid-size product the factorizations live on; "sgemm": north_star's fp32 MFMA GEMM
+            n = n_override or (4096 if name == "gemm4096" else 8192)
+            dt_ = torch.float32 if name == "sgemm" else torch.float64
+            a = colmajor(n, n, dt_, 1)               # replicated on every rank
+            b = colmajor(n, n, dt_, 2 + rank)         # this rank's block columns of B
+            c = torch.empty((n, n), dtype=dt_, device=dev).t()
 
             def step():
                 F.matmul(c, F.ACCUM_REPLACE, a, b, 1.0)
 
-            return step, 2.0 * n ** 3, None, f"dgemm_f64_n{n}", "f64"
+            return step, 2.0 * n ** 3, None, (f"sgemm_f32_n{n}" if name == "sgemm" else f"dgemm_f64_n{n}"), ("f32" if name == "sgemm" else "f64")
         if name == "gemv":
             # level-2 shape of the same entry point (matmul with one rhs column): an HBM stream, not an MFMA kernel
             n = n_override or 16384
@@ -226,6 +259,21 @@ def main():
                 F.partial_piv_lu_factor_in_place(work)
 
             return step, 2.0 * n ** 3 / 3.0, lambda: work.copy_(a), f"lu_f64_n{n}", "f64"
+        if name == "qrlit":
+            # BASELINE.json configs[4] VERBATIM: 1e6 x 256 fp32.  The reference's own rank test rejects every column from 524288
+            # rows on (see "qr" below), so this call does what faer does there -- rank 0, no reflector applied -- and the entry
+            # times that, not a factorization (tests/test_gpu_qr.py::test_qr_fp32_reference_rank_test_limit)
+            m, n = 1000000, 256
+            a = colmajor(m, n, torch.float32, 5)
+            work = a.clone()
+            bs = F.qr_recommended_block_size(m, n, np.float32)
+            h = torch.zeros((min(m, n), bs), dtype=torch.float32, device=dev).t()
+
+            def step():
+                work.copy_(a)
+                F.qr_factor_in_place(work, h)
+
+            return step, 2.0 * m * n * n - 2.0 / 3.0 * n ** 3, lambda: work.copy_(a), f"qr_f32_{m}x{n}", "f32"
         if name in ("qr", "qrmax"):
             # BASELINE config Q says 1e6 x 256, but faer's own rank test rejects every fp32 column once
             # 16 * eps * nrows >= 1 (nrows >= 524288; qr/no_pivoting/factor.rs:52-58), i.e. the reference does no
@@ -326,6 +374,51 @@ def main():
         dt = time.perf_counter() - t0
         return dt, e0.elapsed_time(e1) * 1e-3
 
+    def profiled(fn):
+        """one more repetition with the library's kernel-class profile on (HIP events around every launch of the dominant
+        classes, on the stream the kernel runs on): {class: {ms, launches, units}} -- measured in THIS run"""
+        F.synchronize()
+        torch.cuda.synchronize()
+        F.prof_begin()
+        fn()
+        F.synchronize()
+        torch.cuda.synchronize()
+        return F.prof_end()
+
+    def class_roofline(prof, name, step_ms):
+        """roofline object of one factorization from its profiled repetition: the trailing products (or, QR, the update kernel)"""
+        if name in ("llt", "lu"):
+            c = prof["mfma_products"]
+            if c["launches"] == 0 or c["ms"] <= 0:
+                return None
+            tf = c["units"] / (c["ms"] * 1e-3) / 1e12
+            r = {"bound": "mfma", "kernel_class": "gemm_kernel_p (128 x 128 / 128 x 256 tiles): the trailing updates", "achieved": round(tf, 2),
+                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                 "launches": c["launches"], "launch_ms_avg": round(c["ms"] / c["launches"], 4), "class_ms": round(c["ms"], 3),
+                 "class_share_of_step": round(c["ms"] / step_ms, 4), "algorithmic_flops_in_class": c["units"],
+                 "measured": "this run: HIP events around every launch of the class, one profiled repetition"}
+            side = prof["lu_panel"] if name == "lu" else prof["llt_leaf"]
+            if side["launches"]:
+                r["chain_kernel"] = {"class": "getrf_wpanel_kernel" if name == "lu" else "potrf_leaf_kernel", "bound": "latency",
+                                     "launches": side["launches"], "ms": round(side["ms"], 3),
+                                     "us_per_column": round(side["ms"] * 1e3 / max(side["units"], 1.0), 3)}
+            return r
+        if name == "qr":
+            c, g, pk = prof["qr_update"], prof["qr_gram"], prof["qr_panel"]
+            if c["launches"] == 0 or c["ms"] <= 0:
+                return None
+            gbs = c["units"] / (c["ms"] * 1e-3) / 1e9
+            r = {"bound": "hbm", "kernel_class": "tq_update_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": c["launches"], "launch_ms_avg": round(c["ms"] / c["launches"], 4),
+                 "class_ms": round(c["ms"], 3), "class_share_of_step": round(c["ms"] / step_ms, 4), "algorithmic_bytes_in_class": c["units"],
+                 "measured": "this run: HIP events around every launch of the class, one profiled repetition"}
+            if g["launches"] and g["ms"] > 0:
+                r["gram_kernel"] = {"launches": g["launches"], "ms": round(g["ms"], 3), "GB/s": round(g["units"] / (g["ms"] * 1e-3) / 1e9, 1)}
+            if pk["launches"]:
+                r["panel_kernel"] = {"launches": pk["launches"], "ms": round(pk["ms"], 3), "bound": "latency (one workgroup)"}
+            return r
+        return None
+
     step, flops, overhead, label, dtype_name = make_workload(args.workload, args.n)
     dt, dt_ev = timed(step, args.steps, args.warmup)
     if overhead is not None:  # restoring the input is not part of the factorization
@@ -347,15 +440,66 @@ def main():
             allr = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allr, mine)
             allr = torch.stack(allr).cpu().numpy()
-            per_rank = {"total_device_ms": [round(float(x), 3) for x in allr[:, 0]],
-                        "panel_device_ms": [round(float(x), 3) for x in allr[:, 1]],
-                        "panels_owned": [int(x) for x in allr[:, 2]],
-                        "update_and_wait_device_ms": [round(float(a - b), 3) for a, b in zip(allr[:, 0], allr[:, 1])],
-                        "ncclCommCount": [int(x) for x in allr[:, 3]],
-                        "bcast_device_ms_per_factorization": [round(float(x), 3) for x in allr[:, 6]],
-                        "transport": args.transport}
+            per_rank = per_rank_dict(allr, args.transport)
     ms_per_step = dt / args.steps * 1e3
     value = flops * world * args.steps / dt / 1e9  # whole-job GFLOP/s
+    prof_main = None
+    if world == 1:
+        try:
+            prof_main = profiled(step)
+        except Exception:
+            prof_main = None
+
+    # ---- several GPUs, default run: the collective-free GEMM and the large block-cyclic LU ride along (all ranks take part),
+    # and rank 0 times the single-GPU LU of the headline's size: the N = 1 point of the strong-scaling curve, same run
+    multi_others, lu_1gpu = None, None
+    if dist is not None and defaulted and args.workload == "lu" and not args.no_extras:
+        multi_others = {}
+        del step
+        torch.cuda.empty_cache()
+        for name, nn, reps, wu in (("gemm", 0, 10, 2), ("lu", 65536, 2, 1)):
+            try:
+                st, fl, ov, lb, dn = make_workload(name, nn)
+                t, _ = timed(st, reps, wu)
+                if ov is not None:
+                    t = max(t - timed(ov, reps, 1)[0], 1e-9)
+                tt = torch.tensor([t], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t = tt.item()
+                rate = fl * world * reps / t / 1e9
+                multi_others[lb + ("_block_columns_no_collective" if name == "gemm" else "")] = {
+                    "GFLOP/s": round(rate, 1), "ms": round(t / reps * 1e3, 3), "scaling": "weak" if name == "gemm" else "strong", "reps": reps,
+                    "frac_of_mfma_peak_per_gpu": round(rate / 1e3 / world / FP64_MFMA_PEAK_TFLOPS, 4)}
+                del st, ov
+                torch.cuda.empty_cache()
+            except Exception as ex:  # (symmetric failures only: every rank runs the same sizes)
+                multi_others[name] = {"error": str(ex)[:200]}
+        if rank == 0:
+            try:
+                n1 = args.n or 16384
+                a1 = colmajor(n1, n1, torch.float64, 4)
+                w1 = a1.clone()
+
+                def one():
+                    w1.copy_(a1)
+                    F.partial_piv_lu_factor_in_place(w1)
+
+                def timed_local(fn, reps):
+                    fn()
+                    F.synchronize(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        fn()
+                    F.synchronize(); torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / reps
+
+                t1 = max(timed_local(one, 5) - timed_local(lambda: w1.copy_(a1), 5), 1e-9)
+                lu_1gpu = {"workload": f"lu_f64_n{n1}", "ms": round(t1 * 1e3, 3), "GFLOP/s": round(2.0 * n1 ** 3 / 3.0 / t1 / 1e9, 1),
+                           "speedup_of_this_run": round(t1 * 1e3 / ms_per_step, 3)}
+                del a1, w1
+            except Exception as ex:
+                lu_1gpu = {"error": str(ex)[:200]}
+        dist.barrier()
 
     out = {
         "metric": "achieved fp64 GFLOP/s (and % MFMA peak), GEMM + LU/Cholesky, N=16384",
@@ -378,7 +522,17 @@ def main():
 
     if per_rank is not None:
         out["per_rank"] = per_rank
+    if multi_others is not None:
+        out["others"] = multi_others
+    if lu_1gpu is not None:
+        out["lu_1gpu_same_run"] = lu_1gpu
     if rank == 0:
+        try:
+            # box-population probe: idle-chip hand-off between two workgroups; the latency-bound chains (LU panel, substitution
+            # leaves) scale with it -- ~0.8 us on the fast boxes of the pool, 1.3-1.9 x that on the slow ones
+            out["xwg_hop_us"] = round(F.xwg_hop_us(2000), 3)
+        except Exception:
+            out["xwg_hop_us"] = None
         # ---------------------------------------------------------------- roofline of the dominant kernel
         if args.workload == "gemm":
             launch_s = dt_ev / args.steps  # one step == one launch of the MFMA GEMM kernel
@@ -401,19 +555,32 @@ def main():
                                "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": pmc, "traffic_source": pmc_src,
                                "algorithmic_flops_per_launch": flops, "launch_ms": round(launch_s * 1e3, 4)}
+            if prof_main and prof_main["mfma_products"]["launches"]:
+                c0 = prof_main["mfma_products"]
+                out["roofline"]["launch_ms_single_profiled_launch"] = round(c0["ms"] / c0["launches"], 4)
         elif args.workload == "qr":
             # HBM bound as specified: algorithmic bytes = the matrix read and written once
             gbs = 2.0 * 500000 * 256 * 4 / (dt / args.steps) / 1e9 if not args.n else None
             out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1) if gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None, "traffic": None}
-            out["roofline"].update(dominant_from_profile("qr") or {})
+                               "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None, "traffic": None,
+                               "scope": "whole factorization: algorithmic bytes 2 m n sizeof(f32) over the step time"}
+            kr = class_roofline(prof_main, "qr", ms_per_step) if prof_main else None
+            if kr:
+                out["roofline"]["dominant_kernel"] = kr
+            else:
+                out["roofline"].update(dominant_from_profile("qr") or {})
         else:
             # the factorizations are chains of kernels: the whole-chain rate against the matrix-core peak of their trailing
             # updates; the dominant-kernel fields come from the committed kernel trace
             peak = FP64_MFMA_PEAK_TFLOPS if dtype_name == "f64" else FP32_MFMA_PEAK_TFLOPS
             out["roofline"] = {"bound": "mfma", "achieved": round(value / 1e3, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(value / 1e3 / peak, 4), "traffic": None}
-            out["roofline"].update(dominant_from_profile(args.workload) or {})
+                               "frac": round(value / 1e3 / peak, 4), "traffic": None,
+                               "scope": "whole factorization rate against the matrix-core peak that bounds its trailing updates"}
+            kr = class_roofline(prof_main, args.workload, ms_per_step) if prof_main else None
+            if kr:
+                out["roofline"]["dominant_kernel"] = kr
+            else:
+                out["roofline"].update(dominant_from_profile(args.workload) or {})
             if not args.no_extras:
                 n = 8192
                 a, b = colmajor(n, n, torch.float64, 11), colmajor(n, n, torch.float64, 12)
@@ -430,7 +597,7 @@ def main():
             del step
             torch.cuda.empty_cache()
             only = os.environ.get("BENCH_OTHERS")  # diagnostic: a comma-separated subset
-            for name in ("gemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess", "qrmax"):
+            for name in ("gemm", "llt", "lu", "qr", "gemm4096", "sgemm", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess", "qrmax", "qrlit"):
                 if name == args.workload or (only and name not in only.split(",")):
                     continue
                 try:
@@ -450,13 +617,25 @@ def main():
                     peak = FP64_MFMA_PEAK_TFLOPS if dn == "f64" else FP32_MFMA_PEAK_TFLOPS
                     others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3),
                                   "frac_of_mfma_peak": round(rate / 1e3 / peak, 4), "reps": reps}
+                    kr = None
+                    if name in ("llt", "lu", "qr"):
+                        try:
+                            kr = class_roofline(profiled(st), name, t / 3 * 1e3)
+                        except Exception:
+                            kr = None
                     if name in ("llt", "lu"):
-                        # per-workload roofline object: `achieved` is the whole-factorization rate (measured now) against the
-                        # fp64 matrix-core peak that bounds its trailing updates; the dominant-kernel fields are read from the
-                        # committed kernel trace named in `source`
+                        # per-workload roofline object: `achieved` is the whole-factorization rate against the fp64 matrix-core
+                        # peak that bounds its trailing updates; `dominant_kernel` is its trailing-product class measured in THIS
+                        # run (one more repetition with HIP events around every launch of the class)
                         others[lb]["roofline"] = {"bound": "mfma", "achieved": round(rate / 1e3, 2), "peak": peak, "unit": "TFLOP/s",
                                                   "frac": round(rate / 1e3 / peak, 4)}
-                        others[lb]["roofline"].update(dominant_from_profile(name) or {})
+                        if kr:
+                            others[lb]["roofline"]["dominant_kernel"] = kr
+                        else:
+                            others[lb]["roofline"].update(dominant_from_profile(name) or {})
+                    if name in ("gemm4096", "sgemm"):
+                        others[lb]["roofline"] = {"bound": "mfma", "achieved": round(rate / 1e3, 2), "peak": peak, "unit": "TFLOP/s",
+                                                  "frac": round(rate / 1e3 / peak, 4), "launch_ms": round(t / 3 * 1e3, 4)}
                     if args.workload == "gemm" and name in ("llt", "lu"):
                         others[lb]["frac_of_dgemm_sustained"] = round(rate / value, 4)  # BASELINE target: >= 0.6
                         others[lb]["roofline"]["frac_of_dgemm_sustained"] = others[lb]["frac_of_dgemm_sustained"]
@@ -488,6 +667,11 @@ def main():
                         gbs = sum(3.0 * ((nn - k - 1) ** 2 + (k + 1) * (nn - k - 1)) * 8.0 for k in range(nn)) * 3 / t / 1e9
                         others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3), "GB/s_algorithmic": round(gbs, 1),
                                       "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                    if name == "qrlit":
+                        others[lb] = {"ms": round(t / 3 * 1e3, 3), "reps": reps,
+                                      "note": "BASELINE configs[4] verbatim: the reference's rank test (qr/no_pivoting/factor.rs:52-58) rejects every "
+                                              "fp32 column from 524288 rows on, so this is rank 0 / no reflector on either side -- not a "
+                                              "factorization rate; see qr_f32_500000x256"}
                     if name in ("qr", "qrmax"):  # HBM bound as specified: algorithmic bytes 2 m n sizeof(f32)
                         gbs = 2.0 * (524287 if name == "qrmax" else 500000) * 256 * 4 * 3 / t / 1e9
                         others[lb]["GB/s_algorithmic"] = round(gbs, 1)
@@ -495,7 +679,10 @@ def main():
                             others[lb]["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                       "frac": round(gbs / HBM_PEAK_GBS, 4),
                                                       "algorithmic_bytes": 2.0 * 500000 * 256 * 4}
-                            others[lb]["roofline"].update(dominant_from_profile("qr") or {})
+                            if kr:
+                                others[lb]["roofline"]["dominant_kernel"] = kr
+                            else:
+                                others[lb]["roofline"].update(dominant_from_profile("qr") or {})
                     del st, ov
                     if not os.environ.get("BENCH_KEEP_CACHE"):  # diagnostic
                         torch.cuda.empty_cache()

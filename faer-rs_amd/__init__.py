@@ -162,6 +162,7 @@ def lib():
     L.faer_hip_malloc.restype = C.c_void_p
     L.faer_hip_time_gemm_ms.restype = C.c_double
     L.faer_hip_mfma_peak_tflops.restype = C.c_double
+    L.faer_hip_xwg_hop_us.restype = C.c_double
     L.faer_hip_dist_local_ncols.restype = C.c_size_t
     L.faer_hip_dist_panel_ws_scalars.restype = C.c_size_t
     _LIB = L
@@ -582,6 +583,28 @@ class RcclTransport:
         if self.handle:
             lib().faer_hip_rccl_destroy(C.c_void_p(self.handle))
             self.handle = None
+
+
+PROF_CLASSES = ("mfma_products", "lu_panel", "qr_update", "qr_gram", "qr_panel", "llt_leaf")
+PROF_UNITS = ("flop", "columns", "bytes", "bytes", "launches", "columns")
+
+
+def prof_begin():
+    """Start bracketing the dominant kernel classes of this thread's library calls with timing events (faer_hip.h)."""
+    lib().faer_hip_prof_begin()
+
+
+def prof_end():
+    """-> {class: {"ms", "launches", "units", "unit"}} of the launches since prof_begin (synchronises the device)."""
+    out = (C.c_double * (3 * len(PROF_CLASSES)))()
+    lib().faer_hip_prof_end(out)
+    return {name: {"ms": out[3 * i], "launches": int(out[3 * i + 1]), "units": out[3 * i + 2], "unit": PROF_UNITS[i]}
+            for i, name in enumerate(PROF_CLASSES)}
+
+
+def xwg_hop_us(iters=2000):
+    """Idle-chip hand-off latency between two workgroups on different XCDs, microseconds per hop (< 0: timed out)."""
+    return float(lib().faer_hip_xwg_hop_us(C.c_int(iters)))
 
 
 def dist_last_stats():

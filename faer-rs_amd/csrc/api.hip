@@ -1437,4 +1437,22 @@ double faer_hip_time_gemm_ms(FaerHipDType dtype, size_t m, size_t n, size_t k, v
 }
 double faer_hip_mfma_peak_tflops(FaerHipDType dtype, int iters) { return mfma_peak_tflops(dtype == FaerHipDType_F64, iters); }
 
+void faer_hip_prof_begin(void)
+{
+	Ctx &c = ctx();
+	double scratch[Ctx::PROF_CLASSES * 3];
+	prof_collect(scratch); // (drops spans of an unfinished profile)
+	c.prof_on = true;
+}
+void faer_hip_prof_end(double *out18)
+{
+	FH_CHECK(out18 != nullptr, "prof_end: NULL output");
+	Ctx &c = ctx();
+	c.prof_on = false;
+	FH_HIP(hipDeviceSynchronize());
+	prof_collect(out18);
+}
+double faer_hip_xwg_hop_us(int iters) { return xwg_hop_us(iters); }
+void faer_hip_partial_piv_lu_lend_copy(const void *device_copy) { lu_lend_copy(device_copy); }
+
 } // extern "C"

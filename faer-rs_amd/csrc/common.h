@@ -93,6 +93,20 @@ struct Ctx {
 	void reset_events() { la_next_event = 0; }
 	int ncu = 0;
 	int stream_cus(); // compute units the current stream can occupy (the look-ahead streams are CU masked)
+	// Kernel-class profile (faer_hip_prof_begin / faer_hip_prof_end, bench.py's per-workload `roofline`): while on, every launch
+	// of a dominant kernel class is bracketed by two timing events on ITS stream; prof_end adds the spans up per class.
+	// Classes: 0 big-tile MFMA products (units: flop), 1 LU panel kernel (columns), 2 one-pass QR update (algorithmic bytes),
+	// 3 one-pass QR Gram (bytes), 4 one-pass QR panel kernel (launches), 5 Cholesky leaf (columns).
+	struct ProfSpan {
+		hipEvent_t a, b;
+		int cls;
+		double units;
+	};
+	static constexpr int PROF_CLASSES = 6;
+	bool prof_on = false;
+	std::vector<ProfSpan> prof_spans;
+	std::vector<hipEvent_t> prof_pool;
+	hipEvent_t prof_event();
 
 	void ensure_device();
 	void *alloc(size_t bytes); // returns a device buffer valid until release()
@@ -105,6 +119,8 @@ struct Ctx {
 };
 Ctx &ctx();
 void debug_stream_xcc(int which, int nblocks, unsigned *out_host); // which: 0 caller's stream, 1 bulk, 2 panel
+void prof_collect(double *out); // Ctx::PROF_CLASSES x {ms, launches, units} of the spans recorded since prof_on (ctx.hip)
+double xwg_hop_us(int iters); // idle-chip hand-off latency between two workgroups, microseconds (ctx.hip)
 void ctx_shutdown(); // releases the calling thread's look-ahead streams / events; safe without a device
 
 // stream `s` waits for event `e`
@@ -117,6 +133,31 @@ struct StreamScope {
 	~StreamScope() { ctx().stream = saved; }
 	StreamScope(const StreamScope &) = delete;
 	StreamScope &operator=(const StreamScope &) = delete;
+};
+
+// RAII: one profiled launch (no-op unless Ctx::prof_on)
+struct ProfScope {
+	Ctx::ProfSpan sp;
+	bool on;
+	ProfScope(int cls, double units) : on(ctx().prof_on && cls >= 0)
+	{
+		if (!on)
+			return;
+		sp.cls = cls;
+		sp.units = units;
+		sp.a = ctx().prof_event();
+		sp.b = ctx().prof_event();
+		FH_HIP(hipEventRecord(sp.a, ctx().stream));
+	}
+	~ProfScope()
+	{
+		if (!on)
+			return;
+		FH_HIP(hipEventRecord(sp.b, ctx().stream));
+		ctx().prof_spans.push_back(sp);
+	}
+	ProfScope(const ProfScope &) = delete;
+	ProfScope &operator=(const ProfScope &) = delete;
 };
 
 // RAII scratch
@@ -288,6 +329,8 @@ std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2);
 int lu_leaf_width(idx_t m, int elem_bytes, int resident_workgroups);
 bool dist_two_streams_ok(idx_t panel_rows, int elem_bytes, int panel_cus, int all_cus);
 void lu_force_general(int on); // debug: every LU leaf on the non-cooperative path
+void lu_lend_copy(const void *device_copy); // the calling thread's next LU may restore A from it after an exchange timeout (getrf.hip)
+bool rccl_is_builtin_wait(FaerHipWaitFn fn); // rccl_transport.hip: is this the built-in transport's wait (takes any stream)
 long qr_last_one_pass_columns(); // debug: columns the one-pass QR path completed in this thread's last factorization (-1: not taken)
 // tall-skinny shapes (skinny.hip): streaming kernels; false if the shape / strides do not qualify
 template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV<const T> B, T alpha);

@@ -185,6 +185,95 @@ void debug_stream_xcc(int which, int nblocks, unsigned *out_host)
 	FH_HIP(hipFree(d));
 }
 
+// Box-population probe: two resident workgroups (the dispatcher deals consecutive workgroups to different
+// XCDs) bounce a data-tagged granule (xwg.h, recipe R2) `iters` times; returns microseconds per one-way hand-off on an otherwise
+// idle chip.  The latency-bound kernels (LU panel, substitution leaves) track this number: ~0.8 us on the fast boxes of the pool.
+__global__ void xwg_hop_kernel(unsigned long long *gran, int iters, int *status)
+{
+	const int me = blockIdx.x, other = 1 - me;
+	if (threadIdx.x != 0)
+		return;
+	for (int r = 1; r <= iters; ++r) {
+		if (me == 0)
+			__hip_atomic_store(gran + 0, ((unsigned long long) r << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		bool ok = false;
+		for (int spin = 0; spin < (1 << 22); ++spin) {
+			const unsigned long long v = __hip_atomic_load(gran + (me == 0 ? 16 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((unsigned) (v >> 32) == (unsigned) r) {
+				ok = true;
+				break;
+			}
+		}
+		if (!ok) {
+			atomicExch(status, 1);
+			return;
+		}
+		if (me == 1)
+			__hip_atomic_store(gran + 16, ((unsigned long long) r << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		(void) other;
+	}
+}
+
+double xwg_hop_us(int iters)
+{
+	Ctx &c = ctx();
+	if (iters < 1)
+		iters = 1;
+	Scratch buf(512);
+	FH_HIP(hipMemsetAsync(buf.p, 0, 512, c.stream));
+	unsigned long long *g = buf.as<unsigned long long>();
+	int *st = reinterpret_cast<int *>(g + 32);
+	hipEvent_t e0, e1;
+	FH_HIP(hipEventCreate(&e0));
+	FH_HIP(hipEventCreate(&e1));
+	hipLaunchKernelGGL(xwg_hop_kernel, dim3(2), dim3(64), 0, c.stream, g, 8, st); // warm (code fetch)
+	FH_HIP(hipMemsetAsync(buf.p, 0, 512, c.stream));
+	FH_HIP(hipEventRecord(e0, c.stream));
+	hipLaunchKernelGGL(xwg_hop_kernel, dim3(2), dim3(64), 0, c.stream, g, iters, st);
+	FH_HIP(hipEventRecord(e1, c.stream));
+	FH_HIP(hipEventSynchronize(e1));
+	float ms = 0;
+	FH_HIP(hipEventElapsedTime(&ms, e0, e1));
+	int h = 0;
+	FH_HIP(hipMemcpy(&h, st, sizeof(int), hipMemcpyDeviceToHost));
+	FH_HIP(hipEventDestroy(e0));
+	FH_HIP(hipEventDestroy(e1));
+	if (h != 0)
+		return -1.0; // (the two workgroups were not resident together: a busy GPU)
+	return (double) ms * 1e3 / (2.0 * iters);
+}
+
+hipEvent_t Ctx::prof_event()
+{
+	if (!prof_pool.empty()) {
+		hipEvent_t e = prof_pool.back();
+		prof_pool.pop_back();
+		return e;
+	}
+	hipEvent_t e;
+	FH_HIP(hipEventCreate(&e));
+	return e;
+}
+
+// out: PROF_CLASSES x {milliseconds inside the class's launches, launches, units}; the caller has synchronised
+void prof_collect(double *out)
+{
+	Ctx &c = ctx();
+	for (int i = 0; i < Ctx::PROF_CLASSES * 3; ++i)
+		out[i] = 0.0;
+	for (Ctx::ProfSpan &sp : c.prof_spans) {
+		float ms = 0;
+		if (sp.cls >= 0 && sp.cls < Ctx::PROF_CLASSES && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+			out[3 * sp.cls + 0] += ms;
+			out[3 * sp.cls + 1] += 1.0;
+			out[3 * sp.cls + 2] += sp.units;
+		}
+		c.prof_pool.push_back(sp.a);
+		c.prof_pool.push_back(sp.b);
+	}
+	c.prof_spans.clear();
+}
+
 hipEvent_t Ctx::next_event()
 {
 	if (la_next_event == la_events.size()) {

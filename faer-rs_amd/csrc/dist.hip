@@ -88,16 +88,19 @@ template <typename S> struct DeviceBackend {
 		else
 			bcast(buf, bytes, root);
 	}
-	// The transport's wait orders the CURRENT stream of its own world behind the transfer: the built-in RCCL transport that
-	// is ctx().stream, a callback transport (torch.distributed handles) the caller's stream.  Called from the look-ahead or the
-	// rest part (dist_llt.h waits for a chunk where it is first read, on the panel / bulk stream), the wait is therefore taken
-	// on the caller's stream and handed to the internal stream through an event.
+	// The transport's wait orders a stream behind the transfer.  The built-in RCCL transport's wait is a stream-wait on an event
+	// and takes ctx().stream as it is -- the panel / bulk stream that first reads the chunk (dist_llt.h), and only that stream
+	// waits.  A callback transport (torch.distributed handles) orders the stream of ITS world, the caller's: the wait is taken
+	// there and handed to the internal stream through an event -- that event also carries whatever else the caller's stream is
+	// waiting for at that point (the owner's look-ahead pauses), so with a callback transport the rest of update k can start
+	// later than the transfer alone would demand (a dedicated helper stream would be a fifth stream of this process,
+	// see Ctx::qr_side_streams for what that costs).
 	void bcast_wait(int slot)
 	{
 		if (!(comm.ibcast && comm.wait))
 			return;
 		hipStream_t cur = ctx().stream;
-		if (caller && cur != caller) {
+		if (caller && cur != caller && !rccl_is_builtin_wait(comm.wait)) {
 			ctx().stream = caller;
 			comm.wait(comm.user, slot);
 			hipEvent_t e = ctx().next_event();

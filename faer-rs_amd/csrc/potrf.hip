@@ -289,6 +289,7 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 		return;
 	if (n <= POTRF_NB) {
 		T *W = need_inv ? Wbase + (size_t) (offset / POTRF_NB) * TriPack<T>::SIZE : nullptr;
+		ProfScope prof(5, (double) n);
 		hipLaunchKernelGGL((potrf_leaf_kernel<T, false>), dim3(1), dim3(LDS_NT), 0, ctx().stream, A.p, A.rs, A.cs, (int) n, regularize,
 				   eps, delta, status, (int) offset, W, (const signed char *) nullptr, (T *) nullptr);
 		FH_HIP(hipGetLastError());
@@ -323,8 +324,11 @@ static void potrf_panel_flat(MatV<T> P, int regularize, T eps, T delta, int *sta
 			gemm_dev<T>(P.sub(c0, c0, R - c0, nb), DST_LOWER, true, P.sub(c0, 0, R - c0, c0).c(), P.sub(c0, 0, nb, c0).t().c(), (T) -1);
 		T *W = Wbase + (size_t) ((offset + c0) / POTRF_NB - wblk0) * TriPack<T>::SIZE;
 		MatV<T> D = P.sub(c0, c0, nb, nb);
-		hipLaunchKernelGGL((potrf_leaf_kernel<T, false>), dim3(1), dim3(LDS_NT), 0, ctx().stream, D.p, D.rs, D.cs, (int) nb, regularize, eps,
-				   delta, status, (int) (offset + c0), W, (const signed char *) nullptr, (T *) nullptr);
+		{
+			ProfScope prof(5, (double) nb);
+			hipLaunchKernelGGL((potrf_leaf_kernel<T, false>), dim3(1), dim3(LDS_NT), 0, ctx().stream, D.p, D.rs, D.cs, (int) nb, regularize, eps,
+					   delta, status, (int) (offset + c0), W, (const signed char *) nullptr, (T *) nullptr);
+		}
 		FH_HIP(hipGetLastError());
 		if (R > c0 + nb) // rows below <- rows below * L_kk^-T: substitution leaf, lanes along the rows of the panel
 			trsm_lower_pre_dev<T>(D.c(), P.sub(c0 + nb, c0, R - c0 - nb, nb).t(), W);

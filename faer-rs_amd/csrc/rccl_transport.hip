@@ -139,6 +139,11 @@ void rccl_bcast(void *user, void *buf, size_t bytes, int root)
 
 } // namespace
 
+namespace fh {
+// dist.hip: the built-in transport's wait only needs ctx().stream, whichever stream that is
+bool rccl_is_builtin_wait(FaerHipWaitFn fn) { return fn == rccl_wait; }
+} // namespace fh
+
 extern "C" {
 
 int faer_hip_rccl_unique_id(void *out128)

@@ -1719,6 +1719,8 @@ __global__ __launch_bounds__(256) void tq_tx_general_kernel(const TqTxArgs a)
 static void tq_launch_update(bool vec, int nwg, const TqUpdArgs &ua)
 {
 	hipStream_t s = ctx().stream;
+	// (profile class 2; algorithmic bytes of the launch: the panel and the strip read once, the strip -- and V, if stored -- written once)
+	ProfScope prof(2, (double) ua.rows * 4.0 * ((double) ua.w + 2.0 * (double) ua.ts + (ua.do_v ? (double) ua.w : 0.0)));
 	if (vec)
 		hipLaunchKernelGGL(tq_update_kernel<true>, dim3(nwg), dim3(256), 0, s, ua);
 	else
@@ -1749,10 +1751,13 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 	const int nb = g.nchunks < TQ_NB ? g.nchunks : TQ_NB;
 	if (nb <= 0)
 		return;
-	if (vec)
-		hipLaunchKernelGGL(tq_gram_kernel<true>, dim3(nb), dim3(256), 0, s, g);
-	else
-		hipLaunchKernelGGL(tq_gram_kernel<false>, dim3(nb), dim3(256), 0, s, g);
+	{
+		ProfScope prof(3, (double) rows * 4.0 * ((double) w + (double) t)); // (class 3: the panel and the trailing columns read once)
+		if (vec)
+			hipLaunchKernelGGL(tq_gram_kernel<true>, dim3(nb), dim3(256), 0, s, g);
+		else
+			hipLaunchKernelGGL(tq_gram_kernel<false>, dim3(nb), dim3(256), 0, s, g);
+	}
 	const int total = (want_g ? 4096 : 0) + 64 * g.tp + (want_sq ? 256 : 0);
 	hipLaunchKernelGGL(tq_reduce_kernel, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, Gp, Cp, Sp, nb, g.tp, (int) want_g, (int) want_sq, G, C,
 			   ldc, coff, S, stat, c0, Gf, cnt);
@@ -1912,6 +1917,8 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		pa.taus = taus;
 		pa.stat = stat;
 		pa.dbg = reinterpret_cast<long long *>(stat + 16);
+		StreamScope psc(ps);
+		ProfScope prof(4, 1.0);
 		hipLaunchKernelGGL(tq_panel_kernel, dim3(1), dim3(TQ_PT), 0, ps, pa);
 	};
 	// one block of Q_coeff over all panels (the tall-skinny case): the cross-panel blocks of T in two stages beside the last steps

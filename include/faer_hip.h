@@ -502,6 +502,30 @@ FAER_HIP_API double faer_hip_time_gemm_ms(FaerHipDType dtype, size_t m, size_t n
  * roofline fractions are quoted against next to the datasheet peak. */
 FAER_HIP_API double faer_hip_mfma_peak_tflops(FaerHipDType dtype, int iters);
 
+/* Kernel-class profile of the calling thread's library calls (bench.py's per-workload `roofline` objects): between
+ * faer_hip_prof_begin and faer_hip_prof_end every launch of a dominant kernel class is bracketed by two timing events on
+ * the stream it runs on.  prof_end synchronises the device and fills out[3 * cls + {0, 1, 2}] = {milliseconds inside the
+ * class's launches, launches, units} for cls = 0 big-tile MFMA products (units: flop), 1 LU panel kernel (columns),
+ * 2 one-pass QR update (algorithmic bytes), 3 one-pass QR Gram (bytes), 4 one-pass QR panel kernel (launches),
+ * 5 Cholesky leaf (columns).  Measurement aid: the events cost a few microseconds per launch, do not time a profiled call. */
+#define FAER_HIP_PROF_CLASSES 6
+FAER_HIP_API void faer_hip_prof_begin(void);
+FAER_HIP_API void faer_hip_prof_end(double *out_3_x_classes);
+/* Idle-chip hand-off latency between two resident workgroups on different XCDs, microseconds per one-way hop (tagged
+ * 8-byte granule, write-through store -> polling load).  The latency-bound kernels of the LU / Cholesky chains scale
+ * with it: bench.py prints it so that a line from a slow box of a pool is recognisable.  < 0: the probe timed out. */
+FAER_HIP_API double faer_hip_xwg_hop_us(int iters);
+
+/* Partial-pivot LU on a GPU shared with other work.  The cooperative panel kernel exchanges pivots between resident
+ * workgroups; the library arranges their residency itself (one workgroup per compute unit of the stream's CU set, taller
+ * panels on a non-cooperative kernel), so on a GPU of its own the exchange cannot stall.  If OTHER work holds compute units
+ * for longer than the bounded spin (~0.2 s) the call returns PartialPivLuStatus::Unknown and leaves a partially factored
+ * matrix.  A caller that wants the factorization completed even then lends a copy of the input first: `device_copy` =
+ * device memory holding the nrows x ncols matrix column major with leading dimension nrows, valid until the calling
+ * thread's NEXT partial_piv_lu call returns (which consumes it).  After a timeout that call restores A from the copy and
+ * factors it on the non-cooperative path (identical pivots, slower).  Rounds 3-4 made this copy internally on every call. */
+FAER_HIP_API void faer_hip_partial_piv_lu_lend_copy(const void *device_copy);
+
 /* ---------------------------------------------------------------------------------------------
  * 4. Multi-GPU: 1-D block-column partition, one process per GPU.
  *    The caller owns the transport: `bcast` is invoked with device buffers and must broadcast
@@ -511,8 +535,12 @@ FAER_HIP_API double faer_hip_mfma_peak_tflops(FaerHipDType dtype, int iters);
 typedef void (*FaerHipBcastFn)(void *user, void *device_buf, size_t bytes, int root);
 /* Optional asynchronous pair: `ibcast` starts the broadcast of `bytes` bytes at `device_buf` from `root` (ordered
  * after the work already enqueued on the calling thread's stream), `wait` makes that stream wait for the broadcast
- * started with the same `slot` (0 or 1; at most one broadcast per slot is in flight).  With both NULL the
- * drivers fall back to the blocking `bcast` (same results, no overlap of transfers with compute). */
+ * started with the same `slot` (0 .. FAER_HIP_COMM_SLOTS - 1; at most one broadcast per slot is in flight: the LU uses
+ * slots 0 / 1, the Cholesky ships a panel in up to four row chunks and alternates two panels, slots 0 .. 7).  `wait` may be
+ * called MORE THAN ONCE for the same slot between two `ibcast`s of it (the Cholesky waits for a chunk on every internal
+ * stream that reads it) and must then order the calling thread's stream behind the same transfer again.  With both NULL
+ * the drivers fall back to the blocking `bcast` (same results, no overlap of transfers with compute). */
+#define FAER_HIP_COMM_SLOTS 8
 typedef void (*FaerHipIbcastFn)(void *user, void *device_buf, size_t bytes, int root, int slot);
 typedef void (*FaerHipWaitFn)(void *user, int slot);
 typedef struct FaerHipComm {
