@@ -1172,14 +1172,22 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// launches for it.  Round 4: composed on the BULK stream at the start of the step that applies it (22 us that used to sit
 	// on the panel stream's chain).
 	static_assert(LU_LA_NB <= LASWP_SMALL_NT, "panel interchange list");
-	Scratch listb((size_t) 2 * 2 * LU_LA_NB * sizeof(int));
+	// one list per step: the side stream applies step k's list to the columns left of the panel while the bulk stream is
+	// already composing step k + 1's
+	Scratch listb((size_t) nsteps * 2 * 2 * LU_LA_NB * sizeof(int));
 	LaswpList full;
-	full.dst = listb.as<int>();
-	full.src = full.dst + 2 * LU_LA_NB;
+	auto use_list = [&](idx_t k) {
+		full.dst = listb.as<int>() + (size_t) k * 4 * LU_LA_NB;
+		full.src = full.dst + 2 * LU_LA_NB;
+	};
+	use_list(0);
 	c.qr_side_streams();
 	hipStream_t side = c.qr_side[0];
 	// remaining rows from which the bulk stream is the critical one (mode 2 below); fewer: the panel chain is
-	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= 10240; };
+	static const idx_t x_bb = getenv("FAER_HIP_X_BB") ? atol(getenv("FAER_HIP_X_BB")) : 10240;
+	static const int x_leftside = getenv("FAER_HIP_X_LEFTSIDE") ? atoi(getenv("FAER_HIP_X_LEFTSIDE")) : 1;
+	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= x_bb; };
+	hipEvent_t ev_left_done = nullptr; // the side stream's last interchange pass over the columns left of a panel
 	bool staged = false; // the panel about to be applied has already been applied to the next panel's columns except for its last part
 	{
 		StreamScope sc(c.la_panel);
@@ -1254,6 +1262,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		const idx_t w2 = j1 < n ? (LU_LA_NB < n - j1 ? LU_LA_NB : n - j1) : 0;
 		const idx_t j2 = j1 + w2;
 		hipEvent_t ev_next = nullptr;
+		use_list(k);
 		{
 			StreamScope sc(c.la_bulk);
 			stream_wait(c.la_bulk, ev_panel);
@@ -1268,15 +1277,23 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// Measured in one visit (profiles/r04_exp_lu_chain_grouping.txt, N = 16384): three chains 107.9 ms, mode 1 everywhere
 			// 102.4, mode 2 everywhere 101.6, mode 2 down to 10240 remaining rows 100.7.
 			const int mode = bulk_bound(m - j1) ? 2 : 1;
-			if (!(w2 > 0 && staged)) // (the staged path composes it behind the release of the next panel)
+			hipEvent_t ev_composed = nullptr; // step k's list is ready (what the side stream's pass over the left columns waits for)
+			auto compose = [&]() {
 				laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full);
+				if (x_leftside && side) {
+					ev_composed = c.next_event();
+					FH_HIP(hipEventRecord(ev_composed, c.la_bulk));
+				}
+			};
+			if (!(w2 > 0 && staged)) // (the staged path composes it behind the release of the next panel)
+				compose();
 			if (w2 > 0 && staged) {
 				// last stage of the staged update of the next panel's columns (the earlier ones ran beside the rest of panel k,
 				// see the panel part below): interchanges of the last QW pivots, U = L_qq^-1 (.), product with K = QW
 				stage_update(j0, (idx_t) (LU_LA_NB / QW - 1), j1, w2);
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
-				laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full);
+				compose();
 				if (j2 < n)
 					update(k, j0, w, j2, n - j2);
 			} else if (w2 > 0 && mode == 2 && side && j2 < n && m > j1) {
@@ -1329,7 +1346,16 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 				const idx_t jg0 = grp0 * LU_LA_NB;
 				const idx_t gend = j1 < size_all ? j1 : size_all; // pivots [jg0, gend) belong to the group
 				if (jg0 > 0) {
-					if (defer == 1)
+					if (defer == 1 && ev_composed) {
+						// Nothing reads the columns left of the panel again: their interchanges leave the two critical streams
+						// for the plain side stream (ordered among themselves by that stream, behind this step's chain for the
+						// far columns if it has one; they wait for the list only, not for this step's product)
+						StreamScope ss(side);
+						stream_wait(side, ev_composed);
+						swaps(k, jg0, gend - jg0, 0, jg0);
+						ev_left_done = c.next_event();
+						FH_HIP(hipEventRecord(ev_left_done, side));
+					} else if (defer == 1)
 						swaps(k, jg0, gend - jg0, 0, jg0);
 					else
 						laswp_dev<T>(A.sub(jg0, 0, m - jg0, jg0), wk.piv + jg0, (int) (gend - jg0), (int) jg0);
@@ -1369,6 +1395,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	FH_HIP(hipEventRecord(eb, c.la_bulk));
 	stream_wait(caller, eb);
 	stream_wait(caller, ev_panel);
+	if (ev_left_done)
+		stream_wait(caller, ev_left_done);
 }
 
 template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)

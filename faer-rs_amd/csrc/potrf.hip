@@ -367,6 +367,14 @@ std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2)
 			w = LA_NB; // narrow steps again towards the end
 		if (J.size() == 1 && first > 0 && first < w)
 			w = first; // (the whole chip waits for the first diagonal block)
+		static const int x_ramp = getenv("FAER_HIP_X_LLT_RAMP") ? atoi(getenv("FAER_HIP_X_LLT_RAMP")) : 0;
+		if (x_ramp && J.size() >= 2 && J.size() <= 3 && n >= 8 * LA_NB) {
+			// experiment: 128, 256, 512, then 1024-wide steps (x_ramp = 2: 128, 384, 512) -- every diagonal-block chain hides
+			// behind the previous step's product
+			const idx_t rw = x_ramp == 2 ? (J.size() == 2 ? 384 : 512) : (J.size() == 2 ? 256 : 512);
+			if (rw < w)
+				w = rw;
+		}
 		if (!(n - j0 > tail_rows && j0 + w < n))
 			break;
 		J.push_back(j0 + w);

@@ -1,7 +1,8 @@
 """Two ranks of the distributed drivers with the DEVICE backend (csrc/dist.hip) sharing one GPU: the multi-rank
 control flow (ownership, look-ahead order, two alternating panel buffers, status exchange) on real device kernels.
 The transport is gloo on host copies of the device buffer (one GPU box, no RCCL ring to form); the results must
-equal the single-GPU factorization of the same matrix by the same library: identical pivots, factors within
+equal the single-GPU factorization of the same matrix by the same library AND the CPU oracle's (VERDICT r04 weak 11:
+a device-backend result compared with the oracle directly, not only transitively): identical pivots, factors within
 tolerance."""
 import os
 import subprocess
@@ -64,10 +65,10 @@ if rank == 0:  # single-GPU reference by the same library
     ref = a.clone()
     if what == "lu":
         p, _, c = F.partial_piv_lu_factor_in_place(ref)
-        np.savez(os.path.join(out_dir, "ref.npz"), ref=ref.cpu().numpy(), fwd=p, cnt=c)
+        np.savez(os.path.join(out_dir, "ref.npz"), ref=ref.cpu().numpy(), fwd=p, cnt=c, a=a.cpu().numpy())
     else:
         c = F.llt_factor_in_place(ref)
-        np.savez(os.path.join(out_dir, "ref.npz"), ref=ref.cpu().numpy(), cnt=c)
+        np.savez(os.path.join(out_dir, "ref.npz"), ref=ref.cpu().numpy(), cnt=c, a=a.cpu().numpy())
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -91,17 +92,23 @@ def run(tmp_path, what, n, nb, use_async):
 
 
 @pytest.mark.parametrize("n,nb,use_async", [(1024, 128, True), (900, 256, False)])
-def test_two_rank_lu_equals_single_gpu(tmp_path, n, nb, use_async):
+def test_two_rank_lu_equals_single_gpu(tmp_path, oracle, n, nb, use_async):
     res, ref = run(tmp_path, "lu", n, nb, use_async)
     got = np.zeros((n, n))
     for r in res:
         assert np.array_equal(r["fwd"], ref["fwd"]) and int(r["cnt"]) == int(ref["cnt"])
         got[:, r["cols"]] = r["loc"]
     assert np.abs(got - ref["ref"]).max() <= 256 * n * 2.3e-16 * max(1.0, np.abs(ref["ref"]).max())
+    # ... and the oracle's: same permutation, factors within the forward error of the factorization
+    o = np.asfortranarray(ref["a"])
+    operm, _, ont = oracle.lu_in_place(o)
+    assert np.array_equal(np.asarray(res[0]["fwd"]).astype(np.int64), operm) and int(res[0]["cnt"]) == ont
+    kappa = np.linalg.cond(ref["a"][operm])
+    assert np.abs(got - o).max() <= 4 * n * 2.3e-16 * kappa * max(1.0, np.abs(o).max())
 
 
 @pytest.mark.parametrize("n,nb,use_async", [(1024, 128, True), (1000, 192, False), (2500, 128, True)])
-def test_two_rank_llt_equals_single_gpu(tmp_path, n, nb, use_async):
+def test_two_rank_llt_equals_single_gpu(tmp_path, oracle, n, nb, use_async):
     res, ref = run(tmp_path, "llt", n, nb, use_async)
     got = np.zeros((n, n))
     for r in res:
@@ -110,3 +117,8 @@ def test_two_rank_llt_equals_single_gpu(tmp_path, n, nb, use_async):
         got[:, r["cols"]] = r["loc"]
     il = np.tril_indices(n)
     assert np.abs(got[il] - ref["ref"][il]).max() <= 256 * n * 2.3e-16 * np.abs(ref["ref"][il]).max()
+    # ... and the oracle's Cholesky factor of the same matrix
+    o = np.asfortranarray(ref["a"])
+    assert oracle.llt_in_place(o) == ("ok", 0)
+    kappa = np.linalg.cond(ref["a"])
+    assert np.abs(got[il] - o[il]).max() <= 8 * n * 2.3e-16 * kappa * np.abs(o[il]).max()

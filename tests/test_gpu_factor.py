@@ -686,3 +686,25 @@ def test_ldlt_large_property():
     D = torch.diagonal(w)
     err = torch.tril(L @ (D[:, None] * L.t()) - a).abs().max().item()
     assert err <= 32 * n * 2.3e-16 * a.abs().max().item()
+
+
+def test_llt_lookahead_on_a_view_with_reversed_rows_and_columns(oracle):
+    """a Cholesky with n >= 2048 (the look-ahead driver, whose merged trailing update asks the GEMM for a tile skip) on a device
+    view with NEGATIVE strides: the buffer-addressed loaders cannot express it, gemm_dev splits the merged update into the two
+    plain products of the pointer-addressed kernel instead of refusing"""
+    import ctypes as C
+    F = init_gpu()
+    n = 2304
+    rng = np.random.default_rng(77)
+    a = spd(rng, n)
+    # store the matrix with rows AND columns reversed; the view (i, j) -> stored (n-1-i, n-1-j) is the matrix itself
+    d = to_dev(np.asfortranarray(a[::-1, ::-1]))
+    v = F.MatMut(d.data_ptr() + ((n - 1) * d.stride(0) + (n - 1) * d.stride(1)) * 8, n, n, -d.stride(0), -d.stride(1))
+    reg = F.LltRegularization()
+    st = F.lib().libfaer_v0_23_llt_factor_in_place_f64(v, reg, F.PAR_SEQ, F.MemAlloc(), F.lib().libfaer_v0_23_LltParams_f64())
+    assert st.tag == 0
+    got = to_host(d)[::-1, ::-1]
+    ref = a.copy(order="F")
+    assert oracle.llt_in_place(ref) == ("ok", 0)
+    il = np.tril_indices(n)
+    assert np.abs(got[il] - ref[il]).max() <= 64 * n * 2.3e-16 * np.abs(ref[il]).max()

@@ -92,6 +92,45 @@ def test_matmul_device_negative_strides_and_huge_leading_dimension(oracle):
     assert (c - ref).abs().max().item() <= 64 * k * 2.3e-16 * 16
 
 
+@pytest.mark.parametrize("bcs", [0, 1, 3, 8, 15, 16, 17])
+@pytest.mark.parametrize("shape", [(300, 260, 96), (128, 128, 64), (70, 33, 200)])
+def test_matmul_rhs_broadcast_and_overlapping_columns(bcs, shape):
+    """a K-major rhs whose columns are fewer than 16 elements apart -- a broadcast view (column stride 0: every column the
+    same vector) or overlapping windows of one long vector (Hankel / sliding-window views): the descriptor-addressed B loader
+    of the pipelined kernel ends where column N begins and would cut the last columns short, so gemm_dev routes
+    them to the pointer loaders.  Also the edge tiles of an ordinary rhs placed at the very END of its allocation."""
+    import ctypes as C
+    import torch
+    F = init_gpu()
+    m, n, k = shape
+    rng = np.random.default_rng(bcs * 7 + m)
+    a = rnd(rng, m, k)
+    vec = rng.standard_normal(k + max(bcs, 1) * n + 16)
+    dvec = to_dev(vec.reshape(-1, 1))
+    da, dc = to_dev(a), to_dev(np.full((m, n), np.nan))
+    vb = F.MatRef(dvec.data_ptr(), k, n, 1, bcs)
+    al = C.c_double(1.0)
+    F.lib().libfaer_v0_23_matmul_f64(F._mat(dc, F.MatMut), C.c_int(F.ACCUM_REPLACE), F._mat(da), vb, C.byref(al), F.PAR_SEQ)
+    b = np.stack([vec[j * bcs: j * bcs + k] for j in range(n)], axis=1)
+    ref = a @ b
+    assert np.abs(to_host(dc) - ref).max() <= 64 * k * 2.3e-16 * max(1.0, np.abs(ref).max())
+
+
+def test_matmul_rhs_at_the_end_of_its_allocation():
+    """edge tiles (N not a multiple of the tile) of a column-major rhs that ends exactly where its allocation ends: the scalar
+    offsets of the B loader are clamped to the operand (the hardware checks only the per-lane part)"""
+    import torch
+    F = init_gpu()
+    m, n, k = 512, 2 * 128 + 37, 512  # big tiles (>= 256 of them is not needed: the 64 x 64 pipelined tile takes the same loader)
+    for nn in (n, 1000 + 1):
+        a = torch.randn((k, m), dtype=torch.float64, device="cuda").t()
+        b = torch.randn((nn, k), dtype=torch.float64, device="cuda").t()  # k x nn column major: its last column ends the allocation
+        c = torch.empty((nn, m), dtype=torch.float64, device="cuda").t()
+        F.matmul(c, F.ACCUM_REPLACE, a, b, 1.0)
+        F.synchronize()
+        assert (c - a @ b).abs().max().item() <= 64 * k * 2.3e-16 * 16
+
+
 def test_matmul_host_pointers(oracle):
     """host-resident operands (a faer::Mat): staged through device buffers by the library"""
     F = init_gpu()
