@@ -162,7 +162,8 @@ def lib():
     L.faer_hip_malloc.restype = C.c_void_p
     L.faer_hip_time_gemm_ms.restype = C.c_double
     L.faer_hip_mfma_peak_tflops.restype = C.c_double
-    L.faer_hip_xwg_hop_us.restype = C.c_double
+    if hasattr(L, "faer_hip_xwg_hop_us"):  # (absent from older builds loaded through FAER_HIP_LIB for A/B runs)
+        L.faer_hip_xwg_hop_us.restype = C.c_double
     L.faer_hip_dist_local_ncols.restype = C.c_size_t
     L.faer_hip_dist_panel_ws_scalars.restype = C.c_size_t
     _LIB = L
