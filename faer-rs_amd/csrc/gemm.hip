@@ -586,11 +586,15 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 				  : (unsigned) ((idx_t) min(b_mn0, g.N - 1) * g.bcs + (idx_t) b_k * g.brs) * TS;
 	const idx_t b_ext = (idx_t) (g.N - n_off) * g.bcs * (idx_t) TS;
 	const unsigned b_lim = BKM ? (b_ext < (idx_t) 0xfffffff0u ? (unsigned) b_ext : 0xfffffff0u) : 0x7fffffffu;
-	// The hardware's range check covers the per-lane offset only, NOT the scalar offset: the column step of element
-	// i travels in the scalar offset, so it is clamped here (wave uniform, once per tile) to the last full group of B_NSTEP
-	// columns -- lane part (< B_NSTEP columns) + clamped scalar part <= N - n_off - 1 columns, never beyond the operand; what is
-	// left to the descriptor is the lane part of tiles with fewer than B_NSTEP columns.  Clamped elements are masked (b_mnmask).
-	const int b_ncl = BKM ? max(g.N - n_off - B_NSTEP, 0) : 0;
+	// The hardware's range check covers the per-lane offset only, NOT the scalar offset: with the column step of
+	// element i in the scalar offset, an edge tile would read up to BN - 1 columns past the end of B (masked afterwards, but
+	// outside the operand).  The column steps of a K-major B therefore travel in per-lane offsets prepared here, once per tile
+	// (B_CNT registers, no vector ALU inside the K loop either): every element of every lane is checked against the descriptor,
+	// which ends where column N begins.
+	unsigned b_vo_i[BKM ? B_CNT : 1];
+#pragma unroll
+	for (int i = 0; i < (BKM ? B_CNT : 1); ++i)
+		b_vo_i[i] = b_vo + (unsigned) (i * B_NSTEP * (int) g.bcs) * TS;
 	// (the eight-wavefront 128 x 256 tile loads only B this way: descriptors for both 71.4 -> 70.0 TFLOP/s at N = 8192, for A alone
 	// 69.8, for B alone 72.0; the four-wavefront tiles gain 4 % with both: profiles/r04_gemm_tile_phases.txt)
 	constexpr bool BUF_A = !AKM && WM * WN == 4, BUF_B = true;
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) b_ub, 0, (int) b_lim, 0x00020000);
 #pragma unroll
 			for (int i = 0; i < B_CNT; ++i)
-				rb_[i] = TileIO<T>::load(rs, b_vo, (unsigned) (BKM ? min(i * B_NSTEP, b_ncl) * (int) g.bcs : i * B_KSTEP * (int) g.brs) * TS);
+				rb_[i] = BKM ? TileIO<T>::load(rs, b_vo_i[BKM ? i : 0], 0u) : TileIO<T>::load(rs, b_vo, (unsigned) (i * B_KSTEP * (int) g.brs) * TS);
 		}
 	};
 	// last (possibly partial) tile starting at k0: k >= k_end is clamped to k_end - 1 and masked
