@@ -1160,8 +1160,23 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 {
 	Ctx &c = ctx();
 	const idx_t m = A.nrows, n = A.ncols; // n <= m
-	const idx_t size_all = n;		      // every column is a pivot column (n <= m)
-	const idx_t nsteps = (n + LU_LA_NB - 1) / LU_LA_NB;
+	// Step plan: LU_LA_NB-column panels while the bulk stream is the critical one (wide steps keep its trailing products at
+	// K = 512); once the panel chain is critical (fewer than `nb2_from` rows below the panel) the steps narrow to `nb2` columns:
+	// the top node of a panel's recursion -- interchanges, a solve against half the panel, a product on the reserved CUs -- is
+	// then done by the (idle) bulk stream as part of its update, and what sits between two panels is half as long.
+	static const idx_t x_nb2 = getenv("FAER_HIP_X_NB2") ? atol(getenv("FAER_HIP_X_NB2")) : LU_LA_NB;
+	static const idx_t x_nb2_from = getenv("FAER_HIP_X_NB2_FROM") ? atol(getenv("FAER_HIP_X_NB2_FROM")) : 10240;
+	std::vector<idx_t> J;
+	J.push_back(0);
+	while (J.back() < n) {
+		const idx_t j0 = J.back();
+		idx_t w = (m - j0 - LU_LA_NB >= x_nb2_from || x_nb2 <= 0 || x_nb2 > LU_LA_NB || x_nb2 % 128 != 0) ? LU_LA_NB : x_nb2;
+		if (w > n - j0)
+			w = n - j0;
+		J.push_back(j0 + w);
+	}
+	const idx_t nsteps = (idx_t) J.size() - 1;
+	auto Jat = [&](idx_t k) { return k < (idx_t) J.size() ? J[(size_t) k] : n; };
 	c.reset_events();
 	hipEvent_t e0 = c.next_event();
 	FH_HIP(hipEventRecord(e0, caller));
@@ -1185,13 +1200,13 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	hipStream_t side = c.qr_side[0];
 	// remaining rows from which the bulk stream is the critical one (mode 2 below); fewer: the panel chain is
 	static const idx_t x_bb = getenv("FAER_HIP_X_BB") ? atol(getenv("FAER_HIP_X_BB")) : 10240;
-	static const int x_leftside = getenv("FAER_HIP_X_LEFTSIDE") ? atoi(getenv("FAER_HIP_X_LEFTSIDE")) : 1;
+	static const int x_leftside = getenv("FAER_HIP_X_LEFTSIDE") ? atoi(getenv("FAER_HIP_X_LEFTSIDE")) : 0;
 	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= x_bb; };
 	hipEvent_t ev_left_done = nullptr; // the side stream's last interchange pass over the columns left of a panel
 	bool staged = false; // the panel about to be applied has already been applied to the next panel's columns except for its last part
 	{
 		StreamScope sc(c.la_panel);
-		const idx_t w0 = LU_LA_NB < n ? LU_LA_NB : n;
+		const idx_t w0 = J[1];
 		getrf_rec<T>(A.sub(0, 0, m, w0), 0, 0, wk);
 		ev_panel = c.next_event();
 		FH_HIP(hipEventRecord(ev_panel, c.la_panel));
@@ -1216,7 +1231,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// against that diagonal block, the product with the QW columns below it -- on the bulk stream.
 	// QW = 256 (two stages): with four stages of 128 the part left between two panels is shorter, but the factorization is 2 - 3 ms
 	// SLOWER at N = 8192 .. 16384 (profiles/r04_exp_lu_stages.txt): twice the small launches beside the latency-bound panel kernel
-	constexpr idx_t QW = 256;
+	idx_t QW = 256; // (half of the panel being staged; set per step)
 	hipEvent_t ev_stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	auto stage_update = [&](idx_t jp, idx_t q, idx_t cx, idx_t wx) {
 		const idx_t r0 = jp + q * QW, r1 = r0 + QW;
@@ -1233,7 +1248,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		if (hi - lo == QW) {
 			getrf_rec<T>(A.sub(jp + lo, jp + lo, m - jp - lo, QW), (int) (jp + lo), (int) (jp + lo), wk);
 			const idx_t q = lo / QW;
-			if (hi < LU_LA_NB) { // (the last part's stage opens the next step on the bulk stream)
+			if (hi < 2 * QW) { // (the last part's stage opens the next step on the bulk stream)
 				hipEvent_t ev_part = c.next_event();
 				FH_HIP(hipEventRecord(ev_part, c.la_panel));
 				StreamScope sb(c.la_bulk);
@@ -1256,11 +1271,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		laswp_dev<T>(A.sub(b, a, m - b, mid - lo), wk.piv + b, (int) (hi - mid), (int) b);
 	};
 	for (idx_t k = 0; k < nsteps; ++k) {
-		const idx_t j0 = k * LU_LA_NB;
-		const idx_t w = LU_LA_NB < n - j0 ? LU_LA_NB : n - j0;
-		const idx_t j1 = j0 + w;
-		const idx_t w2 = j1 < n ? (LU_LA_NB < n - j1 ? LU_LA_NB : n - j1) : 0;
-		const idx_t j2 = j1 + w2;
+		const idx_t j0 = J[(size_t) k], j1 = J[(size_t) k + 1], w = j1 - j0;
+		const idx_t j2 = Jat(k + 2), w2 = j2 - j1;
 		hipEvent_t ev_next = nullptr;
 		use_list(k);
 		{
@@ -1290,7 +1302,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			if (w2 > 0 && staged) {
 				// last stage of the staged update of the next panel's columns (the earlier ones ran beside the rest of panel k,
 				// see the panel part below): interchanges of the last QW pivots, U = L_qq^-1 (.), product with K = QW
-				stage_update(j0, (idx_t) (LU_LA_NB / QW - 1), j1, w2);
+				QW = w / 2;
+				stage_update(j0, 1, j1, w2);
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
 				compose();
@@ -1340,29 +1353,16 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// Default 1 (every panel at once): with 8 the composed passes moved ~8 ms off the bulk stream's per-panel
 			// scattered passes but cost as much again in compose_perm / gather / scatter launches and a serial tail
 			// (142.6 vs 145.1 ms at N = 16384, profiles/r02_exp_lu_panel.txt).
-			const idx_t defer = 1;
-			const idx_t grp0 = (k / defer) * defer; // first panel of this group
-			if (k + 1 == nsteps || (k + 1) % defer == 0) {
-				const idx_t jg0 = grp0 * LU_LA_NB;
-				const idx_t gend = j1 < size_all ? j1 : size_all; // pivots [jg0, gend) belong to the group
-				if (jg0 > 0) {
-					if (defer == 1 && ev_composed) {
-						// Nothing reads the columns left of the panel again: their interchanges leave the two critical streams
-						// for the plain side stream (ordered among themselves by that stream, behind this step's chain for the
-						// far columns if it has one; they wait for the list only, not for this step's product)
-						StreamScope ss(side);
-						stream_wait(side, ev_composed);
-						swaps(k, jg0, gend - jg0, 0, jg0);
-						ev_left_done = c.next_event();
-						FH_HIP(hipEventRecord(ev_left_done, side));
-					} else if (defer == 1)
-						swaps(k, jg0, gend - jg0, 0, jg0);
-					else
-						laswp_dev<T>(A.sub(jg0, 0, m - jg0, jg0), wk.piv + jg0, (int) (gend - jg0), (int) jg0);
-				}
-				for (idx_t kb = grp0; kb < k; ++kb) { // inside the group: block kb gets the interchanges of the panels after it
-					const idx_t c0 = kb * LU_LA_NB, r0 = c0 + LU_LA_NB;
-					laswp_dev<T>(A.sub(r0, c0, m - r0, LU_LA_NB), wk.piv + r0, (int) (gend - r0), (int) r0);
+			if (j0 > 0) {
+				if (ev_composed) {
+					// (experiment, slower: the interchanges of the columns left of the panel on the plain side stream)
+					StreamScope ss(side);
+					stream_wait(side, ev_composed);
+					swaps(k, j0, w, 0, j0);
+					ev_left_done = c.next_event();
+					FH_HIP(hipEventRecord(ev_left_done, side));
+				} else {
+					swaps(k, j0, w, 0, j0);
 				}
 			}
 		}
@@ -1377,12 +1377,13 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// panels.  Row interchanges of later parts commute with a stage (they move whole rows of L and of the updated columns
 			// alike); the panel stream only has to wait for a stage before it interchanges rows of that part's columns
 			// (factor.rs:127-185), which the stage reads.
-			const idx_t w3 = j2 < n ? (LU_LA_NB < n - j2 ? LU_LA_NB : n - j2) : 0;
-			const bool stage = w2 == LU_LA_NB && w3 > 0 && !bulk_bound(m - j2) && m - j1 > LU_LA_NB;
+			const idx_t w3 = Jat(k + 3) - j2;
+			const bool stage = w2 >= 256 && w2 % 256 == 0 && w3 > 0 && !bulk_bound(m - j2) && m - j1 > w2;
 			if (!stage) {
 				getrf_rec<T>(A.sub(j1, j1, m - j1, w2), (int) j1, (int) j1, wk);
 			} else {
-				staged_panel(j1, j2, w3, 0, LU_LA_NB);
+				QW = w2 / 2;
+				staged_panel(j1, j2, w3, 0, w2);
 			}
 			staged = stage;
 			ev_panel = c.next_event();
