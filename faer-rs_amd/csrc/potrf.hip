@@ -367,12 +367,22 @@ std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2)
 			w = LA_NB; // narrow steps again towards the end
 		if (J.size() == 1 && first > 0 && first < w)
 			w = first; // (the whole chip waits for the first diagonal block)
-		static const int x_ramp = getenv("FAER_HIP_X_LLT_RAMP") ? atoi(getenv("FAER_HIP_X_LLT_RAMP")) : 0;
-		if (x_ramp && J.size() >= 2 && J.size() <= 3 && n >= 8 * LA_NB) {
-			// experiment: 128, 256, 512, then 1024-wide steps (x_ramp = 2: 128, 384, 512) -- every diagonal-block chain hides
-			// behind the previous step's product
-			const idx_t rw = x_ramp == 2 ? (J.size() == 2 ? 384 : 512) : (J.size() == 2 ? 256 : 512);
-			if (rw < w)
+		// experiment: widths of the steps after the first one, e.g. FAER_HIP_X_LLT_RAMP=256,640 (multiples of 128)
+		static const std::vector<idx_t> x_ramp = []() {
+			std::vector<idx_t> v;
+			if (const char *e = getenv("FAER_HIP_X_LLT_RAMP"))
+				for (const char *p = e; *p;) {
+					v.push_back(atol(p));
+					while (*p && *p != ',')
+						++p;
+					if (*p == ',')
+						++p;
+				}
+			return v;
+		}();
+		if (J.size() >= 2 && J.size() - 2 < x_ramp.size() && n >= 8 * LA_NB) {
+			const idx_t rw = x_ramp[J.size() - 2];
+			if (rw >= 128 && rw % 128 == 0 && rw < w)
 				w = rw;
 		}
 		if (!(n - j0 > tail_rows && j0 + w < n))

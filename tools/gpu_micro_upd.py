@@ -43,6 +43,10 @@ for r in (15360, 8192, 4096):
         c = cm(r, r)
         ms = bench(lambda: F.gemm(c, F.DST_FULL, F.ACCUM_ADD, x, y.t(), -1.0))
         print(f"[{tag}] full  r={r} k={k}: {ms:.3f} ms {2 * r * r * k / ms / 1e9:.1f} TF", flush=True)
+        u = cm(k, r)  # the LU's trailing update: column-major U12 (K-major rhs)
+        ms = bench(lambda: F.gemm(c, F.DST_FULL, F.ACCUM_ADD, x, u, -1.0))
+        print(f"[{tag}] lu    r={r} k={k}: {ms:.3f} ms {2 * r * r * k / ms / 1e9:.1f} TF", flush=True)
+        del u
         ms = bench(lambda: F.gemm(c, F.DST_LOWER, F.ACCUM_ADD, x, x.t(), -1.0))
         nt = r // 128
         fl = nt * (nt + 1) / 2 * 128 * 128 * k * 2
