@@ -1178,6 +1178,12 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	const idx_t nsteps = (idx_t) J.size() - 1;
 	auto Jat = [&](idx_t k) { return k < (idx_t) J.size() ? J[(size_t) k] : n; };
 	c.reset_events();
+	// The FIRST panel has nothing to hide behind: it is factored on the caller's stream, whole chip (its in-panel solves and
+	// products on 256 CUs instead of the 32 reserved ones, its leaves with four wavefronts per workgroup), before the two
+	// internal streams fork off.
+	static const int x_first_whole = getenv("FAER_HIP_X_FIRST_WHOLE") ? atoi(getenv("FAER_HIP_X_FIRST_WHOLE")) : 1;
+	if (x_first_whole)
+		getrf_rec<T>(A.sub(0, 0, m, J[1]), 0, 0, wk);
 	hipEvent_t e0 = c.next_event();
 	FH_HIP(hipEventRecord(e0, caller));
 	stream_wait(c.la_bulk, e0);
@@ -1206,8 +1212,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	bool staged = false; // the panel about to be applied has already been applied to the next panel's columns except for its last part
 	{
 		StreamScope sc(c.la_panel);
-		const idx_t w0 = J[1];
-		getrf_rec<T>(A.sub(0, 0, m, w0), 0, 0, wk);
+		if (!x_first_whole)
+			getrf_rec<T>(A.sub(0, 0, m, J[1]), 0, 0, wk);
 		ev_panel = c.next_event();
 		FH_HIP(hipEventRecord(ev_panel, c.la_panel));
 	}

@@ -23,7 +23,7 @@ for sec in "$@"; do
           case $envs in \#*) continue ;; esac
           [ "$envs" = "-" ] && envs=""
           echo "== $envs $what $n" >> $O
-          timeout 300 env $(echo $envs | tr ',' ' ') python tools/gpu_exp_one.py $what $n >> $O 2>&1 || echo "FAILED" >> $O
+          timeout 300 env $(echo $envs | tr ';' ' ') python tools/gpu_exp_one.py $what $n >> $O 2>&1 || echo "FAILED" >> $O
         done < $f
       done
       grep "==\| n=\|FAILED" $O | sed 's/residual/res/; s/, checksum.*perm/ perm/' ;;
