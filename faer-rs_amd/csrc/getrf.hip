@@ -1164,13 +1164,17 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// K = 512); once the panel chain is critical (fewer than `nb2_from` rows below the panel) the steps narrow to `nb2` columns:
 	// the top node of a panel's recursion -- interchanges, a solve against half the panel, a product on the reserved CUs -- is
 	// then done by the (idle) bulk stream as part of its update, and what sits between two panels is half as long.
-	static const idx_t x_nb2 = getenv("FAER_HIP_X_NB2") ? atol(getenv("FAER_HIP_X_NB2")) : LU_LA_NB;
+	static const idx_t x_nb2 = getenv("FAER_HIP_X_NB2") ? atol(getenv("FAER_HIP_X_NB2")) : 256;
+	static const idx_t x_nb3 = getenv("FAER_HIP_X_NB3") ? atol(getenv("FAER_HIP_X_NB3")) : 0;
+	static const idx_t x_nb3_from = getenv("FAER_HIP_X_NB3_FROM") ? atol(getenv("FAER_HIP_X_NB3_FROM")) : 4096;
 	static const idx_t x_nb2_from = getenv("FAER_HIP_X_NB2_FROM") ? atol(getenv("FAER_HIP_X_NB2_FROM")) : 10240;
 	std::vector<idx_t> J;
 	J.push_back(0);
 	while (J.back() < n) {
 		const idx_t j0 = J.back();
 		idx_t w = (m - j0 - LU_LA_NB >= x_nb2_from || x_nb2 <= 0 || x_nb2 > LU_LA_NB || x_nb2 % 128 != 0) ? LU_LA_NB : x_nb2;
+		if (x_nb3 > 0 && x_nb3 % 128 == 0 && x_nb3 < w && m - j0 - LU_LA_NB < x_nb3_from)
+			w = x_nb3;
 		if (w > n - j0)
 			w = n - j0;
 		J.push_back(j0 + w);
@@ -1181,7 +1185,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// The FIRST panel has nothing to hide behind: it is factored on the caller's stream, whole chip (its in-panel solves and
 	// products on 256 CUs instead of the 32 reserved ones, its leaves with four wavefronts per workgroup), before the two
 	// internal streams fork off.
-	static const int x_first_whole = getenv("FAER_HIP_X_FIRST_WHOLE") ? atoi(getenv("FAER_HIP_X_FIRST_WHOLE")) : 1;
+	static const int x_first_whole = getenv("FAER_HIP_X_FIRST_WHOLE") ? atoi(getenv("FAER_HIP_X_FIRST_WHOLE")) : 0;
 	if (x_first_whole)
 		getrf_rec<T>(A.sub(0, 0, m, J[1]), 0, 0, wk);
 	hipEvent_t e0 = c.next_event();
