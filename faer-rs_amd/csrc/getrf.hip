@@ -547,7 +547,12 @@ __global__ __launch_bounds__(256) void lu_node64_kernel(T *P, idx_t cs, int m, i
 	__shared__ T Us[LUN_W * LUN_UP];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int l15 = lane & 15, lhi = lane >> 4;
-	T *B = P + (idx_t) LUN_W * cs; // the right block
+	// blockIdx.y: group of 64 right-hand columns (the flat panel driver updates ALL columns right of a leaf with one launch; the
+	// groups are independent: each workgroup solves for its own group and updates its 256 rows of it)
+	const int cg = blockIdx.y;
+	nr = min(LUN_W, nr - cg * LUN_W);
+	top += (size_t) cg * LUN_W * LUN_W;
+	T *B = P + (idx_t) (LUN_W + cg * LUN_W) * cs; // the right block
 	// ---- L00 (strictly lower part is used) and this thread's 16 rows of column c = lane of the interchanged top block
 #pragma unroll
 	for (int j = 0; j < LUN_W / 4; ++j) {
@@ -1144,6 +1149,48 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 }
 
 // ------------------------------------------------------------------------------------------------
+// Flat right-looking panel (round 5): the panels of the look-ahead driver below.  getrf_rec's binary recursion puts, per 512
+// columns, 4 fused 64-column nodes, 2 nodes of 128 (interchanges, substitution leaf, K = 128 product) and one of 256
+// (interchanges, a three-launch solve, K = 256 product) on the panel stream's dependent chain -- every one of them bound by its
+// own latency on the 32 reserved CUs.  Here every 64-column leaf is applied at once to ALL panel columns right of it: one
+// interchange launch + ONE launch of the fused node kernel (its column groups along blockIdx.y), K = 64.  Same operations per
+// entry as the recursion (factor.rs:98-117 with bs = 64 at every level), regrouped; same pivots.
+//   after_leaf(j): called behind leaf j and the interchanges it makes on the panel's earlier columns `cols_from .. 64 j`
+//   (the staged driver starts the bulk stream's work on a finished part there); `left_from(j)`: first panel column leaf j's
+//   interchanges are applied to at once (the staged driver defers the ones that reach into an earlier part).
+// ------------------------------------------------------------------------------------------------
+template <typename T> static bool flat_panel_ok(MatV<T> P, const LuWork<T> &wk)
+{
+	return P.rs == 1 && wk.ttop && P.ncols % LUN_W == 0 && P.ncols <= 512 && P.nrows >= P.ncols && P.nrows < (1L << 30) && !wk.general &&
+	       !g_lu_force_general.load() && leaf_width_for<T>(P.nrows) == LU_W;
+}
+template <typename T, typename LeftFrom, typename AfterLeaf>
+static void getrf_panel_flat(MatV<T> P, int col0, int row_base, LuWork<T> &wk, LeftFrom left_from, AfterLeaf after_leaf)
+{
+	const idx_t m = P.nrows, w = P.ncols;
+	const idx_t nl = w / LUN_W;
+	for (idx_t j = 0; j < nl; ++j) {
+		const idx_t c = j * LUN_W;
+		getrf_leaf<T>(P.sub(c, c, m - c, LUN_W), col0 + (int) c, row_base + (int) c, wk);
+		// the leaf's transpositions on the panel columns to its left (factor.rs:127-185)
+		const idx_t lf = left_from(j);
+		if (c > lf)
+			laswp_dev<T>(P.sub(c, lf, m - c, c - lf), wk.piv + col0 + c, (int) LUN_W, row_base + (int) c);
+		after_leaf(j);
+		const idx_t nr = w - c - LUN_W;
+		if (nr > 0) {
+			// ... and on the columns to its right, which then take the leaf's update: A01 <- L00^-1 A01, A11 -= A10 A01
+			laswp_dev<T>(P.sub(c, c + LUN_W, m - c, nr), wk.piv + col0 + c, (int) LUN_W, row_base + (int) c, wk.ttop);
+			const idx_t below = m - c - LUN_W;
+			const unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
+			hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg, (unsigned) ((nr + LUN_W - 1) / LUN_W)), dim3(256), 0, ctx().stream, P.p + c + c * P.cs, P.cs,
+					   (int) (m - c), (int) nr, (const T *) wk.ttop);
+			FH_HIP(hipGetLastError());
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // Right-looking driver with look-ahead for large matrices (same idea as potrf.hip): steps of LU_LA_NB columns,
 //     [panel stream]  P_k : recursive panel factorization above on the m_k x nb panel (cooperative leaves; <= 16
 //                     workgroups for 16384 rows, they fit the CUs reserved for this stream)
@@ -1164,17 +1211,14 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// K = 512); once the panel chain is critical (fewer than `nb2_from` rows below the panel) the steps narrow to `nb2` columns:
 	// the top node of a panel's recursion -- interchanges, a solve against half the panel, a product on the reserved CUs -- is
 	// then done by the (idle) bulk stream as part of its update, and what sits between two panels is half as long.
-	static const idx_t x_nb2 = getenv("FAER_HIP_X_NB2") ? atol(getenv("FAER_HIP_X_NB2")) : 256;
-	static const idx_t x_nb3 = getenv("FAER_HIP_X_NB3") ? atol(getenv("FAER_HIP_X_NB3")) : 0;
-	static const idx_t x_nb3_from = getenv("FAER_HIP_X_NB3_FROM") ? atol(getenv("FAER_HIP_X_NB3_FROM")) : 4096;
-	static const idx_t x_nb2_from = getenv("FAER_HIP_X_NB2_FROM") ? atol(getenv("FAER_HIP_X_NB2_FROM")) : 10240;
+	// (measured: profiles/r05_exp_lu_driver.txt -- N = 16384 92.4 -> 90.5 ms, N = 8192 34.0 -> 30.8 ms; a third, 128-column level
+	// and other switch-over points change nothing)
+	constexpr idx_t LU_LA_NB2 = 256, LU_LA_NB2_FROM = 10240;
 	std::vector<idx_t> J;
 	J.push_back(0);
 	while (J.back() < n) {
 		const idx_t j0 = J.back();
-		idx_t w = (m - j0 - LU_LA_NB >= x_nb2_from || x_nb2 <= 0 || x_nb2 > LU_LA_NB || x_nb2 % 128 != 0) ? LU_LA_NB : x_nb2;
-		if (x_nb3 > 0 && x_nb3 % 128 == 0 && x_nb3 < w && m - j0 - LU_LA_NB < x_nb3_from)
-			w = x_nb3;
+		idx_t w = m - j0 - LU_LA_NB >= LU_LA_NB2_FROM ? LU_LA_NB : LU_LA_NB2;
 		if (w > n - j0)
 			w = n - j0;
 		J.push_back(j0 + w);
@@ -1182,12 +1226,6 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	const idx_t nsteps = (idx_t) J.size() - 1;
 	auto Jat = [&](idx_t k) { return k < (idx_t) J.size() ? J[(size_t) k] : n; };
 	c.reset_events();
-	// The FIRST panel has nothing to hide behind: it is factored on the caller's stream, whole chip (its in-panel solves and
-	// products on 256 CUs instead of the 32 reserved ones, its leaves with four wavefronts per workgroup), before the two
-	// internal streams fork off.
-	static const int x_first_whole = getenv("FAER_HIP_X_FIRST_WHOLE") ? atoi(getenv("FAER_HIP_X_FIRST_WHOLE")) : 0;
-	if (x_first_whole)
-		getrf_rec<T>(A.sub(0, 0, m, J[1]), 0, 0, wk);
 	hipEvent_t e0 = c.next_event();
 	FH_HIP(hipEventRecord(e0, caller));
 	stream_wait(c.la_bulk, e0);
@@ -1197,27 +1235,26 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// launches for it.  Round 4: composed on the BULK stream at the start of the step that applies it (22 us that used to sit
 	// on the panel stream's chain).
 	static_assert(LU_LA_NB <= LASWP_SMALL_NT, "panel interchange list");
-	// one list per step: the side stream applies step k's list to the columns left of the panel while the bulk stream is
-	// already composing step k + 1's
-	Scratch listb((size_t) nsteps * 2 * 2 * LU_LA_NB * sizeof(int));
+	Scratch listb((size_t) 2 * 2 * LU_LA_NB * sizeof(int));
 	LaswpList full;
-	auto use_list = [&](idx_t k) {
-		full.dst = listb.as<int>() + (size_t) k * 4 * LU_LA_NB;
-		full.src = full.dst + 2 * LU_LA_NB;
-	};
-	use_list(0);
+	full.dst = listb.as<int>();
+	full.src = full.dst + 2 * LU_LA_NB;
 	c.qr_side_streams();
 	hipStream_t side = c.qr_side[0];
 	// remaining rows from which the bulk stream is the critical one (mode 2 below); fewer: the panel chain is
-	static const idx_t x_bb = getenv("FAER_HIP_X_BB") ? atol(getenv("FAER_HIP_X_BB")) : 10240;
-	static const int x_leftside = getenv("FAER_HIP_X_LEFTSIDE") ? atoi(getenv("FAER_HIP_X_LEFTSIDE")) : 0;
-	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= x_bb; };
-	hipEvent_t ev_left_done = nullptr; // the side stream's last interchange pass over the columns left of a panel
+	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= 10240; };
+	static const int x_flat = getenv("FAER_HIP_X_FLAT") ? atoi(getenv("FAER_HIP_X_FLAT")) : 1;
+	// one panel on the current stream: flat right-looking (getrf_panel_flat) where its shape allows, else the recursion
+	auto panel = [&](MatV<T> P, idx_t j) {
+		if (x_flat && flat_panel_ok<T>(P, wk))
+			getrf_panel_flat<T>(P, (int) j, (int) j, wk, [](idx_t) { return (idx_t) 0; }, [](idx_t) {});
+		else
+			getrf_rec<T>(P, (int) j, (int) j, wk);
+	};
 	bool staged = false; // the panel about to be applied has already been applied to the next panel's columns except for its last part
 	{
 		StreamScope sc(c.la_panel);
-		if (!x_first_whole)
-			getrf_rec<T>(A.sub(0, 0, m, J[1]), 0, 0, wk);
+		panel(A.sub(0, 0, m, J[1]), 0);
 		ev_panel = c.next_event();
 		FH_HIP(hipEventRecord(ev_panel, c.la_panel));
 	}
@@ -1284,7 +1321,6 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		const idx_t j0 = J[(size_t) k], j1 = J[(size_t) k + 1], w = j1 - j0;
 		const idx_t j2 = Jat(k + 2), w2 = j2 - j1;
 		hipEvent_t ev_next = nullptr;
-		use_list(k);
 		{
 			StreamScope sc(c.la_bulk);
 			stream_wait(c.la_bulk, ev_panel);
@@ -1299,14 +1335,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// Measured in one visit (profiles/r04_exp_lu_chain_grouping.txt, N = 16384): three chains 107.9 ms, mode 1 everywhere
 			// 102.4, mode 2 everywhere 101.6, mode 2 down to 10240 remaining rows 100.7.
 			const int mode = bulk_bound(m - j1) ? 2 : 1;
-			hipEvent_t ev_composed = nullptr; // step k's list is ready (what the side stream's pass over the left columns waits for)
-			auto compose = [&]() {
-				laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full);
-				if (x_leftside && side) {
-					ev_composed = c.next_event();
-					FH_HIP(hipEventRecord(ev_composed, c.la_bulk));
-				}
-			};
+			auto compose = [&]() { laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full); };
 			if (!(w2 > 0 && staged)) // (the staged path composes it behind the release of the next panel)
 				compose();
 			if (w2 > 0 && staged) {
@@ -1354,27 +1383,11 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 				if (j2 < n)
 					update(k, j0, w, j2, n - j2);
 			}
-			// factor.rs:127-185: the panel's transpositions act on the columns to its left as well.  Nothing reads those
-			// columns again during the factorization, so the interchanges of `defer` consecutive panels are applied
-			// TOGETHER, as one composed row permutation per target block (one gather pass over the left part per group of
-			// panels instead of one scattered pass per panel: the per-panel passes were ~10 ms of the bulk stream's
-			// ~110 ms at N = 16384, profiles/r02_lu_kernel_stats.csv).  Bitwise the same result: row interchanges commute
-			// with everything that does not touch the rows' columns.
-			// Default 1 (every panel at once): with 8 the composed passes moved ~8 ms off the bulk stream's per-panel
-			// scattered passes but cost as much again in compose_perm / gather / scatter launches and a serial tail
-			// (142.6 vs 145.1 ms at N = 16384, profiles/r02_exp_lu_panel.txt).
-			if (j0 > 0) {
-				if (ev_composed) {
-					// (experiment, slower: the interchanges of the columns left of the panel on the plain side stream)
-					StreamScope ss(side);
-					stream_wait(side, ev_composed);
-					swaps(k, j0, w, 0, j0);
-					ev_left_done = c.next_event();
-					FH_HIP(hipEventRecord(ev_left_done, side));
-				} else {
-					swaps(k, j0, w, 0, j0);
-				}
-			}
+			// factor.rs:127-185: the panel's transpositions act on the columns to its left as well (nothing reads those columns
+			// again during the factorization; on the plain side stream instead these passes made the factorization 1.2 ms slower,
+			// composed over 8 panels they cost a serial tail: profiles/r05_exp_lu_driver.txt, r02_exp_lu_panel.txt)
+			if (j0 > 0)
+				swaps(k, j0, w, 0, j0);
 		}
 		if (w2 > 0) {
 			StreamScope sc(c.la_panel);
@@ -1389,8 +1402,29 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// (factor.rs:127-185), which the stage reads.
 			const idx_t w3 = Jat(k + 3) - j2;
 			const bool stage = w2 >= 256 && w2 % 256 == 0 && w3 > 0 && !bulk_bound(m - j2) && m - j1 > w2;
+			MatV<T> Pn = A.sub(j1, j1, m - j1, w2);
 			if (!stage) {
-				getrf_rec<T>(A.sub(j1, j1, m - j1, w2), (int) j1, (int) j1, wk);
+				panel(Pn, j1);
+			} else if (x_flat && flat_panel_ok<T>(Pn, wk)) {
+				// the flat panel in two parts: as soon as the left half is final -- its leaves' interchanges applied inside the
+				// half -- the bulk stream starts stage 0; the right half's interchanges on the left half's columns wait for it
+				QW = w2 / 2;
+				const idx_t lpp = QW / LUN_W; // leaves per part
+				getrf_panel_flat<T>(
+					Pn, (int) j1, (int) j1, wk, [&](idx_t jl) { return (jl / lpp) * QW; },
+					[&](idx_t jl) {
+						if (jl + 1 == lpp) {
+							hipEvent_t ev_part = c.next_event();
+							FH_HIP(hipEventRecord(ev_part, c.la_panel));
+							StreamScope sb(c.la_bulk);
+							stream_wait(c.la_bulk, ev_part);
+							stage_update(j1, 0, j2, w3);
+							ev_stage[0] = c.next_event();
+							FH_HIP(hipEventRecord(ev_stage[0], c.la_bulk));
+						}
+					});
+				stream_wait(c.la_panel, ev_stage[0]);
+				laswp_dev<T>(A.sub(j1 + QW, j1, m - j1 - QW, QW), wk.piv + j1 + QW, (int) QW, (int) (j1 + QW));
 			} else {
 				QW = w2 / 2;
 				staged_panel(j1, j2, w3, 0, w2);
@@ -1406,8 +1440,6 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	FH_HIP(hipEventRecord(eb, c.la_bulk));
 	stream_wait(caller, eb);
 	stream_wait(caller, ev_panel);
-	if (ev_left_done)
-		stream_wait(caller, ev_left_done);
 }
 
 template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
@@ -1424,7 +1456,7 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		Scratch granb(gran_bytes + diag_bytes);
 		Scratch misc(256);
 		Scratch wwsb(LW_WS_BYTES);
-		Scratch ttopb((size_t) LUN_W * LUN_W * sizeof(T));
+		Scratch ttopb((size_t) LUN_W * LU_LA_NB * sizeof(T));
 		LuWork<T> wk;
 		wk.wws = wwsb.as<unsigned char>();
 		wk.ttop = ttopb.as<T>();
@@ -1521,7 +1553,7 @@ template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev, int *status_
 	Scratch granb(gran_bytes + diag_bytes);
 	Scratch misc(256);
 	Scratch wwsb(LW_WS_BYTES);
-	Scratch ttopb((size_t) LUN_W * LUN_W * sizeof(T));
+	Scratch ttopb((size_t) LUN_W * 512 * sizeof(T));
 	LuWork<T> wk;
 	wk.wws = wwsb.as<unsigned char>();
 	wk.ttop = ttopb.as<T>();

@@ -367,24 +367,6 @@ std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2)
 			w = LA_NB; // narrow steps again towards the end
 		if (J.size() == 1 && first > 0 && first < w)
 			w = first; // (the whole chip waits for the first diagonal block)
-		// experiment: widths of the steps after the first one, e.g. FAER_HIP_X_LLT_RAMP=256,640 (multiples of 128)
-		static const std::vector<idx_t> x_ramp = []() {
-			std::vector<idx_t> v;
-			if (const char *e = getenv("FAER_HIP_X_LLT_RAMP"))
-				for (const char *p = e; *p;) {
-					v.push_back(atol(p));
-					while (*p && *p != ',')
-						++p;
-					if (*p == ',')
-						++p;
-				}
-			return v;
-		}();
-		if (J.size() >= 2 && J.size() - 2 < x_ramp.size() && n >= 8 * LA_NB) {
-			const idx_t rw = x_ramp[J.size() - 2];
-			if (rw >= 128 && rw % 128 == 0 && rw < w)
-				w = rw;
-		}
 		if (!(n - j0 > tail_rows && j0 + w < n))
 			break;
 		J.push_back(j0 + w);
@@ -402,7 +384,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 	// one tall left-looking panel + ONE trailing update per step.
 	// Look-ahead pays from ~10k rows upwards (measured, N = 8192: 13.3 ms sequential against 13.8 ms); below that and
 	// for the last `tail_rows` rows of a large matrix the steps run back to back on the caller's stream.
-	const idx_t tail_rows = getenv("FAER_HIP_LLT_TAIL") ? atol(getenv("FAER_HIP_LLT_TAIL")) : (n < 10 * LA_NB ? n : 3 * LA_NB);
+	const idx_t tail_rows = getenv("FAER_HIP_LLT_TAIL") ? atol(getenv("FAER_HIP_LLT_TAIL")) : (n < 10 * LA_NB ? n : 4 * LA_NB);
 	// Step widths of the look-ahead part: the FIRST step is LA_NB wide (its diagonal block is factored with the rest
 	// of the chip idle), the following ones LA_NB2 (wider steps: K = LA_NB2 trailing updates run closer to the dense
 	// rate and there are fewer launch boundaries per factorization) while at least 2 * LA_NB2 rows remain.
