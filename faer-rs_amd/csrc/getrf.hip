@@ -1235,10 +1235,33 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// launches for it.  Round 4: composed on the BULK stream at the start of the step that applies it (22 us that used to sit
 	// on the panel stream's chain).
 	static_assert(LU_LA_NB <= LASWP_SMALL_NT, "panel interchange list");
-	Scratch listb((size_t) 2 * 2 * LU_LA_NB * sizeof(int));
+	// (a ring of lists: in the pipelined steps below the side stream composes step k + 1's list while the bulk stream still
+	// applies step k's to the columns left of the panel)
+	constexpr idx_t NLIST = 4;
+	Scratch listb((size_t) NLIST * 2 * 2 * LU_LA_NB * sizeof(int));
 	LaswpList full;
-	full.dst = listb.as<int>();
-	full.src = full.dst + 2 * LU_LA_NB;
+	auto use_list = [&](idx_t k) {
+		full.dst = listb.as<int>() + (size_t) (k % NLIST) * 4 * LU_LA_NB;
+		full.src = full.dst + 2 * LU_LA_NB;
+	};
+	use_list(0);
+	// Pipelined steps (while the bulk stream is the critical one).  Between two trailing products the bulk stream used to run
+	// the chain "interchanges, solve, product" for the next panel's columns (~0.3 ms busy) and then wait for the side stream's
+	// chain on the far columns (~0.25 ms idle): ~0.55 ms per step in which most of the chip does nothing.  The columns right of
+	// the panel are now cut at a fixed column jA into a near group A (with the next panel's columns) and a far group B, and ALL
+	// chains run on the side stream one product ahead: the chain of step k + 1 on A runs beside the product of step k on B, the
+	// chain on B beside the product of step k + 1 on A.  The bulk stream issues nothing but the two products per step.
+	static const int x_pipe = getenv("FAER_HIP_X_PIPE") ? atoi(getenv("FAER_HIP_X_PIPE")) : 1;
+	idx_t jA = 0;
+	{
+		// the boundary: the middle of the columns right of the next panel, taken at the middle step of this phase
+		idx_t kend = 0;
+		while (kend + 1 < nsteps && m - J[(size_t) kend + 1] >= 10240)
+			++kend;
+		const idx_t jm = Jat(kend / 2 + 2);
+		jA = (jm + n) / 2 / LU_LA_NB * LU_LA_NB;
+	}
+	hipEvent_t ev_GA_prev = nullptr, ev_GB_prev = nullptr; // the previous step's products on the two groups (bulk stream)
 	c.qr_side_streams();
 	hipStream_t side = c.qr_side[0];
 	// remaining rows from which the bulk stream is the critical one (mode 2 below); fewer: the panel chain is
@@ -1321,6 +1344,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		const idx_t j0 = J[(size_t) k], j1 = J[(size_t) k + 1], w = j1 - j0;
 		const idx_t j2 = Jat(k + 2), w2 = j2 - j1;
 		hipEvent_t ev_next = nullptr;
+		use_list(k);
 		{
 			StreamScope sc(c.la_bulk);
 			stream_wait(c.la_bulk, ev_panel);
@@ -1336,8 +1360,41 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// 102.4, mode 2 everywhere 101.6, mode 2 down to 10240 remaining rows 100.7.
 			const int mode = bulk_bound(m - j1) ? 2 : 1;
 			auto compose = [&]() { laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full); };
-			if (!(w2 > 0 && staged)) // (the staged path composes it behind the release of the next panel)
+			const bool pipe = x_pipe && w2 > 0 && mode == 2 && side && !staged && m > j1 && j2 + 2 * LU_LA_NB <= jA && jA < n;
+			if (!pipe && !(w2 > 0 && staged)) // (the staged path composes it behind the release of the next panel)
 				compose();
+			if (pipe) {
+				hipEvent_t ev_cA = c.next_event(), ev_cB = c.next_event();
+				{
+					StreamScope ss(side);
+					stream_wait(side, ev_panel);
+					compose();
+					if (ev_GA_prev)
+						stream_wait(side, ev_GA_prev);
+					// near group + the next panel's columns: one chain, then the product on the next panel's columns
+					swaps(k, j0, w, j1, jA - j1);
+					MatV<T> U = A.sub(j0, j1, w, jA - j1);
+					trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, U);
+					gemm_dev<T>(A.sub(j1, j1, m - j1, w2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), U.sub(0, 0, w, w2).c(), (T) -1);
+					ev_next = c.next_event();
+					FH_HIP(hipEventRecord(ev_next, side));
+					FH_HIP(hipEventRecord(ev_cA, side));
+					if (ev_GB_prev)
+						stream_wait(side, ev_GB_prev);
+					swaps(k, j0, w, jA, n - jA);
+					trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, A.sub(j0, jA, w, n - jA));
+					FH_HIP(hipEventRecord(ev_cB, side));
+				}
+				stream_wait(c.la_bulk, ev_cA);
+				if (jA > j2)
+					gemm_dev<T>(A.sub(j1, j2, m - j1, jA - j2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), A.sub(j0, j2, w, jA - j2).c(), (T) -1);
+				ev_GA_prev = c.next_event();
+				FH_HIP(hipEventRecord(ev_GA_prev, c.la_bulk));
+				stream_wait(c.la_bulk, ev_cB);
+				gemm_dev<T>(A.sub(j1, jA, m - j1, n - jA), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), A.sub(j0, jA, w, n - jA).c(), (T) -1);
+				ev_GB_prev = c.next_event();
+				FH_HIP(hipEventRecord(ev_GB_prev, c.la_bulk));
+			} else
 			if (w2 > 0 && staged) {
 				// last stage of the staged update of the next panel's columns (the earlier ones ran beside the rest of panel k,
 				// see the panel part below): interchanges of the last QW pivots, U = L_qq^-1 (.), product with K = QW
@@ -1382,6 +1439,10 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
 				if (j2 < n)
 					update(k, j0, w, j2, n - j2);
+			}
+			if (!pipe) { // (a pipelined step that followed would order its chains behind this step's bulk work)
+				ev_GA_prev = ev_GB_prev = c.next_event();
+				FH_HIP(hipEventRecord(ev_GA_prev, c.la_bulk));
 			}
 			// factor.rs:127-185: the panel's transpositions act on the columns to its left as well (nothing reads those columns
 			// again during the factorization; on the plain side stream instead these passes made the factorization 1.2 ms slower,
