@@ -1252,6 +1252,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// chains run on the side stream one product ahead: the chain of step k + 1 on A runs beside the product of step k on B, the
 	// chain on B beside the product of step k + 1 on A.  The bulk stream issues nothing but the two products per step.
 	static const int x_pipe = getenv("FAER_HIP_X_PIPE") ? atoi(getenv("FAER_HIP_X_PIPE")) : 1;
+	static const idx_t x_pipe_from = getenv("FAER_HIP_X_PIPE_FROM") ? atol(getenv("FAER_HIP_X_PIPE_FROM")) : 13312;
 	idx_t jA = 0;
 	{
 		// the boundary: the middle of the columns right of the next panel, taken at the middle step of this phase
@@ -1360,7 +1361,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// 102.4, mode 2 everywhere 101.6, mode 2 down to 10240 remaining rows 100.7.
 			const int mode = bulk_bound(m - j1) ? 2 : 1;
 			auto compose = [&]() { laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full); };
-			const bool pipe = x_pipe && w2 > 0 && mode == 2 && side && !staged && m > j1 && j2 + 2 * LU_LA_NB <= jA && jA < n;
+			const bool pipe = x_pipe && w2 > 0 && mode == 2 && side && !staged && m > j1 && j2 + 2 * LU_LA_NB <= jA && jA < n && m - j1 >= x_pipe_from;
 			if (!pipe && !(w2 > 0 && staged)) // (the staged path composes it behind the release of the next panel)
 				compose();
 			if (pipe) {
