@@ -1261,6 +1261,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			++kend;
 		const idx_t jm = Jat(kend / 2 + 2);
 		jA = (jm + n) / 2 / LU_LA_NB * LU_LA_NB;
+		if (const char *e = getenv("FAER_HIP_X_JA"))
+			jA = atol(e);
 	}
 	hipEvent_t ev_GA_prev = nullptr, ev_GB_prev = nullptr; // the previous step's products on the two groups (bulk stream)
 	c.qr_side_streams();
@@ -1376,10 +1378,10 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 					swaps(k, j0, w, j1, jA - j1);
 					MatV<T> U = A.sub(j0, j1, w, jA - j1);
 					trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, U);
+					FH_HIP(hipEventRecord(ev_cA, side)); // (the bulk stream's product on A waits for the solve only)
 					gemm_dev<T>(A.sub(j1, j1, m - j1, w2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), U.sub(0, 0, w, w2).c(), (T) -1);
 					ev_next = c.next_event();
 					FH_HIP(hipEventRecord(ev_next, side));
-					FH_HIP(hipEventRecord(ev_cA, side));
 					if (ev_GB_prev)
 						stream_wait(side, ev_GB_prev);
 					swaps(k, j0, w, jA, n - jA);
