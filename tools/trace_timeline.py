@@ -61,3 +61,9 @@ if len(sys.argv) > 3:  # dump the big kernels of every queue in time order
         d = r["e"] - r["s"]
         if d > float(sys.argv[3]) * 1e3:
             print(f"+{(r['s'] - t0) / 1e6:8.3f} ms q{r['Queue_Id']} {d / 1e3:9.1f} us grid {r['Grid_Size_X']:>8s} {short(r['Kernel_Name'])}")
+if os.environ.get("TL_WINDOW"):  # every kernel of every queue inside [a, b] ms of the run, in time order
+    wa, wb = (float(x) for x in os.environ["TL_WINDOW"].split(","))
+    for r in run:
+        ts = (r["s"] - t0) / 1e6
+        if wa <= ts <= wb:
+            print(f"+{ts:8.3f} .. +{(r['e'] - t0) / 1e6:8.3f} ms q{r['Queue_Id']} {(r['e'] - r['s']) / 1e3:8.1f} us grid {r['Grid_Size_X']:>8s} {short(r['Kernel_Name'])}")
