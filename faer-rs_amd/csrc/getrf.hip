@@ -1374,18 +1374,14 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 					compose();
 					if (ev_GA_prev)
 						stream_wait(side, ev_GA_prev);
-					// the next panel's columns first, as a chain of their own: the panel chain (panel k + 1 needs them, the chains
-					// of step k + 1 need panel k + 1) must not run slower than the bulk stream's two products per step
-					// (kernel trace: with one chain for the next panel's and the near columns the panel started 0.65 ms later and
-					// the bulk stream waited ~0.15 ms per step for it)
-					update(k, j0, w, j1, w2);
+					// near group + the next panel's columns: one chain, then the product on the next panel's columns
+					swaps(k, j0, w, j1, jA - j1);
+					MatV<T> U = A.sub(j0, j1, w, jA - j1);
+					trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, U);
+					FH_HIP(hipEventRecord(ev_cA, side)); // (the bulk stream's product on A waits for the solve only)
+					gemm_dev<T>(A.sub(j1, j1, m - j1, w2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), U.sub(0, 0, w, w2).c(), (T) -1);
 					ev_next = c.next_event();
 					FH_HIP(hipEventRecord(ev_next, side));
-					if (jA > j2) {
-						swaps(k, j0, w, j2, jA - j2);
-						trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, A.sub(j0, j2, w, jA - j2));
-					}
-					FH_HIP(hipEventRecord(ev_cA, side));
 					if (ev_GB_prev)
 						stream_wait(side, ev_GB_prev);
 					swaps(k, j0, w, jA, n - jA);
