@@ -596,8 +596,12 @@ __global__ __launch_bounds__(256) void lu_node64_kernel(T *P, idx_t cs, int m, i
 			B[d + (idx_t) c * cs] = Us[d * LUN_UP + c];
 		}
 	}
-	// ---- A11 -= A10 A01 on this workgroup's rows: wavefront w takes 64 of them, 16 at a time
-	const int rb = LUN_W + (int) blockIdx.x * LUN_ROWS + wave * 64;
+	// ---- A11 -= A10 A01 on this workgroup's rows: chunks of LUN_ROWS rows (several per workgroup when the launch has many of
+	// them: the solve above is paid once per workgroup), wavefront w takes 64 rows of a chunk, 16 at a time
+	const int nchunks = (m - LUN_W + LUN_ROWS - 1) / LUN_ROWS;
+#pragma unroll 1
+	for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+	const int rb = LUN_W + chunk * LUN_ROWS + wave * 64;
 #pragma unroll 1
 	for (int rt = 0; rt < 4; ++rt) {
 		const int r0 = rb + 16 * rt;
@@ -637,6 +641,7 @@ __global__ __launch_bounds__(256) void lu_node64_kernel(T *P, idx_t cs, int m, i
 				if (rin && c < nr)
 					B[r + (idx_t) c * cs] = acc[ct][q];
 			}
+	}
 	}
 }
 
@@ -1182,9 +1187,16 @@ static void getrf_panel_flat(MatV<T> P, int col0, int row_base, LuWork<T> &wk, L
 			// ... and on the columns to its right, which then take the leaf's update: A01 <- L00^-1 A01, A11 -= A10 A01
 			laswp_dev<T>(P.sub(c, c + LUN_W, m - c, nr), wk.piv + col0 + c, (int) LUN_W, row_base + (int) c, wk.ttop);
 			const idx_t below = m - c - LUN_W;
-			const unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
-			hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg, (unsigned) ((nr + LUN_W - 1) / LUN_W)), dim3(256), 0, ctx().stream, P.p + c + c * P.cs, P.cs,
-					   (int) (m - c), (int) nr, (const T *) wk.ttop);
+			unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
+			const unsigned ncg = (unsigned) ((nr + LUN_W - 1) / LUN_W);
+			// (every workgroup solves the 64 x 64 system of its column group before it updates: with many row chunks and several
+			// column groups a workgroup takes several chunks -- about four workgroups per compute unit of the stream in all)
+			static const int x_nodecap = getenv("FAER_HIP_X_NODECAP") ? atoi(getenv("FAER_HIP_X_NODECAP")) : 4;
+			const unsigned cap = (unsigned) (x_nodecap * ctx().stream_cus()) / ncg;
+			if (nwg > cap)
+				nwg = cap < 1u ? 1u : cap;
+			hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg, ncg), dim3(256), 0, ctx().stream, P.p + c + c * P.cs, P.cs, (int) (m - c), (int) nr,
+					   (const T *) wk.ttop);
 			FH_HIP(hipGetLastError());
 		}
 	}
