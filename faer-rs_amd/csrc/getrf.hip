@@ -1191,7 +1191,7 @@ static void getrf_panel_flat(MatV<T> P, int col0, int row_base, LuWork<T> &wk, L
 			const unsigned ncg = (unsigned) ((nr + LUN_W - 1) / LUN_W);
 			// (every workgroup solves the 64 x 64 system of its column group before it updates: with many row chunks and several
 			// column groups a workgroup takes several chunks -- about four workgroups per compute unit of the stream in all)
-			static const int x_nodecap = getenv("FAER_HIP_X_NODECAP") ? atoi(getenv("FAER_HIP_X_NODECAP")) : 4;
+			static const int x_nodecap = getenv("FAER_HIP_X_NODECAP") ? atoi(getenv("FAER_HIP_X_NODECAP")) : 2;
 			const unsigned cap = (unsigned) (x_nodecap * ctx().stream_cus()) / ncg;
 			if (nwg > cap)
 				nwg = cap < 1u ? 1u : cap;
