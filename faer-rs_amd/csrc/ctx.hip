@@ -109,8 +109,6 @@ bool Ctx::lookahead_streams()
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
 		return false;
 	const int ncu = prop.multiProcessorCount;
-	if (const char *e = getenv("FAER_HIP_PANEL_CUS"))
-		la_panel_cus = atoi(e);
 	if (la_panel_cus < 8 || la_panel_cus > ncu / 2 || ncu > 1024)
 		return false;
 	// CU i of the mask is enabled by bit i; the panel stream gets the LAST `la_panel_cus` CUs.  Measured
@@ -129,14 +127,6 @@ bool Ctx::lookahead_streams()
 	}
 	const uint32_t words = (uint32_t) ((ncu + 31) / 32);
 	hipStream_t b = nullptr, p = nullptr;
-	if (getenv("FAER_HIP_NO_CUMASK")) { // debugging aid: plain streams, no CU partition
-		FH_HIP(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
-		FH_HIP(hipStreamCreateWithFlags(&p, hipStreamNonBlocking));
-		la_bulk = b;
-		la_panel = p;
-		la_state = 1;
-		return true;
-	}
 	if (hipExtStreamCreateWithCUMask(&b, words, mb) != hipSuccess) {
 		(void) hipGetLastError();
 		return false;

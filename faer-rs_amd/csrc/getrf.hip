@@ -1190,9 +1190,9 @@ static void getrf_panel_flat(MatV<T> P, int col0, int row_base, LuWork<T> &wk, L
 			unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
 			const unsigned ncg = (unsigned) ((nr + LUN_W - 1) / LUN_W);
 			// (every workgroup solves the 64 x 64 system of its column group before it updates: with many row chunks and several
-			// column groups a workgroup takes several chunks -- about four workgroups per compute unit of the stream in all)
-			static const int x_nodecap = getenv("FAER_HIP_X_NODECAP") ? atoi(getenv("FAER_HIP_X_NODECAP")) : 2;
-			const unsigned cap = (unsigned) (x_nodecap * ctx().stream_cus()) / ncg;
+			// column groups a workgroup takes several chunks -- two workgroups per compute unit of the stream in all)
+			// (measured: 2 workgroups per CU 88.1-88.2 ms, 1: 88.7, 3-4: 88.5, one chunk per workgroup 88.9-89.2 -- profiles/r05_exp_lu_driver.txt)
+			const unsigned cap = (unsigned) (2 * ctx().stream_cus()) / ncg;
 			if (nwg > cap)
 				nwg = cap < 1u ? 1u : cap;
 			hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg, ncg), dim3(256), 0, ctx().stream, P.p + c + c * P.cs, P.cs, (int) (m - c), (int) nr,
@@ -1263,8 +1263,10 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// the panel are now cut at a fixed column jA into a near group A (with the next panel's columns) and a far group B, and ALL
 	// chains run on the side stream one product ahead: the chain of step k + 1 on A runs beside the product of step k on B, the
 	// chain on B beside the product of step k + 1 on A.  The bulk stream issues nothing but the two products per step.
-	static const int x_pipe = getenv("FAER_HIP_X_PIPE") ? atoi(getenv("FAER_HIP_X_PIPE")) : 1;
-	static const idx_t x_pipe_from = getenv("FAER_HIP_X_PIPE_FROM") ? atol(getenv("FAER_HIP_X_PIPE_FROM")) : 13312;
+	// It pays while a product is much longer than a chain: down to 13312 rows below the panel (N = 16384: the first six steps;
+	// 89.7-90.1 -> 88.2-88.5 ms; down to 10240 rows 89.0 -- later the chains, which run 2-4 x slower among a product's workgroups,
+	// no longer fit beside half a product: profiles/r05_exp_lu_driver.txt).
+	constexpr idx_t LU_PIPE_FROM = 13312;
 	idx_t jA = 0;
 	{
 		// the boundary: the middle of the columns right of the next panel, taken at the middle step of this phase
@@ -1273,18 +1275,15 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			++kend;
 		const idx_t jm = Jat(kend / 2 + 2);
 		jA = (jm + n) / 2 / LU_LA_NB * LU_LA_NB;
-		if (const char *e = getenv("FAER_HIP_X_JA"))
-			jA = atol(e);
 	}
 	hipEvent_t ev_GA_prev = nullptr, ev_GB_prev = nullptr; // the previous step's products on the two groups (bulk stream)
 	c.qr_side_streams();
 	hipStream_t side = c.qr_side[0];
 	// remaining rows from which the bulk stream is the critical one (mode 2 below); fewer: the panel chain is
 	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= 10240; };
-	static const int x_flat = getenv("FAER_HIP_X_FLAT") ? atoi(getenv("FAER_HIP_X_FLAT")) : 1;
 	// one panel on the current stream: flat right-looking (getrf_panel_flat) where its shape allows, else the recursion
 	auto panel = [&](MatV<T> P, idx_t j) {
-		if (x_flat && flat_panel_ok<T>(P, wk))
+		if (flat_panel_ok<T>(P, wk))
 			getrf_panel_flat<T>(P, (int) j, (int) j, wk, [](idx_t) { return (idx_t) 0; }, [](idx_t) {});
 		else
 			getrf_rec<T>(P, (int) j, (int) j, wk);
@@ -1375,7 +1374,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			// 102.4, mode 2 everywhere 101.6, mode 2 down to 10240 remaining rows 100.7.
 			const int mode = bulk_bound(m - j1) ? 2 : 1;
 			auto compose = [&]() { laswp_compose_list(wk.piv + j0, (int) w, (int) j0, full); };
-			const bool pipe = x_pipe && w2 > 0 && mode == 2 && side && !staged && m > j1 && j2 + 2 * LU_LA_NB <= jA && jA < n && m - j1 >= x_pipe_from;
+			const bool pipe = w2 > 0 && mode == 2 && side && !staged && m > j1 && j2 + 2 * LU_LA_NB <= jA && jA < n && m - j1 >= LU_PIPE_FROM;
 			if (!pipe && !(w2 > 0 && staged)) // (the staged path composes it behind the release of the next panel)
 				compose();
 			if (pipe) {
@@ -1481,7 +1480,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			MatV<T> Pn = A.sub(j1, j1, m - j1, w2);
 			if (!stage) {
 				panel(Pn, j1);
-			} else if (x_flat && flat_panel_ok<T>(Pn, wk)) {
+			} else if (flat_panel_ok<T>(Pn, wk)) {
 				// the flat panel in two parts: as soon as the left half is final -- its leaves' interchanges applied inside the
 				// half -- the bulk stream starts stage 0; the right half's interchanges on the left half's columns wait for it
 				QW = w2 / 2;

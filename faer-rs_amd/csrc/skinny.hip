@@ -171,9 +171,6 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(int M, int N, int K,
 // ------------------------------------------------------------------------------------------------
 template <typename T> bool skinny_dev(MatV<T> C, bool add, MatV<const T> A, MatV<const T> B, T alpha)
 {
-	static const bool off = getenv("FAER_HIP_NO_SKINNY") != nullptr; // A/B switch
-	if (off)
-		return false;
 	idx_t m = C.nrows, n = C.ncols, k = A.ncols;
 	const idx_t LONG = 256;
 	// ---- update, possibly on the transposed problem (C^T = B^T A^T)

@@ -1810,9 +1810,6 @@ __global__ __launch_bounds__(256) void tq_range_rest_kernel(const float *A, long
 
 bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs)
 {
-	static const bool off = getenv("FAER_HIP_QR_TSQR") && atoi(getenv("FAER_HIP_QR_TSQR")) == 0; // A/B switch
-	if (off)
-		return false;
 	if (rs != 1 || cs < m || n < 1 || n > 512 || m < 16384 || m < 8 * n || m >= (1L << 30))
 		return false;
 	// T blocks are written per 64-column panel: a block of Q_coeff is either a whole number of panels or divides one

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One visit to a GPU box, by sections:  gpurun --timeout 900 -- 'bash tools/gpu_visit.sh <tag> <section> [<section> ...]'
-#   qrtests   the tall one-pass QR parity tests            qrbench   QR bench line, one-pass vs classic (A/B in one visit)
+#   qrtests   the tall one-pass QR parity tests
 #   qrprof    rocprofv3 kernel trace of the QR bench       alltests  the whole -m gpu suite + smoke
 #   bench     the default bench line                       prof:<wl> kernel trace of `bench.py --workload <wl>`
 # Outputs go to gpurun_out/<tag>_*; copy what is to be judged into profiles/.
@@ -15,14 +15,6 @@ for sec in "$@"; do
     qrall)
       timeout 1500 python -m pytest tests/test_gpu_qr.py tests/test_gpu_extras.py -q > gpurun_out/${tag}_qrall.log 2>&1; echo "qrall rc=$?"
       tail -15 gpurun_out/${tag}_qrall.log ;;
-    qrbench)
-      for sw in 1 0; do
-        FAER_HIP_QR_TSQR=$sw timeout 300 python bench.py --workload qr --steps 10 --warmup 2 --no-extras --no-cpu 2>&1 | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/tsqr=$sw /"
-      done ;;
-    qrla)
-      for sw in 2 0 2 0; do
-        FAER_HIP_QR_TSQR_LA=$sw timeout 300 python bench.py --workload qr --steps 10 --warmup 2 --no-extras --no-cpu 2>&1 | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/lookahead=$sw /"
-      done ;;
     qrprof)
       rm -rf gpurun_out/prof_${tag}_qr
       timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_qr -o qr -- python bench.py --workload qr --steps 10 --warmup 2 --no-extras --no-cpu > gpurun_out/prof_${tag}_qr.log 2>&1; echo "prof qr rc=$?"
