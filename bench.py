@@ -151,11 +151,29 @@ def main():
     rccl = None
     if dist is not None and args.transport == "rccl" and args.workload in ("lu", "llt"):
         # the 128-byte ncclUniqueId of the library's own communicator travels through the torch process group
+        # (a rank that cannot open the library's own communicator -- librccl not loadable, ncclCommInitRank failing -- must not
+        # leave the others waiting: every rank reports, and unless ALL succeeded the run falls back to the torch.distributed
+        # transport, which is RCCL under the nccl backend as well; the line then says transport = "torch (fallback: ...)")
         idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(F.RcclTransport.unique_id()), dtype=torch.uint8))
+        err = ""
+        try:
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(F.RcclTransport.unique_id()), dtype=torch.uint8))
+        except Exception as ex:
+            err = str(ex)[:120]
         dist.broadcast(idt, src=0)
-        rccl = F.RcclTransport(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        if not err and int(idt.sum().item()) == 0:
+            err = "no ncclUniqueId"
+        try:
+            if not err:
+                rccl = F.RcclTransport(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        except Exception as ex:
+            err, rccl = str(ex)[:120], None
+        okt = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            rccl = None
+            args.transport = f"torch (fallback: built-in RCCL transport unavailable on some rank{': ' + err if err else ''})"
 
     def barrier():
         if dist is not None:
