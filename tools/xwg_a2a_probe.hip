@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void a2a_kernel(unsigned char *ws, int iters, 
 					dead = true;
 					break;
 				}
+				asm volatile("" ::: "memory"); // (the buffer loads below must be re-issued, not hoisted)
+				__builtin_amdgcn_s_sleep(1);
 				if (mode == 1) {
 					a0 = b0;
 					a1 = b1;
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void a2a_kernel(unsigned char *ws, int iters, 
 			const unsigned voff = (unsigned) ((g * GMAX + (lane >> 2)) * 64 + (lane & 3) * 16);
 			const int t = lane >> 2;
 			for (int spin = 0;; ++spin) {
+				asm volatile("" ::: "memory");
 				u32x4 a0 = ld(hr, voff, base), a1 = ld(hr, voff + 16u * 64u, base);
 				bool ok = (t >= G || (a0.x == tag && a0.z == tag)) && (t + 16 >= G || (a1.x == tag && a1.z == tag));
 				if (__all(ok)) {
