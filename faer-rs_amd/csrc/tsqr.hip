@@ -1273,14 +1273,24 @@ template <bool VEC> __global__ __launch_bounds__(256, 1) void tq_update_kernel(c
 	if (tq_skip(a.stat, a.c0))
 		return;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	for (int e = tid; e < 64 * PITCH; e += 256) {
-		const int k = e / PITCH, c = e - k * PITCH;
-		float v = 0.f;
-		if (c < a.ts)
-			v = a.Yn[(long) k * a.typ + a.coff + c];
-		else if (c >= TQ_TS && a.do_v)
-			v = a.Mn[k * 64 + (c - TQ_TS)];
-		Ys[e] = v;
+	{
+		// PITCH == 256 == the workgroup: thread c stages column c of Ys, row k per iteration -- 16 independent loads in flight per
+		// thread (one element per iteration was 64 dependent memory round trips at the head of every launch)
+		static_assert(PITCH == 256, "one thread per staged column");
+		const int c = tid;
+		const bool isy = c < a.ts, isv = c >= TQ_TS && a.do_v;
+		const float *src = isy ? a.Yn + a.coff + c : a.Mn + (c - TQ_TS);
+		const long step = isy ? (long) a.typ : 64L;
+#pragma unroll 1
+		for (int k0 = 0; k0 < 64; k0 += 16) {
+			float v[16];
+#pragma unroll
+			for (int u = 0; u < 16; ++u)
+				v[u] = (isy || isv) ? src[(long) (k0 + u) * step] : 0.f;
+#pragma unroll
+			for (int u = 0; u < 16; ++u)
+				Ys[(k0 + u) * PITCH + c] = v[u];
+		}
 	}
 	__syncthreads();
 	const int lam = lane & 31, h = lane >> 5;
