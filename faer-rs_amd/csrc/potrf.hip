@@ -313,8 +313,8 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 // instead of the ~38 launches of the recursion above for 8 blocks.  Used where the diagonal-block chain is the
 // critical path (look-ahead panel stream, and the sequential tail where R is small enough that every launch is
 // latency bound anyway).  Same operations per entry as cholesky/ldlt/factor.rs:367-498 grouped by block columns.
-template <typename T>
-static void potrf_panel_flat(MatV<T> P, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase, idx_t wblk0 = 0)
+template <typename T, typename AfterLeaf>
+static void potrf_panel_flat_hook(MatV<T> P, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase, idx_t wblk0, AfterLeaf after_leaf)
 {
 	// the inverse of the 128-block starting at global column offset + c0 goes to slot (offset + c0) / 128 - wblk0 of Wbase
 	const idx_t R = P.nrows, w = P.ncols;
@@ -330,9 +330,15 @@ static void potrf_panel_flat(MatV<T> P, int regularize, T eps, T delta, int *sta
 					   delta, status, (int) (offset + c0), W, (const signed char *) nullptr, (T *) nullptr);
 		}
 		FH_HIP(hipGetLastError());
+		after_leaf(c0, nb, W); // (block column c0 of L above the rows below is final, its packed image is in W)
 		if (R > c0 + nb) // rows below <- rows below * L_kk^-T: substitution leaf, lanes along the rows of the panel
 			trsm_lower_pre_dev<T>(D.c(), P.sub(c0 + nb, c0, R - c0 - nb, nb).t(), W);
 	}
+}
+template <typename T>
+static void potrf_panel_flat(MatV<T> P, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase, idx_t wblk0 = 0)
+{
+	potrf_panel_flat_hook<T>(P, regularize, eps, delta, status, offset, Wbase, wblk0, [](idx_t, idx_t, T *) {});
 }
 
 // Right-looking driver with look-ahead for large matrices: steps of LA_NB columns,
@@ -401,12 +407,55 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		stream_wait(c.la_bulk, e0);
 		stream_wait(c.la_panel, e0);
 		hipEvent_t ev_diag; // D_k factored (its packed 128-blocks are in Wbase)
-		{
-			StreamScope sc(c.la_panel);
-			const idx_t w0 = J[1];
-			potrf_panel_flat<T>(A.sub(0, 0, w0, w0), regularize, eps, delta, status, 0, Wbase);
+		c.qr_side_streams();
+		hipStream_t side = c.qr_side[0];
+		// Round 5: the late steps.  Once the trailing products are shorter than the chains (fewer than LLT_SIDE_RMIN rows below the
+		// next panel) a step was the SUM of two chains: the diagonal block D_{k+1} on the panel stream (24 launches, 0.97 ms), then
+		// the solve of all of P_{k+1} on the bulk stream (15 launches, 0.41 ms), then the product of D_{k+2}: 1.48 ms per 1024
+		// columns with the trailing product hidden beside the first chain (kernel trace, profiles/r05_exp_llt_driver.txt).  But
+		// D_{k+2} needs only the TOP rows X0_{k+1} of P_{k+1} (the next diagonal block's rows), and those can be solved block column
+		// by block column right behind the leaves of D_{k+1}: a FOLLOWER on the side stream -- per 128-block one small product and one
+		// substitution leaf on w2 rows, behind an event of the leaf that produced the block's packed image -- finishes one block
+		// behind the diagonal chain.  The solve of the rows below X0 then runs on the bulk stream BESIDE the next diagonal chain.
+		// For the follower to start early the bulk stream brings X0's rows up to date in a launch of their own (and the diagonal
+		// block two steps ahead, which shares those rows) before the rest of the product.
+		static const int x_follow = getenv("FAER_HIP_X_LLT_FOLLOW") ? atoi(getenv("FAER_HIP_X_LLT_FOLLOW")) : 1;
+		auto rows_below = [&](idx_t kk) { return n - J[(size_t) kk + 1]; };
+		auto solved_on_side = [&](idx_t kk) { return kk >= 1 && rows_below(kk) >= LLT_SIDE_RMIN; }; // (decided in step kk - 1)
+		auto follow = [&](idx_t kk) { return x_follow && kk + 1 < ks && !solved_on_side(kk); };
+		hipEvent_t ev_x0 = nullptr;     // X0_k solved by the follower (implies D_k factored)
+		hipEvent_t ev_x0upd = nullptr;  // the rows of X0_{k+1} are up to date with panel k (bulk stream)
+		// D_kk on the current (panel) stream, with the follower for X0_kk if that panel is solved that way
+		auto factor_diag = [&](idx_t kk, hipEvent_t x0upd) {
+			const idx_t jj0 = J[(size_t) kk], jj1 = J[(size_t) kk + 1], ww = jj1 - jj0;
+			MatV<T> D = A.sub(jj0, jj0, ww, ww);
+			if (!follow(kk)) {
+				potrf_panel_flat<T>(D, regularize, eps, delta, status, jj0, Wbase);
+			} else {
+				const idx_t ww1 = J[(size_t) kk + 2] - jj1;
+				MatV<T> X0f = A.sub(jj1, jj0, ww1, ww);
+				bool first = true;
+				potrf_panel_flat_hook<T>(D, regularize, eps, delta, status, jj0, Wbase, 0, [&](idx_t c0, idx_t nb, T *W) {
+					hipEvent_t el = c.next_event();
+					FH_HIP(hipEventRecord(el, c.la_panel));
+					StreamScope ss(side);
+					if (first && x0upd)
+						stream_wait(side, x0upd);
+					first = false;
+					stream_wait(side, el);
+					if (c0 > 0)
+						gemm_dev<T>(X0f.sub(0, c0, ww1, nb), DST_FULL, true, X0f.sub(0, 0, ww1, c0).c(), A.sub(jj0 + c0, jj0, nb, c0).t().c(), (T) -1);
+					trsm_lower_pre_dev<T>(A.sub(jj0 + c0, jj0 + c0, nb, nb).c(), X0f.sub(0, c0, ww1, nb).t(), W);
+				});
+				ev_x0 = c.next_event();
+				FH_HIP(hipEventRecord(ev_x0, side));
+			}
 			ev_diag = c.next_event();
 			FH_HIP(hipEventRecord(ev_diag, c.la_panel));
+		};
+		{
+			StreamScope sc(c.la_panel);
+			factor_diag(0, nullptr);
 		}
 		// trailing size from which the update of the next diagonal block runs on the panel stream (it has slack to
 		// spare while the trailing matrix is large, and the bulk stream then issues fewer launches per step)
@@ -418,8 +467,6 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		// stream solves P_{k+1} = A_{>k+1,k+1} L_{k+1,k+1}^-T as soon as the panel stream has factored the diagonal block.
 		// Its small kernels find their slots among the product's workgroups (the two launches are independent); towards the
 		// end, where the rest of the update is shorter than the chain, the chain is exposed as before.
-		c.qr_side_streams();
-		hipStream_t side = c.qr_side[0];
 		hipEvent_t ev_solved = nullptr; // P_k solved (recorded on the stream that did it)
 		for (idx_t k = 0; k < ks; ++k) {
 			const idx_t j0 = J[(size_t) k], j1 = J[(size_t) k + 1], w = j1 - j0; // panel columns [j0, j1)
@@ -428,7 +475,8 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 			const idx_t w1 = last ? 0 : J[(size_t) k + 2] - j1;		       // width of the next look-ahead panel
 			MatV<T> Pk = A.sub(j1, j0, r, w);
 			MatV<const T> X = Pk.c(), X0 = Pk.sub(0, 0, w1, w).c();
-			const bool d_on_panel = !last && dpanel_rmin > 0 && r >= dpanel_rmin;
+			const bool fol_k = follow(k), fol_n = !last && follow(k + 1);
+			const bool d_on_panel = !last && dpanel_rmin > 0 && r >= dpanel_rmin && !fol_k;
 			// (the side-stream solve pays only while the rest of the update is much longer than the chain it hides)
 			const bool side_solve = !last && r - w1 >= LLT_SIDE_RMIN;
 			hipEvent_t ev_upd, ev_col = nullptr;
@@ -436,6 +484,14 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 				StreamScope sc(c.la_bulk);
 				if (ev_solved) {
 					stream_wait(c.la_bulk, ev_solved);
+				} else if (fol_k) {
+					// X0_k came from the follower: the next diagonal block at once (-> the panel stream), then the rows below X0_k
+					stream_wait(c.la_bulk, ev_x0);
+					gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
+					ev_col = c.next_event();
+					FH_HIP(hipEventRecord(ev_col, c.la_bulk));
+					if (r > w1)
+						trsm_lower_pre_dev<T>(A.sub(j0, j0, w, w).c(), Pk.sub(w1, 0, r - w1, w).t(), Wbase + (size_t) (j0 / POTRF_NB) * TriPack<T>::SIZE);
 				} else {
 					stream_wait(c.la_bulk, ev_diag);
 					// P_k <- P_k L_kk^-T in place (cholesky/ldlt/factor.rs:422-426): the reference's TRSM recursion on the
@@ -448,17 +504,31 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 				if (last) {
 					gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1);
 				} else if (!side_solve) {
-					if (!d_on_panel) { // next diagonal block first
+					if (!d_on_panel && !fol_k) { // next diagonal block first
 						gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
 						ev_col = c.next_event();
 						FH_HIP(hipEventRecord(ev_col, c.la_bulk));
 					}
-					// block column k+1 below its diagonal block + the remaining lower square in ONE launch: the lower
-					// triangle of the whole trailing matrix minus its leading w1 rows
 					GemmExtra<T> ex;
 					ex.tri_skip = w1;
-					gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1, &ex);
+					ev_x0upd = nullptr;
+					if (fol_n) {
+						// the rows of X0_{k+1} (the follower of the next diagonal block waits for them) and, in the same rows, the
+						// diagonal block two steps ahead; the merged product below then skips these rows as well
+						const idx_t w2 = J[(size_t) k + 3] - J[(size_t) k + 2];
+						MatV<const T> X1 = Pk.sub(w1, 0, w2, w).c();
+						gemm_dev<T>(A.sub(j1 + w1, j1, w2, w1), DST_FULL, true, X1, X0.t(), (T) -1);
+						ev_x0upd = c.next_event();
+						FH_HIP(hipEventRecord(ev_x0upd, c.la_bulk));
+						gemm_dev<T>(A.sub(j1 + w1, j1 + w1, w2, w2), DST_LOWER, true, X1, X1.t(), (T) -1);
+						ex.tri_skip = w1 + w2;
+					}
+					// block column k+1 below its diagonal block + the remaining lower square in ONE launch: the lower
+					// triangle of the whole trailing matrix minus its leading rows
+					if (ex.tri_skip < r)
+						gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1, &ex);
 				} else {
+					ev_x0upd = nullptr;
 					if (!d_on_panel) // next diagonal block first
 						gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
 					// block column k + 1 below its diagonal block
@@ -477,9 +547,9 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 					stream_wait(c.la_panel, d_on_panel ? ev_upd : ev_col);
 					if (d_on_panel)
 						gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
-					potrf_panel_flat<T>(A.sub(j1, j1, w1, w1), regularize, eps, delta, status, j1, Wbase);
-					ev_diag = c.next_event();
-					FH_HIP(hipEventRecord(ev_diag, c.la_panel));
+					// (the follower of D_{k+1} must not start before X0_{k+1}'s rows are up to date with panel k: in the steps that
+					// solve on the side stream the whole block column is updated before ev_col, in the late steps ev_x0upd says so)
+					factor_diag(k + 1, fol_n ? (ev_x0upd ? ev_x0upd : ev_col) : nullptr);
 				}
 				if (side_solve) {
 					StreamScope sc(side);
