@@ -529,7 +529,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 						gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1, &ex);
 				} else {
 					ev_x0upd = nullptr;
-					if (!d_on_panel) // next diagonal block first
+					if (!d_on_panel && !fol_k) // next diagonal block first (a follower step has done it above)
 						gemm_dev<T>(A.sub(j1, j1, w1, w1), DST_LOWER, true, X0, X0.t(), (T) -1);
 					// block column k + 1 below its diagonal block
 					gemm_dev<T>(A.sub(j1 + w1, j1, r - w1, w1), DST_FULL, true, Pk.sub(w1, 0, r - w1, w).c(), X0.t(), (T) -1);
