@@ -313,8 +313,8 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 // instead of the ~38 launches of the recursion above for 8 blocks.  Used where the diagonal-block chain is the
 // critical path (look-ahead panel stream, and the sequential tail where R is small enough that every launch is
 // latency bound anyway).  Same operations per entry as cholesky/ldlt/factor.rs:367-498 grouped by block columns.
-template <typename T, typename AfterLeaf>
-static void potrf_panel_flat_hook(MatV<T> P, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase, idx_t wblk0, AfterLeaf after_leaf)
+template <typename T, typename AfterBlock>
+static void potrf_panel_flat_hook(MatV<T> P, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase, idx_t wblk0, AfterBlock after_block)
 {
 	// the inverse of the 128-block starting at global column offset + c0 goes to slot (offset + c0) / 128 - wblk0 of Wbase
 	const idx_t R = P.nrows, w = P.ncols;
@@ -330,9 +330,9 @@ static void potrf_panel_flat_hook(MatV<T> P, int regularize, T eps, T delta, int
 					   delta, status, (int) (offset + c0), W, (const signed char *) nullptr, (T *) nullptr);
 		}
 		FH_HIP(hipGetLastError());
-		after_leaf(c0, nb, W); // (block column c0 of L above the rows below is final, its packed image is in W)
 		if (R > c0 + nb) // rows below <- rows below * L_kk^-T: substitution leaf, lanes along the rows of the panel
 			trsm_lower_pre_dev<T>(D.c(), P.sub(c0 + nb, c0, R - c0 - nb, nb).t(), W);
+		after_block(c0, nb, W); // (block column c0 of L is final, the packed image of its diagonal block is in W)
 	}
 }
 template <typename T>
@@ -443,9 +443,13 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 						stream_wait(side, x0upd);
 					first = false;
 					stream_wait(side, el);
-					if (c0 > 0)
-						gemm_dev<T>(X0f.sub(0, c0, ww1, nb), DST_FULL, true, X0f.sub(0, 0, ww1, c0).c(), A.sub(jj0 + c0, jj0, nb, c0).t().c(), (T) -1);
+					// RIGHT-looking on these rows: solve block column c0, then take it out of the block columns right of it
+					// (K = 128 products: ~15 us each; the left-looking form with K = c0 on w1 x 128 outputs took ~100 us per block
+					// and the follower finished 0.34 ms behind the diagonal chain -- kernel trace r5v29)
 					trsm_lower_pre_dev<T>(A.sub(jj0 + c0, jj0 + c0, nb, nb).c(), X0f.sub(0, c0, ww1, nb).t(), W);
+					const idx_t c1 = c0 + nb;
+					if (c1 < ww)
+						gemm_dev<T>(X0f.sub(0, c1, ww1, ww - c1), DST_FULL, true, X0f.sub(0, c0, ww1, nb).c(), A.sub(jj0 + c1, jj0 + c0, ww - c1, nb).t().c(), (T) -1);
 				});
 				ev_x0 = c.next_event();
 				FH_HIP(hipEventRecord(ev_x0, side));
