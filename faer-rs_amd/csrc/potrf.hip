@@ -419,7 +419,11 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		// behind the diagonal chain.  The solve of the rows below X0 then runs on the bulk stream BESIDE the next diagonal chain.
 		// For the follower to start early the bulk stream brings X0's rows up to date in a launch of their own (and the diagonal
 		// block two steps ahead, which shares those rows) before the rest of the product.
-		static const int x_follow = getenv("FAER_HIP_X_LLT_FOLLOW") ? atoi(getenv("FAER_HIP_X_LLT_FOLLOW")) : 1;
+		// Measured (profiles/r05_exp_llt_driver.txt): a late step 1.47 -> 1.36 ms, N = 16384 35.1-35.4 -> 34.9-35.0 ms -- less than the
+		// 0.4 ms per step the chains promise: the follower cannot start before the bulk stream has solved the rows that update X0
+		// (0.6 ms into the step), its small products run ~5 x slower beside the trailing product, and with the extra launches the
+		// bulk stream's own chain (solve 0.41 + four products) is now as long as the panel stream's.
+		const bool x_follow = true;
 		auto rows_below = [&](idx_t kk) { return n - J[(size_t) kk + 1]; };
 		auto solved_on_side = [&](idx_t kk) { return kk >= 1 && rows_below(kk) >= LLT_SIDE_RMIN; }; // (decided in step kk - 1)
 		auto follow = [&](idx_t kk) { return x_follow && kk + 1 < ks && !solved_on_side(kk); };
