@@ -523,12 +523,14 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 					if (fol_n) {
 						// the rows of X0_{k+1} (the follower of the next diagonal block waits for them) and, in the same rows, the
 						// diagonal block two steps ahead; the merged product below then skips these rows as well
+						// (ONE launch: the rows [w1, w1 + w2) of the lower triangle of the leading (w1 + w2)^2 block)
 						const idx_t w2 = J[(size_t) k + 3] - J[(size_t) k + 2];
-						MatV<const T> X1 = Pk.sub(w1, 0, w2, w).c();
-						gemm_dev<T>(A.sub(j1 + w1, j1, w2, w1), DST_FULL, true, X1, X0.t(), (T) -1);
+						MatV<const T> X01 = Pk.sub(0, 0, w1 + w2, w).c();
+						GemmExtra<T> exb;
+						exb.tri_skip = w1;
+						gemm_dev<T>(A.sub(j1, j1, w1 + w2, w1 + w2), DST_LOWER, true, X01, X01.t(), (T) -1, &exb);
 						ev_x0upd = c.next_event();
 						FH_HIP(hipEventRecord(ev_x0upd, c.la_bulk));
-						gemm_dev<T>(A.sub(j1 + w1, j1 + w1, w2, w2), DST_LOWER, true, X1, X1.t(), (T) -1);
 						ex.tri_skip = w1 + w2;
 					}
 					// block column k+1 below its diagonal block + the remaining lower square in ONE launch: the lower
