@@ -562,17 +562,12 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 					factor_diag(k + 1, fol_n ? (ev_x0upd ? ev_x0upd : ev_col) : nullptr);
 				}
 				if (side_solve) {
-					// While the trailing product is much longer than the panel stream's work, the solve runs THERE, behind the
-					// diagonal block, on the reserved CUs: its ~15 launches of a few hundred workgroups no longer take slots from the
-					// product on the other 224 (experiment: FAER_HIP_X_LLT_PSOLVE = rows below the next panel from which it does)
-					static const idx_t x_psolve = getenv("FAER_HIP_X_LLT_PSOLVE") ? atol(getenv("FAER_HIP_X_LLT_PSOLVE")) : (idx_t) 1 << 40;
-					hipStream_t ss = r - w1 >= x_psolve ? c.la_panel : side;
-					StreamScope sc(ss);
-					stream_wait(ss, ev_col);
-					stream_wait(ss, ev_diag);
+					StreamScope sc(side);
+					stream_wait(side, ev_col);
+					stream_wait(side, ev_diag);
 					trsm_lower_pre_dev<T>(A.sub(j1, j1, w1, w1).c(), A.sub(j1 + w1, j1, r - w1, w1).t(), Wbase + (size_t) (j1 / POTRF_NB) * TriPack<T>::SIZE);
 					ev_solved = c.next_event();
-					FH_HIP(hipEventRecord(ev_solved, ss));
+					FH_HIP(hipEventRecord(ev_solved, side));
 				}
 			}
 		}
