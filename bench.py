@@ -82,10 +82,11 @@ def resolve_run(gpus, workload, transport):
     and no --workload: configs[3], the block-cyclic LU over the library's RCCL transport (a collective-free GEMM would show
     N x with zero RCCL traffic and say nothing about the distributed path -- VERDICT r04 item 4)."""
     defaulted = workload is None
+    multi = gpus > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))  # (BENCH_FORCE_DIST=1: the N > 1 code path with ONE rank, a dry run)
     if workload is None:
-        workload = "lu" if gpus > 1 else "gemm"
+        workload = "lu" if multi else "gemm"
     if transport is None:
-        transport = "rccl" if (gpus > 1 and defaulted) else "torch"
+        transport = "rccl" if (multi and defaulted) else "torch"
     return workload, transport, defaulted
 
 
@@ -136,11 +137,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1:
+    force_dist = bool(os.environ.get("BENCH_FORCE_DIST")) and args.gpus == 1
+    if args.gpus > 1 or force_dist:
         assert world == args.gpus, f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})"
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
@@ -211,7 +217,7 @@ def main():
                 F.matmul(yv, F.ACCUM_REPLACE, a, xv, 1.0)
 
             return step, 2.0 * n * n, None, f"dgemv_f64_n{n}", "f64"
-        if name == "llt" and world > 1:
+        if name == "llt" and dist is not None:
             # 1-D block-cyclic columns over the ranks, one RCCL broadcast per factored column panel, look-ahead
             # (csrc/dist_llt.h); the total work is fixed => strong scaling.  The SPD matrix is built per rank from
             # the same generator state: rank r keeps its own block columns of G G^T + n I.
@@ -250,7 +256,7 @@ def main():
             return step, n ** 3 / 3.0, lambda: work.copy_(spd), f"llt_f64_n{n}", "f64"
         if name == "lu":
             n = n_override or 16384
-            if world > 1:
+            if dist is not None:
                 # BASELINE.json configs[3]: 1-D block-cyclic columns over the ranks, RCCL broadcast of each factored
                 # panel (csrc/dist_lu.h); the total work is fixed => strong scaling
                 nb = 512
@@ -462,7 +468,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = flops * world * args.steps / dt / 1e9  # whole-job GFLOP/s
     prof_main = None
-    if world == 1:
+    if dist is None:
         try:
             prof_main = profiled(step)
         except Exception:
@@ -528,12 +534,12 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "strong" if (args.workload in ("lu", "llt") and world > 1) else "weak",
+        "scaling": "strong" if (args.workload in ("lu", "llt") and dist is not None) else "weak",
         "vs_baseline": None,
         "dtype": dtype_name,
         "data": "synthetic",
         "config": {"workload": label, "layout": "column-major, resident in HBM",
-                   "sharding": "none" if world == 1 else (
+                   "sharding": "none" if dist is None else (
                        f"1-D block-cyclic columns over {world} GPUs, one RCCL broadcast per factored panel, look-ahead" if args.workload in ("lu", "llt")
                        else f"block columns of C over {world} GPUs, no collective")},
     }
@@ -610,7 +616,7 @@ def main():
                 del a, b, c
 
         # ---------------------------------------------------------------- other hot-path workloads (one GPU)
-        if world == 1 and not args.no_extras:
+        if dist is None and not args.no_extras:
             others = {}
             del step
             torch.cuda.empty_cache()
@@ -709,7 +715,7 @@ def main():
             out["others"] = others
 
         # ---------------------------------------------------------------- CPU baseline (oracle port, bounded sample)
-        if world == 1 and not args.no_cpu:
+        if dist is None and not args.no_cpu:
             from oracle import oracle as orc
 
             ncpu = os.cpu_count() or 1

@@ -45,5 +45,5 @@ def test_source_wires_the_defaults_into_the_run():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "args.workload, args.transport, defaulted = resolve_run(args.gpus, args.workload, args.transport)" in src
     assert re.search(r'rccl = F\.RcclTransport\(', src) and "transport=rccl" in src
-    assert '"scaling": "strong" if (args.workload in ("lu", "llt") and world > 1) else "weak"' in src
+    assert '"scaling": "strong" if (args.workload in ("lu", "llt") and dist is not None) else "weak"' in src
     assert 'out["per_rank"] = per_rank' in src and "lu_1gpu_same_run" in src
