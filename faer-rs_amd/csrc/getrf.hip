@@ -1640,7 +1640,10 @@ template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev, int *status_
 	wk.status = status_dev ? status_dev : misc.as<int>() + 8;
 	FH_HIP(hipMemsetAsync(misc.p, 0, 256, ctx().stream));
 	FH_HIP(hipMemsetAsync(granb.p, 0, gran_bytes + diag_bytes, ctx().stream));
-	getrf_rec<T>(P, 0, 0, wk);
+	if (flat_panel_ok<T>(P, wk)) // (the distributed driver's block columns: the flat right-looking panel of the look-ahead driver)
+		getrf_panel_flat<T>(P, 0, 0, wk, [](idx_t) { return (idx_t) 0; }, [](idx_t) {});
+	else
+		getrf_rec<T>(P, 0, 0, wk);
 	if (status_dev)
 		return;
 	int st[4] = {0, 0, 0, 0};
