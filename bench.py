@@ -259,7 +259,7 @@ def main():
             if dist is not None:
                 # BASELINE.json configs[3]: 1-D block-cyclic columns over the ranks, RCCL broadcast of each factored
                 # panel (csrc/dist_lu.h); the total work is fixed => strong scaling
-                nb = 512
+                nb = int(os.environ.get("BENCH_DIST_NB", "512"))
                 ncols = F.dist_local_ncols(n, nb, rank, world)
                 a = colmajor(n, ncols, torch.float64, 40 + rank)
                 work = a.clone()
