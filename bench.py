@@ -20,6 +20,8 @@ RCCL broadcast per factored panel through the library's own transport (`resolve_
 the same size timed on rank 0 in the same run (the N = 1 point of the curve; it is also `others.lu_f64_n16384` of
 the --gpus 1 line).  `others` then carries the collective-free weak-scaling GEMM (every rank multiplies the same
 A by its own N x 8192 slice of B) and the block-cyclic LU at N = 65536.  Rank 0 prints ONE JSON line.
+BENCH_FORCE_DIST=1 with --gpus 1 runs exactly that code path with ONE rank (process group, RCCL communicator, block-cyclic
+driver, the N = 65536 entry): a dry run of the multi-GPU default on a one-GPU box (profiles/r05_bench_dryrun_dist_one_rank.json).
 
 The line also carries
   "roofline":     the dominant kernel (the MFMA GEMM) against the fp64 MFMA peak, timed with HIP events on the
