@@ -779,6 +779,12 @@ def main():
                                              f"{ncpu} host cores) fp64 matmul n={n_mm}, 1 rep ({t_mm:.2f} s); "
                                              f"llt n={n_llt}: {n_llt ** 3 / 3.0 / t_llt / 1e9:.2f} GFLOP/s ({t_llt:.2f} s)",
                                    "note": "faer itself cannot be built here (no Rust toolchain); proxy, see BASELINE.md"}
+        try:
+            # RCCL prints a version banner through C stdio, which is block buffered on a pipe and would otherwise land BEHIND this
+            # line at exit: flush it first, so that the JSON line is the last line of stdout
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
 
     if dist is not None:
