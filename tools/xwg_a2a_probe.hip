@@ -93,6 +93,103 @@ __global__ __launch_bounds__(256) void a2a_kernel(unsigned char *ws, int iters, 
 					a1 = ld(hr, voff + 16u * STRIDE, soff);
 				}
 			}
+		} else if (mode == 5 || mode == 6) {
+			// mode 5: 32-byte records (two 16-byte granules, lanes 2 t and 2 t + 1), ONE load instruction sweeps all 32 records
+			// mode 6: 16-byte records, lane t reads record t
+			const unsigned rb = mode == 5 ? 32u : 16u, rstride = 128u;
+			if (lane < (mode == 5 ? 2 : 1)) {
+				u32x4 q = {tag, (unsigned) (g * 7 + r), tag, (unsigned) lane};
+				st(q, hr, (unsigned) (lane * 16), (par * GMAX + g) * rstride);
+			}
+			const int t = mode == 5 ? lane >> 1 : lane;
+			const unsigned voff = (unsigned) (t * rstride + (mode == 5 ? (lane & 1) * 16 : 0)), soff = par * GMAX * rstride;
+			(void) rb;
+			u32x4 a0 = ld(hr, voff, soff);
+			for (int spin = 0;; ++spin) {
+				bool ok = t >= G || (a0.x == tag && a0.z == tag);
+				if (__all(ok)) {
+					acc += a0.y;
+					break;
+				}
+				if (spin > SPIN) {
+					dead = true;
+					break;
+				}
+				asm volatile("" ::: "memory");
+				a0 = ld(hr, voff, soff);
+			}
+		} else if (mode == 8 || mode == 9) {
+			// 16-byte records through GLOBAL instructions (scalar base + 32-bit lane offset, sc1) instead of buffer instructions;
+			// mode 9: 64-byte records, two loads per sweep (the LU kernel's layout)
+			const unsigned rstride = mode == 8 ? 128u : (unsigned) STRIDE;
+			const unsigned long long base = (unsigned long long) ws + (unsigned long long) par * GMAX * rstride;
+			if (lane < (mode == 8 ? 1 : 4)) {
+				u32x4 q = {tag, (unsigned) (g * 7 + r), tag, (unsigned) lane};
+				const unsigned so = (unsigned) (g * rstride + lane * 16);
+				asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(so), "v"(q), "s"(base) : "memory");
+			}
+			const int t = mode == 8 ? lane : lane >> 2;
+			const unsigned vo = mode == 8 ? (unsigned) (lane * rstride) : (unsigned) ((lane >> 2) * rstride + (lane & 3) * 16);
+			for (int spin = 0;; ++spin) {
+				u32x4 a0, a1 = {tag, 0u, tag, 0u};
+				asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(a0) : "v"(vo), "s"(base) : "memory");
+				if (mode == 9) {
+					const unsigned vo1 = vo + 16u * rstride;
+					asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(a1) : "v"(vo1), "s"(base) : "memory");
+				}
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				bool ok = (t >= G || (a0.x == tag && a0.z == tag)) && (mode == 8 || t + 16 >= G || (a1.x == tag && a1.z == tag));
+				if (__all(ok)) {
+					acc += a0.y + a1.y;
+					break;
+				}
+				if (spin > SPIN) {
+					dead = true;
+					break;
+				}
+			}
+		} else if (mode == 10) {
+			// 8-byte granules through BUFFER instructions (b64, sc1): lane t reads record t (128 bytes apart)
+			typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+			if (lane == 0) {
+				u32x2 q = {(unsigned) (g * 7 + r), tag};
+				__builtin_amdgcn_raw_buffer_store_b64(q, hr, 0, (int) ((par * GMAX + g) * 128u), 16);
+			}
+			for (int spin = 0;; ++spin) {
+				asm volatile("" ::: "memory");
+				u32x2 v = {0u, tag};
+				if (lane < G)
+					v = __builtin_amdgcn_raw_buffer_load_b64(hr, (int) (lane * 128), (int) (par * GMAX * 128u), 16);
+				if (__all(v.y == tag)) {
+					acc += v.x;
+					break;
+				}
+				if (spin > SPIN) {
+					dead = true;
+					break;
+				}
+			}
+		} else if (mode == 7) {
+			// mode 0 without the s_sleep between sweeps
+			if (lane < 4) {
+				u32x4 q = {tag, (unsigned) (g * 7 + r), tag, (unsigned) lane};
+				st(q, hr, (unsigned) (lane * 16), (par * GMAX + g) * STRIDE);
+			}
+			const unsigned voff = (unsigned) ((lane >> 2) * STRIDE + (lane & 3) * 16), soff = par * GMAX * STRIDE;
+			const int t = lane >> 2;
+			for (int spin = 0;; ++spin) {
+				asm volatile("" ::: "memory");
+				u32x4 a0 = ld(hr, voff, soff), a1 = ld(hr, voff + 16u * STRIDE, soff);
+				bool ok = (t >= G || (a0.x == tag && a0.z == tag)) && (t + 16 >= G || (a1.x == tag && a1.z == tag));
+				if (__all(ok)) {
+					acc += a0.y + a1.y;
+					break;
+				}
+				if (spin > SPIN) {
+					dead = true;
+					break;
+				}
+			}
 		} else if (mode == 2) {
 			// inbox of consumer c: [par][c][GMAX records of 64 bytes]; lane l < 4 G stores piece l & 3 into inbox (l >> 2) ... two rounds
 			const unsigned base = par * (GMAX * GMAX * 64);
@@ -181,8 +278,8 @@ int main()
 	hipStream_t s;
 	CK(hipExtStreamCreateWithCUMask(&s, (uint32_t) ((ncu + 31) / 32), mask));
 	const int iters = 3000;
-	for (int G : {32, 16, 8, 4, 2}) {
-		for (int mode = 0; mode < 5; ++mode) {
+	for (int G : {32, 16}) {
+		for (int mode : {0, 10, 3}) {
 			for (unsigned long long D : {0ull, 2300ull}) {
 				CK(hipMemsetAsync(ws, 0, WS, s));
 				CK(hipMemsetAsync(status, 0, 4, s));
