@@ -538,9 +538,28 @@ constexpr int LUN_W = 64;   // left width = rows of the triangular system
 constexpr int LUN_LP = 65;  // LDS pitch of L00 (row major: broadcast reads)
 constexpr int LUN_UP = 80;  // LDS pitch of U (k major; pitch = 16 mod 32 keeps the four k groups of an operand read on disjoint banks)
 constexpr int LUN_ROWS = 256; // rows of A11 per workgroup
+// the node kernel addresses its 64-column blocks as base + 32-bit byte offset: rows + 64 columns must stay below 4 GB
+template <typename T> static bool lu_node_offsets_ok(idx_t m, idx_t cs)
+{
+	return m > 0 && cs > 0 && m < (1L << 30) && (double) sizeof(T) * ((double) m + 64.0 * (double) cs) < 4294967296.0;
+}
 
+#ifdef FH_LU_TIMING
+// timing build: s_memtime ticks of workgroup (0, 0), wavefront 0 per phase of the node kernel, summed over launches (lu_dump_timing)
+__device__ unsigned long long g_node_phase[8];
+#define LUN_TICK(i)                                                                                                                      \
+	do {                                                                                                                             \
+		if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {                                                                    \
+			const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                    \
+			atomicAdd(&g_node_phase[i], now_ - tick_);                                                                       \
+			tick_ = now_;                                                                                                    \
+		}                                                                                                                        \
+	} while (0)
+#else
+#define LUN_TICK(i)
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void lu_node64_kernel(T *P, idx_t cs, int m, int nr, const T *__restrict__ top)
+__global__ __launch_bounds__(256, 2) void lu_node64_kernel(T *P, idx_t cs, int m, int nr, const T *__restrict__ top)
 {
 	typedef typename Mfma<T>::acc_t acc_t;
 	__shared__ T Ls[LUN_W * LUN_LP];
@@ -553,6 +572,81 @@ __global__ __launch_bounds__(256) void lu_node64_kernel(T *P, idx_t cs, int m, i
 	nr = min(LUN_W, nr - cg * LUN_W);
 	top += (size_t) cg * LUN_W * LUN_W;
 	T *B = P + (idx_t) (LUN_W + cg * LUN_W) * cs; // the right block
+#ifdef FH_LU_TIMING
+	unsigned long long tick_ = __builtin_amdgcn_s_memtime();
+#endif
+	// ---- A11 -= A10 A01 runs on 16-row tiles: chunks of LUN_ROWS rows (several per workgroup when the launch has many of them:
+	// the solve below is paid once per workgroup), wavefront w takes 64 rows of a chunk, 16 at a time.  Every tile is a dependent
+	// "32 loads -> 64 matrix-core steps -> 16 stores", and a wavefront runs its tiles one after the other: with the loads issued
+	// when the tile starts, each tile waited a full memory round trip (alone on the panel stream 4-5 us per tile for < 1 us of
+	// arithmetic, profiles/r05_exp_lu_driver.txt item 8).  So the loads run ONE TILE AHEAD in a second set of registers -- raw
+	// values, clamped addresses, no arithmetic on them before the tile is due -- and the first tile's loads are issued before the
+	// triangular solve, which neither reads nor writes those rows.
+	const int nchunks = (m - LUN_W + LUN_ROWS - 1) / LUN_ROWS;
+	auto tile_r0 = [&](int idx) -> int { // first row of this wavefront's idx-th tile, -1 behind the last one (wave uniform)
+		const int chunk = (int) blockIdx.x + (idx >> 2) * (int) gridDim.x;
+		if (chunk >= nchunks)
+			return -1;
+		const int r0 = LUN_W + chunk * LUN_ROWS + wave * 64 + 16 * (idx & 3);
+		return r0 < m ? r0 : -1;
+	};
+	// lanes outside the matrix (rows >= m, columns >= nr) load a valid entry instead and never store: every output entry depends on
+	// its own row of L, its own column of U and its own old value only
+	// (addresses as uniform base + 32-bit byte offset per lane -- lu_node_offsets_ok on the host: 64-bit addresses for the 2 x 32 loads in
+	// flight cost more registers than two workgroups per CU leave)
+	const char *Pc = reinterpret_cast<const char *>(P), *Bc = reinterpret_cast<const char *>(B);
+	const unsigned csb = (unsigned) cs * (unsigned) sizeof(T);
+	auto tile_load = [&](int r0, T (&braw)[16], acc_t (&acc)[4]) {
+		const unsigned rb = (unsigned) min(r0 + l15, m - 1) * (unsigned) sizeof(T);
+#pragma unroll
+		for (int j = 0; j < 16; ++j)
+			braw[j] = *reinterpret_cast<const T *>(Pc + (rb + (unsigned) (4 * j + lhi) * csb)); // L[r][4 j + lhi]: b operand of step k0 = 4 j (negated when used)
+#pragma unroll
+		for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int c = 16 * ct + Mfma<T>::row(q, lhi);
+				acc[ct][q] = *reinterpret_cast<const T *>(Bc + (rb + (unsigned) (c < nr ? c : 0) * csb));
+			}
+	};
+	auto tile_finish = [&](int r0, T (&braw)[16], acc_t (&acc)[4]) {
+		const int r = r0 + l15;
+		// (the U operands one k step ahead, and nothing moves across a step: left to itself the scheduler hoists all 64 LDS reads
+		// of a tile, which with two tiles' loads in registers no longer fits two workgroups per CU)
+		T a_cur[4], a_nxt[4];
+#pragma unroll
+		for (int ct = 0; ct < 4; ++ct)
+			a_cur[ct] = Us[lhi * LUN_UP + 16 * ct + l15];
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+			if (j + 1 < 16) {
+#pragma unroll
+				for (int ct = 0; ct < 4; ++ct)
+					a_nxt[ct] = Us[(4 * (j + 1) + lhi) * LUN_UP + 16 * ct + l15];
+			}
+			const T bneg = -braw[j];
+#pragma unroll
+			for (int ct = 0; ct < 4; ++ct)
+				acc[ct] = Mfma<T>::run(a_cur[ct], bneg, acc[ct]);
+#pragma unroll
+			for (int ct = 0; ct < 4; ++ct)
+				a_cur[ct] = a_nxt[ct];
+			__builtin_amdgcn_sched_barrier(0);
+		}
+#pragma unroll
+		for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int c = 16 * ct + Mfma<T>::row(q, lhi);
+				if (r < m && c < nr)
+					*reinterpret_cast<T *>(const_cast<char *>(Bc) + ((unsigned) r * (unsigned) sizeof(T) + (unsigned) c * csb)) = acc[ct][q];
+			}
+	};
+	T b_a[16], b_b[16];
+	acc_t acc_a[4], acc_b[4];
+	int r_a = tile_r0(0), r_b = -1;
+	if (r_a >= 0)
+		tile_load(r_a, b_a, acc_a);
 	// ---- L00 (strictly lower part is used) and this thread's 16 rows of column c = lane of the interchanged top block
 #pragma unroll
 	for (int j = 0; j < LUN_W / 4; ++j) {
@@ -564,6 +658,7 @@ __global__ __launch_bounds__(256) void lu_node64_kernel(T *P, idx_t cs, int m, i
 	for (int i = 0; i < 16; ++i)
 		u[i] = lane < nr ? top[(size_t) lane * LUN_W + 16 * wave + i] : (T) 0;
 	__syncthreads();
+	LUN_TICK(0);
 	// ---- U = L00^-1 top (factor.rs:104-109 -> triangular_solve.rs: forward substitution, unit diagonal)
 #pragma unroll
 	for (int kb = 0; kb < 4; ++kb) {
@@ -589,6 +684,7 @@ __global__ __launch_bounds__(256) void lu_node64_kernel(T *P, idx_t cs, int m, i
 			}
 		}
 	}
+	LUN_TICK(1);
 	// ---- workgroup 0 stores A01 (lanes along the rows)
 	if (blockIdx.x == 0) {
 		for (int idx = tid; idx < LUN_W * nr; idx += 256) {
@@ -596,53 +692,26 @@ __global__ __launch_bounds__(256) void lu_node64_kernel(T *P, idx_t cs, int m, i
 			B[d + (idx_t) c * cs] = Us[d * LUN_UP + c];
 		}
 	}
-	// ---- A11 -= A10 A01 on this workgroup's rows: chunks of LUN_ROWS rows (several per workgroup when the launch has many of
-	// them: the solve above is paid once per workgroup), wavefront w takes 64 rows of a chunk, 16 at a time
-	const int nchunks = (m - LUN_W + LUN_ROWS - 1) / LUN_ROWS;
+	LUN_TICK(2);
+	// ---- the tiles, two register sets in turn
 #pragma unroll 1
-	for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-	const int rb = LUN_W + chunk * LUN_ROWS + wave * 64;
-#pragma unroll 1
-	for (int rt = 0; rt < 4; ++rt) {
-		const int r0 = rb + 16 * rt;
-		if (r0 >= m) // wave uniform
+	for (int idx = 0; r_a >= 0; idx += 2) {
+		r_b = tile_r0(idx + 1);
+		if (r_b >= 0)
+			tile_load(r_b, b_b, acc_b);
+		tile_finish(r_a, b_a, acc_a);
+		if (r_b < 0)
 			break;
-		const int r = r0 + l15;
-		const bool rin = r < m;
-		T bneg[16]; // b operand of step k0 = 4 j: -L[r][4 j + lhi]
-#pragma unroll
-		for (int j = 0; j < 16; ++j) {
-			const T v = P[(rin ? r : m - 1) + (idx_t) (4 * j + lhi) * cs];
-			bneg[j] = rin ? -v : (T) 0;
-		}
-		acc_t acc[4];
-#pragma unroll
-		for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				const int c = 16 * ct + Mfma<T>::row(q, lhi);
-				const bool in = rin && c < nr;
-				const T v = B[(in ? r : 0) + (idx_t) (in ? c : 0) * cs];
-				acc[ct][q] = in ? v : (T) 0;
-			}
-#pragma unroll
-		for (int j = 0; j < 16; ++j) {
-#pragma unroll
-			for (int ct = 0; ct < 4; ++ct) {
-				const T a = Us[(4 * j + lhi) * LUN_UP + 16 * ct + l15];
-				acc[ct] = Mfma<T>::run(a, bneg[j], acc[ct]);
-			}
-		}
-#pragma unroll
-		for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				const int c = 16 * ct + Mfma<T>::row(q, lhi);
-				if (rin && c < nr)
-					B[r + (idx_t) c * cs] = acc[ct][q];
-			}
+		r_a = tile_r0(idx + 2);
+		if (r_a >= 0)
+			tile_load(r_a, b_a, acc_a);
+		tile_finish(r_b, b_b, acc_b);
 	}
-	}
+	LUN_TICK(3);
+#ifdef FH_LU_TIMING
+	if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+		atomicAdd(&g_node_phase[7], 1ull);
+#endif
 }
 
 // The same with the net permutation prepared ONCE (laswp_compose_list_kernel): the look-ahead driver applies a panel's
@@ -996,6 +1065,15 @@ static unsigned long long *lu_phase_words()
 void lu_dump_timing()
 {
 #ifdef FH_LU_TIMING
+	{
+		unsigned long long d[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		FH_HIP(hipDeviceSynchronize());
+		FH_HIP(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_node_phase), sizeof(d)));
+		FH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_node_phase), z, sizeof(z)));
+		if (d[7])
+			fprintf(stderr, "node kernel phases (s_memtime ticks per launch, workgroup (0,0) wave 0, %llu launches): prefetch + L00 + top in %.0f | solve %.0f | A01 store %.0f | tiles %.0f\n",
+				d[7], (double) d[0] / d[7], (double) d[1] / d[7], (double) d[2] / d[7], (double) d[3] / d[7]);
+	}
 	if (!g_lu_phase)
 		return;
 	unsigned long long h[16];
@@ -1136,7 +1214,7 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 	// bring the right half up to date: swaps, A01 <- L00^-1 A01, A11 -= A10 A01 (factor.rs:98-117)
 	MatV<T> A00 = P.sub(0, 0, bs, bs), A01 = P.sub(0, bs, bs, n - bs), A10 = P.sub(bs, 0, m - bs, bs),
 		A11 = P.sub(bs, bs, m - bs, n - bs);
-	if (bs == LUN_W && n - bs <= LUN_W && P.rs == 1 && wk.ttop && m < (1L << 30)) {
+	if (bs == LUN_W && n - bs <= LUN_W && P.rs == 1 && wk.ttop && lu_node_offsets_ok<T>(m, P.cs)) {
 		// the 128-column nodes: interchanges (+ a copy of the interchanged top block), then solve and product in one launch
 		laswp_dev<T>(right, wk.piv + col0, (int) bs, row_base, wk.ttop);
 		const idx_t below = m - bs;
@@ -1166,7 +1244,7 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 // ------------------------------------------------------------------------------------------------
 template <typename T> static bool flat_panel_ok(MatV<T> P, const LuWork<T> &wk)
 {
-	return P.rs == 1 && wk.ttop && P.ncols % LUN_W == 0 && P.ncols <= 512 && P.nrows >= P.ncols && P.nrows < (1L << 30) && !wk.general &&
+	return P.rs == 1 && wk.ttop && P.ncols % LUN_W == 0 && P.ncols <= 512 && P.nrows >= P.ncols && lu_node_offsets_ok<T>(P.nrows, P.cs) && !wk.general &&
 	       !g_lu_force_general.load() && leaf_width_for<T>(P.nrows) == LU_W;
 }
 template <typename T, typename LeftFrom, typename AfterLeaf>
@@ -1562,6 +1640,8 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		const bool la = !force_general && size >= 8 * LU_LA_NB && ctx().lookahead_streams() && (m + leaf_r - 1) / leaf_r <= (idx_t) ctx().la_panel_cus;
 		if (la)
 			getrf_lookahead<T>(A.sub(0, 0, m, size), wk, ctx().stream);
+		else if (flat_panel_ok<T>(A.sub(0, 0, m, size), wk)) // (one panel of the look-ahead driver: same launches, same pivots)
+			getrf_panel_flat<T>(A.sub(0, 0, m, size), 0, 0, wk, [](idx_t) { return (idx_t) 0; }, [](idx_t) {});
 		else
 			getrf_rec<T>(A.sub(0, 0, m, size), 0, 0, wk);
 		if (lent && !force_general) {

@@ -44,6 +44,15 @@ for sec in "$@"; do
       [ -n "$t" ] && python tools/trace_timeline.py $t > gpurun_out/${tag}_${wl}_timeline.txt 2>&1 && head -60 gpurun_out/${tag}_${wl}_timeline.txt
       # keep the merged output small: drop the raw trace
       rm -rf gpurun_out/prof_${tag}_$wl ;;
+    rprof:*)
+      sc=${sec#rprof:}; b=$(basename $sc .py)_${PANEL_MODE:-x}
+      rm -rf gpurun_out/prof_${tag}_$b
+      timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$b -o $b -- python $sc > gpurun_out/prof_${tag}_$b.log 2>&1; echo "rprof $sc rc=$?"
+      tail -2 gpurun_out/prof_${tag}_$b.log
+      f=$(find gpurun_out/prof_${tag}_$b -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_${b}_kernel_stats.csv && head -12 $f | cut -c1-200
+      t=$(find gpurun_out/prof_${tag}_$b -name '*kernel_trace.csv' | head -1)
+      [ -n "$t" ] && python tools/trace_rows.py $t "${TRACE_GREP:-node64}" | tail -${TRACE_TAIL:-24}
+      rm -rf gpurun_out/prof_${tag}_$b ;;
     py:*)
       timeout 600 python ${sec#py:} > gpurun_out/${tag}_$(basename ${sec#py:} .py).log 2>&1; echo "$sec rc=$?"
       tail -40 gpurun_out/${tag}_$(basename ${sec#py:} .py).log ;;
