@@ -5,7 +5,7 @@
 //
 // The reference is right-looking with 128-column steps (factor.rs:392).  A rank-128 fp64 update is only
 // ~16 flop/byte -- at the MI355X machine balance -- so the GPU drivers use larger steps with the same arithmetic per
-// entry: recursion by HALVES below 2048 columns (potrf_rec), 1024-column steps above (potrf_lookahead: left-looking
+// entry: recursion by HALVES below 2048 columns (potrf_rec), 1024-column steps above (potrf_lookahead: right-looking
 // panels in 128-column blocks, trailing updates with K = 1024, look-ahead on two CU-masked streams for large n).
 //
 // Leaf (n <= 128): ONE 512-thread workgroup, the block resident in LDS (lds_blocks.h), blocked right-looking
@@ -305,14 +305,18 @@ static void potrf_rec(MatV<T> A, int regularize, T eps, T delta, int *status, id
 	potrf_rec<T>(A11, regularize, eps, delta, status, offset + h, Wbase, need_inv);
 }
 
-// Left-looking factorization of a tall panel P (R x w, R >= w; the top w x w block is the diagonal block) in 128
-// column blocks -- three launches per block on ONE dependent chain:
-//     block column j  -=  P[c0:, 0:c0] P[c0:c0+128, 0:c0]^T   (lower trapezoid, one GEMM with K = c0)
+// Factorization of a tall panel P (R x w, R >= w; the top w x w block is the diagonal block) in 128-column blocks -- three
+// launches per block on ONE dependent chain, right-looking like the reference's own sweep (cholesky/ldlt/factor.rs:367-498
+// with its 128-column step, :392):
 //     leaf on the diagonal block                               (also yields the packed image W_j of L_jj)
 //     rows below      <-  rows below * L_jj^-T                 (substitution leaf against W_j, trsm.hip)
-// instead of the ~38 launches of the recursion above for 8 blocks.  Used where the diagonal-block chain is the
-// critical path (look-ahead panel stream, and the sequential tail where R is small enough that every launch is
-// latency bound anyway).  Same operations per entry as cholesky/ldlt/factor.rs:367-498 grouped by block columns.
+//     panel right of block j  -=  P[c1:, j] P[c1:w, j]^T       (lower trapezoid, ONE GEMM with K = 128)
+// instead of the ~38 launches of the recursion above for 8 blocks.  Used where the diagonal-block chain is the critical
+// path (look-ahead panel stream, the sequential tail, the distributed driver's panels).
+// Rounds 2-4 ran this LEFT-looking (block column j -= P[c0:, 0:c0] P[c0:c0+128, 0:c0]^T before its leaf, K = c0): on the 32
+// reserved CUs those launches were 15-59 us (a K = 896 product on a 128-column output has 4-16 workgroups), the K = 128
+// trapezoids are 12-25 us.  Measured (profiles/r05_exp_llt_driver.txt): N = 16384 34.7-35.0 -> 34.0-34.1 ms, N = 8192 10.4-11.5
+// -> 9.6-9.7 ms; with the cheaper diagonal chains the look-ahead steps beat the sequential tail down to 1024 rows: 33.2 ms.
 template <typename T, typename AfterBlock>
 static void potrf_panel_flat_hook(MatV<T> P, int regularize, T eps, T delta, int *status, idx_t offset, T *Wbase, idx_t wblk0, AfterBlock after_block)
 {
@@ -320,8 +324,6 @@ static void potrf_panel_flat_hook(MatV<T> P, int regularize, T eps, T delta, int
 	const idx_t R = P.nrows, w = P.ncols;
 	for (idx_t c0 = 0; c0 < w; c0 += POTRF_NB) {
 		const idx_t nb = POTRF_NB < w - c0 ? POTRF_NB : w - c0;
-		if (c0 > 0)
-			gemm_dev<T>(P.sub(c0, c0, R - c0, nb), DST_LOWER, true, P.sub(c0, 0, R - c0, c0).c(), P.sub(c0, 0, nb, c0).t().c(), (T) -1);
 		T *W = Wbase + (size_t) ((offset + c0) / POTRF_NB - wblk0) * TriPack<T>::SIZE;
 		MatV<T> D = P.sub(c0, c0, nb, nb);
 		{
@@ -333,6 +335,10 @@ static void potrf_panel_flat_hook(MatV<T> P, int regularize, T eps, T delta, int
 		if (R > c0 + nb) // rows below <- rows below * L_kk^-T: substitution leaf, lanes along the rows of the panel
 			trsm_lower_pre_dev<T>(D.c(), P.sub(c0 + nb, c0, R - c0 - nb, nb).t(), W);
 		after_block(c0, nb, W); // (block column c0 of L is final, the packed image of its diagonal block is in W)
+		if (c0 + nb < w) {
+			const idx_t c1 = c0 + nb;
+			gemm_dev<T>(P.sub(c1, c1, R - c1, w - c1), DST_LOWER, true, P.sub(c1, c0, R - c1, nb).c(), P.sub(c1, c0, w - c1, nb).t().c(), (T) -1);
+		}
 	}
 }
 template <typename T>
@@ -387,10 +393,12 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 	const idx_t n = A.nrows;
 	// Once the remaining matrix is small the chain "diagonal block -> panel solve -> next diagonal block" is longer
 	// than the trailing update it is meant to hide behind: the tail is factored on the caller's stream, whole chip,
-	// one tall left-looking panel + ONE trailing update per step.
+	// one tall panel (potrf_panel_flat) + ONE trailing update per step.
 	// Look-ahead pays from ~10k rows upwards (measured, N = 8192: 13.3 ms sequential against 13.8 ms); below that and
 	// for the last `tail_rows` rows of a large matrix the steps run back to back on the caller's stream.
-	const idx_t tail_rows = getenv("FAER_HIP_LLT_TAIL") ? atol(getenv("FAER_HIP_LLT_TAIL")) : (n < 10 * LA_NB ? n : 4 * LA_NB);
+	// (round 5, right-looking diagonal chains: look-ahead from 8192 rows on -- 9.5 ms either way there, 6144: 6.2 sequential against
+	// 6.5 -- and down to the last 1024 rows: tails of 4096 / 3072 / 2048 / 1024 rows 34.1 / 33.6-33.7 / 33.4 / 33.2 ms at N = 16384)
+	const idx_t tail_rows = getenv("FAER_HIP_LLT_TAIL") ? atol(getenv("FAER_HIP_LLT_TAIL")) : (n < 8 * LA_NB ? n : LA_NB);
 	// Step widths of the look-ahead part: the FIRST step is LA_NB wide (its diagonal block is factored with the rest
 	// of the chip idle), the following ones LA_NB2 (wider steps: K = LA_NB2 trailing updates run closer to the dense
 	// rate and there are fewer launch boundaries per factorization) while at least 2 * LA_NB2 rows remain.
@@ -581,6 +589,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		stream_wait(caller, ep);
 	}
 	// ---- tail (everything, if the matrix is small): sequential, whole chip
+	// (steps of 128 / 256 / 512 / 2048 columns here: 34.2-34.3 / 34.3 / 34.4-34.5 ms at N = 16384 against 34.0-34.1; N = 8192: 10.4 / 9.7 / 9.6 / 9.8 against 9.65)
 	for (idx_t j0 = tail0; j0 < n; j0 += LA_NB) {
 		const idx_t w = LA_NB < n - j0 ? LA_NB : n - j0, R = n - j0;
 		potrf_panel_flat<T>(A.sub(j0, j0, R, w), regularize, eps, delta, status, j0, Wbase);
@@ -592,7 +601,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 }
 
 // Tall panel entry point for the distributed driver (dist_llt.h): Cholesky of the top square block of P and the
-// solve of the rows below it, left-looking in 128-column blocks (potrf_panel_flat).  status: 2 device ints,
+// solve of the rows below it, right-looking in 128-column blocks (potrf_panel_flat).  status: 2 device ints,
 // [0] = first failing global index + 1 (kept if already set), [1] += regularisation count; no synchronisation.
 template <typename T> void potrf_panel_dev(MatV<T> P, T reg_delta, T reg_eps, int *status_dev, idx_t offset)
 {
