@@ -431,9 +431,12 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		// 0.4 ms per step the chains promise: the follower cannot start before the bulk stream has solved the rows that update X0
 		// (0.6 ms into the step), its small products run ~5 x slower beside the trailing product, and with the extra launches the
 		// bulk stream's own chain (solve 0.41 + four products) is now as long as the panel stream's.
+		// (re-swept with the right-looking chains: side solve from 4096 / 6144 / 8192 / 10240 rows 33.7 / 33.0-33.2 / 33.1-33.6 / 33.6-34.0 ms,
+		// next diagonal block's product on the panel stream from 4096 / 8192 / 12288 rows 33.2 / 33.1-33.6 / 33.6-33.9: both left at 8192)
+		const idx_t side_rmin = LLT_SIDE_RMIN, dpanel_rmin = 8192;
 		const bool x_follow = true;
 		auto rows_below = [&](idx_t kk) { return n - J[(size_t) kk + 1]; };
-		auto solved_on_side = [&](idx_t kk) { return kk >= 1 && rows_below(kk) >= LLT_SIDE_RMIN; }; // (decided in step kk - 1)
+		auto solved_on_side = [&](idx_t kk) { return kk >= 1 && rows_below(kk) >= side_rmin; }; // (decided in step kk - 1)
 		auto follow = [&](idx_t kk) { return x_follow && kk + 1 < ks && !solved_on_side(kk); };
 		hipEvent_t ev_x0 = nullptr;     // X0_k solved by the follower (implies D_k factored)
 		hipEvent_t ev_x0upd = nullptr;  // the rows of X0_{k+1} are up to date with panel k (bulk stream)
@@ -475,7 +478,6 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		}
 		// trailing size from which the update of the next diagonal block runs on the panel stream (it has slack to
 		// spare while the trailing matrix is large, and the bulk stream then issues fewer launches per step)
-		const idx_t dpanel_rmin = 8192;
 		// Round 4: the panel solve of step k + 1 (a dependent chain of ~15 small launches, ~0.4 ms whatever the number of rows:
 		// 6.4 of the bulk stream's 34 ms, profiles/r03_llt_timeline.txt) no longer sits between two trailing updates on the bulk
 		// stream.  Update k brings block column k + 1 up to date FIRST (its own launch), and while the rest of update k -- the
@@ -494,7 +496,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 			const bool fol_k = follow(k), fol_n = !last && follow(k + 1);
 			const bool d_on_panel = !last && dpanel_rmin > 0 && r >= dpanel_rmin && !fol_k;
 			// (the side-stream solve pays only while the rest of the update is much longer than the chain it hides)
-			const bool side_solve = !last && r - w1 >= LLT_SIDE_RMIN;
+			const bool side_solve = !last && r - w1 >= side_rmin;
 			hipEvent_t ev_upd, ev_col = nullptr;
 			{
 				StreamScope sc(c.la_bulk);
