@@ -559,6 +559,30 @@ def main():
             out["xwg_hop_us"] = round(F.xwg_hop_us(2000), 3)
         except Exception:
             out["xwg_hop_us"] = None
+        try:
+            # second probe: ONE workgroup, LDS bound -- the Cholesky leaf on a 128 x 128 block, back to back on the timed stream.
+            # Some boxes pass the hop probe (0.39 us) and still run every single-workgroup kernel 1.4 x slower (leaf 74 us
+            # against 53; LU 104 ms against 88 with the same DGEMM rate): profiles/README.md, round 5
+            g1 = torch.Generator(device=dev).manual_seed(11)
+            x1 = torch.randn((128, 128), dtype=torch.float64, device=dev, generator=g1)
+            spd = (x1 @ x1.t() + 128.0 * torch.eye(128, dtype=torch.float64, device=dev)).t().contiguous().t()
+            wk1 = spd.clone()
+            for _ in range(3):
+                wk1.copy_(spd)
+                F.llt_factor_in_place(wk1)
+            torch.cuda.synchronize()
+            tot, nrep = 0.0, 20
+            for _ in range(nrep):
+                wk1.copy_(spd)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                F.llt_factor_in_place(wk1)
+                e1.record()
+                torch.cuda.synchronize()
+                tot += e0.elapsed_time(e1)
+            out["llt128_call_us"] = round(tot / nrep * 1e3, 1)
+        except Exception:
+            out["llt128_call_us"] = None
         # ---------------------------------------------------------------- roofline of the dominant kernel
         if args.workload == "gemm":
             launch_s = dt_ev / args.steps  # one step == one launch of the MFMA GEMM kernel
