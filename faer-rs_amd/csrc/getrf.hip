@@ -34,6 +34,7 @@
 #include "mfma.h"
 #include "xwg.h"
 #include "lu_wpanel.h"
+#include "lu_small_leaf.h"
 
 namespace fh {
 
@@ -1085,6 +1086,8 @@ void lu_dump_timing()
 		"wpanel phases (s_memtime ticks per column, wg 0 / wave 0, %llu columns): sweep %.0f | barrier+result %.0f | relabel+scale+col J+1 %.0f | candidate+combine+publish %.0f | "
 		"row record wait+correct %.0f | rank-1 update %.0f || per 8 columns: rotate %.0f || header sweeps checked per column %.2f\n",
 		h[8], h[0] / n, h[7] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, 8.0 * h[5] / n, h[6] / n);
+	fprintf(stderr, "wpanel: ticks per group of 8 columns and leaf, groups 0..6: %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", 64.0 * h[9] / n, 64.0 * h[10] / n, 64.0 * h[11] / n,
+		64.0 * h[12] / n, 64.0 * h[13] / n, 64.0 * h[14] / n, 64.0 * h[15] / n);
 #endif
 }
 
@@ -1098,6 +1101,21 @@ template <typename T> static void getrf_leaf(MatV<T> P, int col0, int row_base, 
 		return;
 	}
 	FH_CHECK(w <= lw, "getrf leaf: panel too wide");
+	// a panel of at most 512 (fp64) / 1024 (fp32) rows: one workgroup holds it in registers, nothing to exchange (lu_small_leaf.h)
+	constexpr idx_t SMALL_ROWS = sizeof(T) == 8 ? 512 : 1024;
+	if (w <= LW_W && w <= m && m <= SMALL_ROWS) {
+		hipStream_t s = ctx().stream;
+		ProfScope prof(1, (double) w);
+		if (m <= 256)
+			hipLaunchKernelGGL((getrf_small_leaf_kernel<T, 4>), dim3(1), dim3(256), 0, s, P.p, P.rs, P.cs, (int) m, w, wk.piv + col0, row_base);
+		else if (m <= 512)
+			hipLaunchKernelGGL((getrf_small_leaf_kernel<T, 8>), dim3(1), dim3(512), 0, s, P.p, P.rs, P.cs, (int) m, w, wk.piv + col0, row_base);
+		else
+			hipLaunchKernelGGL((getrf_small_leaf_kernel<T, (sizeof(T) == 8 ? 8 : 16)>), dim3(1), dim3(sizeof(T) == 8 ? 512 : 1024), 0, s, P.p, P.rs, P.cs,
+					   (int) m, w, wk.piv + col0, row_base);
+		FH_HIP(hipGetLastError());
+		return;
+	}
 	if (lw == LU_W && w <= m && wk.wws) {
 		// round-4 kernel (lu_wpanel.h): one exchange per column.  64 x RPT rows per wavefront; four wavefronts per workgroup
 		// (one per SIMD) while that many workgroups are resident, else eight

@@ -594,6 +594,9 @@ template <typename T, int RPT, int NW, int RND> __global__ __launch_bounds__(NW 
 	lw_sweep_issue<RND>(C, hr, G, 0, svoff);
 	int rot = 0;
 	for (int grp = 0; grp * 8 < steps; ++grp) {
+#ifdef FH_LU_TIMING
+		const unsigned long long t_grp0 = __builtin_amdgcn_s_memtime();
+#endif
 		lw_step<T, RPT, NW, RND, 0>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
 		lw_step<T, RPT, NW, RND, 1>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
 		lw_step<T, RPT, NW, RND, 2>(a, hr, rr, x, lab, uprev, sh, grp, G, steps, nsteps, dead, svoff, A, B, C LW_TARGS);
@@ -619,6 +622,10 @@ template <typename T, int RPT, int NW, int RND> __global__ __launch_bounds__(NW 
 		uprev = __shfl(uprev, (lane + 8) & 63);
 		rot += 8;
 		LW_TICK(5);
+#ifdef FH_LU_TIMING
+		if (blockIdx.x == 0 && tid == 0 && a.phase && grp < 7)
+			atomicAdd(a.phase + 9 + grp, __builtin_amdgcn_s_memtime() - t_grp0); // per group of 8 columns: is the first pass over the code slower?
+#endif
 	}
 #undef LW_TARGS
 	if (dead) { // wave uniform: an exchange timed out, nothing is stored (getrf_dev restores A and reruns without this kernel)
