@@ -263,15 +263,28 @@ def test_plu_ties_and_zero_column(oracle):
     perm, _, _ = F.partial_piv_lu_factor_in_place(d)
     assert (perm.astype(np.int64) == rperm).all()
     assert np.allclose(to_host(d), ref)
-    z = np.zeros((600, 5), order="F")
-    z[:, 1:] = np.random.default_rng(3).standard_normal((600, 4))
-    ref = z.copy(order="F")
+    # (600 rows: the cooperative leaf; 300 and 40 rows: the single-workgroup leaf, csrc/lu_small_leaf.h)
+    for rows in (600, 300, 40):
+        z = np.zeros((rows, 5), order="F")
+        z[:, 1:] = np.random.default_rng(3).standard_normal((rows, 4))
+        ref = z.copy(order="F")
+        rperm, _, _ = oracle.lu_in_place(ref)
+        d = to_dev(z)
+        perm, _, _ = F.partial_piv_lu_factor_in_place(d)
+        got = to_host(d)
+        assert (perm.astype(np.int64) == rperm).all()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.allclose(got[~np.isnan(got)], ref[~np.isnan(ref)])
+    # ties inside a panel of several wavefronts: equal |a| in different wavefronts' rows, the smaller row index wins
+    t = np.random.default_rng(5).standard_normal((200, 6))
+    t[150, 0] = t[20, 0] = -(np.abs(t[:, 0]).max() + 1.0)
+    t[199, 2] = 9.0
+    t[70, 2] = -9.0
+    ref = np.asfortranarray(t.copy())
     rperm, _, _ = oracle.lu_in_place(ref)
-    d = to_dev(z)
+    d = to_dev(np.asfortranarray(t))
     perm, _, _ = F.partial_piv_lu_factor_in_place(d)
-    got = to_host(d)
     assert (perm.astype(np.int64) == rperm).all()
-    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.allclose(got[~np.isnan(got)], ref[~np.isnan(ref)])
+    assert np.allclose(to_host(d), ref, rtol=1e-12, atol=1e-12)
 
 
 def test_plu_full_size_property(oracle):
