@@ -554,35 +554,13 @@ def main():
         out["lu_1gpu_same_run"] = lu_1gpu
     if rank == 0:
         try:
-            # box-population probe: idle-chip hand-off between two workgroups; the latency-bound chains (LU panel, substitution
-            # leaves) scale with it -- ~0.8 us on the fast boxes of the pool, 1.3-1.9 x that on the slow ones
+            # idle-chip hand-off between two workgroups.  It separated the pool's two kinds of boxes for most of
+            # round 5 and then read 0.39-0.42 us on boxes that ran LU in 104-105 ms and 0.58 us on one that ran it in 87.8: it does
+            # NOT classify a box.  What does is in the line already: others.*.roofline.dominant_kernel.chain_kernel.us_per_column,
+            # measured in the same run (LU leaf 3.0 against 3.85 us per column, Cholesky leaf 0.475 against 0.56-0.58)
             out["xwg_hop_us"] = round(F.xwg_hop_us(2000), 3)
         except Exception:
             out["xwg_hop_us"] = None
-        try:
-            # second probe: ONE workgroup, LDS bound -- the Cholesky leaf on a 128 x 128 block, back to back on the timed stream.
-            # Some boxes pass the hop probe (0.39 us) and still run every single-workgroup kernel 1.4 x slower (leaf 74 us
-            # against 53; LU 104 ms against 88 with the same DGEMM rate): profiles/README.md, round 5
-            g1 = torch.Generator(device=dev).manual_seed(11)
-            x1 = torch.randn((128, 128), dtype=torch.float64, device=dev, generator=g1)
-            spd = (x1 @ x1.t() + 128.0 * torch.eye(128, dtype=torch.float64, device=dev)).t().contiguous().t()
-            wk1 = spd.clone()
-            for _ in range(3):
-                wk1.copy_(spd)
-                F.llt_factor_in_place(wk1)
-            torch.cuda.synchronize()
-            tot, nrep = 0.0, 20
-            for _ in range(nrep):
-                wk1.copy_(spd)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                F.llt_factor_in_place(wk1)
-                e1.record()
-                torch.cuda.synchronize()
-                tot += e0.elapsed_time(e1)
-            out["llt128_call_us"] = round(tot / nrep * 1e3, 1)
-        except Exception:
-            out["llt128_call_us"] = None
         # ---------------------------------------------------------------- roofline of the dominant kernel
         if args.workload == "gemm":
             launch_s = dt_ev / args.steps  # one step == one launch of the MFMA GEMM kernel
