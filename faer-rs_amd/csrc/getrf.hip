@@ -1385,6 +1385,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			getrf_rec<T>(P, (int) j, (int) j, wk);
 	};
 	bool staged = false; // the panel about to be applied has already been applied to the next panel's columns except for its last part
+	idx_t staged_last = 0; // ... whose width this is (half the panel, or one leaf: see the panel part below)
 	{
 		StreamScope sc(c.la_panel);
 		panel(A.sub(0, 0, m, J[1]), 0);
@@ -1413,14 +1414,16 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// SLOWER at N = 8192 .. 16384 (profiles/r04_exp_lu_stages.txt): twice the small launches beside the latency-bound panel kernel
 	idx_t QW = 256; // (half of the panel being staged; set per step)
 	hipEvent_t ev_stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-	auto stage_update = [&](idx_t jp, idx_t q, idx_t cx, idx_t wx) {
-		const idx_t r0 = jp + q * QW, r1 = r0 + QW;
-		laswp_dev<T>(A.sub(r0, cx, m - r0, wx), wk.piv + r0, (int) QW, (int) r0);
-		MatV<T> U = A.sub(r0, cx, QW, wx);
-		trsm_lower_dev<T>(A.sub(r0, r0, QW, QW).c(), true, U);
+	// (general form: the pivots / columns [r0, r0 + qw) of the panel)
+	auto stage_update_at = [&](idx_t r0, idx_t qw, idx_t cx, idx_t wx) {
+		const idx_t r1 = r0 + qw;
+		laswp_dev<T>(A.sub(r0, cx, m - r0, wx), wk.piv + r0, (int) qw, (int) r0);
+		MatV<T> U = A.sub(r0, cx, qw, wx);
+		trsm_lower_dev<T>(A.sub(r0, r0, qw, qw).c(), true, U);
 		if (m > r1)
-			gemm_dev<T>(A.sub(r1, cx, m - r1, wx), DST_FULL, true, A.sub(r1, r0, m - r1, QW).c(), U.c(), (T) -1);
+			gemm_dev<T>(A.sub(r1, cx, m - r1, wx), DST_FULL, true, A.sub(r1, r0, m - r1, qw).c(), U.c(), (T) -1);
 	};
+	auto stage_update = [&](idx_t jp, idx_t q, idx_t cx, idx_t wx) { stage_update_at(jp + q * QW, QW, cx, wx); };
 	// The panel [jp, jp + 512) on the panel stream with the top levels of getrf_rec's recursion written out (factor.rs:84-117,
 	// :127-185), columns [lo, hi) of it: as soon as a QW-column part is final, its stage starts on the bulk stream; the
 	// interchanges a later part makes on that part's columns wait for the stage, which reads them.
@@ -1508,8 +1511,25 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			if (w2 > 0 && staged) {
 				// last stage of the staged update of the next panel's columns (the earlier ones ran beside the rest of panel k,
 				// see the panel part below): interchanges of the last QW pivots, U = L_qq^-1 (.), product with K = QW
-				QW = w / 2;
-				stage_update(j0, 1, j1, w2);
+				if (staged_last == LUN_W) {
+					// the last LEAF of panel k is all that is left: its interchanges (which also gather the top block) and ONE
+					// launch of the fused node kernel on the next panel's columns, which sit right behind the leaf's -- two launches
+					// on the whole chip between two panels instead of "interchanges, substitution leaf, product" for 128 pivots
+					const idx_t r0 = j1 - LUN_W;
+					laswp_dev<T>(A.sub(r0, j1, m - r0, w2), wk.piv + r0, (int) LUN_W, (int) r0, wk.ttop);
+					const idx_t below = m - r0 - LUN_W;
+					unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
+					const unsigned ncg = (unsigned) ((w2 + LUN_W - 1) / LUN_W);
+					const unsigned cap = (unsigned) (2 * ctx().stream_cus()) / ncg;
+					if (nwg > cap)
+						nwg = cap < 1u ? 1u : cap;
+					hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg, ncg), dim3(256), 0, ctx().stream, A.p + r0 * A.rs + r0 * A.cs, A.cs, (int) (m - r0), (int) w2,
+							   (const T *) wk.ttop);
+					FH_HIP(hipGetLastError());
+				} else {
+					QW = w / 2;
+					stage_update(j0, 1, j1, w2);
+				}
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
 				compose();
@@ -1579,26 +1599,32 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			} else if (flat_panel_ok<T>(Pn, wk)) {
 				// the flat panel in two parts: as soon as the left half is final -- its leaves' interchanges applied inside the
 				// half -- the bulk stream starts stage 0; the right half's interchanges on the left half's columns wait for it
-				QW = w2 / 2;
-				const idx_t lpp = QW / LUN_W; // leaves per part
+				// (round 5, second half: the first part is everything but the LAST LEAF -- its stage runs beside that leaf, and what is
+				// left between two panels is one leaf's worth of interchanges + one fused node launch; halves before)
+				const idx_t nl = w2 / LUN_W;
+				const idx_t s0 = lu_node_offsets_ok<T>(m - j1, A.cs) ? w2 - LUN_W : w2 / 2; // width of the first part
+				const idx_t lp0 = s0 / LUN_W;						    // its leaves
+				(void) nl;
 				getrf_panel_flat<T>(
-					Pn, (int) j1, (int) j1, wk, [&](idx_t jl) { return (jl / lpp) * QW; },
+					Pn, (int) j1, (int) j1, wk, [&](idx_t jl) { return jl < lp0 ? (idx_t) 0 : s0; },
 					[&](idx_t jl) {
-						if (jl + 1 == lpp) {
+						if (jl + 1 == lp0) {
 							hipEvent_t ev_part = c.next_event();
 							FH_HIP(hipEventRecord(ev_part, c.la_panel));
 							StreamScope sb(c.la_bulk);
 							stream_wait(c.la_bulk, ev_part);
-							stage_update(j1, 0, j2, w3);
+							stage_update_at(j1, s0, j2, w3);
 							ev_stage[0] = c.next_event();
 							FH_HIP(hipEventRecord(ev_stage[0], c.la_bulk));
 						}
 					});
 				stream_wait(c.la_panel, ev_stage[0]);
-				laswp_dev<T>(A.sub(j1 + QW, j1, m - j1 - QW, QW), wk.piv + j1 + QW, (int) QW, (int) (j1 + QW));
+				laswp_dev<T>(A.sub(j1 + s0, j1, m - j1 - s0, s0), wk.piv + j1 + s0, (int) (w2 - s0), (int) (j1 + s0));
+				staged_last = w2 - s0;
 			} else {
 				QW = w2 / 2;
 				staged_panel(j1, j2, w3, 0, w2);
+				staged_last = QW;
 			}
 			staged = stage;
 			ev_panel = c.next_event();
