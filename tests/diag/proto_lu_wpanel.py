@@ -113,3 +113,71 @@ def lu_wpanel_model(a, rows_per_part):
         for i, lb in enumerate(P["lab"]):
             out[lb] = P["x"][i]
     return out, piv
+
+
+def lu_small_leaf_model(a, rows_per_wave=8):
+    """Lock-step model of the single-workgroup leaf (faer-rs_amd/csrc/lu_small_leaf.h, getrf_small_leaf_kernel): every row keeps
+    its LABEL instead of moving, the registers of a row are ROTATED left by 8 positions after every group of 8 steps (the column
+    being eliminated sits at position J mod 8), every "wavefront" (rows_per_wave rows) publishes its candidate (|a|, label) and the
+    candidate's whole row in position order, every row then reads the winner's row by position.  Steps past min(w, m) run on the
+    zero padding of the 64 positions and store nothing."""
+    a = np.array(a, dtype=a.dtype)
+    m, w = a.shape
+    W = 64
+    assert w <= W and w <= m
+    x = np.zeros((m, W), a.dtype)
+    x[:, :w] = a
+    lab = list(range(m))
+    steps = min(w, m)
+    piv = []
+    rot = 0
+    zero = a.dtype.type(0)
+    waves = [range(r0, min(m, r0 + rows_per_wave)) for r0 in range(0, m, rows_per_wave)]
+    with np.errstate(all="ignore"):
+        grp = 0
+        while grp * 8 < steps:
+            lim = W - grp * 8
+            for JJ in range(8):
+                J = grp * 8 + JJ
+                # per wavefront: candidate and its row (by position)
+                cands = []
+                for rows in waves:
+                    best, bl, bi = -1.0, None, None
+                    for i in rows:
+                        if lab[i] < J:
+                            continue
+                        v = abs(float(x[i, JJ]))
+                        cv = v if v > 0 else (0.0 if lab[i] == J else -1.0)
+                        if cv > best or (cv == best and cv >= 0 and lab[i] < bl):
+                            best, bl, bi = cv, lab[i], i
+                    cands.append((best, bl, None if bi is None else x[bi].copy()))
+                # the workgroup's winner: largest |a|, smallest label on ties
+                gbest, gl, grow = -1.0, None, None
+                for cv, lb, row in cands:
+                    if cv < 0:
+                        continue
+                    if cv > gbest or (cv == gbest and lb < gl):
+                        gbest, gl, grow = cv, lb, row
+                if gbest < 0:
+                    continue  # nobody has a candidate (padding, J >= m)
+                p = gl
+                lab = [p if lb == J else (J if lb == p else lb) for lb in lab]
+                if J < steps:
+                    piv.append(p)
+                inv = a.dtype.type(1) / grow[JJ]
+                for i in range(m):
+                    if lab[i] > J:
+                        l = x[i, JJ] * inv
+                        x[i, JJ] = l
+                        for pos in range(JJ + 1, lim):
+                            x[i, pos] = x[i, pos] - l * grow[pos]
+            x = np.concatenate([x[:, 8:], x[:, :8]], axis=1)
+            rot += 8
+            grp += 1
+    out = np.zeros((m, w), a.dtype)
+    for i in range(m):
+        for pos in range(W):
+            gc = (pos + rot) % W
+            if gc < w:
+                out[lab[i], gc] = x[i, pos]
+    return out, piv
