@@ -1321,7 +1321,9 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// then done by the (idle) bulk stream as part of its update, and what sits between two panels is half as long.
 	// (measured: profiles/r05_exp_lu_driver.txt -- N = 16384 92.4 -> 90.5 ms, N = 8192 34.0 -> 30.8 ms; a third, 128-column level
 	// and other switch-over points change nothing)
-	constexpr idx_t LU_LA_NB2 = 256, LU_LA_NB2_FROM = 10240;
+	// (second half of round 5, with the leaf-wise hand-over: switch-over at 12288 / 11264 / 10240 / 9216 / 8192 rows: 89.3 / 88.0 / 86.8-86.9 /
+	// 86.5-86.6 / 86.8 ms -- 9216, for the bulk_bound threshold below as well)
+	constexpr idx_t LU_LA_NB2 = 256, LU_LA_NB2_FROM = 9216;
 	std::vector<idx_t> J;
 	J.push_back(0);
 	while (J.back() < n) {
@@ -1376,7 +1378,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	c.qr_side_streams();
 	hipStream_t side = c.qr_side[0];
 	// remaining rows from which the bulk stream is the critical one (mode 2 below); fewer: the panel chain is
-	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= 10240; };
+	auto bulk_bound = [&](idx_t rows_below) { return rows_below >= LU_LA_NB2_FROM; };
 	// one panel on the current stream: flat right-looking (getrf_panel_flat) where its shape allows, else the recursion
 	auto panel = [&](MatV<T> P, idx_t j) {
 		if (flat_panel_ok<T>(P, wk))

@@ -17,7 +17,7 @@ for sec in "$@"; do
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 ;;
     ab:*)
       f=${sec#ab:}; O=gpurun_out/${tag}_$(basename $f .txt).log; : > $O
-      for rep in 1 2; do
+      for rep in ${AB_REPS:-1 2}; do
         while read -r envs what n; do
           [ -z "$envs" ] && continue
           case $envs in \#*) continue ;; esac
