@@ -149,12 +149,18 @@ struct ProfScope {
 		sp.b = ctx().prof_event();
 		FH_HIP(hipEventRecord(sp.a, ctx().stream));
 	}
-	~ProfScope()
+	~ProfScope() // may run while an exception unwinds: never throws, a span whose end cannot be recorded is dropped
 	{
 		if (!on)
 			return;
-		FH_HIP(hipEventRecord(sp.b, ctx().stream));
-		ctx().prof_spans.push_back(sp);
+		if (hipEventRecord(sp.b, ctx().stream) != hipSuccess) {
+			(void) hipGetLastError();
+			sp.cls = -1;
+		}
+		try {
+			ctx().prof_spans.push_back(sp);
+		} catch (...) {
+		}
 	}
 	ProfScope(const ProfScope &) = delete;
 	ProfScope &operator=(const ProfScope &) = delete;
@@ -329,7 +335,8 @@ std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2);
 int lu_leaf_width(idx_t m, int elem_bytes, int resident_workgroups);
 bool dist_two_streams_ok(idx_t panel_rows, int elem_bytes, int panel_cus, int all_cus);
 void lu_force_general(int on); // debug: every LU leaf on the non-cooperative path
-void lu_lend_copy(const void *device_copy); // the calling thread's next LU may restore A from it after an exchange timeout (getrf.hip)
+void lu_debug_plan(long nb2_from, long pipe_from, long la_min); // debug: switch-over points of the look-ahead LU driver (0 = default)
+void lu_lend_copy(const void *device_copy, idx_t nrows, idx_t ncols, int elem_bytes); // the calling thread's next LU may restore A from it after an exchange timeout (getrf.hip)
 bool rccl_is_builtin_wait(FaerHipWaitFn fn); // rccl_transport.hip: is this the built-in transport's wait (takes any stream)
 long qr_last_one_pass_columns(); // debug: columns the one-pass QR path completed in this thread's last factorization (-1: not taken)
 // tall-skinny shapes (skinny.hip): streaming kernels; false if the shape / strides do not qualify

@@ -253,10 +253,16 @@ void prof_collect(double *out)
 		out[i] = 0.0;
 	for (Ctx::ProfSpan &sp : c.prof_spans) {
 		float ms = 0;
-		if (sp.cls >= 0 && sp.cls < Ctx::PROF_CLASSES && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-			out[3 * sp.cls + 0] += ms;
-			out[3 * sp.cls + 1] += 1.0;
-			out[3 * sp.cls + 2] += sp.units;
+		if (sp.cls >= 0 && sp.cls < Ctx::PROF_CLASSES) {
+			if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+				out[3 * sp.cls + 0] += ms;
+				out[3 * sp.cls + 1] += 1.0;
+				out[3 * sp.cls + 2] += sp.units;
+			} else {
+				// spans of an unfinished profile (prof_begin drops them without synchronising): hipErrorNotReady would
+				// stay behind as the thread's last error and fail the next launch check
+				(void) hipGetLastError();
+			}
 		}
 		c.prof_pool.push_back(sp.a);
 		c.prof_pool.push_back(sp.b);

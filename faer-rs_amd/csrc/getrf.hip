@@ -29,6 +29,7 @@
 #include <atomic>
 
 #include "common.h"
+#include <optional>
 #include <functional>
 #include "lds_blocks.h"
 #include "mfma.h"
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(256) void laswp_small_kernel(T *B, idx_t rs, idx_t 
 //     hold 16 consecutive rows of a column: 128-byte accesses in the column-major panel.
 // ------------------------------------------------------------------------------------------------
 constexpr int LUN_W = 64;   // left width = rows of the triangular system
+constexpr int LU_FLAT_MAXW = 512; // widest flat panel / widest run of column groups one node launch serves: sizes LuWork::ttop
 constexpr int LUN_LP = 65;  // LDS pitch of L00 (row major: broadcast reads)
 constexpr int LUN_UP = 80;  // LDS pitch of U (k major; pitch = 16 mod 32 keeps the four k groups of an operand read on disjoint banks)
 constexpr int LUN_ROWS = 256; // rows of A11 per workgroup
@@ -844,7 +846,8 @@ template <typename T> struct LuWork {
 	xwg_u64 *gran_diag; // [LU2_NSLOT][2 * LU_W]
 	xwg_u64 epoch_base; // epochs consumed by earlier leaf launches of this factorization
 	unsigned char *wws = nullptr; // LW_WS_BYTES of getrf_wpanel_kernel's exchange records (zeroed once per factorization)
-	T *ttop = nullptr;	      // 64 x 64 scalars: interchanged top block of a 128-column node (lu_node64_kernel)
+	T *ttop = nullptr;	      // LUN_W x LU_FLAT_MAXW scalars: the interchanged top blocks (64 x 64 each, one per 64-column group right of a leaf)
+				      // that lu_node64_kernel reads -- up to LU_FLAT_MAXW / 64 - 1 groups from a flat panel or a staged last leaf
 	int *status;
 	bool general = false;		 // every leaf on the non-cooperative path (rerun after an exchange timeout, debug switch)
 };
@@ -893,10 +896,32 @@ bool dist_two_streams_ok(idx_t panel_rows, int elem_bytes, int panel_cus, int al
 // 0: the panel is taller than the cooperative kernel can keep resident -> the non-cooperative leaf (getrf_leaf_general)
 template <typename T> static int leaf_width_for(idx_t m) { return lu_leaf_width(m, (int) sizeof(T), resident_workgroups()); }
 
-static thread_local const void *t_lu_lent_copy = nullptr; // faer_hip_partial_piv_lu_lend_copy: consumed by the thread's next LU
-void lu_lend_copy(const void *p) { t_lu_lent_copy = p; }
+// faer_hip_partial_piv_lu_lend_copy: a copy of the NEXT LU's input, with the shape and element size it was made for.  The
+// thread's next getrf_dev takes it at ENTRY, before anything can throw (LentGuard), whatever its size or type, and uses it
+// only if shape and type are its own: a stale pointer never survives a call and is never read with another extent.
+struct LuLent {
+	const void *p = nullptr;
+	idx_t nrows = 0, ncols = 0;
+	int elem_bytes = 0;
+};
+static thread_local LuLent t_lu_lent;
+void lu_lend_copy(const void *p, idx_t nrows, idx_t ncols, int elem_bytes) { t_lu_lent = LuLent{p, nrows, ncols, elem_bytes}; }
+// Above this size the library does not copy A on its own (one read + one write of A per call: VERDICT r04 item 5); below
+// it the copy costs < 1 % of the factorization (512 MiB: 0.25 ms against the 30 ms of an N = 8192 fp64 LU) and a caller of
+// the reference's FFI surface, which has no way to lend anything, still gets a completed factorization after a timeout.
+static constexpr size_t LU_AUTO_BACKUP_BYTES = (size_t) 512 << 20;
 static std::atomic<int> g_lu_force_general{0}; // faer_hip_debug_lu_force_general: tests run the whole suite of shapes on the fallback
 void lu_force_general(int on) { g_lu_force_general.store(on); }
+// faer_hip_debug_lu_plan: the switch-over points of the look-ahead driver (0 = the tuned default), so that tests can drive its three
+// phases -- pipelined bulk-bound steps, plain bulk-bound steps, staged panel-bound steps -- and the transitions between them at
+// N ~ 2-6 k instead of only at the full benchmark size
+static std::atomic<long> g_lu_plan_nb2_from{0}, g_lu_plan_pipe_from{0}, g_lu_plan_la_min{0};
+void lu_debug_plan(long nb2_from, long pipe_from, long la_min)
+{
+	g_lu_plan_nb2_from.store(nb2_from);
+	g_lu_plan_pipe_from.store(pipe_from);
+	g_lu_plan_la_min.store(la_min);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Non-cooperative leaf: the same unblocked elimination (factor.rs:19-67: first largest |a| of the column, interchange,
@@ -1262,7 +1287,7 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 // ------------------------------------------------------------------------------------------------
 template <typename T> static bool flat_panel_ok(MatV<T> P, const LuWork<T> &wk)
 {
-	return P.rs == 1 && wk.ttop && P.ncols % LUN_W == 0 && P.ncols <= 512 && P.nrows >= P.ncols && lu_node_offsets_ok<T>(P.nrows, P.cs) && !wk.general &&
+	return P.rs == 1 && wk.ttop && P.ncols % LUN_W == 0 && P.ncols <= LU_FLAT_MAXW && P.nrows >= P.ncols && lu_node_offsets_ok<T>(P.nrows, P.cs) && !wk.general &&
 	       !g_lu_force_general.load() && leaf_width_for<T>(P.nrows) == LU_W;
 }
 template <typename T, typename LeftFrom, typename AfterLeaf>
@@ -1281,6 +1306,7 @@ static void getrf_panel_flat(MatV<T> P, int col0, int row_base, LuWork<T> &wk, L
 		const idx_t nr = w - c - LUN_W;
 		if (nr > 0) {
 			// ... and on the columns to its right, which then take the leaf's update: A01 <- L00^-1 A01, A11 -= A10 A01
+			FH_CHECK(nr <= LU_FLAT_MAXW - LUN_W, "lu: more column groups than LuWork::ttop holds");
 			laswp_dev<T>(P.sub(c, c + LUN_W, m - c, nr), wk.piv + col0 + c, (int) LUN_W, row_base + (int) c, wk.ttop);
 			const idx_t below = m - c - LUN_W;
 			unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
@@ -1323,7 +1349,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// and other switch-over points change nothing)
 	// (second half of round 5, with the leaf-wise hand-over: switch-over at 12288 / 11264 / 10240 / 9216 / 8192 rows: 89.3 / 88.0 / 86.8-86.9 /
 	// 86.5-86.6 / 86.8 ms -- 9216, for the bulk_bound threshold below as well)
-	constexpr idx_t LU_LA_NB2 = 256, LU_LA_NB2_FROM = 9216;
+	constexpr idx_t LU_LA_NB2 = 256;
+	const idx_t LU_LA_NB2_FROM = g_lu_plan_nb2_from.load() > 0 ? (idx_t) g_lu_plan_nb2_from.load() : 9216;
 	std::vector<idx_t> J;
 	J.push_back(0);
 	while (J.back() < n) {
@@ -1364,12 +1391,12 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 	// It pays while a product is much longer than a chain: down to 13312 rows below the panel (N = 16384: the first six steps;
 	// 89.7-90.1 -> 88.2-88.5 ms; down to 10240 rows 89.0 -- later the chains, which run 2-4 x slower among a product's workgroups,
 	// no longer fit beside half a product: profiles/r05_exp_lu_driver.txt).
-	constexpr idx_t LU_PIPE_FROM = 13312;
+	const idx_t LU_PIPE_FROM = g_lu_plan_pipe_from.load() > 0 ? (idx_t) g_lu_plan_pipe_from.load() : 13312;
 	idx_t jA = 0;
 	{
 		// the boundary: the middle of the columns right of the next panel, taken at the middle step of this phase
 		idx_t kend = 0;
-		while (kend + 1 < nsteps && m - J[(size_t) kend + 1] >= 10240)
+		while (kend + 1 < nsteps && m - J[(size_t) kend + 1] >= LU_PIPE_FROM - 3072)
 			++kend;
 		const idx_t jm = Jat(kend / 2 + 2);
 		jA = (jm + n) / 2 / LU_LA_NB * LU_LA_NB;
@@ -1518,6 +1545,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 					// launch of the fused node kernel on the next panel's columns, which sit right behind the leaf's -- two launches
 					// on the whole chip between two panels instead of "interchanges, substitution leaf, product" for 128 pivots
 					const idx_t r0 = j1 - LUN_W;
+					FH_CHECK(w2 <= LU_FLAT_MAXW, "lu: more column groups than LuWork::ttop holds");
 					laswp_dev<T>(A.sub(r0, j1, m - r0, w2), wk.piv + r0, (int) LUN_W, (int) r0, wk.ttop);
 					const idx_t below = m - r0 - LUN_W;
 					unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
@@ -1644,6 +1672,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 {
 	const idx_t m = A.nrows, n = A.ncols;
+	const LuLent lent_rec = t_lu_lent; // consumed by this call whatever happens next
+	t_lu_lent = LuLent{};
 	FH_CHECK(m < (1L << 30) && n < (1L << 30), "partial_piv_lu: matrix too large");
 	for (idx_t i = 0; i < m; ++i)
 		perm[i] = i;
@@ -1655,7 +1685,7 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		Scratch granb(gran_bytes + diag_bytes);
 		Scratch misc(256);
 		Scratch wwsb(LW_WS_BYTES);
-		Scratch ttopb((size_t) LUN_W * LU_LA_NB * sizeof(T));
+		Scratch ttopb((size_t) LUN_W * LU_FLAT_MAXW * sizeof(T));
 		LuWork<T> wk;
 		wk.wws = wwsb.as<unsigned char>();
 		wk.ttop = ttopb.as<T>();
@@ -1679,11 +1709,23 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)
 		// (getrf_leaf_general), which wait for nobody.  Rounds 3-4 made that copy themselves on every call (+N^2 scalars of
 		// memory, one read + one write of A per factorization: VERDICT r04 item 5); it is the caller's choice now.
 		const bool force_general = g_lu_force_general.load() != 0;
-		const T *lent = static_cast<const T *>(t_lu_lent_copy);
-		t_lu_lent_copy = nullptr; // (consumed by this call)
+		const T *lent = nullptr;
+		if (lent_rec.p) {
+			FH_CHECK(lent_rec.nrows == m && lent_rec.ncols == n && lent_rec.elem_bytes == (int) sizeof(T),
+				 "partial_piv_lu: the lent copy was made for another shape or scalar type");
+			lent = static_cast<const T *>(lent_rec.p);
+		}
+		// nobody lent one: the library keeps its own while that is cheap (and only where a cooperative leaf can run at all)
+		std::optional<Scratch> backup;
+		if (!lent && !force_general && (size_t) m * (size_t) n * sizeof(T) <= LU_AUTO_BACKUP_BYTES) {
+			backup.emplace((size_t) m * (size_t) n * sizeof(T));
+			copy_dev<T>(MatV<T>{backup->as<T>(), m, n, 1, m}, A.c());
+			lent = backup->as<T>();
+		}
 		// look-ahead needs every workgroup of a cooperative leaf resident on the CUs reserved for the panel stream
 		const idx_t leaf_r = leaf_rows_per_wg<T>(LU_W);
-		const bool la = !force_general && size >= 8 * LU_LA_NB && ctx().lookahead_streams() && (m + leaf_r - 1) / leaf_r <= (idx_t) ctx().la_panel_cus;
+		const idx_t la_min = g_lu_plan_la_min.load() > 0 ? (idx_t) g_lu_plan_la_min.load() : 8 * LU_LA_NB;
+		const bool la = !force_general && size >= la_min && ctx().lookahead_streams() && (m + leaf_r - 1) / leaf_r <= (idx_t) ctx().la_panel_cus;
 		if (la)
 			getrf_lookahead<T>(A.sub(0, 0, m, size), wk, ctx().stream);
 		else if (flat_panel_ok<T>(A.sub(0, 0, m, size), wk)) // (one panel of the look-ahead driver: same launches, same pivots)
@@ -1754,7 +1796,7 @@ template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev, int *status_
 	Scratch granb(gran_bytes + diag_bytes);
 	Scratch misc(256);
 	Scratch wwsb(LW_WS_BYTES);
-	Scratch ttopb((size_t) LUN_W * 512 * sizeof(T));
+	Scratch ttopb((size_t) LUN_W * LU_FLAT_MAXW * sizeof(T));
 	LuWork<T> wk;
 	wk.wws = wwsb.as<unsigned char>();
 	wk.ttop = ttopb.as<T>();

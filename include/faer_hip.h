@@ -482,6 +482,10 @@ FAER_HIP_API int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, 
 /* tests: run every leaf of the partial-pivot LU on the non-cooperative path (the fallback for panels taller than the
  * cooperative kernel can keep resident and for the rerun after an exchange timeout) */
 FAER_HIP_API void faer_hip_debug_lu_force_general(int on);
+/* tests: switch-over points of the look-ahead LU driver, in rows below the panel (0 = the tuned default): 256-column staged steps
+ * below `nb2_from`, pipelined bulk-bound steps from `pipe_from` on, look-ahead at all from `la_min_cols` columns.  Lets a test drive
+ * every phase of the driver and the transitions between them at N = 2-6 k; pivots and factors do not depend on the plan. */
+FAER_HIP_API void faer_hip_debug_lu_plan(size_t nb2_from, size_t pipe_from, size_t la_min_cols);
 /* tests: how many columns the one-pass tall-skinny QR path (csrc/tsqr.hip) completed in the calling thread's last
  * qr_factor_in_place (== ncols: the whole factorization; fewer: a panel was rejected and the classic path finished; -1: the
  * path was not applicable) */
@@ -520,11 +524,15 @@ FAER_HIP_API double faer_hip_xwg_hop_us(int iters);
  * workgroups; the library arranges their residency itself (one workgroup per compute unit of the stream's CU set, taller
  * panels on a non-cooperative kernel), so on a GPU of its own the exchange cannot stall.  If OTHER work holds compute units
  * for longer than the bounded spin (~0.2 s) the call returns PartialPivLuStatus::Unknown and leaves a partially factored
- * matrix.  A caller that wants the factorization completed even then lends a copy of the input first: `device_copy` =
- * device memory holding the nrows x ncols matrix column major with leading dimension nrows, valid until the calling
- * thread's NEXT partial_piv_lu call returns (which consumes it).  After a timeout that call restores A from the copy and
- * factors it on the non-cooperative path (identical pivots, slower).  Rounds 3-4 made this copy internally on every call. */
-FAER_HIP_API void faer_hip_partial_piv_lu_lend_copy(const void *device_copy);
+ * matrix -- for matrices above 512 MiB.  Up to that size the library keeps a copy of its own (< 1 % of the call), restores
+ * A after a timeout and finishes on the non-cooperative path, so callers of the reference's FFI surface need nothing.
+ * For larger matrices a caller that wants the factorization completed even then lends a copy of the input first:
+ * `device_copy` = device memory holding the nrows x ncols matrix (elements of `elem_bytes` = 4 or 8 bytes) column major
+ * with leading dimension nrows, valid until the calling thread's NEXT partial_piv_lu call returns.  That call consumes
+ * the loan at entry whatever its own shape; a loan made for another shape or scalar type is a precondition violation
+ * (abort), never a read with the wrong extent.  After a timeout the call restores A from the copy and factors it on the
+ * non-cooperative path (identical pivots, slower). */
+FAER_HIP_API void faer_hip_partial_piv_lu_lend_copy(const void *device_copy, size_t nrows, size_t ncols, int elem_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * 4. Multi-GPU: 1-D block-column partition, one process per GPU.

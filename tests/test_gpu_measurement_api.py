@@ -49,7 +49,7 @@ def test_lu_with_a_lent_copy_is_the_same_factorization(oracle):
     for lend in (True, False):
         d, cp = to_dev(a), to_dev(a)
         if lend:
-            F.lib().faer_hip_partial_piv_lu_lend_copy(C.c_void_p(cp.data_ptr()))
+            F.lib().faer_hip_partial_piv_lu_lend_copy(C.c_void_p(cp.data_ptr()), C.c_size_t(m), C.c_size_t(n), 8)
         perm, _, nt = F.partial_piv_lu_factor_in_place(d)
         assert (perm.astype(np.int64) == rperm).all() and nt == rnt
         assert np.abs(to_host(d) - ref).max() <= 4 * n * 2.3e-16 * np.linalg.cond(a[rperm]) * max(1.0, np.abs(ref).max())
