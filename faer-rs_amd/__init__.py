@@ -603,6 +603,24 @@ def prof_end():
             for i, name in enumerate(PROF_CLASSES)}
 
 
+def prof_end_spans(cap=8192):
+    """prof_end plus one record per profiled launch: (totals, [{"cls", "ms", "units", "d": (d0, d1, d2, d3), "stream", "t0_ms"}])"""
+    out = (C.c_double * (3 * len(PROF_CLASSES)))()
+    sp = (C.c_double * (8 * cap))()
+    L = lib()
+    L.faer_hip_prof_end_spans.restype = C.c_size_t
+    n = L.faer_hip_prof_end_spans(out, sp, C.c_size_t(cap))
+    tot = {name: {"ms": out[3 * i], "launches": int(out[3 * i + 1]), "units": out[3 * i + 2], "unit": PROF_UNITS[i]}
+           for i, name in enumerate(PROF_CLASSES)}
+    spans = []
+    for i in range(n):
+        r = sp[8 * i:8 * i + 8]
+        d3 = int(r[6])
+        spans.append({"cls": PROF_CLASSES[int(r[0])], "ms": r[1], "units": r[2], "d": (int(r[3]), int(r[4]), int(r[5]), d3 & 0xFFFF),
+                      "stream": ("caller", "bulk", "panel", "side")[d3 >> 16], "t0_ms": r[7]})
+    return tot, spans
+
+
 def xwg_hop_us(iters=2000):
     """Idle-chip hand-off latency between two workgroups on different XCDs, microseconds per hop (< 0: timed out)."""
     return float(lib().faer_hip_xwg_hop_us(C.c_int(iters)))

@@ -1414,6 +1414,7 @@ int faer_hip_debug_dist_two_streams_ok(size_t panel_rows, FaerHipDType dtype, in
 	return dist_two_streams_ok((idx_t) panel_rows, dtype == FaerHipDType_F64 ? 8 : 4, panel_cus, all_cus) ? 1 : 0;
 }
 void faer_hip_debug_lu_force_general(int on) { lu_force_general(on); }
+void faer_hip_debug_lend_cus(int on) { g_lend_cus.store(on); }
 void faer_hip_debug_lu_plan(size_t nb2_from, size_t pipe_from, size_t la_min_cols) { lu_debug_plan((long) nb2_from, (long) pipe_from, (long) la_min_cols); }
 long faer_hip_debug_qr_one_pass_columns(void) { return qr_last_one_pass_columns(); }
 void *faer_hip_debug_internal_stream(int which)
@@ -1452,6 +1453,16 @@ void faer_hip_prof_end(double *out18)
 	c.prof_on = false;
 	FH_HIP(hipDeviceSynchronize());
 	prof_collect(out18);
+}
+size_t faer_hip_prof_end_spans(double *out18, double *spans, size_t cap)
+{
+	FH_CHECK(out18 != nullptr && (spans != nullptr || cap == 0), "prof_end_spans: NULL output");
+	Ctx &c = ctx();
+	c.prof_on = false;
+	FH_HIP(hipDeviceSynchronize());
+	size_t n = 0;
+	prof_collect(out18, spans, cap, &n);
+	return n;
 }
 double faer_hip_xwg_hop_us(int iters) { return xwg_hop_us(iters); }
 void faer_hip_partial_piv_lu_lend_copy(const void *device_copy, size_t nrows, size_t ncols, int elem_bytes)

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <atomic>
 #include <vector>
 
 #include "../../include/faer_hip.h"
@@ -101,6 +102,8 @@ struct Ctx {
 		hipEvent_t a, b;
 		int cls;
 		double units;
+		long d[4] = {0, 0, 0, 0}; // class 0: m, n, k of the product, 1 + tri_skip for a Lower destination (0: Full)
+		int sid = 0;		  // 0 caller's stream, 1 bulk, 2 panel, 3 side
 	};
 	static constexpr int PROF_CLASSES = 6;
 	bool prof_on = false;
@@ -119,7 +122,7 @@ struct Ctx {
 };
 Ctx &ctx();
 void debug_stream_xcc(int which, int nblocks, unsigned *out_host); // which: 0 caller's stream, 1 bulk, 2 panel
-void prof_collect(double *out); // Ctx::PROF_CLASSES x {ms, launches, units} of the spans recorded since prof_on (ctx.hip)
+void prof_collect(double *out, double *spans = nullptr, size_t cap = 0, size_t *nspans = nullptr); // Ctx::PROF_CLASSES x {ms, launches, units} of the spans recorded since prof_on; optionally one record of 8 doubles per span (ctx.hip)
 double xwg_hop_us(int iters); // idle-chip hand-off latency between two workgroups, microseconds (ctx.hip)
 void ctx_shutdown(); // releases the calling thread's look-ahead streams / events; safe without a device
 
@@ -145,6 +148,10 @@ struct ProfScope {
 			return;
 		sp.cls = cls;
 		sp.units = units;
+		{
+			Ctx &c = ctx();
+			sp.sid = c.stream == c.la_bulk ? 1 : (c.stream == c.la_panel ? 2 : (c.qr_side[0] && c.stream == c.qr_side[0] ? 3 : 0));
+		}
 		sp.a = ctx().prof_event();
 		sp.b = ctx().prof_event();
 		FH_HIP(hipEventRecord(sp.a, ctx().stream));
@@ -312,6 +319,12 @@ template <typename T> struct GemmExtra {
 	int k_trim = 0;
 	idx_t tri_skip = 0;
 	idx_t stair_nb = 0, stair_gap = 0, stair_row0 = 0;
+	// Lending idle CUs to a big product (128 x 128 pipelined tile): `ticket` = 8 zeroed device ints; the launch's tiles are then
+	// handed out through per-XCD counters (gemm.hip, GemmArgs::ticket).  helper_wgs == 0: the main launch; > 0: a HELPER launch
+	// of that many workgroups -- the same call with the same operands on another stream -- which takes tiles only while more
+	// than helper_margin remain in an XCD's share.  The caller orders consumers of dst behind BOTH launches.
+	int *ticket = nullptr;
+	int helper_wgs = 0, helper_margin = 0;
 };
 
 // dst(kind) <- [dst +] alpha * A * diag * B        (gemm.hip)
@@ -335,6 +348,7 @@ std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2);
 int lu_leaf_width(idx_t m, int elem_bytes, int resident_workgroups);
 bool dist_two_streams_ok(idx_t panel_rows, int elem_bytes, int panel_cus, int all_cus);
 void lu_force_general(int on); // debug: every LU leaf on the non-cooperative path
+extern std::atomic<int> g_lend_cus; // faer_hip_debug_lend_cus: the look-ahead drivers lend the panel stream's idle CUs to their big products (ctx.hip; A/B, tests)
 void lu_debug_plan(long nb2_from, long pipe_from, long la_min); // debug: switch-over points of the look-ahead LU driver (0 = default)
 void lu_lend_copy(const void *device_copy, idx_t nrows, idx_t ncols, int elem_bytes); // the calling thread's next LU may restore A from it after an exchange timeout (getrf.hip)
 bool rccl_is_builtin_wait(FaerHipWaitFn fn); // rccl_transport.hip: is this the built-in transport's wait (takes any stream)

@@ -233,6 +233,8 @@ double xwg_hop_us(int iters)
 	return (double) ms * 1e3 / (2.0 * iters);
 }
 
+std::atomic<int> g_lend_cus{0}; // (measured: no gain, see potrf.hip / getrf.hip -- off by default)
+
 hipEvent_t Ctx::prof_event()
 {
 	if (!prof_pool.empty()) {
@@ -245,12 +247,15 @@ hipEvent_t Ctx::prof_event()
 	return e;
 }
 
-// out: PROF_CLASSES x {milliseconds inside the class's launches, launches, units}; the caller has synchronised
-void prof_collect(double *out)
+// out: PROF_CLASSES x {milliseconds inside the class's launches, launches, units}; the caller has synchronised.
+// spans (optional): per recorded launch {class, ms, units, d0, d1, d2, d3 + 16 * stream id, start in ms after the first recorded launch}
+void prof_collect(double *out, double *spans, size_t cap, size_t *nspans)
 {
 	Ctx &c = ctx();
 	for (int i = 0; i < Ctx::PROF_CLASSES * 3; ++i)
 		out[i] = 0.0;
+	size_t ns = 0;
+	hipEvent_t first = nullptr;
 	for (Ctx::ProfSpan &sp : c.prof_spans) {
 		float ms = 0;
 		if (sp.cls >= 0 && sp.cls < Ctx::PROF_CLASSES) {
@@ -258,6 +263,24 @@ void prof_collect(double *out)
 				out[3 * sp.cls + 0] += ms;
 				out[3 * sp.cls + 1] += 1.0;
 				out[3 * sp.cls + 2] += sp.units;
+				if (!first)
+					first = sp.a;
+				if (spans && ns < cap) {
+					float t0 = 0;
+					if (hipEventElapsedTime(&t0, first, sp.a) != hipSuccess) {
+						(void) hipGetLastError();
+						t0 = 0;
+					}
+					double *r = spans + 8 * ns++;
+					r[0] = sp.cls;
+					r[1] = ms;
+					r[2] = sp.units;
+					r[3] = (double) sp.d[0];
+					r[4] = (double) sp.d[1];
+					r[5] = (double) sp.d[2];
+					r[6] = (double) sp.d[3] + 65536.0 * sp.sid;
+					r[7] = t0;
+				}
 			} else {
 				// spans of an unfinished profile (prof_begin drops them without synchronising): hipErrorNotReady would
 				// stay behind as the thread's last error and fail the next launch check
@@ -268,6 +291,8 @@ void prof_collect(double *out)
 		c.prof_pool.push_back(sp.b);
 	}
 	c.prof_spans.clear();
+	if (nspans)
+		*nspans = ns;
 }
 
 hipEvent_t Ctx::next_event()

@@ -64,6 +64,15 @@ template <typename T> struct GemmArgs {
 	// pipelined kernel, interior tiles of a plain column-major dst (see "fast tile I/O" there): 0 = off, 1 = replace (dst = alpha acc),
 	// 2 / 3 = accumulate with alpha == +1 / -1: the accumulators START from the old dst values (-dst for 3, stored negated)
 	int fast_io;
+	// Tiles handed out through per-XCD counters instead of blockIdx (GemmExtra::ticket, pipelined kernel only): 8 zeroed device
+	// ints.  XCD x owns the contiguous share of the `ticket_total` logical tile ids that xcd_remap would give it and hands them
+	// out in order to whichever workgroup asks; a workgroup of the main launch (role 0, grid = all tiles) whose own XCD has
+	// run dry takes from the next XCD that still has tiles, and returns at once when nobody has.  A HELPER launch (role 1, any
+	// grid) is the same kernel with the same arguments on another stream -- the idle CUs of the look-ahead drivers' panel
+	// stream -- whose workgroups take a tile only while more than `ticket_margin` remain in their XCD's share (so that the
+	// helpers are done well before the main launch is) and never steal.
+	int *ticket;
+	int ticket_total, ticket_role, ticket_margin, helper_wgs;
 };
 
 // column index the lower-part test of dst uses (GemmExtra::stair_nb: a staircase instead of a diagonal)
@@ -494,9 +503,44 @@ __global__ __launch_bounds__(WM *WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kern
 
 	// ---- tile coordinates (same mapping as gemm_kernel)
 	int tm, tn;
+	int pid_t = 0;
+	if (g.ticket) {
+		__shared__ int s_pid;
+		if (tid == 0) {
+			unsigned xcc;
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+			const int T_ = g.ticket_total, q = T_ >> 3, r = T_ & 7;
+			const int x0 = (int) (xcc & 7u);
+			int got = -1;
+			if (g.ticket_role) {
+				const int cnt = q + (x0 < r ? 1 : 0), start = x0 < r ? x0 * (q + 1) : r * (q + 1) + (x0 - r) * q;
+				const int cur = __hip_atomic_load(&g.ticket[x0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (cnt - cur > g.ticket_margin) {
+					const int t = atomicAdd(&g.ticket[x0], 1);
+					if (t < cnt)
+						got = start + t;
+				}
+			} else {
+				for (int i = 0; i < 8 && got < 0; ++i) {
+					const int x = (x0 + i) & 7;
+					const int cnt = q + (x < r ? 1 : 0), start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+					if (cnt <= 0)
+						continue;
+					const int t = atomicAdd(&g.ticket[x], 1);
+					if (t < cnt)
+						got = start + t;
+				}
+			}
+			s_pid = got;
+		}
+		__syncthreads();
+		pid_t = s_pid;
+		if (pid_t < 0)
+			return;
+	}
 	{
 		const int nblocks = gridDim.x;
-		const int pid = xcd_remap(blockIdx.x, nblocks) + g.tri_off;
+		const int pid = (g.ticket ? pid_t : xcd_remap(blockIdx.x, nblocks)) + g.tri_off;
 		if (g.tri_enum && BN == 2 * BM) {
 			// lower trapezoid of BM x 2 BM tiles: tile row tm holds tn = 0 .. tm / 2, i.e. rows 2 p and 2 p + 1 hold p + 1
 			// tiles each and p (p + 1) tiles precede row 2 p
@@ -1152,16 +1196,19 @@ template <typename T, int BM, int BN, int WM, int WN> static void launch_cfg_p(c
 	constexpr int PF = (BM * BN >= 128 * 128) ? 1 : 4; // register prefetch depth (tiles)
 	constexpr int NT = WM * WN * 64;
 	int nblocks = g.tri_enum ? tri_tiles(g.ntm, BN == 2 * BM) - g.tri_off : g.ntm * g.ntn;
+	if (g.ticket && g.ticket_role) // helper launch: as many workgroups as asked for (at most one per tile)
+		nblocks = g.helper_wgs < nblocks ? g.helper_wgs : nblocks;
 	dim3 grid((unsigned) nblocks, 1, (unsigned) splits), block(NT);
 	hipStream_t s = ctx().stream;
+	const unsigned dyn = 0u;
 	if (akm && bkm)
-		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, true, PF>), grid, block, 0, s, g);
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, true, PF>), grid, block, dyn, s, g);
 	else if (akm && !bkm)
-		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, false, PF>), grid, block, 0, s, g);
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, true, false, PF>), grid, block, dyn, s, g);
 	else if (!akm && bkm)
-		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, true, PF>), grid, block, 0, s, g);
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, true, PF>), grid, block, dyn, s, g);
 	else
-		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, false, PF>), grid, block, 0, s, g);
+		hipLaunchKernelGGL((gemm_kernel_p<T, BM, BN, BK, WM, WN, false, false, PF>), grid, block, dyn, s, g);
 	FH_HIP(hipGetLastError());
 }
 
@@ -1410,9 +1457,23 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 				g.fast_io = 3;
 		}
 	}
+	g.ticket = nullptr;
+	g.ticket_total = g.ticket_role = g.ticket_margin = g.helper_wgs = 0;
+	if (ex.ticket) {
+		FH_CHECK(!extra_path && !legacy && shape == 0 && splits == 1 && !ex.inplace, "gemm: ticketed launches are for the 128 x 128 pipelined tile");
+		g.ticket = ex.ticket;
+		g.ticket_role = ex.helper_wgs > 0 ? 1 : 0;
+		g.ticket_margin = ex.helper_margin;
+		g.ticket_total = (int) tiles;
+		g.helper_wgs = ex.helper_wgs; // (a helper launch's grid: launch_cfg_p)
+	}
 	// (profile class 0: the big pipelined tiles -- the trailing updates of the factorizations, the headline product)
 	const double out_elems = g.tri_enum ? 0.5 * (double) m * (double) (m + 1) - 0.5 * (double) ex.tri_skip * (double) (ex.tri_skip + 1) : (double) m * (double) n;
 	ProfScope prof(!extra_path && !legacy && (shape == 0 || shape == 5) ? 0 : -1, 2.0 * (double) k * out_elems);
+	prof.sp.d[0] = (long) m;
+	prof.sp.d[1] = (long) n;
+	prof.sp.d[2] = (long) k;
+	prof.sp.d[3] = g.tri_enum ? 1 + (long) ex.tri_skip : 0;
 	if (extra_path)
 		launch_cfg<T, 64, 64, 2, 2, true>(g, akm, bkm, splits); // triangular operands / diag scaling
 	else if (shape == 5)

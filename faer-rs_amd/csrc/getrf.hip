@@ -1382,6 +1382,51 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		full.src = full.dst + 2 * LU_LA_NB;
 	};
 	use_list(0);
+	// Lending the panel stream's idle CUs to the big product of a step.  While the bulk stream is the critical
+	// one the panel stream finishes panel k + 1 before the bulk stream has finished product k and then idles.  The product's tiles
+	// are handed out through per-XCD counters (GemmExtra::ticket); a HELPER launch of the same product, queued on the panel stream
+	// right behind panel k + 1, takes tiles on the reserved CUs while more than a margin remain, and the consumers of the product
+	// wait for both launches.  Same arithmetic per tile whoever computes it: results do not depend on the split.
+	// MEASURED, OFF BY DEFAULT (faer_hip_debug_lend_cus(1) turns it on; profiles/r06_exp_lend.txt): the helpers take 8-25 % of a
+	// product's tiles in the pipelined steps, the product ends earlier -- and N = 16384 takes 87.2-87.4 ms instead of 86.9-87.0: the
+	// reserved CUs are where the side stream's interchange / solve chains run undisturbed while the panel stream idles, and with
+	// helpers on them those chains (which the next product waits for) queue behind 130 us tiles on every CU of the chip.
+	constexpr int LU_TICKETS = 64;
+	Scratch tickb((size_t) LU_TICKETS * 8 * sizeof(int));
+	FH_HIP(hipMemsetAsync(tickb.p, 0, (size_t) LU_TICKETS * 8 * sizeof(int), caller)); // (before e0: older than everything below)
+	int tick_used = 0;
+	struct HelpJob {
+		bool on = false;
+		MatV<T> C;
+		MatV<const T> A, B;
+		int *ticket = nullptr;
+		int wgs = 0;
+		hipEvent_t ev_in = nullptr;
+		idx_t c0 = 0; // first column of the helped product
+	} help;
+	hipEvent_t ev_help_prev = nullptr; // the previous step's helper launch (panel stream)
+	idx_t help_prev_c0 = 0;
+	const bool lend = (g_lend_cus.load() & 1) != 0;
+	// the big product of a step on the bulk stream; `helped`: a helper launch will follow on the panel stream
+	auto big_product = [&](MatV<T> Cd, MatV<const T> Ad, MatV<const T> Bd, bool helped, idx_t c0) {
+		const idx_t tiles = ((Cd.nrows + 127) / 128) * ((Cd.ncols + 127) / 128);
+		if (!helped || !lend || tiles < 2048 || tick_used >= LU_TICKETS) {
+			gemm_dev<T>(Cd, DST_FULL, true, Ad, Bd, (T) -1);
+			return;
+		}
+		GemmExtra<T> ex;
+		ex.ticket = tickb.as<int>() + 8 * (tick_used++);
+		help.on = true;
+		help.C = Cd;
+		help.A = Ad;
+		help.B = Bd;
+		help.ticket = ex.ticket;
+		help.wgs = (int) (tiles / 8 + 64);
+		help.c0 = c0;
+		help.ev_in = c.next_event();
+		FH_HIP(hipEventRecord(help.ev_in, c.la_bulk)); // (the product's inputs are final: everything older on the bulk stream)
+		gemm_dev<T>(Cd, DST_FULL, true, Ad, Bd, (T) -1, &ex);
+	};
 	// Pipelined steps (while the bulk stream is the critical one).  Between two trailing products the bulk stream used to run
 	// the chain "interchanges, solve, product" for the next panel's columns (~0.3 ms busy) and then wait for the side stream's
 	// chain on the far columns (~0.25 ms idle): ~0.55 ms per step in which most of the chip does nothing.  The columns right of
@@ -1490,6 +1535,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 		{
 			StreamScope sc(c.la_bulk);
 			stream_wait(c.la_bulk, ev_panel);
+			if (ev_help_prev)
+				stream_wait(c.la_bulk, ev_help_prev); // (the helper's tiles of the previous product: done well before that product's last tile)
 			// Every solve U = L_kk^-1 A is a dependent chain of ~8 launches whose length does not depend on the number of columns
 			// (profiles/r04_lu_v4_timeline.txt: ~240 us per chain, three chains per step -- the first 64 columns of the next panel,
 			// its other 448, the rest -- were 20 of the bulk stream's 87 ms).  How the columns right of the panel are grouped:
@@ -1513,6 +1560,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 					compose();
 					if (ev_GA_prev)
 						stream_wait(side, ev_GA_prev);
+					if (ev_help_prev && help_prev_c0 < jA)
+						stream_wait(side, ev_help_prev);
 					// near group + the next panel's columns: one chain, then the product on the next panel's columns
 					swaps(k, j0, w, j1, jA - j1);
 					MatV<T> U = A.sub(j0, j1, w, jA - j1);
@@ -1523,6 +1572,8 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 					FH_HIP(hipEventRecord(ev_next, side));
 					if (ev_GB_prev)
 						stream_wait(side, ev_GB_prev);
+					if (ev_help_prev)
+						stream_wait(side, ev_help_prev);
 					swaps(k, j0, w, jA, n - jA);
 					trsm_lower_dev<T>(A.sub(j0, j0, w, w).c(), true, A.sub(j0, jA, w, n - jA));
 					FH_HIP(hipEventRecord(ev_cB, side));
@@ -1533,7 +1584,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 				ev_GA_prev = c.next_event();
 				FH_HIP(hipEventRecord(ev_GA_prev, c.la_bulk));
 				stream_wait(c.la_bulk, ev_cB);
-				gemm_dev<T>(A.sub(j1, jA, m - j1, n - jA), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), A.sub(j0, jA, w, n - jA).c(), (T) -1);
+				big_product(A.sub(j1, jA, m - j1, n - jA), A.sub(j1, j0, m - j1, w).c(), A.sub(j0, jA, w, n - jA).c(), true, jA);
 				ev_GB_prev = c.next_event();
 				FH_HIP(hipEventRecord(ev_GB_prev, c.la_bulk));
 			} else
@@ -1582,7 +1633,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
 				stream_wait(c.la_bulk, ev_side);
-				gemm_dev<T>(A.sub(j1, j2, m - j1, n - j2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), A.sub(j0, j2, w, n - j2).c(), (T) -1);
+				big_product(A.sub(j1, j2, m - j1, n - j2), A.sub(j1, j0, m - j1, w).c(), A.sub(j0, j2, w, n - j2).c(), true, j2);
 			} else if (w2 > 0 && mode == 2) {
 				swaps(k, j0, w, j1, n - j1);
 				MatV<T> U = A.sub(j0, j1, w, n - j1);
@@ -1592,7 +1643,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 				ev_next = c.next_event();
 				FH_HIP(hipEventRecord(ev_next, c.la_bulk));
 				if (j2 < n && m > j1)
-					gemm_dev<T>(A.sub(j1, j2, m - j1, n - j2), DST_FULL, true, A.sub(j1, j0, m - j1, w).c(), U.sub(0, w2, w, n - j2).c(), (T) -1);
+					big_product(A.sub(j1, j2, m - j1, n - j2), A.sub(j1, j0, m - j1, w).c(), U.sub(0, w2, w, n - j2).c(), true, j2);
 			} else if (w2 > 0) {
 				update(k, j0, w, j1, w2);
 				ev_next = c.next_event();
@@ -1659,14 +1710,31 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 			staged = stage;
 			ev_panel = c.next_event();
 			FH_HIP(hipEventRecord(ev_panel, c.la_panel));
+			ev_help_prev = nullptr;
+			if (help.on) { // the panel stream's CUs join the step's big product until its tiles run low
+				stream_wait(c.la_panel, help.ev_in);
+				GemmExtra<T> ex;
+				ex.ticket = help.ticket;
+				ex.helper_wgs = help.wgs;
+				ex.helper_margin = 2 * (ctx().ncu > 0 ? ctx().ncu - ctx().la_panel_cus : 224) / 8 * 2;
+				gemm_dev<T>(help.C, DST_FULL, true, help.A, help.B, (T) -1, &ex);
+				ev_help_prev = c.next_event();
+				FH_HIP(hipEventRecord(ev_help_prev, c.la_panel));
+				help_prev_c0 = help.c0;
+				help.on = false;
+			}
 		} else {
 			staged = false;
+			ev_help_prev = nullptr;
 		}
+		FH_CHECK(!help.on, "lu: a helped product without a helper launch");
 	}
 	hipEvent_t eb = c.next_event();
 	FH_HIP(hipEventRecord(eb, c.la_bulk));
 	stream_wait(caller, eb);
-	stream_wait(caller, ev_panel);
+	hipEvent_t ep = c.next_event(); // (everything on the panel stream, a last helper launch included)
+	FH_HIP(hipEventRecord(ep, c.la_panel));
+	stream_wait(caller, ep);
 }
 
 template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv)

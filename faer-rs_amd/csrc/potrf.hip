@@ -438,6 +438,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		auto rows_below = [&](idx_t kk) { return n - J[(size_t) kk + 1]; };
 		auto solved_on_side = [&](idx_t kk) { return kk >= 1 && rows_below(kk) >= side_rmin; }; // (decided in step kk - 1)
 		auto follow = [&](idx_t kk) { return x_follow && kk + 1 < ks && !solved_on_side(kk); };
+		const bool lend = (g_lend_cus.load() & 1) != 0;
 		hipEvent_t ev_x0 = nullptr;     // X0_k solved by the follower (implies D_k factored)
 		hipEvent_t ev_x0upd = nullptr;  // the rows of X0_{k+1} are up to date with panel k (bulk stream)
 		// D_kk on the current (panel) stream, with the follower for X0_kk if that panel is solved that way
@@ -486,6 +487,46 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 		// Its small kernels find their slots among the product's workgroups (the two launches are independent); towards the
 		// end, where the rest of the update is shorter than the chain, the chain is exposed as before.
 		hipEvent_t ev_solved = nullptr; // P_k solved (recorded on the stream that did it)
+		// Lending the panel stream's idle CUs to the big product of a step (as in getrf.hip, getrf_lookahead): the diagonal chain of
+		// step k + 1 takes ~1 ms, the trailing product beside it up to 4 ms.  The product's tiles are handed out through per-XCD
+		// counters; a helper launch of the same product queued on the panel stream behind the diagonal chain takes tiles on the
+		// reserved CUs while more than a margin remain; the next step's bulk work waits for both.
+		// MEASURED, OFF BY DEFAULT (faer_hip_debug_lend_cus; profiles/r06_exp_lend.txt): the helped products end 0.3-0.45 ms earlier
+		// per step, and the factorization takes as long as before -- the reserved CUs were not idle in effect: the side stream's
+		// solve chain ran on them, and among the product's workgroups its kernels take 110 instead of 69 us; the chain "block column
+		// up to date -> D_{k+1} -> solve of P_{k+1}" is as long as the product it hides behind (3.5-3.7 ms in the early steps).
+		constexpr int LLT_TICKETS = 32;
+		Scratch tickb((size_t) LLT_TICKETS * 8 * sizeof(int));
+		{
+			StreamScope sb(c.la_bulk);
+			FH_HIP(hipMemsetAsync(tickb.p, 0, (size_t) LLT_TICKETS * 8 * sizeof(int), c.la_bulk));
+		}
+		int tick_used = 0;
+		struct HelpJob {
+			bool on = false;
+			MatV<T> C;
+			MatV<const T> X;
+			GemmExtra<T> ex;
+			hipEvent_t ev_in = nullptr;
+		} help;
+		hipEvent_t ev_help_prev = nullptr;
+		// Cd(lower) -= Xd Xd^T on the bulk stream (tri_skip in exb); helped when a diagonal chain follows on the panel stream
+		auto big_lower = [&](MatV<T> Cd, MatV<const T> Xd, GemmExtra<T> exb, bool helped) {
+			const idx_t tr = (Cd.nrows + 127) / 128, sk = exb.tri_skip / 128;
+			const idx_t tiles = tr * (tr + 1) / 2 - sk * (sk + 1) / 2;
+			if (helped && lend && tiles >= 2048 && tick_used < LLT_TICKETS) {
+				exb.ticket = tickb.as<int>() + 8 * (tick_used++);
+				help.on = true;
+				help.C = Cd;
+				help.X = Xd;
+				help.ex = exb;
+				help.ex.helper_wgs = (int) (tiles / 8 + 64);
+				help.ex.helper_margin = 2 * (c.ncu > 0 ? c.ncu - c.la_panel_cus : 224) / 8 * 2;
+				help.ev_in = c.next_event();
+				FH_HIP(hipEventRecord(help.ev_in, c.la_bulk));
+			}
+			gemm_dev<T>(Cd, DST_LOWER, true, Xd, Xd.t(), (T) -1, &exb);
+		};
 		for (idx_t k = 0; k < ks; ++k) {
 			const idx_t j0 = J[(size_t) k], j1 = J[(size_t) k + 1], w = j1 - j0; // panel columns [j0, j1)
 			const idx_t r = n - j1;						       // rows below
@@ -500,6 +541,10 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 			hipEvent_t ev_upd, ev_col = nullptr;
 			{
 				StreamScope sc(c.la_bulk);
+				if (ev_help_prev) {
+					stream_wait(c.la_bulk, ev_help_prev); // (the helper's tiles of the previous big product)
+					ev_help_prev = nullptr;
+				}
 				if (ev_solved) {
 					stream_wait(c.la_bulk, ev_solved);
 				} else if (fol_k) {
@@ -546,7 +591,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 					// block column k+1 below its diagonal block + the remaining lower square in ONE launch: the lower
 					// triangle of the whole trailing matrix minus its leading rows
 					if (ex.tri_skip < r)
-						gemm_dev<T>(A.sub(j1, j1, r, r), DST_LOWER, true, X, X.t(), (T) -1, &ex);
+						big_lower(A.sub(j1, j1, r, r), X, ex, true);
 				} else {
 					ev_x0upd = nullptr;
 					if (!d_on_panel && !fol_k) // next diagonal block first (a follower step has done it above)
@@ -557,7 +602,7 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 					FH_HIP(hipEventRecord(ev_col, c.la_bulk));
 					// the remaining lower square
 					MatV<const T> X2 = Pk.sub(w1, 0, r - w1, w).c();
-					gemm_dev<T>(A.sub(j1 + w1, j1 + w1, r - w1, r - w1), DST_LOWER, true, X2, X2.t(), (T) -1);
+					big_lower(A.sub(j1 + w1, j1 + w1, r - w1, r - w1), X2, GemmExtra<T>(), true);
 				}
 			}
 			ev_solved = nullptr;
@@ -570,6 +615,13 @@ static void potrf_lookahead(MatV<T> A, int regularize, T eps, T delta, int *stat
 					// (the follower of D_{k+1} must not start before X0_{k+1}'s rows are up to date with panel k: in the steps that
 					// solve on the side stream the whole block column is updated before ev_col, in the late steps ev_x0upd says so)
 					factor_diag(k + 1, fol_n ? (ev_x0upd ? ev_x0upd : ev_col) : nullptr);
+					if (help.on) { // the panel stream's CUs join the step's big product until its tiles run low
+						stream_wait(c.la_panel, help.ev_in);
+						gemm_dev<T>(help.C, DST_LOWER, true, help.X, help.X.t(), (T) -1, &help.ex);
+						ev_help_prev = c.next_event();
+						FH_HIP(hipEventRecord(ev_help_prev, c.la_panel));
+						help.on = false;
+					}
 				}
 				if (side_solve) {
 					StreamScope sc(side);

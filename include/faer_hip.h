@@ -482,6 +482,10 @@ FAER_HIP_API int faer_hip_debug_lu_leaf_width(size_t nrows, FaerHipDType dtype, 
 /* tests: run every leaf of the partial-pivot LU on the non-cooperative path (the fallback for panels taller than the
  * cooperative kernel can keep resident and for the rerun after an exchange timeout) */
 FAER_HIP_API void faer_hip_debug_lu_force_general(int on);
+/* tests / A-B measurements: 1 = the look-ahead LU and Cholesky drivers lend the panel stream's idle compute units to their big
+ * trailing products (helper launches that pull tiles from per-XCD counters).  Default 0: measured without gain on MI355X
+ * (profiles/r06_exp_lend.txt); the factors do not depend on it. */
+FAER_HIP_API void faer_hip_debug_lend_cus(int on);
 /* tests: switch-over points of the look-ahead LU driver, in rows below the panel (0 = the tuned default): 256-column staged steps
  * below `nb2_from`, pipelined bulk-bound steps from `pipe_from` on, look-ahead at all from `la_min_cols` columns.  Lets a test drive
  * every phase of the driver and the transitions between them at N = 2-6 k; pivots and factors do not depend on the plan. */
@@ -515,6 +519,11 @@ FAER_HIP_API double faer_hip_mfma_peak_tflops(FaerHipDType dtype, int iters);
 #define FAER_HIP_PROF_CLASSES 6
 FAER_HIP_API void faer_hip_prof_begin(void);
 FAER_HIP_API void faer_hip_prof_end(double *out_3_x_classes);
+/* The same, plus one record of 8 doubles per profiled launch (at most `cap` records; returns how many): {class, ms, units,
+ * d0, d1, d2, d3 + 65536 * stream, start in ms after the first recorded launch}.  Class 0 (the MFMA products): d = m, n, k of the
+ * product and 0 for a Full, 1 + tri_skip for a Lower destination; stream 0 = the caller's, 1 = bulk, 2 = panel, 3 = side.
+ * tools/gpu_update_in_situ.py replays every product of a factorization alone on the same stream from these records. */
+FAER_HIP_API size_t faer_hip_prof_end_spans(double *out_3_x_classes, double *spans_8_per_launch, size_t cap);
 /* Idle-chip hand-off latency between two resident workgroups on different XCDs, microseconds per one-way hop (tagged
  * 8-byte granule, write-through store -> polling load).  The latency-bound kernels of the LU / Cholesky chains scale
  * with it: bench.py prints it so that a line from a slow box of a pool is recognisable.  < 0: the probe timed out. */

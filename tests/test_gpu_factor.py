@@ -1,5 +1,7 @@
 """GPU parity: TRSM, LLT, partial-pivot LU through the C-ABI vs the CPU oracle, with the reference's own
 test sizes and tolerances and full-size property tests."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -345,6 +347,44 @@ def test_plu_lookahead_path(m, n):
     perm2, _, _ = F.partial_piv_lu_factor_in_place(lu2)
     F.synchronize()
     assert np.array_equal(perm, perm2) and torch.equal(lu, lu2)
+
+
+@pytest.mark.parametrize("plan", [(2048, 3584, 2048), (1024, 100000, 2048), (100000, 100000, 2048), (512, 1536, 2048)])
+def test_plu_lookahead_phases_and_transitions_at_small_n(oracle, plan):
+    """the look-ahead LU driver has three phases -- pipelined bulk-bound steps, plain bulk-bound steps, staged 256-column steps -- whose
+    switch-over points sit at 9-13 k rows; `faer_hip_debug_lu_plan` moves them so that N = 5120 / 3072 runs every phase and every
+    transition.  Pivots and factors must not depend on the plan: identical permutation to the default plan's and to the
+    oracle's on the first panel, P A == L U, the bitwise same answer twice."""
+    import torch
+
+    F = init_gpu()
+    nb2_from, pipe_from, la_min = plan
+    for n in (5120, 3072):
+        g = torch.Generator(device="cuda").manual_seed(n + 11)
+        a = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g).t()
+        base = a.clone()
+        perm0, _, _ = F.partial_piv_lu_factor_in_place(base)  # the tuned plan (n = 3072: the flat / recursive driver)
+        F.synchronize()
+        F.lib().faer_hip_debug_lu_plan(C.c_size_t(nb2_from), C.c_size_t(pipe_from), C.c_size_t(la_min))
+        try:
+            lu = a.clone()
+            perm, _, _ = F.partial_piv_lu_factor_in_place(lu)
+            lu2 = a.clone()
+            perm2, _, _ = F.partial_piv_lu_factor_in_place(lu2)
+            F.synchronize()
+        finally:
+            F.lib().faer_hip_debug_lu_plan(C.c_size_t(0), C.c_size_t(0), C.c_size_t(0))
+        assert np.array_equal(perm, perm0) and np.array_equal(perm, perm2) and torch.equal(lu, lu2)
+        p = torch.as_tensor(perm.astype(np.int64), device="cuda")
+        L = torch.tril(lu, -1) + torch.eye(n, dtype=torch.float64, device="cuda")
+        U = torch.triu(lu)
+        assert (L @ U - a[p]).abs().max().item() <= 16 * n * 2.3e-16 * (L.abs() @ U.abs()).max().item()
+        scale = max(1.0, lu.abs().max().item())
+        assert (lu - base).abs().max().item() <= 4 * n * 2.3e-16 * 1e4 * scale  # same pivots: forward-error level agreement
+        k = 256
+        ref = np.asfortranarray(a[:, :k].cpu().numpy())
+        rperm, _, _ = oracle.lu_in_place(ref)
+        assert (perm.astype(np.int64)[:k] == rperm[:k]).all()
 
 
 def test_lookahead_paths_fp32():

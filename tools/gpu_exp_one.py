@@ -16,7 +16,9 @@ L = F.lib()
 torch.cuda.set_device(0)
 F.use_torch_stream()
 what = sys.argv[1] if len(sys.argv) > 1 else "lu"
-tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("FAER_HIP_"))
+if os.environ.get("EXP_LEND") is not None:  # A/B: lending the panel stream's idle CUs to the big products (round 6)
+    L.faer_hip_debug_lend_cus(int(os.environ["EXP_LEND"]))
+tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("FAER_HIP_") or k.startswith("EXP_"))
 
 
 def timeit(fn, reset, reps=4):
