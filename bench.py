@@ -500,15 +500,30 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as ex:  # (symmetric failures only: every rank runs the same sizes)
                 multi_others[name] = {"error": str(ex)[:200]}
+        dist.barrier()
+    # ---- the N = 1 point of a strong-scaling curve, measured in the SAME run: rank 0 times the single-GPU driver on the same
+    # workload (lu / llt) and size while the others wait; `speedup_vs_1gpu_same_run` at top level
+    if dist is not None and args.workload in ("lu", "llt"):
         if rank == 0:
             try:
+                torch.cuda.empty_cache()
                 n1 = args.n or 16384
-                a1 = colmajor(n1, n1, torch.float64, 4)
+                if args.workload == "lu":
+                    a1 = colmajor(n1, n1, torch.float64, 4)
+                    fl1 = 2.0 * n1 ** 3 / 3.0
+                else:
+                    g1 = colmajor(n1, n1, torch.float64, 3)
+                    a1 = (g1 @ g1.t() + n1 * torch.eye(n1, dtype=torch.float64, device=dev)).t()
+                    del g1
+                    fl1 = n1 ** 3 / 3.0
                 w1 = a1.clone()
 
                 def one():
                     w1.copy_(a1)
-                    F.partial_piv_lu_factor_in_place(w1)
+                    if args.workload == "lu":
+                        F.partial_piv_lu_factor_in_place(w1)
+                    else:
+                        F.llt_factor_in_place(w1)
 
                 def timed_local(fn, reps):
                     fn()
@@ -520,7 +535,7 @@ def main():
                     return (time.perf_counter() - t0) / reps
 
                 t1 = max(timed_local(one, 5) - timed_local(lambda: w1.copy_(a1), 5), 1e-9)
-                lu_1gpu = {"workload": f"lu_f64_n{n1}", "ms": round(t1 * 1e3, 3), "GFLOP/s": round(2.0 * n1 ** 3 / 3.0 / t1 / 1e9, 1),
+                lu_1gpu = {"workload": f"{args.workload}_f64_n{n1}", "ms": round(t1 * 1e3, 3), "GFLOP/s": round(fl1 / t1 / 1e9, 1),
                            "speedup_of_this_run": round(t1 * 1e3 / ms_per_step, 3)}
                 del a1, w1
             except Exception as ex:
@@ -551,7 +566,9 @@ def main():
     if multi_others is not None:
         out["others"] = multi_others
     if lu_1gpu is not None:
-        out["lu_1gpu_same_run"] = lu_1gpu
+        out[f"{args.workload}_1gpu_same_run"] = lu_1gpu
+        if "speedup_of_this_run" in lu_1gpu:
+            out["speedup_vs_1gpu_same_run"] = lu_1gpu["speedup_of_this_run"]
     if rank == 0:
         try:
             # idle-chip hand-off between two workgroups.  It separated the pool's two kinds of boxes for most of

@@ -391,6 +391,9 @@ template <typename T> long getrf_dev(MatV<T> A, idx_t *perm, idx_t *perm_inv);
 // the application of such a transposition list to the rows of another block
 template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev, int *status_dev = nullptr);
 template <typename T> void laswp_rows_dev(MatV<T> B, const int *piv_dev, int nt);
+int laswp_list_max(); // most interchanges one composed list holds
+void laswp_compose_rows_dev(const int *piv_dev, int nt, int *list_4nt); // net permutation of (j <-> piv[j]), j < nt, composed once ...
+template <typename T> void laswp_list_rows_dev(MatV<T> B, const int *list_4nt, int nt); // ... and applied to any number of column ranges
 
 // Householder QR without pivoting (qr.hip); H is block_size x min(m,n) (device). returns rank
 template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold);

@@ -3,6 +3,7 @@
 // this file is its device backend: every operation is one of the library's own HIP drivers on the calling
 // thread's stream, the broadcast is handed a DEVICE buffer.
 #include "common.h"
+#include <memory>
 #include "dist_llt.h"
 #include "dist_lu.h"
 using namespace fh;
@@ -71,7 +72,34 @@ template <typename S> struct DeviceBackend {
 		getrf_panel_dev<T>(mv(P), piv_out, lu_status);
 		t_panel.end();
 	}
-	void laswp(View B, const int *piv, int nt) { laswp_rows_dev<T>(mv(B), piv, nt); }
+	// The orchestration applies the pivots of panel k to up to three column ranges per step (left of the panel, the look-ahead
+	// block column, everything right of it).  The net permutation is composed ONCE per (step, pivot buffer) and the launches
+	// gather / scatter through it, as in the single-GPU driver: laswp_small_kernel rebuilt it in every workgroup, 199 us per
+	// launch, 18 of a rank's 110 ms at N = 16384 (profiles/r06_exp_dist.txt).  All interchanges of a step are issued on one
+	// stream, in order; two list buffers alternate so that a step never rewrites the list of the step before.
+	long step_id = 0;
+	const int *list_piv = nullptr;
+	long list_step = -1;
+	int list_nt = 0;
+	std::unique_ptr<Scratch> lists;
+	void laswp(View B, const int *piv, int nt)
+	{
+		if (nt > laswp_list_max() || nt < 64) {
+			laswp_rows_dev<T>(mv(B), piv, nt);
+			return;
+		}
+		const size_t cap = (size_t) 4 * laswp_list_max();
+		if (!lists)
+			lists.reset(new Scratch(2 * cap * sizeof(int)));
+		int *list = lists->as<int>() + (size_t) (step_id & 1) * cap;
+		if (list_piv != piv || list_step != step_id || list_nt != nt) {
+			laswp_compose_rows_dev(piv, nt, list);
+			list_piv = piv;
+			list_step = step_id;
+			list_nt = nt;
+		}
+		laswp_list_rows_dev<T>(mv(B), list, nt);
+	}
 	void trsm_unit_lower(View L, View X) { trsm_lower_dev<T>(mv(L).c(), true, mv(X)); }
 	void gemm_sub(View C, View A, View B) { gemm_dev<T>(mv(C), DST_FULL, true, mv(A).c(), mv(B).c(), (T) -1); }
 	void pack(View src, T *dst) { copy_dev<T>(MatV<T>{dst, src.nrows, src.ncols, 1, src.nrows}, mv(src).c()); }
@@ -115,7 +143,7 @@ template <typename S> struct DeviceBackend {
 	// (update of block column k+1 + its panel factorization, cooperative leaves on the reserved CUs) on the panel stream
 	bool two = false;     // the two internal streams are available
 	bool two_now = false; // ... and used in the current step
-	long two_min_work = 100000000; // trailing entries (rows x local columns right of the panel) from which a step uses both streams
+	long two_min_work = 0; // trailing entries (rows x local columns right of the panel) from which a step uses both streams (round 6: always)
 	hipStream_t caller = nullptr;
 	hipEvent_t ev0 = nullptr, ev_bulk = nullptr, ev_ahead = nullptr;
 	void streams_init()
@@ -127,14 +155,14 @@ template <typename S> struct DeviceBackend {
 		if (two)
 			ctx().reset_events();
 	}
-	// The panel stream owns 32 CUs: a panel factored there takes ~0.75 ms longer per 8192 rows than on the whole chip
-	// (its products, solves and interchanges run on 1/8 of the CUs), which only pays when the rest of the update it
-	// overlaps with is longer than that.  Measured on one rank (profiles/r02_dist_overlap.txt): N = 8192 (at most 6.3e7
-	// trailing entries per step) runs 57.2 ms on one stream, 59.7 ms with the two streams in every step; the single-GPU
-	// driver's N = 16384 (2.5e8 entries in the first step) needs them (121 vs 193 ms).  Steps with fewer than 1e8 trailing
-	// entries on this rank run on the caller's stream (FAER_HIP_DIST_TWO_MIN overrides; the count only shrinks).
+	// Rounds 2-5 used both streams only in steps with >= 1e8 trailing entries on the rank: the look-ahead part then
+	// INCLUDED the update of block column k + 1, on the panel stream's 32 CUs (~1 ms per step), and that only paid beside a
+	// long rest.  Round 6 runs that update on the bulk stream in front of the rest (dist_lu.h), so the panel stream carries the
+	// panel alone, as in the single-GPU driver, which keeps its two streams down to the last step: one rank, N = 16384,
+	// threshold 1e8 / 3e7 / 0: 191.7 / 156.7 / 123.6 ms (profiles/r06_exp_dist.txt).  FAER_HIP_DIST_TWO_MIN overrides.
 	void step_begin(long local_trailing_entries, long next_panel_rows)
 	{
+		++step_id;
 		if (!two)
 			return;
 		// the bulk stream's reads of the panel buffer that the next receive overwrites, and its writes to the columns the
@@ -167,11 +195,32 @@ template <typename S> struct DeviceBackend {
 		FH_HIP(hipEventRecord(ev_bulk, ctx().la_bulk));
 		ctx().stream = caller;
 	}
+	// the update of the look-ahead block column: on the bulk stream, in front of the rest of the step (dist_lu.h)
+	hipEvent_t ev_cols = nullptr;
+	void ahead_cols_begin()
+	{
+		if (!two_now)
+			return;
+		stream_wait(ctx().la_bulk, ev0);
+		ctx().stream = ctx().la_bulk;
+	}
+	void ahead_cols_end()
+	{
+		if (!two_now)
+			return;
+		ev_cols = ctx().next_event();
+		FH_HIP(hipEventRecord(ev_cols, ctx().la_bulk));
+		ctx().stream = caller;
+	}
 	void ahead_begin()
 	{
 		if (!two_now)
 			return;
 		stream_wait(ctx().la_panel, ev0);
+		if (ev_cols) {
+			stream_wait(ctx().la_panel, ev_cols);
+			ev_cols = nullptr;
+		}
 		ctx().stream = ctx().la_panel;
 	}
 	void ahead_end()
@@ -348,6 +397,11 @@ FaerLltStatus dist_llt_api(FaerMatMut A_local, size_t n_global, size_t nb, FaerL
 	be.reg_delta = reg.dynamic_regularization_delta ? *static_cast<const T *>(reg.dynamic_regularization_delta) : (T) 0;
 	be.reg_eps = reg.dynamic_regularization_epsilon ? *static_cast<const T *>(reg.dynamic_regularization_epsilon) : (T) 0;
 	be.streams_init(); // the two-stream schedule of the LU (step_begin / ahead_* / rest_*: no-ops without it -- ADVICE r03)
+	// (the Cholesky's look-ahead part still CONTAINS level-3 work -- the update of block column k + 1 and the solve of the rows below
+	// its diagonal block -- which crawls on the panel stream's 32 CUs: both streams only beside >= 1e8 trailing entries, as in rounds
+	// 2-5; one rank, N = 16384: 100-105 ms with the threshold, 123 ms without -- profiles/r06_exp_dist.txt)
+	if (!getenv("FAER_HIP_DIST_TWO_MIN"))
+		be.two_min_work = 100000000;
 	typename B::View Av{static_cast<T *>(A_local.ptr), n, (long) A_local.ncols, 1, (long) A_local.col_stride};
 	be.t_total.begin();
 	const long r = DistLlt<B>::run(be, Av, n, (long) nb, comm.rank, comm.world_size, static_cast<T *>(panel_ws));

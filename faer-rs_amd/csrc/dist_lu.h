@@ -30,20 +30,24 @@ namespace fh {
 //   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)
 //                                                        -- collective on the backend's memory space; may be
 //                                                           asynchronous (slot = 0 / 1, at most one in flight each)
-//   void step_begin(long local_trailing_entries, long next_panel_rows) / void rest_begin() / rest_end() / ahead_begin() / ahead_end() / ahead_join()
+//   void step_begin(long local_trailing_entries, long next_panel_rows) / void rest_begin() / rest_end() / ahead_cols_begin() /
+//   ahead_cols_end() / ahead_begin() / ahead_end() / ahead_join()
 //                                                        -- scheduling hooks (no-ops for a synchronous backend): the
-//                                                           device backend runs the "rest" updates of a step on the
-//                                                           bulk stream and the look-ahead part (update + panel of
-//                                                           block column k+1) on the CU-masked panel stream
+//                                                           device backend runs the update of block column k+1 and then
+//                                                           the "rest" updates of a step on the bulk stream, and the panel
+//                                                           of block column k+1 on the CU-masked panel stream as soon as
+//                                                           its columns are up to date
 //   void copy_ints(int *dst, const int *src, size_t n)   -- inside the backend's memory space, stream ordered
 //   void to_host(int *dst, const int *src, size_t n)     -- pivots back to the host (synchronising)
 //
 // Look-ahead: the owner of block column k+1 brings that column up to date with panel k and factors it FIRST, then
 // starts its broadcast; every rank posts the receive before it runs the rest of update k, so the transfer of
 // panel k+1 and the latency-bound panel factorization on its owner overlap with the trailing updates of step k.
-// On the owner itself the look-ahead part is issued first (an asynchronous backend queues it on its panel stream) and
-// the REST of update k second (on its bulk stream): the two run concurrently inside the rank, exactly like the two
-// streams of the single-GPU driver (getrf.hip, getrf_lookahead).
+// On the owner itself the update of block column k+1 is issued first, on the stream that also takes the REST of update k
+// (an asynchronous backend: its bulk stream, most of the chip), the panel factorization behind it on the panel stream, the
+// rest last: panel k+1 and the rest of update k run concurrently inside the rank, exactly like the two streams of the
+// single-GPU driver (getrf.hip, getrf_lookahead, "mode 1").  Rounds 2-5 ran the update of block column k+1 on the panel
+// stream's 32 CUs in front of the panel: ~1 ms per step on the critical chain (profiles/r05_bench_dryrun_dist_one_rank.json).
 // Two panel buffers alternate; the pivots stay in the backend's memory until the end (no host synchronisation
 // inside the loop).
 template <class B> struct DistLu {
@@ -125,14 +129,26 @@ template <class B> struct DistLu {
 						    View{Lp.p + w * Lp.rs, rows - w, w, Lp.rs, Lp.cs}, top); // A11 -= A10 A01 (:108-117)
 			}
 		};
+		// The ROOT of a broadcast reads its own buffer: it does not wait for the transfer before it applies the panel, only
+		// before the slot is written again (two steps later).  With one rank, and wherever a rank owns consecutive panels, the
+		// transport is then off the chain "panel k+1 -> update of block column k+2" (round 6: every wait is still taken exactly
+		// once, tests/test_dist_lu.py).
+		bool sent[2] = {false, false}; // this rank's own broadcast from the slot has not been awaited yet
+		auto wait_own = [&](int slot) {
+			if (sent[slot]) {
+				be.bcast_wait(slot);
+				sent[slot] = false;
+			}
+		};
 		if (nblk > 0) {
 			if (rank == 0)
 				factor_and_pack(0);
 			be.bcast_begin(piv_of(0), bytes_of(0), 0, 0);
+			sent[0] = rank == 0;
 		}
 		for (long k = 0; k < nblk; ++k) {
-			be.bcast_wait((int) (k & 1));
-			be.copy_ints(piv_all + k * nb, piv_of(k), (size_t) fw(k));
+			if ((int) (k % world) != rank)
+				be.bcast_wait((int) (k & 1));
 			const bool ahead = k + 1 < nblk;
 			const int next_owner = ahead ? (int) ((k + 1) % world) : -1;
 			{ // local columns right of block k x remaining rows: how much trailing work this rank has beside the next panel
@@ -149,6 +165,7 @@ template <class B> struct DistLu {
 			// and the product runs on the large tiles.  Per column the arithmetic is the same as block by block.
 			auto rest = [&]() {
 				be.rest_begin();
+				be.copy_ints(piv_all + k * nb, piv_of(k), (size_t) fw(k)); // (needed at the very end only: off the caller's chain)
 				const bool skip_next = ahead && rank == next_owner; // block k + 1 is brought up to date by the look-ahead part
 				long cl = 0, cr = 0, ctot = 0;			    // local columns: left of block k / up to the right range / all
 				for (long b = rank; b < nblk_all; b += world) {
@@ -184,19 +201,27 @@ template <class B> struct DistLu {
 				// started when the host had finished queueing the rest -- the two streams ran one after the other).  The
 				// caller's stream joins the panel stream only AFTER the rest has been queued, so a blocking transport that
 				// synchronises in bcast_begin does not hold the rest back either.
-				be.ahead_begin();
+				be.ahead_cols_begin();
 				update(k, k + 1);
+				be.ahead_cols_end();
+				be.ahead_begin();
+				wait_own((int) ((k + 1) & 1)); // (block k - 1 has left the buffer that panel k + 1 is packed into)
 				factor_and_pack(k + 1);
 				be.ahead_end();
 				rest(); // runs beside the panel on an asynchronous backend
 				be.ahead_join();
 				be.bcast_begin(piv_of(k + 1), bytes_of(k + 1), next_owner, (int) ((k + 1) & 1));
+				sent[(k + 1) & 1] = true;
 			} else {
-				if (ahead) // post the receive before the updates: the transfer overlaps them
+				if (ahead) { // post the receive before the updates: the transfer overlaps them
+					wait_own((int) ((k + 1) & 1));
 					be.bcast_begin(piv_of(k + 1), bytes_of(k + 1), next_owner, (int) ((k + 1) & 1));
+				}
 				rest();
 			}
 		}
+		wait_own(0);
+		wait_own(1);
 		be.run_end();
 		std::vector<int> rel((size_t) size);
 		if (size > 0)

@@ -1888,6 +1888,26 @@ template <typename T> void getrf_panel_dev(MatV<T> P, int *piv_dev, int *status_
 	FH_CHECK(st[2] == 0, "partial_piv_lu: device exchange timed out in the panel kernel");
 }
 template <typename T> void laswp_rows_dev(MatV<T> B, const int *piv_dev, int nt) { laswp_dev<T>(B, piv_dev, nt, 0); }
+// The same interchanges with the net permutation composed once and shared by several launches (the distributed driver applies a
+// panel's pivots to three column ranges per step): `list` = 4 * nt device ints.  nt <= laswp_list_max().
+int laswp_list_max() { return LASWP_SMALL_NT; }
+void laswp_compose_rows_dev(const int *piv_dev, int nt, int *list)
+{
+	LaswpList l;
+	l.dst = list;
+	l.src = list + 2 * nt;
+	laswp_compose_list(piv_dev, nt, 0, l);
+}
+template <typename T> void laswp_list_rows_dev(MatV<T> B, const int *list, int nt)
+{
+	LaswpList l;
+	l.dst = const_cast<int *>(list);
+	l.src = const_cast<int *>(list) + 2 * nt;
+	l.nt = nt;
+	laswp_list_dev<T>(B, l);
+}
+template void laswp_list_rows_dev<double>(MatV<double>, const int *, int);
+template void laswp_list_rows_dev<float>(MatV<float>, const int *, int);
 
 template void getrf_panel_dev<double>(MatV<double>, int *, int *);
 template void getrf_panel_dev<float>(MatV<float>, int *, int *);

@@ -113,6 +113,8 @@ struct HostBackend {
 	void step_begin(long, long) {}
 	void rest_begin() {}
 	void rest_end() {}
+	void ahead_cols_begin() {}
+	void ahead_cols_end() {}
 	void ahead_begin() {}
 	void ahead_end() {}
 	void ahead_join() {}

@@ -387,6 +387,44 @@ def test_plu_lookahead_phases_and_transitions_at_small_n(oracle, plan):
         assert (perm.astype(np.int64)[:k] == rperm[:k]).all()
 
 
+def test_lending_the_panel_cus_gives_the_bitwise_same_factors():
+    """faer_hip_debug_lend_cus(1): the big trailing products of the look-ahead LU / Cholesky hand their tiles out through per-XCD
+    counters and a helper launch on the panel stream takes some of them (gemm.hip GemmArgs::ticket).  Who computes a tile must not
+    matter: bitwise the same factors and pivots as with lending off (the default, profiles/r06_exp_lend.txt)."""
+    import torch
+
+    F = init_gpu()
+    n = 12288
+    g = torch.Generator(device="cuda").manual_seed(21)
+    a = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g).t()
+    out = {}
+    for lend in (0, 1):
+        F.lib().faer_hip_debug_lend_cus(lend)
+        try:
+            lu = a.clone()
+            perm, _, _ = F.partial_piv_lu_factor_in_place(lu)
+            F.synchronize()
+        finally:
+            F.lib().faer_hip_debug_lend_cus(0)
+        out[lend] = (perm, lu)
+    assert np.array_equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    del out, lu
+    b = torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g)
+    spd_ = (b @ b.t() / n + 2 * torch.eye(n, dtype=torch.float64, device="cuda")).t()
+    del b
+    res = {}
+    for lend in (0, 1):
+        F.lib().faer_hip_debug_lend_cus(lend)
+        try:
+            l = spd_.clone()
+            assert F.llt_factor_in_place(l) == 0
+            F.synchronize()
+        finally:
+            F.lib().faer_hip_debug_lend_cus(0)
+        res[lend] = l
+    assert torch.equal(res[0], res[1])
+
+
 def test_lookahead_paths_fp32():
     """fp32 through the two-stream drivers: LLT n = 8192 (L L^T == A) and LU n = 4608 (P A == L U), tolerances
     scaled with eps_f32"""
