@@ -734,6 +734,14 @@ def main():
                 except Exception as ex:  # keep the headline line even if an extra fails
                     others[name] = {"error": str(ex)[:200]}
             out["others"] = others
+            # which kind of box of the pool produced this line: the latency-bound leaf kernels run 1.25-1.3 x slower
+            # on one population at identical product rates; the LU leaf's time per column, measured in this run, tells them apart
+            try:
+                upc = others["lu_f64_n16384"]["roofline"]["dominant_kernel"]["chain_kernel"]["us_per_column"]
+                out["box_kind"] = {"kind": "fast" if upc < 3.4 else "slow", "lu_leaf_us_per_column": upc,
+                                   "rule": "LU leaf < 3.4 us per column in situ: the faster population (2.9-3.0), else the slower one (3.8-3.9)"}
+            except Exception:
+                out["box_kind"] = None
 
         # ---------------------------------------------------------------- CPU baseline (oracle port, bounded sample)
         if dist is None and not args.no_cpu:
@@ -792,8 +800,68 @@ def main():
             except Exception as ex:
                 blas = {"error": str(ex)[:200]}
             out["cpu_baseline_openblas"] = blas
+            # BASELINE.json configs[0] itself: fp64 matmul + llt on a 1024 x 1024 random SPD Mat (faer/examples/bench.rs:1511-1539) -- the
+            # port, the host's OpenBLAS and this GPU on exactly those shapes, best of several repetitions each
+            cfg0 = {}
+            try:
+                n0 = 1024
+                h0 = np.asfortranarray(rng.standard_normal((n0, n0)))
+                s0 = np.asfortranarray(h0 @ h0.T + n0 * np.eye(n0))  # bench.rs:1511-1513
+                c0 = np.zeros((n0, n0), order="F")
+
+                def best_of(fn, reps):
+                    tb = 1e30
+                    for _ in range(reps):
+                        t0_ = time.perf_counter()
+                        fn()
+                        tb = min(tb, time.perf_counter() - t0_)
+                    return tb
+
+                t_pm = best_of(lambda: orc.matmul(c0, h0, s0), 5)
+                t_pl = best_of(lambda: orc.llt_in_place(s0.copy(order="F")), 5) - best_of(lambda: s0.copy(order="F"), 5)
+                cfg0["port_matmul_GFLOP/s"] = round(2.0 * n0 ** 3 / t_pm / 1e9, 2)
+                cfg0["port_llt_GFLOP/s"] = round(n0 ** 3 / 3.0 / max(t_pl, 1e-9) / 1e9, 2)
+                try:
+                    cfg0["openblas_dgemm_GFLOP/s"] = round(2.0 * n0 ** 3 / best_of(lambda: sblas.dgemm(1.0, h0, s0), 10) / 1e9, 1)
+                    cfg0["openblas_dpotrf_GFLOP/s"] = round(n0 ** 3 / 3.0 / best_of(lambda: slap.dpotrf(s0, lower=1), 10) / 1e9, 1)
+                except Exception as ex:
+                    cfg0["openblas_error"] = str(ex)[:120]
+                # the GPU on the same shapes, operands resident in HBM, events on the library's stream, best of 20
+                d_a = torch.from_numpy(np.ascontiguousarray(h0.T)).to(dev).t()
+                d_s = torch.from_numpy(np.ascontiguousarray(s0.T)).to(dev).t()
+                d_c = torch.empty((n0, n0), dtype=torch.float64, device=dev).t()
+                d_w = d_s.clone()
+
+                def gpu_best(fn, reps=20):
+                    fn()
+                    torch.cuda.synchronize()
+                    tb = 1e30
+                    for _ in range(reps):
+                        e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0_.record()
+                        fn()
+                        e1_.record()
+                        torch.cuda.synchronize()
+                        tb = min(tb, e0_.elapsed_time(e1_) * 1e-3)
+                    return tb
+
+                t_gm = gpu_best(lambda: F.matmul(d_c, F.ACCUM_REPLACE, d_a, d_s, 1.0))
+
+                def gllt():
+                    d_w.copy_(d_s)
+                    F.llt_factor_in_place(d_w)
+
+                t_gl = gpu_best(gllt) - gpu_best(lambda: d_w.copy_(d_s))
+                cfg0["gpu_matmul_GFLOP/s"] = round(2.0 * n0 ** 3 / t_gm / 1e9, 1)
+                cfg0["gpu_llt_GFLOP/s"] = round(n0 ** 3 / 3.0 / max(t_gl, 1e-9) / 1e9, 1)
+                cfg0["gpu_matmul_us"], cfg0["gpu_llt_us"] = round(t_gm * 1e6, 1), round(t_gl * 1e6, 1)
+                cfg0["workload"] = "BASELINE configs[0]: fp64 matmul + llt, 1024 x 1024 random SPD Mat"
+                cfg0["note"] = (f"port = oracle/ ({nthr} OpenMP threads); openblas = scipy on the same host; gpu = this library, operands in HBM, "
+                                "the llt call includes its one host synchronisation (status word); faer itself cannot be built here")
+            except Exception as ex:
+                cfg0 = {"error": str(ex)[:200]}
             out["cpu_baseline"] = {"value": round(2.0 * n_mm ** 3 / t_mm / 1e9, 2), "unit": "GFLOP/s", "cores": nthr,
-                                   "kind": "port",
+                                   "kind": "port", "config_r_1024": cfg0,
                                    "sample": f"oracle (C restatement of faer's algorithm, OpenMP over columns, {nthr} threads of "
                                              f"{ncpu} host cores) fp64 matmul n={n_mm}, 1 rep ({t_mm:.2f} s); "
                                              f"llt n={n_llt}: {n_llt ** 3 / 3.0 / t_llt / 1e9:.2f} GFLOP/s ({t_llt:.2f} s)",
