@@ -1343,13 +1343,23 @@ template <typename T> struct TdArgs {
 	T *A;
 	idx_t rs, cs;
 	int n, k;
-	T *y, *w, *ysum, *taus;
-	double *csum;
+	T *y, *w, *taus;
+	// partial sums of the two matrix passes (round 6): row sums per COLUMN chunk of TD_CC columns, rpart[c * n + i], and column sums per
+	// ROW chunk of TD_RC rows, cpart[c * n + j]; td_step_body adds them in a fixed order
+	double *rpart, *cpart;
 	TdState *st;
 };
 constexpr int TD_NT = 1024; // td_step_kernel
-constexpr int TD_PW = 16;   // panel width of the two matrix passes
-constexpr int TD_UNR = 4;   // independent loads in flight per thread in the matrix passes (8 spills: 128 registers per lane at 1024 threads)
+constexpr int TD_PW = 16;   // rows per workgroup of the row pass (128-byte segments per column)
+constexpr int TD_UNR = 4;   // independent loads in flight per thread in the matrix passes
+// Round 6: both matrix passes were bound by their LONGEST workgroup -- one workgroup per 16 columns (column pass) / 16 rows (row pass)
+// of a triangle is anything between 16 and 16 r entries, and with r / 16 <= 256 workgroups for 256 CUs the chip waited for the longest
+// one (kernel trace: max 44.8 / 25.6 us against averages of 23.8 / 11.9 per launch).  The passes are now cut into uniform pieces --
+// a column x TD_RC rows per wavefront, 16 rows x TD_CC columns per workgroup -- whose sums are partial; the step kernel adds the
+// (at most n / TD_CC + n / TD_RC) partials of an entry in a fixed order, so the result stays deterministic.
+constexpr int TD_RC = 1024; // rows per piece of a column (column pass)
+constexpr int TD_CC = 512;  // columns per piece of a 16-row panel (row pass)
+constexpr int TD_PT = 256;  // threads per workgroup of the two matrix passes
 
 // sums CNT doubles over the 1024 threads; every thread may read s_red afterwards
 template <int CNT> static __device__ __forceinline__ void td_block_sum(double (&v)[CNT], double *s_part, double *s_red)
@@ -1384,7 +1394,16 @@ template <typename T> static __device__ __forceinline__ void td_step_body(const 
 		double d[2] = {0.0, 0.0};
 		for (int i = k + 1 + tid; i < n; i += TD_NT) {
 			const T aik = at(i, k), xi = at(i, k - 1);
-			T yv = tau_inv * a.ysum[i];
+			// (sym(A22) x)_i of the fused pass of step k - 1 (A22 = A[k+1.., k+1..] there): its partial sums in a fixed order
+			double ys = 0.0;
+			{
+				const int ii = i - (k + 1), rr = n - (k + 1);
+				for (int c = 0; c * TD_CC <= ii; ++c)
+					ys += a.rpart[(size_t) c * n + i];
+				for (int c = ii / TD_RC; c * TD_RC < rr; ++c)
+					ys += a.cpart[(size_t) c * n + i];
+			}
+			T yv = tau_inv * (T) ys;
 			yv += aik * tau_inv;
 			a.y[i] = yv;
 			d[0] += (double) aik * (double) xi;
@@ -1468,16 +1487,23 @@ template <typename T> static __device__ __forceinline__ void td_step_body(const 
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void td_step_kernel(const TdArgs<T> a) { td_step_body<T>(a, a.k); }
 
-// Column j of the lower triangle of A22 (one wavefront per column, lanes along the rows: 512-byte accesses): the rank-2
-// update A22 -= u w^H + w u^H WRITTEN BACK (every entry belongs to exactly one wavefront) and the column sum
-// striu(A22^H) x over the rows below the diagonal -> csum[j], complete per wavefront.
-template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel(const TdArgs<T> a)
+// Column j of the lower triangle of A22, rows [c TD_RC, (c + 1) TD_RC) of it (one wavefront per piece, lanes along the rows: 512-byte
+// accesses): the rank-2 update A22 -= u w^H + w u^H WRITTEN BACK (every entry belongs to exactly one wavefront) and the piece's share of
+// the column sum striu(A22^H) x over the rows below the diagonal -> cpart[c][j].  grid = (columns / 4, row chunks).
+template <typename T> __global__ __launch_bounds__(TD_PT) void td_colpass_kernel(const TdArgs<T> a)
 {
 	const int tid = threadIdx.x, k = a.k;
 	const int base = k + 2, r = a.n - base; // A22 = A[base.., base..], r x r
-	const int lane = tid & 63, j = blockIdx.x * (TD_NT / 64) + (tid >> 6);
+	const int lane = tid & 63, j = blockIdx.x * (TD_PT / 64) + (tid >> 6);
+	const int c = blockIdx.y;
 	if (j >= r)
 		return;
+	const int pbeg = max(j, c * TD_RC), pend = min(r, (c + 1) * TD_RC);
+	if (pbeg >= pend) { // (the piece lies above the diagonal: it still owns its slot of the partial sums)
+		if (lane == 0 && (c + 1) * TD_RC > j)
+			a.cpart[(size_t) c * a.n + base + j] = 0.0;
+		return;
+	}
 	const bool upd = k > 0;
 	const T *u = a.A + (idx_t) base * a.rs + (idx_t) (k > 0 ? k - 1 : 0) * a.cs; // u[i * rs]
 	const T *x = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;
@@ -1485,12 +1511,12 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel
 	const T wj = upd ? w[j] : (T) 0, uj = upd ? u[(idx_t) j * a.rs] : (T) 0;
 	T *col = a.A + (idx_t) base * a.rs + (idx_t) (base + j) * a.cs;
 	double acc = 0.0;
-	for (int p0 = j + lane; p0 < r; p0 += 64 * TD_UNR) {
+	for (int p0 = pbeg + lane; p0 < pend; p0 += 64 * TD_UNR) {
 		T v[TD_UNR], xp[TD_UNR], up[TD_UNR], wp[TD_UNR];
 #pragma unroll
 		for (int q = 0; q < TD_UNR; ++q) {
 			const int pr = p0 + 64 * q;
-			const bool in = pr < r;
+			const bool in = pr < pend;
 			const idx_t o = (idx_t) (in ? pr : j) * a.rs;
 			v[q] = col[o];
 			xp[q] = (in && pr > j) ? x[o] : (T) 0; // the diagonal entry is not part of the strictly-upper product
@@ -1500,7 +1526,7 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel
 #pragma unroll
 		for (int q = 0; q < TD_UNR; ++q) {
 			const int pr = p0 + 64 * q;
-			if (pr < r) {
+			if (pr < pend) {
 				T t = v[q];
 				if (upd) {
 					t = fh_fma(-up[q], wj, t);
@@ -1513,33 +1539,37 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_colpass_kernel
 	}
 	const double sv = wave_sum(acc);
 	if (lane == 0)
-		a.csum[base + j] = sv;
+		a.cpart[(size_t) c * a.n + base + j] = sv;
 }
 
-// Rows i0 .. i0+15 of the (already updated) lower triangle of A22, read only: row sums tril(A22) x, plus csum -> ysum.
-// Thread (ri, cj): row ri of the panel, columns cj, cj + NC, ...; TD_UNR independent loads in flight per thread.
-template <typename T> __global__ __launch_bounds__(TD_NT) void td_rowpass_kernel(const TdArgs<T> a)
+// Rows i0 .. i0+15, columns [c TD_CC, (c + 1) TD_CC) of the (already updated) lower triangle of A22, read only: the piece's share of the
+// row sums tril(A22) x -> rpart[c][i].  Thread (ri, cj): row ri of the panel, columns cj, cj + NC, ...; TD_UNR independent loads in
+// flight per thread.  grid = (row panels, column chunks).
+template <typename T> __global__ __launch_bounds__(TD_PT) void td_rowpass_kernel(const TdArgs<T> a)
 {
-	constexpr int NC = TD_NT / TD_PW;
+	constexpr int NC = TD_PT / TD_PW;
 	__shared__ double red[TD_PW][NC + 1];
 	const int tid = threadIdx.x, k = a.k;
 	const int base = k + 2, r = a.n - base;
-	const int i0 = blockIdx.x * TD_PW;
+	const int i0 = blockIdx.x * TD_PW, c = blockIdx.y;
+	const int jbeg = c * TD_CC;
+	if (jbeg >= min(i0 + TD_PW, r))
+		return; // (the piece lies right of the panel's last diagonal entry: no row of the panel has a partial for this chunk)
 	const T *x = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;
 	const T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
 	{
 		const int ri = tid & (TD_PW - 1), cj = tid >> 4;
 		const int gi = i0 + ri;
 		const bool vi = gi < r;
-		const int jend = min(i0 + TD_PW, r);
+		const int jend = min(min(i0 + TD_PW, r), jbeg + TD_CC);
 		const T *row = A22 + (idx_t) (vi ? gi : 0) * a.rs;
 		double acc = 0.0;
-		for (int j0 = cj; j0 < jend; j0 += TD_UNR * NC) {
+		for (int j0 = jbeg + cj; j0 < jend; j0 += TD_UNR * NC) {
 			T v[TD_UNR], xj[TD_UNR];
 #pragma unroll
 			for (int q = 0; q < TD_UNR; ++q) {
 				const int j = j0 + NC * q;
-				const bool in = vi && j <= gi; // (j <= gi < jend)
+				const bool in = vi && j <= gi && j < jend;
 				const int jc = in ? j : 0;
 				v[q] = row[(idx_t) jc * a.cs];
 				xj[q] = in ? x[(idx_t) jc * a.rs] : (T) 0;
@@ -1551,11 +1581,11 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void td_rowpass_kernel
 		red[ri][cj] = acc;
 	}
 	__syncthreads();
-	if (tid < TD_PW && i0 + tid < r) {
+	if (tid < TD_PW && i0 + tid < r && jbeg <= i0 + tid) {
 		double rs_ = 0.0;
-		for (int c = 0; c < NC; ++c)
-			rs_ += red[tid][c];
-		a.ysum[base + i0 + tid] = (T) (rs_ + a.csum[base + i0 + tid]);
+		for (int q = 0; q < NC; ++q)
+			rs_ += red[tid][q];
+		a.rpart[(size_t) c * a.n + base + i0 + tid] = rs_;
 	}
 }
 
@@ -1569,7 +1599,8 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 	if (n <= 1)
 		return;
 	hipStream_t s = ctx().stream;
-	Scratch vb((size_t) (4 * n) * sizeof(T) + 256), cb((size_t) n * sizeof(double)), stb(sizeof(TdState));
+	const idx_t ncc = (n + TD_CC - 1) / TD_CC, nrc = (n + TD_RC - 1) / TD_RC;
+	Scratch vb((size_t) (4 * n) * sizeof(T) + 256), cb((size_t) (ncc + nrc) * (size_t) n * sizeof(double)), stb(sizeof(TdState));
 	TdArgs<T> a;
 	a.A = A.p;
 	a.rs = A.rs;
@@ -1577,9 +1608,9 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 	a.n = (int) n;
 	a.y = vb.as<T>();
 	a.w = a.y + n;
-	a.ysum = a.w + n;
-	a.taus = a.ysum + n;
-	a.csum = cb.as<double>();
+	a.taus = a.w + 2 * n;
+	a.rpart = cb.as<double>();
+	a.cpart = a.rpart + (size_t) ncc * (size_t) n;
 	a.st = stb.as<TdState>();
 	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (4 * n) * sizeof(T), s));
 	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(TdState), s));
@@ -1588,8 +1619,9 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 		hipLaunchKernelGGL(td_step_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
 		const idx_t r = n - k - 2;
 		if (r > 0) {
-			hipLaunchKernelGGL(td_colpass_kernel<T>, dim3((unsigned) ((r + TD_NT / 64 - 1) / (TD_NT / 64))), dim3(TD_NT), 0, s, a);
-			hipLaunchKernelGGL(td_rowpass_kernel<T>, dim3((unsigned) ((r + TD_PW - 1) / TD_PW)), dim3(TD_NT), 0, s, a);
+			hipLaunchKernelGGL(td_colpass_kernel<T>, dim3((unsigned) ((r + TD_PT / 64 - 1) / (TD_PT / 64)), (unsigned) ((r + TD_RC - 1) / TD_RC)), dim3(TD_PT), 0,
+					   s, a);
+			hipLaunchKernelGGL(td_rowpass_kernel<T>, dim3((unsigned) ((r + TD_PW - 1) / TD_PW), (unsigned) ((r + TD_CC - 1) / TD_CC)), dim3(TD_PT), 0, s, a);
 		}
 	}
 	FH_HIP(hipGetLastError());
