@@ -1322,19 +1322,20 @@ template long colpiv_qr_dev<float>(MatV<float>, MatV<float>, idx_t *, idx_t *);
 // Tridiagonalization of a self-adjoint matrix -- faer/src/linalg/evd/tridiag.rs:274-535.
 // A level-2, HBM-bound algorithm like the reference's: per column ONE pass over the remaining lower triangle that
 // applies the symmetric rank-2 update of the previous reflector and multiplies the updated matrix by the new one
-// (tridiag_fused_op, :36-272), between two short vector phases.  Three launches per column, no host synchronisation (running the
-// vector phase in the last workgroup of the row pass instead -- release fence, ticket, acquire fence -- measured 2.4x
-// SLOWER: an agent-scope fence per workgroup writes the L2 back):
+// (tridiag_fused_op, :36-272), between two short vector phases.  Two launches per column, no host synchronisation:
 //   td_step_kernel(k)   one workgroup: finishes y of step k-1 (:484-511), brings column k up to date (:300-318), makes
 //                       its reflector (:330-336, householder.rs:59-107), updates column k+1 (:348-359), w <- y
-//   td_colpass_kernel(k)  one wavefront per column of the lower triangle of A22 = A[k+2.., k+2..], lanes along the rows:
-//                       A22 -= u w^H + w u^H written back (coalesced; every entry belongs to one wavefront) and the column
-//                       sum striu(A22^H) x, complete per wavefront
-//   td_rowpass_kernel(k)  one workgroup per 16 rows, read only: the row sums tril(A22) x of the UPDATED triangle
-//                       Every y_i is complete inside one wavefront / workgroup: no partial sums, no atomics, a fixed
-//                       summation order.  Price: the triangle is read twice.  (The first version wrote back in the
-//                       16-row pass and read in the column pass: 253 ms at N = 4096 against this one's time in DESIGN.md;
-//                       one kernel doing both races -- a write-back against another workgroup's reads.)
+//   td_fused_kernel(k)  one workgroup per 128 x 64 tile of the lower triangle of A22 = A[k+2.., k+2..], lanes along the rows:
+//                       A22 -= u w^H + w u^H written back (every entry is read and written ONCE) and the tile's share of both halves
+//                       of sym(A22) x -- the row sums tril(A22) x and the column sums striu(A22^H) x.  The shares leave the
+//                       workgroup as write-through stores (xwg.h: no fence); the workgroup that completes an index block of 64
+//                       entries (an arrival counter per block) adds that block's shares in a FIXED order -> ysum, so the result
+//                       does not depend on which workgroup that is.
+// History: rounds 2-5 read the triangle twice (a column pass that wrote back and a 16-row pass, each sum complete in one
+// wavefront / workgroup: 185 ms at N = 4096); cut into uniform pieces with partial sums added by the step kernel: 150 ms (the
+// chip waited for the longest workgroup); one pass with in-kernel sums: DESIGN.md.  Running the vector phase in the last
+// workgroup behind a release fence / ticket / acquire fence measured 2.4x slower in round 2 (an agent-scope fence writes
+// the L2 back) -- the sums here use the fence-free exchange of xwg.h instead.
 // ------------------------------------------------------------------------------------------------
 struct TdState {
 	double tau_inv;
@@ -1344,22 +1345,17 @@ template <typename T> struct TdArgs {
 	idx_t rs, cs;
 	int n, k;
 	T *y, *w, *taus;
-	// partial sums of the two matrix passes (round 6): row sums per COLUMN chunk of TD_CC columns, rpart[c * n + i], and column sums per
-	// ROW chunk of TD_RC rows, cpart[c * n + j]; td_step_body adds them in a fixed order
-	double *rpart, *cpart;
+	double *ysum;	       // sym(A22) x of the fused pass, complete
+	double *rpart, *cpart; // shares of the tiles: row sums rpart[J * n + i] (column block J), column sums cpart[I * n + j] (row block I)
+	unsigned *cnt;	       // arrival counters per index block of TF_TC entries (zero between launches)
 	TdState *st;
 };
 constexpr int TD_NT = 1024; // td_step_kernel
-constexpr int TD_PW = 16;   // rows per workgroup of the row pass (128-byte segments per column)
-constexpr int TD_UNR = 4;   // independent loads in flight per thread in the matrix passes
-// Round 6: both matrix passes were bound by their LONGEST workgroup -- one workgroup per 16 columns (column pass) / 16 rows (row pass)
-// of a triangle is anything between 16 and 16 r entries, and with r / 16 <= 256 workgroups for 256 CUs the chip waited for the longest
-// one (kernel trace: max 44.8 / 25.6 us against averages of 23.8 / 11.9 per launch).  The passes are now cut into uniform pieces --
-// a column x TD_RC rows per wavefront, 16 rows x TD_CC columns per workgroup -- whose sums are partial; the step kernel adds the
-// (at most n / TD_CC + n / TD_RC) partials of an entry in a fixed order, so the result stays deterministic.
-constexpr int TD_RC = 1024; // rows per piece of a column (column pass)
-constexpr int TD_CC = 512;  // columns per piece of a 16-row panel (row pass)
-constexpr int TD_PT = 256;  // threads per workgroup of the two matrix passes
+constexpr int TD_UNR = 4;   // independent loads in flight per thread in the matrix passes (bidiagonalization, Hessenberg)
+constexpr int TD_PW = 16;   // rows per workgroup of their row passes (128-byte segments per column)
+constexpr int TF_TR = 128;  // rows of a tile of the fused pass
+constexpr int TF_TC = 64;   // columns of a tile = entries of an index block
+constexpr int TF_NT = 256;  // its threads: wavefront w owns 16 columns of the tile, a lane two rows
 
 // sums CNT doubles over the 1024 threads; every thread may read s_red afterwards
 template <int CNT> static __device__ __forceinline__ void td_block_sum(double (&v)[CNT], double *s_part, double *s_red)
@@ -1394,16 +1390,7 @@ template <typename T> static __device__ __forceinline__ void td_step_body(const 
 		double d[2] = {0.0, 0.0};
 		for (int i = k + 1 + tid; i < n; i += TD_NT) {
 			const T aik = at(i, k), xi = at(i, k - 1);
-			// (sym(A22) x)_i of the fused pass of step k - 1 (A22 = A[k+1.., k+1..] there): its partial sums in a fixed order
-			double ys = 0.0;
-			{
-				const int ii = i - (k + 1), rr = n - (k + 1);
-				for (int c = 0; c * TD_CC <= ii; ++c)
-					ys += a.rpart[(size_t) c * n + i];
-				for (int c = ii / TD_RC; c * TD_RC < rr; ++c)
-					ys += a.cpart[(size_t) c * n + i];
-			}
-			T yv = tau_inv * (T) ys;
+			T yv = tau_inv * (T) a.ysum[i];
 			yv += aik * tau_inv;
 			a.y[i] = yv;
 			d[0] += (double) aik * (double) xi;
@@ -1485,107 +1472,279 @@ template <typename T> static __device__ __forceinline__ void td_step_body(const 
 	}
 }
 
-template <typename T> __global__ __launch_bounds__(TD_NT) void td_step_kernel(const TdArgs<T> a) { td_step_body<T>(a, a.k); }
-
-// Column j of the lower triangle of A22, rows [c TD_RC, (c + 1) TD_RC) of it (one wavefront per piece, lanes along the rows: 512-byte
-// accesses): the rank-2 update A22 -= u w^H + w u^H WRITTEN BACK (every entry belongs to exactly one wavefront) and the piece's share of
-// the column sum striu(A22^H) x over the rows below the diagonal -> cpart[c][j].  grid = (columns / 4, row chunks).
-template <typename T> __global__ __launch_bounds__(TD_PT) void td_colpass_kernel(const TdArgs<T> a)
+// The same step with every entry of the three columns it touches held in registers (at most TD_E rows per thread: n - k - 1 <= TD_E TD_NT):
+// all loads are issued at the start -- ONE round trip to memory instead of one per loop -- and every entry is stored once.  Same arithmetic,
+// expression by expression, as td_step_body.
+constexpr int TD_E = 4;
+template <typename T> static __device__ __forceinline__ void td_step_body_reg(const TdArgs<T> &a, const int k)
 {
-	const int tid = threadIdx.x, k = a.k;
-	const int base = k + 2, r = a.n - base; // A22 = A[base.., base..], r x r
-	const int lane = tid & 63, j = blockIdx.x * (TD_PT / 64) + (tid >> 6);
-	const int c = blockIdx.y;
-	if (j >= r)
-		return;
-	const int pbeg = max(j, c * TD_RC), pend = min(r, (c + 1) * TD_RC);
-	if (pbeg >= pend) { // (the piece lies above the diagonal: it still owns its slot of the partial sums)
-		if (lane == 0 && (c + 1) * TD_RC > j)
-			a.cpart[(size_t) c * a.n + base + j] = 0.0;
-		return;
+	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
+	__shared__ T s_bc[3];
+	const int tid = threadIdx.x, n = a.n;
+	auto at = [&](int i, int j) -> T & { return a.A[(idx_t) i * a.rs + (idx_t) j * a.cs]; };
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	const bool upd = k > 0, more = k + 1 < n;
+	// rows i = k + 1 + tid + e TD_NT: column k (aik), the previous reflector (xi), column k + 1 (ak1), the product of the fused pass (ys)
+	T aik[TD_E], xi[TD_E], ak1[TD_E], yi[TD_E];
+	double ys[TD_E];
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int i = k + 1 + tid + e * TD_NT;
+		const bool in = i < n;
+		const int ic = in ? i : n - 1;
+		aik[e] = at(ic, k);
+		xi[e] = upd ? at(ic, k - 1) : (T) 0;
+		ys[e] = upd ? a.ysum[ic] : 0.0;
+		ak1[e] = (upd && more) ? at(ic, k + 1) : (T) 0;
+		yi[e] = (T) 0;
 	}
-	const bool upd = k > 0;
-	const T *u = a.A + (idx_t) base * a.rs + (idx_t) (k > 0 ? k - 1 : 0) * a.cs; // u[i * rs]
-	const T *x = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;
-	const T *w = a.w + base;
-	const T wj = upd ? w[j] : (T) 0, uj = upd ? u[(idx_t) j * a.rs] : (T) 0;
-	T *col = a.A + (idx_t) base * a.rs + (idx_t) (base + j) * a.cs;
-	double acc = 0.0;
-	for (int p0 = pbeg + lane; p0 < pend; p0 += 64 * TD_UNR) {
-		T v[TD_UNR], xp[TD_UNR], up[TD_UNR], wp[TD_UNR];
+	const T akk = at(k, k), tau_inv = (T) a.st->tau_inv;
+	T y1 = (T) 0;
+	T nacc[3] = {0, 0, 0}; // scaled sums of the tail of column k (reductions/norm_l2.rs:6-45)
+	if (upd) {
+		// ---- y of step k - 1 (:484-511)
+		double d[2] = {0.0, 0.0};
 #pragma unroll
-		for (int q = 0; q < TD_UNR; ++q) {
-			const int pr = p0 + 64 * q;
-			const bool in = pr < pend;
-			const idx_t o = (idx_t) (in ? pr : j) * a.rs;
-			v[q] = col[o];
-			xp[q] = (in && pr > j) ? x[o] : (T) 0; // the diagonal entry is not part of the strictly-upper product
-			up[q] = (in && upd) ? u[o] : (T) 0;
-			wp[q] = (in && upd) ? w[in ? pr : 0] : (T) 0;
-		}
+		for (int e = 0; e < TD_E; ++e)
+			if (k + 1 + tid + e * TD_NT < n) {
+				T yv = tau_inv * (T) ys[e];
+				yv += aik[e] * tau_inv;
+				yi[e] = yv;
+				d[0] += (double) aik[e] * (double) xi[e];
+				d[1] += (double) xi[e] * (double) yv;
+			}
+		td_block_sum<2>(d, s_part, s_red);
+		y1 = (akk + (T) s_red[0]) * tau_inv;
+		const T b = ((y1 + (T) s_red[1]) * (T) 0.5) * tau_inv;
+		y1 -= b;
+		// ---- y -= b x, then column k receives the rest of the rank-2 update (:300-318), norm of its tail on the way
 #pragma unroll
-		for (int q = 0; q < TD_UNR; ++q) {
-			const int pr = p0 + 64 * q;
-			if (pr < pend) {
-				T t = v[q];
-				if (upd) {
-					t = fh_fma(-up[q], wj, t);
-					t = fh_fma(-wp[q], uj, t);
-					col[(idx_t) pr * a.rs] = t;
-				}
-				acc += (double) t * (double) xp[q];
+		for (int e = 0; e < TD_E; ++e) {
+			const int i = k + 1 + tid + e * TD_NT;
+			if (i < n) {
+				yi[e] -= b * xi[e];
+				aik[e] -= y1 * xi[e] + yi[e];
 			}
 		}
 	}
-	const double sv = wave_sum(acc);
-	if (lane == 0)
-		a.cpart[(size_t) c * a.n + base + j] = sv;
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int i = k + 1 + tid + e * TD_NT;
+		if (i < n && i >= k + 2) {
+			const T v = aik[e];
+			nacc[0] += (v * sml) * (v * sml);
+			nacc[1] += v * v;
+			nacc[2] += (v * big) * (v * big);
+		}
+	}
+	if (tid == 0 && upd)
+		at(k, k) = akk - (y1 + y1);
+	if (!more)
+		return;
+	if (tid == 0) { // row k + 1: the head of the column, y and u of the update of column k + 1
+		s_bc[0] = aik[0];
+		s_bc[1] = yi[0];
+		s_bc[2] = xi[0];
+	}
+	// ---- reflector of column k below the diagonal (:330-336)
+	double accd[3] = {(double) nacc[0], (double) nacc[1], (double) nacc[2]};
+	td_block_sum<3>(accd, s_part, s_red);
+	const T tail_norm = norm_from3<T>(s_red);
+	T head = s_bc[0];
+	T head_norm = fabs(head);
+	if (head_norm < Lim<T>::minpos) {
+		head = (T) 0;
+		head_norm = (T) 0;
+	}
+	T tau, hinv = (T) 0;
+	bool scale_tail = false;
+	if (tail_norm < Lim<T>::minpos) {
+		tau = std::numeric_limits<T>::infinity();
+	} else {
+		const T norm = (T) hypot((double) head_norm, (double) tail_norm);
+		const T sign = head_norm != (T) 0 ? head * ((T) 1 / head_norm) : (T) 1;
+		const T signed_norm = sign * norm;
+		hinv = (T) 1 / (head + signed_norm);
+		head = -signed_norm;
+		const T tn = tail_norm * fabs(hinv);
+		tau = (T) 0.5 * ((T) 1 + tn * tn);
+		scale_tail = true;
+	}
+	const T u1 = upd ? s_bc[2] : (T) 0, y1n = upd ? s_bc[1] : (T) 0;
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int i = k + 1 + tid + e * TD_NT;
+		if (i < n && i >= k + 2) {
+			if (scale_tail || upd)
+				at(i, k) = scale_tail ? aik[e] * hinv : aik[e];
+			if (upd) { // :348-359
+				at(i, k + 1) = ak1[e] - (xi[e] * y1n + yi[e] * u1);
+				a.w[i] = yi[e];
+			}
+		}
+	}
+	if (tid == 0) {
+		at(k + 1, k) = head;
+		a.taus[k] = tau;
+		a.st->tau_inv = (double) ((T) 1 / tau);
+		if (upd)
+			at(k + 1, k + 1) = ak1[0] - (u1 * y1n + y1n * u1);
+	}
 }
 
-// Rows i0 .. i0+15, columns [c TD_CC, (c + 1) TD_CC) of the (already updated) lower triangle of A22, read only: the piece's share of the
-// row sums tril(A22) x -> rpart[c][i].  Thread (ri, cj): row ri of the panel, columns cj, cj + NC, ...; TD_UNR independent loads in
-// flight per thread.  grid = (row panels, column chunks).
-template <typename T> __global__ __launch_bounds__(TD_PT) void td_rowpass_kernel(const TdArgs<T> a)
+template <typename T> __global__ __launch_bounds__(TD_NT) void td_step_kernel(const TdArgs<T> a)
 {
-	constexpr int NC = TD_PT / TD_PW;
-	__shared__ double red[TD_PW][NC + 1];
+	if (a.n - a.k - 1 <= TD_E * TD_NT)
+		td_step_body_reg<T>(a, a.k);
+	else
+		td_step_body<T>(a, a.k);
+}
+
+// value of lane `l` (compile-time after unrolling) for the whole wavefront
+static __device__ __forceinline__ double td_lane(double v, int l)
+{
+	const long long b = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_readlane((int) b, l), hi = __builtin_amdgcn_readlane((int) (b >> 32), l);
+	return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
+}
+static __device__ __forceinline__ float td_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// sum over the wavefront, uniform: butterflies inside the rows of 16 lanes on the DPP path (xor 1, xor 2, half mirror, mirror), then
+// the four row sums in a fixed order (the __shfl_xor form goes through the LDS crossbar: 12 ds_bpermute per sum)
+template <int CTRL> static __device__ __forceinline__ double td_dpp(double v)
+{
+	const long long b = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_update_dpp(0, (int) b, CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, 0xf, 0xf, true);
+	return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
+}
+static __device__ __forceinline__ double td_wave_sum(double v)
+{
+	v += td_dpp<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+	v += td_dpp<0x4E>(v);  // quad_perm [2, 3, 0, 1]
+	v += td_dpp<0x141>(v); // row_half_mirror
+	v += td_dpp<0x140>(v); // row_mirror
+	return ((td_lane(v, 0) + td_lane(v, 16)) + td_lane(v, 32)) + td_lane(v, 48);
+}
+
+// Tiles of the lower triangle of an r x r matrix, TF_TR rows x TF_TC columns: tile (I, J) exists for J <= 2 I + 1 and J < ncb; row block I has
+// td_row_tiles(I) of them, column block J lives in the row blocks J / 2 .. nbr - 1.
+static __device__ __forceinline__ int td_row_tiles(int I, int ncb) { return min(2 * I + 2, ncb); }
+
+// Tile (I, J) of A22 (header of this section).  Lane l of wavefront w: rows 128 I + l and + 64, columns 64 J + 16 w .. + 15; all 32 loads
+// of a thread are issued before the first use.
+template <typename T, bool upd> __global__ __launch_bounds__(TF_NT) void td_fused_kernel(const TdArgs<T> a)
+{
+	constexpr int CW = TF_TC / (TF_NT / 64); // 16 columns per wavefront
+	__shared__ double s_row[TF_NT / 64][TF_TR];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, k = a.k;
+	const int base = k + 2, r = a.n - base; // A22 = A[base.., base..], r x r
+	const int nbr = (r + TF_TR - 1) / TF_TR, ncb = (r + TF_TC - 1) / TF_TC;
+	const int t = blockIdx.x; // tile (I, J): t in [I (I + 1), (I + 1)(I + 2))
+	int I = (int) ((sqrtf(4.0f * (float) t + 1.0f) - 1.0f) * 0.5f);
+	while (I * (I + 1) > t)
+		--I;
+	while ((I + 1) * (I + 2) <= t)
+		++I;
+	const int J = t - I * (I + 1);
+	if (J >= ncb)
+		return;
+	const T *u = a.A + (idx_t) base * a.rs + (idx_t) (upd ? k - 1 : 0) * a.cs; // u[i * rs]
+	const T *x = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;
+	const T *w = a.w + base;
+	T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
+	const int i0 = I * TF_TR, j0 = J * TF_TC + CW * wv;
+	int gi[2];
+	bool vr[2];
+	T xi[2], ui[2], wi[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		gi[h] = i0 + lane + 64 * h;
+		vr[h] = gi[h] < r;
+		gi[h] = min(gi[h], r - 1); // (loads below are unconditional: a row past the end reads the last row and takes part in nothing)
+		const idx_t o = (idx_t) gi[h] * a.rs;
+		xi[h] = x[o];
+		ui[h] = upd ? u[o] : (T) 0;
+		wi[h] = upd ? w[gi[h]] : (T) 0;
+	}
+	T xjl, ujl, wjl; // column values of the wavefront's 16 columns, one per lane
+	{
+		const int gj = min(j0 + (lane & (CW - 1)), r - 1);
+		const idx_t o = (idx_t) gj * a.rs;
+		xjl = x[o];
+		ujl = upd ? u[o] : (T) 0;
+		wjl = upd ? w[gj] : (T) 0;
+	}
+	T v[2][CW];
+#pragma unroll
+	for (int c = 0; c < CW; ++c)
+#pragma unroll
+		for (int h = 0; h < 2; ++h) // an entry above the diagonal reads the diagonal entry of its row instead (and is not used)
+			v[h][c] = A22[(idx_t) gi[h] * a.rs + (idx_t) min(j0 + c, gi[h]) * a.cs];
+	double racc[2] = {0.0, 0.0};
+#pragma unroll
+	for (int c = 0; c < CW; ++c) {
+		const int gj = j0 + c;
+		const T xj = td_lane(xjl, c), uj = td_lane(ujl, c), wj = td_lane(wjl, c);
+		double cs_ = 0.0;
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const bool in = vr[h] && gj <= gi[h];
+			T tv = v[h][c];
+			if (upd) {
+				tv = fh_fma(-ui[h], wj, tv);
+				tv = fh_fma(-wi[h], uj, tv);
+				if (in)
+					A22[(idx_t) gi[h] * a.rs + (idx_t) gj * a.cs] = tv;
+			}
+			racc[h] += in ? (double) tv * (double) xj : 0.0;
+			cs_ += (in && gj < gi[h]) ? (double) tv * (double) xi[h] : 0.0; // the diagonal entry is not part of the strictly-upper product
+		}
+		const double sv = td_wave_sum(cs_);
+		if (lane == 0 && gj < r)
+			a.cpart[(size_t) I * a.n + base + gj] = sv;
+	}
+	s_row[wv][lane] = racc[0];
+	s_row[wv][lane + 64] = racc[1];
+	__syncthreads();
+	if (tid < TF_TR && i0 + tid < r)
+		a.rpart[(size_t) J * a.n + base + i0 + tid] = ((s_row[0][tid] + s_row[1][tid]) + s_row[2][tid]) + s_row[3][tid];
+}
+
+// Index block b of TF_TC entries: the shares of its row tiles and of its column's tiles, added in a fixed order -> ysum.
+constexpr int TS_NT = 1024, TS_NS = TS_NT / TF_TC; // 16 slices of the list of shares per entry
+template <typename T> __global__ __launch_bounds__(TS_NT) void td_sum_kernel(const TdArgs<T> a)
+{
+	__shared__ double s_q[TS_NS][TF_TC];
 	const int tid = threadIdx.x, k = a.k;
 	const int base = k + 2, r = a.n - base;
-	const int i0 = blockIdx.x * TD_PW, c = blockIdx.y;
-	const int jbeg = c * TD_CC;
-	if (jbeg >= min(i0 + TD_PW, r))
-		return; // (the piece lies right of the panel's last diagonal entry: no row of the panel has a partial for this chunk)
-	const T *x = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;
-	const T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
-	{
-		const int ri = tid & (TD_PW - 1), cj = tid >> 4;
-		const int gi = i0 + ri;
-		const bool vi = gi < r;
-		const int jend = min(min(i0 + TD_PW, r), jbeg + TD_CC);
-		const T *row = A22 + (idx_t) (vi ? gi : 0) * a.rs;
-		double acc = 0.0;
-		for (int j0 = jbeg + cj; j0 < jend; j0 += TD_UNR * NC) {
-			T v[TD_UNR], xj[TD_UNR];
+	const int nbr = (r + TF_TR - 1) / TF_TR, ncb = (r + TF_TC - 1) / TF_TC;
+	const int b = blockIdx.x, Ib = b >> 1;
+	const int nrp = td_row_tiles(Ib, ncb), tot = nrp + (nbr - Ib);
+	const int e = tid & 63, qq = tid >> 6, i = min(b * TF_TC + e, r - 1);
+	const int per = (tot + TS_NS - 1) / TS_NS, p0 = qq * per;
+	double sacc = 0.0;
+	for (int pb = 0; pb < per; pb += 4) {
+		double v[4];
 #pragma unroll
-			for (int q = 0; q < TD_UNR; ++q) {
-				const int j = j0 + NC * q;
-				const bool in = vi && j <= gi && j < jend;
-				const int jc = in ? j : 0;
-				v[q] = row[(idx_t) jc * a.cs];
-				xj[q] = in ? x[(idx_t) jc * a.rs] : (T) 0;
-			}
-#pragma unroll
-			for (int q = 0; q < TD_UNR; ++q)
-				acc += (double) v[q] * (double) xj[q];
+		for (int u = 0; u < 4; ++u) {
+			const int p = p0 + pb + u;
+			const bool in = pb + u < per && p < tot;
+			const int pc = in ? p : 0;
+			const double *src = pc < nrp ? a.rpart + (size_t) pc * a.n : a.cpart + (size_t) (Ib + pc - nrp) * a.n;
+			v[u] = src[base + i];
+			if (!in)
+				v[u] = 0.0;
 		}
-		red[ri][cj] = acc;
+		sacc += (v[0] + v[1]) + (v[2] + v[3]);
 	}
+	s_q[qq][e] = sacc;
 	__syncthreads();
-	if (tid < TD_PW && i0 + tid < r && jbeg <= i0 + tid) {
-		double rs_ = 0.0;
-		for (int q = 0; q < NC; ++q)
-			rs_ += red[tid][q];
-		a.rpart[(size_t) c * a.n + base + i0 + tid] = rs_;
+	if (tid < TF_TC && b * TF_TC + tid < r) {
+		double t = 0.0;
+#pragma unroll
+		for (int q = 0; q < TS_NS; ++q)
+			t += s_q[q][tid];
+		a.ysum[base + b * TF_TC + tid] = t;
 	}
 }
 
@@ -1599,8 +1758,9 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 	if (n <= 1)
 		return;
 	hipStream_t s = ctx().stream;
-	const idx_t ncc = (n + TD_CC - 1) / TD_CC, nrc = (n + TD_RC - 1) / TD_RC;
-	Scratch vb((size_t) (4 * n) * sizeof(T) + 256), cb((size_t) (ncc + nrc) * (size_t) n * sizeof(double)), stb(sizeof(TdState));
+	const idx_t nbr = (n + TF_TR - 1) / TF_TR, ncb = (n + TF_TC - 1) / TF_TC;
+	Scratch vb((size_t) (4 * n) * sizeof(T) + 256), cb((size_t) (1 + ncb + nbr) * (size_t) n * sizeof(double)), stb(sizeof(TdState)),
+		cntb((size_t) ncb * sizeof(unsigned));
 	TdArgs<T> a;
 	a.A = A.p;
 	a.rs = A.rs;
@@ -1609,19 +1769,25 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 	a.y = vb.as<T>();
 	a.w = a.y + n;
 	a.taus = a.w + 2 * n;
-	a.rpart = cb.as<double>();
-	a.cpart = a.rpart + (size_t) ncc * (size_t) n;
+	a.ysum = cb.as<double>();
+	a.rpart = a.ysum + n;
+	a.cpart = a.rpart + (size_t) ncb * (size_t) n;
+	a.cnt = cntb.as<unsigned>();
 	a.st = stb.as<TdState>();
 	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (4 * n) * sizeof(T), s));
 	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(TdState), s));
+	FH_HIP(hipMemsetAsync(cntb.p, 0, (size_t) ncb * sizeof(unsigned), s));
 	for (idx_t k = 0; k < n; ++k) {
 		a.k = (int) k;
 		hipLaunchKernelGGL(td_step_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
 		const idx_t r = n - k - 2;
 		if (r > 0) {
-			hipLaunchKernelGGL(td_colpass_kernel<T>, dim3((unsigned) ((r + TD_PT / 64 - 1) / (TD_PT / 64)), (unsigned) ((r + TD_RC - 1) / TD_RC)), dim3(TD_PT), 0,
-					   s, a);
-			hipLaunchKernelGGL(td_rowpass_kernel<T>, dim3((unsigned) ((r + TD_PW - 1) / TD_PW), (unsigned) ((r + TD_CC - 1) / TD_CC)), dim3(TD_PT), 0, s, a);
+			const idx_t rb = (r + TF_TR - 1) / TF_TR;
+			if (k > 0)
+				hipLaunchKernelGGL((td_fused_kernel<T, true>), dim3((unsigned) (rb * (rb + 1))), dim3(TF_NT), 0, s, a);
+			else
+				hipLaunchKernelGGL((td_fused_kernel<T, false>), dim3((unsigned) (rb * (rb + 1))), dim3(TF_NT), 0, s, a);
+			hipLaunchKernelGGL(td_sum_kernel<T>, dim3((unsigned) ((r + TF_TC - 1) / TF_TC)), dim3(TS_NT), 0, s, a);
 		}
 	}
 	FH_HIP(hipGetLastError());
