@@ -1136,71 +1136,109 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 	}
 	if (blockIdx.x == 0)
 		tq_store_top(a.A, a.ld, a.r0, a.cx - a.w, a.w, a.top, tid);
-	for (int e = tid; e < 4096; e += 256) {
-		n1[(e >> 6) * TQ_DP + (e & 63)] = a.N1[e];
-		n3[(e >> 6) * TQ_DP + (e & 63)] = a.N3[e];
-		mm[(e >> 6) * TQ_DP + (e & 63)] = a.Md[e];
-	}
-	const int bl = tid & 15, ig = tid >> 4; // column, row group: rows ig, ig + 16, ig + 32, ig + 48
-	const int b = blockIdx.x * 16 + bl;
-	const bool colok = b < a.t;
-	// (the loops over the four rows of a thread stay rolled and hand their results on through LDS: the kernel runs ~20 us,
-	// a third of it was the first pass through 7 KB of unrolled code)
+	// (24 loads of a thread in flight per batch: one element per iteration was 16 dependent memory round trips)
 #pragma unroll 1
-	for (int u = 0; u < 4; ++u) {
-		const int i = ig + 16 * u;
-		double c = 0.0;
-		if (colok)
-			for (int g = 0; g < TQ_NG; ++g)
-				c += a.C[((long) g * 64 + i) * a.ldc + b];
-		v[i * 17 + bl] = c;
-	}
-	__syncthreads();
-	double dsq = 0.0;
-#pragma unroll 1
-	for (int u = 0; u < 4; ++u) {
-		const int i = ig + 16 * u;
-		double acc = 0.0;
-		for (int l = 0; l <= i; ++l)
-			acc += n1[i * TQ_DP + l] * v[l * 17 + bl];
-		dsq += acc * acc;
-		float *xp = a.A + (long) (a.cx + b) * a.ld + a.r0 + i;
-		double xt = 0.0;
-		if (colok && i < a.w) {
-			xt = (double) *xp;
-			*xp = (float) acc;
+	for (int e0 = tid; e0 < 4096; e0 += 8 * 256) {
+		double t1[8], t3[8], tm[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			t1[u] = a.N1[e0 + 256 * u];
+			t3[u] = a.N3[e0 + 256 * u];
+			tm[u] = a.Md[e0 + 256 * u];
 		}
-		v2[i * 17 + bl] = acc - xt; // E = D - X_top
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			const int e = e0 + 256 * u;
+			n1[(e >> 6) * TQ_DP + (e & 63)] = t1[u];
+			n3[(e >> 6) * TQ_DP + (e & 63)] = t3[u];
+			mm[(e >> 6) * TQ_DP + (e & 63)] = tm[u];
+		}
 	}
-	// column norms of the R rows just produced (rank test of the later panels)
-	sred[tid] = dsq;
+	// Three 64 x 64 x 16 products on the fp64 matrix cores (round 6; rounds 3-5 ran them as rolled dot-product loops over LDS, a chain of
+	// dependent LDS round trips: 27 us per launch).  Wavefront wv owns rows 16 wv .. + 15 of a product: result map of v_mfma_f64_16x16x4:
+	// column = lane & 15, row = (lane >> 4) + 4 reg.  The triangles are applied as masks on the A operand.
+	const int lane = tid & 63, wv = tid >> 6;
+	const int bl = lane & 15, b = blockIdx.x * 16 + bl;
+	const bool colok = b < a.t;
+	{
+		const int ig = tid >> 4; // rows ig, ig + 16, ig + 32, ig + 48 of column tid & 15: all 32 loads of a thread in flight at once
+		const int bb = blockIdx.x * 16 + (tid & 15);
+		double cv[4][TQ_NG];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+#pragma unroll
+			for (int g = 0; g < TQ_NG; ++g)
+				cv[u][g] = bb < a.t ? a.C[((long) g * 64 + ig + 16 * u) * a.ldc + bb] : 0.0;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			double c = 0.0;
+#pragma unroll
+			for (int g = 0; g < TQ_NG; ++g)
+				c += cv[u][g];
+			v[(ig + 16 * u) * 17 + (tid & 15)] = c;
+		}
+	}
 	__syncthreads();
-	if (ig == 0 && colok) {
+	// acc = Am (rows 16 wv .., masked: lower / upper triangle incl. the diagonal) * Bv (64 x 16)
+	auto mm16 = [&](const double *Am, const double *Bv, bool lower) {
+		f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+		const int i = 16 * wv + (lane & 15);
+#pragma unroll 4
+		for (int k0 = 0; k0 < 64; k0 += 4) {
+			const int l = k0 + (lane >> 4);
+			double av = Am[i * TQ_DP + l];
+			if (lower ? l > i : l < i)
+				av = 0.0;
+			acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bv[l * 17 + (lane & 15)], acc, 0, 0, 0);
+		}
+		return acc;
+	};
+	// D = R^-T C: the new top rows of X; E = D - X_top
+	{
+		const f64x4 acc = mm16(n1, v, true);
+		double dsq = 0.0;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int i = 16 * wv + (lane >> 4) + 4 * r;
+			dsq += acc[r] * acc[r];
+			float *xp = a.A + (long) (a.cx + b) * a.ld + a.r0 + i;
+			double xt = 0.0;
+			if (colok && i < a.w) {
+				xt = (double) *xp;
+				*xp = (float) acc[r];
+			}
+			v2[i * 17 + bl] = acc[r] - xt;
+		}
+		sred[tid] = dsq;
+	}
+	__syncthreads();
+	// column norms of the R rows just produced (rank test of the later panels)
+	if (tid < 16 && blockIdx.x * 16 + tid < a.t) {
 		double s = 0.0;
 		for (int g = 0; g < 16; ++g)
-			s += sred[g * 16 + bl];
-		a.abv[a.cx + b] += s;
+			s += sred[g * 16 + tid]; // (tid & 15 == column in every group of 16 threads)
+		a.abv[a.cx + blockIdx.x * 16 + tid] += s;
 	}
 	// zn = V1^-1 (D - X_top) = -Z, then  -Y = M zn  (Y = R^-1 U^-1 V1^-1 (D - X_top), M = -(U R)^-1 upper triangular)
-#pragma unroll 1
-	for (int u = 0; u < 4; ++u) {
-		const int k = ig + 16 * u;
-		double zz = 0.0;
-		for (int l = 0; l <= k; ++l)
-			zz += n3[k * TQ_DP + l] * v2[l * 17 + bl];
-		v[k * 17 + bl] = zz; // (every read of the C sums in v is behind the barrier above)
-		if (colok)
-			a.Z[(long) k * a.ldz + a.cx + b] = -zz;
+	{
+		const f64x4 acc = mm16(n3, v2, true);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int k = 16 * wv + (lane >> 4) + 4 * r;
+			v[k * 17 + bl] = acc[r]; // (every read of the C sums in v is behind the barrier above)
+			if (colok)
+				a.Z[(long) k * a.ldz + a.cx + b] = -acc[r];
+		}
 	}
 	__syncthreads();
-#pragma unroll 1
-	for (int u = 0; u < 4; ++u) {
-		const int k = ig + 16 * u;
-		double acc = 0.0;
-		for (int l = k; l < 64; ++l)
-			acc += mm[k * TQ_DP + l] * v[l * 17 + bl];
-		if (b < a.typ)
-			a.Yn[(long) k * a.typ + b] = colok ? (float) acc : 0.f;
+	{
+		const f64x4 acc = mm16(mm, v, false);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int k = 16 * wv + (lane >> 4) + 4 * r;
+			if (b < a.typ)
+				a.Yn[(long) k * a.typ + b] = colok ? (float) acc[r] : 0.f;
+		}
 	}
 }
 
@@ -1296,7 +1334,10 @@ template <bool VEC> __global__ __launch_bounds__(256, 1) void tq_update_kernel(c
 	const int lam = lane & 31, h = lane >> 5;
 	const int nx = (a.ts + 31) >> 5;	   // 32-column strips of X
 	const int nv = a.do_v ? (a.w + 31) >> 5 : 0; // strips of V
-	for (int rb = blockIdx.x * 4 + wv; rb < a.nrb; rb += gridDim.x * 4) {
+	for (int rbi = blockIdx.x * 4 + wv; rbi < a.nrb; rbi += gridDim.x * 4) {
+		// The row blocks are visited from the LAST one up, the Gram launches read from the first row down: each pass starts with what the
+		// pass before it touched last, i.e. with what the memory-side cache (256 MB) still holds
+		const int rb = a.nrb - 1 - rbi;
 		const int rows = a.rows - rb * 128; // valid rows from the block's first row (may exceed 128)
 		const float *Pb = a.P + (long) rb * 128;
 		float *Xb = a.X + (long) rb * 128;
@@ -1738,7 +1779,7 @@ static void tq_launch_update(bool vec, int nwg, const TqUpdArgs &ua)
 }
 
 static void tq_gram(const float *P, const float *X, long ld, int rows, int w, int t, bool want_g, bool want_sq, bool vec, double *Gp, float *Cp,
-		    float *Sp, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0, float *A1s, double *Gf, int *cnt)
+		    float *Sp, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0, float *A1s, double *Gf, int *cnt, int nb_max)
 {
 	hipStream_t s = ctx().stream;
 	TqGramArgs g;
@@ -1758,7 +1799,8 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 	g.Sp = Sp;
 	g.stat = stat;
 	g.c0 = c0;
-	const int nb = g.nchunks < TQ_NB ? g.nchunks : TQ_NB;
+	const int nbmax = nb_max > 0 && nb_max < TQ_NB ? nb_max : TQ_NB;
+	const int nb = g.nchunks < nbmax ? g.nchunks : nbmax;
 	if (nb <= 0)
 		return;
 	{
@@ -1858,6 +1900,10 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	const bool cross = bs > TQ_PW && npan > 1;
 	if (cross)
 		FH_HIP(hipMemsetAsync(Z, 0, (size_t) npan * 64 * ldz * 8, s));
+	const int ncu_all = ctx().stream_cus();
+	int cus_taken = 0; // CUs held by side-stream kernels while the persistent update kernels run
+	// two Gram workgroups per CU; a CU held by a side-stream kernel (its LDS leaves no room for one) would run its two AFTER the others
+	auto gram_nb = [&]() { return cus_taken > 0 && ncu_all - cus_taken > 8 ? 2 * (ncu_all - cus_taken) : TQ_NB; };
 	// Gram launches of panel [c0, c0 + w), rows from c0 down: G (want_g) and / or C against the columns [cx, cx + t) in strips
 	// of <= 192
 	auto launch_gram = [&](int c0, int w, bool want_g, int cx, int t, bool first, double *Sd) {
@@ -1865,14 +1911,14 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		const int rows = (int) (m - c0);
 		if (t == 0) {
 			if (want_g)
-				tq_gram(P, P, ld, rows, w, 0, true, first, vec, gp.as<double>(), cp.as<float>(), sp.as<float>(), G, C, ldc, 0, Sd, stat, c0, A1s, Gf, stat + 128);
+				tq_gram(P, P, ld, rows, w, 0, true, first, vec, gp.as<double>(), cp.as<float>(), sp.as<float>(), G, C, ldc, 0, Sd, stat, c0, A1s, Gf, stat + 128, gram_nb());
 			return;
 		}
 		for (int off = 0; off < t; off += TQ_TS) {
 			const int ts = t - off < TQ_TS ? t - off : TQ_TS;
 			// the range guard of these launches covers the first strip only (n <= 256); tq_range_rest_kernel checks the others
 			tq_gram(P, A.p + (long) (cx + off) * ld + c0, ld, rows, w, ts, want_g && off == 0, first && off == 0, vec, gp.as<double>(),
-				cp.as<float>(), sp.as<float>(), G, C, ldc, cx + off - (c0 + w), Sd, stat, c0, A1s, Gf, stat + 128);
+				cp.as<float>(), sp.as<float>(), G, C, ldc, cx + off - (c0 + w), Sd, stat, c0, A1s, Gf, stat + 128, gram_nb());
 		}
 	};
 	auto tx_args = [&]() {
@@ -1936,8 +1982,6 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	// columns).  Two variants that forced it (always / a split Gram launch beside the panel kernel) measured slower and are
 	// gone: profiles/r03_qr_lookahead.txt keeps the record.
 	const TqSide side = tq_side();
-	const int ncu_all = ctx().stream_cus();
-	int cus_taken = 0; // CUs held by side-stream kernels while the persistent update kernels run
 	bool tx_on_side = false;
 	bool panel_on_side = false;
 	// Gram products and panel kernel of panel p
@@ -2040,10 +2084,27 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 				tq_launch_update(v2, nwg, ua);
 			}
 		};
+		// everything of the cross-panel T blocks that does not depend on the last panel's kernel: beside the Gram / reduce / panel
+		// kernels of the last panel (a single workgroup busy most of that time), one CU per panel.  The fork is recorded BEHIND the
+		// update of step npan - 2 and IN FRONT of the last panel's launches (rounds 3-5 recorded it behind them: the stage then ran
+		// beside the last update and the factorization ended with ~110 us of three workgroups)
+		auto tx_stage1 = [&]() {
+			if (!(two_stage && k == npan - 2))
+				return;
+			TqTxArgs t1 = tx_args();
+			t1.stage = 1;
+			FH_HIP(hipEventRecord(side.xfork, s));
+			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
+			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.tx, t1);
+			tx_on_side = true;
+			if (ncu_all > 8 * npan)
+				cus_taken += npan - 1;
+		};
 		if (t == 0) {
 			update(0, 0, true);
 		} else if (t - wn < TQ_TS) {
 			update(0, t, true);
+			tx_stage1();
 			gram_and_panel(k + 1, false);
 		} else {
 			update(0, wn, false);
@@ -2057,18 +2118,8 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			update(wn, t, true);
 			launch_gram(c0 + w, wn, false, c0 + w + wn, t - wn, false, S);
 		}
-		if (two_stage && k == npan - 2) {
-			// everything of the cross-panel T blocks that does not depend on the last panel's kernel: beside the Gram / reduce /
-			// panel kernels of the last panel (a single workgroup busy most of that time), one CU per panel
-			TqTxArgs t1 = tx_args();
-			t1.stage = 1;
-			FH_HIP(hipEventRecord(side.xfork, s));
-			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
-			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.tx, t1);
-			tx_on_side = true;
-			if (ncu_all > 8 * npan)
-				cus_taken += npan - 1;
-		}
+		if (!tx_on_side)
+			tx_stage1(); // (the look-ahead branch: behind its last launch, as before)
 		FH_HIP(hipGetLastError());
 	}
 	if (cross) {
