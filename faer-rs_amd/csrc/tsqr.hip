@@ -30,6 +30,8 @@
 // column fails the reference's rank test (factor.rs:52-64, evaluated from R): nothing of that panel has been written
 // at that point, every earlier reflector has been applied to everything right of it, and geqrf_dev continues with the
 // classic path on the remaining submatrix.  fp64 input never comes here (it would need a wider Gram accumulator).
+#include <atomic>
+
 #include "common.h"
 
 namespace fh {
@@ -1401,6 +1403,279 @@ template <bool VEC> __global__ __launch_bounds__(256, 1) void tq_update_kernel(c
 }
 
 // ------------------------------------------------------------------------------------------------
+// update + Gram in ONE pass (round 6): panel k's block reflector applied to the next panel's columns N and / or a strip F of the columns
+// behind them, V = P M, and -- from the UPDATED values, which never leave the CU in between -- the Gram products of panel k + 1:
+// G' = N'^T N' (fp64 matrix cores) and C' = N'^T F' (fp32).  Rounds 3-5 wrote X' out and read it back for the Gram launch: 2.5 of the 7.5
+// passes of a 5e5 x 256 factorization.  64-row chunks are staged through LDS as [P | N | F] (column major, quads of four consecutive rows);
+//   update   a wavefront owns one 32-row half of the chunk and up to three 32-column tiles: D = X + P (-Y) on v_mfma_f32_32x32x2 with the
+//            P operand from LDS and ITS -Y operand in registers for the whole launch (the tiles of a wavefront are the same in every
+//            chunk); the result map of the instruction (lane = column, registers = four groups of four consecutive rows) goes back into
+//            the chunk as 16-byte quads; V = P M the same way into its own 64 columns of LDS;
+//   store    every thread writes the quads it staged (its own columns: 16-byte stores, 256 contiguous bytes per column and 16 lanes);
+//   gram     the products of tq_gram_kernel on the updated chunk.
+// Modes (driver): U1 = N updated, G' formed (the panel kernel of k + 1 starts behind it); U2 = N read only, F updated, C' formed, beside
+// that panel kernel; V = P M rides on whichever of the two runs beside the panel kernel.
+// ------------------------------------------------------------------------------------------------
+struct TqFusedArgs {
+	float *P;	// A[r1, c0]: panel k below its top block
+	float *N;	// A[r1, c0 + w]: the next panel's columns
+	float *F;	// A[r1, c0 + w + wn + fo]: a strip of the columns behind them
+	long ld;
+	int rows;	// m - r1
+	int w, wn, ts;	// widths: panel (<= 64), next panel (<= 64, 0: none), strip (<= 128, 0: none)
+	int upd_n;	// N is updated (else read only: the A operand of C')
+	int do_v, want_g;
+	const float *Yn; // -Y, row major 64 x typ, column = index inside the trailing block
+	int typ, fo;	// fo: first column of F behind N
+	const float *Mn; // M, row major 64 x 64
+	double *Gp;	// [grid][64 * 64]
+	float *Cp;	// [grid][64 * tp]
+	int tp;		// ts rounded up to 32
+	int nchunks;
+	float *A1s;	// want_g: the next panel's (updated) top 64 x 64 block, column major, for the panel kernel
+	long ldp;	// leading dimension of P (MODE 2 may read the panel from the copy)
+	float *Pc;	// MODE 1 with do_v: if set, the RAW panel rows are saved here (leading dimension ldpc) for the U2 launches that follow
+	long ldpc;
+	const int *stat;
+	int c0;
+};
+
+constexpr int TU_CF = 128;		      // widest strip F
+// Barrier between LDS phases that leaves global memory operations in flight (__syncthreads() is a workgroup-scope fence as well)
+static __device__ __forceinline__ void tq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// MODE 1 (U1): stages [P | N], updates N, forms G', V = P M if asked.  MODE 2 (U2): stages [P | N | F], updates F, forms C' = N^T F'.
+// Two variants instead of one general kernel: each needs fewer than 256 registers and 52 / 70 KB of LDS, so TWO workgroups share a CU --
+// twice the bytes in flight (one general workgroup per CU with one 64 KB chunk in flight ran at 1.2-1.6 TB/s: a chunk per memory round
+// trip) and one workgroup's products behind the other's barriers.
+template <bool VEC, int MODE> __global__ __launch_bounds__(MODE == 1 ? 256 : 512, MODE == 1 ? 2 : 4) void tq_fused_kernel(const TqFusedArgs a)
+{
+	constexpr int NTHR = MODE == 1 ? 256 : 512; // MODE 2: eight wavefronts, one tile of F and one of C' each
+	constexpr int CGN = NTHR / 16;		    // columns staged per pass of the threads
+	constexpr int NC = MODE == 1 ? 2 * TQ_PW : 2 * TQ_PW + TU_CF; // staged columns
+	constexpr int NQ = NC / CGN;				       // quads per thread and chunk
+	constexpr int NT = 1;					       // column tiles per wavefront
+	__shared__ float sm[NC * TQ_LP];
+	__shared__ float vs[MODE == 1 ? TQ_PW * TQ_LP : 4];
+	if (tq_skip(a.stat, a.c0))
+		return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int quad = tid & 15, cg = tid >> 4;
+	const int lam = lane & 31, h = lane >> 5;
+	const int rt = wv & 1, cp = wv >> 1; // this wavefront's 32-row half of a chunk, and the parity of its column tiles
+	// ---- the wavefront's operands of the whole launch: -Y for its column tiles (MODE 1: tile cp of N; MODE 2: tile cp of F), M for its V tile
+	float yreg[NT][32], mreg[MODE == 1 ? 32 : 1];
+	bool act[NT];
+#pragma unroll
+	for (int u = 0; u < NT; ++u) {
+		const int cl = 32 * cp; // first column of the tile inside N / F
+		act[u] = MODE == 1 ? cl < a.wn : cl < a.ts;
+		const bool cok = MODE == 1 ? cl + lam < a.wn : cl + lam < a.ts;
+		const int yc = MODE == 1 ? cl + lam : a.wn + a.fo + cl + lam;
+#pragma unroll
+		for (int s2 = 0; s2 < 32; ++s2) {
+			const int k = 2 * s2 + h;
+			yreg[u][s2] = (act[u] && cok && k < a.w) ? a.Yn[(long) k * a.typ + yc] : 0.f;
+		}
+	}
+	const bool vact = MODE == 1 && a.do_v && 32 * cp < a.w;
+	if (MODE == 1) {
+#pragma unroll
+		for (int s2 = 0; s2 < 32; ++s2) {
+			const int k = 2 * s2 + h;
+			mreg[s2] = (vact && k < a.w && 32 * cp + lam < a.w) ? a.Mn[k * 64 + 32 * cp + lam] : 0.f;
+		}
+	}
+	const int ntile = MODE == 2 ? 2 * (a.tp >> 5) : 0; // 32 x 32 tiles of C'
+	f64x4 gacc[MODE == 1 ? 3 : 1];
+	f32x16 cacc[1];
+#pragma unroll
+	for (int i = 0; i < (MODE == 1 ? 3 : 1); ++i)
+		gacc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int r = 0; r < 16; ++r)
+		cacc[0][r] = 0.f;
+	// column c of the staged chunk: source pointer (nullptr: not staged) -- thread (quad, cg) stages the columns 16 i + cg
+	auto col_ptr = [&](int c) -> float * {
+		if (c < TQ_PW)
+			return c < a.w ? a.P + (long) c * a.ldp : nullptr;
+		if (c < 2 * TQ_PW)
+			return c - TQ_PW < a.wn ? a.N + (long) (c - TQ_PW) * a.ld : nullptr;
+		return c - 2 * TQ_PW < a.ts ? a.F + (long) (c - 2 * TQ_PW) * a.ld : nullptr;
+	};
+	f32x4 st[NQ];
+	auto load_chunk = [&](int ch) {
+		const int rbase = ch * 64 + quad * 4;
+#pragma unroll
+		for (int i = 0; i < NQ; ++i) {
+			f32x4 v = {0.f, 0.f, 0.f, 0.f};
+			const float *src = col_ptr(i * CGN + cg);
+			if (src && rbase < a.rows) {
+				src += rbase;
+				if (VEC && rbase + 3 < a.rows) {
+					v = *reinterpret_cast<const f32x4 *>(src);
+				} else {
+#pragma unroll
+					for (int e = 0; e < 4; ++e)
+						if (rbase + e < a.rows)
+							v[e] = src[e];
+				}
+			}
+			st[i] = v;
+		}
+	};
+	auto store_quad = [&](float *dst, int rbase, f32x4 v) {
+		if (rbase >= a.rows)
+			return;
+		dst += rbase;
+		if (VEC && rbase + 3 < a.rows) {
+			*reinterpret_cast<f32x4 *>(dst) = v;
+		} else {
+#pragma unroll
+			for (int e = 0; e < 4; ++e)
+				if (rbase + e < a.rows)
+					dst[e] = v[e];
+		}
+	};
+	constexpr int XC0 = MODE == 1 ? TQ_PW : 2 * TQ_PW; // first staged column of the updated block
+	int ch = blockIdx.x;
+	if (ch < a.nchunks)
+		load_chunk(ch);
+	for (; ch < a.nchunks; ch += gridDim.x) {
+		tq_lds_barrier(); // the previous chunk has been consumed
+#pragma unroll
+		for (int i = 0; i < NQ; ++i)
+			*reinterpret_cast<f32x4 *>(&sm[(i * CGN + cg) * TQ_LP + quad * 4]) = st[i];
+		tq_lds_barrier();
+		if (ch + (int) gridDim.x < a.nchunks)
+			load_chunk(ch + gridDim.x); // in flight during the products
+		// ---- update: D = X + P (-Y), tiles (rt, cp + 2 u); V = P M
+		{
+			f32x16 acc[NT], vacc;
+#pragma unroll
+			for (int u = 0; u < NT; ++u) {
+				const int c0l = XC0 + 32 * cp + lam;
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					const f32x4 x = *reinterpret_cast<const f32x4 *>(&sm[c0l * TQ_LP + 32 * rt + 8 * g + 4 * h]);
+#pragma unroll
+					for (int e = 0; e < 4; ++e)
+						acc[u][4 * g + e] = x[e];
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < 16; ++r)
+				vacc[r] = 0.f;
+#pragma unroll
+			for (int s2 = 0; s2 < 32; ++s2) {
+				const float pv = sm[(2 * s2 + h) * TQ_LP + 32 * rt + lam];
+#pragma unroll
+				for (int u = 0; u < NT; ++u)
+					if (act[u]) // (uniform)
+						acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, yreg[u][s2], acc[u], 0, 0, 0);
+				if (MODE == 1 && vact)
+					vacc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, mreg[s2], vacc, 0, 0, 0);
+			}
+#pragma unroll
+			for (int u = 0; u < NT; ++u)
+				if (act[u]) {
+					const int c0l = XC0 + 32 * cp + lam;
+#pragma unroll
+					for (int g = 0; g < 4; ++g)
+						*reinterpret_cast<f32x4 *>(&sm[c0l * TQ_LP + 32 * rt + 8 * g + 4 * h]) =
+							f32x4{acc[u][4 * g], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]};
+				}
+			if (MODE == 1 && vact) {
+#pragma unroll
+				for (int g = 0; g < 4; ++g)
+					*reinterpret_cast<f32x4 *>(&vs[(32 * cp + lam) * TQ_LP + 32 * rt + 8 * g + 4 * h]) =
+						f32x4{vacc[4 * g], vacc[4 * g + 1], vacc[4 * g + 2], vacc[4 * g + 3]};
+			}
+		}
+		tq_lds_barrier();
+		// ---- store: the quads this thread staged
+		{
+			const int rbase = ch * 64 + quad * 4;
+#pragma unroll
+			for (int i = 0; i < NQ; ++i) {
+				const int c = i * CGN + cg;
+				if (c < TQ_PW) {
+					if (MODE == 1 && a.do_v && c < a.w) {
+						store_quad(a.P + (long) c * a.ld, rbase, *reinterpret_cast<const f32x4 *>(&vs[c * TQ_LP + quad * 4]));
+						if (a.Pc)
+							store_quad(a.Pc + (long) c * a.ldpc, rbase, *reinterpret_cast<const f32x4 *>(&sm[c * TQ_LP + quad * 4]));
+					}
+				} else if (c < 2 * TQ_PW) {
+					if (MODE == 1 && c - TQ_PW < a.wn) {
+						const f32x4 v = *reinterpret_cast<const f32x4 *>(&sm[c * TQ_LP + quad * 4]);
+						store_quad(a.N + (long) (c - TQ_PW) * a.ld, rbase, v);
+						if (ch == 0 && a.want_g)
+							*reinterpret_cast<f32x4 *>(a.A1s + (c - TQ_PW) * 64 + quad * 4) = v;
+					}
+				} else if (c - 2 * TQ_PW < a.ts) {
+					store_quad(a.F + (long) (c - 2 * TQ_PW) * a.ld, rbase, *reinterpret_cast<const f32x4 *>(&sm[c * TQ_LP + quad * 4]));
+				}
+			}
+		}
+		// ---- gram on the updated chunk (tq_gram_kernel's products with N in the place of its panel and F in the place of its X)
+		if (MODE == 1 && a.want_g) {
+			const int t0 = wv == 0 ? 0x30 : (wv == 1 ? 0x33 : (wv == 2 ? 0x22 : 0x00)); // (ia << 4) | ib
+			const int t1 = wv == 0 ? 0x31 : (wv == 1 ? 0x20 : (wv == 2 ? 0x10 : -1));
+			const int t2 = wv == 0 ? 0x32 : (wv == 1 ? 0x21 : (wv == 2 ? 0x11 : -1));
+#pragma unroll
+			for (int s4 = 0; s4 < 4; ++s4) {
+				const int roff = 16 * s4 + 4 * (lane >> 4);
+#pragma unroll
+				for (int u = 0; u < 3; ++u) {
+					const int tt = u == 0 ? t0 : (u == 1 ? t1 : t2);
+					if (tt >= 0) { // wave uniform
+						const f32x4 av = *reinterpret_cast<const f32x4 *>(&sm[(TQ_PW + 16 * (tt >> 4) + (lane & 15)) * TQ_LP + roff]);
+						const f32x4 bv = *reinterpret_cast<const f32x4 *>(&sm[(TQ_PW + 16 * (tt & 15) + (lane & 15)) * TQ_LP + roff]);
+#pragma unroll
+						for (int q = 0; q < 4; ++q)
+							gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double) av[q], (double) bv[q], gacc[u], 0, 0, 0);
+					}
+				}
+			}
+		}
+		if (MODE == 2 && wv < ntile) { // tile wv of C': N half wv & 1, strip wv >> 1 of F
+			const int ia = wv & 1, ib = wv >> 1;
+#pragma unroll
+			for (int s8 = 0; s8 < 8; ++s8) {
+				const int roff = 8 * s8 + 4 * (lane >> 5);
+				const f32x4 av = *reinterpret_cast<const f32x4 *>(&sm[(TQ_PW + 32 * ia + lam) * TQ_LP + roff]);
+				const f32x4 bv = *reinterpret_cast<const f32x4 *>(&sm[(2 * TQ_PW + 32 * ib + lam) * TQ_LP + roff]);
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+					cacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], cacc[0], 0, 0, 0);
+			}
+		}
+	}
+	const long blk = blockIdx.x;
+	if (MODE == 1 && a.want_g) {
+		const int t0 = wv == 0 ? 0x30 : (wv == 1 ? 0x33 : (wv == 2 ? 0x22 : 0x00));
+		const int t1 = wv == 0 ? 0x31 : (wv == 1 ? 0x20 : (wv == 2 ? 0x10 : -1));
+		const int t2 = wv == 0 ? 0x32 : (wv == 1 ? 0x21 : (wv == 2 ? 0x11 : -1));
+#pragma unroll
+		for (int u = 0; u < 3; ++u) {
+			const int tt = u == 0 ? t0 : (u == 1 ? t1 : t2);
+			if (tt >= 0) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					a.Gp[blk * 4096 + (16 * (tt >> 4) + (lane >> 4) + 4 * r) * 64 + 16 * (tt & 15) + (lane & 15)] = gacc[u][r];
+			}
+		}
+	}
+	if (MODE == 2 && wv < ntile) {
+		const int ia = wv & 1, ib = wv >> 1;
+#pragma unroll
+		for (int r = 0; r < 16; ++r) {
+			const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+			a.Cp[blk * 64 * a.tp + (long) (32 * ia + i) * a.tp + 32 * ib + lam] = cacc[0][r];
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // cross-panel blocks of T inside one block of Q_coeff, from small matrices only (no pass over V).
 // After the block reflector of panel k has been applied,  V_k^T X' = -T_k Z_k  (T_k + T_k^T = V_k^T V_k), and every
 // later reflector changes it by  -(V_k^T V_j) Z_j = -T_kj Z_j.  With V_l = (A~_l - [R_l; 0]) M_l below row c_l and zero above:
@@ -1816,6 +2091,28 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 	FH_HIP(hipGetLastError());
 }
 
+static std::atomic<int> g_tq_fused{1};
+void tsqr_debug_fused(int on) { g_tq_fused.store(on); }
+
+static void tq_launch_fused(bool vec, int mode, int nwg, const TqFusedArgs &fa)
+{
+	hipStream_t s = ctx().stream;
+	// (profile class 2; algorithmic bytes of the launch: everything staged read once, N / F / V written once)
+	ProfScope prof(2, (double) fa.rows * 4.0 *
+				  ((double) fa.w + (double) fa.wn + (mode == 1 ? (double) fa.wn + (fa.do_v ? (double) fa.w : 0.0) : 2.0 * (double) fa.ts)));
+	if (mode == 1) {
+		if (vec)
+			hipLaunchKernelGGL((tq_fused_kernel<true, 1>), dim3(nwg), dim3(256), 0, s, fa);
+		else
+			hipLaunchKernelGGL((tq_fused_kernel<false, 1>), dim3(nwg), dim3(256), 0, s, fa);
+	} else {
+		if (vec)
+			hipLaunchKernelGGL((tq_fused_kernel<true, 2>), dim3(nwg), dim3(512), 0, s, fa);
+		else
+			hipLaunchKernelGGL((tq_fused_kernel<false, 2>), dim3(nwg), dim3(512), 0, s, fa);
+	}
+}
+
 // side streams of the factorization (owned by the per-thread context, ctx.hip): the panel kernel of step k + 1 (one
 // workgroup) beside the rest of step k's update, and the cross-panel T blocks beside the last steps
 struct TqSide {
@@ -1975,6 +2272,21 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		hipLaunchKernelGGL(tq_panel_kernel, dim3(1), dim3(TQ_PT), 0, ps, pa);
 	};
 	// one block of Q_coeff over all panels (the tall-skinny case): the cross-panel blocks of T in two stages beside the last steps
+	const bool fused = g_tq_fused.load() != 0;
+	// raw copy of the current panel below its top block for the U2 launches (see there); not for matrices where it would exceed 1 GiB
+	const long ldpc = (long) ((m + 63) & ~(idx_t) 63);
+	const bool want_copy = fused && npan > 2 && (size_t) ldpc * TQ_PW * sizeof(float) <= ((size_t) 1 << 30);
+	struct OptScratch {
+		void *p = nullptr;
+		~OptScratch()
+		{
+			if (p)
+				ctx().release(p);
+		}
+		float *f() const { return static_cast<float *>(p); }
+	} pcopy;
+	if (want_copy)
+		pcopy.p = ctx().alloc((size_t) ldpc * TQ_PW * sizeof(float));
 	const bool two_stage = cross && bs >= n && bs <= (TQ_TX_MAXL + 1) * TQ_PW && npan >= 2;
 	// look-ahead: the columns of the next panel are updated first, its Gram matrix and its panel kernel (ONE workgroup, ~110 us)
 	// follow at once, and the rest of the update + the products against the next panel run beside that kernel.  It is on where
@@ -1996,7 +2308,26 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		hipLaunchKernelGGL(tq_range_rest_kernel, dim3((unsigned) (n - (TQ_PW + TQ_TS))), dim3(256), 0, s, A.p, (long) ld, (int) m, TQ_PW + TQ_TS, stat);
 		FH_HIP(hipGetLastError());
 	}
-	gram_and_panel(0, true);
+	double *Sy = S; // the column squares the first y kernel checks
+	if (fused && n > TQ_PW) {
+		// the first panel's kernel needs G only: the products against the trailing columns (most of the first Gram launch: 190 us) run on
+		// the side stream beside it; their column squares go to the second slab of S
+		const int w0 = TQ_PW, t0 = (int) n - TQ_PW;
+		launch_gram(0, w0, true, w0, 0, true, S);
+		FH_HIP(hipEventRecord(side.pfork, s));
+		FH_HIP(hipStreamWaitEvent(side.panel, side.pfork, 0));
+		cus_taken += 1;
+		{
+			StreamScope sc(side.panel);
+			Sy = S + (size_t) TQ_NG * 256;
+			launch_gram(0, w0, false, w0, t0, true, Sy);
+			FH_HIP(hipEventRecord(side.pdone, side.panel));
+		}
+		launch_panel(0, s);
+		panel_on_side = true;
+	} else {
+		gram_and_panel(0, true);
+	}
 	for (int k = 0; k < npan; ++k) {
 		const int c0 = k * TQ_PW;
 		const int w = (int) (n - c0 < TQ_PW ? n - c0 : TQ_PW);
@@ -2027,7 +2358,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			ya.ldz = ldz;
 			ya.top = top;
 			ya.stat = stat;
-			ya.Sr = S;
+			ya.Sr = Sy;
 			ya.check_range = k == 0;
 			ya.range_cols = t < TQ_TS ? t : TQ_TS;
 			ya.mrows = (int) m;
@@ -2100,7 +2431,85 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			if (ncu_all > 8 * npan)
 				cus_taken += npan - 1;
 		};
-		if (t == 0) {
+		if (fused && t > 0) {
+			// ---- round 6: update + Gram in one pass, the next panel's kernel beside the second half
+			const int nchunks = (rows + 63) / 64;
+			TqFusedArgs fa;
+			fa.P = ua.P;
+			fa.N = A.p + (long) (c0 + w) * ld + r1;
+			fa.F = fa.N;
+			fa.ld = ld;
+			fa.ldp = ld;
+			fa.rows = rows;
+			fa.w = w;
+			fa.wn = wn;
+			fa.ts = 0;
+			fa.upd_n = 1;
+			// V overwrites the panel, which the U2 launches read again: U1 leaves them a copy of the raw rows (one more write of 64
+			// columns; a separate V launch behind U2 costs a read and a write and ran beside the next step's first kernels: the y kernel
+			// 17 -> 80 us, U1 114 -> 180 us)
+			const bool copyp = t - wn > 0 && pcopy.p != nullptr;
+			fa.do_v = t - wn == 0 || copyp;
+			fa.Pc = copyp ? pcopy.f() : nullptr;
+			fa.ldpc = ldpc;
+			fa.want_g = 1;
+			fa.Yn = Yn;
+			fa.typ = typ;
+			fa.fo = 0;
+			fa.Mn = Mn + (size_t) k * 4096;
+			fa.Gp = gp.as<double>();
+			fa.Cp = cp.as<float>();
+			fa.tp = 0;
+			fa.nchunks = nchunks;
+			fa.A1s = A1s;
+			fa.stat = stat;
+			fa.c0 = c0;
+			auto grid = [&]() { // two workgroups per CU
+				const int ncu = ncu_all - cus_taken > 8 ? ncu_all - cus_taken : ncu_all;
+				return nchunks < 2 * ncu ? nchunks : 2 * ncu;
+			};
+			const int nc0 = c0 + w; // first column of the next panel
+			// U1: the next panel's columns, its Gram matrix, V = P M
+			int nb = grid();
+			tq_launch_fused(v2, 1, nb, fa);
+			hipLaunchKernelGGL(tq_reduce_kernel, dim3(4096 / 256, TQ_NG), dim3(256), 0, s, fa.Gp, fa.Cp, sp.as<float>(), nb, 0, 1, 0, G, C, ldc, 0, S, stat, nc0, Gf,
+					   stat + 128);
+			if (t - wn > 0) {
+				// U2 (side stream): the columns behind it and C'; the next panel's kernel runs on the main stream meanwhile
+				FH_HIP(hipEventRecord(side.pfork, s));
+				FH_HIP(hipStreamWaitEvent(side.panel, side.pfork, 0));
+				cus_taken += 1;
+				{
+					StreamScope sc(side.panel);
+					fa.upd_n = 0;
+					fa.want_g = 0;
+					fa.do_v = 0;
+					if (copyp) {
+						fa.P = pcopy.f();
+						fa.ldp = ldpc;
+					}
+					for (int fo = 0; fo < t - wn; fo += TU_CF) {
+						fa.ts = t - wn - fo < TU_CF ? t - wn - fo : TU_CF;
+						fa.tp = (fa.ts + 31) & ~31;
+						fa.fo = fo;
+						fa.F = A.p + (long) (nc0 + wn + fo) * ld + r1;
+						nb = grid();
+						tq_launch_fused(v2, 2, nb, fa);
+						hipLaunchKernelGGL(tq_reduce_kernel, dim3((64 * fa.tp + 255) / 256, TQ_NG), dim3(256), 0, side.panel, fa.Gp, fa.Cp, sp.as<float>(), nb,
+								   fa.tp, 0, 0, G, C, ldc, fo, S, stat, nc0, Gf, stat + 128);
+					}
+					FH_HIP(hipEventRecord(side.pdone, side.panel));
+					// V = P M once nothing reads the panel any more: behind U2 on the side stream, beside the next step's first
+					// launches (nothing waits for it before the end of the factorization or the cross-panel T blocks)
+					// (only without the raw copy: matrices too tall for it)
+					if (!copyp)
+						update(0, 0, true);
+				}
+				panel_on_side = true; // (here: U2 is what runs on the side stream)
+			}
+			tx_stage1(); // (k == npan - 2: on the side stream, beside the last panel's kernel)
+			launch_panel(k + 1, s);
+		} else if (t == 0) {
 			update(0, 0, true);
 		} else if (t - wn < TQ_TS) {
 			update(0, t, true);
@@ -2133,6 +2542,10 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			hipLaunchKernelGGL(tq_tx_general_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
 		}
 		FH_HIP(hipGetLastError());
+	}
+	if (fused && npan > 1) { // the V launches on the side stream
+		FH_HIP(hipEventRecord(side.pdone, side.panel));
+		FH_HIP(hipStreamWaitEvent(s, side.pdone, 0));
 	}
 	int *st = ctx().pinned_ints(); // (a pageable target makes the copy a staged, blocking one)
 	FH_HIP(hipMemcpyAsync(st, stat, 4 * sizeof(int), hipMemcpyDeviceToHost, s));

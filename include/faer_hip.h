@@ -494,6 +494,9 @@ FAER_HIP_API void faer_hip_debug_lu_plan(size_t nb2_from, size_t pipe_from, size
  * qr_factor_in_place (== ncols: the whole factorization; fewer: a panel was rejected and the classic path finished; -1: the
  * path was not applicable) */
 FAER_HIP_API long faer_hip_debug_qr_one_pass_columns(void);
+/* tests / A-B measurements: 0 = the one-pass QR path applies a panel and forms the next panel's Gram products in separate launches (the
+ * round 3-5 schedule), 1 (default) = in one pass per panel with the next panel's kernel beside its second half (csrc/tsqr.hip). */
+FAER_HIP_API void faer_hip_debug_qr_fused(int on);
 /* host logic of the distributed LU: may a step factor its look-ahead panel of `panel_rows` rows on the CU-masked panel stream? */
 FAER_HIP_API int faer_hip_debug_dist_two_streams_ok(size_t panel_rows, FaerHipDType dtype, int panel_cus, int all_cus);
 /* Instrumented builds (make -C csrc timing): prints and resets the in-kernel phase counters; a no-op otherwise. */
