@@ -434,7 +434,7 @@ def main():
             if c["launches"] == 0 or c["ms"] <= 0:
                 return None
             gbs = c["units"] / (c["ms"] * 1e-3) / 1e9
-            r = {"bound": "hbm", "kernel_class": "tq_update_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            r = {"bound": "hbm", "kernel_class": "tq_fused_kernel<1|2> + tq_update_kernel (panel applied, next panel's Gram products formed in the same pass)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": c["launches"], "launch_ms_avg": round(c["ms"] / c["launches"], 4),
                  "class_ms": round(c["ms"], 3), "class_share_of_step": round(c["ms"] / step_ms, 4), "algorithmic_bytes_in_class": c["units"],
                  "measured": "this run: HIP events around every launch of the class, one profiled repetition"}

@@ -1822,6 +1822,7 @@ template <typename T> struct BdArgs {
 	idx_t rs, cs;
 	int m, n, size, k;
 	T *y, *z, *ysum, *zsum, *vrow, *taul, *taur;
+	double *ypart, *zpart; // shares of the tiles: ypart[row block * n + j], zpart[column block * m + i]
 	BdState *st;
 };
 
@@ -1847,7 +1848,7 @@ template <typename T> static __device__ __forceinline__ T bd_householder(T &head
 	return (T) 0.5 * ((T) 1 + tn * tn);
 }
 
-template <typename T> __global__ __launch_bounds__(TD_NT) void bd_pre_kernel(const BdArgs<T> a)
+template <typename T> static __device__ __forceinline__ void bd_pre_body(const BdArgs<T> &a)
 {
 	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
 	const int tid = threadIdx.x, k = a.k, m = a.m, n = a.n;
@@ -1915,49 +1916,285 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void bd_pre_kernel(con
 	}
 }
 
-template <typename T> __global__ __launch_bounds__(TD_NT) void bd_colpass_kernel(const BdArgs<T> a)
+template <typename T> static __device__ __forceinline__ void bd_mid_body(const BdArgs<T> &a);
+
+// bd_pre_body with every entry it touches in registers (at most TD_E per thread and direction): all loads -- the strided ones of rows k - 1
+// and k among them -- are issued at the start, every entry is stored once.  Same arithmetic, expression by expression.
+template <typename T> static __device__ __forceinline__ void bd_pre_body_reg(const BdArgs<T> &a)
 {
-	const int tid = threadIdx.x, k = a.k, m = a.m;
-	const int lane = tid & 63, j = k + 1 + blockIdx.x * (TD_NT / 64) + (tid >> 6);
-	if (j >= a.n)
-		return;
+	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
+	const int tid = threadIdx.x, k = a.k, m = a.m, n = a.n;
+	auto at = [&](int i, int j) -> T & { return a.A[(idx_t) i * a.rs + (idx_t) j * a.cs]; };
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
 	const bool upd = k > 0;
-	const T yj = upd ? a.y[j] : (T) 0, vpj = upd ? a.A[(idx_t) (k - 1) * a.rs + (idx_t) j * a.cs] : (T) 0;
-	T *col = a.A + (idx_t) j * a.cs;
-	const T *ucol = a.A + (idx_t) k * a.cs, *upcol = a.A + (idx_t) (upd ? k - 1 : 0) * a.cs;
-	double acc = 0.0;
-	for (int i0 = k + 1 + lane; i0 < m; i0 += 64 * TD_UNR) {
-		T v[TD_UNR], u[TD_UNR], up[TD_UNR], z[TD_UNR];
+	T cu[TD_E], cold[TD_E], czs[TD_E], rk[TD_E], rkm[TD_E], ry[TD_E];
 #pragma unroll
-		for (int q = 0; q < TD_UNR; ++q) {
-			const int i = i0 + 64 * q;
-			const bool in = i < m;
-			const idx_t o = (idx_t) (in ? i : k) * a.rs;
-			v[q] = col[o];
-			u[q] = in ? ucol[o] : (T) 0;
-			up[q] = (in && upd) ? upcol[o] : (T) 0;
-			z[q] = (in && upd) ? a.z[in ? i : 0] : (T) 0;
-		}
+	for (int e = 0; e < TD_E; ++e) {
+		const int i = k + 1 + tid + e * TD_NT, ic = i < m ? i : m - 1;
+		cold[e] = at(ic, k);
+		cu[e] = upd ? at(ic, k - 1) : (T) 0;
+		czs[e] = upd ? a.zsum[ic] : (T) 0;
+		const int j = k + 1 + tid + e * TD_NT, jc = j < n ? j : n - 1;
+		rk[e] = upd ? at(k, jc) : (T) 0;
+		rkm[e] = upd ? at(k - 1, jc) : (T) 0;
+		ry[e] = upd ? a.y[jc] : (T) 0;
+	}
+	T akk = at(k, k);
+	T nacc[3] = {0, 0, 0};
+	if (upd) {
+		const T beta = (T) a.st->beta, hinv = (T) a.st->hinv, b = (T) a.st->b, tr_inv = (T) a.st->tr_inv;
+		const bool inf = a.st->hinv_inf != 0;
+		auto fix = [&](T zs, T a22a, T u) -> T {
+			T w;
+			if (!inf) {
+				w = zs - a22a * beta;
+				w = w * hinv;
+				w = w - u * b;
+			} else {
+				w = a22a - u * b;
+			}
+			return w * tr_inv;
+		};
+		const T up0 = at(k, k - 1), y1 = a.y[k];
+		const T z1 = fix(a.zsum[k], akk, up0);
+		akk -= up0 * y1 + z1;
+		if (tid == 0)
+			a.z[k] = z1; // (a_kk itself is stored once, below, as the reflector's beta: nobody may see an intermediate value)
 #pragma unroll
-		for (int q = 0; q < TD_UNR; ++q) {
-			const int i = i0 + 64 * q;
+		for (int e = 0; e < TD_E; ++e) {
+			const int i = k + 1 + tid + e * TD_NT;
 			if (i < m) {
-				T t = v[q];
-				if (upd) {
-					t = fh_fma(-up[q], yj, t);  // A22 -= up y2 (:292)
-					t = fh_fma(-z[q], vpj, t);  // A22 -= z2 vp (:293)
-					col[(idx_t) i * a.rs] = t;
-				}
-				acc += (double) u[q] * (double) t; // y2 = u^H A22 (:294-300)
+				const T zf = fix(czs[e], cold[e], cu[e]);
+				a.z[i] = zf;
+				cold[e] = cold[e] - (cu[e] * y1 + zf);
+			}
+			const int j = k + 1 + tid + e * TD_NT;
+			if (j < n)
+				at(k, j) = rk[e] - (up0 * ry[e] + z1 * rkm[e]);
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e)
+		if (k + 1 + tid + e * TD_NT < m) {
+			const T v = cold[e];
+			nacc[0] += (v * sml) * (v * sml);
+			nacc[1] += v * v;
+			nacc[2] += (v * big) * (v * big);
+		}
+	// ---- (ii) left reflector of column k (:99-102)
+	double accd[3] = {(double) nacc[0], (double) nacc[1], (double) nacc[2]};
+	td_block_sum<3>(accd, s_part, s_red);
+	const T tail_norm = norm_from3<T>(s_red);
+	T head = akk, hinv;
+	bool negligible;
+	const T tau = bd_householder<T>(head, tail_norm, hinv, negligible);
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int i = k + 1 + tid + e * TD_NT;
+		if (i < m && (upd || !negligible))
+			at(i, k) = negligible ? cold[e] : cold[e] * hinv;
+	}
+	if (tid == 0) {
+		at(k, k) = head;
+		a.taul[k] = tau;
+		a.st->tl_inv = (double) ((T) 1 / tau);
+	}
+}
+
+template <typename T> __global__ __launch_bounds__(TD_NT) void bd_pre_kernel(const BdArgs<T> a)
+{
+	if (a.m - a.k - 1 <= TD_E * TD_NT && a.n - a.k - 1 <= TD_E * TD_NT)
+		bd_pre_body_reg<T>(a);
+	else
+		bd_pre_body<T>(a);
+}
+
+// bd_mid_body with row k in registers: ONE strided read and one strided write of the row instead of three each.
+template <typename T> static __device__ __forceinline__ void bd_mid_body_reg(const BdArgs<T> &a)
+{
+	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
+	__shared__ T s_bc[1];
+	const int tid = threadIdx.x, k = a.k, n = a.n;
+	auto row = [&](int j) -> T & { return a.A[(idx_t) k * a.rs + (idx_t) j * a.cs]; };
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	const T tl_inv = (T) a.st->tl_inv;
+	T v[TD_E], yv[TD_E];
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int j = k + 1 + tid + e * TD_NT, jc = j < n ? j : n - 1;
+		v[e] = row(jc);
+		yv[e] = a.ysum[jc];
+	}
+	// ---- (iv) y2 = (y2 + A12) / tau_l, A12 -= y2, norm of A12 (:156-164)
+	T nacc[3] = {0, 0, 0};
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int j = k + 1 + tid + e * TD_NT;
+		if (j < n) {
+			yv[e] = (yv[e] + v[e]) * tl_inv;
+			a.y[j] = yv[e];
+			v[e] = v[e] - yv[e];
+			nacc[0] += (v[e] * sml) * (v[e] * sml);
+			nacc[1] += v[e] * v[e];
+			nacc[2] += (v[e] * big) * (v[e] * big);
+		}
+	}
+	double accd[3] = {(double) nacc[0], (double) nacc[1], (double) nacc[2]};
+	td_block_sum<3>(accd, s_part, s_red);
+	const T norm = norm_from3<T>(s_red);
+	const T norm_inv = (T) 1 / norm;
+	T tacc[3] = {0, 0, 0};
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int j = k + 1 + tid + e * TD_NT;
+		if (j < n) {
+			if (norm != (T) 0)
+				v[e] *= norm_inv;
+			a.vrow[j] = v[e]; // (v) multiplies by the normalised row as it is BEFORE the right reflector touches it
+			if (j >= k + 2) {
+				tacc[0] += (v[e] * sml) * (v[e] * sml);
+				tacc[1] += v[e] * v[e];
+				tacc[2] += (v[e] * big) * (v[e] * big);
 			}
 		}
 	}
-	const double sv = wave_sum(acc);
-	if (lane == 0)
-		a.ysum[j] = (T) sv;
+	if (k + 1 >= a.size) {
+#pragma unroll
+		for (int e = 0; e < TD_E; ++e)
+			if (k + 1 + tid + e * TD_NT < n)
+				row(k + 1 + tid + e * TD_NT) = v[e];
+		return;
+	}
+	if (tid == 0)
+		s_bc[0] = v[0]; // the head of the row (j = k + 1)
+	// ---- (vi) right reflector of the normalised row (:176-185) and b (:186-193)
+	double tad[3] = {(double) tacc[0], (double) tacc[1], (double) tacc[2]};
+	td_block_sum<3>(tad, s_part, s_red);
+	const T tail_norm = norm_from3<T>(s_red);
+	T head = s_bc[0], hinv;
+	bool negligible;
+	const T tau = bd_householder<T>(head, tail_norm, hinv, negligible);
+	double d[1] = {0.0};
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int j = k + 1 + tid + e * TD_NT;
+		if (j < n && j >= k + 2) {
+			if (!negligible)
+				v[e] *= hinv;
+			row(j) = v[e];
+			d[0] += (double) yv[e] * (double) v[e];
+		}
+	}
+	td_block_sum<1>(d, s_part, s_red);
+	if (tid == 0) {
+		const T b = yv[0] + (T) s_red[0];
+		row(k + 1) = head * norm; // beta, rescaled (:183-184)
+		a.taur[k] = tau;
+		a.st->tr_inv = (double) ((T) 1 / tau);
+		a.st->beta = (double) head;
+		a.st->hinv = (double) hinv;
+		a.st->hinv_inf = negligible ? 1 : 0;
+		a.st->b = (double) b;
+		a.st->norm = (double) norm;
+	}
 }
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void bd_mid_kernel(const BdArgs<T> a)
+{
+	if (a.n - a.k - 1 <= TD_E * TD_NT)
+		bd_mid_body_reg<T>(a);
+	else
+		bd_mid_body<T>(a);
+}
+
+// out[e] = the sum of `np` partial vectors part[p * stride + e], e in [off, off + len), added in the order of p (round 6: the matrix passes
+// of the reductions to condensed form are cut into uniform tiles whose shares are added here -- one short launch -- in a fixed order)
+template <typename T> __global__ __launch_bounds__(256) void vec_sum_kernel(const double *part, int np, size_t stride, int off, int len, T *out)
+{
+	const int e = blockIdx.x * 256 + threadIdx.x;
+	if (e >= len)
+		return;
+	const double *src = part + off + e;
+	double s0 = 0.0;
+	int p = 0;
+	for (; p + 8 <= np; p += 8) {
+		double v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u)
+			v[u] = src[(size_t) (p + u) * stride];
+#pragma unroll
+		for (int u = 0; u < 8; ++u)
+			s0 += v[u];
+	}
+	for (; p < np; ++p)
+		s0 += src[(size_t) p * stride];
+	out[off + e] = (T) s0;
+}
+
+// (iii): tile of BC_TR rows x BC_TC columns of A22 = A[k+1.., k+1..]; wavefront w owns 8 columns, a lane four rows of each (32 loads in
+// flight per thread): A22 -= up y2 + z2 vp written back, and the tile's share of y2 = u^H A22 -> ypart[row block][column].
+constexpr int BC_TR = 256, BC_TC = 32, BC_NT = 256;
+template <typename T, bool upd> __global__ __launch_bounds__(BC_NT) void bd_col_kernel(const BdArgs<T> a)
+{
+	constexpr int CW = BC_TC / (BC_NT / 64), RH = BC_TR / 64; // 8 columns per wavefront, 4 rows per lane
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, k = a.k;
+	const int base = k + 1, rr = a.m - base, cc = a.n - base;
+	const int ncb = (cc + BC_TC - 1) / BC_TC;
+	const int I = blockIdx.x / ncb, J = blockIdx.x - I * ncb;
+	const int i0 = I * BC_TR, j0 = J * BC_TC + CW * wv;
+	T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
+	const T *ucol = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;		    // u_i (the left reflector, rows base..)
+	const T *upcol = a.A + (idx_t) base * a.rs + (idx_t) (upd ? k - 1 : 0) * a.cs; // up_i
+	const T *vprow = a.A + (idx_t) (upd ? k - 1 : 0) * a.rs + (idx_t) base * a.cs; // vp_j (row k - 1)
+	int gi[RH];
+	bool vr[RH];
+	T ui[RH], upi[RH], zi[RH];
+#pragma unroll
+	for (int h = 0; h < RH; ++h) {
+		gi[h] = i0 + lane + 64 * h;
+		vr[h] = gi[h] < rr;
+		gi[h] = min(gi[h], rr - 1);
+		const idx_t o = (idx_t) gi[h] * a.rs;
+		ui[h] = ucol[o];
+		upi[h] = upd ? upcol[o] : (T) 0;
+		zi[h] = upd ? a.z[base + gi[h]] : (T) 0;
+	}
+	T yjl = (T) 0, vpjl = (T) 0; // column values of the wavefront's columns, one per lane
+	if (upd) {
+		const int gj = min(j0 + (lane & (CW - 1)), cc - 1);
+		yjl = a.y[base + gj];
+		vpjl = vprow[(idx_t) gj * a.cs];
+	}
+	T v[RH][CW];
+#pragma unroll
+	for (int c = 0; c < CW; ++c)
+#pragma unroll
+		for (int h = 0; h < RH; ++h)
+			v[h][c] = A22[(idx_t) gi[h] * a.rs + (idx_t) min(j0 + c, cc - 1) * a.cs];
+#pragma unroll
+	for (int c = 0; c < CW; ++c) {
+		const int gj = j0 + c;
+		const T yj = td_lane(yjl, c), vpj = td_lane(vpjl, c);
+		double cs_ = 0.0;
+#pragma unroll
+		for (int h = 0; h < RH; ++h) {
+			const bool in = vr[h] && gj < cc;
+			T tv = v[h][c];
+			if (upd) {
+				tv = fh_fma(-upi[h], yj, tv); // A22 -= up y2 (:292)
+				tv = fh_fma(-zi[h], vpj, tv); // A22 -= z2 vp (:293)
+				if (in)
+					A22[(idx_t) gi[h] * a.rs + (idx_t) gj * a.cs] = tv;
+			}
+			cs_ += in ? (double) ui[h] * (double) tv : 0.0; // y2 = u^H A22 (:294-300)
+		}
+		const double sv = td_wave_sum(cs_);
+		if (lane == 0 && gj < cc)
+			a.ypart[(size_t) I * a.n + base + gj] = sv;
+	}
+}
+
+template <typename T> static __device__ __forceinline__ void bd_mid_body(const BdArgs<T> &a)
 {
 	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
 	const int tid = threadIdx.x, k = a.k, n = a.n;
@@ -2026,42 +2263,47 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void bd_mid_kernel(con
 	}
 }
 
-// z2 = A22 A12^H with the normalised row (vrow), read only; rows i0 .. i0+15 per workgroup, thread (ri, cj) takes the
-// columns cj, cj + NC, ...
-template <typename T> __global__ __launch_bounds__(TD_NT) void bd_rowpass_kernel(const BdArgs<T> a)
+// (v): z2 = A22 A12^H with the normalised row (vrow), read only: tile of BR_TR rows x BR_TC columns; wavefront w owns 32 columns, a lane two
+// rows of each (64 loads in two batches); the tile's share of the row sums -> zpart[column block][row].
+constexpr int BR_TR = 128, BR_TC = 128, BR_NT = 256;
+template <typename T> __global__ __launch_bounds__(BR_NT) void bd_row_kernel(const BdArgs<T> a)
 {
-	constexpr int NC = TD_NT / TD_PW;
-	__shared__ double red[TD_PW][NC + 1];
-	const int tid = threadIdx.x, k = a.k;
-	const int ri = tid & (TD_PW - 1), cj = tid >> 4;
-	const int i = k + 1 + blockIdx.x * TD_PW + ri;
-	const bool vi = i < a.m;
-	const T *rowp = a.A + (idx_t) (vi ? i : k + 1) * a.rs;
-	double acc = 0.0;
-	for (int j0 = k + 1 + cj; j0 < a.n; j0 += TD_UNR * NC) {
-		T v[TD_UNR], x[TD_UNR];
+	constexpr int CW = BR_TC / (BR_NT / 64); // 32 columns per wavefront
+	__shared__ double s_row[BR_NT / 64][BR_TR];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, k = a.k;
+	const int base = k + 1, rr = a.m - base, cc = a.n - base;
+	const int ncb = (cc + BR_TC - 1) / BR_TC;
+	const int I = blockIdx.x / ncb, J = blockIdx.x - I * ncb;
+	const int i0 = I * BR_TR, j0 = J * BR_TC + CW * wv;
+	const T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
+	int gi[2];
 #pragma unroll
-		for (int q = 0; q < TD_UNR; ++q) {
-			const int j = j0 + NC * q;
-			const bool in = vi && j < a.n;
-			v[q] = rowp[(idx_t) (in ? j : k + 1) * a.cs];
-			x[q] = in ? a.vrow[j] : (T) 0;
+	for (int h = 0; h < 2; ++h)
+		gi[h] = min(i0 + lane + 64 * h, rr - 1);
+	double racc[2] = {0.0, 0.0};
+#pragma unroll
+	for (int cb = 0; cb < CW; cb += 16) {
+		const int gjl = min(j0 + cb + (lane & 15), cc - 1);
+		const T xl = (j0 + cb + (lane & 15) < cc) ? a.vrow[base + gjl] : (T) 0; // (columns past the end contribute nothing)
+		T v[2][16];
+#pragma unroll
+		for (int c = 0; c < 16; ++c)
+#pragma unroll
+			for (int h = 0; h < 2; ++h)
+				v[h][c] = A22[(idx_t) gi[h] * a.rs + (idx_t) min(j0 + cb + c, cc - 1) * a.cs];
+#pragma unroll
+		for (int c = 0; c < 16; ++c) {
+			const T xj = td_lane(xl, c);
+#pragma unroll
+			for (int h = 0; h < 2; ++h)
+				racc[h] += (double) v[h][c] * (double) xj;
 		}
-#pragma unroll
-		for (int q = 0; q < TD_UNR; ++q)
-			acc += (double) v[q] * (double) x[q];
 	}
-	red[ri][cj] = acc;
+	s_row[wv][lane] = racc[0];
+	s_row[wv][lane + 64] = racc[1];
 	__syncthreads();
-	if (tid < TD_PW) {
-		const int io = k + 1 + blockIdx.x * TD_PW + tid;
-		if (io < a.m) {
-			double t = 0.0;
-			for (int c = 0; c < NC; ++c)
-				t += red[tid][c];
-			a.zsum[io] = (T) t;
-		}
-	}
+	if (tid < BR_TR && i0 + tid < rr)
+		a.zpart[(size_t) J * a.m + base + i0 + tid] = ((s_row[0][tid] + s_row[1][tid]) + s_row[2][tid]) + s_row[3][tid];
 }
 
 // A: m x n; Hl: bl x min(m, n), Hr: br x (min(m, n) - 1)
@@ -2077,7 +2319,8 @@ template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
 	if (size == 0)
 		return;
 	hipStream_t s = ctx().stream;
-	Scratch vb((size_t) (3 * n + 2 * m + 2 * n) * sizeof(T) + 256), stb(sizeof(BdState));
+	const idx_t nrb = (m + BC_TR - 1) / BC_TR, ncb = (n + BR_TC - 1) / BR_TC;
+	Scratch vb((size_t) (3 * n + 2 * m + 2 * n) * sizeof(T) + 256), stb(sizeof(BdState)), pb((size_t) (nrb * n + ncb * m) * sizeof(double));
 	BdArgs<T> a;
 	a.A = A.p;
 	a.rs = A.rs;
@@ -2092,6 +2335,8 @@ template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
 	a.zsum = a.z + m;
 	a.taul = a.zsum + m;
 	a.taur = a.taul + n;
+	a.ypart = pb.as<double>();
+	a.zpart = a.ypart + (size_t) nrb * (size_t) n;
 	a.st = stb.as<BdState>();
 	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (3 * n + 2 * m + 2 * n) * sizeof(T), s));
 	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(BdState), s));
@@ -2100,10 +2345,22 @@ template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
 		const idx_t rr = m - k - 1, cc = n - k - 1;
 		hipLaunchKernelGGL(bd_pre_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
 		if (cc > 0) {
-			hipLaunchKernelGGL(bd_colpass_kernel<T>, dim3((unsigned) ((cc + TD_NT / 64 - 1) / (TD_NT / 64))), dim3(TD_NT), 0, s, a);
+			if (rr > 0) {
+				const unsigned rb = (unsigned) ((rr + BC_TR - 1) / BC_TR), cb = (unsigned) ((cc + BC_TC - 1) / BC_TC);
+				if (k > 0)
+					hipLaunchKernelGGL((bd_col_kernel<T, true>), dim3(rb * cb), dim3(BC_NT), 0, s, a);
+				else
+					hipLaunchKernelGGL((bd_col_kernel<T, false>), dim3(rb * cb), dim3(BC_NT), 0, s, a);
+				hipLaunchKernelGGL(vec_sum_kernel<T>, dim3((unsigned) ((cc + 255) / 256)), dim3(256), 0, s, a.ypart, (int) rb, (size_t) n, (int) (k + 1), (int) cc, a.ysum);
+			} else {
+				FH_HIP(hipMemsetAsync(a.ysum + k + 1, 0, (size_t) cc * sizeof(T), s)); // (no row below: y2 = 0)
+			}
 			hipLaunchKernelGGL(bd_mid_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
-			if (k + 1 < size && rr > 0)
-				hipLaunchKernelGGL(bd_rowpass_kernel<T>, dim3((unsigned) ((rr + TD_PW - 1) / TD_PW)), dim3(TD_NT), 0, s, a);
+			if (k + 1 < size && rr > 0) {
+				const unsigned rb = (unsigned) ((rr + BR_TR - 1) / BR_TR), cb = (unsigned) ((cc + BR_TC - 1) / BR_TC);
+				hipLaunchKernelGGL(bd_row_kernel<T>, dim3(rb * cb), dim3(BR_NT), 0, s, a);
+				hipLaunchKernelGGL(vec_sum_kernel<T>, dim3((unsigned) ((rr + 255) / 256)), dim3(256), 0, s, a.zpart, (int) cb, (size_t) m, (int) (k + 1), (int) rr, a.zsum);
+			}
 		}
 	}
 	FH_HIP(hipGetLastError());
