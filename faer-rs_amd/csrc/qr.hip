@@ -2396,10 +2396,11 @@ template <typename T> struct HsArgs {
 	idx_t rs, cs;
 	int n, k;
 	T *y, *z, *ysum, *zsum, *taus;
+	double *ypart, *zpart; // shares of the tiles of the fused pass: ypart[row block * n + j], zpart[column block * n + i]
 	HsState *st;
 };
 
-template <typename T> __global__ __launch_bounds__(TD_NT) void hs_pre_kernel(const HsArgs<T> a)
+template <typename T> static __device__ __forceinline__ void hs_pre_body(const HsArgs<T> &a)
 {
 	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
 	const int tid = threadIdx.x, k = a.k, n = a.n;
@@ -2467,55 +2468,208 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void hs_pre_kernel(con
 	}
 }
 
-template <typename T> __global__ __launch_bounds__(TD_NT) void hs_colpass_kernel(const HsArgs<T> a)
+// hs_pre_body with column k - 1, column k, row k and the two products in registers (n - k <= TD_E TD_NT): one round trip to memory, every
+// entry stored once.  Same arithmetic, expression by expression.
+template <typename T> static __device__ __forceinline__ void hs_pre_body_reg(const HsArgs<T> &a)
 {
+	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
+	__shared__ T s_bc[1];
 	const int tid = threadIdx.x, k = a.k, n = a.n;
-	const int lane = tid & 63, j = k + 1 + blockIdx.x * (TD_NT / 64) + (tid >> 6);
-	if (j >= n)
-		return;
+	auto at = [&](int i, int j) -> T & { return a.A[(idx_t) i * a.rs + (idx_t) j * a.cs]; };
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
 	const bool upd = k > 0;
-	const T *upcol = a.A + (idx_t) (upd ? k - 1 : 0) * a.cs; // u2 = previous reflector (rows k+1..: its tail)
-	const T yj = upd ? a.y[j] : (T) 0, uj = upd ? upcol[(idx_t) j * a.rs] : (T) 0;
-	T *col = a.A + (idx_t) j * a.cs;
-	const T *xcol = a.A + (idx_t) k * a.cs;
-	double acc = 0.0;
-	for (int i0 = k + 1 + lane; i0 < n; i0 += 64 * TD_UNR) {
-		T v[TD_UNR], x[TD_UNR], u[TD_UNR], z[TD_UNR];
+	// rows / columns i = k + tid + e TD_NT
+	T u[TD_E], ck[TD_E], rk[TD_E], ys[TD_E], zs[TD_E];
 #pragma unroll
-		for (int q = 0; q < TD_UNR; ++q) {
-			const int i = i0 + 64 * q;
-			const bool in = i < n;
-			const idx_t o = (idx_t) (in ? i : k + 1) * a.rs;
-			v[q] = col[o];
-			x[q] = in ? xcol[o] : (T) 0;
-			u[q] = (in && upd) ? upcol[o] : (T) 0;
-			z[q] = (in && upd) ? a.z[in ? i : 0] : (T) 0;
-		}
+	for (int e = 0; e < TD_E; ++e) {
+		const int i = k + tid + e * TD_NT, ic = i < n ? i : n - 1;
+		ck[e] = at(ic, k);
+		u[e] = upd ? at(ic, k - 1) : (T) 0;
+		rk[e] = upd ? at(k, ic) : (T) 0;
+		ys[e] = upd ? a.ysum[ic] : (T) 0;
+		zs[e] = upd ? a.zsum[ic] : (T) 0;
+	}
+	T nacc[3] = {0, 0, 0};
+	if (upd) {
+		// ---- (iv) of step k-1 (:342-357)
+		const T tau_inv = (T) a.st->tau_inv, x0 = at(k, k - 1), ysk = a.ysum[k], zsk = a.zsum[k], beta = (T) a.st->beta;
+		double d[1] = {0.0};
 #pragma unroll
-		for (int q = 0; q < TD_UNR; ++q) {
-			const int i = i0 + 64 * q;
-			if (i < n) {
-				T t = v[q];
-				if (upd) {
-					t = fh_fma(-u[q], yj, t); // A22 -= u2 y2      (:160-167)
-					t = fh_fma(-z[q], uj, t); // A22 -= z2 u2^H    (:168-175)
-					col[(idx_t) i * a.rs] = t;
-				}
-				acc += (double) x[q] * (double) t; // l_out = x^H A22 (:184-191)
+		for (int e = 0; e < TD_E; ++e)
+			if (k + tid + e * TD_NT < n)
+				d[0] += (double) u[e] * (double) zs[e];
+		td_block_sum<1>(d, s_part, s_red);
+		const T b = ((T) s_red[0] * (T) 0.5) * tau_inv;
+		const T y1 = (ysk - b * x0) * tau_inv, z1 = (zsk - b * x0) * tau_inv;
+		// ---- (i) (:266-281) fused with the rest of (iv)
+#pragma unroll
+		for (int e = 0; e < TD_E; ++e) {
+			const int i = k + tid + e * TD_NT;
+			if (i < n && i >= k + 1) {
+				const T yi = (ys[e] - b * u[e]) * tau_inv, zi = (zs[e] - b * u[e]) * tau_inv;
+				a.y[i] = yi;
+				a.z[i] = zi;
+				at(k, i) = rk[e] - (yi + z1 * u[e]);   // row k: A12 -= y2 + z1 u2^H
+				ck[e] = ck[e] - (u[e] * y1 + zi);       // column k: A21 -= u2 y1 + z2
 			}
 		}
+		if (tid == 0) {
+			at(k, k - 1) = beta; // (:379) the previous reflector's head goes back to beta
+			a.y[k] = y1;
+			a.z[k] = z1;
+			at(k, k) = ck[0] - (y1 + z1);
+		}
 	}
-	const double sv = wave_sum(acc);
-	if (lane == 0)
-		a.ysum[j] = (T) sv;
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int i = k + tid + e * TD_NT;
+		if (i < n && i >= k + 2) {
+			const T v = ck[e];
+			nacc[0] += (v * sml) * (v * sml);
+			nacc[1] += v * v;
+			nacc[2] += (v * big) * (v * big);
+		}
+	}
+	if (k + 1 >= n)
+		return;
+	if (tid == 1)
+		s_bc[0] = ck[0]; // row k + 1: the head of the column
+	// ---- (ii) reflector of column k below the subdiagonal (:294-305)
+	double accd[3] = {(double) nacc[0], (double) nacc[1], (double) nacc[2]};
+	td_block_sum<3>(accd, s_part, s_red);
+	const T tail_norm = norm_from3<T>(s_red);
+	T head = s_bc[0], hinv;
+	bool negligible;
+	const T tau = bd_householder<T>(head, tail_norm, hinv, negligible);
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int i = k + tid + e * TD_NT;
+		if (i < n && i >= k + 2 && (upd || !negligible))
+			at(i, k) = negligible ? ck[e] : ck[e] * hinv;
+	}
+	if (tid == 0) {
+		at(k + 1, k) = (T) 1; // head of x while the step runs; beta comes back in the next hs_pre_kernel
+		a.taus[k] = tau;
+		a.st->tau_inv = (double) ((T) 1 / tau);
+		a.st->beta = (double) head;
+	}
 }
 
+template <typename T> __global__ __launch_bounds__(TD_NT) void hs_pre_kernel(const HsArgs<T> a)
+{
+	if (a.n - a.k <= TD_E * TD_NT)
+		hs_pre_body_reg<T>(a);
+	else
+		hs_pre_body<T>(a);
+}
+
+// Round 6: both products of a step use the SAME x, so ONE pass over A22 = A[k+1.., k+1..] applies the two-sided update of the previous step
+// and forms the tile's shares of l_out = x^H A22 (column sums) and r_out = A22 x (row sums): 128 x 64 tiles as in the tridiagonalization
+// (lane = two rows, wavefront = 16 columns, 32 loads in flight per thread); the shares are added in a fixed order by vec_sum_kernel.
+// The rows above (0 .. k, which receive the reflector from the right once their sums are complete) stay with hs_rowpass_kernel.
+template <typename T, bool upd> __global__ __launch_bounds__(TF_NT) void hs_fused_kernel(const HsArgs<T> a)
+{
+	constexpr int CW = TF_TC / (TF_NT / 64); // 16 columns per wavefront
+	__shared__ double s_row[TF_NT / 64][TF_TR];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, k = a.k;
+	const int base = k + 1, r = a.n - base;
+	const int ncb = (r + TF_TC - 1) / TF_TC;
+	const int I = blockIdx.x / ncb, J = blockIdx.x - I * ncb;
+	const int i0 = I * TF_TR, j0 = J * TF_TC + CW * wv;
+	T *A22 = a.A + (idx_t) base * a.rs + (idx_t) base * a.cs;
+	const T *xcol = a.A + (idx_t) base * a.rs + (idx_t) k * a.cs;		    // x (head = 1 in memory)
+	const T *ucol = a.A + (idx_t) base * a.rs + (idx_t) (upd ? k - 1 : 0) * a.cs; // u2: the previous reflector's tail
+	int gi[2];
+	bool vr[2];
+	T xi[2], ui[2], zi[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		gi[h] = i0 + lane + 64 * h;
+		vr[h] = gi[h] < r;
+		gi[h] = min(gi[h], r - 1);
+		const idx_t o = (idx_t) gi[h] * a.rs;
+		xi[h] = xcol[o];
+		ui[h] = upd ? ucol[o] : (T) 0;
+		zi[h] = upd ? a.z[base + gi[h]] : (T) 0;
+	}
+	T xjl, yjl = (T) 0, ujl = (T) 0;
+	{
+		const int gj = min(j0 + (lane & (CW - 1)), r - 1);
+		xjl = xcol[(idx_t) gj * a.rs];
+		if (upd) {
+			yjl = a.y[base + gj];
+			ujl = ucol[(idx_t) gj * a.rs];
+		}
+	}
+	T v[2][CW];
+#pragma unroll
+	for (int c = 0; c < CW; ++c)
+#pragma unroll
+		for (int h = 0; h < 2; ++h)
+			v[h][c] = A22[(idx_t) gi[h] * a.rs + (idx_t) min(j0 + c, r - 1) * a.cs];
+	double racc[2] = {0.0, 0.0};
+#pragma unroll
+	for (int c = 0; c < CW; ++c) {
+		const int gj = j0 + c;
+		const T xj = td_lane(xjl, c), yj = td_lane(yjl, c), uj = td_lane(ujl, c);
+		double cs_ = 0.0;
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const bool in = vr[h] && gj < r;
+			T tv = v[h][c];
+			if (upd) {
+				tv = fh_fma(-ui[h], yj, tv); // A22 -= u2 y2      (:160-167)
+				tv = fh_fma(-zi[h], uj, tv); // A22 -= z2 u2^H    (:168-175)
+				if (in)
+					A22[(idx_t) gi[h] * a.rs + (idx_t) gj * a.cs] = tv;
+			}
+			cs_ += in ? (double) xi[h] * (double) tv : 0.0;	 // l_out = x^H A22 (:184-191)
+			racc[h] += in ? (double) tv * (double) xj : 0.0; // r_out = A22 x   (:176-183)
+		}
+		const double sv = td_wave_sum(cs_);
+		if (lane == 0 && gj < r)
+			a.ypart[(size_t) I * a.n + base + gj] = sv;
+	}
+	s_row[wv][lane] = racc[0];
+	s_row[wv][lane + 64] = racc[1];
+	__syncthreads();
+	if (tid < TF_TR && i0 + tid < r)
+		a.zpart[(size_t) J * a.n + base + i0 + tid] = ((s_row[0][tid] + s_row[1][tid]) + s_row[2][tid]) + s_row[3][tid];
+}
+
+// rows 0 .. k of the columns right of k (hs_fused_kernel has the rows below): w = A[0..k, k+1..] x, then A[0..k, k+1..] -= (w / tau) x^H
+// (the blocks behind those of the top rows add the shares of hs_fused_kernel in a fixed order -> ysum, zsum: one launch less per column)
 template <typename T> __global__ __launch_bounds__(TD_NT) void hs_rowpass_kernel(const HsArgs<T> a)
 {
 	constexpr int NC = TD_NT / TD_PW;
 	__shared__ double red[TD_PW][NC + 1];
 	__shared__ T s_w[TD_PW];
 	const int tid = threadIdx.x, k = a.k, n = a.n;
+	const int ntop = (k + 1 + TD_PW - 1) / TD_PW;
+	if ((int) blockIdx.x >= ntop) {
+		const int r = n - (k + 1);
+		const int e = ((int) blockIdx.x - ntop) * TD_NT + tid;
+		if (e >= 2 * r)
+			return;
+		const bool isz = e >= r;
+		const int np = isz ? (r + TF_TC - 1) / TF_TC : (r + TF_TR - 1) / TF_TR;
+		const double *src = (isz ? a.zpart : a.ypart) + (k + 1) + (isz ? e - r : e);
+		double s0 = 0.0;
+		int p = 0;
+		for (; p + 8 <= np; p += 8) {
+			double v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				v[u] = src[(size_t) (p + u) * n];
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				s0 += v[u];
+		}
+		for (; p < np; ++p)
+			s0 += src[(size_t) p * n];
+		(isz ? a.zsum : a.ysum)[(k + 1) + (isz ? e - r : e)] = (T) s0;
+		return;
+	}
 	const int ri = tid & (TD_PW - 1), cj = tid >> 4;
 	const int i = blockIdx.x * TD_PW + ri;
 	const bool vi = i < n;
@@ -2542,8 +2696,6 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void hs_rowpass_kernel
 		double t = 0.0;
 		for (int c = 0; c < NC; ++c)
 			t += red[tid][c];
-		if (io < n && io > k)
-			a.zsum[io] = (T) t; // r_out = A22 x (:176-183)
 		s_w[tid] = (T) t;
 	}
 	// rows 0 .. k: the sum is the w of (:358-378), the row receives the reflector from the right at once
@@ -2568,8 +2720,11 @@ template <typename T> void hessenberg_dev(MatV<T> A, MatV<T> H)
 		return;
 	FH_CHECK(H.nrows > 0, "hessenberg: householder needs at least one row");
 	hipStream_t s = ctx().stream;
-	Scratch vb((size_t) (5 * n) * sizeof(T) + 256), stb(sizeof(HsState));
+	const idx_t nrb = (n + TF_TR - 1) / TF_TR, ncb = (n + TF_TC - 1) / TF_TC;
+	Scratch vb((size_t) (5 * n) * sizeof(T) + 256), stb(sizeof(HsState)), pb((size_t) (nrb + ncb) * (size_t) n * sizeof(double));
 	HsArgs<T> a;
+	a.ypart = pb.as<double>();
+	a.zpart = a.ypart + (size_t) nrb * (size_t) n;
 	a.A = A.p;
 	a.rs = A.rs;
 	a.cs = A.cs;
@@ -2587,8 +2742,14 @@ template <typename T> void hessenberg_dev(MatV<T> A, MatV<T> H)
 		hipLaunchKernelGGL(hs_pre_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
 		const idx_t r = n - k - 1;
 		if (r > 0) {
-			hipLaunchKernelGGL(hs_colpass_kernel<T>, dim3((unsigned) ((r + TD_NT / 64 - 1) / (TD_NT / 64))), dim3(TD_NT), 0, s, a);
-			hipLaunchKernelGGL(hs_rowpass_kernel<T>, dim3((unsigned) ((n + TD_PW - 1) / TD_PW)), dim3(TD_NT), 0, s, a);
+			const unsigned rb = (unsigned) ((r + TF_TR - 1) / TF_TR), cb = (unsigned) ((r + TF_TC - 1) / TF_TC);
+			if (k > 0)
+				hipLaunchKernelGGL((hs_fused_kernel<T, true>), dim3(rb * cb), dim3(TF_NT), 0, s, a);
+			else
+				hipLaunchKernelGGL((hs_fused_kernel<T, false>), dim3(rb * cb), dim3(TF_NT), 0, s, a);
+			// rows 0 .. k: their sums with x are the w of the right-side application, applied at once (a workgroup owns its 16 rows);
+			// behind them the blocks that add the shares of the fused pass
+			hipLaunchKernelGGL(hs_rowpass_kernel<T>, dim3((unsigned) ((k + 1 + TD_PW - 1) / TD_PW + (2 * r + TD_NT - 1) / TD_NT)), dim3(TD_NT), 0, s, a);
 		}
 	}
 	FH_HIP(hipGetLastError());
