@@ -19,7 +19,7 @@
 namespace fh {
 
 struct FpBest {
-	double score;
+	double score, val; // |a|, a
 	int row, col;
 };
 
@@ -32,6 +32,7 @@ static __device__ __forceinline__ FpBest fp_shfl_xor(const FpBest &v, int off)
 {
 	FpBest o;
 	o.score = __shfl_xor(v.score, off, 64);
+	o.val = __shfl_xor(v.val, off, 64);
 	o.row = __shfl_xor(v.row, off, 64);
 	o.col = __shfl_xor(v.col, off, 64);
 	return o;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void fplu_update_kernel(T *V, idx_t rs, idx_t 
 		const int i = ib + tid + 256 * r;
 		l[r] = (do_update && i < m) ? V[(idx_t) i * rs + (idx_t) k * cs] : (T) 0;
 	}
-	FpBest best{0.0, 0, 0};
+	FpBest best{0.0, 0.0, 0, 0};
 	// all FP_COLS x 4 elements of the thread are loaded before the first store: stores to V would otherwise pin every
 	// later load behind them (same base pointer) and the pass would run one memory round trip per column
 	T u[FP_COLS], v[FP_COLS][4];
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void fplu_update_kernel(T *V, idx_t rs, idx_t 
 					x = fh_fma(-l[r], u[jj], x);
 					V[(idx_t) i * rs + (idx_t) j * cs] = x;
 				}
-				const FpBest c{fabs((double) x), i, j};
+				const FpBest c{fabs((double) x), (double) x, i, j};
 				if (fp_better(c, best))
 					best = c;
 			}
@@ -116,17 +117,24 @@ __global__ __launch_bounds__(256) void fplu_update_kernel(T *V, idx_t rs, idx_t 
 		partials[(size_t) blockIdx.y * gridDim.x + blockIdx.x] = best;
 }
 
+// Round 6: the pivot step is a grid over the longer of the two dimensions.  EVERY workgroup combines the candidates of the last pass in the
+// same fixed order (a few thousand 24-byte records: cheaper than a launch of its own), workgroup 0 records the transpositions; then thread e
+// of the grid swaps the pair (k, e) / (mr, e) of the two rows and the pair (e, k) / (e, mc) of the two columns and scales the pivot column
+// (the pivot row on the transposed view) by the reciprocal pivot (factor.rs:333-362); the four entries where the swapped rows meet the
+// swapped columns belong to thread 0 alone, so every entry is read and written by exactly one thread.  As ONE workgroup (rounds 1-5) the
+// two swaps -- the row swap walks 2 n entries a leading dimension apart -- took 23 us per step whatever the size of the trailing matrix:
+// more than the update pass.
 template <typename T>
-__global__ __launch_bounds__(1024) void fplu_pivot_kernel(T *V, idx_t rs, idx_t cs, int m, int n, int k, int size, int transpose,
-							   const FpBest *__restrict__ partials, int nparts, int *rt, int *ct, int *done)
+__global__ __launch_bounds__(256) void fplu_swap_kernel(T *V, idx_t rs, idx_t cs, int m, int n, int k, int size, int transpose,
+							 const FpBest *__restrict__ partials, int nparts, int *rt, int *ct, int *done)
 {
-	__shared__ FpBest s_part[16];
+	__shared__ FpBest s_part[4];
 	__shared__ FpBest s_best;
 	if (*done)
 		return;
 	const int tid = threadIdx.x;
-	FpBest best{0.0, 0, 0};
-	for (int p = tid; p < nparts; p += 1024)
+	FpBest best{0.0, 0.0, 0, 0};
+	for (int p = tid; p < nparts; p += 256)
 		if (fp_better(partials[p], best))
 			best = partials[p];
 	best = fp_block_best(best, s_part);
@@ -135,44 +143,67 @@ __global__ __launch_bounds__(1024) void fplu_pivot_kernel(T *V, idx_t rs, idx_t 
 	__syncthreads();
 	best = s_best;
 	if (best.score < (double) std::numeric_limits<T>::min()) { // factor.rs:324-332
-		for (int i = k + tid; i < size; i += 1024) {
-			rt[i] = i;
-			ct[i] = i;
+		if (blockIdx.x == 0) {
+			for (int i = k + tid; i < size; i += 256) {
+				rt[i] = i;
+				ct[i] = i;
+			}
 		}
-		if (tid == 0)
+		// (every workgroup of THIS launch has read *done == 0 or will see 1 and return: both leave the matrix alone from here on)
+		if (blockIdx.x == 0 && tid == 0)
 			*done = 1;
 		return;
 	}
+	const int e = blockIdx.x * 256 + tid;
 	const int mr = best.row, mc = best.col;
-	if (tid == 0) {
+	const T inv = (T) 1 / (T) best.val;
+	auto at = [&](int i, int j) -> T & { return V[(idx_t) i * rs + (idx_t) j * cs]; };
+	if (e == 0) {
 		rt[k] = mr;
 		ct[k] = mc;
+		// new (i, j) = old (pr(i), pc(j)) on {k, mr} x {k, mc}, pr = (k mr), pc = (k mc)
+		const int R[2] = {k, mr}, C[2] = {k, mc};
+		T o[2][2];
+#pragma unroll
+		for (int x = 0; x < 2; ++x)
+#pragma unroll
+			for (int y = 0; y < 2; ++y)
+				o[x][y] = at(R[x], C[y]);
+#pragma unroll
+		for (int x = 0; x < 2; ++x)
+#pragma unroll
+			for (int y = 0; y < 2; ++y) {
+				if ((x == 1 && mr == k) || (y == 1 && mc == k))
+					continue;
+				const int i = R[x], j = C[y];
+				T v = o[1 - x][1 - y];
+				if (transpose ? (i == k && j > k) : (j == k && i > k))
+					v *= inv;
+				at(i, j) = v;
+			}
 	}
-	if (mr != k) {
-		for (int j = tid; j < n; j += 1024) {
-			T *p = V + (idx_t) k * rs + (idx_t) j * cs, *q = V + (idx_t) mr * rs + (idx_t) j * cs;
-			const T a = *p, b = *q;
-			*p = b;
-			*q = a;
-		}
+	const bool crosses_r = e == k || e == mr, crosses_c = e == k || e == mc;
+	// ---- row pair in column e (not a swapped column), scaled on the transposed view
+	if (e < n && !crosses_c) {
+		T a = at(k, e), b = mr != k ? at(mr, e) : a;
+		T nk = mr != k ? b : a;
+		if (transpose && e > k)
+			nk *= inv;
+		if (mr != k)
+			at(mr, e) = a;
+		if (mr != k || (transpose && e > k))
+			at(k, e) = nk;
 	}
-	__syncthreads();
-	if (mc != k) {
-		for (int i = tid; i < m; i += 1024) {
-			T *p = V + (idx_t) i * rs + (idx_t) k * cs, *q = V + (idx_t) i * rs + (idx_t) mc * cs;
-			const T a = *p, b = *q;
-			*p = b;
-			*q = a;
-		}
-	}
-	__syncthreads();
-	const T inv = (T) 1 / V[(idx_t) k * rs + (idx_t) k * cs];
-	if (transpose) {
-		for (int j = k + 1 + tid; j < n; j += 1024)
-			V[(idx_t) k * rs + (idx_t) j * cs] *= inv;
-	} else {
-		for (int i = k + 1 + tid; i < m; i += 1024)
-			V[(idx_t) i * rs + (idx_t) k * cs] *= inv;
+	// ---- column pair in row e (not a swapped row), scaled on the plain view
+	if (e < m && !crosses_r) {
+		T a = at(e, k), b = mc != k ? at(e, mc) : a;
+		T nk = mc != k ? b : a;
+		if (!transpose && e > k)
+			nk *= inv;
+		if (mc != k)
+			at(e, mc) = a;
+		if (mc != k || (!transpose && e > k))
+			at(e, k) = nk;
 	}
 }
 
@@ -200,8 +231,9 @@ template <typename T> long full_piv_lu_dev(MatV<T> A, idx_t *row_perm, idx_t *ro
 		FH_HIP(hipMemsetAsync(done, 0, 4 * sizeof(int), s));
 		hipLaunchKernelGGL(fplu_update_kernel<T>, g0, dim3(256), 0, s, V.p, V.rs, V.cs, m, n, 0, 0, 0, 0, partb.as<FpBest>(), done);
 		int nparts = (int) (g0.x * g0.y);
+		const unsigned swap_grid = (unsigned) (((m > n ? m : n) + 255) / 256);
 		for (idx_t k = 0; k < size; ++k) {
-			hipLaunchKernelGGL(fplu_pivot_kernel<T>, dim3(1), dim3(1024), 0, s, V.p, V.rs, V.cs, m, n, (int) k, (int) size, transpose ? 1 : 0,
+			hipLaunchKernelGGL(fplu_swap_kernel<T>, dim3(swap_grid), dim3(256), 0, s, V.p, V.rs, V.cs, m, n, (int) k, (int) size, transpose ? 1 : 0,
 					   partb.as<const FpBest>(), nparts, rt, ct, done);
 			if (k + 1 == size)
 				break;
