@@ -951,7 +951,7 @@ template <typename T> static void qr_t_blocks_from_taus(MatV<T> A, MatV<T> H, id
 struct CpState {
 	double best_threshold, scale_fwd, scale_bwd;
 	double l, tau_inv;
-	int delayed, best_col, n_trans, pad;
+	int delayed, best_col, n_trans, flush; // flush: this step applies the pending update at once and recomputes the norms (:178-203)
 };
 
 template <typename T> struct CpArgs {
@@ -1071,59 +1071,31 @@ template <typename T> __global__ void cp_scale_kernel(const CpArgs<T> a, int upp
 	}
 }
 
-// factor.rs:163-177: best remaining column by the down-dated norms, decision "delayed update or recompute"
-template <typename T> __global__ __launch_bounds__(1024) void cp_select_kernel(const CpArgs<T> a)
-{
-	__shared__ double s_v[16];
-	__shared__ int s_c[16];
-	T best;
-	int col;
-	cp_argmax<T>(a.norm, a.k, a.n, best, col, s_v, s_c);
-	if (threadIdx.x == 0) {
-		a.st->delayed = (a.delayed_ok && a.k > 0 && (double) best >= a.st->best_threshold) ? 1 : 0;
-		a.st->best_col = col;
-	}
-}
-
-// factor.rs:178-203 (k > 0 and not delayed): A11 += A10[:, k-1] dot[k:], fresh norms; one workgroup per column
+// factor.rs:178-203 (k > 0 and not delayed): A11 += A10[:, k-1] dot[k:], fresh norms; a workgroup per column, a fixed small grid (the
+// launch is a no-op on most steps: st->flush is decided on the device)
 template <typename T> __global__ __launch_bounds__(256) void cp_flush_kernel(const CpArgs<T> a)
 {
 	__shared__ double s_part[4 * 3], s_red[3];
-	if (a.st->delayed)
+	if (!a.st->flush)
 		return;
-	const int j = a.k + blockIdx.x;
-	const T d = a.dot[j];
-	for (int i = a.k + threadIdx.x; i < a.m; i += 256) {
-		T *p = a.A + (idx_t) i * a.rs + (idx_t) j * a.cs;
-		*p = fh_fma(a.A[(idx_t) i * a.rs + (idx_t) (a.k - 1) * a.cs], d, *p);
-	}
-	__syncthreads();
-	const T v = cp_col_norm<T>(a, a.k, j, s_part, s_red);
-	if (threadIdx.x == 0)
-		a.norm[j] = v;
-}
-
-template <typename T> __global__ __launch_bounds__(1024) void cp_select2_kernel(const CpArgs<T> a)
-{
-	__shared__ double s_v[16];
-	__shared__ int s_c[16];
-	if (a.st->delayed)
-		return;
-	T best;
-	int col;
-	cp_argmax<T>(a.norm, a.k, a.n, best, col, s_v, s_c);
-	if (threadIdx.x == 0) {
-		a.st->best_col = col;
-		a.st->best_threshold = (double) (best * (T) sqrt((double) Lim<T>::eps));
+	for (int j = a.k + blockIdx.x; j < a.n; j += gridDim.x) {
+		const T d = a.dot[j];
+		for (int i = a.k + threadIdx.x; i < a.m; i += 256) {
+			T *p = a.A + (idx_t) i * a.rs + (idx_t) j * a.cs;
+			*p = fh_fma(a.A[(idx_t) i * a.rs + (idx_t) (a.k - 1) * a.cs], d, *p);
+		}
+		__syncthreads();
+		const T v = cp_col_norm<T>(a, a.k, j, s_part, s_red);
+		if (threadIdx.x == 0)
+			a.norm[j] = v;
 	}
 }
 
 // factor.rs:204-252: column swap, the pending update of column k, its reflector (householder.rs:59-107)
-template <typename T> __global__ __launch_bounds__(1024) void cp_house_kernel(const CpArgs<T> a)
+template <typename T> static __device__ __forceinline__ void cp_house_body(const CpArgs<T> &a, const int bc, const int delayed)
 {
 	__shared__ double s_part[16 * 3], s_red[3];
 	const int tid = threadIdx.x, k = a.k;
-	const int bc = a.st->best_col, delayed = a.st->delayed;
 	if (bc != k) {
 		for (int i = tid; i < a.m; i += 1024) {
 			T *p = a.A + (idx_t) i * a.rs + (idx_t) k * a.cs, *q = a.A + (idx_t) i * a.rs + (idx_t) bc * a.cs;
@@ -1218,6 +1190,46 @@ template <typename T> __global__ __launch_bounds__(1024) void cp_house_kernel(co
 			a.A[(idx_t) k * a.rs + (idx_t) j * a.cs] += l * a.dot[j];
 }
 
+// Round 6: one launch per step on the common path.  factor.rs:163-177: the best remaining column by the down-dated norms and the decision
+// "delayed update or recompute"; if delayed (or k == 0) the column swap and the reflector follow in the same workgroup, else the step is
+// handed to cp_flush_kernel + cp_step2_kernel (both return at once otherwise).  Rounds 1-5: select, flush, select2, house = four launches,
+// two of them no-ops of 3-4 us on almost every step.
+template <typename T> __global__ __launch_bounds__(1024) void cp_step_kernel(const CpArgs<T> a)
+{
+	__shared__ double s_v[16];
+	__shared__ int s_c[16];
+	T best;
+	int col;
+	cp_argmax<T>(a.norm, a.k, a.n, best, col, s_v, s_c);
+	const int delayed = (a.delayed_ok && a.k > 0 && (double) best >= a.st->best_threshold) ? 1 : 0;
+	const int flush = a.k > 0 && !delayed;
+	__syncthreads(); // (everyone has read the threshold)
+	if (threadIdx.x == 0) {
+		a.st->delayed = delayed;
+		a.st->best_col = col;
+		a.st->flush = flush;
+	}
+	if (flush)
+		return;
+	cp_house_body<T>(a, col, delayed);
+}
+
+template <typename T> __global__ __launch_bounds__(1024) void cp_step2_kernel(const CpArgs<T> a)
+{
+	__shared__ double s_v[16];
+	__shared__ int s_c[16];
+	if (!a.st->flush)
+		return;
+	T best;
+	int col;
+	cp_argmax<T>(a.norm, a.k, a.n, best, col, s_v, s_c);
+	if (threadIdx.x == 0) {
+		a.st->best_col = col;
+		a.st->best_threshold = (double) (best * (T) sqrt((double) Lim<T>::eps));
+	}
+	cp_house_body<T>(a, col, 0);
+}
+
 // factor.rs:266-301 / update_mat_and_dot_simd (:60-98): one workgroup per trailing column
 template <typename T> __global__ __launch_bounds__(256) void cp_update_kernel(const CpArgs<T> a)
 {
@@ -1290,12 +1302,11 @@ template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, 
 	hipLaunchKernelGGL(cp_scale_kernel<T>, dim3(1024), dim3(256), 0, s, a, 0);
 	for (idx_t k = 0; k < size; ++k) {
 		a.k = (int) k;
-		hipLaunchKernelGGL(cp_select_kernel<T>, dim3(1), dim3(1024), 0, s, a);
+		hipLaunchKernelGGL(cp_step_kernel<T>, dim3(1), dim3(1024), 0, s, a);
 		if (k > 0) {
-			hipLaunchKernelGGL(cp_flush_kernel<T>, dim3((unsigned) (n - k)), dim3(256), 0, s, a);
-			hipLaunchKernelGGL(cp_select2_kernel<T>, dim3(1), dim3(1024), 0, s, a);
+			hipLaunchKernelGGL(cp_flush_kernel<T>, dim3((unsigned) (n - k < 512 ? n - k : 512)), dim3(256), 0, s, a);
+			hipLaunchKernelGGL(cp_step2_kernel<T>, dim3(1), dim3(1024), 0, s, a);
 		}
-		hipLaunchKernelGGL(cp_house_kernel<T>, dim3(1), dim3(1024), 0, s, a);
 		if (k + 1 < size)
 			hipLaunchKernelGGL(cp_update_kernel<T>, dim3((unsigned) (n - k - 1)), dim3(256), 0, s, a);
 	}
