@@ -574,7 +574,7 @@ def main():
             # idle-chip hand-off between two workgroups.  It separated the pool's two kinds of boxes for most of
             # round 5 and then read 0.39-0.42 us on boxes that ran LU in 104-105 ms and 0.58 us on one that ran it in 87.8: it does
             # NOT classify a box.  What does is in the line already: others.*.roofline.dominant_kernel.chain_kernel.us_per_column,
-            # measured in the same run (LU leaf 3.0 against 3.85 us per column, Cholesky leaf 0.475 against 0.56-0.58)
+            # measured in the same run (LU leaf 3.0 against 3.85 us per column, Cholesky leaf 0.475 against 0.56-0.58; profiles/notes/DESIGN_history_r01_r05.md 6e)
             out["xwg_hop_us"] = round(F.xwg_hop_us(2000), 3)
         except Exception:
             out["xwg_hop_us"] = None
@@ -650,7 +650,7 @@ def main():
                     if args.pause > 0:
                         # the chip leaves a long MFMA-bound run (the headline, LLT, LU) at reduced clocks for a while and the
                         # latency-bound workloads after it measured up to 40 % slower than on their own: every entry of
-                        # `others` starts from an idle chip (documented in DESIGN.md 6c; --pause 0 restores back-to-back runs)
+                        # `others` starts from an idle chip (documented in profiles/notes/DESIGN_history_r01_r05.md 6c; --pause 0 restores back-to-back runs)
                         torch.cuda.synchronize()
                         time.sleep(args.pause)
                     reps = 5

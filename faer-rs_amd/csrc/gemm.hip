@@ -1298,7 +1298,7 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 	g.stair_gap = (int) ex.stair_gap;
 	g.stair_row0 = (int) ex.stair_row0;
 	{
-		g.raster_g = 8; // (2 ... 32 measured within 0.3 % of each other at N = 8192: DESIGN.md 3.1)
+		g.raster_g = 8; // (2 ... 32 measured within 0.3 % of each other at N = 8192: profiles/notes/DESIGN_history_r01_r05.md 3.1)
 	}
 	g.epi_serial = 0; // (1: one read-modify-write per element, the pre-round-1-fix epilogue; kept for the record, profiles/r01_exp_syrk_rates.txt)
 	const bool extra_path = ex.diag || ex.a_struct || ex.b_struct;

@@ -913,7 +913,7 @@ template <typename T> static void qr_t_blocks_from_taus(MatV<T> A, MatV<T> H, id
 {
 	const idx_t m = A.nrows, n = A.ncols, bs = H.nrows;
 	const idx_t size = m < n ? m : n;
-	const bool batched = true; // (one split-K GEMM per block was 15 ms of every N = 4096 reduction: DESIGN.md 3.5c)
+	const bool batched = true; // (one split-K GEMM per block was 15 ms of every N = 4096 reduction: DESIGN.md 3.8)
 	if (batched && bs <= TB_MAXW && rank > 0) {
 		if (bs > 1) {
 			hipLaunchKernelGGL(qr_tblock_gram_kernel<T>, dim3((unsigned) ((rank + bs - 1) / bs)), dim3(TB_NT), 0, ctx().stream, A.p, A.rs, A.cs, (int) m,
