@@ -20,6 +20,7 @@
 //  * GENERAL (rank revealing): a literal restatement of qr_in_place_unblocked (factor.rs:11-86) with the
 //    running `row` kept in device memory (no host round trip per column), followed by the T blocks
 //    T = striu(V^H V) + diag(tau) per block of accepted reflectors.
+#include <atomic>
 #include <climits>
 #include <limits>
 
@@ -1348,13 +1349,18 @@ template long colpiv_qr_dev<float>(MatV<float>, MatV<float>, idx_t *, idx_t *);
 // workgroup behind a release fence / ticket / acquire fence measured 2.4x slower in round 2 (an agent-scope fence writes
 // the L2 back) -- the sums here use the fence-free exchange of xwg.h instead.
 // ------------------------------------------------------------------------------------------------
+// tests: 1 = the vector kernels of the three reductions run their memory-resident bodies at every size (the bodies that keep their columns
+// in registers take over from 4096 remaining rows down; both must give the same bits)
+static std::atomic<int> g_l2_force_mem{0};
+void level2_debug_force_memory_bodies(int on) { g_l2_force_mem.store(on); }
+
 struct TdState {
 	double tau_inv;
 };
 template <typename T> struct TdArgs {
 	T *A;
 	idx_t rs, cs;
-	int n, k;
+	int n, k, force_mem;
 	T *y, *w, *taus;
 	double *ysum;	       // sym(A22) x of the fused pass, complete
 	double *rpart, *cpart; // shares of the tiles: row sums rpart[J * n + i] (column block J), column sums cpart[I * n + j] (row block I)
@@ -1605,7 +1611,7 @@ template <typename T> static __device__ __forceinline__ void td_step_body_reg(co
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void td_step_kernel(const TdArgs<T> a)
 {
-	if (a.n - a.k - 1 <= TD_E * TD_NT)
+	if (a.n - a.k - 1 <= TD_E * TD_NT && !a.force_mem)
 		td_step_body_reg<T>(a, a.k);
 	else
 		td_step_body<T>(a, a.k);
@@ -1773,6 +1779,7 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 	Scratch vb((size_t) (4 * n) * sizeof(T) + 256), cb((size_t) (1 + ncb + nbr) * (size_t) n * sizeof(double)), stb(sizeof(TdState)),
 		cntb((size_t) ncb * sizeof(unsigned));
 	TdArgs<T> a;
+	a.force_mem = g_l2_force_mem.load();
 	a.A = A.p;
 	a.rs = A.rs;
 	a.cs = A.cs;
@@ -1831,7 +1838,7 @@ struct BdState {
 template <typename T> struct BdArgs {
 	T *A;
 	idx_t rs, cs;
-	int m, n, size, k;
+	int m, n, size, k, force_mem;
 	T *y, *z, *ysum, *zsum, *vrow, *taul, *taur;
 	double *ypart, *zpart; // shares of the tiles: ypart[row block * n + j], zpart[column block * m + i]
 	BdState *st;
@@ -2014,7 +2021,7 @@ template <typename T> static __device__ __forceinline__ void bd_pre_body_reg(con
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void bd_pre_kernel(const BdArgs<T> a)
 {
-	if (a.m - a.k - 1 <= TD_E * TD_NT && a.n - a.k - 1 <= TD_E * TD_NT)
+	if (a.m - a.k - 1 <= TD_E * TD_NT && a.n - a.k - 1 <= TD_E * TD_NT && !a.force_mem)
 		bd_pre_body_reg<T>(a);
 	else
 		bd_pre_body<T>(a);
@@ -2112,7 +2119,7 @@ template <typename T> static __device__ __forceinline__ void bd_mid_body_reg(con
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void bd_mid_kernel(const BdArgs<T> a)
 {
-	if (a.n - a.k - 1 <= TD_E * TD_NT)
+	if (a.n - a.k - 1 <= TD_E * TD_NT && !a.force_mem)
 		bd_mid_body_reg<T>(a);
 	else
 		bd_mid_body<T>(a);
@@ -2333,6 +2340,7 @@ template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
 	const idx_t nrb = (m + BC_TR - 1) / BC_TR, ncb = (n + BR_TC - 1) / BR_TC;
 	Scratch vb((size_t) (3 * n + 2 * m + 2 * n) * sizeof(T) + 256), stb(sizeof(BdState)), pb((size_t) (nrb * n + ncb * m) * sizeof(double));
 	BdArgs<T> a;
+	a.force_mem = g_l2_force_mem.load();
 	a.A = A.p;
 	a.rs = A.rs;
 	a.cs = A.cs;
@@ -2405,7 +2413,7 @@ struct HsState {
 template <typename T> struct HsArgs {
 	T *A;
 	idx_t rs, cs;
-	int n, k;
+	int n, k, force_mem;
 	T *y, *z, *ysum, *zsum, *taus;
 	double *ypart, *zpart; // shares of the tiles of the fused pass: ypart[row block * n + j], zpart[column block * n + i]
 	HsState *st;
@@ -2568,7 +2576,7 @@ template <typename T> static __device__ __forceinline__ void hs_pre_body_reg(con
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void hs_pre_kernel(const HsArgs<T> a)
 {
-	if (a.n - a.k <= TD_E * TD_NT)
+	if (a.n - a.k <= TD_E * TD_NT && !a.force_mem)
 		hs_pre_body_reg<T>(a);
 	else
 		hs_pre_body<T>(a);
@@ -2734,6 +2742,7 @@ template <typename T> void hessenberg_dev(MatV<T> A, MatV<T> H)
 	const idx_t nrb = (n + TF_TR - 1) / TF_TR, ncb = (n + TF_TC - 1) / TF_TC;
 	Scratch vb((size_t) (5 * n) * sizeof(T) + 256), stb(sizeof(HsState)), pb((size_t) (nrb + ncb) * (size_t) n * sizeof(double));
 	HsArgs<T> a;
+	a.force_mem = g_l2_force_mem.load();
 	a.ypart = pb.as<double>();
 	a.zpart = a.ypart + (size_t) nrb * (size_t) n;
 	a.A = A.p;

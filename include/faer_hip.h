@@ -497,6 +497,9 @@ FAER_HIP_API long faer_hip_debug_qr_one_pass_columns(void);
 /* tests / A-B measurements: 0 = the one-pass QR path applies a panel and forms the next panel's Gram products in separate launches (the
  * round 3-5 schedule), 1 (default) = in one pass per panel with the next panel's kernel beside its second half (csrc/tsqr.hip). */
 FAER_HIP_API void faer_hip_debug_qr_fused(int on);
+/* tests: 1 = the single-workgroup vector kernels of the tridiagonal / bidiagonal / Hessenberg reductions run their memory-resident bodies
+ * at every size (default: from 4096 remaining rows down they keep their columns in registers); results must not depend on it. */
+FAER_HIP_API void faer_hip_debug_level2_force_memory_bodies(int on);
 /* host logic of the distributed LU: may a step factor its look-ahead panel of `panel_rows` rows on the CU-masked panel stream? */
 FAER_HIP_API int faer_hip_debug_dist_two_streams_ok(size_t panel_rows, FaerHipDType dtype, int panel_cus, int all_cus);
 /* Instrumented builds (make -C csrc timing): prints and resets the in-kernel phase counters; a no-op otherwise. */
