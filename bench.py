@@ -88,7 +88,9 @@ def resolve_run(gpus, workload, transport):
     if workload is None:
         workload = "lu" if multi else "gemm"
     if transport is None:
-        transport = "rccl" if (multi and defaulted) else "torch"
+        # (round 6: an explicit --workload lu / llt on several GPUs takes the library's RCCL transport as well -- the torch transport runs a
+        # Python callback per broadcast, which measured 201 ms against ~100 for the one-rank Cholesky and is not what a user would deploy)
+        transport = "rccl" if (multi and workload in ("lu", "llt")) else "torch"
     return workload, transport, defaulted
 
 

@@ -27,7 +27,8 @@ def test_default_workload_several_gpus_is_the_block_cyclic_lu_over_rccl():
 def test_explicit_choices_are_kept():
     assert bench.resolve_run(8, "gemm", None) == ("gemm", "torch", False)
     assert bench.resolve_run(8, "llt", "rccl") == ("llt", "rccl", False)
-    assert bench.resolve_run(2, "lu", None) == ("lu", "torch", False)  # (the historical default transport of an explicit --workload)
+    assert bench.resolve_run(2, "lu", None) == ("lu", "rccl", False)  # (round 6: the library's own transport for every distributed factorization)
+    assert bench.resolve_run(2, "llt", None) == ("llt", "rccl", False) and bench.resolve_run(2, "lu", "torch") == ("lu", "torch", False)
     assert bench.resolve_run(1, "lu", "rccl") == ("lu", "rccl", False)
 
 
