@@ -1335,22 +1335,23 @@ template long colpiv_qr_dev<float>(MatV<float>, MatV<float>, idx_t *, idx_t *);
 // A level-2, HBM-bound algorithm like the reference's: per column ONE pass over the remaining lower triangle that
 // applies the symmetric rank-2 update of the previous reflector and multiplies the updated matrix by the new one
 // (tridiag_fused_op, :36-272), between two short vector phases.  Two launches per column, no host synchronisation:
-//   td_step_kernel(k)   one workgroup: finishes y of step k-1 (:484-511), brings column k up to date (:300-318), makes
-//                       its reflector (:330-336, householder.rs:59-107), updates column k+1 (:348-359), w <- y
+//   td_step_kernel(k)   block 0: finishes y of step k-1 (:484-511), brings column k up to date (:300-318), makes its reflector
+//                       (:330-336, householder.rs:59-107), updates column k+1 (:348-359), w <- y; blocks 1 ..: add the shares of the
+//                       previous pass in a fixed order -> ysum (one block per 64 entries) while block 0 loads its columns, and hand
+//                       them over inside the launch (write-through stores + one flag per block, xwg.h: no fence)
 //   td_fused_kernel(k)  one workgroup per 128 x 64 tile of the lower triangle of A22 = A[k+2.., k+2..], lanes along the rows:
 //                       A22 -= u w^H + w u^H written back (every entry is read and written ONCE) and the tile's share of both halves
-//                       of sym(A22) x -- the row sums tril(A22) x and the column sums striu(A22^H) x.  The shares leave the
-//                       workgroup as write-through stores (xwg.h: no fence); the workgroup that completes an index block of 64
-//                       entries (an arrival counter per block) adds that block's shares in a FIXED order -> ysum, so the result
-//                       does not depend on which workgroup that is.
-// History: rounds 2-5 read the triangle twice (a column pass that wrote back and a 16-row pass, each sum complete in one
-// wavefront / workgroup: 185 ms at N = 4096); cut into uniform pieces with partial sums added by the step kernel: 150 ms (the
-// chip waited for the longest workgroup); one pass with in-kernel sums: DESIGN.md.  Running the vector phase in the last
-// workgroup behind a release fence / ticket / acquire fence measured 2.4x slower in round 2 (an agent-scope fence writes
-// the L2 back) -- the sums here use the fence-free exchange of xwg.h instead.
+//                       of sym(A22) x -- the row sums tril(A22) x and the column sums striu(A22^H) x
+// History (N = 4096 fp64): rounds 2-5 read the triangle twice (a column pass that wrote back and a 16-row pass, each sum complete in
+// one wavefront / workgroup): 185 ms; cut into uniform pieces with partial sums added by the step kernel: 150 ms (the chip had waited
+// for the longest workgroup); one pass over tiles, the sums inside that pass behind a ticket (write-through + atomic, no fence): 140 ms
+// -- the tail "drain, ticket, reload, add" is four memory round trips in every launch; the sums as a launch of their own: 116 ms; loads
+// without branches, DPP column sums, a step kernel that holds its three columns in registers: 95 ms; the sums as helper blocks of the
+// step launch: 88 ms.  Running the vector phase in the last workgroup behind a release fence measured 2.4x slower in round 2 (an
+// agent-scope fence writes the L2 back).
 // ------------------------------------------------------------------------------------------------
 // tests: 1 = the vector kernels of the three reductions run their memory-resident bodies at every size (the bodies that keep their columns
-// in registers take over from 4096 remaining rows down; both must give the same bits)
+// in registers take over from 4096 remaining rows down)
 static std::atomic<int> g_l2_force_mem{0};
 void level2_debug_force_memory_bodies(int on) { g_l2_force_mem.store(on); }
 
@@ -1364,7 +1365,7 @@ template <typename T> struct TdArgs {
 	T *y, *w, *taus;
 	double *ysum;	       // sym(A22) x of the fused pass, complete
 	double *rpart, *cpart; // shares of the tiles: row sums rpart[J * n + i] (column block J), column sums cpart[I * n + j] (row block I)
-	unsigned *cnt;	       // arrival counters per index block of TF_TC entries (zero between launches)
+	xwg_u64 *flags;	       // per index block: the step whose sums are complete (td_sum_block / td_wait_sums)
 	TdState *st;
 };
 constexpr int TD_NT = 1024; // td_step_kernel
@@ -1394,6 +1395,68 @@ template <int CNT> static __device__ __forceinline__ void td_block_sum(double (&
 	__syncthreads();
 }
 
+// Tiles of the lower triangle of an r x r matrix, TF_TR rows x TF_TC columns: tile (I, J) exists for J <= 2 I + 1 and J < ncb; row block I has
+// td_row_tiles(I) of them, column block J lives in the row blocks J / 2 .. nbr - 1.
+static __device__ __forceinline__ int td_row_tiles(int I, int ncb) { return min(2 * I + 2, ncb); }
+
+// Index block b of TF_TC entries of the fused pass of step kk (A22 = A[kk+2.., kk+2..]): the shares of its row tiles and of its column's
+// tiles, added in a fixed order -> ysum, by the 1024 threads of the calling workgroup; stored write-through (xwg.h) because the reader is
+// another workgroup of the SAME launch: the blocks 1 .. of td_step_kernel(k) add the shares of pass k - 1 while block 0 loads its columns,
+// then raise their flag; block 0 waits for the flags and reads the sums past its caches.  (A launch of its own for the sums -- round 6's
+// first version -- cost 4.7 us per column: a launch and a memory round trip that nothing overlapped.)
+constexpr int TS_NT = 1024, TS_NS = TS_NT / TF_TC; // 16 slices of the list of shares per entry
+template <typename T> static __device__ __forceinline__ void td_sum_block(const TdArgs<T> &a, const int kk, const int b)
+{
+	__shared__ double s_q[TS_NS][TF_TC];
+	const int tid = threadIdx.x;
+	const int base = kk + 2, r = a.n - base;
+	const int nbr = (r + TF_TR - 1) / TF_TR, ncb = (r + TF_TC - 1) / TF_TC;
+	const int Ib = b >> 1;
+	const int nrp = td_row_tiles(Ib, ncb), tot = nrp + (nbr - Ib);
+	const int e = tid & 63, qq = tid >> 6, i = min(b * TF_TC + e, r - 1);
+	const int per = (tot + TS_NS - 1) / TS_NS, p0 = qq * per;
+	double sacc = 0.0;
+	for (int pb = 0; pb < per; pb += 4) {
+		double v[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int p = p0 + pb + u;
+			const bool in = pb + u < per && p < tot;
+			const int pc = in ? p : 0;
+			const double *src = pc < nrp ? a.rpart + (size_t) pc * a.n : a.cpart + (size_t) (Ib + pc - nrp) * a.n;
+			v[u] = src[base + i];
+			if (!in)
+				v[u] = 0.0;
+		}
+		sacc += (v[0] + v[1]) + (v[2] + v[3]);
+	}
+	__syncthreads(); // (s_q of a previous call has been read)
+	s_q[qq][e] = sacc;
+	__syncthreads();
+	if (tid < TF_TC && b * TF_TC + tid < r) {
+		double t = 0.0;
+#pragma unroll
+		for (int q = 0; q < TS_NS; ++q)
+			t += s_q[q][tid];
+		xwg_store(a.ysum + base + b * TF_TC + tid, t);
+	}
+}
+// block 0 of td_step_kernel(k), k > 0: the sums of pass k - 1 are complete (flags of the helper blocks; if they do not come -- the
+// launch shares the GPU and the helpers are not resident -- block 0 adds the shares itself)
+template <typename T> static __device__ __forceinline__ void td_wait_sums(const TdArgs<T> &a, const int k)
+{
+	__shared__ int s_flag;
+	const int nsb = (a.n - (k + 1) + TF_TC - 1) / TF_TC;
+	if (nsb <= 0)
+		return;
+	if (!xwg_wait_all(a.flags, nsb, (xwg_u64) k, &s_flag)) {
+		for (int b = 0; b < nsb; ++b)
+			td_sum_block<T>(a, k - 1, b);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+	}
+}
+
 template <typename T> static __device__ __forceinline__ void td_step_body(const TdArgs<T> &a, const int k)
 {
 	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
@@ -1404,10 +1467,11 @@ template <typename T> static __device__ __forceinline__ void td_step_body(const 
 	if (k > 0) {
 		// ---- y of step k - 1 (:484-511): x = the reflector in column k-1 (rows k+1..), ysum = sym(A22) x from the fused pass
 		const T tau_inv = (T) a.st->tau_inv;
+		td_wait_sums<T>(a, k);
 		double d[2] = {0.0, 0.0};
 		for (int i = k + 1 + tid; i < n; i += TD_NT) {
 			const T aik = at(i, k), xi = at(i, k - 1);
-			T yv = tau_inv * (T) a.ysum[i];
+			T yv = tau_inv * (T) xwg_load(a.ysum + i);
 			yv += aik * tau_inv;
 			a.y[i] = yv;
 			d[0] += (double) aik * (double) xi;
@@ -1511,11 +1575,19 @@ template <typename T> static __device__ __forceinline__ void td_step_body_reg(co
 		const int ic = in ? i : n - 1;
 		aik[e] = at(ic, k);
 		xi[e] = upd ? at(ic, k - 1) : (T) 0;
-		ys[e] = upd ? a.ysum[ic] : 0.0;
+		ys[e] = 0.0;
 		ak1[e] = (upd && more) ? at(ic, k + 1) : (T) 0;
 		yi[e] = (T) 0;
 	}
 	const T akk = at(k, k), tau_inv = (T) a.st->tau_inv;
+	if (upd) { // (the loads above are in flight while the helper blocks finish the sums)
+		td_wait_sums<T>(a, k);
+#pragma unroll
+		for (int e = 0; e < TD_E; ++e) {
+			const int i = k + 1 + tid + e * TD_NT;
+			ys[e] = xwg_load(a.ysum + (i < n ? i : n - 1));
+		}
+	}
 	T y1 = (T) 0;
 	T nacc[3] = {0, 0, 0}; // scaled sums of the tail of column k (reductions/norm_l2.rs:6-45)
 	if (upd) {
@@ -1611,6 +1683,14 @@ template <typename T> static __device__ __forceinline__ void td_step_body_reg(co
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void td_step_kernel(const TdArgs<T> a)
 {
+	if (blockIdx.x > 0) { // helper block: the sums of index block blockIdx.x - 1 of pass k - 1
+		td_sum_block<T>(a, a.k - 1, (int) blockIdx.x - 1);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0)
+			__hip_atomic_store(a.flags + (blockIdx.x - 1), (xwg_u64) a.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return;
+	}
 	if (a.n - a.k - 1 <= TD_E * TD_NT && !a.force_mem)
 		td_step_body_reg<T>(a, a.k);
 	else
@@ -1643,9 +1723,6 @@ static __device__ __forceinline__ double td_wave_sum(double v)
 	return ((td_lane(v, 0) + td_lane(v, 16)) + td_lane(v, 32)) + td_lane(v, 48);
 }
 
-// Tiles of the lower triangle of an r x r matrix, TF_TR rows x TF_TC columns: tile (I, J) exists for J <= 2 I + 1 and J < ncb; row block I has
-// td_row_tiles(I) of them, column block J lives in the row blocks J / 2 .. nbr - 1.
-static __device__ __forceinline__ int td_row_tiles(int I, int ncb) { return min(2 * I + 2, ncb); }
 
 // Tile (I, J) of A22 (header of this section).  Lane l of wavefront w: rows 128 I + l and + 64, columns 64 J + 16 w .. + 15; all 32 loads
 // of a thread are issued before the first use.
@@ -1727,44 +1804,6 @@ template <typename T, bool upd> __global__ __launch_bounds__(TF_NT) void td_fuse
 		a.rpart[(size_t) J * a.n + base + i0 + tid] = ((s_row[0][tid] + s_row[1][tid]) + s_row[2][tid]) + s_row[3][tid];
 }
 
-// Index block b of TF_TC entries: the shares of its row tiles and of its column's tiles, added in a fixed order -> ysum.
-constexpr int TS_NT = 1024, TS_NS = TS_NT / TF_TC; // 16 slices of the list of shares per entry
-template <typename T> __global__ __launch_bounds__(TS_NT) void td_sum_kernel(const TdArgs<T> a)
-{
-	__shared__ double s_q[TS_NS][TF_TC];
-	const int tid = threadIdx.x, k = a.k;
-	const int base = k + 2, r = a.n - base;
-	const int nbr = (r + TF_TR - 1) / TF_TR, ncb = (r + TF_TC - 1) / TF_TC;
-	const int b = blockIdx.x, Ib = b >> 1;
-	const int nrp = td_row_tiles(Ib, ncb), tot = nrp + (nbr - Ib);
-	const int e = tid & 63, qq = tid >> 6, i = min(b * TF_TC + e, r - 1);
-	const int per = (tot + TS_NS - 1) / TS_NS, p0 = qq * per;
-	double sacc = 0.0;
-	for (int pb = 0; pb < per; pb += 4) {
-		double v[4];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const int p = p0 + pb + u;
-			const bool in = pb + u < per && p < tot;
-			const int pc = in ? p : 0;
-			const double *src = pc < nrp ? a.rpart + (size_t) pc * a.n : a.cpart + (size_t) (Ib + pc - nrp) * a.n;
-			v[u] = src[base + i];
-			if (!in)
-				v[u] = 0.0;
-		}
-		sacc += (v[0] + v[1]) + (v[2] + v[3]);
-	}
-	s_q[qq][e] = sacc;
-	__syncthreads();
-	if (tid < TF_TC && b * TF_TC + tid < r) {
-		double t = 0.0;
-#pragma unroll
-		for (int q = 0; q < TS_NS; ++q)
-			t += s_q[q][tid];
-		a.ysum[base + b * TF_TC + tid] = t;
-	}
-}
-
 // A: n x n (lower triangle used), H: block_size x (n - 1)
 template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 {
@@ -1777,7 +1816,7 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 	hipStream_t s = ctx().stream;
 	const idx_t nbr = (n + TF_TR - 1) / TF_TR, ncb = (n + TF_TC - 1) / TF_TC;
 	Scratch vb((size_t) (4 * n) * sizeof(T) + 256), cb((size_t) (1 + ncb + nbr) * (size_t) n * sizeof(double)), stb(sizeof(TdState)),
-		cntb((size_t) ncb * sizeof(unsigned));
+		cntb((size_t) (ncb + 1) * sizeof(xwg_u64));
 	TdArgs<T> a;
 	a.force_mem = g_l2_force_mem.load();
 	a.A = A.p;
@@ -1790,14 +1829,16 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 	a.ysum = cb.as<double>();
 	a.rpart = a.ysum + n;
 	a.cpart = a.rpart + (size_t) ncb * (size_t) n;
-	a.cnt = cntb.as<unsigned>();
+	a.flags = cntb.as<xwg_u64>();
 	a.st = stb.as<TdState>();
 	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (4 * n) * sizeof(T), s));
 	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(TdState), s));
-	FH_HIP(hipMemsetAsync(cntb.p, 0, (size_t) ncb * sizeof(unsigned), s));
+	FH_HIP(hipMemsetAsync(cntb.p, 0, (size_t) (ncb + 1) * sizeof(xwg_u64), s));
 	for (idx_t k = 0; k < n; ++k) {
 		a.k = (int) k;
-		hipLaunchKernelGGL(td_step_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
+		// block 0: the step; blocks 1 ..: the sums of the previous pass (k > 0), one per index block of TF_TC entries
+		const unsigned nsb = k > 0 ? (unsigned) ((n - k - 1 + TF_TC - 1) / TF_TC) : 0u;
+		hipLaunchKernelGGL(td_step_kernel<T>, dim3(1 + nsb), dim3(TD_NT), 0, s, a);
 		const idx_t r = n - k - 2;
 		if (r > 0) {
 			const idx_t rb = (r + TF_TR - 1) / TF_TR;
@@ -1805,7 +1846,6 @@ template <typename T> void tridiag_dev(MatV<T> A, MatV<T> H)
 				hipLaunchKernelGGL((td_fused_kernel<T, true>), dim3((unsigned) (rb * (rb + 1))), dim3(TF_NT), 0, s, a);
 			else
 				hipLaunchKernelGGL((td_fused_kernel<T, false>), dim3((unsigned) (rb * (rb + 1))), dim3(TF_NT), 0, s, a);
-			hipLaunchKernelGGL(td_sum_kernel<T>, dim3((unsigned) ((r + TF_TC - 1) / TF_TC)), dim3(TS_NT), 0, s, a);
 		}
 	}
 	FH_HIP(hipGetLastError());
