@@ -1879,8 +1879,11 @@ template <typename T> struct BdArgs {
 	T *A;
 	idx_t rs, cs;
 	int m, n, size, k, force_mem;
-	T *y, *z, *ysum, *zsum, *vrow, *taul, *taur;
+	T *y, *z, *vrow, *taul, *taur;
+	double *ysum, *zsum;   // u^H A22 and A22 v of the two passes, complete (fixed-order sums of the shares below)
 	double *ypart, *zpart; // shares of the tiles: ypart[row block * n + j], zpart[column block * m + i]
+	xwg_u64 *yflag, *zflag; // per helper block of bd_mid_kernel / bd_pre_kernel: the launch whose sums are complete
+	int nh;		       // helper blocks of this launch (0: the sums were prepared otherwise)
 	BdState *st;
 };
 
@@ -1906,6 +1909,63 @@ template <typename T> static __device__ __forceinline__ T bd_householder(T &head
 	return (T) 0.5 * ((T) 1 + tn * tn);
 }
 
+constexpr int BC_TR = 256, BC_TC = 32, BC_NT = 256; // tiles of bd_col_kernel
+constexpr int BR_TR = 128, BR_TC = 128, BR_NT = 256; // tiles of bd_row_kernel
+// Helper block h of a single-workgroup launch: out[off + e] = the sum of `np` shares part[p * stride + off + e], e in [1024 h, 1024 h + 1024)
+// and < len, added in the order of p; stored write-through and flagged, because the reader is block 0 of the SAME launch (xwg.h; the
+// tridiagonalization's td_sum_block has the reasoning).  All 1024 threads of the calling workgroup.
+static __device__ __forceinline__ void bd_sum_block(const double *part, int np, size_t stride, int off, int len, double *out, int h)
+{
+	const int e = h * TD_NT + (int) threadIdx.x;
+	if (e >= len)
+		return;
+	const double *src = part + off + e;
+	double s0 = 0.0;
+	int p = 0;
+	for (; p + 8 <= np; p += 8) {
+		double v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u)
+			v[u] = src[(size_t) (p + u) * stride];
+#pragma unroll
+		for (int u = 0; u < 8; ++u)
+			s0 += v[u];
+	}
+	for (; p < np; ++p)
+		s0 += src[(size_t) p * stride];
+	xwg_store(out + off + e, s0);
+}
+// which = 0: z sums of row pass k - 1 for bd_pre_kernel(k) (rows k .., column blocks of BR_TC); 1: y sums of column pass k for
+// bd_mid_kernel(k) (columns k + 1 .., row blocks of BC_TR)
+template <typename T> static __device__ __forceinline__ void bd_helper(const BdArgs<T> &a, int which, int h)
+{
+	if (which == 0)
+		bd_sum_block(a.zpart, (a.n - a.k + BR_TC - 1) / BR_TC, (size_t) a.m, a.k, a.m - a.k, a.zsum, h);
+	else
+		bd_sum_block(a.ypart, (a.m - a.k - 1 + BC_TR - 1) / BC_TR, (size_t) a.n, a.k + 1, a.n - a.k - 1, a.ysum, h);
+}
+template <typename T> static __device__ __forceinline__ void bd_helper_block(const BdArgs<T> &a, int which)
+{
+	bd_helper<T>(a, which, (int) blockIdx.x - 1);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0)
+		__hip_atomic_store((which == 0 ? a.zflag : a.yflag) + (blockIdx.x - 1), (xwg_u64) (a.k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// block 0: the sums are complete (or it adds the shares itself if the helpers' flags do not come)
+template <typename T> static __device__ __forceinline__ void bd_wait_sums(const BdArgs<T> &a, int which)
+{
+	__shared__ int s_flag;
+	if (a.nh <= 0)
+		return;
+	if (!xwg_wait_all(which == 0 ? a.zflag : a.yflag, a.nh, (xwg_u64) (a.k + 1), &s_flag)) {
+		for (int h = 0; h < a.nh; ++h)
+			bd_helper<T>(a, which, h);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+	}
+}
+
 template <typename T> static __device__ __forceinline__ void bd_pre_body(const BdArgs<T> &a)
 {
 	__shared__ double s_part[(TD_NT / 64) * 3], s_red[3];
@@ -1928,8 +1988,9 @@ template <typename T> static __device__ __forceinline__ void bd_pre_body(const B
 			}
 			return w * tr_inv;
 		};
+		bd_wait_sums<T>(a, 0);
 		const T up0 = at(k, k - 1), y1 = a.y[k];
-		const T z1 = fix(a.zsum[k], at(k, k), up0);
+		const T z1 = fix((T) xwg_load(a.zsum + k), at(k, k), up0);
 		__syncthreads(); // everyone has read a_kk
 		// ---- (i): the rest of the previous rank-2 update on column k, row k and a_kk (:80-98)
 		if (tid == 0) {
@@ -1938,7 +1999,7 @@ template <typename T> static __device__ __forceinline__ void bd_pre_body(const B
 		}
 		for (int i = k + 1 + tid; i < m; i += TD_NT) {
 			const T u = at(i, k - 1), old = at(i, k);
-			const T zf = fix(a.zsum[i], old, u);
+			const T zf = fix((T) xwg_load(a.zsum + i), old, u);
 			a.z[i] = zf;
 			const T v = old - (u * y1 + zf);
 			at(i, k) = v;
@@ -1991,7 +2052,7 @@ template <typename T> static __device__ __forceinline__ void bd_pre_body_reg(con
 		const int i = k + 1 + tid + e * TD_NT, ic = i < m ? i : m - 1;
 		cold[e] = at(ic, k);
 		cu[e] = upd ? at(ic, k - 1) : (T) 0;
-		czs[e] = upd ? a.zsum[ic] : (T) 0;
+		czs[e] = (T) 0;
 		const int j = k + 1 + tid + e * TD_NT, jc = j < n ? j : n - 1;
 		rk[e] = upd ? at(k, jc) : (T) 0;
 		rkm[e] = upd ? at(k - 1, jc) : (T) 0;
@@ -2014,7 +2075,13 @@ template <typename T> static __device__ __forceinline__ void bd_pre_body_reg(con
 			return w * tr_inv;
 		};
 		const T up0 = at(k, k - 1), y1 = a.y[k];
-		const T z1 = fix(a.zsum[k], akk, up0);
+		bd_wait_sums<T>(a, 0); // (the loads above are in flight while the helper blocks finish the sums)
+#pragma unroll
+		for (int e = 0; e < TD_E; ++e) {
+			const int i = k + 1 + tid + e * TD_NT;
+			czs[e] = (T) xwg_load(a.zsum + (i < m ? i : m - 1));
+		}
+		const T z1 = fix((T) xwg_load(a.zsum + k), akk, up0);
 		akk -= up0 * y1 + z1;
 		if (tid == 0)
 			a.z[k] = z1; // (a_kk itself is stored once, below, as the reflector's beta: nobody may see an intermediate value)
@@ -2061,6 +2128,10 @@ template <typename T> static __device__ __forceinline__ void bd_pre_body_reg(con
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void bd_pre_kernel(const BdArgs<T> a)
 {
+	if (blockIdx.x > 0) {
+		bd_helper_block<T>(a, 0);
+		return;
+	}
 	if (a.m - a.k - 1 <= TD_E * TD_NT && a.n - a.k - 1 <= TD_E * TD_NT && !a.force_mem)
 		bd_pre_body_reg<T>(a);
 	else
@@ -2081,7 +2152,12 @@ template <typename T> static __device__ __forceinline__ void bd_mid_body_reg(con
 	for (int e = 0; e < TD_E; ++e) {
 		const int j = k + 1 + tid + e * TD_NT, jc = j < n ? j : n - 1;
 		v[e] = row(jc);
-		yv[e] = a.ysum[jc];
+	}
+	bd_wait_sums<T>(a, 1); // (the strided loads of the row are in flight meanwhile)
+#pragma unroll
+	for (int e = 0; e < TD_E; ++e) {
+		const int j = k + 1 + tid + e * TD_NT;
+		yv[e] = (T) xwg_load(a.ysum + (j < n ? j : n - 1));
 	}
 	// ---- (iv) y2 = (y2 + A12) / tau_l, A12 -= y2, norm of A12 (:156-164)
 	T nacc[3] = {0, 0, 0};
@@ -2159,6 +2235,10 @@ template <typename T> static __device__ __forceinline__ void bd_mid_body_reg(con
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void bd_mid_kernel(const BdArgs<T> a)
 {
+	if (blockIdx.x > 0) {
+		bd_helper_block<T>(a, 1);
+		return;
+	}
 	if (a.n - a.k - 1 <= TD_E * TD_NT && !a.force_mem)
 		bd_mid_body_reg<T>(a);
 	else
@@ -2191,7 +2271,6 @@ template <typename T> __global__ __launch_bounds__(256) void vec_sum_kernel(cons
 
 // (iii): tile of BC_TR rows x BC_TC columns of A22 = A[k+1.., k+1..]; wavefront w owns 8 columns, a lane four rows of each (32 loads in
 // flight per thread): A22 -= up y2 + z2 vp written back, and the tile's share of y2 = u^H A22 -> ypart[row block][column].
-constexpr int BC_TR = 256, BC_TC = 32, BC_NT = 256;
 template <typename T, bool upd> __global__ __launch_bounds__(BC_NT) void bd_col_kernel(const BdArgs<T> a)
 {
 	constexpr int CW = BC_TC / (BC_NT / 64), RH = BC_TR / 64; // 8 columns per wavefront, 4 rows per lane
@@ -2261,8 +2340,9 @@ template <typename T> static __device__ __forceinline__ void bd_mid_body(const B
 	const T tl_inv = (T) a.st->tl_inv;
 	// ---- (iv) y2 = (y2 + A12) / tau_l, A12 -= y2, norm of A12 (:156-164)
 	T nacc[3] = {0, 0, 0};
+	bd_wait_sums<T>(a, 1);
 	for (int j = k + 1 + tid; j < n; j += TD_NT) {
-		const T yv = (a.ysum[j] + row(j)) * tl_inv;
+		const T yv = ((T) xwg_load(a.ysum + j) + row(j)) * tl_inv;
 		a.y[j] = yv;
 		const T v = row(j) - yv;
 		row(j) = v;
@@ -2323,7 +2403,6 @@ template <typename T> static __device__ __forceinline__ void bd_mid_body(const B
 
 // (v): z2 = A22 A12^H with the normalised row (vrow), read only: tile of BR_TR rows x BR_TC columns; wavefront w owns 32 columns, a lane two
 // rows of each (64 loads in two batches); the tile's share of the row sums -> zpart[column block][row].
-constexpr int BR_TR = 128, BR_TC = 128, BR_NT = 256;
 template <typename T> __global__ __launch_bounds__(BR_NT) void bd_row_kernel(const BdArgs<T> a)
 {
 	constexpr int CW = BR_TC / (BR_NT / 64); // 32 columns per wavefront
@@ -2378,7 +2457,9 @@ template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
 		return;
 	hipStream_t s = ctx().stream;
 	const idx_t nrb = (m + BC_TR - 1) / BC_TR, ncb = (n + BR_TC - 1) / BR_TC;
-	Scratch vb((size_t) (3 * n + 2 * m + 2 * n) * sizeof(T) + 256), stb(sizeof(BdState)), pb((size_t) (nrb * n + ncb * m) * sizeof(double));
+	const idx_t nhy = (n + TD_NT - 1) / TD_NT, nhz = (m + TD_NT - 1) / TD_NT; // helper blocks of bd_mid_kernel / bd_pre_kernel at most
+	Scratch vb((size_t) (4 * n + m) * sizeof(T) + 256), stb(sizeof(BdState)), pb((size_t) (nrb * n + ncb * m + n + m) * sizeof(double)),
+		fb((size_t) (nhy + nhz) * sizeof(xwg_u64));
 	BdArgs<T> a;
 	a.force_mem = g_l2_force_mem.load();
 	a.A = A.p;
@@ -2388,37 +2469,46 @@ template <typename T> void bidiag_dev(MatV<T> A, MatV<T> Hl, MatV<T> Hr)
 	a.n = (int) n;
 	a.size = (int) size;
 	a.y = vb.as<T>();
-	a.ysum = a.y + n;
-	a.vrow = a.ysum + n;
+	a.vrow = a.y + n;
 	a.z = a.vrow + n;
-	a.zsum = a.z + m;
-	a.taul = a.zsum + m;
+	a.taul = a.z + m;
 	a.taur = a.taul + n;
 	a.ypart = pb.as<double>();
 	a.zpart = a.ypart + (size_t) nrb * (size_t) n;
+	a.ysum = a.zpart + (size_t) ncb * (size_t) m;
+	a.zsum = a.ysum + n;
+	a.yflag = fb.as<xwg_u64>();
+	a.zflag = a.yflag + nhy;
 	a.st = stb.as<BdState>();
-	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (3 * n + 2 * m + 2 * n) * sizeof(T), s));
+	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (4 * n + m) * sizeof(T), s));
+	FH_HIP(hipMemsetAsync(a.ysum, 0, (size_t) (n + m) * sizeof(double), s));
+	FH_HIP(hipMemsetAsync(fb.p, 0, (size_t) (nhy + nhz) * sizeof(xwg_u64), s));
 	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(BdState), s));
+	bool have_z = false; // a row pass has left shares for the next bd_pre_kernel
 	for (idx_t k = 0; k < size; ++k) {
 		a.k = (int) k;
 		const idx_t rr = m - k - 1, cc = n - k - 1;
-		hipLaunchKernelGGL(bd_pre_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
+		// block 0: the step; blocks 1 ..: the sums of the previous row pass (1024 entries each)
+		a.nh = have_z ? (int) ((m - k + TD_NT - 1) / TD_NT) : 0;
+		hipLaunchKernelGGL(bd_pre_kernel<T>, dim3((unsigned) (1 + a.nh)), dim3(TD_NT), 0, s, a);
+		have_z = false;
 		if (cc > 0) {
+			a.nh = 0;
 			if (rr > 0) {
 				const unsigned rb = (unsigned) ((rr + BC_TR - 1) / BC_TR), cb = (unsigned) ((cc + BC_TC - 1) / BC_TC);
 				if (k > 0)
 					hipLaunchKernelGGL((bd_col_kernel<T, true>), dim3(rb * cb), dim3(BC_NT), 0, s, a);
 				else
 					hipLaunchKernelGGL((bd_col_kernel<T, false>), dim3(rb * cb), dim3(BC_NT), 0, s, a);
-				hipLaunchKernelGGL(vec_sum_kernel<T>, dim3((unsigned) ((cc + 255) / 256)), dim3(256), 0, s, a.ypart, (int) rb, (size_t) n, (int) (k + 1), (int) cc, a.ysum);
+				a.nh = (int) ((cc + TD_NT - 1) / TD_NT);
 			} else {
-				FH_HIP(hipMemsetAsync(a.ysum + k + 1, 0, (size_t) cc * sizeof(T), s)); // (no row below: y2 = 0)
+				FH_HIP(hipMemsetAsync(a.ysum + k + 1, 0, (size_t) cc * sizeof(double), s)); // (no row below: y2 = 0)
 			}
-			hipLaunchKernelGGL(bd_mid_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
+			hipLaunchKernelGGL(bd_mid_kernel<T>, dim3((unsigned) (1 + a.nh)), dim3(TD_NT), 0, s, a);
 			if (k + 1 < size && rr > 0) {
 				const unsigned rb = (unsigned) ((rr + BR_TR - 1) / BR_TR), cb = (unsigned) ((cc + BR_TC - 1) / BR_TC);
 				hipLaunchKernelGGL(bd_row_kernel<T>, dim3(rb * cb), dim3(BR_NT), 0, s, a);
-				hipLaunchKernelGGL(vec_sum_kernel<T>, dim3((unsigned) ((rr + 255) / 256)), dim3(256), 0, s, a.zpart, (int) cb, (size_t) m, (int) (k + 1), (int) rr, a.zsum);
+				have_z = true;
 			}
 		}
 	}
