@@ -2275,7 +2275,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	const bool fused = g_tq_fused.load() != 0;
 	// raw copy of the current panel below its top block for the U2 launches (see there); not for matrices where it would exceed 1 GiB
 	const long ldpc = (long) ((m + 63) & ~(idx_t) 63);
-	const bool want_copy = fused && npan > 2 && (size_t) ldpc * TQ_PW * sizeof(float) <= ((size_t) 1 << 30);
+	const bool want_copy = fused && g_tq_fused.load() != 2 && npan > 2 && (size_t) ldpc * TQ_PW * sizeof(float) <= ((size_t) 1 << 30);
 	struct OptScratch {
 		void *p = nullptr;
 		~OptScratch()

@@ -495,7 +495,8 @@ FAER_HIP_API void faer_hip_debug_lu_plan(size_t nb2_from, size_t pipe_from, size
  * path was not applicable) */
 FAER_HIP_API long faer_hip_debug_qr_one_pass_columns(void);
 /* tests / A-B measurements: 0 = the one-pass QR path applies a panel and forms the next panel's Gram products in separate launches (the
- * round 3-5 schedule), 1 (default) = in one pass per panel with the next panel's kernel beside its second half (csrc/tsqr.hip). */
+ * round 3-5 schedule), 1 (default) = in one pass per panel with the next panel's kernel beside its second half (csrc/tsqr.hip), 2 = the
+ * same without the raw copy of the panel (what matrices of more than 4.19 M rows run: V = P M as a launch of its own behind U2). */
 FAER_HIP_API void faer_hip_debug_qr_fused(int on);
 /* tests: 1 = the single-workgroup vector kernels of the tridiagonal / bidiagonal / Hessenberg reductions run their memory-resident bodies
  * at every size (default: from 4096 remaining rows down they keep their columns in registers); results must not depend on it. */

@@ -511,14 +511,16 @@ def test_qr_norm_l2_scaling_cases(oracle, m, n, factor):
     assert np.abs(h - rh)[fin & tu].max(initial=0) <= 512 * max(m, n) * e * max(1.0, np.abs(rh[fin & tu]).max(initial=0))
 
 
+@pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("m,n,bs", [(40000, 256, 256), (30001, 300, 64), (33000, 384, 128)])
-def test_qr_tall_round5_schedule_still_agrees_with_the_oracle(oracle, m, n, bs):
+def test_qr_tall_other_schedules_still_agree_with_the_oracle(oracle, m, n, bs, mode):
     """faer_hip_debug_qr_fused(0): the one-pass path with update and Gram products as separate launches (the schedule of rounds 3-5, kept
-    for A/B measurements) must keep producing the reference's R / V / T -- the default (fused) schedule is what every other test runs."""
+    for A/B measurements); (2): the fused schedule without the raw copy of the panel (what matrices of more than 4.19 M rows run).  Both
+    must keep producing the reference's R / V / T -- the default schedule is what every other test runs."""
     F = init_gpu()
     rng = np.random.default_rng(m + n)
     a = np.asfortranarray(rng.standard_normal((m, n)).astype(np.float32))
-    F.lib().faer_hip_debug_qr_fused(0)
+    F.lib().faer_hip_debug_qr_fused(mode)
     try:
         _tall_vs_oracle(oracle, F, a, bs)
     finally:
