@@ -457,17 +457,48 @@ __global__ void scatter_rows_kernel(T *B, idx_t rs, idx_t cs, int nrows, int nco
 // gathers their sources into LDS and scatters them back -- no global temporary, no separate compose pass.
 constexpr int LASWP_SMALL_NT = 512;
 constexpr int LASWP_CC = 8;
+constexpr int LUN_W_HOST = 64; // (= LUN_W, defined with the node kernel below)
 
 // `top_out` (optional, nt x ncols, column major with pitch nt): receives a copy of the rows 0 .. nt-1 AFTER the interchanges
 // (the fused node update below reads the block it overwrites from there).
+static __device__ __forceinline__ double lu_readlane(double v, int l)
+{
+	const long long b = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_readlane((int) b, l), hi = __builtin_amdgcn_readlane((int) (b >> 32), l);
+	return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
+}
+static __device__ __forceinline__ float lu_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// `L00` (optional, with top_out and nt == 64): the unit lower 64 x 64 block of the leaf whose interchanges these are (column stride lcs).
+// The workgroup then SOLVES its columns of the interchanged top block, U = L00^-1 top (factor.rs:104-109: forward substitution, the
+// same fma per row and column in the same order as lu_node64_kernel's), and writes U into rows 0 .. 63 of B and into top_out: the node
+// launch behind it finds the solved block and only updates (round 6; every workgroup of the node launch used to repeat the solve of
+// its column group: a third of that launch on the panel chain).
 template <typename T>
 __global__ __launch_bounds__(256) void laswp_small_kernel(T *B, idx_t rs, idx_t cs, int nrows, int ncols,
-							  const int *__restrict__ piv, int nt, int row_base, T *top_out)
+							  const int *__restrict__ piv, int nt, int row_base, T *top_out, const T *__restrict__ L00, idx_t lcs)
 {
 	__shared__ int s_piv[LASWP_SMALL_NT];
 	__shared__ int s_dst[2 * LASWP_SMALL_NT], s_src[2 * LASWP_SMALL_NT];
 	__shared__ T tmp[LASWP_CC * 2 * LASWP_SMALL_NT];
 	const int tid = threadIdx.x;
+	const bool solve = L00 != nullptr && top_out != nullptr; // (host: nt == 64)
+	// L00 into the part of tmp the gather does not use (nt = 64: 8 x 128 entries of it), row major with pitch 65 -- issued first, so that
+	// its round trip overlaps the list building below
+	T *s_l = tmp + LASWP_CC * 2 * 64;
+	if (solve) {
+		T lv[16];
+#pragma unroll
+		for (int q = 0; q < 16; ++q) {
+			const int idx = tid + 256 * q;
+			lv[q] = L00[(idx & 63) + (idx_t) (idx >> 6) * lcs];
+		}
+#pragma unroll
+		for (int q = 0; q < 16; ++q) {
+			const int idx = tid + 256 * q;
+			s_l[(idx & 63) * 65 + (idx >> 6)] = lv[q];
+		}
+	}
 	for (int j = tid; j < nt; j += 256)
 		s_piv[j] = piv[j] - row_base;
 	__syncthreads();
@@ -491,6 +522,12 @@ __global__ __launch_bounds__(256) void laswp_small_kernel(T *B, idx_t rs, idx_t 
 	__syncthreads();
 	const int c0 = blockIdx.x * LASWP_CC;
 	const int nc = min(LASWP_CC, ncols - c0);
+	// (solve: this thread's two rows of the top block as they are now -- used where the row stays; in flight during the gather)
+	T keep0 = (T) 0, keep1 = (T) 0;
+	if (solve && (tid >> 5) < nc) {
+		keep0 = B[(idx_t) (tid & 31) * rs + (idx_t) (c0 + (tid >> 5)) * cs];
+		keep1 = B[(idx_t) ((tid & 31) + 32) * rs + (idx_t) (c0 + (tid >> 5)) * cs];
+	}
 	// gather in batches of 8 independent loads per thread (one memory round trip per batch, not per element)
 	for (int idx0 = tid; idx0 < nc * ne; idx0 += 256 * 8) {
 		T v[8];
@@ -512,8 +549,35 @@ __global__ __launch_bounds__(256) void laswp_small_kernel(T *B, idx_t rs, idx_t 
 	__syncthreads();
 	for (int idx = tid; idx < nc * ne; idx += 256) {
 		const int c = idx / ne, e = idx - c * ne;
-		if (s_src[e] >= 0)
+		if (s_src[e] >= 0 && !(solve && s_dst[e] < nt)) // (rows 0 .. 63 receive U below)
 			B[(idx_t) s_dst[e] * rs + (idx_t) (c0 + c) * cs] = tmp[idx];
+	}
+	if (solve) {
+		// thread: column c = tid >> 5 of the workgroup's eight, rows h and h + 32; row k's value is read from the lane that owns it
+		// (v_readlane per half wavefront: a column lives in one half)
+		const int c = tid >> 5, h = tid & 31, lane = tid & 63;
+		const bool vc = c < nc;
+		T u0 = (T) 0, u1 = (T) 0;
+		if (vc) {
+			u0 = s_src[h] >= 0 ? tmp[c * ne + h] : keep0;
+			u1 = s_src[h + 32] >= 0 ? tmp[c * ne + h + 32] : keep1;
+		}
+#pragma unroll
+		for (int k = 0; k < 64; ++k) {
+			const T src = k < 32 ? u0 : u1;
+			const T lo = lu_readlane(src, k & 31), hi = lu_readlane(src, 32 + (k & 31));
+			const T uk = lane < 32 ? lo : hi;
+			if (k < 31) // (rows h <= k of the first half are final)
+				u0 = h > k ? fh_fma(-s_l[h * 65 + k], uk, u0) : u0;
+			u1 = h + 32 > k ? fh_fma(-s_l[(h + 32) * 65 + k], uk, u1) : u1;
+		}
+		if (vc) {
+			B[(idx_t) h * rs + (idx_t) (c0 + c) * cs] = u0;
+			B[(idx_t) (h + 32) * rs + (idx_t) (c0 + c) * cs] = u1;
+			top_out[(size_t) (c0 + c) * 64 + h] = u0;
+			top_out[(size_t) (c0 + c) * 64 + h + 32] = u1;
+		}
+		return;
 	}
 	if (top_out) {
 		for (int idx = tid; idx < nc * nt; idx += 256) {
@@ -562,7 +626,7 @@ __device__ unsigned long long g_node_phase[8];
 #define LUN_TICK(i)
 #endif
 template <typename T>
-__global__ __launch_bounds__(256, 2) void lu_node64_kernel(T *P, idx_t cs, int m, int nr, const T *__restrict__ top)
+__global__ __launch_bounds__(256, 2) void lu_node64_kernel(T *P, idx_t cs, int m, int nr, const T *__restrict__ top, int solved)
 {
 	typedef typename Mfma<T>::acc_t acc_t;
 	__shared__ T Ls[LUN_W * LUN_LP];
@@ -650,6 +714,16 @@ __global__ __launch_bounds__(256, 2) void lu_node64_kernel(T *P, idx_t cs, int m
 	int r_a = tile_r0(0), r_b = -1;
 	if (r_a >= 0)
 		tile_load(r_a, b_a, acc_a);
+	if (solved) {
+		// the interchange launch has solved the block (laswp_small_kernel with L00): `top` holds U = A01, already stored
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			Us[(16 * wave + i) * LUN_UP + lane] = lane < nr ? top[(size_t) lane * LUN_W + 16 * wave + i] : (T) 0;
+		__syncthreads();
+		LUN_TICK(0);
+		LUN_TICK(1);
+		LUN_TICK(2);
+	} else {
 	// ---- L00 (strictly lower part is used) and this thread's 16 rows of column c = lane of the interchanged top block
 #pragma unroll
 	for (int j = 0; j < LUN_W / 4; ++j) {
@@ -696,6 +770,7 @@ __global__ __launch_bounds__(256, 2) void lu_node64_kernel(T *P, idx_t cs, int m
 		}
 	}
 	LUN_TICK(2);
+	}
 	// ---- the tiles, two register sets in turn
 #pragma unroll 1
 	for (int idx = 0; r_a >= 0; idx += 2) {
@@ -807,7 +882,7 @@ template <typename T> static void laswp_list_dev(MatV<T> B, const LaswpList &l)
 
 // Applies the transpositions (j <-> piv[j] - row_base), j < nt, to all columns of B (B's row 0 is the
 // row the first transposition refers to).
-template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, int row_base, T *top_out = nullptr)
+template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, int row_base, T *top_out = nullptr, const T *L00 = nullptr, idx_t lcs = 0)
 {
 	if (B.nrows == 0 || B.ncols == 0 || nt == 0)
 		return;
@@ -815,7 +890,7 @@ template <typename T> static void laswp_dev(MatV<T> B, const int *piv, int nt, i
 	hipStream_t s = ctx().stream;
 	if (nt <= LASWP_SMALL_NT) {
 		hipLaunchKernelGGL(laswp_small_kernel<T>, dim3((unsigned) ((B.ncols + LASWP_CC - 1) / LASWP_CC)), dim3(256), 0, s, B.p,
-				   B.rs, B.cs, nrows, (int) B.ncols, piv, nt, row_base, top_out);
+				   B.rs, B.cs, nrows, (int) B.ncols, piv, nt, row_base, top_out, (nt == LUN_W_HOST && top_out) ? L00 : (const T *) nullptr, lcs);
 		FH_HIP(hipGetLastError());
 		return;
 	}
@@ -1259,10 +1334,10 @@ template <typename T> static void getrf_rec(MatV<T> P, int col0, int row_base, L
 		A11 = P.sub(bs, bs, m - bs, n - bs);
 	if (bs == LUN_W && n - bs <= LUN_W && P.rs == 1 && wk.ttop && lu_node_offsets_ok<T>(m, P.cs)) {
 		// the 128-column nodes: interchanges (+ a copy of the interchanged top block), then solve and product in one launch
-		laswp_dev<T>(right, wk.piv + col0, (int) bs, row_base, wk.ttop);
+		laswp_dev<T>(right, wk.piv + col0, (int) bs, row_base, wk.ttop, (const T *) P.p, P.cs);
 		const idx_t below = m - bs;
 		const unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
-		hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg), dim3(256), 0, ctx().stream, P.p, P.cs, (int) m, (int) (n - bs), (const T *) wk.ttop);
+		hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg), dim3(256), 0, ctx().stream, P.p, P.cs, (int) m, (int) (n - bs), (const T *) wk.ttop, 1);
 		FH_HIP(hipGetLastError());
 	} else {
 		laswp_dev<T>(right, wk.piv + col0, (int) bs, row_base);
@@ -1307,7 +1382,7 @@ static void getrf_panel_flat(MatV<T> P, int col0, int row_base, LuWork<T> &wk, L
 		if (nr > 0) {
 			// ... and on the columns to its right, which then take the leaf's update: A01 <- L00^-1 A01, A11 -= A10 A01
 			FH_CHECK(nr <= LU_FLAT_MAXW - LUN_W, "lu: more column groups than LuWork::ttop holds");
-			laswp_dev<T>(P.sub(c, c + LUN_W, m - c, nr), wk.piv + col0 + c, (int) LUN_W, row_base + (int) c, wk.ttop);
+			laswp_dev<T>(P.sub(c, c + LUN_W, m - c, nr), wk.piv + col0 + c, (int) LUN_W, row_base + (int) c, wk.ttop, (const T *) (P.p + c + c * P.cs), P.cs);
 			const idx_t below = m - c - LUN_W;
 			unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
 			const unsigned ncg = (unsigned) ((nr + LUN_W - 1) / LUN_W);
@@ -1318,7 +1393,7 @@ static void getrf_panel_flat(MatV<T> P, int col0, int row_base, LuWork<T> &wk, L
 			if (nwg > cap)
 				nwg = cap < 1u ? 1u : cap;
 			hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg, ncg), dim3(256), 0, ctx().stream, P.p + c + c * P.cs, P.cs, (int) (m - c), (int) nr,
-					   (const T *) wk.ttop);
+					   (const T *) wk.ttop, 1);
 			FH_HIP(hipGetLastError());
 		}
 	}
@@ -1597,7 +1672,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 					// on the whole chip between two panels instead of "interchanges, substitution leaf, product" for 128 pivots
 					const idx_t r0 = j1 - LUN_W;
 					FH_CHECK(w2 <= LU_FLAT_MAXW, "lu: more column groups than LuWork::ttop holds");
-					laswp_dev<T>(A.sub(r0, j1, m - r0, w2), wk.piv + r0, (int) LUN_W, (int) r0, wk.ttop);
+					laswp_dev<T>(A.sub(r0, j1, m - r0, w2), wk.piv + r0, (int) LUN_W, (int) r0, wk.ttop, (const T *) (A.p + r0 * A.rs + r0 * A.cs), A.cs);
 					const idx_t below = m - r0 - LUN_W;
 					unsigned nwg = below > 0 ? (unsigned) ((below + LUN_ROWS - 1) / LUN_ROWS) : 1u;
 					const unsigned ncg = (unsigned) ((w2 + LUN_W - 1) / LUN_W);
@@ -1605,7 +1680,7 @@ template <typename T> static void getrf_lookahead(MatV<T> A, LuWork<T> &wk, hipS
 					if (nwg > cap)
 						nwg = cap < 1u ? 1u : cap;
 					hipLaunchKernelGGL(lu_node64_kernel<T>, dim3(nwg, ncg), dim3(256), 0, ctx().stream, A.p + r0 * A.rs + r0 * A.cs, A.cs, (int) (m - r0), (int) w2,
-							   (const T *) wk.ttop);
+							   (const T *) wk.ttop, 1);
 					FH_HIP(hipGetLastError());
 				} else {
 					QW = w / 2;
