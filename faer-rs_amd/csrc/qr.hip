@@ -2530,12 +2530,14 @@ template void bidiag_dev<float>(MatV<float>, MatV<float>, MatV<float>);
 // Per column k: (i) row k, column k and a_kk receive the rest of the previous two-sided update (:266-281), (ii) the
 // reflector of column k below the subdiagonal, head = 1 while the step runs (:294-305), (iii) ONE pass over A22 applying
 // A22 -= u2 y2 + z2 u2^H and forming x^H A22 and A22 x (hessenberg_fused_op, :149-193), (iv) y2, z2 (:342-357), (v) the
-// reflector from the right on row k and the rows above it (:358-378).  Four launches per column:
-//   hs_pre_kernel(k)      one workgroup: (iv) of step k-1, restores its beta, (i), (ii)
-//   hs_colpass_kernel(k)  one wavefront per column of A22: the update written back, x^H A22 complete per wavefront
-//   hs_rowpass_kernel(k)  one workgroup per 16 rows of ALL n rows, columns k+1..: row sums with x (read only) = A22 x for
-//                         the rows below k, and for the rows 0..k the sums ARE the w of (v): those rows are updated at once
-// Algorithmic bytes per column: A22 read + written + read, the k+1 rows above read twice + written.
+// reflector from the right on row k and the rows above it (:358-378).  Three launches per column (round 6):
+//   hs_pre_kernel(k)    block 0: (iv) of step k-1, restores its beta, (i), (ii); blocks 1 ..: w of step k-1 from the shares of its
+//                       top-rows pass, and the application dwp = w / tau it leaves pending
+//   hs_fused_kernel(k)  128 x 64 tiles of A22: the update written back and the tile's shares of BOTH x^H A22 and A22 x (same x)
+//   hs_top_kernel(k)    128 x 64 tiles of the rows 0 .. k: the pending application of step k-1 written back, the shares of this
+//                       step's w; extra blocks add the shares of hs_fused_kernel -> ysum, zsum
+// Traffic per column: A22 and the k+1 rows above read and written ONCE (the reference's count -- and rounds 2-5 -- read A22 twice and the
+// rows above twice).  N = 4096 fp64: 257.6 ms (round 5) -> 219 (one fused pass over A22) -> 165 (deferred application on the rows above).
 // ------------------------------------------------------------------------------------------------
 struct HsState {
 	double tau_inv, beta;
@@ -2546,6 +2548,8 @@ template <typename T> struct HsArgs {
 	int n, k, force_mem;
 	T *y, *z, *ysum, *zsum, *taus;
 	double *ypart, *zpart; // shares of the tiles of the fused pass: ypart[row block * n + j], zpart[column block * n + i]
+	double *wpart;	       // shares of the tiles of the top-rows pass: wpart[column block * n + i]
+	T *dwp;		       // per row i <= k - 1: w_i / tau of step k - 1, the right-side application that is still pending (0: none)
 	HsState *st;
 };
 
@@ -2706,6 +2710,30 @@ template <typename T> static __device__ __forceinline__ void hs_pre_body_reg(con
 
 template <typename T> __global__ __launch_bounds__(TD_NT) void hs_pre_kernel(const HsArgs<T> a)
 {
+	if (blockIdx.x > 0) {
+		// helper block: rows 1024 (blockIdx.x - 1) ..: w of step k - 1 = the shares of its top-rows pass in a fixed order, then the
+		// pending application dwp = w / tau_{k-1} for hs_top_kernel(k).  Independent of block 0 (which overwrites st->tau_inv: taken from taus)
+		const int k = a.k, i = ((int) blockIdx.x - 1) * TD_NT + (int) threadIdx.x;
+		if (i >= k)
+			return;
+		const int np = (a.n - (k - 1) + TF_TC - 1) / TF_TC;
+		const double *src = a.wpart + i;
+		double s0 = 0.0;
+		int p = 0;
+		for (; p + 8 <= np; p += 8) {
+			double v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				v[u] = src[(size_t) (p + u) * a.n];
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				s0 += v[u];
+		}
+		for (; p < np; ++p)
+			s0 += src[(size_t) p * a.n];
+		a.dwp[i] = (T) s0 * ((T) 1 / a.taus[k - 1]);
+		return;
+	}
 	if (a.n - a.k <= TD_E * TD_NT && !a.force_mem)
 		hs_pre_body_reg<T>(a);
 	else
@@ -2786,18 +2814,23 @@ template <typename T, bool upd> __global__ __launch_bounds__(TF_NT) void hs_fuse
 		a.zpart[(size_t) J * a.n + base + i0 + tid] = ((s_row[0][tid] + s_row[1][tid]) + s_row[2][tid]) + s_row[3][tid];
 }
 
-// rows 0 .. k of the columns right of k (hs_fused_kernel has the rows below): w = A[0..k, k+1..] x, then A[0..k, k+1..] -= (w / tau) x^H
-// (the blocks behind those of the top rows add the shares of hs_fused_kernel in a fixed order -> ysum, zsum: one launch less per column)
-template <typename T> __global__ __launch_bounds__(TD_NT) void hs_rowpass_kernel(const HsArgs<T> a)
+// Rows 0 .. k (hs_fused_kernel has the rows below): their sums with x are the w of the right-side application (:358-378), A[0..k, k+1..] -=
+// (w / tau) x^H.  Rounds 2-5 gave 16 rows to a workgroup that summed them and then applied the reflector (every row read twice per step).
+// Round 6: the application is DEFERRED by one step and rides on the next step's pass -- tile (rows 0 .. k) x (columns k .. n-1): entries
+// first receive the pending application of step k - 1 (dwp_i x_{k-1,j}; column k only that: it is final afterwards), are written back, and
+// contribute to the new sums with x_k; the shares of the tiles are added by helper blocks of the next hs_pre_kernel, which also turn them
+// into the next dwp.  One read and one write per entry and step; a last call behind the loop (k = n - 1) applies what is still pending.
+// The blocks behind the tiles add the shares of hs_fused_kernel in a fixed order -> ysum, zsum (one launch less per column).
+template <typename T> __global__ __launch_bounds__(TF_NT) void hs_top_kernel(const HsArgs<T> a)
 {
-	constexpr int NC = TD_NT / TD_PW;
-	__shared__ double red[TD_PW][NC + 1];
-	__shared__ T s_w[TD_PW];
-	const int tid = threadIdx.x, k = a.k, n = a.n;
-	const int ntop = (k + 1 + TD_PW - 1) / TD_PW;
-	if ((int) blockIdx.x >= ntop) {
+	constexpr int CW = TF_TC / (TF_NT / 64); // 16 columns per wavefront
+	__shared__ double s_row[TF_NT / 64][TF_TR];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, k = a.k, n = a.n;
+	const int nrows = k + 1, ncols = n - k; // rows 0 .. k, columns k .. n - 1
+	const int ncb = (ncols + TF_TC - 1) / TF_TC, nrb = (nrows + TF_TR - 1) / TF_TR;
+	if ((int) blockIdx.x >= nrb * ncb) {
 		const int r = n - (k + 1);
-		const int e = ((int) blockIdx.x - ntop) * TD_NT + tid;
+		const int e = ((int) blockIdx.x - nrb * ncb) * TF_NT + tid;
 		if (e >= 2 * r)
 			return;
 		const bool isz = e >= r;
@@ -2819,43 +2852,53 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void hs_rowpass_kernel
 		(isz ? a.zsum : a.ysum)[(k + 1) + (isz ? e - r : e)] = (T) s0;
 		return;
 	}
-	const int ri = tid & (TD_PW - 1), cj = tid >> 4;
-	const int i = blockIdx.x * TD_PW + ri;
-	const bool vi = i < n;
-	T *rowp = a.A + (idx_t) (vi ? i : 0) * a.rs;
-	const T *xcol = a.A + (idx_t) k * a.cs; // x[j] = A[j, k], j > k (head = 1 in memory)
-	double acc = 0.0;
-	for (int j0 = k + 1 + cj; j0 < n; j0 += TD_UNR * NC) {
-		T v[TD_UNR], x[TD_UNR];
+	const bool upd = k > 0;
+	const int I = blockIdx.x / ncb, J = blockIdx.x - I * ncb;
+	const int i0 = I * TF_TR, j0 = k + J * TF_TC + CW * wv; // (absolute column)
+	int gi[2];
+	bool vr[2];
+	T dwi[2];
 #pragma unroll
-		for (int q = 0; q < TD_UNR; ++q) {
-			const int j = j0 + NC * q;
-			const bool in = vi && j < n;
-			v[q] = rowp[(idx_t) (in ? j : k + 1) * a.cs];
-			x[q] = in ? xcol[(idx_t) j * a.rs] : (T) 0;
+	for (int h = 0; h < 2; ++h) {
+		gi[h] = i0 + lane + 64 * h;
+		vr[h] = gi[h] < nrows;
+		gi[h] = min(gi[h], nrows - 1);
+		dwi[h] = upd ? a.dwp[gi[h]] : (T) 0;
+	}
+	T xpl, xnl; // per lane: the pending reflector x_{k-1} and the new one x_k at this wavefront's columns
+	{
+		const int gj = min(j0 + (lane & (CW - 1)), n - 1);
+		xpl = !upd ? (T) 0 : (gj == k ? (T) 1 : a.A[(idx_t) gj * a.rs + (idx_t) (k - 1) * a.cs]);
+		xnl = gj >= k + 1 ? a.A[(idx_t) gj * a.rs + (idx_t) k * a.cs] : (T) 0; // (head = 1 in memory while the step runs)
+	}
+	T v[2][CW];
+#pragma unroll
+	for (int c = 0; c < CW; ++c)
+#pragma unroll
+		for (int h = 0; h < 2; ++h)
+			v[h][c] = a.A[(idx_t) gi[h] * a.rs + (idx_t) min(j0 + c, n - 1) * a.cs];
+	double racc[2] = {0.0, 0.0};
+#pragma unroll
+	for (int c = 0; c < CW; ++c) {
+		const int gj = j0 + c;
+		const T xp = td_lane(xpl, c), xn = td_lane(xnl, c);
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const bool in = vr[h] && gj < n;
+			T tv = v[h][c];
+			if (upd) {
+				tv = tv - dwi[h] * xp;
+				if (in)
+					a.A[(idx_t) gi[h] * a.rs + (idx_t) gj * a.cs] = tv;
+			}
+			racc[h] += in ? (double) tv * (double) xn : 0.0;
 		}
-#pragma unroll
-		for (int q = 0; q < TD_UNR; ++q)
-			acc += (double) v[q] * (double) x[q];
 	}
-	red[ri][cj] = acc;
+	s_row[wv][lane] = racc[0];
+	s_row[wv][lane + 64] = racc[1];
 	__syncthreads();
-	if (tid < TD_PW) {
-		const int io = blockIdx.x * TD_PW + tid;
-		double t = 0.0;
-		for (int c = 0; c < NC; ++c)
-			t += red[tid][c];
-		s_w[tid] = (T) t;
-	}
-	// rows 0 .. k: the sum is the w of (:358-378), the row receives the reflector from the right at once
-	if (blockIdx.x * TD_PW > k)
-		return; // (uniform) no such row in this panel
-	__syncthreads();
-	if (vi && i <= k) {
-		const T dw = s_w[ri] * (T) a.st->tau_inv;
-		for (int j = k + 1 + cj; j < n; j += NC)
-			rowp[(idx_t) j * a.cs] -= dw * xcol[(idx_t) j * a.rs];
-	}
+	if (tid < TF_TR && i0 + tid < nrows)
+		a.wpart[(size_t) J * n + i0 + tid] = ((s_row[0][tid] + s_row[1][tid]) + s_row[2][tid]) + s_row[3][tid];
 }
 
 // A: n x n, H: block_size x (n - 1)
@@ -2870,11 +2913,12 @@ template <typename T> void hessenberg_dev(MatV<T> A, MatV<T> H)
 	FH_CHECK(H.nrows > 0, "hessenberg: householder needs at least one row");
 	hipStream_t s = ctx().stream;
 	const idx_t nrb = (n + TF_TR - 1) / TF_TR, ncb = (n + TF_TC - 1) / TF_TC;
-	Scratch vb((size_t) (5 * n) * sizeof(T) + 256), stb(sizeof(HsState)), pb((size_t) (nrb + ncb) * (size_t) n * sizeof(double));
+	Scratch vb((size_t) (6 * n) * sizeof(T) + 256), stb(sizeof(HsState)), pb((size_t) (nrb + 2 * ncb) * (size_t) n * sizeof(double));
 	HsArgs<T> a;
 	a.force_mem = g_l2_force_mem.load();
 	a.ypart = pb.as<double>();
 	a.zpart = a.ypart + (size_t) nrb * (size_t) n;
+	a.wpart = a.zpart + (size_t) ncb * (size_t) n;
 	a.A = A.p;
 	a.rs = A.rs;
 	a.cs = A.cs;
@@ -2884,12 +2928,19 @@ template <typename T> void hessenberg_dev(MatV<T> A, MatV<T> H)
 	a.ysum = a.z + n;
 	a.zsum = a.ysum + n;
 	a.taus = a.zsum + n;
+	a.dwp = a.taus + n;
 	a.st = stb.as<HsState>();
-	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (5 * n) * sizeof(T), s));
+	FH_HIP(hipMemsetAsync(vb.p, 0, (size_t) (6 * n) * sizeof(T), s));
 	FH_HIP(hipMemsetAsync(stb.p, 0, sizeof(HsState), s));
+	auto launch_top = [&](idx_t k) {
+		const idx_t r = n - k - 1;
+		const unsigned tiles = (unsigned) (((k + 1 + TF_TR - 1) / TF_TR) * ((n - k + TF_TC - 1) / TF_TC));
+		hipLaunchKernelGGL(hs_top_kernel<T>, dim3(tiles + (unsigned) ((2 * r + TF_NT - 1) / TF_NT)), dim3(TF_NT), 0, s, a);
+	};
 	for (idx_t k = 0; k < n; ++k) {
 		a.k = (int) k;
-		hipLaunchKernelGGL(hs_pre_kernel<T>, dim3(1), dim3(TD_NT), 0, s, a);
+		// block 0: the step; blocks 1 ..: w of step k - 1 and the pending application it leaves (1024 rows each)
+		hipLaunchKernelGGL(hs_pre_kernel<T>, dim3((unsigned) (1 + (k + TD_NT - 1) / TD_NT)), dim3(TD_NT), 0, s, a);
 		const idx_t r = n - k - 1;
 		if (r > 0) {
 			const unsigned rb = (unsigned) ((r + TF_TR - 1) / TF_TR), cb = (unsigned) ((r + TF_TC - 1) / TF_TC);
@@ -2897,11 +2948,12 @@ template <typename T> void hessenberg_dev(MatV<T> A, MatV<T> H)
 				hipLaunchKernelGGL((hs_fused_kernel<T, true>), dim3(rb * cb), dim3(TF_NT), 0, s, a);
 			else
 				hipLaunchKernelGGL((hs_fused_kernel<T, false>), dim3(rb * cb), dim3(TF_NT), 0, s, a);
-			// rows 0 .. k: their sums with x are the w of the right-side application, applied at once (a workgroup owns its 16 rows);
-			// behind them the blocks that add the shares of the fused pass
-			hipLaunchKernelGGL(hs_rowpass_kernel<T>, dim3((unsigned) ((k + 1 + TD_PW - 1) / TD_PW + (2 * r + TD_NT - 1) / TD_NT)), dim3(TD_NT), 0, s, a);
+			launch_top(k);
 		}
 	}
+	// the application of the last step (k = n - 2) is still pending on column n - 1
+	a.k = (int) (n - 1);
+	launch_top(n - 1);
 	FH_HIP(hipGetLastError());
 	qr_t_blocks_from_taus<T>(A.sub(1, 0, n - 1, n - 1), H, n - 1, a.taus); // (:382-406)
 	FH_HIP(hipStreamSynchronize(s)); // the scratch vectors above are released on return
