@@ -953,6 +953,7 @@ struct CpState {
 	double best_threshold, scale_fwd, scale_bwd;
 	double l, tau_inv;
 	int delayed, best_col, n_trans, flush; // flush: this step applies the pending update at once and recomputes the norms (:178-203)
+	int timeout, pad;		       // the flush blocks of a step did not report (GPU shared with other work)
 };
 
 template <typename T> struct CpArgs {
@@ -961,6 +962,7 @@ template <typename T> struct CpArgs {
 	int m, n, size, k, delayed_ok;
 	T *norm, *dot, *taus;
 	int *perm;
+	xwg_u64 *flags; // per flush block: the step it has finished (cp_flush_step_kernel)
 	CpState *st;
 };
 
@@ -998,12 +1000,24 @@ template <typename T> __global__ __launch_bounds__(256) void cp_norms_kernel(con
 }
 
 // first maximum (strict '>') of norm[lo .. n)
-template <typename T> static __device__ void cp_argmax(const T *norm, int lo, int n, T &best, int &col, double *s_v, int *s_c)
+// Loads / stores that pass the caches (xwg.h): for data another workgroup of the SAME launch has written or will read
+static __device__ __forceinline__ double cp_ld(const double *p) { return xwg_load(p); }
+static __device__ __forceinline__ float cp_ld(const float *p)
+{
+	return __int_as_float(__hip_atomic_load(reinterpret_cast<const int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+static __device__ __forceinline__ void cp_st(double *p, double v) { xwg_store(p, v); }
+static __device__ __forceinline__ void cp_st(float *p, float v)
+{
+	__hip_atomic_store(reinterpret_cast<int *>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T, bool COH = false> static __device__ void cp_argmax(const T *norm, int lo, int n, T &best, int &col, double *s_v, int *s_c)
 {
 	T bv = (T) 0;
 	int bc = lo;
 	for (int j = lo + threadIdx.x; j < n; j += blockDim.x) {
-		const T v = norm[j];
+		const T v = COH ? cp_ld(norm + j) : norm[j];
 		if (v > bv) { // ascending j per thread: the first maximum of the thread's subsequence
 			bv = v;
 			bc = j;
@@ -1072,35 +1086,19 @@ template <typename T> __global__ void cp_scale_kernel(const CpArgs<T> a, int upp
 	}
 }
 
-// factor.rs:178-203 (k > 0 and not delayed): A11 += A10[:, k-1] dot[k:], fresh norms; a workgroup per column, a fixed small grid (the
-// launch is a no-op on most steps: st->flush is decided on the device)
-template <typename T> __global__ __launch_bounds__(256) void cp_flush_kernel(const CpArgs<T> a)
-{
-	__shared__ double s_part[4 * 3], s_red[3];
-	if (!a.st->flush)
-		return;
-	for (int j = a.k + blockIdx.x; j < a.n; j += gridDim.x) {
-		const T d = a.dot[j];
-		for (int i = a.k + threadIdx.x; i < a.m; i += 256) {
-			T *p = a.A + (idx_t) i * a.rs + (idx_t) j * a.cs;
-			*p = fh_fma(a.A[(idx_t) i * a.rs + (idx_t) (a.k - 1) * a.cs], d, *p);
-		}
-		__syncthreads();
-		const T v = cp_col_norm<T>(a, a.k, j, s_part, s_red);
-		if (threadIdx.x == 0)
-			a.norm[j] = v;
-	}
-}
-
 // factor.rs:204-252: column swap, the pending update of column k, its reflector (householder.rs:59-107)
-template <typename T> static __device__ __forceinline__ void cp_house_body(const CpArgs<T> &a, const int bc, const int delayed)
+// COH: the columns and norms may have been rewritten by the flush blocks of the SAME launch (cp_flush_step_kernel): every read of them
+// passes the caches
+template <typename T, bool COH = false> static __device__ __forceinline__ void cp_house_body(const CpArgs<T> &a, const int bc, const int delayed)
 {
+	auto ld = [&](const T *q) -> T { return COH ? cp_ld(q) : *q; };
+
 	__shared__ double s_part[16 * 3], s_red[3];
 	const int tid = threadIdx.x, k = a.k;
 	if (bc != k) {
 		for (int i = tid; i < a.m; i += 1024) {
 			T *p = a.A + (idx_t) i * a.rs + (idx_t) k * a.cs, *q = a.A + (idx_t) i * a.rs + (idx_t) bc * a.cs;
-			const T x = *p, y = *q;
+			const T x = ld(p), y = ld(q);
 			*p = y;
 			*q = x;
 		}
@@ -1108,10 +1106,10 @@ template <typename T> static __device__ __forceinline__ void cp_house_body(const
 			const int tp = a.perm[k];
 			a.perm[k] = a.perm[bc];
 			a.perm[bc] = tp;
-			const T td = a.dot[k], tn = a.norm[k];
+			const T td = a.dot[k], tn = ld(a.norm + k);
 			a.dot[k] = a.dot[bc];
 			a.dot[bc] = td;
-			a.norm[k] = a.norm[bc];
+			a.norm[k] = ld(a.norm + bc);
 			a.norm[bc] = tn;
 			a.st->n_trans += 1;
 		}
@@ -1125,7 +1123,7 @@ template <typename T> static __device__ __forceinline__ void cp_house_body(const
 	T acc[3] = {0, 0, 0};
 	for (int i = k + 1 + tid; i < a.m; i += 1024) {
 		T *p = a.A + (idx_t) i * a.rs + (idx_t) k * a.cs;
-		T x = *p;
+		T x = ld(p);
 		if (delayed) {
 			x += r * a.A[(idx_t) i * a.rs + (idx_t) (k - 1) * a.cs];
 			*p = x;
@@ -1154,7 +1152,7 @@ template <typename T> static __device__ __forceinline__ void cp_house_body(const
 	}
 	const T tail_norm = norm_from3<T>(s_red);
 	T *hp = a.A + (idx_t) k * a.rs + (idx_t) k * a.cs;
-	T head = *hp;
+	T head = ld(hp);
 	if (delayed)
 		head += l * r;
 	T head_norm = fabs(head);
@@ -1179,7 +1177,10 @@ template <typename T> static __device__ __forceinline__ void cp_house_body(const
 	__syncthreads();
 	if (scale_tail)
 		for (int i = k + 1 + tid; i < a.m; i += 1024)
-			a.A[(idx_t) i * a.rs + (idx_t) k * a.cs] *= hinv;
+		{
+				T *pp = a.A + (idx_t) i * a.rs + (idx_t) k * a.cs;
+				*pp = ld(pp) * hinv;
+			}
 	if (tid == 0) {
 		*hp = head;
 		a.taus[k] = tau;
@@ -1215,20 +1216,70 @@ template <typename T> __global__ __launch_bounds__(1024) void cp_step_kernel(con
 	cp_house_body<T>(a, col, delayed);
 }
 
-template <typename T> __global__ __launch_bounds__(1024) void cp_step2_kernel(const CpArgs<T> a)
+// factor.rs:178-203 (k > 0 and the norms must be recomputed; returns at once otherwise): blocks 1 .. apply the pending update to the
+// trailing columns, A11 += A10[:, k-1] dot[k:], and recompute their norms (a column per block and turn; the first 256 threads work, with the
+// strides and the sum order of the 256-thread kernel this replaces), write-through, then raise their flag; block 0 waits for the flags,
+// picks the pivot from the fresh norms and makes the reflector -- reading what the other blocks wrote past its caches.  One launch instead
+// of two (flush, select2 + house) that returned at once on almost every step.
+constexpr int CP_NFL = 63; // flush blocks (the launch returns at once on most steps: a small grid keeps that cheap)
+template <typename T> __global__ __launch_bounds__(1024) void cp_flush_step_kernel(const CpArgs<T> a)
 {
 	__shared__ double s_v[16];
 	__shared__ int s_c[16];
+	__shared__ double s_part[16 * 3], s_red[3];
+	__shared__ int s_flag;
 	if (!a.st->flush)
 		return;
+	const int tid = threadIdx.x, k = a.k;
+	if (blockIdx.x > 0) {
+		const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+		for (int j = k + (int) blockIdx.x - 1; j < a.n; j += (int) gridDim.x - 1) {
+			const T d = a.dot[j];
+			T acc[3] = {0, 0, 0};
+			if (tid < 256)
+				for (int i = k + tid; i < a.m; i += 256) {
+					T *p = a.A + (idx_t) i * a.rs + (idx_t) j * a.cs;
+					const T x = fh_fma(a.A[(idx_t) i * a.rs + (idx_t) (k - 1) * a.cs], d, *p);
+					cp_st(p, x);
+					acc[0] += (x * sml) * (x * sml);
+					acc[1] += x * x;
+					acc[2] += (x * big) * (x * big);
+				}
+			const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const double sv = wave_sum((double) acc[c]);
+				if (lane == 0)
+					s_part[wave * 3 + c] = sv;
+			}
+			__syncthreads();
+			if (tid < 3)
+				s_red[tid] = s_part[tid] + s_part[3 + tid] + s_part[6 + tid] + s_part[9 + tid]; // (the four working wavefronts, in their order)
+			__syncthreads();
+			if (tid == 0)
+				cp_st(a.norm + j, norm_from3<T>(s_red));
+			__syncthreads();
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (tid == 0)
+			__hip_atomic_store(a.flags + (blockIdx.x - 1), (xwg_u64) (k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return;
+	}
+	// block 0 (a time-out cannot be repaired here -- the columns are half rewritten by then --: it is reported through the status word)
+	if (!xwg_wait_all(a.flags, (int) gridDim.x - 1, (xwg_u64) (k + 1), &s_flag)) {
+		if (tid == 0)
+			a.st->timeout = 1;
+		return;
+	}
 	T best;
 	int col;
-	cp_argmax<T>(a.norm, a.k, a.n, best, col, s_v, s_c);
-	if (threadIdx.x == 0) {
+	cp_argmax<T, true>(a.norm, k, a.n, best, col, s_v, s_c);
+	if (tid == 0) {
 		a.st->best_col = col;
 		a.st->best_threshold = (double) (best * (T) sqrt((double) Lim<T>::eps));
 	}
-	cp_house_body<T>(a, col, 0);
+	cp_house_body<T, true>(a, col, 0);
 }
 
 // factor.rs:266-301 / update_mat_and_dot_simd (:60-98): one workgroup per trailing column
@@ -1282,8 +1333,10 @@ template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, 
 	if (size == 0)
 		return 0;
 	hipStream_t s = ctx().stream;
-	Scratch nb((size_t) (2 * n + size) * sizeof(T) + 256), pb((size_t) n * sizeof(int) + 256), stb(sizeof(CpState));
+	Scratch nb((size_t) (2 * n + size) * sizeof(T) + 256), pb((size_t) n * sizeof(int) + 256), stb(sizeof(CpState)), flb((size_t) (CP_NFL + 1) * sizeof(xwg_u64));
 	CpArgs<T> a;
+	a.flags = flb.as<xwg_u64>();
+	FH_HIP(hipMemsetAsync(flb.p, 0, (size_t) (CP_NFL + 1) * sizeof(xwg_u64), s));
 	a.A = A.p;
 	a.rs = A.rs;
 	a.cs = A.cs;
@@ -1304,10 +1357,8 @@ template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, 
 	for (idx_t k = 0; k < size; ++k) {
 		a.k = (int) k;
 		hipLaunchKernelGGL(cp_step_kernel<T>, dim3(1), dim3(1024), 0, s, a);
-		if (k > 0) {
-			hipLaunchKernelGGL(cp_flush_kernel<T>, dim3((unsigned) (n - k < 512 ? n - k : 512)), dim3(256), 0, s, a);
-			hipLaunchKernelGGL(cp_step2_kernel<T>, dim3(1), dim3(1024), 0, s, a);
-		}
+		if (k > 0)
+			hipLaunchKernelGGL(cp_flush_step_kernel<T>, dim3((unsigned) (1 + (n - k < CP_NFL ? n - k : CP_NFL))), dim3(1024), 0, s, a);
 		if (k + 1 < size)
 			hipLaunchKernelGGL(cp_update_kernel<T>, dim3((unsigned) (n - k - 1)), dim3(256), 0, s, a);
 	}
@@ -1319,6 +1370,7 @@ template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, 
 	FH_HIP(hipMemcpyAsync(hp.data(), a.perm, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, s));
 	FH_HIP(hipMemcpyAsync(&fin, stb.p, sizeof(fin), hipMemcpyDeviceToHost, s));
 	FH_HIP(hipStreamSynchronize(s));
+	FH_CHECK(!fin.timeout, "colpiv_qr: the blocks that recompute the column norms did not report in time (GPU shared with other work)");
 	for (idx_t j = 0; j < n; ++j) {
 		FH_CHECK(hp[(size_t) j] >= 0 && hp[(size_t) j] < n, "colpiv_qr: corrupt permutation");
 		col_perm[j] = hp[(size_t) j];
