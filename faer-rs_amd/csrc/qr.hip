@@ -854,8 +854,10 @@ __global__ void qr_finalize_kernel(T *H, idx_t hrs, idx_t hcs, int bs, int size,
 // one block is a 32 x 32 .. 64 x 64 Gram matrix over up to m rows -- as separate split-K GEMM launches they were 127 x
 // 118 us = 15 ms of every N = 4096 reduction to condensed form.  Rows in chunks through LDS with the unit-lower structure
 // applied on the way in (zeros above the diagonal, 1 on it), sums in fp64 in ascending row order.
-constexpr int TB_MAXW = 64, TB_ROWS = 32, TB_NT = 256;
-template <typename T>
+// (round 6: a second instantiation for blocks of up to 128 reflectors -- the recommended block size from 2048^2 entries on -- with 512 threads:
+// the column-pivot QR at N = 4096 spent 9 of its 134 ms in 126 per-block GEMM launches)
+constexpr int TB_ROWS = 32;
+template <typename T, int TB_MAXW, int TB_NT>
 __global__ __launch_bounds__(TB_NT) void qr_tblock_gram_kernel(const T *V, idx_t vrs, idx_t vcs, int m, int rank, int bs, T *H, idx_t hrs, idx_t hcs)
 {
 	__shared__ T L[TB_ROWS][TB_MAXW + 1];
@@ -915,12 +917,14 @@ template <typename T> static void qr_t_blocks_from_taus(MatV<T> A, MatV<T> H, id
 	const idx_t m = A.nrows, n = A.ncols, bs = H.nrows;
 	const idx_t size = m < n ? m : n;
 	const bool batched = true; // (one split-K GEMM per block was 15 ms of every N = 4096 reduction: DESIGN.md 3.8)
-	if (batched && bs <= TB_MAXW && rank > 0) {
-		if (bs > 1) {
-			hipLaunchKernelGGL(qr_tblock_gram_kernel<T>, dim3((unsigned) ((rank + bs - 1) / bs)), dim3(TB_NT), 0, ctx().stream, A.p, A.rs, A.cs, (int) m,
-					   (int) rank, (int) bs, H.p, H.rs, H.cs);
-			FH_HIP(hipGetLastError());
-		}
+	if (batched && bs <= 128 && rank > 0) {
+		if (bs > 64)
+			hipLaunchKernelGGL((qr_tblock_gram_kernel<T, 128, 512>), dim3((unsigned) ((rank + bs - 1) / bs)), dim3(512), 0, ctx().stream, A.p, A.rs, A.cs,
+					   (int) m, (int) rank, (int) bs, H.p, H.rs, H.cs);
+		else if (bs > 1)
+			hipLaunchKernelGGL((qr_tblock_gram_kernel<T, 64, 256>), dim3((unsigned) ((rank + bs - 1) / bs)), dim3(256), 0, ctx().stream, A.p, A.rs, A.cs,
+					   (int) m, (int) rank, (int) bs, H.p, H.rs, H.cs);
+		FH_HIP(hipGetLastError());
 	} else {
 		for (idx_t c0 = 0; c0 < rank; c0 += bs) {
 			const idx_t wb = bs < rank - c0 ? bs : rank - c0;
