@@ -1919,11 +1919,15 @@ template void tridiag_dev<float>(MatV<float>, MatV<float>);
 // A22 -= up y2 + z2 vp and forms y2 = u^H A22 (bidiag_fused_op, :257-301), (iv) y2, row k and its norm (:156-164),
 // (v) z2 = A22 A12^H (:165-172), (vi) the right reflector of the normalised row and the correction of z2 (:176-213).
 // Four launches per column, no host synchronisation in the loop:
-//   bd_pre_kernel(k)      one workgroup: (vi)'s correction of z for step k-1, then (i) and (ii)
-//   bd_colpass_kernel(k)  one wavefront per column of A22, lanes along the rows: (iii), written back; y sums complete per
-//                         wavefront (columns are independent: no race, fixed summation order)
-//   bd_mid_kernel(k)      one workgroup: (iv), a copy of the normalised row for (v), then the reflector part of (vi)
-//   bd_rowpass_kernel(k)  one workgroup per 16 rows of A22 (read only): (v)
+//   bd_pre_kernel(k)   block 0: (vi)'s correction of z for step k-1, then (i) and (ii); blocks 1 ..: the sums of the row pass of step k-1
+//   bd_col_kernel(k)   256 x 32 tiles of A22, lanes along the rows, 32 loads in flight per thread: (iii) written back and the tile's
+//                      share of y2 = u^H A22
+//   bd_mid_kernel(k)   block 0: (iv), a copy of the normalised row for (v), then the reflector part of (vi); blocks 1 ..: the sums of
+//                      the column pass
+//   bd_row_kernel(k)   128 x 128 tiles of A22 (read only): the tile's share of (v)
+// The shares of the tiles are added in a fixed order (bd_sum_block) and handed to block 0 inside the launch (xwg.h).  Rounds 2-5: one
+// wavefront per column / one workgroup per 16 rows with complete sums (302 ms at N = 4096); tiles with sums as launches of their own:
+// 272; pre / mid with their rows and columns in registers: 230; the sums as helper blocks: 210.
 // Algorithmic bytes: A22 read + written once and read once more per column, sum_k 3 (m-k-1)(n-k-1) sizeof(T).
 // ------------------------------------------------------------------------------------------------
 struct BdState {
@@ -2299,30 +2303,6 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void bd_mid_kernel(con
 		bd_mid_body_reg<T>(a);
 	else
 		bd_mid_body<T>(a);
-}
-
-// out[e] = the sum of `np` partial vectors part[p * stride + e], e in [off, off + len), added in the order of p (round 6: the matrix passes
-// of the reductions to condensed form are cut into uniform tiles whose shares are added here -- one short launch -- in a fixed order)
-template <typename T> __global__ __launch_bounds__(256) void vec_sum_kernel(const double *part, int np, size_t stride, int off, int len, T *out)
-{
-	const int e = blockIdx.x * 256 + threadIdx.x;
-	if (e >= len)
-		return;
-	const double *src = part + off + e;
-	double s0 = 0.0;
-	int p = 0;
-	for (; p + 8 <= np; p += 8) {
-		double v[8];
-#pragma unroll
-		for (int u = 0; u < 8; ++u)
-			v[u] = src[(size_t) (p + u) * stride];
-#pragma unroll
-		for (int u = 0; u < 8; ++u)
-			s0 += v[u];
-	}
-	for (; p < np; ++p)
-		s0 += src[(size_t) p * stride];
-	out[off + e] = (T) s0;
 }
 
 // (iii): tile of BC_TR rows x BC_TC columns of A22 = A[k+1.., k+1..]; wavefront w owns 8 columns, a lane four rows of each (32 loads in
@@ -2798,7 +2778,7 @@ template <typename T> __global__ __launch_bounds__(TD_NT) void hs_pre_kernel(con
 
 // Round 6: both products of a step use the SAME x, so ONE pass over A22 = A[k+1.., k+1..] applies the two-sided update of the previous step
 // and forms the tile's shares of l_out = x^H A22 (column sums) and r_out = A22 x (row sums): 128 x 64 tiles as in the tridiagonalization
-// (lane = two rows, wavefront = 16 columns, 32 loads in flight per thread); the shares are added in a fixed order by vec_sum_kernel.
+// (lane = two rows, wavefront = 16 columns, 32 loads in flight per thread); the shares are added in a fixed order by extra blocks of hs_top_kernel.
 // The rows above (0 .. k, which receive the reflector from the right once their sums are complete) stay with hs_rowpass_kernel.
 template <typename T, bool upd> __global__ __launch_bounds__(TF_NT) void hs_fused_kernel(const HsArgs<T> a)
 {
