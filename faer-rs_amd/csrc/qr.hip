@@ -966,7 +966,7 @@ template <typename T> struct CpArgs {
 	int m, n, size, k, delayed_ok;
 	T *norm, *dot, *taus;
 	int *perm;
-	xwg_u64 *flags; // per flush block: the step it has finished (cp_flush_step_kernel)
+	xwg_u64 *flags; // per flush block: the step it has finished (cp_step_kernel)
 	CpState *st;
 };
 
@@ -1091,7 +1091,7 @@ template <typename T> __global__ void cp_scale_kernel(const CpArgs<T> a, int upp
 }
 
 // factor.rs:204-252: column swap, the pending update of column k, its reflector (householder.rs:59-107)
-// COH: the columns and norms may have been rewritten by the flush blocks of the SAME launch (cp_flush_step_kernel): every read of them
+// COH: the columns and norms may have been rewritten by the flush blocks of the SAME launch (cp_step_kernel): every read of them
 // passes the caches
 template <typename T, bool COH = false> static __device__ __forceinline__ void cp_house_body(const CpArgs<T> &a, const int bc, const int delayed)
 {
@@ -1196,46 +1196,169 @@ template <typename T, bool COH = false> static __device__ __forceinline__ void c
 			a.A[(idx_t) k * a.rs + (idx_t) j * a.cs] += l * a.dot[j];
 }
 
-// Round 6: one launch per step on the common path.  factor.rs:163-177: the best remaining column by the down-dated norms and the decision
-// "delayed update or recompute"; if delayed (or k == 0) the column swap and the reflector follow in the same workgroup, else the step is
-// handed to cp_flush_kernel + cp_step2_kernel (both return at once otherwise).  Rounds 1-5: select, flush, select2, house = four launches,
-// two of them no-ops of 3-4 us on almost every step.
-template <typename T> __global__ __launch_bounds__(1024) void cp_step_kernel(const CpArgs<T> a)
+// cp_house_body with the two swapped columns and column k - 1 in registers (m <= 4 x 1024 rows): one round trip to memory after the pivot
+// is known instead of three (swap, pending update, scaling), every entry stored once.  Same arithmetic, expression by expression.
+template <typename T, bool COH> static __device__ __forceinline__ void cp_house_body_reg(const CpArgs<T> &a, const int bc, const int delayed)
 {
-	__shared__ double s_v[16];
-	__shared__ int s_c[16];
-	T best;
-	int col;
-	cp_argmax<T>(a.norm, a.k, a.n, best, col, s_v, s_c);
-	const int delayed = (a.delayed_ok && a.k > 0 && (double) best >= a.st->best_threshold) ? 1 : 0;
-	const int flush = a.k > 0 && !delayed;
-	__syncthreads(); // (everyone has read the threshold)
-	if (threadIdx.x == 0) {
-		a.st->delayed = delayed;
-		a.st->best_col = col;
-		a.st->flush = flush;
+	auto ld = [&](const T *q) -> T { return COH ? cp_ld(q) : *q; };
+	constexpr int E = 4;
+	__shared__ double s_part[16 * 3], s_red[3];
+	__shared__ T s_head;
+	const int tid = threadIdx.x, k = a.k, m = a.m;
+	const bool sw = bc != k;
+	T ck[E], cb[E], c1[E];
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const int i = tid + e * 1024, ic = i < m ? i : m - 1;
+		ck[e] = ld(a.A + (idx_t) ic * a.rs + (idx_t) k * a.cs);
+		cb[e] = sw ? ld(a.A + (idx_t) ic * a.rs + (idx_t) bc * a.cs) : ck[e];
+		c1[e] = delayed ? a.A[(idx_t) ic * a.rs + (idx_t) (k - 1) * a.cs] : (T) 0;
 	}
-	if (flush)
-		return;
-	cp_house_body<T>(a, col, delayed);
+	const T l = delayed ? a.A[(idx_t) k * a.rs + (idx_t) (k - 1) * a.cs] : (T) 0;
+	const T r = a.dot[sw ? bc : k];
+	T tn_k = (T) 0, tn_b = (T) 0;
+	if (tid == 0 && sw) {
+		tn_k = ld(a.norm + k);
+		tn_b = ld(a.norm + bc);
+	}
+	__syncthreads(); // every read of dot / norm / perm is done
+	if (tid == 0 && sw) {
+		const int tp = a.perm[k];
+		a.perm[k] = a.perm[bc];
+		a.perm[bc] = tp;
+		const T td = a.dot[k];
+		a.dot[k] = r;
+		a.dot[bc] = td;
+		a.norm[k] = tn_b;
+		a.norm[bc] = tn_k;
+		a.st->n_trans += 1;
+	}
+	// pending update of column k and the scaled sums of its tail
+	const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
+	T acc[3] = {0, 0, 0};
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const int i = tid + e * 1024;
+		if (i < m && i >= k + 1) {
+			T x = cb[e];
+			if (delayed)
+				x += r * c1[e];
+			cb[e] = x;
+			acc[0] += (x * sml) * (x * sml);
+			acc[1] += x * x;
+			acc[2] += (x * big) * (x * big);
+		}
+		if (i == k)
+			s_head = cb[e];
+	}
+	double accd[3] = {(double) acc[0], (double) acc[1], (double) acc[2]};
+	{ // 16 waves
+		const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const double sv = wave_sum(accd[c]);
+			if (lane == 0)
+				s_part[wave * 3 + c] = sv;
+		}
+		__syncthreads();
+		if (tid < 3) {
+			double t = 0.0;
+			for (int w = 0; w < 16; ++w)
+				t += s_part[w * 3 + tid];
+			s_red[tid] = t;
+		}
+		__syncthreads();
+	}
+	const T tail_norm = norm_from3<T>(s_red);
+	T head = s_head;
+	if (delayed)
+		head += l * r;
+	T head_norm = fabs(head);
+	if (head_norm < Lim<T>::minpos) {
+		head = (T) 0;
+		head_norm = (T) 0;
+	}
+	T tau, hinv = (T) 0;
+	bool scale_tail = false;
+	if (tail_norm < Lim<T>::minpos) {
+		tau = std::numeric_limits<T>::infinity();
+	} else {
+		const T norm = (T) hypot((double) head_norm, (double) tail_norm);
+		const T sign = head_norm != (T) 0 ? head * ((T) 1 / head_norm) : (T) 1;
+		const T signed_norm = sign * norm;
+		hinv = (T) 1 / (head + signed_norm);
+		head = -signed_norm;
+		const T tn = tail_norm * fabs(hinv);
+		tau = (T) 0.5 * ((T) 1 + tn * tn);
+		scale_tail = true;
+	}
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const int i = tid + e * 1024;
+		if (i < m) {
+			if (sw)
+				a.A[(idx_t) i * a.rs + (idx_t) bc * a.cs] = ck[e];
+			T *pk = a.A + (idx_t) i * a.rs + (idx_t) k * a.cs;
+			if (i > k) {
+				if (sw || delayed || scale_tail)
+					*pk = scale_tail ? cb[e] * hinv : cb[e];
+			} else if (i == k) {
+				*pk = head;
+			} else if (sw) {
+				*pk = cb[e];
+			}
+		}
+	}
+	if (tid == 0) {
+		a.taus[k] = tau;
+		a.st->tau_inv = (double) ((T) 1 / tau);
+		a.st->l = (double) l;
+	}
+	if (k + 1 == a.size && delayed) // factor.rs:253-262
+		for (int j = k + 1 + tid; j < a.n; j += 1024)
+			a.A[(idx_t) k * a.rs + (idx_t) j * a.cs] += l * a.dot[j];
+}
+template <typename T, bool COH> static __device__ __forceinline__ void cp_house(const CpArgs<T> &a, const int bc, const int delayed)
+{
+	if (a.m <= 4 * 1024)
+		cp_house_body_reg<T, COH>(a, bc, delayed);
+	else
+		cp_house_body<T, COH>(a, bc, delayed);
 }
 
-// factor.rs:178-203 (k > 0 and the norms must be recomputed; returns at once otherwise): blocks 1 .. apply the pending update to the
-// trailing columns, A11 += A10[:, k-1] dot[k:], and recompute their norms (a column per block and turn; the first 256 threads work, with the
-// strides and the sum order of the 256-thread kernel this replaces), write-through, then raise their flag; block 0 waits for the flags,
-// picks the pivot from the fresh norms and makes the reflector -- reading what the other blocks wrote past its caches.  One launch instead
-// of two (flush, select2 + house) that returned at once on almost every step.
-constexpr int CP_NFL = 63; // flush blocks (the launch returns at once on most steps: a small grid keeps that cheap)
-template <typename T> __global__ __launch_bounds__(1024) void cp_flush_step_kernel(const CpArgs<T> a)
+// Round 6: ONE launch per step.  Block 0 (factor.rs:163-177): the best remaining column by the down-dated norms and the decision "delayed
+// update or recompute", published to the other blocks of the launch (one flag word: 2 (k + 1) + recompute).  Common case: the column swap
+// and the reflector follow in block 0 and the other blocks leave as soon as they see the flag.  Recompute (:178-203, k > 0): blocks 1 ..
+// apply the pending update to the trailing columns, A11 += A10[:, k-1] dot[k:], and recompute their norms (a column per block and turn; the
+// first 256 threads work, with the strides and the sum order of the 256-thread kernel this replaces), write-through, then raise their flag;
+// block 0 waits for the flags, picks the pivot from the fresh norms and makes the reflector -- reading what the other blocks wrote past its
+// caches.  Rounds 1-5: select, flush, select2, house = four launches, two of them returning at once on almost every step (3-5 us each).
+constexpr int CP_NFL = 15; // helper blocks
+template <typename T> __global__ __launch_bounds__(1024) void cp_step_kernel(const CpArgs<T> a)
 {
 	__shared__ double s_v[16];
 	__shared__ int s_c[16];
 	__shared__ double s_part[16 * 3], s_red[3];
 	__shared__ int s_flag;
-	if (!a.st->flush)
-		return;
 	const int tid = threadIdx.x, k = a.k;
+	xwg_u64 *dflag = a.flags + CP_NFL;
 	if (blockIdx.x > 0) {
+		// ---- helper block: wait for block 0's decision
+		if (tid == 0) {
+			int dec = -1;
+			for (int spin = 0; spin < (1 << 21); ++spin) {
+				const xwg_u64 v = __hip_atomic_load(dflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((v >> 1) == (xwg_u64) (k + 1)) {
+					dec = (int) (v & 1);
+					break;
+				}
+				__builtin_amdgcn_s_sleep(2);
+			}
+			s_flag = dec;
+		}
+		__syncthreads();
+		if (s_flag != 1)
+			return; // (no recomputation -- or block 0 never spoke: it reports the time-out itself)
 		const T sml = (T) scale_sml<T>(), big = (T) scale_big<T>();
 		for (int j = k + (int) blockIdx.x - 1; j < a.n; j += (int) gridDim.x - 1) {
 			const T d = a.dot[j];
@@ -1270,20 +1393,36 @@ template <typename T> __global__ __launch_bounds__(1024) void cp_flush_step_kern
 			__hip_atomic_store(a.flags + (blockIdx.x - 1), (xwg_u64) (k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		return;
 	}
-	// block 0 (a time-out cannot be repaired here -- the columns are half rewritten by then --: it is reported through the status word)
+	// ---- block 0
+	T best;
+	int col;
+	cp_argmax<T>(a.norm, k, a.n, best, col, s_v, s_c);
+	const int delayed = (a.delayed_ok && k > 0 && (double) best >= a.st->best_threshold) ? 1 : 0;
+	const int flush = k > 0 && !delayed;
+	__syncthreads(); // (everyone has read the threshold)
+	if (tid == 0) {
+		if (gridDim.x > 1)
+			__hip_atomic_store(dflag, ((xwg_u64) (k + 1) << 1) | (xwg_u64) flush, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		a.st->delayed = delayed;
+		a.st->best_col = col;
+		a.st->flush = flush;
+	}
+	if (!flush) {
+		cp_house<T, false>(a, col, delayed);
+		return;
+	}
+	// (a time-out cannot be repaired here -- the columns are half rewritten by then --: it is reported through the status word)
 	if (!xwg_wait_all(a.flags, (int) gridDim.x - 1, (xwg_u64) (k + 1), &s_flag)) {
 		if (tid == 0)
 			a.st->timeout = 1;
 		return;
 	}
-	T best;
-	int col;
 	cp_argmax<T, true>(a.norm, k, a.n, best, col, s_v, s_c);
 	if (tid == 0) {
 		a.st->best_col = col;
 		a.st->best_threshold = (double) (best * (T) sqrt((double) Lim<T>::eps));
 	}
-	cp_house_body<T, true>(a, col, 0);
+	cp_house<T, true>(a, col, 0);
 }
 
 // factor.rs:266-301 / update_mat_and_dot_simd (:60-98): one workgroup per trailing column
@@ -1360,9 +1499,7 @@ template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, 
 	hipLaunchKernelGGL(cp_scale_kernel<T>, dim3(1024), dim3(256), 0, s, a, 0);
 	for (idx_t k = 0; k < size; ++k) {
 		a.k = (int) k;
-		hipLaunchKernelGGL(cp_step_kernel<T>, dim3(1), dim3(1024), 0, s, a);
-		if (k > 0)
-			hipLaunchKernelGGL(cp_flush_step_kernel<T>, dim3((unsigned) (1 + (n - k < CP_NFL ? n - k : CP_NFL))), dim3(1024), 0, s, a);
+		hipLaunchKernelGGL(cp_step_kernel<T>, dim3((unsigned) (k > 0 ? 1 + (n - k < CP_NFL ? n - k : CP_NFL) : 1)), dim3(1024), 0, s, a);
 		if (k + 1 < size)
 			hipLaunchKernelGGL(cp_update_kernel<T>, dim3((unsigned) (n - k - 1)), dim3(256), 0, s, a);
 	}

@@ -427,7 +427,8 @@ def test_qr_is_bitwise_reproducible():
 
 # ------------------------------------------------------------------------------------ QR with column pivoting
 @pytest.mark.parametrize("m,n,layout", [(1, 1, "F"), (5, 5, "F"), (40, 30, "F"), (30, 40, "F"), (64, 64, "C"), (200, 50, "F"), (1, 7, "F"), (7, 1, "F"),
-                                        (300, 300, "F"), (1500, 260, "F"), (700, 900, "F"), (257, 257, "C")])
+                                        (300, 300, "F"), (1500, 260, "F"), (700, 900, "F"), (257, 257, "C"),
+                                        (4100, 40, "F"), (5000, 33, "C")])  # (beyond 4096 rows: the memory-resident step body)
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_colpiv_qr_vs_oracle(oracle, m, n, layout, dtype):
     """colpiv_qr_dev through the C-ABI: IDENTICAL column permutation (index work), R / reflectors / T blocks within
