@@ -309,8 +309,13 @@ def main():
             # quoted on the largest round tall-skinny shape the reference really factors.
             # ("qrmax": 524287 rows, the LARGEST height the reference's rank test still accepts in fp32)
             m, n = (n_override or (524287 if name == "qrmax" else 500000)), 256
-            a = colmajor(m, n, torch.float32, 5)
-            work = a.clone()
+            # faer's Mat pads the column stride to 64 bytes (mat/matown.rs:67-80): 16 floats -- what a faer caller hands over for a height
+            # that is not a multiple of 16 (524287); round 6 (rounds 3-5 timed "qrmax" with stride = height: scalar loads in every kernel)
+            ldp = (m + 15) // 16 * 16
+            g_ = torch.Generator(device=dev).manual_seed(5)
+            a = torch.randn((n, ldp), dtype=torch.float32, device=dev, generator=g_)[:, :m].t()
+            work = torch.empty((n, ldp), dtype=torch.float32, device=dev)[:, :m].t()
+            work.copy_(a)
             bs = F.qr_recommended_block_size(m, n, np.float32)
             h = torch.zeros((min(m, n), bs), dtype=torch.float32, device=dev).t()
 
