@@ -108,13 +108,30 @@ template <typename S> struct DeviceBackend {
 		FH_CHECK(comm.bcast != nullptr, "dist: FaerHipComm.bcast is NULL");
 		comm.bcast(comm.user, buf, bytes, root);
 	}
+	// The caller's stream is usually the NULL stream (torch's default stream), and the look-ahead streams are blocking streams
+	// (hipExtStreamCreateWithCUMask takes no flags): every command on the null stream -- an event record, even a wait -- is
+	// ordered against ALL of them, so one transport call or hand-shake on the caller's stream in the middle of a step stalls the
+	// bulk stream for a cross-queue round trip (one-rank Cholesky over the RCCL transport: 170 us between two pack launches,
+	// 83.7 ms against 66.3 with a callback that does nothing; profiles/r06_exp_dist.txt).  With the built-in RCCL transport
+	// (`quiet`: its calls only need ctx().stream, whichever stream that is) a run therefore leaves the caller's stream alone
+	// between its first two-stream step and run_end: broadcasts start from the stream that packed (owner) or last read (receiver)
+	// the buffer, waits are taken by the bulk stream, the panel stream joins the bulk stream directly.
+	bool quiet() const { return comm.ibcast && comm.wait && rccl_is_builtin_wait(comm.wait); }
+	bool bcast_from_panel = false; // dist_lu.h: the next broadcast ships what the panel stream has just packed (set by ahead_join)
+	hipEvent_t ev_join = nullptr;  // quiet: panel-stream work the bulk stream has to join before its next section
 	// asynchronous pair when the transport offers one, else the blocking broadcast at `begin`
 	void bcast_begin(void *buf, size_t bytes, int root, int slot)
 	{
-		if (comm.ibcast && comm.wait)
+		if (comm.ibcast && comm.wait) {
+			hipStream_t cur = ctx().stream;
+			if (quiet() && prev_two && cur == caller)
+				ctx().stream = bcast_from_panel ? ctx().la_panel : ctx().la_bulk;
 			comm.ibcast(comm.user, buf, bytes, root, slot);
-		else
+			ctx().stream = cur;
+		} else {
 			bcast(buf, bytes, root);
+		}
+		bcast_from_panel = false;
 	}
 	// The transport's wait orders a stream behind the transfer.  The built-in RCCL transport's wait is a stream-wait on an event
 	// and takes ctx().stream as it is -- the panel / bulk stream that first reads the chunk (dist_llt.h), and only that stream
@@ -135,8 +152,15 @@ template <typename S> struct DeviceBackend {
 			FH_HIP(hipEventRecord(e, caller));
 			ctx().stream = cur;
 			stream_wait(cur, e);
+		} else if (quiet() && prev_two && cur == caller) {
+			// (every consumer of a received panel, and every later writer of its buffer, runs on or behind the bulk stream)
+			ctx().stream = ctx().la_bulk;
+			comm.wait(comm.user, slot);
+			ctx().stream = cur;
 		} else {
 			comm.wait(comm.user, slot);
+			if (cur == caller)
+				caller_dirty = true;
 		}
 	}
 	// ---- two-stream schedule inside the rank (dist_lu.h): the rest of update k on the bulk stream, the look-ahead part
@@ -160,31 +184,59 @@ template <typename S> struct DeviceBackend {
 	// long rest.  Round 6 runs that update on the bulk stream in front of the rest (dist_lu.h), so the panel stream carries the
 	// panel alone, as in the single-GPU driver, which keeps its two streams down to the last step: one rank, N = 16384,
 	// threshold 1e8 / 3e7 / 0: 191.7 / 156.7 / 123.6 ms (profiles/r06_exp_dist.txt).  FAER_HIP_DIST_TWO_MIN overrides.
+	// `caller_dirty`: the caller's stream has taken a dependency since the last hand-shake that the internal streams do not have
+	// (a transfer awaited there, the panel stream joined into it).  While it has not, a step that uses both streams like the step
+	// before it is ordered by the streams themselves and keeps the old (long complete) ev0: the hand-shake "caller waits for the
+	// bulk stream, records ev0, the bulk stream waits for ev0" cost two cross-stream hops (~70 us) in front of every step of the
+	// one-rank Cholesky (profiles/r06_exp_dist.txt).
+	bool caller_dirty = true, prev_two = false;
 	void step_begin(long local_trailing_entries, long next_panel_rows)
 	{
 		++step_id;
 		if (!two)
 			return;
-		// the bulk stream's reads of the panel buffer that the next receive overwrites, and its writes to the columns the
-		// look-ahead part touches, are older than everything issued from here on
-		if (ev_bulk) {
-			stream_wait(caller, ev_bulk);
-			ev_bulk = nullptr;
-		}
 		// the look-ahead panel is factored on the CU-masked panel stream: its cooperative leaves must fit those CUs at the
 		// width they would have on the whole chip (dist_two_streams_ok, getrf.hip) -- beyond 131072 fp64 rows they do not
 		// fit at all and the leaf would abort
 		two_now = local_trailing_entries >= two_min_work && dist_two_streams_ok(next_panel_rows, (int) sizeof(T), ctx().la_panel_cus, ctx().ncu > 0 ? ctx().ncu : 256);
-		if (!two_now)
+		const bool keep = two_now && prev_two && !caller_dirty && ev0; // the streams order this step against the last one themselves
+		// the bulk stream's reads of the panel buffer that the next receive overwrites, and its writes to the columns the
+		// look-ahead part touches, are older than everything issued from here on
+		if (!(keep && quiet())) {
+			if (ev_bulk) {
+				stream_wait(caller, ev_bulk);
+				ev_bulk = nullptr;
+			}
+			if (ev_join) {
+				stream_wait(caller, ev_join);
+				ev_join = nullptr;
+			}
+		}
+		if (!two_now) {
+			prev_two = false;
 			return;
-		ev0 = ctx().next_event();
-		FH_HIP(hipEventRecord(ev0, caller));
+		}
+		if (!keep) {
+			ev0 = ctx().next_event();
+			FH_HIP(hipEventRecord(ev0, caller));
+			caller_dirty = false;
+		}
+		prev_two = true;
+	}
+	// quiet: what the panel stream did in the step before (ahead_join) is joined by the bulk stream's next section
+	void bulk_joins_panel()
+	{
+		if (ev_join) {
+			stream_wait(ctx().la_bulk, ev_join);
+			ev_join = nullptr;
+		}
 	}
 	void rest_begin()
 	{
 		if (!two_now)
 			return;
 		stream_wait(ctx().la_bulk, ev0);
+		bulk_joins_panel();
 		ctx().stream = ctx().la_bulk;
 	}
 	void rest_end()
@@ -202,6 +254,7 @@ template <typename S> struct DeviceBackend {
 		if (!two_now)
 			return;
 		stream_wait(ctx().la_bulk, ev0);
+		bulk_joins_panel();
 		ctx().stream = ctx().la_bulk;
 	}
 	void ahead_cols_end()
@@ -233,24 +286,52 @@ template <typename S> struct DeviceBackend {
 	}
 	// inside the look-ahead part (dist_llt.h: the broadcast of a chunk): the caller's stream joins the panel stream's work so
 	// far and takes the next launches / transport calls; the panel stream goes on afterwards
+	hipStream_t paused = nullptr;
 	void ahead_pause()
 	{
-		if (!two_now)
-			return;
+		paused = nullptr;
+		if (!two_now || ctx().stream == caller || quiet())
+			return; // (quiet: the broadcast starts from the stream that packed the chunk)
+		paused = ctx().stream;
 		hipEvent_t e = ctx().next_event();
-		FH_HIP(hipEventRecord(e, ctx().la_panel));
+		FH_HIP(hipEventRecord(e, paused));
 		stream_wait(caller, e);
 		ctx().stream = caller;
 	}
 	void ahead_resume()
 	{
-		if (two_now)
-			ctx().stream = ctx().la_panel;
+		if (paused)
+			ctx().stream = paused;
+		paused = nullptr;
+	}
+	// dist_llt.h: the solve of the new panel's rows -- on the bulk stream, behind the diagonal block (panel stream)
+	void ahead_solve_begin()
+	{
+		if (!two_now)
+			return;
+		stream_wait(ctx().la_bulk, ev0);
+		if (ev_ahead)
+			stream_wait(ctx().la_bulk, ev_ahead);
+		ctx().stream = ctx().la_bulk;
+	}
+	void ahead_solve_end()
+	{
+		if (!two_now)
+			return;
+		ev_bulk = ctx().next_event();
+		FH_HIP(hipEventRecord(ev_bulk, ctx().la_bulk));
+		ctx().stream = caller;
 	}
 	void ahead_join()
 	{
 		if (two_now && ev_ahead) {
-			stream_wait(caller, ev_ahead); // the broadcast of the new panel is ordered behind it
+			if (quiet()) { // the broadcast starts from the panel stream; the bulk stream joins it before its next section
+				ev_join = ev_ahead;
+				bcast_from_panel = true;
+			} else {
+				stream_wait(caller, ev_ahead); // the broadcast of the new panel is ordered behind it
+				caller_dirty = true;
+			}
 			ev_ahead = nullptr;
 		}
 	}
@@ -258,6 +339,9 @@ template <typename S> struct DeviceBackend {
 	{
 		if (two && ev_bulk)
 			stream_wait(caller, ev_bulk);
+		if (two && ev_join)
+			stream_wait(caller, ev_join);
+		ev_bulk = ev_join = nullptr;
 	}
 	void copy_ints(int *dst, const int *src, size_t n)
 	{
@@ -397,11 +481,8 @@ FaerLltStatus dist_llt_api(FaerMatMut A_local, size_t n_global, size_t nb, FaerL
 	be.reg_delta = reg.dynamic_regularization_delta ? *static_cast<const T *>(reg.dynamic_regularization_delta) : (T) 0;
 	be.reg_eps = reg.dynamic_regularization_epsilon ? *static_cast<const T *>(reg.dynamic_regularization_epsilon) : (T) 0;
 	be.streams_init(); // the two-stream schedule of the LU (step_begin / ahead_* / rest_*: no-ops without it -- ADVICE r03)
-	// (the Cholesky's look-ahead part still CONTAINS level-3 work -- the update of block column k + 1 and the solve of the rows below
-	// its diagonal block -- which crawls on the panel stream's 32 CUs: both streams only beside >= 1e8 trailing entries, as in rounds
-	// 2-5; one rank, N = 16384: 100-105 ms with the threshold, 123 ms without -- profiles/r06_exp_dist.txt)
-	if (!getenv("FAER_HIP_DIST_TWO_MIN"))
-		be.two_min_work = 100000000;
+	// (rounds 2-5: both streams only beside >= 1e8 trailing entries, because the look-ahead part put its level-3 work on the panel
+	// stream's 32 CUs; now only the diagonal block's chain runs there -- dist_llt.h -- and every step uses both streams)
 	typename B::View Av{static_cast<T *>(A_local.ptr), n, (long) A_local.ncols, 1, (long) A_local.col_stride};
 	be.t_total.begin();
 	const long r = DistLlt<B>::run(be, Av, n, (long) nb, comm.rank, comm.world_size, static_cast<T *>(panel_ws));

@@ -5,18 +5,19 @@
 // (:436-446) restricted to the columns a rank owns.
 //
 // Round 4: the panel travels in ROW CHUNKS.  Once L_kk is known the rows of A21 L_kk^-T are independent of each other
-// (factor.rs:422-426), so the owner solves, packs and broadcasts the rows below the diagonal block in up to LLT_NCH
-// block-aligned chunks -- chunk c's transfer overlaps chunk c + 1's solve -- and every receiver updates the rows of a
-// chunk as soon as that chunk has arrived: the rows of the panel that multiply an owned column lie in the same or an
+// (factor.rs:422-426), so the owner packs and broadcasts the rows below the diagonal block in up to LLT_NCH
+// block-aligned chunks (round 6: solved in one go before -- the solve chain is latency bound, not row bound) and every receiver
+// updates the rows of a chunk as soon as that chunk has arrived: the rows of the panel that multiply an owned column lie in the same or an
 // earlier chunk (lower triangle).  The owner of block column k + 1 does the same in its look-ahead part: diagonal block
-// after chunk 0 of panel k, then chunk by chunk "update rows, solve, pack, start the broadcast".  With the whole panel as
+// after chunk 0 of panel k, the rows' update chunk by chunk, one solve, then chunk by chunk "pack, start the broadcast".  With the whole panel as
 // ONE message (rounds 2-3) every step carried "panel + transfer of up to 134 MB" on its critical chain; now it carries one
 // diagonal block and one chunk.  The diagonal block itself is needed by nobody else and stays home.
 //
-// Look-ahead: the owner of block column k+1 updates and factors that column FIRST and starts its broadcasts; every
-// rank posts the receives before it runs the rest of update k.  Two panel buffers alternate.
-// On the owner the look-ahead part is issued first (an asynchronous backend queues it on its panel stream) and the
-// rest of the update second (bulk stream): the two run concurrently inside the rank, as in dist_lu.h.
+// Look-ahead: the owner of block column k+1 updates and factors that column before (most of) the rest of update k and
+// starts its broadcasts; every rank posts the receives before it runs the rest of update k.  Two panel buffers alternate.
+// On the owner (round 6) only the diagonal block's factorization is queued on the panel stream of an asynchronous backend;
+// the update of block column k+1, the solve of its rows and the rest of update k share the bulk stream in the order
+// "diagonal block's update | rows' update, first half of the rest | solve, pack, broadcast | second half of the rest".
 //
 // The rest of update k is one staircase product per rank AND CHUNK, not one per owned block column: the owned block
 // columns right of the panel lie next to each other in A_local, the rows of the panel that belong to them are gathered
@@ -38,9 +39,13 @@
 //   void syrk_stair_sub(View C, View A, View Bt, long nb, long gap, long row0)
 //                                                        -- C(i, c) -= (A Bt^T)(i, c) for i + row0 >= c + (c / nb) * gap
 //   void step_begin(long local_trailing_entries, long next_panel_rows) / rest_begin() / rest_end() / ahead_begin() /
-//        ahead_end() / ahead_join() / run_end()          -- scheduling hooks as in dist_lu.h
-//   void ahead_pause() / ahead_resume()                  -- inside the look-ahead part: what follows (a broadcast) is issued
-//                                                           on the caller's context, ordered behind the look-ahead work so far
+//        ahead_end() / ahead_join() / ahead_cols_begin() / ahead_cols_end() / run_end()
+//                                                        -- scheduling hooks as in dist_lu.h (rest_begin / rest_end may bracket
+//                                                           several parts of one step's rest)
+//   void ahead_solve_begin() / ahead_solve_end()         -- level-3 work of the look-ahead part that needs the diagonal block
+//                                                           factored between ahead_begin / ahead_end
+//   void ahead_pause() / ahead_resume()                  -- inside ahead_solve_*: what follows (a broadcast) is issued on the
+//                                                           caller's context, ordered behind the look-ahead work so far
 //   void pack(View src, T *dst)                          -- contiguous column-major copy into the panel buffer
 //   void bcast_begin(void *buf, size_t bytes, int root, int slot) / void bcast_wait(int slot)   -- slots 0 .. 2 LLT_NCH - 1;
 //                                                           a slot may be waited for more than once (once per context)
@@ -130,10 +135,16 @@ template <class B> struct DistLlt {
 				waited[ctx][c] = true;
 			}
 		};
-		// owner of block column k, its diagonal block factored: chunk c of the rows below -- solve, pack, start the broadcast
+		// owner of block column k, its diagonal block factored: ALL rows below are solved in one go (a substitution leaf is latency
+		// bound -- ~35 us for 4096 rows or for 16384 -- so chunk-wise solves cost nch times the chain: 1.0 against 0.3 ms per step
+		// at N = 16384, profiles/r06_exp_dist.txt), then chunk by chunk: pack, start the broadcast
+		auto solve_panel = [&](long k, const Plan &p) {
+			const long j0 = k * nb, w = width(k), lc = local_col0(k);
+			if (p.nch > 0)
+				be.solve_rows(view(j0, lc, w, w), view(p.g[0], lc, n - p.g[0], w));
+		};
 		auto produce_chunk = [&](long k, const Plan &p, int c) {
-			const long j0 = k * nb, w = width(k), lc = local_col0(k), rows = p.g[c + 1] - p.g[c];
-			be.solve_rows(view(j0, lc, w, w), view(p.g[c], lc, rows, w));
+			const long w = width(k), lc = local_col0(k), rows = p.g[c + 1] - p.g[c];
 			View dst = chunk_rows(k, p, c, p.g[c], p.g[c + 1]);
 			be.pack(view(p.g[c], lc, rows, w), dst.p);
 			be.ahead_pause();
@@ -149,39 +160,52 @@ template <class B> struct DistLlt {
 		};
 		T *gbuf = bufs + 2 * bsz;
 		// the rest of update k: all owned block columns right of the panel (without block k + 1 if this rank brings it up
-		// to date in the look-ahead part), one staircase product per chunk of the panel as the chunks arrive
-		auto rest = [&](long k, const Plan &p, bool skip_next) {
-			be.rest_begin();
-			long b0 = -1, c_first = 0, c_all = 0; // first block of the range, its first local column, local columns in all
+		// to date in the look-ahead part), one staircase product per chunk of the panel as the chunks arrive.  It can be
+		// issued in two parts (chunks [0, c_end) first, the others later): the owner of block column k + 1 puts the solve of
+		// its new panel between them (below).
+		struct Rest {
+			long b0 = -1, c_first = 0, nc = 0, nc_done = 0, b_next = 0;
+			int c_next = 0;
+		};
+		auto rest_init = [&](long k, bool skip_next) {
+			Rest s;
+			long c_all = 0; // first block of the range, its first local column, local columns in all
 			for (long b = rank; b < nblk; b += world) {
-				if (b0 < 0 && b > k && !(skip_next && b == k + 1)) {
-					b0 = b;
-					c_first = c_all;
+				if (s.b0 < 0 && b > k && !(skip_next && b == k + 1)) {
+					s.b0 = b;
+					s.c_first = c_all;
 				}
 				c_all += width(b);
 			}
-			if (b0 >= 0) {
-				const long nc = c_all - c_first, gap = (world - 1) * nb;
-				long nc_done = 0, b_next = b0; // gathered columns so far, next owned block to gather
-				for (int c = 0; c < p.nch; ++c) {
+			s.nc = c_all - s.c_first;
+			s.b_next = s.b0;
+			return s;
+		};
+		auto rest_run = [&](long k, const Plan &p, Rest &s, int c_end) {
+			be.rest_begin();
+			if (s.b0 >= 0) {
+				const long gap = (world - 1) * nb, b0 = s.b0;
+				for (int c = s.c_next; c < c_end; ++c) {
 					if (p.g[c + 1] <= b0 * nb)
 						continue; // rows above the first owned column: nothing to update
 					wait_chunk(k, c, 1);
 					// rows of the owned blocks that start inside this chunk
 					long ncols_c = 0;
-					const long b_first = b_next;
-					while (b_next < nblk && b_next * nb < p.g[c + 1]) {
-						ncols_c += width(b_next);
-						b_next += world;
+					const long b_first = s.b_next;
+					while (s.b_next < nblk && s.b_next * nb < p.g[c + 1]) {
+						ncols_c += width(s.b_next);
+						s.b_next += world;
 					}
 					if (ncols_c > 0)
-						be.gather_stair(chunk_rows(k, p, c, b_first * nb, p.g[c + 1]), ncols_c, nb, gap, gbuf + nc_done, nc);
-					nc_done += ncols_c;
+						be.gather_stair(chunk_rows(k, p, c, b_first * nb, p.g[c + 1]), ncols_c, nb, gap, gbuf + s.nc_done, s.nc);
+					s.nc_done += ncols_c;
 					const long r0 = p.g[c] > b0 * nb ? p.g[c] : b0 * nb;
-					be.syrk_stair_sub(view(r0, c_first, p.g[c + 1] - r0, nc_done), chunk_rows(k, p, c, r0, p.g[c + 1]),
-							  View{gbuf, nc_done, width(k), 1, nc}, nb, gap, r0 - b0 * nb);
+					be.syrk_stair_sub(view(r0, s.c_first, p.g[c + 1] - r0, s.nc_done), chunk_rows(k, p, c, r0, p.g[c + 1]),
+							  View{gbuf, s.nc_done, width(k), 1, s.nc}, nb, gap, r0 - b0 * nb);
 				}
 			}
+			if (c_end > s.c_next)
+				s.c_next = c_end;
 			be.rest_end();
 		};
 		be.zero_ints(status, 4);
@@ -189,6 +213,7 @@ template <class B> struct DistLlt {
 			const Plan p0 = plan(0, nblk, n, nb);
 			if (rank == 0 % world) {
 				be.potrf_panel(view(0, local_col0(0), width(0), width(0)), 0, status);
+				solve_panel(0, p0);
 				for (int c = 0; c < p0.nch; ++c)
 					produce_chunk(0, p0, c);
 			} else {
@@ -209,31 +234,47 @@ template <class B> struct DistLlt {
 				be.step_begin((n - k * nb) * right / 2, n - (k + 1) * nb);
 			}
 			if (ahead && rank == next_owner) {
-				// look-ahead part: block column k + 1 is brought up to date, factored and sent chunk by chunk
-				be.ahead_begin();
+				// Look-ahead part: block column k + 1 is brought up to date, factored and sent chunk by chunk.  Round 6: only the
+				// DIAGONAL block's factorization (a chain of latency-bound leaves) runs on the panel stream; the level-3 work --
+				// the update of block column k + 1 and the solve of the rows below its diagonal block -- runs on the bulk stream
+				// in front of / between the parts of the rest of update k, as the single-GPU driver does (potrf.hip): rounds 2-5
+				// had all of it on the panel stream's few CUs, or everything on one stream (one rank, N = 16384: 100-105 ms
+				// against 34 ms for the single-GPU driver, profiles/r06_exp_dist.txt).
 				const Plan q = plan(k + 1, nblk, n, nb);
 				const long d0 = (k + 1) * nb, w1 = width(k + 1), lc1 = local_col0(k + 1);
-				wait_chunk(k, 0, 0);
 				View Bt1 = chunk_rows(k, p, 0, d0, d0 + w1); // the rows of panel k that belong to block column k + 1
+				be.ahead_cols_begin();
+				wait_chunk(k, 0, 0);
 				be.syrk_sub(view(d0, lc1, w1, w1), Bt1, Bt1);
+				be.ahead_cols_end();
+				be.ahead_begin();
 				be.potrf_panel(view(d0, lc1, w1, w1), d0, status);
-				for (int cq = 0; cq < q.nch; ++cq) {
-					for (int c = 0; c < p.nch; ++c) {
-						const long lo = q.g[cq] > p.g[c] ? q.g[cq] : p.g[c], hi = q.g[cq + 1] < p.g[c + 1] ? q.g[cq + 1] : p.g[c + 1];
-						if (lo >= hi)
-							continue;
-						wait_chunk(k, c, 0);
-						be.gemm_sub_nt(view(lo, lc1, hi - lo, w1), chunk_rows(k, p, c, lo, hi), Bt1);
-					}
-					produce_chunk(k + 1, q, cq);
-				}
 				be.ahead_end();
-				rest(k, p, true); // runs beside the panel on an asynchronous backend
-				be.ahead_join();
+				// the rows below the diagonal block: updated beside its factorization
+				be.ahead_cols_begin();
+				for (int c = 0; c < p.nch; ++c) {
+					const long lo = q.g[0] > p.g[c] ? q.g[0] : p.g[c], hi = p.g[c + 1];
+					if (lo >= hi)
+						continue;
+					wait_chunk(k, c, 0);
+					be.gemm_sub_nt(view(lo, lc1, hi - lo, w1), chunk_rows(k, p, c, lo, hi), Bt1);
+				}
+				be.ahead_cols_end();
+				// the first chunks of the rest of update k fill the time the diagonal block takes; everybody else needs panel
+				// k + 1 only after THEIR rest of update k
+				Rest rs = rest_init(k, true);
+				rest_run(k, p, rs, p.nch / 2);
+				be.ahead_solve_begin(); // (behind the diagonal block)
+				solve_panel(k + 1, q);
+				for (int cq = 0; cq < q.nch; ++cq)
+					produce_chunk(k + 1, q, cq);
+				be.ahead_solve_end();
+				rest_run(k, p, rs, p.nch); // (the bulk stream has joined the panel stream in ahead_solve_begin: no ahead_join)
 			} else {
 				if (ahead) // post the receives before the updates: the transfers overlap them
 					post_receives(k + 1);
-				rest(k, p, false);
+				Rest rs = rest_init(k, false);
+				rest_run(k, p, rs, p.nch);
 			}
 			// every chunk of panel k has been waited for by somebody on this rank before its buffer is reused two steps later
 			for (int c = 0; c < p.nch; ++c)

@@ -119,6 +119,8 @@ struct HostBackend {
 	void ahead_end() {}
 	void ahead_join() {}
 	void ahead_pause() {}
+	void ahead_solve_begin() {}
+	void ahead_solve_end() {}
 	void ahead_resume() {}
 	void run_end() {}
 	void copy_ints(int *dst, const int *src, size_t n) { std::memcpy(dst, src, n * sizeof(int)); }
