@@ -340,6 +340,7 @@ template <typename T> void ldlt_scale_lower_dev(MatV<T> out, MatV<const T> L, co
 template <typename T> void ldlt_inverse_prepare_dev(MatV<T> W, const T *d, idx_t ds);
 template <typename T> void zero_then_upper_dev(MatV<T> out, const MatV<const T> *R);
 // fplu.hip: LU with full pivoting (perm arrays are host memory); returns the transposition count
+void fplu_debug_inplace(int on); // fplu.hip: 1 = the in-place two-launch path (A/B tests)
 template <typename T> long full_piv_lu_dev(MatV<T> A, idx_t *row_perm, idx_t *row_perm_inv, idx_t *col_perm, idx_t *col_perm_inv);
 // qr.hip: QR with column pivoting (perm arrays are host memory); returns the transposition count
 template <typename T> long colpiv_qr_dev(MatV<T> A, MatV<T> H, idx_t *col_perm, idx_t *col_perm_inv);

@@ -498,6 +498,9 @@ FAER_HIP_API long faer_hip_debug_qr_one_pass_columns(void);
  * round 3-5 schedule), 1 (default) = in one pass per panel with the next panel's kernel beside its second half (csrc/tsqr.hip), 2 = the
  * same without the raw copy of the panel (what matrices of more than 4.19 M rows run: V = P M as a launch of its own behind U2). */
 FAER_HIP_API void faer_hip_debug_qr_fused(int on);
+/* Full-pivot LU: 1 = the in-place path (two launches per step) instead of the one-launch-per-step path between two scratch copies
+ * (default 0; identical factors and permutations, tests/test_gpu_factor.py). */
+FAER_HIP_API void faer_hip_debug_fplu_inplace(int on);
 /* tests: 1 = the single-workgroup vector kernels of the tridiagonal / bidiagonal / Hessenberg reductions run their memory-resident bodies
  * at every size (default: from 4096 remaining rows down they keep their columns in registers); results must not depend on it. */
 FAER_HIP_API void faer_hip_debug_level2_force_memory_bodies(int on);

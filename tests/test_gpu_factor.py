@@ -505,6 +505,35 @@ def test_full_piv_lu_vs_oracle(oracle, m, n, layout, dtype):
         assert np.abs(a64.T @ to_host(x) - b).max() <= tol * np.abs(b).max()
 
 
+@pytest.mark.parametrize("m,n,layout", [(1, 1, "F"), (1, 7, "F"), (7, 1, "F"), (5, 5, "F"), (300, 300, "F"), (1030, 700, "F"), (700, 1100, "C"),
+                                        (2100, 9, "F"), (9, 2100, "F"), (1500, 1500, "C")])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_full_piv_lu_one_launch_path_equals_in_place_path(m, n, layout, dtype):
+    """the default path (one launch per step between two scratch copies of the matrix) and the in-place path of rounds 1-6
+    (faer_hip_debug_fplu_inplace(1): interchange launch + update launch per step) run the same arithmetic per entry and the same
+    pivot rule: factors and permutations bit for bit -- Gaussian data, small integers (ties in the pivot search) and a matrix of
+    rank 3 (the elimination ends early and the live block travels back from the scratch copy)"""
+    F = init_gpu()
+    rng = np.random.default_rng(m * 17 + n)
+    cases = [np.array(rng.standard_normal((m, n)), dtype=dtype, order=layout),
+             np.array(rng.integers(-3, 4, (m, n)), dtype=dtype, order=layout)]
+    r = min(3, m, n)
+    cases.append(np.array((rng.integers(-2, 3, (m, r)) @ rng.integers(-2, 3, (r, n))), dtype=dtype, order=layout))
+    for a in cases:
+        out = []
+        for mode in (1, 0):
+            F.lib().faer_hip_debug_fplu_inplace(mode)
+            try:
+                da = to_dev(a, layout)
+                rf, rb, cf, cb, cnt = F.full_piv_lu_factor_in_place(da)
+                out.append((to_host(da), rf, rb, cf, cb, cnt))
+            finally:
+                F.lib().faer_hip_debug_fplu_inplace(0)
+        (g0, rf0, rb0, cf0, cb0, c0), (g1, rf1, rb1, cf1, cb1, c1) = out
+        assert np.array_equal(rf0, rf1) and np.array_equal(rb0, rb1) and np.array_equal(cf0, cf1) and np.array_equal(cb0, cb1) and c0 == c1
+        assert np.array_equal(g0, g1)
+
+
 def test_full_piv_lu_singular_trailing_block_and_size_property():
     """exactly singular trailing block: the elimination stops like the reference's (identity transpositions from
     there on); N = 2048: P A Q x == L (U x) and |l_ij| <= 1, independent of the oracle"""
