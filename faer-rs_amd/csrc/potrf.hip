@@ -370,6 +370,7 @@ std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2)
 	// width of the first look-ahead step: the whole chip waits for the first diagonal block, so it is ONE 128-block (a
 	// leaf, ~55 us) instead of a 1024-wide one (~1.05 ms): 41.1 -> 40.1 ms at N = 16384
 	const idx_t first = POTRF_NB;
+	const idx_t second = 512; // (measured: 0 / 256 / 512: 33.54-33.56 / 33.34 / 33.21-33.30 ms at N = 16384)
 	std::vector<idx_t> J;
 	J.push_back(0);
 	while (true) {
@@ -379,6 +380,10 @@ std::vector<idx_t> llt_plan(idx_t n, idx_t tail_rows, idx_t nb2)
 			w = LA_NB; // narrow steps again towards the end
 		if (J.size() == 1 && first > 0 && first < w)
 			w = first; // (the whole chip waits for the first diagonal block)
+		// the SECOND step: its diagonal chain + panel solve have only the K = `first` update of the whole matrix to hide
+		// behind (0.73 ms at N = 16384; a 1024-wide step needs 1.1 + 0.6 ms: the bulk stream idled 1.06 ms) -- LLT_SECOND wide
+		if (J.size() == 2 && first > 0 && second > 0 && second < w && n - j0 - second >= 2 * w)
+			w = second;
 		if (!(n - j0 > tail_rows && j0 + w < n))
 			break;
 		J.push_back(j0 + w);

@@ -88,15 +88,16 @@ def test_driver_planning_logic_needs_no_gpu():
         return [int(buf[i]) for i in range(cnt)]
 
     # N = 16384, look-ahead until at most 4096 rows remain: the first step is ONE 128-block (the whole chip waits for the
-    # first diagonal block), then steps of 1024; tail from column 12416
-    assert plan(16384, 4096) == [0] + [128 + 1024 * i for i in range(13)]
+    # first diagonal block), the second 512 wide (its chain only has the K = 128 update to hide behind), then steps of 1024;
+    # tail from column 12928
+    assert plan(16384, 4096) == [0, 128] + [640 + 1024 * i for i in range(13)]
     # everything to the tail when the matrix is not larger than the tail threshold
     assert plan(8192, 8192) == [0]
     # ragged size: steps stop when the next panel would reach the end
-    assert plan(5197, 2048) == [0, 128, 1152, 2176, 3200]
-    assert plan(5197, 0) == [0, 128, 1152, 2176, 3200, 4224]  # the last 973 columns are the tail
-    # wider later steps: first step 128, then 2048 while 2 * 2048 rows remain behind them, 1024 again at the end
-    assert plan(16384, 4096, 2048) == [0, 128, 2176, 4224, 6272, 8320, 10368, 11392, 12416]
+    assert plan(5197, 2048) == [0, 128, 640, 1664, 2688, 3712]
+    assert plan(5197, 0) == [0, 128, 640, 1664, 2688, 3712, 4736]  # the last 461 columns are the tail
+    # wider later steps: first step 128, second 512, then 2048 while 2 * 2048 rows remain behind them, 1024 again at the end
+    assert plan(16384, 4096, 2048) == [0, 128, 640, 2688, 4736, 6784, 8832, 10880, 11904, 12928]
     for n in (2049, 3000, 10240, 16384, 20000):
         for tail in (0, 1024, 4096, 1 << 30):
             j = plan(n, tail)
