@@ -1459,7 +1459,8 @@ template <bool VEC, int MODE> __global__ __launch_bounds__(MODE == 1 ? 256 : 512
 	if (tq_skip(a.stat, a.c0))
 		return;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const int quad = tid & 15, cg = tid >> 4;
+	const int quad = tid & 15;
+	int cg = tid >> 4; // (MODE 2: made opaque once per chunk, see the loop)
 	const int lam = lane & 31, h = lane >> 5;
 	const int rt = wv & 1, cp = wv >> 1; // this wavefront's 32-row half of a chunk, and the parity of its column tiles
 	// ---- the wavefront's operands of the whole launch: -Y for its column tiles (MODE 1: tile cp of N; MODE 2: tile cp of F), M for its V tile
@@ -1541,13 +1542,24 @@ template <bool VEC, int MODE> __global__ __launch_bounds__(MODE == 1 ? 256 : 512
 	if (ch < a.nchunks)
 		load_chunk(ch);
 	for (; ch < a.nchunks; ch += gridDim.x) {
+		// MODE 2 has 128 registers per wavefront; the compiler kept the loop-invariant column pointers of the loads and stores (12 64-bit
+		// values per thread) and spilled 16 registers of the -Y operand for them -- and on gfx9 a scratch reload counts in the same
+		// in-order counter as the global loads: every reload inside the products waited for the NEXT chunk's loads, which had just been
+		// issued.  An opaque copy of the column group makes it recompute the pointers where they are used (114 registers, no spill:
+		// U2 220 -> 200 us; in MODE 1, which has the registers, the same trick costs 18 us per launch and is not applied).
+		if (MODE == 2)
+			asm volatile("" : "+v"(cg));
 		tq_lds_barrier(); // the previous chunk has been consumed
 #pragma unroll
 		for (int i = 0; i < NQ; ++i)
 			*reinterpret_cast<f32x4 *>(&sm[(i * CGN + cg) * TQ_LP + quad * 4]) = st[i];
 		tq_lds_barrier();
+		if (MODE == 2)
+			asm volatile("" : "+v"(cg));
 		if (ch + (int) gridDim.x < a.nchunks)
 			load_chunk(ch + gridDim.x); // in flight during the products
+		if (MODE == 2)
+			asm volatile("" : "+v"(cg));
 		// ---- update: D = X + P (-Y), tiles (rt, cp + 2 u); V = P M
 		{
 			f32x16 acc[NT], vacc;
