@@ -50,7 +50,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # launch duration and its launch count are PARSED at run time from the committed rocprofv3 kernel trace of
 # `bench.py --workload X --steps 10 --warmup 2` (profiles/rNN_X_kernel_stats.csv, newest round first) -- they describe that
 # recorded run, not this one, and the JSON says so (`source`, `not_measured_this_run`).
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02")
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02")
 BOUND_OF = {  # what bounds the dominant kernel of each chain
     "gemm_kernel": "mfma", "getrf_panel": "latency", "getrf_wpanel": "latency", "qr_panel": "latency", "tq_update": "hbm", "tq_gram": "mfma", "tq_panel": "latency",
     "trsm_leaf": "latency", "potrf_leaf": "latency",
