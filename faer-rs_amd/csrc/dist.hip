@@ -337,8 +337,13 @@ template <typename S> struct DeviceBackend {
 	}
 	void run_end()
 	{
-		if (two && ev_bulk)
-			stream_wait(caller, ev_bulk);
+		if (two && (ev_bulk || prev_two)) {
+			// everything queued on the bulk stream so far -- with the built-in transport that includes the last waits for this
+			// rank's own broadcasts, which still read the workspace the caller may release after the call
+			hipEvent_t e = ctx().next_event();
+			FH_HIP(hipEventRecord(e, ctx().la_bulk));
+			stream_wait(caller, e);
+		}
 		if (two && ev_join)
 			stream_wait(caller, ev_join);
 		ev_bulk = ev_join = nullptr;
