@@ -730,7 +730,14 @@ def main():
                         if name == "qr":
                             others[lb]["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                       "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                                      "algorithmic_bytes": 2.0 * 500000 * 256 * 4}
+                                                      "algorithmic_bytes": 2.0 * 500000 * 256 * 4,
+                                                      # (what else bounds this chain -- DESIGN.md 3.5: the streaming kernels are co-bound by the matrix
+                                                      # cores; constants of the algorithm and of the committed PMC pass, not measurements of this run)
+                                                      "co_bounds": {"fp32_mfma_flop": 2.0 * 500000 * 256 * 256, "fp64_mfma_flop": 4 * 2.0 * 500000 * 64 * 64 * 10 / 16,
+                                                                    "mfma_floor_ms": round(1e3 * (2.0 * 500000 * 256 * 256 / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+                                                                                                  + 4 * 2.0 * 500000 * 64 * 64 * 10 / 16 / (FP64_MFMA_PEAK_TFLOPS * 1e12)), 3),
+                                                                    "hbm_side_bytes_pmc": 4.24e9, "hbm_floor_ms_at_5TBps": round(4.24e9 / 5e12 * 1e3, 3),
+                                                                    "source": "profiles/r06_pmc_qr_summary.json, tools/tall_stream_probe.hip"}}
                             if kr:
                                 others[lb]["roofline"]["dominant_kernel"] = kr
                             else:
