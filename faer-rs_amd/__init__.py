@@ -586,6 +586,52 @@ class RcclTransport:
             self.handle = None
 
 
+class LoopbackGroup:
+    """Loop-back transport (csrc/loop_transport.hip, TEST infrastructure): the ranks of a distributed factorization as threads of this
+    process on one GPU.  `group.rank(r)` must be called on the thread that runs rank r; the returned object is a `transport=` argument
+    of dist_partial_piv_lu / dist_llt (it has the `.comm` of an RcclTransport)."""
+
+    class Rank:
+        def __init__(self, group, rank):
+            L = lib()
+            L.faer_hip_loopback_rank_create.restype = C.c_void_p
+            L.faer_hip_loopback_rank_create.argtypes = [C.c_void_p, C.c_int]
+            L.faer_hip_loopback_comm.restype = HipComm
+            L.faer_hip_loopback_comm.argtypes = [C.c_void_p]
+            self.handle = L.faer_hip_loopback_rank_create(C.c_void_p(group.handle), int(rank))
+            self.comm = L.faer_hip_loopback_comm(C.c_void_p(self.handle))
+
+        def stats(self):
+            out = (C.c_double * 2)()
+            L = lib()
+            L.faer_hip_loopback_stats.argtypes = [C.c_void_p, C.c_void_p]
+            L.faer_hip_loopback_stats(C.c_void_p(self.handle), out)
+            return {"broadcasts": int(out[0]), "bytes": float(out[1])}
+
+        def close(self):
+            if self.handle:
+                L = lib()
+                L.faer_hip_loopback_rank_destroy.argtypes = [C.c_void_p]
+                L.faer_hip_loopback_rank_destroy(C.c_void_p(self.handle))
+                self.handle = None
+
+    def __init__(self, world_size):
+        L = lib()
+        L.faer_hip_loopback_group_create.restype = C.c_void_p
+        self.handle = L.faer_hip_loopback_group_create(C.c_int(int(world_size)))
+        self.world_size = int(world_size)
+
+    def rank(self, rank):
+        return LoopbackGroup.Rank(self, rank)
+
+    def close(self):
+        if self.handle:
+            L = lib()
+            L.faer_hip_loopback_group_destroy.argtypes = [C.c_void_p]
+            L.faer_hip_loopback_group_destroy(C.c_void_p(self.handle))
+            self.handle = None
+
+
 PROF_CLASSES = ("mfma_products", "lu_panel", "qr_update", "qr_gram", "qr_panel", "llt_leaf")
 PROF_UNITS = ("flop", "columns", "bytes", "bytes", "launches", "columns")
 

@@ -353,6 +353,7 @@ extern std::atomic<int> g_lend_cus; // faer_hip_debug_lend_cus: the look-ahead d
 void lu_debug_plan(long nb2_from, long pipe_from, long la_min); // debug: switch-over points of the look-ahead LU driver (0 = default)
 void lu_lend_copy(const void *device_copy, idx_t nrows, idx_t ncols, int elem_bytes); // the calling thread's next LU may restore A from it after an exchange timeout (getrf.hip)
 bool rccl_is_builtin_wait(FaerHipWaitFn fn); // rccl_transport.hip: is this the built-in transport's wait (takes any stream)
+bool loop_is_builtin_wait(FaerHipWaitFn fn); // loop_transport.hip: the loop-back transport of the tests (ranks = threads on one GPU)
 void level2_debug_force_memory_bodies(int on); // debug: tridiag / bidiag / Hessenberg vector kernels never keep their columns in registers
 void tsqr_debug_fused(int on); // debug: 0 = the one-pass QR runs update and Gram as separate launches (rounds 3-5), 1 = fused with look-ahead (default)
 long qr_last_one_pass_columns(); // debug: columns the one-pass QR path completed in this thread's last factorization (-1: not taken)

@@ -116,7 +116,9 @@ template <typename S> struct DeviceBackend {
 	// (`quiet`: its calls only need ctx().stream, whichever stream that is) a run therefore leaves the caller's stream alone
 	// between its first two-stream step and run_end: broadcasts start from the stream that packed (owner) or last read (receiver)
 	// the buffer, waits are taken by the bulk stream, the panel stream joins the bulk stream directly.
-	bool quiet() const { return comm.ibcast && comm.wait && rccl_is_builtin_wait(comm.wait); }
+	// (the loop-back transport of the tests has the same contract: loop_transport.hip)
+	bool builtin_wait() const { return rccl_is_builtin_wait(comm.wait) || loop_is_builtin_wait(comm.wait); }
+	bool quiet() const { return comm.ibcast && comm.wait && builtin_wait(); }
 	bool bcast_from_panel = false; // dist_lu.h: the next broadcast ships what the panel stream has just packed (set by ahead_join)
 	hipEvent_t ev_join = nullptr;  // quiet: panel-stream work the bulk stream has to join before its next section
 	// asynchronous pair when the transport offers one, else the blocking broadcast at `begin`
@@ -145,7 +147,7 @@ template <typename S> struct DeviceBackend {
 		if (!(comm.ibcast && comm.wait))
 			return;
 		hipStream_t cur = ctx().stream;
-		if (caller && cur != caller && !rccl_is_builtin_wait(comm.wait)) {
+		if (caller && cur != caller && !builtin_wait()) {
 			ctx().stream = caller;
 			comm.wait(comm.user, slot);
 			hipEvent_t e = ctx().next_event();

@@ -584,6 +584,16 @@ FAER_HIP_API FaerHipComm faer_hip_rccl_comm(void *handle);
 FAER_HIP_API void faer_hip_rccl_destroy(void *handle);
 
 /* Number of block columns of width `nb` owned by `rank` out of n columns distributed block-cyclically. */
+/* Loop-back transport (TEST infrastructure): the ranks of a distributed factorization as threads of ONE process on ONE GPU, data moved by
+ * device-to-device copies; same contract as the RCCL transport (its calls only need the calling thread's current stream), so the stream
+ * schedule a rank runs over the built-in transport can be exercised with several ranks on a one-GPU box (tests/test_gpu_dist_threads.py).
+ * faer_hip_loopback_group_create once, faer_hip_loopback_rank_create on each rank's thread, faer_hip_loopback_comm(rank_handle) -> comm. */
+FAER_HIP_API void *faer_hip_loopback_group_create(int world_size);
+FAER_HIP_API void *faer_hip_loopback_rank_create(void *group, int rank);
+FAER_HIP_API FaerHipComm faer_hip_loopback_comm(void *rank_handle);
+FAER_HIP_API void faer_hip_loopback_stats(void *rank_handle, double *out2);
+FAER_HIP_API void faer_hip_loopback_rank_destroy(void *rank_handle);
+FAER_HIP_API void faer_hip_loopback_group_destroy(void *group);
 FAER_HIP_API size_t faer_hip_dist_local_ncols(size_t n, size_t nb, int rank, int world_size);
 /* measurement aids (bench.py --gpus N --workload lu|llt): the calling thread's last faer_hip_dist_* factorization --
  * out3 = {device ms of the whole call, device ms of the panel factorizations this rank owned, their number};
