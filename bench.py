@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=["gemm", "sgemm", "llt", "lu", "qr", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess"],
+    ap.add_argument("--workload", default=None, choices=["gemm", "sgemm", "llt", "lu", "qr", "qr64", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess"],
                     help="default: gemm on one GPU, the block-cyclic lu (RCCL transport) on several (resolve_run)")
     ap.add_argument("--n", type=int, default=0, help="override the matrix size (testing only)")
     ap.add_argument("--no-extras", action="store_true")
@@ -324,6 +324,23 @@ def main():
                 F.qr_factor_in_place(work, h)
 
             return step, 2.0 * m * n * n - 2.0 / 3.0 * n ** 3, lambda: work.copy_(a), f"qr_f32_{m}x{n}", "f32"
+        if name == "qr64":
+            # the same tall-skinny shape in the reference's main arithmetic (fp64): the one-pass path's fp64 instantiation (csrc/tsqr.hip,
+            # tsqr_factor64).  faer's Mat layout: column stride padded to 64 bytes
+            m, n = (n_override or 500000), 256
+            ldp = (m + 7) // 8 * 8
+            g_ = torch.Generator(device=dev).manual_seed(5)
+            a = torch.randn((n, ldp), dtype=torch.float64, device=dev, generator=g_)[:, :m].t()
+            work = torch.empty((n, ldp), dtype=torch.float64, device=dev)[:, :m].t()
+            work.copy_(a)
+            bs = F.qr_recommended_block_size(m, n, np.float64)
+            h = torch.zeros((min(m, n), bs), dtype=torch.float64, device=dev).t()
+
+            def step():
+                work.copy_(a)
+                F.qr_factor_in_place(work, h)
+
+            return step, 2.0 * m * n * n - 2.0 / 3.0 * n ** 3, lambda: work.copy_(a), f"qr_f64_{m}x{n}", "f64"
         if name == "fplu":
             # LU with full pivoting, a level-2 (HBM bound) algorithm; algorithmic bytes =
             # one read + one write of the trailing matrix per step
@@ -649,7 +666,7 @@ def main():
             del step
             torch.cuda.empty_cache()
             only = os.environ.get("BENCH_OTHERS")  # diagnostic: a comma-separated subset
-            for name in ("gemm", "llt", "lu", "qr", "gemm4096", "sgemm", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess", "qrmax", "qrlit"):
+            for name in ("gemm", "llt", "lu", "qr", "qr64", "gemm4096", "sgemm", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess", "qrmax", "qrlit"):
                 if name == args.workload or (only and name not in only.split(",")):
                     continue
                 try:
@@ -670,9 +687,11 @@ def main():
                     others[lb] = {"GFLOP/s": round(rate, 1), "ms": round(t / 3 * 1e3, 3),
                                   "frac_of_mfma_peak": round(rate / 1e3 / peak, 4), "reps": reps}
                     kr = None
-                    if name in ("llt", "lu", "qr"):
+                    if name in ("llt", "lu", "qr", "qr64"):
                         try:
-                            kr = class_roofline(profiled(st), name, t / 3 * 1e3)
+                            kr = class_roofline(profiled(st), "qr" if name == "qr64" else name, t / 3 * 1e3)
+                            if kr and name == "qr64":
+                                kr["kernel_class"] = "tq_update64_kernel (panel applied: X - P Y and V = P M on the fp64 matrix cores)"
                         except Exception:
                             kr = None
                     if name in ("llt", "lu"):
@@ -724,6 +743,13 @@ def main():
                                       "note": "BASELINE configs[4] verbatim: the reference's rank test (qr/no_pivoting/factor.rs:52-58) rejects every "
                                               "fp32 column from 524288 rows on, so this is rank 0 / no reflector on either side -- not a "
                                               "factorization rate; see qr_f32_500000x256"}
+                    if name == "qr64":  # HBM bound as specified: algorithmic bytes 2 m n sizeof(f64)
+                        gbs = 2.0 * 500000 * 256 * 8 * 3 / t / 1e9
+                        others[lb]["GB/s_algorithmic"] = round(gbs, 1)
+                        others[lb]["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": 2.0 * 500000 * 256 * 8}
+                        if kr:
+                            others[lb]["roofline"]["dominant_kernel"] = kr
                     if name in ("qr", "qrmax"):  # HBM bound as specified: algorithmic bytes 2 m n sizeof(f32)
                         gbs = 2.0 * (524287 if name == "qrmax" else 500000) * 256 * 4 * 3 / t / 1e9
                         others[lb]["GB/s_algorithmic"] = round(gbs, 1)

@@ -1418,6 +1418,7 @@ void faer_hip_debug_lend_cus(int on) { g_lend_cus.store(on); }
 void faer_hip_debug_lu_plan(size_t nb2_from, size_t pipe_from, size_t la_min_cols) { lu_debug_plan((long) nb2_from, (long) pipe_from, (long) la_min_cols); }
 long faer_hip_debug_qr_one_pass_columns(void) { return qr_last_one_pass_columns(); }
 void faer_hip_debug_qr_fused(int on) { tsqr_debug_fused(on); }
+void faer_hip_debug_qr_one_pass_f64(int on) { tsqr_debug_f64(on); }
 void faer_hip_debug_fplu_inplace(int on) { fplu_debug_inplace(on); }
 void faer_hip_debug_level2_force_memory_bodies(int on) { level2_debug_force_memory_bodies(on); }
 void *faer_hip_debug_internal_stream(int which)

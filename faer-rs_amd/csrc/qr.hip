@@ -3251,6 +3251,13 @@ template <typename T> static long geqrf_classic(MatV<T> A, MatV<T> H, idx_t bloc
 // tsqr.hip: the one-pass path for tall fp32 matrices
 bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs);
 idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason);
+// ... and its fp64 instantiation (fp64 Gram sums: well-conditioned panels only, the rest goes to the classic path)
+bool tsqr_applicable64(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs, const void *p);
+idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason);
+static inline bool tsqr_ok(const MatV<float> &A, idx_t bs) { return tsqr_applicable(A.nrows, A.ncols, A.rs, A.cs, bs); }
+static inline bool tsqr_ok(const MatV<double> &A, idx_t bs) { return tsqr_applicable64(A.nrows, A.ncols, A.rs, A.cs, bs, A.p); }
+static inline idx_t tsqr_run(MatV<float> A, MatV<float> H, float *taus, int *reason) { return tsqr_factor(A, H, taus, reason); }
+static inline idx_t tsqr_run(MatV<double> A, MatV<double> H, double *taus, int *reason) { return tsqr_factor64(A, H, taus, reason); }
 
 template <typename T> __global__ void qr_taus_from_blocks_kernel(const T *H, idx_t hrs, idx_t hcs, int bs, int count, T *taus)
 {
@@ -3259,7 +3266,7 @@ template <typename T> __global__ void qr_taus_from_blocks_kernel(const T *H, idx
 		taus[j] = H[(idx_t) (j % bs) * hrs + (idx_t) j * hcs];
 }
 
-// Tall fp32 matrices take the one-pass path (tsqr.hip).  It stops in front of the first 64-column panel it cannot
+// Tall matrices take the one-pass path (tsqr.hip; fp64 since the end of round 6).  It stops in front of the first 64-column panel it cannot
 // take (ill conditioned, a column failing the reference's rank test, ...) with every earlier reflector applied to
 // everything on its right -- the state qr_in_place_blocked (factor.rs:137-256) is in at that column -- so the classic
 // path simply factors the remaining submatrix and the T blocks are rebuilt from V and the taus.
@@ -3269,14 +3276,14 @@ long qr_last_one_pass_columns() { return g_qr_one_pass_columns; }
 template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_threshold)
 {
 	g_qr_one_pass_columns = -1;
-	if constexpr (std::is_same<T, float>::value) {
+	{
 		const idx_t m = A.nrows, n = A.ncols, bs = H.nrows;
 		const idx_t size = m < n ? m : n;
 		const bool ref_rejects_all = (double) Lim<T>::eps * 16.0 * (double) m >= 1.0;
-		if (size > 0 && bs > 0 && H.ncols == size && !ref_rejects_all && tsqr_applicable(m, n, A.rs, A.cs, bs)) {
+		if (size > 0 && bs > 0 && H.ncols == size && !ref_rejects_all && tsqr_ok(A, bs)) {
 			Scratch taus((size_t) size * sizeof(T));
 			int reason = 0;
-			const idx_t done = tsqr_factor(A, H, taus.as<T>(), &reason);
+			const idx_t done = tsqr_run(A, H, taus.as<T>(), &reason);
 			g_qr_one_pass_columns = (long) done;
 			if (done == size)
 				return (long) size;

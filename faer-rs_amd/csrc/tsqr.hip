@@ -47,6 +47,22 @@ constexpr int TQ_NB = 512;  // workgroups (= partial sums) of a Gram launch: two
 constexpr int TQ_DP = 65;   // pitch of the fp64 64 x 64 matrices in LDS
 constexpr double TQ_COND_MAX = 64.0 * 512.0; // |R D|_F |(R D)^-1|_F of the equilibrated panel (>= 64 for any panel): cond_2 below ~512
 constexpr double TQ_TAIL_MIN = 1e-9;	     // 1 - |head| / |column| below this: the tail is numerically zero
+// Per scalar type: the reference's epsilon (rank test), the condition bound of a panel and the range of column scales.
+// fp32 data: the Gram sums are EXACT products accumulated in fp64, so R~ is good to cond^2 2^-53 -- far below fp32 rounding.
+// fp64 data: the Gram sums carry fp64 rounding themselves, R~ and everything derived from it is good to ~cond^2 eps64: the
+// one-pass path keeps panels whose equilibrated condition number is a small constant (cond_2 below ~4: Gaussian and other
+// well-conditioned tall panels) and hands everything else to the classic path.
+template <typename T> struct TqLim;
+template <> struct TqLim<float> {
+	static constexpr double eps = 1.1920928955078125e-07;
+	static constexpr double cond_max = TQ_COND_MAX;
+	static constexpr double sq_lo = 1e-24, sq_hi = 1e24; // mean square of a column
+};
+template <> struct TqLim<double> {
+	static constexpr double eps = 2.220446049250313e-16;
+	static constexpr double cond_max = 64.0 * 4.0;
+	static constexpr double sq_lo = 1e-200, sq_hi = 1e200;
+};
 enum { TQ_OK = 0, TQ_FAIL_CHOL = 1, TQ_FAIL_TAIL = 2, TQ_FAIL_RANK = 3, TQ_FAIL_COND = 4, TQ_FAIL_RANGE = 5 };
 
 // Status word 0 of a factorization: 0, or 1 + the number of columns completed when a panel was rejected.  The kernels of
@@ -237,7 +253,7 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram_kernel(con
 // One level (every entry summed over 512 partials by one thread) took 40-120 us per launch: 64 workgroups, 512 dependent
 // strided loads each.
 constexpr int TQ_NG = 8;
-__global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const float *Cp, const float *Sp, int nb, int tp, int want_g,
+template <typename TC> __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const TC *Cp, const TC *Sp, int nb, int tp, int want_g,
 							 int want_sq, double *G, double *C, int ldc, int coff, double *S, const int *stat, int c0,
 							 double *Gf, int *cnt)
 {
@@ -335,8 +351,8 @@ __global__ __launch_bounds__(256) void tq_reduce_kernel(const double *Gp, const 
 // the 3.4 ms of a 5e5 x 256 factorization at the time); every row in registers, one wavefront per kind of row, one workgroup
 // barrier per 4 columns: 146 us; this version ~110 us.
 // ------------------------------------------------------------------------------------------------
-struct TqPanelArgs {
-	float *A;
+template <typename T> struct TqPanelArgs {
+	T *A;
 	long ld;
 	int m, r0, c0, w, n;
 	const double *G;   // the Gram matrix (sum of the TQ_NG slices), row major 64 x 64 (w x w valid, lower 16 x 16 tiles)
@@ -344,15 +360,15 @@ struct TqPanelArgs {
 	int check_range, range_cols;
 	double *abv;	   // per global column: sum of squares of the R entries above the current block row
 	double *N1, *N3; // out: R^-T, V1^-1 (row major 64 x 64); with M they give Y = -M V1^-1 (R^-T C - X_top)
-	float *Mn;	   // out: M = -(U R)^-1, row major 64 x 64
-	const float *A1s;  // the panel's top block before the factorization, column major 64 x 64 (written by the Gram kernel)
-	float *top;	   // out: the panel's top block (R on and above the diagonal, V1 below), row major 64 x 64 -- NOT written
+	T *Mn;	   // out: M = -(U R)^-1, row major 64 x 64
+	const T *A1s;  // the panel's top block before the factorization, column major 64 x 64 (written by the Gram kernel)
+	T *top;	   // out: the panel's top block (R on and above the diagonal, V1 below), row major 64 x 64 -- NOT written
 			   // into A here: the Gram launch of this panel's trailing columns may still be reading those rows
 	double *Md, *Td;   // out: M and T of this panel in fp64 (cross-panel blocks of T)
-	float *H;
+	T *H;
 	long hrs, hcs;
 	int bs;
-	float *taus;
+	T *taus;
 	int *stat;
 	long long *dbg; // phase stamps (timing build only)
 };
@@ -639,7 +655,7 @@ static __device__ __forceinline__ void tq_trinv_levels(const TqInvJob &job0, con
 	} while (0)
 #endif
 constexpr int TQ_PT = 256;
-__global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
+template <typename T> __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs<T> a)
 {
 	__shared__ double Lm[64 * TQ_DP]; // G, then L (lower Cholesky factor, R~ = L^T), later M
 	__shared__ double Wm[64 * TQ_DP]; // A1, then Q1~, then [V1 strictly lower | U upper]
@@ -666,7 +682,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	};
 	if (a.check_range) {
 		// fp32 products of the C sums underflow / overflow for columns far from unit scale: rms outside [1e-12, 1e12]
-		const double lo = 1e-24 * (double) (a.m - a.r0), hi = 1e24 * (double) (a.m - a.r0);
+		const double lo = TqLim<T>::sq_lo * (double) (a.m - a.r0), hi = TqLim<T>::sq_hi * (double) (a.m - a.r0);
 		bool bad = false;
 		for (int c = tid; c < w; c += TQ_PT) { // the trailing columns: tq_y_kernel of this step
 			double sq = 0.0;
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 #pragma unroll 1
 	for (int e0 = tid; e0 < 4096; e0 += 4 * TQ_PT) {
 		double gs[4];
-		float av[4];
+		T av[4];
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
 			const int e = e0 + u * TQ_PT;
@@ -699,7 +715,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 			gs[u] = in ? a.G[el] : 0.0;
 			// the top block as the Gram kernel's first workgroup copied it: read from A it is 64 columns on 64 different
 			// pages (2 MB apart at m = 5e5), and this single workgroup waited for every one of the address translations
-			av[u] = in ? a.A1s[e] : 0.f;
+			av[u] = in ? a.A1s[e] : (T) 0;
 		}
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
@@ -978,7 +994,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 				ab += Lm[j * TQ_DP + l] * Lm[j * TQ_DP + l];
 			const double rjj = Lm[j * TQ_DP + j];
 			const double full = sqrt(rjj * rjj + ab);
-			const double thr = (double) 1.1920928955078125e-07f * 16.0 * (double) (a.m - a.c0 - j) * full;
+			const double thr = TqLim<T>::eps * 16.0 * (double) (a.m - a.c0 - j) * full;
 			if (!(rjj > thr))
 				atomicMax(&s_fail, (int) TQ_FAIL_RANK);
 		}
@@ -998,7 +1014,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 		}
 		for (int o = 32; o > 0; o >>= 1)
 			f2 += __shfl_xor(f2, o);
-		if (!(sqrt(64.0 * f2) <= TQ_COND_MAX))
+		if (!(sqrt(64.0 * f2) <= TqLim<T>::cond_max))
 			atomicMax(&s_fail, (int) TQ_FAIL_COND);
 	}
 	__syncthreads();
@@ -1010,7 +1026,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 	// ---- outputs that read L: the top block of A (R = S R~ on and above the diagonal, V1 below), N1 = R^-T, N3 = V1^-1
 	for (int e = tid; e < 4096; e += TQ_PT) {
 		const int i = e >> 6, j = e & 63;
-		a.top[e] = (float) (i <= j ? sgn[i] * Lm[j * TQ_DP + i] : Wm[i * TQ_DP + j]);
+		a.top[e] = (T) (i <= j ? sgn[i] * Lm[j * TQ_DP + i] : Wm[i * TQ_DP + j]);
 		// R^-1 = R~^-1 S  =>  N1[i][l] = R^-1[l][i] = Ri[l][i] * s_i  (Ri holds only its upper triangle)
 		a.N1[e] = j <= i ? Ri[j * TQ_DP + i] * sgn[i] : 0.0;
 		a.N3[e] = i == j ? 1.0 : (j < i ? UL[i * TQ_DP + j] : 0.0);
@@ -1047,7 +1063,7 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 				const int k = 16 * wv + (lane >> 4) + 4 * q, j = 16 * tj + (lane & 15);
 				if (pass == 0) {
 					const double mv = k <= j ? -acc[q] : 0.0;
-					a.Mn[k * 64 + j] = (float) mv;
+					a.Mn[k * 64 + j] = (T) mv;
 					a.Md[k * 64 + j] = mv;
 				} else {
 					const double tt = k <= j ? acc[q] : 0.0;
@@ -1056,9 +1072,9 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 						// multiple of 64 or divides it (tsqr_applicable): no integer division per entry
 						const int kb = big_bs ? 0 : (int) (((float) k + 0.5f) * bs_rcp), jbk = big_bs ? 0 : (int) (((float) j + 0.5f) * bs_rcp);
 						if (kb == jbk)
-							a.H[(long) (hrow0 + k - kb * a.bs) * a.hrs + (long) (a.c0 + j) * a.hcs] = (float) tt;
+							a.H[(long) (hrow0 + k - kb * a.bs) * a.hrs + (long) (a.c0 + j) * a.hcs] = (T) tt;
 						if (k == j)
-							a.taus[a.c0 + j] = (float) tt;
+							a.taus[a.c0 + j] = (T) tt;
 					}
 					a.Td[k * 64 + j] = tt;
 				}
@@ -1073,26 +1089,26 @@ __global__ __launch_bounds__(TQ_PT) void tq_panel_kernel(const TqPanelArgs a)
 // ------------------------------------------------------------------------------------------------
 // y: 16 trailing columns per workgroup
 // ------------------------------------------------------------------------------------------------
-struct TqYArgs {
-	float *A;
+template <typename T> struct TqYArgs {
+	T *A;
 	long ld;
 	int r0, cx, w, t;
 	const double *C; // TQ_NG slices, each row major 64 x ldc
 	int ldc;
 	const double *N1, *N3, *Md; // R^-T, V1^-1, M = -(U R)^-1
 	double *abv;
-	float *Yn; // out: -Y, row major 64 x typ
+	T *Yn; // out: -Y, row major 64 x typ
 	int typ;
 	double *Z; // out: Z = -V1^-1 (D - X_top) = T^-H V^H X, row major 64 x ldz, column index = GLOBAL column
 	int ldz;
-	const float *top; // the panel's top block as the panel kernel left it (workgroup 0 stores it into A)
+	const T *top; // the panel's top block as the panel kernel left it (workgroup 0 stores it into A)
 	int *stat;
 	const double *Sr; // first step only (check_range): TQ_NG slices of the column squares, trailing columns at [64, 64 + range_cols)
 	int check_range, range_cols, mrows;
 };
 
 // the panel's top block from its staging copy into A (once every reader of the original rows is done)
-static __device__ __forceinline__ void tq_store_top(float *A, long ld, int r0, int c0, int w, const float *top, int tid)
+template <typename T> static __device__ __forceinline__ void tq_store_top(T *A, long ld, int r0, int c0, int w, const T *top, int tid)
 {
 	for (int e = tid; e < 4096; e += 256) {
 		const int i = e >> 6, j = e & 63;
@@ -1100,14 +1116,14 @@ static __device__ __forceinline__ void tq_store_top(float *A, long ld, int r0, i
 			A[(long) (c0 + j) * ld + r0 + i] = top[e];
 	}
 }
-__global__ __launch_bounds__(256) void tq_top_kernel(float *A, long ld, int r0, int c0, int w, const float *top, const int *stat)
+template <typename T> __global__ __launch_bounds__(256) void tq_top_kernel(T *A, long ld, int r0, int c0, int w, const T *top, const int *stat)
 {
 	if (tq_skip(stat, c0))
 		return;
 	tq_store_top(A, ld, r0, c0, w, top, threadIdx.x);
 }
 
-__global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
+template <typename T> __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs<T> a)
 {
 	__shared__ double n1[64 * TQ_DP], n3[64 * TQ_DP], mm[64 * TQ_DP];
 	__shared__ double v[64 * 17], v2[64 * 17];
@@ -1118,7 +1134,7 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 	if (a.check_range) {
 		// fp32 products of the C sums underflow / overflow for columns far from unit scale: rms outside [1e-12, 1e12] (the
 		// panel kernel checked its own columns).  Every workgroup evaluates the same sums; nothing has been written yet.
-		const double lo = 1e-24 * (double) a.mrows, hi = 1e24 * (double) a.mrows;
+		const double lo = TqLim<T>::sq_lo * (double) a.mrows, hi = TqLim<T>::sq_hi * (double) a.mrows;
 		int bad = 0;
 		if (tid < a.range_cols) {
 			double sq = 0.0;
@@ -1203,11 +1219,11 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 		for (int r = 0; r < 4; ++r) {
 			const int i = 16 * wv + (lane >> 4) + 4 * r;
 			dsq += acc[r] * acc[r];
-			float *xp = a.A + (long) (a.cx + b) * a.ld + a.r0 + i;
+			T *xp = a.A + (long) (a.cx + b) * a.ld + a.r0 + i;
 			double xt = 0.0;
 			if (colok && i < a.w) {
 				xt = (double) *xp;
-				*xp = (float) acc[r];
+				*xp = (T) acc[r];
 			}
 			v2[i * 17 + bl] = acc[r] - xt;
 		}
@@ -1239,7 +1255,7 @@ __global__ __launch_bounds__(256) void tq_y_kernel(const TqYArgs a)
 		for (int r = 0; r < 4; ++r) {
 			const int k = 16 * wv + (lane >> 4) + 4 * r;
 			if (b < a.typ)
-				a.Yn[(long) k * a.typ + b] = colok ? (float) acc[r] : 0.f;
+				a.Yn[(long) k * a.typ + b] = colok ? (T) acc[r] : (T) 0;
 		}
 	}
 }
@@ -1697,15 +1713,15 @@ template <bool VEC, int MODE> __global__ __launch_bounds__(MODE == 1 ? 256 : 512
 // blocks l = k + 1, ... of its block of Q_coeff in sequence; 64 x 64 x 64 products on the fp64 matrix cores.
 // The first version computed these blocks as Gram products over V: three more passes, 0.46 of 3.4 ms.
 // ------------------------------------------------------------------------------------------------
-struct TqTxArgs {
-	const float *A;
+template <typename T> struct TqTxArgs {
+	const T *A;
 	long ld;
 	int n, bs;
 	const double *Td, *Md; // per panel 64 x 64
 	const double *Z;       // per panel 64 x ldz
 	int ldz;
 	double *B; // scratch per panel 64 x ldz (general kernel); per panel 2 x 64 x 64: B_L and V^T R between the stages
-	float *H;
+	T *H;
 	long hrs, hcs;
 	const int *stat;
 	int stage; // 0: everything; 1: all that does not need the LAST panel's kernel (runs beside it); 2: the rest
@@ -1735,7 +1751,7 @@ struct TqTxUnit {
 
 constexpr int TQ_TX_MAXL = 3; // later panels of one block of Q_coeff kept in registers (blocks of Q_coeff up to 256 columns)
 
-__global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
+template <typename T> __global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs<T> a)
 {
 	__shared__ double Am[64 * TQ_DP], Bm[64 * TQ_DP], Tm[64 * TQ_DP];
 	if (a.stat[0])
@@ -1771,17 +1787,17 @@ __global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
 	// element (i, j) = (e >> 6, e & 63), e = tid + 256 q, of the operands of a product.  Only what comes from global memory
 	// is fetched ahead: the fp64 B operand of types 0 / 2 / 3 (rb) or the two fp32 chunks of type 1 (fa, fb); the A operand of
 	// type 0 (T_k) is loaded once, those of types 2 / 3 are written to LDS by the previous epilogue
-	auto fetch = [&](const TqTxUnit &u, double (&rb)[16], float (&fa)[16], float (&fb)[16]) {
+	auto fetch = [&](const TqTxUnit &u, double (&rb)[16], T (&fa)[16], T (&fb)[16]) {
 		const int cl = u.l * TQ_PW, wl = min(TQ_PW, a.n - cl);
 		if (u.type == 1) {
 #pragma unroll
 			for (int q = 0; q < 16; ++q) {
 				// transposed fill: this thread handles row gr = x + (e & 63) of A and column ii = e >> 6 (lanes along the rows)
 				const int e = tid + 256 * q, gr = u.x + (e & 63), ii = e >> 6;
-				float va = 0.f, vb = 0.f;
+				T va = 0, vb = 0;
 				if (gr < cl + wl) {
 					const int rr = gr - ck; // row inside V_k: unit lower trapezoid
-					va = rr < ii ? 0.f : (rr == ii ? 1.f : a.A[(long) (ck + ii) * a.ld + gr]);
+					va = rr < ii ? (T) 0 : (rr == ii ? (T) 1 : a.A[(long) (ck + ii) * a.ld + gr]);
 					if (ii < wl && !(gr - cl > ii)) // strictly below the diagonal of R_l the array holds V_l
 						vb = a.A[(long) (cl + ii) * a.ld + gr];
 				}
@@ -1808,7 +1824,7 @@ __global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
 			}
 		}
 	};
-	auto stage = [&](const TqTxUnit &u, const double (&rb)[16], const float (&fa)[16], const float (&fb)[16]) {
+	auto stage = [&](const TqTxUnit &u, const double (&rb)[16], const T (&fa)[16], const T (&fb)[16]) {
 #pragma unroll
 		for (int q = 0; q < 16; ++q) {
 			const int e = tid + 256 * q, i = e >> 6, j = e & 63;
@@ -1833,7 +1849,7 @@ __global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
 	for (int jb = 0; jb < 4; ++jb)
 		vr[jb] = f64x4{0.0, 0.0, 0.0, 0.0};
 	double rb[16];
-	float fa[16], fb[16];
+	T fa[16], fb[16];
 	// Two stages: everything up to the last 64-row chunk of V_k^T R for the LAST panel L of the block needs nothing of panel
 	// L's kernel (its R block and M) and runs on a second stream beside it; B_L and the partial V^T R travel through a.B.
 	const int L = lend - 1, cL = L * TQ_PW;
@@ -1917,7 +1933,7 @@ __global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
 					Tm[i * TQ_DP + j] = acc[jb][r]; // read as the A operand of the type-3 products (behind their barriers)
 					if (j < wl) {
 						const int gi = ck + i, gj = cl + j;
-						a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) acc[jb][r];
+						a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (T) acc[jb][r];
 					}
 				}
 		} else {
@@ -1934,7 +1950,7 @@ __global__ __launch_bounds__(256) void tq_tx_kernel(const TqTxArgs a)
 }
 
 // General form (any number of later panels in the block of Q_coeff): B in global memory, operands staged per product.
-__global__ __launch_bounds__(256) void tq_tx_general_kernel(const TqTxArgs a)
+template <typename T> __global__ __launch_bounds__(256) void tq_tx_general_kernel(const TqTxArgs<T> a)
 {
 	__shared__ double Am[64 * TQ_DP], Bm[64 * TQ_DP], Tm[64 * TQ_DP];
 	if (a.stat[0])
@@ -2025,7 +2041,7 @@ __global__ __launch_bounds__(256) void tq_tx_general_kernel(const TqTxArgs a)
 				Tm[i * TQ_DP + j] = acc[jb][r];
 				if (j < wl) {
 					const int gi = ck + i, gj = cl + j;
-					a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (float) acc[jb][r];
+					a.H[(long) (gi % a.bs) * a.hrs + (long) gj * a.hcs] = (T) acc[jb][r];
 				}
 			}
 		// ---- B[:, later panels] -= T_kl Z_l[:, later panels]
@@ -2048,6 +2064,287 @@ __global__ __launch_bounds__(256) void tq_tx_general_kernel(const TqTxArgs a)
 				}
 		}
 		__syncthreads(); // Bk written by this workgroup is read by it in the next round (workgroup-scope visibility)
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp64 data (round 6): the same factorization with Gram products and updates on the fp64 matrix cores.  Two streaming kernels of
+// their own -- an fp64 chunk is twice the bytes, v_mfma_f64_16x16x4 has another operand shape -- everything else (reduce, panel, y,
+// T blocks) is the code above instantiated for double.  Schedule: the plain one (Gram, panel, y, update per panel on one stream).
+// ------------------------------------------------------------------------------------------------
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int TQ_LP64 = 18; // LDS pitch (doubles) of one staged column of a 16-row chunk: 16-byte aligned; 16 lanes x 16 bytes hit 64 distinct banks
+
+struct TqGram64Args {
+	const double *P; // A[r0, c0]
+	const double *X; // A[r0, cx]
+	long ld;
+	int rows, w, t, tp; // rows from r0 down, panel width, trailing columns of this launch, t rounded up to 16
+	int nchunks;	    // 16-row chunks
+	int want_g, want_sq;
+	double *Gp; // [grid][64 * 64]
+	double *Cp; // [grid][64 * tp]
+	double *Sp; // [grid][256]
+	const int *stat;
+	int c0;
+	double *A1s; // want_g: the panel's top 64 x 64 block, column major
+};
+
+template <bool VEC> static __device__ __forceinline__ f64x2 tq_ld2(const double *p, int r, int rows)
+{
+	f64x2 v = {0.0, 0.0};
+	if (VEC && r + 1 < rows) {
+		v = *reinterpret_cast<const f64x2 *>(p + r);
+	} else {
+		if (r < rows)
+			v[0] = p[r];
+		if (r + 1 < rows)
+			v[1] = p[r + 1];
+	}
+	return v;
+}
+template <bool VEC> static __device__ __forceinline__ void tq_st2(double *p, int r, int rows, f64x2 v)
+{
+	if (VEC && r + 1 < rows) {
+		*reinterpret_cast<f64x2 *>(p + r) = v;
+	} else {
+		if (r < rows)
+			p[r] = v[0];
+		if (r + 1 < rows)
+			p[r + 1] = v[1];
+	}
+}
+
+// G = P^T P (lower 16 x 16 tiles) and C = P^T X, per-workgroup partial sums.  16-row chunks of [P | X] (<= 256 columns, 32 KB)
+// go through LDS; thread (q = tid & 7, cg = tid >> 3) stages rows 2q, 2q + 1 of the columns cg + 32 i: eight lanes cover the 128
+// bytes a column contributes to a chunk.  Wavefront wv owns the panel columns 16 wv .. + 15 (rows of G and C): its A operand is
+// read once per chunk, the B operand once per 16 x 16 tile; lane (i = l & 15, g = l >> 4) takes rows 4 g .. 4 g + 3 of its
+// column as the four k-slices -- the order of the rows inside a Gram sum is free.
+// Balance at t = 192: 58 tiles x 4 MFMAs x 64 cycles per 32 KB chunk and four SIMDs = 4.8 TB/s chip-wide at the fp64 matrix-core
+// peak: the kernel is bound by both at once.
+template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram64_kernel(const TqGram64Args a)
+{
+	__shared__ double sm[256 * TQ_LP64];
+	if (tq_skip(a.stat, a.c0))
+		return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int q = tid & 7, cg = tid >> 3;
+	const int ncol = TQ_PW + a.tp;
+	const int ntile = a.tp >> 4;
+	f64x4 gacc[4], cacc[12];
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+		gacc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int i = 0; i < 12; ++i)
+		cacc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+	double sq[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		sq[i] = 0.0;
+	f64x2 st[8];
+	auto load_chunk = [&](int ch) {
+		const int rbase = ch * 16 + 2 * q;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			f64x2 v = {0.0, 0.0};
+			const int c = i * 32 + cg;
+			if (i * 32 < ncol) {
+				const bool isp = c < TQ_PW;
+				const int cc = isp ? c : c - TQ_PW;
+				const bool colok = isp ? cc < a.w : cc < a.t;
+				if (colok)
+					v = tq_ld2<VEC>((isp ? a.P : a.X) + (long) cc * a.ld, rbase, a.rows);
+			}
+			st[i] = v;
+		}
+	};
+	int ch = blockIdx.x;
+	if (ch < a.nchunks)
+		load_chunk(ch);
+	for (; ch < a.nchunks; ch += gridDim.x) {
+		__syncthreads(); // the previous chunk has been consumed
+		if (ch < 4 && a.want_g) {
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+				*reinterpret_cast<f64x2 *>(a.A1s + (i * 32 + cg) * 64 + ch * 16 + 2 * q) = st[i];
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+			if (i * 32 < ncol) {
+				*reinterpret_cast<f64x2 *>(&sm[(i * 32 + cg) * TQ_LP64 + 2 * q]) = st[i];
+				if (a.want_sq)
+					sq[i] += st[i][0] * st[i][0] + st[i][1] * st[i][1];
+			}
+		__syncthreads();
+		if (ch + (int) gridDim.x < a.nchunks)
+			load_chunk(ch + gridDim.x); // in flight during the products
+		const int ro = 4 * (lane >> 4);
+		const double *ap = &sm[(16 * wv + (lane & 15)) * TQ_LP64 + ro];
+		const f64x2 a01 = *reinterpret_cast<const f64x2 *>(ap), a23 = *reinterpret_cast<const f64x2 *>(ap + 2);
+		if (a.want_g) {
+#pragma unroll
+			for (int jb = 0; jb < 4; ++jb)
+				if (jb <= wv) { // wave uniform
+					const double *bp = &sm[(16 * jb + (lane & 15)) * TQ_LP64 + ro];
+					const f64x2 b01 = *reinterpret_cast<const f64x2 *>(bp), b23 = *reinterpret_cast<const f64x2 *>(bp + 2);
+					gacc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b01[0], gacc[jb], 0, 0, 0);
+					gacc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b01[1], gacc[jb], 0, 0, 0);
+					gacc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b23[0], gacc[jb], 0, 0, 0);
+					gacc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b23[1], gacc[jb], 0, 0, 0);
+				}
+		}
+#pragma unroll
+		for (int cb = 0; cb < 12; ++cb)
+			if (cb < ntile) {
+				const double *bp = &sm[(TQ_PW + 16 * cb + (lane & 15)) * TQ_LP64 + ro];
+				const f64x2 b01 = *reinterpret_cast<const f64x2 *>(bp), b23 = *reinterpret_cast<const f64x2 *>(bp + 2);
+				cacc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b01[0], cacc[cb], 0, 0, 0);
+				cacc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b01[1], cacc[cb], 0, 0, 0);
+				cacc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b23[0], cacc[cb], 0, 0, 0);
+				cacc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b23[1], cacc[cb], 0, 0, 0);
+			}
+	}
+	// f64 16x16x4 result map: col = lane & 15, row = (lane >> 4) + 4 * reg
+	const long blk = blockIdx.x;
+	if (a.want_g) {
+#pragma unroll
+		for (int jb = 0; jb < 4; ++jb)
+			if (jb <= wv) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					a.Gp[blk * 4096 + (16 * wv + (lane >> 4) + 4 * r) * 64 + 16 * jb + (lane & 15)] = gacc[jb][r];
+			}
+	}
+#pragma unroll
+	for (int cb = 0; cb < 12; ++cb)
+		if (cb < ntile) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				a.Cp[blk * 64 * a.tp + (long) (16 * wv + (lane >> 4) + 4 * r) * a.tp + 16 * cb + (lane & 15)] = cacc[cb][r];
+		}
+	if (a.want_sq) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			double v = sq[i];
+			v += __shfl_xor(v, 1);
+			v += __shfl_xor(v, 2);
+			v += __shfl_xor(v, 4);
+			if (q == 0)
+				a.Sp[blk * 256 + i * 32 + cg] = v;
+		}
+	}
+}
+
+// update: X <- X - P Y on a strip of <= 192 trailing columns and, if do_v, V = P M over the panel (at most 12 column tiles of 16
+// together).  The result tile is the TRANSPOSE of the strip's tile: D[i][j] = X[row j][column i] (lanes along the rows), so the A
+// operand is (-Y)^T / M^T -- kept in registers for the whole launch, tile wv + 4 u belongs to wavefront wv -- and the B operand the
+// panel rows, staged per 32-row chunk through LDS (16 KB).  A lane owns the row PAIR 2 j, 2 j + 1 of a chunk: 16-byte loads and
+// stores, two tiles per column tile.  Two workgroups per CU: one's memory phase behind the other's products.
+// Balance: 2 x 64 x 16 x 32 flop per 8 KB read + written: at the fp64 matrix-core peak the strip would stream at 11 TB/s -- the
+// kernel is HBM bound.
+struct TqUpd64Args {
+	double *P; // A[r1, c0], r1 = first row below the top block
+	double *X; // A[r1, cx + coff]
+	long ld;
+	int rows, w, ts; // rows from r1 down; strip width
+	const double *Yn; // -Y, row major 64 x typ
+	int typ, coff;
+	const double *Mn; // M, row major 64 x 64
+	int do_v;
+	int nchunks; // 32-row chunks
+	const int *stat;
+	int c0;
+};
+constexpr int TQ_LPP = 34; // LDS pitch (doubles) of a staged panel column of a 32-row chunk
+
+template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_update64_kernel(const TqUpd64Args a)
+{
+	__shared__ double Pl[64 * TQ_LPP];
+	if (tq_skip(a.stat, a.c0))
+		return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int li = lane & 15, g = lane >> 4;
+	const int nx = (a.ts + 15) >> 4;
+	const int nt = nx + (a.do_v ? 4 : 0);
+	// A operands: ya[u][ks] = A[i = li][k = 4 ks + g] of tile wv + 4 u
+	double ya[3][16];
+#pragma unroll
+	for (int u = 0; u < 3; ++u) {
+		const int tl = wv + 4 * u;
+		const bool isx = tl < nx, isv = !isx && tl < nt;
+		const int col = isx ? 16 * tl + li : 16 * (tl - nx) + li;
+		const bool ok = isx ? col < a.ts : (isv && col < a.w);
+		const double *src = isx ? a.Yn + a.coff + col : a.Mn + col;
+		const long step = isx ? (long) a.typ : 64L;
+#pragma unroll
+		for (int ks = 0; ks < 16; ++ks)
+			ya[u][ks] = ok && (4 * ks + g) < a.w ? src[(long) (4 * ks + g) * step] : 0.0;
+	}
+	const int pq = tid & 15, pc = tid >> 4; // staging: rows 2 pq, 2 pq + 1 of the panel columns pc + 16 i
+	f64x2 pst[4];
+	auto load_panel = [&](int ch) {
+		const int rbase = ch * 32 + 2 * pq;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int c = pc + 16 * i;
+			pst[i] = f64x2{0.0, 0.0};
+			if (c < a.w)
+				pst[i] = tq_ld2<VEC>(a.P + (long) c * a.ld, rbase, a.rows);
+		}
+	};
+	int ch = blockIdx.x;
+	if (ch < a.nchunks)
+		load_panel(ch);
+	for (; ch < a.nchunks; ch += gridDim.x) {
+		const int rbase = ch * 32 + 2 * li;
+		// the strip's tiles of this wavefront: all loads of the chunk in flight before the first product
+		f64x2 xv[3][4];
+#pragma unroll
+		for (int u = 0; u < 3; ++u) {
+			const int tl = wv + 4 * u;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				xv[u][r] = f64x2{0.0, 0.0};
+				const int col = 16 * tl + g + 4 * r;
+				if (tl < nx && col < a.ts)
+					xv[u][r] = tq_ld2<VEC>(a.X + (long) col * a.ld, rbase, a.rows);
+			}
+		}
+		__syncthreads(); // the previous chunk's panel rows have been consumed
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			*reinterpret_cast<f64x2 *>(&Pl[(pc + 16 * i) * TQ_LPP + 2 * pq]) = pst[i];
+		__syncthreads();
+		if (ch + (int) gridDim.x < a.nchunks)
+			load_panel(ch + gridDim.x);
+#pragma unroll
+		for (int u = 0; u < 3; ++u) {
+			const int tl = wv + 4 * u;
+			if (tl < nt) { // wave uniform
+				const bool isx = tl < nx;
+				f64x4 acc0, acc1;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					acc0[r] = xv[u][r][0];
+					acc1[r] = xv[u][r][1];
+				}
+#pragma unroll
+				for (int ks = 0; ks < 16; ++ks) {
+					const f64x2 b = *reinterpret_cast<const f64x2 *>(&Pl[(4 * ks + g) * TQ_LPP + 2 * li]);
+					acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][ks], b[0], acc0, 0, 0, 0);
+					acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][ks], b[1], acc1, 0, 0, 0);
+				}
+				double *dst = isx ? a.X + (long) (16 * tl) * a.ld : a.P + (long) (16 * (tl - nx)) * a.ld;
+				const int nvalid = isx ? a.ts - 16 * tl : a.w - 16 * (tl - nx);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const int cl = g + 4 * r;
+					if (cl < nvalid)
+						tq_st2<VEC>(dst + (long) cl * a.ld, rbase, a.rows, f64x2{acc0[r], acc1[r]});
+				}
+			}
+		}
 	}
 }
 
@@ -2098,7 +2395,7 @@ static void tq_gram(const float *P, const float *X, long ld, int rows, int w, in
 			hipLaunchKernelGGL(tq_gram_kernel<false>, dim3(nb), dim3(256), 0, s, g);
 	}
 	const int total = (want_g ? 4096 : 0) + 64 * g.tp + (want_sq ? 256 : 0);
-	hipLaunchKernelGGL(tq_reduce_kernel, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, Gp, Cp, Sp, nb, g.tp, (int) want_g, (int) want_sq, G, C,
+	hipLaunchKernelGGL(tq_reduce_kernel<float>, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, Gp, Cp, Sp, nb, g.tp, (int) want_g, (int) want_sq, G, C,
 			   ldc, coff, S, stat, c0, Gf, cnt);
 	FH_HIP(hipGetLastError());
 }
@@ -2142,10 +2439,10 @@ static TqSide tq_side()
 // columns come out of those launches, tq_panel_kernel / tq_y_kernel check them): one workgroup per column, BEFORE anything is
 // written -- a column whose rms is outside [1e-12, 1e12] would be updated by the first steps with flushed or overflowed fp32
 // products, and a later rejection could not undo that.  One more read of those columns (n <= 512).
-__global__ __launch_bounds__(256) void tq_range_rest_kernel(const float *A, long ld, int m, int c_first, int *stat)
+template <typename T> __global__ __launch_bounds__(256) void tq_range_rest_kernel(const T *A, long ld, int m, int c_first, int *stat)
 {
 	__shared__ double red[256];
-	const float *col = A + (long) (c_first + (int) blockIdx.x) * ld;
+	const T *col = A + (long) (c_first + (int) blockIdx.x) * ld;
 	double sq = 0.0;
 	for (int i = threadIdx.x; i < m; i += 256) {
 		const double v = (double) col[i];
@@ -2159,7 +2456,7 @@ __global__ __launch_bounds__(256) void tq_range_rest_kernel(const float *A, long
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) {
-		const double lo = 1e-24 * (double) m, hi = 1e24 * (double) m;
+		const double lo = TqLim<T>::sq_lo * (double) m, hi = TqLim<T>::sq_hi * (double) m;
 		if (!(red[0] >= lo && red[0] <= hi)) {
 			stat[1] = 0;
 			stat[2] = TQ_FAIL_RANGE;
@@ -2231,7 +2528,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		}
 	};
 	auto tx_args = [&]() {
-		TqTxArgs ta;
+		TqTxArgs<float> ta;
 		ta.A = A.p;
 		ta.ld = ld;
 		ta.n = (int) n;
@@ -2252,7 +2549,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		const int c0 = k * TQ_PW;
 		const int w = (int) (n - c0 < TQ_PW ? n - c0 : TQ_PW);
 		const int t = (int) n - c0 - w;
-		TqPanelArgs pa;
+		TqPanelArgs<float> pa;
 		pa.A = A.p;
 		pa.ld = ld;
 		pa.m = (int) m;
@@ -2281,7 +2578,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		pa.dbg = reinterpret_cast<long long *>(stat + 16);
 		StreamScope psc(ps);
 		ProfScope prof(4, 1.0);
-		hipLaunchKernelGGL(tq_panel_kernel, dim3(1), dim3(TQ_PT), 0, ps, pa);
+		hipLaunchKernelGGL(tq_panel_kernel<float>, dim3(1), dim3(TQ_PT), 0, ps, pa);
 	};
 	// one block of Q_coeff over all panels (the tall-skinny case): the cross-panel blocks of T in two stages beside the last steps
 	const bool fused = g_tq_fused.load() != 0;
@@ -2317,7 +2614,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		launch_panel(p, s);
 	};
 	if (n > TQ_PW + TQ_TS) {
-		hipLaunchKernelGGL(tq_range_rest_kernel, dim3((unsigned) (n - (TQ_PW + TQ_TS))), dim3(256), 0, s, A.p, (long) ld, (int) m, TQ_PW + TQ_TS, stat);
+		hipLaunchKernelGGL(tq_range_rest_kernel<float>, dim3((unsigned) (n - (TQ_PW + TQ_TS))), dim3(256), 0, s, A.p, (long) ld, (int) m, TQ_PW + TQ_TS, stat);
 		FH_HIP(hipGetLastError());
 	}
 	double *Sy = S; // the column squares the first y kernel checks
@@ -2351,7 +2648,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			cus_taken -= 1;
 		}
 		if (t > 0) {
-			TqYArgs ya;
+			TqYArgs<float> ya;
 			ya.A = A.p;
 			ya.ld = ld;
 			ya.r0 = c0;
@@ -2374,17 +2671,17 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			ya.check_range = k == 0;
 			ya.range_cols = t < TQ_TS ? t : TQ_TS;
 			ya.mrows = (int) m;
-			hipLaunchKernelGGL(tq_y_kernel, dim3((t + 15) / 16), dim3(256), 0, s, ya);
+			hipLaunchKernelGGL(tq_y_kernel<float>, dim3((t + 15) / 16), dim3(256), 0, s, ya);
 		} else {
-			hipLaunchKernelGGL(tq_top_kernel, dim3(1), dim3(256), 0, s, A.p, ld, c0, c0, w, top, stat);
+			hipLaunchKernelGGL(tq_top_kernel<float>, dim3(1), dim3(256), 0, s, A.p, ld, c0, c0, w, top, stat);
 		}
 		if (two_stage && k == npan - 1 && tx_on_side) {
 			// stage 2 needs this panel's kernel and the V rows the last update wrote: beside the update below
-			TqTxArgs t2 = tx_args();
+			TqTxArgs<float> t2 = tx_args();
 			t2.stage = 2;
 			FH_HIP(hipEventRecord(side.xfork, s));
 			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
-			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.tx, t2);
+			hipLaunchKernelGGL(tq_tx_kernel<float>, dim3(npan - 1), dim3(256), 0, side.tx, t2);
 		}
 		const int r1 = c0 + w;
 		const int rows = (int) (m - r1);
@@ -2434,11 +2731,11 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		auto tx_stage1 = [&]() {
 			if (!(two_stage && k == npan - 2))
 				return;
-			TqTxArgs t1 = tx_args();
+			TqTxArgs<float> t1 = tx_args();
 			t1.stage = 1;
 			FH_HIP(hipEventRecord(side.xfork, s));
 			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
-			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, side.tx, t1);
+			hipLaunchKernelGGL(tq_tx_kernel<float>, dim3(npan - 1), dim3(256), 0, side.tx, t1);
 			tx_on_side = true;
 			if (ncu_all > 8 * npan)
 				cus_taken += npan - 1;
@@ -2484,7 +2781,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 			// U1: the next panel's columns, its Gram matrix, V = P M
 			int nb = grid();
 			tq_launch_fused(v2, 1, nb, fa);
-			hipLaunchKernelGGL(tq_reduce_kernel, dim3(4096 / 256, TQ_NG), dim3(256), 0, s, fa.Gp, fa.Cp, sp.as<float>(), nb, 0, 1, 0, G, C, ldc, 0, S, stat, nc0, Gf,
+			hipLaunchKernelGGL(tq_reduce_kernel<float>, dim3(4096 / 256, TQ_NG), dim3(256), 0, s, fa.Gp, fa.Cp, sp.as<float>(), nb, 0, 1, 0, G, C, ldc, 0, S, stat, nc0, Gf,
 					   stat + 128);
 			if (t - wn > 0) {
 				// U2 (side stream): the columns behind it and C'; the next panel's kernel runs on the main stream meanwhile
@@ -2507,7 +2804,7 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 						fa.F = A.p + (long) (nc0 + wn + fo) * ld + r1;
 						nb = grid();
 						tq_launch_fused(v2, 2, nb, fa);
-						hipLaunchKernelGGL(tq_reduce_kernel, dim3((64 * fa.tp + 255) / 256, TQ_NG), dim3(256), 0, side.panel, fa.Gp, fa.Cp, sp.as<float>(), nb,
+						hipLaunchKernelGGL(tq_reduce_kernel<float>, dim3((64 * fa.tp + 255) / 256, TQ_NG), dim3(256), 0, side.panel, fa.Gp, fa.Cp, sp.as<float>(), nb,
 								   fa.tp, 0, 0, G, C, ldc, fo, S, stat, nc0, Gf, stat + 128);
 					}
 					FH_HIP(hipEventRecord(side.pdone, side.panel));
@@ -2544,14 +2841,14 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		FH_HIP(hipGetLastError());
 	}
 	if (cross) {
-		TqTxArgs ta = tx_args();
+		TqTxArgs<float> ta = tx_args();
 		if (tx_on_side) {
 			FH_HIP(hipEventRecord(side.xdone, side.tx));
 			FH_HIP(hipStreamWaitEvent(s, side.xdone, 0));
 		} else if (bs <= (TQ_TX_MAXL + 1) * TQ_PW) {
-			hipLaunchKernelGGL(tq_tx_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
+			hipLaunchKernelGGL(tq_tx_kernel<float>, dim3(npan - 1), dim3(256), 0, s, ta);
 		} else {
-			hipLaunchKernelGGL(tq_tx_general_kernel, dim3(npan - 1), dim3(256), 0, s, ta);
+			hipLaunchKernelGGL(tq_tx_general_kernel<float>, dim3(npan - 1), dim3(256), 0, s, ta);
 		}
 		FH_HIP(hipGetLastError());
 	}
@@ -2580,6 +2877,223 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 		fprintf(stderr, "tq_panel residuals of the last panel: |V1 V1^-1 - I| %.3e  |U U^-1 - I| %.3e  |R~ R~^-1 - I| %.3e\n", res[0], res[1], res[2]);
 	}
 #endif
+	*reason = st[0] ? st[2] : TQ_OK;
+	return st[0] ? (idx_t) st[1] : n;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// fp64 driver: the contract of tsqr_factor for double data (columns completed, state of the reference algorithm at that column)
+// ------------------------------------------------------------------------------------------------
+static std::atomic<int> g_tq_f64{1};
+void tsqr_debug_f64(int on) { g_tq_f64.store(on); }
+
+bool tsqr_applicable64(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs, const void *p)
+{
+	if (g_tq_f64.load() == 0)
+		return false;
+	if (rs != 1 || cs < m || n < 1 || n > 512 || m < 16384 || m < 8 * n || m >= (1L << 30))
+		return false;
+	if (cs % 2 != 0 || (uintptr_t) p % 16 != 0) // 16-byte accesses down the columns (faer's Mat pads the column stride to 64 bytes)
+		return false;
+	return bs % TQ_PW == 0 || TQ_PW % bs == 0;
+}
+
+idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason)
+{
+	const idx_t m = A.nrows, n = A.ncols, ld = A.cs, bs = H.nrows;
+	hipStream_t s = ctx().stream;
+	const int npan = (int) ((n + TQ_PW - 1) / TQ_PW);
+	const int ldc = ((int) n + 63) & ~63;
+	const int typ = ldc, ldz = ldc;
+	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * 8), sp((size_t) TQ_NB * 256 * 8);
+	// workspace (all fp64): G (NG x 4096), N1, N3, Gf (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64), Td, Md (npan x 4096 each),
+	//                       Z, B (npan x 64 x ldz each), Mn (4096), top, A1s (4096 each), Yn (64 x typ); then the status words
+	const size_t nd = (size_t) TQ_NG * 4096 + 3 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
+			  (size_t) 2 * npan * 64 * ldz + 3 * 4096 + (size_t) 64 * typ;
+	Scratch small(nd * 8 + 2048);
+	double *G = small.as<double>();
+	double *N1 = G + (size_t) TQ_NG * 4096, *N3 = N1 + 4096, *Gf = N3 + 4096, *C = Gf + 4096;
+	double *S = C + (size_t) TQ_NG * 64 * ldc, *abv = S + (size_t) TQ_NG * 256;
+	double *Td = abv + n + 64, *Md = Td + (size_t) npan * 4096, *Z = Md + (size_t) npan * 4096, *Bx = Z + (size_t) npan * 64 * ldz;
+	double *Mn = Bx + (size_t) npan * 64 * ldz, *top = Mn + 4096, *A1s = top + 4096, *Yn = A1s + 4096;
+	int *stat = reinterpret_cast<int *>(Yn + (size_t) 64 * typ);
+	FH_HIP(hipMemsetAsync(stat, 0, 2048, s));
+	FH_HIP(hipMemsetAsync(abv, 0, (size_t) (n + 64) * 8, s));
+	const bool cross = bs > TQ_PW && npan > 1;
+	if (cross)
+		FH_HIP(hipMemsetAsync(Z, 0, (size_t) npan * 64 * ldz * 8, s));
+	const int ncu = ctx().stream_cus();
+	// Gram launches of panel [c0, c0 + w), rows from c0 down, against the columns [cx, cx + t) in strips of <= 192
+	auto launch_gram = [&](int c0, int w, int cx, int t, bool first) {
+		const int rows = (int) (m - c0);
+		const int nstrip = t == 0 ? 1 : (t + TQ_TS - 1) / TQ_TS;
+		for (int st = 0; st < nstrip; ++st) {
+			const int off = st * TQ_TS;
+			TqGram64Args g;
+			g.P = A.p + (long) c0 * ld + c0;
+			g.X = A.p + (long) (cx + off) * ld + c0;
+			g.ld = ld;
+			g.rows = rows;
+			g.w = w;
+			g.t = t - off < TQ_TS ? t - off : TQ_TS;
+			g.tp = (g.t + 15) & ~15;
+			g.nchunks = (rows + 15) / 16;
+			g.want_g = st == 0;
+			g.want_sq = first && st == 0; // (the range guard covers the first strip; tq_range_rest_kernel checks the others)
+			g.Gp = gp.as<double>();
+			g.Cp = cp.as<double>();
+			g.Sp = sp.as<double>();
+			g.stat = stat;
+			g.c0 = c0;
+			g.A1s = A1s;
+			const int nb = g.nchunks < TQ_NB ? g.nchunks : TQ_NB;
+			{
+				ProfScope prof(3, (double) rows * 8.0 * ((double) w + (double) g.t));
+				hipLaunchKernelGGL(tq_gram64_kernel<true>, dim3(nb), dim3(256), 0, s, g);
+			}
+			const int total = (g.want_g ? 4096 : 0) + 64 * g.tp + (g.want_sq ? 256 : 0);
+			hipLaunchKernelGGL(tq_reduce_kernel<double>, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, g.Gp, g.Cp, g.Sp, nb, g.tp, g.want_g, g.want_sq, G, C, ldc,
+					   cx + off - (c0 + w), S, stat, c0, Gf, stat + 128);
+			FH_HIP(hipGetLastError());
+		}
+	};
+	auto launch_panel = [&](int k) {
+		const int c0 = k * TQ_PW;
+		const int w = (int) (n - c0 < TQ_PW ? n - c0 : TQ_PW);
+		const int t = (int) n - c0 - w;
+		TqPanelArgs<double> pa;
+		pa.A = A.p;
+		pa.ld = ld;
+		pa.m = (int) m;
+		pa.r0 = c0;
+		pa.c0 = c0;
+		pa.w = w;
+		pa.n = (int) n;
+		pa.G = Gf;
+		pa.S = S;
+		pa.check_range = k == 0;
+		pa.range_cols = t < TQ_TS ? t : TQ_TS;
+		pa.abv = abv;
+		pa.N1 = N1;
+		pa.N3 = N3;
+		pa.Mn = Mn;
+		pa.top = top;
+		pa.A1s = A1s;
+		pa.Md = Md + (size_t) k * 4096;
+		pa.Td = Td + (size_t) k * 4096;
+		pa.H = H.p;
+		pa.hrs = H.rs;
+		pa.hcs = H.cs;
+		pa.bs = (int) bs;
+		pa.taus = taus;
+		pa.stat = stat;
+		pa.dbg = reinterpret_cast<long long *>(stat + 16);
+		ProfScope prof(4, 1.0);
+		hipLaunchKernelGGL(tq_panel_kernel<double>, dim3(1), dim3(TQ_PT), 0, s, pa);
+	};
+	if (n > TQ_PW + TQ_TS) {
+		hipLaunchKernelGGL(tq_range_rest_kernel<double>, dim3((unsigned) (n - (TQ_PW + TQ_TS))), dim3(256), 0, s, A.p, (long) ld, (int) m, TQ_PW + TQ_TS, stat);
+		FH_HIP(hipGetLastError());
+	}
+	for (int k = 0; k < npan; ++k) {
+		const int c0 = k * TQ_PW;
+		const int w = (int) (n - c0 < TQ_PW ? n - c0 : TQ_PW);
+		const int t = (int) n - c0 - w;
+		launch_gram(c0, w, c0 + w, t, k == 0);
+		launch_panel(k);
+		if (t > 0) {
+			TqYArgs<double> ya;
+			ya.A = A.p;
+			ya.ld = ld;
+			ya.r0 = c0;
+			ya.cx = c0 + w;
+			ya.w = w;
+			ya.t = t;
+			ya.C = C;
+			ya.ldc = ldc;
+			ya.N1 = N1;
+			ya.N3 = N3;
+			ya.Md = Md + (size_t) k * 4096;
+			ya.abv = abv;
+			ya.Yn = Yn;
+			ya.typ = typ;
+			ya.Z = Z + (size_t) k * 64 * ldz;
+			ya.ldz = ldz;
+			ya.top = top;
+			ya.stat = stat;
+			ya.Sr = S;
+			ya.check_range = k == 0;
+			ya.range_cols = t < TQ_TS ? t : TQ_TS;
+			ya.mrows = (int) m;
+			hipLaunchKernelGGL(tq_y_kernel<double>, dim3((t + 15) / 16), dim3(256), 0, s, ya);
+		} else {
+			hipLaunchKernelGGL(tq_top_kernel<double>, dim3(1), dim3(256), 0, s, A.p, (long) ld, c0, c0, w, (const double *) top, (const int *) stat);
+		}
+		const int r1 = c0 + w;
+		const int rows = (int) (m - r1);
+		if (rows > 0) {
+			TqUpd64Args ua;
+			ua.P = A.p + (long) c0 * ld + r1;
+			ua.ld = ld;
+			ua.rows = rows;
+			ua.w = w;
+			ua.Yn = Yn;
+			ua.typ = typ;
+			ua.Mn = Md + (size_t) k * 4096;
+			ua.nchunks = (rows + 31) / 32;
+			ua.stat = stat;
+			ua.c0 = c0;
+			const bool v2 = r1 % 2 == 0;
+			const int nwg = ua.nchunks < 2 * ncu ? ua.nchunks : 2 * ncu;
+			// strips of at most 12 column tiles; V = P M (4 tiles, it overwrites the panel) rides on the last one
+			int from = 0;
+			do {
+				int ts = t - from;
+				const bool last = ts <= 128;
+				if (!last)
+					ts = ts - 128 > 192 ? 192 : ts - 128 >= 64 ? ts - 128 : 64;
+				ua.coff = from;
+				ua.ts = ts;
+				ua.X = A.p + (long) (c0 + w + from) * ld + r1;
+				ua.do_v = last;
+				ProfScope prof(2, (double) rows * 8.0 * ((double) w + 2.0 * (double) ts + (last ? (double) w : 0.0)));
+				if (v2)
+					hipLaunchKernelGGL(tq_update64_kernel<true>, dim3(nwg), dim3(256), 0, s, ua);
+				else
+					hipLaunchKernelGGL(tq_update64_kernel<false>, dim3(nwg), dim3(256), 0, s, ua);
+				from += ts;
+				if (last)
+					break;
+			} while (true);
+		}
+		FH_HIP(hipGetLastError());
+	}
+	if (cross) {
+		TqTxArgs<double> ta;
+		ta.A = A.p;
+		ta.ld = ld;
+		ta.n = (int) n;
+		ta.bs = (int) bs;
+		ta.Td = Td;
+		ta.Md = Md;
+		ta.Z = Z;
+		ta.ldz = ldz;
+		ta.B = Bx;
+		ta.H = H.p;
+		ta.hrs = H.rs;
+		ta.hcs = H.cs;
+		ta.stat = stat;
+		ta.stage = 0;
+		if (bs <= (TQ_TX_MAXL + 1) * TQ_PW)
+			hipLaunchKernelGGL(tq_tx_kernel<double>, dim3(npan - 1), dim3(256), 0, s, ta);
+		else
+			hipLaunchKernelGGL(tq_tx_general_kernel<double>, dim3(npan - 1), dim3(256), 0, s, ta);
+		FH_HIP(hipGetLastError());
+	}
+	int *st = ctx().pinned_ints();
+	FH_HIP(hipMemcpyAsync(st, stat, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+	FH_HIP(hipStreamSynchronize(s));
 	*reason = st[0] ? st[2] : TQ_OK;
 	return st[0] ? (idx_t) st[1] : n;
 }

@@ -498,6 +498,9 @@ FAER_HIP_API long faer_hip_debug_qr_one_pass_columns(void);
  * round 3-5 schedule), 1 (default) = in one pass per panel with the next panel's kernel beside its second half (csrc/tsqr.hip), 2 = the
  * same without the raw copy of the panel (what matrices of more than 4.19 M rows run: V = P M as a launch of its own behind U2). */
 FAER_HIP_API void faer_hip_debug_qr_fused(int on);
+/* tests / A-B measurements: 0 = fp64 matrices never take the one-pass tall-skinny QR path (the classic path of rounds 1-6 runs), 1 (default) =
+ * they take it under the same shape rule as fp32 (rows >= 16384, rows >= 8 cols, cols <= 512, unit row stride, even column stride). */
+FAER_HIP_API void faer_hip_debug_qr_one_pass_f64(int on);
 /* Full-pivot LU: 1 = the in-place path (two launches per step) instead of the one-launch-per-step path between two scratch copies
  * (default 0; identical factors and permutations, tests/test_gpu_factor.py). */
 FAER_HIP_API void faer_hip_debug_fplu_inplace(int on);
