@@ -50,8 +50,8 @@ constexpr double TQ_TAIL_MIN = 1e-9;	     // 1 - |head| / |column| below this: t
 // Per scalar type: the reference's epsilon (rank test), the condition bound of a panel and the range of column scales.
 // fp32 data: the Gram sums are EXACT products accumulated in fp64, so R~ is good to cond^2 2^-53 -- far below fp32 rounding.
 // fp64 data: the Gram sums carry fp64 rounding themselves, R~ and everything derived from it is good to ~cond^2 eps64: the
-// one-pass path keeps panels whose equilibrated condition number is a small constant (cond_2 below ~4: Gaussian and other
-// well-conditioned tall panels) and hands everything else to the classic path.
+// one-pass path keeps panels whose equilibrated condition number is a small constant (|R D|_F |(R D)^-1|_F <= 128: cond_2 below
+// ~8 for a graded spectrum; Gaussian and other well-conditioned tall panels) and hands everything else to the classic path.
 template <typename T> struct TqLim;
 template <> struct TqLim<float> {
 	static constexpr double eps = 1.1920928955078125e-07;
@@ -60,7 +60,7 @@ template <> struct TqLim<float> {
 };
 template <> struct TqLim<double> {
 	static constexpr double eps = 2.220446049250313e-16;
-	static constexpr double cond_max = 64.0 * 4.0;
+	static constexpr double cond_max = 64.0 * 2.0;
 	static constexpr double sq_lo = 1e-200, sq_hi = 1e200;
 };
 enum { TQ_OK = 0, TQ_FAIL_CHOL = 1, TQ_FAIL_TAIL = 2, TQ_FAIL_RANK = 3, TQ_FAIL_COND = 4, TQ_FAIL_RANGE = 5 };
@@ -68,6 +68,7 @@ enum { TQ_OK = 0, TQ_FAIL_CHOL = 1, TQ_FAIL_TAIL = 2, TQ_FAIL_RANK = 3, TQ_FAIL_
 // Status word 0 of a factorization: 0, or 1 + the number of columns completed when a panel was rejected.  The kernels of
 // the steps before the rejected panel still run (some of them beside the panel kernel that rejects), all later ones
 // return at once: `c0` is the first column of the panel a launch belongs to.
+static __device__ __forceinline__ void tq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 static __device__ __forceinline__ bool tq_skip(const int *stat, int c0)
 {
 	const int s = *reinterpret_cast<const volatile int *>(stat);
@@ -1458,7 +1459,6 @@ struct TqFusedArgs {
 
 constexpr int TU_CF = 128;		      // widest strip F
 // Barrier between LDS phases that leaves global memory operations in flight (__syncthreads() is a workgroup-scope fence as well)
-static __device__ __forceinline__ void tq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // MODE 1 (U1): stages [P | N], updates N, forms G', V = P M if asked.  MODE 2 (U2): stages [P | N | F], updates F, forms C' = N^T F'.
 // Two variants instead of one general kernel: each needs fewer than 256 registers and 52 / 70 KB of LDS, so TWO workgroups share a CU --
 // twice the bytes in flight (one general workgroup per CU with one 64 KB chunk in flight ran at 1.2-1.6 TB/s: a chunk per memory round
@@ -2079,8 +2079,8 @@ struct TqGram64Args {
 	const double *P; // A[r0, c0]
 	const double *X; // A[r0, cx]
 	long ld;
-	int rows, w, t, tp; // rows from r0 down, panel width, trailing columns of this launch, t rounded up to 16
-	int nchunks;	    // 16-row chunks
+	int rows, w, t, tp; // rows from r0 down, panel width, trailing columns of this launch, t rounded up to 64 (32 NC)
+	int nsub, nchunks;  // 16-row sub-chunks per chunk (4 / 2 / 1 for <= 64 / <= 128 / more staged columns), chunks
 	int want_g, want_sq;
 	double *Gp; // [grid][64 * 64]
 	double *Cp; // [grid][64 * tp]
@@ -2115,133 +2115,236 @@ template <bool VEC> static __device__ __forceinline__ void tq_st2(double *p, int
 	}
 }
 
-// G = P^T P (lower 16 x 16 tiles) and C = P^T X, per-workgroup partial sums.  16-row chunks of [P | X] (<= 256 columns, 32 KB)
-// go through LDS; thread (q = tid & 7, cg = tid >> 3) stages rows 2q, 2q + 1 of the columns cg + 32 i: eight lanes cover the 128
-// bytes a column contributes to a chunk.  Wavefront wv owns the panel columns 16 wv .. + 15 (rows of G and C): its A operand is
-// read once per chunk, the B operand once per 16 x 16 tile; lane (i = l & 15, g = l >> 4) takes rows 4 g .. 4 g + 3 of its
-// column as the four k-slices -- the order of the rows inside a Gram sum is free.
-// Balance at t = 192: 58 tiles x 4 MFMAs x 64 cycles per 32 KB chunk and four SIMDs = 4.8 TB/s chip-wide at the fp64 matrix-core
+// G = P^T P (lower 16 x 16 tiles) and C = P^T X, per-workgroup partial sums.  One persistent workgroup of 512 threads per CU.
+// A chunk is 32 KB of [P | X]: 16 rows of <= 256 columns, or -- narrow launches -- 32 / 64 rows of <= 128 / 64 columns as 2 / 4
+// sub-chunks side by side (a 16-row chunk of 64 columns is 8 KB: a memory round trip per 8 KB).  Thread (q = tid & 7,
+// cg = tid >> 3) loads rows 2 q, 2 q + 1 of the staged columns cg + 64 i: eight lanes cover the 128 bytes a column contributes to a
+// sub-chunk.  FOUR chunks per workgroup are in flight in registers (64 staging registers) and the LDS image is double buffered:
+// per chunk ONE barrier that leaves the global loads in flight; the first version (two 256-thread workgroups per CU, one chunk
+// ahead each) ran at 2.1-2.4 TB/s.  Wavefront (ia = wv & 3, hf = wv >> 2) owns the panel columns 16 ia .. + 15 (rows of G and C) and
+// every other column tile: its A operand is read once per sub-chunk, the B operand once per tile; lane (i = l & 15, g = l >> 4)
+// takes rows 4 g .. 4 g + 3 of its column as the four k-slices -- the order of the rows inside a Gram sum is free.
+// Balance at t = 192: 58 tiles x 4 MFMAs x 64 cycles per 32 KB chunk and four SIMDs = 4.5-4.8 TB/s chip-wide at the fp64 matrix-core
 // peak: the kernel is bound by both at once.
-template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_gram64_kernel(const TqGram64Args a)
+template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(const TqGram64Args a)
 {
-	__shared__ double sm[256 * TQ_LP64];
+	__shared__ double sm[2][256 * TQ_LP64];
 	if (tq_skip(a.stat, a.c0))
 		return;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int ia = wv & 3, hf = wv >> 2;
 	const int q = tid & 7, cg = tid >> 3;
 	const int ncol = TQ_PW + a.tp;
-	const int ntile = a.tp >> 4;
-	f64x4 gacc[4], cacc[12];
+	const int nslot = (ncol + 63) >> 6;	      // 64-column load slots per sub-chunk: 1 .. 4
+	const int nsub = a.nsub;		      // sub-chunks per chunk: 4 / nslot
+	const int ncolp = nslot * 64;		      // staged columns per sub-chunk
+	f64x4 gacc[2], cacc[NC > 0 ? NC : 1];
 #pragma unroll
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < 2; ++i)
 		gacc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-	for (int i = 0; i < 12; ++i)
+	for (int i = 0; i < (NC > 0 ? NC : 1); ++i)
 		cacc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
-	double sq[8];
+	double sq[4] = {0.0, 0.0, 0.0, 0.0};
+	// slot i of a thread: sub-chunk si, column ci of [P | X]; a slot without a column (a column beyond the launch's, the fourth slot of
+	// a 192-column chunk) loads from column 0 of the panel and stages zeros into a part of the image no product reads
+	int ldsoff[4], roff[4];
+	bool act[4];
+	const double *colp[4];
 #pragma unroll
-	for (int i = 0; i < 8; ++i)
-		sq[i] = 0.0;
-	f64x2 st[8];
-	auto load_chunk = [&](int ch) {
-		const int rbase = ch * 16 + 2 * q;
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {
+	for (int i = 0; i < 4; ++i) {
+		const int si = i / nslot, ci = (i - si * nslot) * 64 + cg;
+		const bool isp = ci < TQ_PW;
+		const int cc = isp ? ci : ci - TQ_PW;
+		act[i] = si < nsub && (isp ? cc < a.w : cc < a.t);
+		colp[i] = act[i] ? (isp ? a.P : a.X) + (long) cc * a.ld : a.P;
+		roff[i] = act[i] ? 16 * si + 2 * q : 2 * q;
+		ldsoff[i] = (si * ncolp + ci) * TQ_LP64 + 2 * q; // (si * ncolp + ci < 256 always)
+	}
+	const int crows = 16 * nsub;
+	// A workgroup owns a contiguous run of FULL chunks; the partial chunk at the end of the matrix (if any) is the last workgroup's
+	// epilogue.  The main loop is straight-line code: unconditional 16-byte loads, counted waits.  (Loads under per-lane branches --
+	// the bounds checks of the first version -- share their destination registers with the scalar loads of the other branch, the
+	// compiler drained the memory counter in front of every one of them and the kernel streamed at 2.3 TB/s whatever it did with
+	// the data: one round trip per load.)
+	const int nfull = a.rows / crows;
+	const int cpw = (nfull + (int) gridDim.x - 1) / (int) gridDim.x;
+	const int first = (int) blockIdx.x * cpw;
+	const int nmine = nfull - first < 0 ? 0 : (nfull - first < cpw ? nfull - first : cpw);
+	if (blockIdx.x == 0 && a.want_g) {
+		// the panel's top block for the panel kernel (64 rows: rows >= 8 n)
+		for (int e = tid; e < 64 * 32; e += 512) {
+			const int c = e >> 5, rp = e & 31;
 			f64x2 v = {0.0, 0.0};
-			const int c = i * 32 + cg;
-			if (i * 32 < ncol) {
-				const bool isp = c < TQ_PW;
-				const int cc = isp ? c : c - TQ_PW;
-				const bool colok = isp ? cc < a.w : cc < a.t;
-				if (colok)
-					v = tq_ld2<VEC>((isp ? a.P : a.X) + (long) cc * a.ld, rbase, a.rows);
-			}
-			st[i] = v;
+			if (c < a.w)
+				v = *reinterpret_cast<const f64x2 *>(a.P + (long) c * a.ld + 2 * rp);
+			*reinterpret_cast<f64x2 *>(a.A1s + c * 64 + 2 * rp) = v;
+		}
+	}
+	f64x2 s0[4], s1[4], s2[4], s3[4];
+	auto load_chunk = [&](int j, f64x2 (&st)[4]) { // chunk min(j, nmine - 1) of this workgroup
+		const int jj = j < nmine ? j : nmine - 1;
+		const long r0 = (long) (first + jj) * crows;
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			st[i] = *reinterpret_cast<const f64x2 *>(colp[i] + r0 + roff[i]);
+	};
+	auto stage = [&](int j, const f64x2 (&st)[4], double count) { // into LDS half j & 1
+		double *dst = sm[j & 1];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const f64x2 v = act[i] ? st[i] : f64x2{0.0, 0.0};
+			*reinterpret_cast<f64x2 *>(&dst[ldsoff[i]]) = v;
+			sq[i] += count * (v[0] * v[0] + v[1] * v[1]);
 		}
 	};
-	int ch = blockIdx.x;
-	if (ch < a.nchunks)
-		load_chunk(ch);
-	for (; ch < a.nchunks; ch += gridDim.x) {
-		__syncthreads(); // the previous chunk has been consumed
-		if (ch < 4 && a.want_g) {
-#pragma unroll
-			for (int i = 0; i < 2; ++i)
-				*reinterpret_cast<f64x2 *>(a.A1s + (i * 32 + cg) * 64 + ch * 16 + 2 * q) = st[i];
-		}
-#pragma unroll
-		for (int i = 0; i < 8; ++i)
-			if (i * 32 < ncol) {
-				*reinterpret_cast<f64x2 *>(&sm[(i * 32 + cg) * TQ_LP64 + 2 * q]) = st[i];
-				if (a.want_sq)
-					sq[i] += st[i][0] * st[i][0] + st[i][1] * st[i][1];
-			}
-		__syncthreads();
-		if (ch + (int) gridDim.x < a.nchunks)
-			load_chunk(ch + gridDim.x); // in flight during the products
+	// NC column tiles of C per wavefront (a.tp == 32 NC): every B operand of a sub-chunk is requested before the first product,
+	// consecutive MFMAs go to different accumulators
+	auto products = [&](int j) {
+		const double *src = sm[j & 1];
 		const int ro = 4 * (lane >> 4);
-		const double *ap = &sm[(16 * wv + (lane & 15)) * TQ_LP64 + ro];
-		const f64x2 a01 = *reinterpret_cast<const f64x2 *>(ap), a23 = *reinterpret_cast<const f64x2 *>(ap + 2);
-		if (a.want_g) {
+#pragma unroll 1
+		for (int sb = 0; sb < nsub; ++sb) {
+			const double *base = src + (long) sb * ncolp * TQ_LP64 + (lane & 15) * TQ_LP64 + ro;
+			const double *ap = base + 16 * ia * TQ_LP64;
+			const f64x2 a01 = *reinterpret_cast<const f64x2 *>(ap), a23 = *reinterpret_cast<const f64x2 *>(ap + 2);
+			// (groups of two tiles: their B operands are requested together, consecutive MFMAs go to different accumulators)
 #pragma unroll
-			for (int jb = 0; jb < 4; ++jb)
-				if (jb <= wv) { // wave uniform
-					const double *bp = &sm[(16 * jb + (lane & 15)) * TQ_LP64 + ro];
-					const f64x2 b01 = *reinterpret_cast<const f64x2 *>(bp), b23 = *reinterpret_cast<const f64x2 *>(bp + 2);
-					gacc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b01[0], gacc[jb], 0, 0, 0);
-					gacc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b01[1], gacc[jb], 0, 0, 0);
-					gacc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b23[0], gacc[jb], 0, 0, 0);
-					gacc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b23[1], gacc[jb], 0, 0, 0);
+			for (int c0 = 0; c0 < NC; c0 += 2) {
+				f64x2 b01[2], b23[2];
+#pragma unroll
+				for (int c = 0; c < 2; ++c) {
+					const double *bp = base + (TQ_PW + 16 * (2 * (c0 + c) + hf)) * TQ_LP64;
+					b01[c] = *reinterpret_cast<const f64x2 *>(bp);
+					b23[c] = *reinterpret_cast<const f64x2 *>(bp + 2);
 				}
-		}
 #pragma unroll
-		for (int cb = 0; cb < 12; ++cb)
-			if (cb < ntile) {
-				const double *bp = &sm[(TQ_PW + 16 * cb + (lane & 15)) * TQ_LP64 + ro];
-				const f64x2 b01 = *reinterpret_cast<const f64x2 *>(bp), b23 = *reinterpret_cast<const f64x2 *>(bp + 2);
-				cacc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b01[0], cacc[cb], 0, 0, 0);
-				cacc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b01[1], cacc[cb], 0, 0, 0);
-				cacc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b23[0], cacc[cb], 0, 0, 0);
-				cacc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b23[1], cacc[cb], 0, 0, 0);
+				for (int c = 0; c < 2; ++c)
+					cacc[c0 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b01[c][0], cacc[c0 + c], 0, 0, 0);
+#pragma unroll
+				for (int c = 0; c < 2; ++c)
+					cacc[c0 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b01[c][1], cacc[c0 + c], 0, 0, 0);
+#pragma unroll
+				for (int c = 0; c < 2; ++c)
+					cacc[c0 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b23[c][0], cacc[c0 + c], 0, 0, 0);
+#pragma unroll
+				for (int c = 0; c < 2; ++c)
+					cacc[c0 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b23[c][1], cacc[c0 + c], 0, 0, 0);
 			}
+			if (a.want_g) {
+#pragma unroll
+				for (int u = 0; u < 2; ++u) {
+					const int jb = 2 * hf + u;
+					if (jb <= ia) { // wave uniform
+						const double *bp = base + 16 * jb * TQ_LP64;
+						const f64x2 g01 = *reinterpret_cast<const f64x2 *>(bp), g23 = *reinterpret_cast<const f64x2 *>(bp + 2);
+						gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], g01[0], gacc[u], 0, 0, 0);
+						gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], g01[1], gacc[u], 0, 0, 0);
+						gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], g23[0], gacc[u], 0, 0, 0);
+						gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], g23[1], gacc[u], 0, 0, 0);
+					}
+				}
+			}
+		}
+	};
+	// chunk j lives in staging buffer j & 3; step j: chunk j + 1 into the other LDS half, its buffer refilled with chunk j + 5,
+	// the products of chunk j, one barrier (that leaves the global loads in flight).  Beyond the workgroup's last chunk the steps
+	// reload and restage that chunk (never consumed, not counted in the column squares): no branch around a load.
+	if (nmine > 0) {
+		load_chunk(0, s0);
+		load_chunk(1, s1);
+		load_chunk(2, s2);
+		load_chunk(3, s3);
+		stage(0, s0, 1.0);
+		load_chunk(4, s0);
+		tq_lds_barrier();
+#define TQ_G64_STEP(J, SN)                                                                                                                  \
+	{                                                                                                                                   \
+		stage((J) + 1, SN, (J) + 1 < nmine ? 1.0 : 0.0);                                                                            \
+		load_chunk((J) + 5, SN);                                                                                                    \
+		products(J);                                                                                                                \
+		tq_lds_barrier();                                                                                                           \
+	}
+		int j = 0;
+#pragma unroll 1
+		for (; j + 3 < nmine; j += 4) {
+			TQ_G64_STEP(j, s1)
+			TQ_G64_STEP(j + 1, s2)
+			TQ_G64_STEP(j + 2, s3)
+			TQ_G64_STEP(j + 3, s0)
+		}
+		// (the last 0 .. 3 chunks)
+		if (j < nmine)
+			TQ_G64_STEP(j, s1)
+		if (j + 1 < nmine)
+			TQ_G64_STEP(j + 1, s2)
+		if (j + 2 < nmine)
+			TQ_G64_STEP(j + 2, s3)
+#undef TQ_G64_STEP
+	}
+	if (blockIdx.x == gridDim.x - 1 && nfull * crows < a.rows) {
+		// the partial chunk: bounds-checked loads
+		const long r0 = (long) nfull * crows;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			s0[i] = f64x2{0.0, 0.0};
+			if (act[i])
+				s0[i] = tq_ld2<true>(colp[i] + r0, roff[i], a.rows - (int) r0);
+		}
+		__syncthreads();
+		stage(0, s0, 1.0);
+		__syncthreads();
+		products(0);
 	}
 	// f64 16x16x4 result map: col = lane & 15, row = (lane >> 4) + 4 * reg
 	const long blk = blockIdx.x;
 	if (a.want_g) {
 #pragma unroll
-		for (int jb = 0; jb < 4; ++jb)
-			if (jb <= wv) {
+		for (int u = 0; u < 2; ++u) {
+			const int jb = 2 * hf + u;
+			if (jb <= ia) {
 #pragma unroll
 				for (int r = 0; r < 4; ++r)
-					a.Gp[blk * 4096 + (16 * wv + (lane >> 4) + 4 * r) * 64 + 16 * jb + (lane & 15)] = gacc[jb][r];
+					a.Gp[blk * 4096 + (16 * ia + (lane >> 4) + 4 * r) * 64 + 16 * jb + (lane & 15)] = gacc[u][r];
 			}
+		}
 	}
 #pragma unroll
-	for (int cb = 0; cb < 12; ++cb)
-		if (cb < ntile) {
+	for (int c = 0; c < NC; ++c) {
+		const int cb = 2 * c + hf;
 #pragma unroll
-			for (int r = 0; r < 4; ++r)
-				a.Cp[blk * 64 * a.tp + (long) (16 * wv + (lane >> 4) + 4 * r) * a.tp + 16 * cb + (lane & 15)] = cacc[cb][r];
-		}
+		for (int r = 0; r < 4; ++r)
+			a.Cp[blk * 64 * a.tp + (long) (16 * ia + (lane >> 4) + 4 * r) * a.tp + 16 * cb + (lane & 15)] = cacc[c][r];
+	}
 	if (a.want_sq) {
+		// the slots of a thread that hold the same column (sub-chunks) are added in a fixed order
+		if (nslot == 1) {
+			sq[0] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+		} else if (nslot == 2) {
+			sq[0] += sq[2];
+			sq[1] += sq[3];
+		}
 #pragma unroll
-		for (int i = 0; i < 8; ++i) {
+		for (int i = 0; i < 4; ++i) {
 			double v = sq[i];
 			v += __shfl_xor(v, 1);
 			v += __shfl_xor(v, 2);
 			v += __shfl_xor(v, 4);
-			if (q == 0)
-				a.Sp[blk * 256 + i * 32 + cg] = v;
+			if (q == 0 && i < nslot)
+				a.Sp[blk * 256 + i * 64 + cg] = v;
 		}
 	}
 }
 
-// update: X <- X - P Y on a strip of <= 192 trailing columns and, if do_v, V = P M over the panel (at most 12 column tiles of 16
-// together).  The result tile is the TRANSPOSE of the strip's tile: D[i][j] = X[row j][column i] (lanes along the rows), so the A
-// operand is (-Y)^T / M^T -- kept in registers for the whole launch, tile wv + 4 u belongs to wavefront wv -- and the B operand the
-// panel rows, staged per 32-row chunk through LDS (16 KB).  A lane owns the row PAIR 2 j, 2 j + 1 of a chunk: 16-byte loads and
-// stores, two tiles per column tile.  Two workgroups per CU: one's memory phase behind the other's products.
-// Balance: 2 x 64 x 16 x 32 flop per 8 KB read + written: at the fp64 matrix-core peak the strip would stream at 11 TB/s -- the
+// update: X <- X - P Y on a strip of <= 192 trailing columns and, if do_v, V = P M over the panel (at most 16 column tiles of 16
+// together: the whole trailing matrix of a 256-column factorization in ONE launch per panel).  The result tile is the TRANSPOSE of
+// the strip's tile: D[i][j] = X[row j][column i] (lanes along the rows), so the A operand is (-Y)^T / M^T -- kept in registers for
+// the whole launch, tiles wv and wv + 8 belong to wavefront wv of eight -- and the B operand the panel rows, staged per 32-row
+// chunk through LDS (16 KB).  A lane owns the row PAIR 2 j, 2 j + 1 of a chunk: 16-byte loads and stores, two tiles per column
+// tile.  The strip's tiles and the panel rows of the NEXT chunk are loaded before the products of this one (first version: the
+// strip's loads at the head of their own iteration, two 256-thread workgroups per CU covering for each other: 3.2-3.4 TB/s).
+// Chunks are visited from the last rows up: the Gram pass in front of this launch ended there, the one behind it starts at the top.
+// Balance: 2 x 64 x 16 x 32 flop per 8 KB read + written: at the fp64 matrix-core peak the strip would stream at 9-11 TB/s -- the
 // kernel is HBM bound.
 struct TqUpd64Args {
 	double *P; // A[r1, c0], r1 = first row below the top block
@@ -2258,7 +2361,7 @@ struct TqUpd64Args {
 };
 constexpr int TQ_LPP = 34; // LDS pitch (doubles) of a staged panel column of a 32-row chunk
 
-template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_update64_kernel(const TqUpd64Args a)
+template <bool VEC> __global__ __launch_bounds__(512, 1) void tq_update64_kernel(const TqUpd64Args a)
 {
 	__shared__ double Pl[64 * TQ_LPP];
 	if (tq_skip(a.stat, a.c0))
@@ -2267,11 +2370,11 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_update64_kernel
 	const int li = lane & 15, g = lane >> 4;
 	const int nx = (a.ts + 15) >> 4;
 	const int nt = nx + (a.do_v ? 4 : 0);
-	// A operands: ya[u][ks] = A[i = li][k = 4 ks + g] of tile wv + 4 u
-	double ya[3][16];
+	// A operands: ya[u][ks] = A[i = li][k = 4 ks + g] of tile wv + 8 u
+	double ya[2][16];
 #pragma unroll
-	for (int u = 0; u < 3; ++u) {
-		const int tl = wv + 4 * u;
+	for (int u = 0; u < 2; ++u) {
+		const int tl = wv + 8 * u;
 		const bool isx = tl < nx, isv = !isx && tl < nt;
 		const int col = isx ? 16 * tl + li : 16 * (tl - nx) + li;
 		const bool ok = isx ? col < a.ts : (isv && col < a.w);
@@ -2281,53 +2384,73 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_update64_kernel
 		for (int ks = 0; ks < 16; ++ks)
 			ya[u][ks] = ok && (4 * ks + g) < a.w ? src[(long) (4 * ks + g) * step] : 0.0;
 	}
-	const int pq = tid & 15, pc = tid >> 4; // staging: rows 2 pq, 2 pq + 1 of the panel columns pc + 16 i
-	f64x2 pst[4];
-	auto load_panel = [&](int ch) {
-		const int rbase = ch * 32 + 2 * pq;
+	const int pq = tid & 15, pc = tid >> 4; // staging: rows 2 pq, 2 pq + 1 of the panel columns pc, pc + 32
+	f64x2 pst[2];
+	f64x2 xv[2][4], xn[2][4];
+	// chunk ch of the launch is rows 32 (nchunks - 1 - ch) ..: chunk 0 is the one that may be partial
+	auto load_checked = [&](int ch, f64x2 (&x)[2][4]) {
+		const int cr = a.nchunks - 1 - ch;
+		const int rb = cr * 32 + 2 * pq, rbase = cr * 32 + 2 * li;
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			const int c = pc + 16 * i;
+		for (int i = 0; i < 2; ++i) {
+			const int c = pc + 32 * i;
 			pst[i] = f64x2{0.0, 0.0};
 			if (c < a.w)
-				pst[i] = tq_ld2<VEC>(a.P + (long) c * a.ld, rbase, a.rows);
+				pst[i] = tq_ld2<VEC>(a.P + (long) c * a.ld, rb, a.rows);
 		}
-	};
-	int ch = blockIdx.x;
-	if (ch < a.nchunks)
-		load_panel(ch);
-	for (; ch < a.nchunks; ch += gridDim.x) {
-		const int rbase = ch * 32 + 2 * li;
-		// the strip's tiles of this wavefront: all loads of the chunk in flight before the first product
-		f64x2 xv[3][4];
 #pragma unroll
-		for (int u = 0; u < 3; ++u) {
-			const int tl = wv + 4 * u;
+		for (int u = 0; u < 2; ++u) {
+			const int tl = wv + 8 * u;
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
-				xv[u][r] = f64x2{0.0, 0.0};
+				x[u][r] = f64x2{0.0, 0.0};
 				const int col = 16 * tl + g + 4 * r;
 				if (tl < nx && col < a.ts)
-					xv[u][r] = tq_ld2<VEC>(a.X + (long) col * a.ld, rbase, a.rows);
+					x[u][r] = tq_ld2<VEC>(a.X + (long) col * a.ld, rbase, a.rows);
 			}
 		}
-		__syncthreads(); // the previous chunk's panel rows have been consumed
+	};
+	// a chunk inside the matrix: unconditional 16-byte loads (see tq_gram64_kernel) -- panel columns beyond w read column 0 and are
+	// zeroed when staged, tiles beyond the strip read a valid column and never use or store it
+	const double *pcol[2], *xcol[2][4];
 #pragma unroll
-		for (int i = 0; i < 4; ++i)
-			*reinterpret_cast<f64x2 *>(&Pl[(pc + 16 * i) * TQ_LPP + 2 * pq]) = pst[i];
-		__syncthreads();
-		if (ch + (int) gridDim.x < a.nchunks)
-			load_panel(ch + gridDim.x);
+	for (int i = 0; i < 2; ++i)
+		pcol[i] = a.P + (long) (pc + 32 * i < a.w ? pc + 32 * i : 0) * a.ld + 2 * pq;
 #pragma unroll
-		for (int u = 0; u < 3; ++u) {
-			const int tl = wv + 4 * u;
+	for (int u = 0; u < 2; ++u)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int col = 16 * (wv + 8 * u) + g + 4 * r;
+			xcol[u][r] = (a.ts > 0 ? a.X + (long) (col < a.ts ? col : a.ts - 1) * a.ld : a.P) + 2 * li;
+		}
+	auto load_full = [&](int ch, f64x2 (&x)[2][4]) {
+		const long r0 = (long) (a.nchunks - 1 - ch) * 32;
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+			pst[i] = *reinterpret_cast<const f64x2 *>(pcol[i] + r0);
+#pragma unroll
+		for (int u = 0; u < 2; ++u)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				x[u][r] = *reinterpret_cast<const f64x2 *>(xcol[u][r] + r0);
+	};
+	auto stage_panel = [&]() {
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+			*reinterpret_cast<f64x2 *>(&Pl[(pc + 32 * i) * TQ_LPP + 2 * pq]) = pc + 32 * i < a.w ? pst[i] : f64x2{0.0, 0.0};
+	};
+	auto compute_store = [&](int ch, const f64x2 (&x)[2][4]) {
+		const int rbase = (a.nchunks - 1 - ch) * 32 + 2 * li;
+#pragma unroll
+		for (int u = 0; u < 2; ++u) {
+			const int tl = wv + 8 * u;
 			if (tl < nt) { // wave uniform
 				const bool isx = tl < nx;
 				f64x4 acc0, acc1;
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
-					acc0[r] = xv[u][r][0];
-					acc1[r] = xv[u][r][1];
+					acc0[r] = isx ? x[u][r][0] : 0.0;
+					acc1[r] = isx ? x[u][r][1] : 0.0;
 				}
 #pragma unroll
 				for (int ks = 0; ks < 16; ++ks) {
@@ -2345,6 +2468,36 @@ template <bool VEC> __global__ __launch_bounds__(256, 2) void tq_update64_kernel
 				}
 			}
 		}
+	};
+	// a workgroup owns a contiguous run of chunks
+	const int cpw = (a.nchunks + (int) gridDim.x - 1) / (int) gridDim.x;
+	int ch = (int) blockIdx.x * cpw;
+	const int chend = ch + cpw < a.nchunks ? ch + cpw : a.nchunks;
+	const int nchecked = VEC ? ((a.rows & 31) != 0 ? 1 : 0) : a.nchunks; // chunks [0, nchecked) take the bounds-checked path
+	for (; ch < chend && ch < nchecked; ++ch) {
+		load_checked(ch, xv);
+		__syncthreads();
+		stage_panel();
+		__syncthreads();
+		compute_store(ch, xv);
+	}
+	if (ch >= chend)
+		return;
+	// main loop, straight-line: the strip's tiles and the panel rows of the NEXT chunk are requested before the products of this one
+	// (beyond the run's last chunk: that chunk again, never used)
+	load_full(ch, xv);
+#pragma unroll 1
+	for (; ch < chend; ++ch) {
+		tq_lds_barrier(); // the previous chunk's panel rows have been consumed (a barrier that leaves the global loads in flight)
+		stage_panel();
+		tq_lds_barrier();
+		load_full(ch + 1 < chend ? ch + 1 : ch, xn);
+		compute_store(ch, xv);
+#pragma unroll
+		for (int u = 0; u < 2; ++u)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				xv[u][r] = xn[u][r];
 	}
 }
 
@@ -2937,8 +3090,12 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason)
 			g.rows = rows;
 			g.w = w;
 			g.t = t - off < TQ_TS ? t - off : TQ_TS;
-			g.tp = (g.t + 15) & ~15;
-			g.nchunks = (rows + 15) / 16;
+			g.tp = (g.t + 63) & ~63;
+			{
+				const int nslot = (TQ_PW + g.tp + 63) / 64;
+				g.nsub = 4 / nslot;
+			}
+			g.nchunks = (rows + 16 * g.nsub - 1) / (16 * g.nsub);
 			g.want_g = st == 0;
 			g.want_sq = first && st == 0; // (the range guard covers the first strip; tq_range_rest_kernel checks the others)
 			g.Gp = gp.as<double>();
@@ -2947,10 +3104,15 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason)
 			g.stat = stat;
 			g.c0 = c0;
 			g.A1s = A1s;
-			const int nb = g.nchunks < TQ_NB ? g.nchunks : TQ_NB;
+			const int nb = g.nchunks < ncu ? g.nchunks : ncu; // one persistent workgroup per CU (<= TQ_NB partial sums)
 			{
 				ProfScope prof(3, (double) rows * 8.0 * ((double) w + (double) g.t));
-				hipLaunchKernelGGL(tq_gram64_kernel<true>, dim3(nb), dim3(256), 0, s, g);
+				switch (g.tp / 32) {
+				case 0: hipLaunchKernelGGL(tq_gram64_kernel<0>, dim3(nb), dim3(512), 0, s, g); break;
+				case 2: hipLaunchKernelGGL(tq_gram64_kernel<2>, dim3(nb), dim3(512), 0, s, g); break;
+				case 4: hipLaunchKernelGGL(tq_gram64_kernel<4>, dim3(nb), dim3(512), 0, s, g); break;
+				default: hipLaunchKernelGGL(tq_gram64_kernel<6>, dim3(nb), dim3(512), 0, s, g); break;
+				}
 			}
 			const int total = (g.want_g ? 4096 : 0) + 64 * g.tp + (g.want_sq ? 256 : 0);
 			hipLaunchKernelGGL(tq_reduce_kernel<double>, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, g.Gp, g.Cp, g.Sp, nb, g.tp, g.want_g, g.want_sq, G, C, ldc,
@@ -3045,23 +3207,23 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason)
 			ua.stat = stat;
 			ua.c0 = c0;
 			const bool v2 = r1 % 2 == 0;
-			const int nwg = ua.nchunks < 2 * ncu ? ua.nchunks : 2 * ncu;
-			// strips of at most 12 column tiles; V = P M (4 tiles, it overwrites the panel) rides on the last one
+			const int nwg = ua.nchunks < ncu ? ua.nchunks : ncu; // one persistent 512-thread workgroup per CU
+			// strips of at most 192 columns; V = P M (it overwrites the panel) rides on the last one
 			int from = 0;
 			do {
 				int ts = t - from;
-				const bool last = ts <= 128;
+				const bool last = ts <= TQ_TS;
 				if (!last)
-					ts = ts - 128 > 192 ? 192 : ts - 128 >= 64 ? ts - 128 : 64;
+					ts = TQ_TS;
 				ua.coff = from;
 				ua.ts = ts;
 				ua.X = A.p + (long) (c0 + w + from) * ld + r1;
 				ua.do_v = last;
 				ProfScope prof(2, (double) rows * 8.0 * ((double) w + 2.0 * (double) ts + (last ? (double) w : 0.0)));
 				if (v2)
-					hipLaunchKernelGGL(tq_update64_kernel<true>, dim3(nwg), dim3(256), 0, s, ua);
+					hipLaunchKernelGGL(tq_update64_kernel<true>, dim3(nwg), dim3(512), 0, s, ua);
 				else
-					hipLaunchKernelGGL(tq_update64_kernel<false>, dim3(nwg), dim3(256), 0, s, ua);
+					hipLaunchKernelGGL(tq_update64_kernel<false>, dim3(nwg), dim3(512), 0, s, ua);
 				from += ts;
 				if (last)
 					break;
