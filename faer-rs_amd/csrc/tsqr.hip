@@ -3158,10 +3158,37 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason)
 		hipLaunchKernelGGL(tq_range_rest_kernel<double>, dim3((unsigned) (n - (TQ_PW + TQ_TS))), dim3(256), 0, s, A.p, (long) ld, (int) m, TQ_PW + TQ_TS, stat);
 		FH_HIP(hipGetLastError());
 	}
+	auto tx_args = [&](int stage) {
+		TqTxArgs<double> ta;
+		ta.A = A.p;
+		ta.ld = ld;
+		ta.n = (int) n;
+		ta.bs = (int) bs;
+		ta.Td = Td;
+		ta.Md = Md;
+		ta.Z = Z;
+		ta.ldz = ldz;
+		ta.B = Bx;
+		ta.H = H.p;
+		ta.hrs = H.rs;
+		ta.hcs = H.cs;
+		ta.stat = stat;
+		ta.stage = stage;
+		return ta;
+	};
+	// one block of Q_coeff over all panels (the tall-skinny case): the cross-panel blocks of T in two stages on the side stream -- what
+	// does not need the last panel's kernel beside that panel's Gram launch and kernel, the rest beside the last update (tsqr_factor)
+	const bool two_stage = cross && bs >= n && bs <= (TQ_TX_MAXL + 1) * TQ_PW && npan >= 2;
+	const TqSide side = tq_side();
 	for (int k = 0; k < npan; ++k) {
 		const int c0 = k * TQ_PW;
 		const int w = (int) (n - c0 < TQ_PW ? n - c0 : TQ_PW);
 		const int t = (int) n - c0 - w;
+		if (two_stage && k == npan - 1) {
+			FH_HIP(hipEventRecord(side.xfork, s));
+			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
+			hipLaunchKernelGGL(tq_tx_kernel<double>, dim3(npan - 1), dim3(256), 0, side.tx, tx_args(1));
+		}
 		launch_gram(c0, w, c0 + w, t, k == 0);
 		launch_panel(k);
 		if (t > 0) {
@@ -3191,6 +3218,13 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason)
 			hipLaunchKernelGGL(tq_y_kernel<double>, dim3((t + 15) / 16), dim3(256), 0, s, ya);
 		} else {
 			hipLaunchKernelGGL(tq_top_kernel<double>, dim3(1), dim3(256), 0, s, A.p, (long) ld, c0, c0, w, (const double *) top, (const int *) stat);
+		}
+		if (two_stage && k == npan - 1) {
+			// stage 2 reads this panel's R block and M: beside the update below (which writes V below that block only)
+			FH_HIP(hipEventRecord(side.xfork, s));
+			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
+			hipLaunchKernelGGL(tq_tx_kernel<double>, dim3(npan - 1), dim3(256), 0, side.tx, tx_args(2));
+			FH_HIP(hipEventRecord(side.xdone, side.tx));
 		}
 		const int r1 = c0 + w;
 		const int rows = (int) (m - r1);
@@ -3231,26 +3265,13 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason)
 		}
 		FH_HIP(hipGetLastError());
 	}
-	if (cross) {
-		TqTxArgs<double> ta;
-		ta.A = A.p;
-		ta.ld = ld;
-		ta.n = (int) n;
-		ta.bs = (int) bs;
-		ta.Td = Td;
-		ta.Md = Md;
-		ta.Z = Z;
-		ta.ldz = ldz;
-		ta.B = Bx;
-		ta.H = H.p;
-		ta.hrs = H.rs;
-		ta.hcs = H.cs;
-		ta.stat = stat;
-		ta.stage = 0;
+	if (two_stage) {
+		FH_HIP(hipStreamWaitEvent(s, side.xdone, 0));
+	} else if (cross) {
 		if (bs <= (TQ_TX_MAXL + 1) * TQ_PW)
-			hipLaunchKernelGGL(tq_tx_kernel<double>, dim3(npan - 1), dim3(256), 0, s, ta);
+			hipLaunchKernelGGL(tq_tx_kernel<double>, dim3(npan - 1), dim3(256), 0, s, tx_args(0));
 		else
-			hipLaunchKernelGGL(tq_tx_general_kernel<double>, dim3(npan - 1), dim3(256), 0, s, ta);
+			hipLaunchKernelGGL(tq_tx_general_kernel<double>, dim3(npan - 1), dim3(256), 0, s, tx_args(0));
 		FH_HIP(hipGetLastError());
 	}
 	int *st = ctx().pinned_ints();
