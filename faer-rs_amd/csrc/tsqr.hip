@@ -1,4 +1,4 @@
-// One-pass tall-skinny Householder QR for gfx950 (fp32 data): faer's (V, T, R) -- qr/no_pivoting/factor.rs:137-256,
+// One-pass tall-skinny Householder QR for gfx950 (fp32 data; fp64 data: the section "fp64 data" further down): faer's (V, T, R) -- qr/no_pivoting/factor.rs:137-256,
 // householder.rs:21-23,59-107,132-272 -- without a cross-workgroup reduction per column.
 //
 // The classic path (qr.hip) follows the reference's recursion: every column of a panel costs one device-wide
@@ -29,7 +29,9 @@
 // TQ_COND_MAX, whose updated column is (numerically) zero below the diagonal (the reference's tau = +inf case) or whose
 // column fails the reference's rank test (factor.rs:52-64, evaluated from R): nothing of that panel has been written
 // at that point, every earlier reflector has been applied to everything right of it, and geqrf_dev continues with the
-// classic path on the remaining submatrix.  fp64 input never comes here (it would need a wider Gram accumulator).
+// classic path on the remaining submatrix.  fp64 input (end of round 6) runs the same factorization with fp64 Gram sums: those are
+// NOT exact, R~ is good to ~cond(panel)^2 eps64, so its guard keeps well-conditioned panels only (TqLim<double>::cond_max) and the
+// classic path takes every other one.
 #include <atomic>
 
 #include "common.h"
