@@ -1419,6 +1419,7 @@ void faer_hip_debug_lu_plan(size_t nb2_from, size_t pipe_from, size_t la_min_col
 long faer_hip_debug_qr_one_pass_columns(void) { return qr_last_one_pass_columns(); }
 void faer_hip_debug_qr_fused(int on) { tsqr_debug_fused(on); }
 void faer_hip_debug_qr_one_pass_f64(int on) { tsqr_debug_f64(on); }
+void faer_hip_debug_qr_panels_one_pass(int on) { tsqr_debug_panels(on); }
 void faer_hip_debug_fplu_inplace(int on) { fplu_debug_inplace(on); }
 void faer_hip_debug_level2_force_memory_bodies(int on) { level2_debug_force_memory_bodies(on); }
 void *faer_hip_debug_internal_stream(int which)

@@ -537,6 +537,15 @@ template <typename T> static void qr_leaf(MatV<T> P, MatV<T> Tb, idx_t row_abs, 
 	}
 }
 
+// tsqr.hip: the one-pass path (whole tall matrices: geqrf_dev; single panels of this recursion: qr_rec)
+bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs);
+idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason, idx_t top = 0);
+bool tsqr_applicable64(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs, const void *p);
+idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, idx_t top = 0);
+bool tsqr_panel_applicable(idx_t m, idx_t w, idx_t rs, idx_t cs, const void *p, int elem);
+static inline idx_t tsqr_run(MatV<float> A, MatV<float> H, float *taus, int *reason, idx_t top = 0) { return tsqr_factor(A, H, taus, reason, top); }
+static inline idx_t tsqr_run(MatV<double> A, MatV<double> H, double *taus, int *reason, idx_t top = 0) { return tsqr_factor64(A, H, taus, reason, top); }
+
 // P: rows from the diagonal row of its first column; Tb: w x w block of Q_coeff
 template <typename T> static void qr_rec(MatV<T> P, MatV<T> Tb, idx_t row_abs, idx_t col_abs, QrWork<T> &wk)
 {
@@ -547,9 +556,27 @@ template <typename T> static void qr_rec(MatV<T> P, MatV<T> Tb, idx_t row_abs, i
 		qr_leaf<T>(P, Tb, row_abs, col_abs, wk);
 		return;
 	}
+	// A panel of up to 64 columns that is tall enough takes the one-pass panel (tsqr.hip): Gram matrix, ONE small kernel, V = P M --
+	// instead of 8 cooperative leaves (one all-reduce per column) and the level-3 steps between them.  A panel it refuses (ill
+	// conditioned, a column failing the reference's rank test, ...) is untouched and goes down the recursion as before.
+	const bool onepass_tall = P.nrows >= 1024 && P.nrows >= 8 * 64;
+	if (w <= 64 && tsqr_panel_applicable(m, w, P.rs, P.cs, P.p, (int) sizeof(T))) {
+		Scratch taus((size_t) w * sizeof(T));
+		int reason = 0;
+		// (rows above the panel in the parent count in the rank test: row_abs of them)
+		const idx_t done = tsqr_run(P, MatV<T>{Tb.p, w, w, Tb.rs, Tb.cs}, taus.as<T>(), &reason, row_abs);
+		if (done == w)
+			return;
+	}
 	idx_t w1 = ((w / 2 + QR_PW - 1) / QR_PW) * QR_PW;
 	if (w1 >= w)
 		w1 = w - QR_PW;
+	if (onepass_tall && w > 64) {
+		// split at a multiple of 64 so that both halves end in whole one-pass panels where they can
+		w1 = ((w / 2 + 63) / 64) * 64;
+		if (w1 >= w)
+			w1 = w - 64;
+	}
 	const idx_t w2 = w - w1;
 	MatV<T> V1 = P.sub(0, 0, m, w1), B = P.sub(0, w1, m, w2);
 	MatV<T> T11 = Tb.sub(0, 0, w1, w1), T12 = Tb.sub(0, w1, w1, w2), T22 = Tb.sub(w1, w1, w2, w2);
@@ -3249,15 +3276,9 @@ template <typename T> static long geqrf_classic(MatV<T> A, MatV<T> H, idx_t bloc
 }
 
 // tsqr.hip: the one-pass path for tall fp32 matrices
-bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs);
-idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason);
-// ... and its fp64 instantiation (fp64 Gram sums: well-conditioned panels only, the rest goes to the classic path)
-bool tsqr_applicable64(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs, const void *p);
-idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason);
+// (fp64: fp64 Gram sums -- well-conditioned panels only, the rest goes to the classic path)
 static inline bool tsqr_ok(const MatV<float> &A, idx_t bs) { return tsqr_applicable(A.nrows, A.ncols, A.rs, A.cs, bs); }
 static inline bool tsqr_ok(const MatV<double> &A, idx_t bs) { return tsqr_applicable64(A.nrows, A.ncols, A.rs, A.cs, bs, A.p); }
-static inline idx_t tsqr_run(MatV<float> A, MatV<float> H, float *taus, int *reason) { return tsqr_factor(A, H, taus, reason); }
-static inline idx_t tsqr_run(MatV<double> A, MatV<double> H, double *taus, int *reason) { return tsqr_factor64(A, H, taus, reason); }
 
 template <typename T> __global__ void qr_taus_from_blocks_kernel(const T *H, idx_t hrs, idx_t hcs, int bs, int count, T *taus)
 {

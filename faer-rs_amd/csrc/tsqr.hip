@@ -2590,6 +2590,29 @@ static TqSide tq_side()
 	return TqSide{c.qr_side[0], c.qr_side[1], c.qr_ev[0], c.qr_ev[1], c.qr_ev[2], c.qr_ev[3]};
 }
 
+// A matrix that is a sub-block of a larger one whose rows above it belong to the same columns (a panel of the classic path, qr.hip):
+// the reference's rank test takes the norm of ALL rows above the diagonal (factor.rs:26,52-58), so abv starts from the squares of the
+// `top` entries above each column.  One workgroup per column, fixed summation order.
+template <typename T> __global__ __launch_bounds__(256) void tq_above_kernel(const T *A, long ld, int top, double *abv)
+{
+	__shared__ double red[256];
+	const T *col = A + (long) blockIdx.x * ld;
+	double sq = 0.0;
+	for (int i = 1 + (int) threadIdx.x; i <= top; i += 256) {
+		const double v = (double) col[-(long) i];
+		sq += v * v;
+	}
+	red[threadIdx.x] = sq;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1) {
+		if ((int) threadIdx.x < o)
+			red[threadIdx.x] += red[threadIdx.x + o];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		abv[blockIdx.x] = red[0];
+}
+
 // Range guard of the columns the first step's Gram launches do not cover (n > 256: the squares of the first 64 + 192
 // columns come out of those launches, tq_panel_kernel / tq_y_kernel check them): one workgroup per column, BEFORE anything is
 // written -- a column whose rms is outside [1e-12, 1e12] would be updated by the first steps with flushed or overflowed fp32
@@ -2633,7 +2656,7 @@ bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs)
 // completed (a multiple of 64, or n); the state is then that of the reference algorithm after those columns: R and
 // V in place, the T blocks in H, taus[j] = T_jj, every reflector applied to all columns on the right.
 // `reason` reports why it stopped early (TQ_FAIL_*).
-idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
+idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason, idx_t rows_above)
 {
 	const idx_t m = A.nrows, n = A.ncols, ld = A.cs, bs = H.nrows;
 	hipStream_t s = ctx().stream;
@@ -2658,6 +2681,8 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 	int *stat = reinterpret_cast<int *>(Yn + (size_t) 64 * typ);
 	FH_HIP(hipMemsetAsync(stat, 0, 2048, s));
 	FH_HIP(hipMemsetAsync(abv, 0, (size_t) (n + 64) * 8, s));
+	if (rows_above > 0 && A.rs == 1)
+		hipLaunchKernelGGL(tq_above_kernel<float>, dim3((unsigned) n), dim3(256), 0, s, (const float *) A.p, (long) ld, (int) rows_above, abv);
 	const bool cross = bs > TQ_PW && npan > 1;
 	if (cross)
 		FH_HIP(hipMemsetAsync(Z, 0, (size_t) npan * 64 * ldz * 8, s));
@@ -3042,6 +3067,25 @@ idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason)
 // ------------------------------------------------------------------------------------------------
 static std::atomic<int> g_tq_f64{1};
 void tsqr_debug_f64(int on) { g_tq_f64.store(on); }
+static std::atomic<int> g_tq_panels{1};
+void tsqr_debug_panels(int on) { g_tq_panels.store(on); }
+
+// Panels of the classic path (qr.hip, qr_rec): ONE 64-column panel (or a divisor of 64: a narrower block of Q_coeff) of a matrix of
+// any shape, rows from its diagonal down, with its w x w block of T.  The one-pass panel costs a fixed ~180 us (Gram launch, reduce,
+// the single-workgroup panel kernel, V launch, status read-back) against 9 us per column of the cooperative leaf + the level-3 steps
+// of the recursion between 8 and 64 columns.
+bool tsqr_panel_applicable(idx_t m, idx_t w, idx_t rs, idx_t cs, const void *p, int elem)
+{
+	if (g_tq_panels.load() == 0 || (elem == 8 && g_tq_f64.load() == 0))
+		return false;
+	if (rs != 1 || cs < m || w < 16 || w > TQ_PW || TQ_PW % w != 0 || m < 1024 || m < 8 * w || m >= (1L << 30))
+		return false;
+	if (elem == 8 && (cs % 2 != 0 || (uintptr_t) p % 16 != 0))
+		return false;
+	if (elem == 4 && 16.0 * 1.1920928955078125e-07 * (double) m >= 1.0)
+		return false;
+	return true;
+}
 
 bool tsqr_applicable64(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs, const void *p)
 {
@@ -3054,7 +3098,7 @@ bool tsqr_applicable64(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs, const voi
 	return bs % TQ_PW == 0 || TQ_PW % bs == 0;
 }
 
-idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason)
+idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, idx_t rows_above)
 {
 	const idx_t m = A.nrows, n = A.ncols, ld = A.cs, bs = H.nrows;
 	hipStream_t s = ctx().stream;
@@ -3075,6 +3119,8 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason)
 	int *stat = reinterpret_cast<int *>(Yn + (size_t) 64 * typ);
 	FH_HIP(hipMemsetAsync(stat, 0, 2048, s));
 	FH_HIP(hipMemsetAsync(abv, 0, (size_t) (n + 64) * 8, s));
+	if (rows_above > 0)
+		hipLaunchKernelGGL(tq_above_kernel<double>, dim3((unsigned) n), dim3(256), 0, s, (const double *) A.p, (long) ld, (int) rows_above, abv);
 	const bool cross = bs > TQ_PW && npan > 1;
 	if (cross)
 		FH_HIP(hipMemsetAsync(Z, 0, (size_t) npan * 64 * ldz * 8, s));

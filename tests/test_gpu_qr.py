@@ -526,3 +526,58 @@ def test_qr_tall_other_schedules_still_agree_with_the_oracle(oracle, m, n, bs, m
         _tall_vs_oracle(oracle, F, a, bs)
     finally:
         F.lib().faer_hip_debug_qr_fused(1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("m,n,bs", [(2048, 2048, None), (3000, 1500, 64), (2500, 700, 128), (4096, 1024, 32), (2100, 320, 192)])
+def test_qr_classic_path_one_pass_panels_vs_oracle(oracle, m, n, bs, dtype):
+    """square / moderately tall matrices: the recursion of the classic path (qr.hip qr_rec) hands panels of up to 64 columns with at
+    least 1024 rows to the one-pass panel of tsqr.hip (end of round 6); same factors as the oracle at the classic path's tolerance,
+    with the switch off (recursion down to the 8-column leaves) as well, and the two agree"""
+    F = init_gpu()
+    rng = np.random.default_rng(m + 3 * n)
+    a = rnd(rng, m, n, dtype)
+    size = min(m, n)
+    if bs is None:
+        bs = F.qr_recommended_block_size(m, n, dtype)
+    ref, rh = a.copy(order="F"), np.zeros((bs, size), dtype=dtype, order="F")
+    assert oracle.qr_in_place(ref, rh) == size
+    e = EPS[np.dtype(dtype)]
+    tol = 64 * max(m, n) * e * max(1.0, np.abs(a).max())
+    up = np.zeros((bs, size), bool)
+    for j0 in range(0, size, bs):
+        w = min(bs, size - j0)
+        up[:w, j0:j0 + w] = np.triu(np.ones((w, w), bool))
+    out = []
+    for on in (1, 0):
+        F.lib().faer_hip_debug_qr_panels_one_pass(on)
+        try:
+            dqr, dh = to_dev(a), to_dev(np.zeros((bs, size), dtype=dtype))
+            assert F.qr_factor_in_place(dqr, dh) == size
+        finally:
+            F.lib().faer_hip_debug_qr_panels_one_pass(1)
+        qr, h = to_host(dqr).astype(np.float64), to_host(dh).astype(np.float64)
+        assert np.abs(qr - ref).max() <= 8 * tol
+        fin = np.isfinite(rh)  # (the last reflector of a square matrix has tau = +inf)
+        assert (np.isfinite(h) == fin).all()
+        assert np.abs(h - np.where(fin, rh, 0.0))[fin & up].max() <= 8 * tol * max(1.0, np.abs(rh[fin & up]).max())
+        out.append((qr, h))
+    assert np.abs(out[0][0] - out[1][0]).max() <= 8 * tol
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_qr_classic_path_one_pass_panels_rank_deficient(oracle, dtype):
+    """a rank-deficient matrix whose dependent columns sit in a LATER panel: the one-pass panel must refuse it (rank test with the rows
+    above the panel counted, factor.rs:52-58) and the result is the oracle's rank and pattern of skipped reflectors"""
+    F = init_gpu()
+    rng = np.random.default_rng(21)
+    m, n, r = 2048, 512, 200
+    a = np.asfortranarray((rnd(rng, m, r) @ rnd(rng, r, n)).astype(dtype))
+    ref, rh = a.copy(order="F"), np.zeros((64, n), dtype=dtype, order="F")
+    rk = oracle.qr_in_place(ref, rh)
+    dqr, dh = to_dev(a), to_dev(np.zeros((64, n), dtype=dtype))
+    assert F.qr_factor_in_place(dqr, dh) == rk
+    assert r <= rk < n
+    e = EPS[np.dtype(dtype)]
+    q = q_from(F, dqr, dh, m, dtype).astype(np.float64)
+    assert np.abs(q @ np.triu(to_host(dqr)).astype(np.float64) - a).max() <= 256 * np.sqrt(m) * e * np.abs(a).max()
