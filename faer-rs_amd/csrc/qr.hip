@@ -559,7 +559,7 @@ template <typename T> static void qr_rec(MatV<T> P, MatV<T> Tb, idx_t row_abs, i
 	// A panel of up to 64 columns that is tall enough takes the one-pass panel (tsqr.hip): Gram matrix, ONE small kernel, V = P M --
 	// instead of 8 cooperative leaves (one all-reduce per column) and the level-3 steps between them.  A panel it refuses (ill
 	// conditioned, a column failing the reference's rank test, ...) is untouched and goes down the recursion as before.
-	const bool onepass_tall = P.nrows >= 1024 && P.nrows >= 8 * 64;
+	const bool onepass_tall = P.nrows >= 256;
 	if (w <= 64 && tsqr_panel_applicable(m, w, P.rs, P.cs, P.p, (int) sizeof(T))) {
 		Scratch taus((size_t) w * sizeof(T));
 		int reason = 0;

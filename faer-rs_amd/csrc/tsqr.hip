@@ -3070,7 +3070,7 @@ void tsqr_debug_f64(int on) { g_tq_f64.store(on); }
 static std::atomic<int> g_tq_panels{1};
 void tsqr_debug_panels(int on) { g_tq_panels.store(on); }
 
-// Panels of the classic path (qr.hip, qr_rec): ONE 64-column panel (or a divisor of 64: a narrower block of Q_coeff) of a matrix of
+// Panels of the classic path (qr.hip, qr_rec): ONE panel of 16 .. 64 columns of a matrix of
 // any shape, rows from its diagonal down, with its w x w block of T.  The one-pass panel costs a fixed ~180 us (Gram launch, reduce,
 // the single-workgroup panel kernel, V launch, status read-back) against 9 us per column of the cooperative leaf + the level-3 steps
 // of the recursion between 8 and 64 columns.
@@ -3078,7 +3078,8 @@ bool tsqr_panel_applicable(idx_t m, idx_t w, idx_t rs, idx_t cs, const void *p, 
 {
 	if (g_tq_panels.load() == 0 || (elem == 8 && g_tq_f64.load() == 0))
 		return false;
-	if (rs != 1 || cs < m || w < 16 || w > TQ_PW || TQ_PW % w != 0 || m < 1024 || m < 8 * w || m >= (1L << 30))
+	// (ONE panel: any width up to 64 -- the block-size rule of tsqr_applicable is about panels that share a block of Q_coeff)
+	if (rs != 1 || cs < m || w < 16 || w > TQ_PW || m < 256 || m < 4 * w || m >= (1L << 30))
 		return false;
 	if (elem == 8 && (cs % 2 != 0 || (uintptr_t) p % 16 != 0))
 		return false;

@@ -502,7 +502,7 @@ FAER_HIP_API void faer_hip_debug_qr_fused(int on);
  * they take it under the same shape rule as fp32 (rows >= 16384, rows >= 8 cols, cols <= 512, unit row stride, even column stride). */
 FAER_HIP_API void faer_hip_debug_qr_one_pass_f64(int on);
 /* tests / A-B measurements: 0 = the classic QR path (square / wide matrices, rejected panels) factors its panels by the recursion down to
- * the 8-column cooperative leaf as in rounds 1-6, 1 (default) = a panel of up to 64 columns with at least 1024 rows takes the one-pass
+ * the 8-column cooperative leaf as in rounds 1-6, 1 (default) = a panel of up to 64 columns with at least 256 rows (and 4 rows per column) takes the one-pass
  * panel of csrc/tsqr.hip (and the recursion only if that refuses it). */
 FAER_HIP_API void faer_hip_debug_qr_panels_one_pass(int on);
 /* Full-pivot LU: 1 = the in-place path (two launches per step) instead of the one-launch-per-step path between two scratch copies
