@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=["gemm", "sgemm", "llt", "lu", "qr", "qr64", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess"],
+    ap.add_argument("--workload", default=None, choices=["gemm", "sgemm", "llt", "lu", "qr", "qr64", "qrsq", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess"],
                     help="default: gemm on one GPU, the block-cyclic lu (RCCL transport) on several (resolve_run)")
     ap.add_argument("--n", type=int, default=0, help="override the matrix size (testing only)")
     ap.add_argument("--no-extras", action="store_true")
@@ -341,6 +341,20 @@ def main():
                 F.qr_factor_in_place(work, h)
 
             return step, 2.0 * m * n * n - 2.0 / 3.0 * n ** 3, lambda: work.copy_(a), f"qr_f64_{m}x{n}", "f64"
+        if name == "qrsq":
+            # square Householder QR (qr/no_pivoting/factor.rs:137-256 on the classic path of csrc/qr.hip, one-pass panels inside the recursion
+            # since the end of round 6): not a BASELINE config, kept in the line because it is the QR every square solve runs
+            n = n_override or 4096
+            a = colmajor(n, n, torch.float64, 7)
+            work = a.clone()
+            bs = F.qr_recommended_block_size(n, n, np.float64)
+            h = torch.zeros((n, bs), dtype=torch.float64, device=dev).t()
+
+            def step():
+                work.copy_(a)
+                F.qr_factor_in_place(work, h)
+
+            return step, 4.0 / 3.0 * n ** 3, lambda: work.copy_(a), f"qr_f64_n{n}", "f64"
         if name == "fplu":
             # LU with full pivoting, a level-2 (HBM bound) algorithm; algorithmic bytes =
             # one read + one write of the trailing matrix per step
@@ -666,7 +680,7 @@ def main():
             del step
             torch.cuda.empty_cache()
             only = os.environ.get("BENCH_OTHERS")  # diagnostic: a comma-separated subset
-            for name in ("gemm", "llt", "lu", "qr", "qr64", "gemm4096", "sgemm", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess", "qrmax", "qrlit"):
+            for name in ("gemm", "llt", "lu", "qr", "qr64", "qrsq", "gemm4096", "sgemm", "gemv", "fplu", "cpqr", "tridiag", "bidiag", "hess", "qrmax", "qrlit"):
                 if name == args.workload or (only and name not in only.split(",")):
                     continue
                 try:
