@@ -1420,6 +1420,7 @@ long faer_hip_debug_qr_one_pass_columns(void) { return qr_last_one_pass_columns(
 void faer_hip_debug_qr_fused(int on) { tsqr_debug_fused(on); }
 void faer_hip_debug_qr_one_pass_f64(int on) { tsqr_debug_f64(on); }
 void faer_hip_debug_qr_panels_one_pass(int on) { tsqr_debug_panels(on); }
+void faer_hip_debug_qr_one_pass_shape_rule(long min_rows, long min_rows_per_column) { tsqr_debug_shape_rule(min_rows, min_rows_per_column); }
 void faer_hip_debug_fplu_inplace(int on) { fplu_debug_inplace(on); }
 void faer_hip_debug_level2_force_memory_bodies(int on) { level2_debug_force_memory_bodies(on); }
 void *faer_hip_debug_internal_stream(int which)

@@ -357,6 +357,7 @@ bool loop_is_builtin_wait(FaerHipWaitFn fn); // loop_transport.hip: the loop-bac
 void level2_debug_force_memory_bodies(int on); // debug: tridiag / bidiag / Hessenberg vector kernels never keep their columns in registers
 void tsqr_debug_fused(int on); // debug: 0 = the one-pass QR runs update and Gram as separate launches (rounds 3-5), 1 = fused with look-ahead (default)
 void tsqr_debug_f64(int on); // debug: 0 = fp64 matrices never take the one-pass QR path
+void tsqr_debug_shape_rule(long min_rows, long min_aspect); // debug: shape rule of the whole-matrix one-pass QR path (0 = default)
 void tsqr_debug_panels(int on); // debug: 0 = the classic QR path never factors a panel on the one-pass path
 long qr_last_one_pass_columns(); // debug: columns the one-pass QR path completed in this thread's last factorization (-1: not taken)
 // tall-skinny shapes (skinny.hip): streaming kernels; false if the shape / strides do not qualify

@@ -3301,13 +3301,24 @@ template <typename T> long geqrf_dev(MatV<T> A, MatV<T> H, idx_t blocking_thresh
 		const idx_t m = A.nrows, n = A.ncols, bs = H.nrows;
 		const idx_t size = m < n ? m : n;
 		const bool ref_rejects_all = (double) Lim<T>::eps * 16.0 * (double) m >= 1.0;
-		if (size > 0 && bs > 0 && H.ncols == size && !ref_rejects_all && tsqr_ok(A, bs)) {
+		// A block size of Q_coeff that neither divides a 64-column panel nor is a multiple of it (faer recommends 48 for many moderately
+		// tall shapes): the path runs with 64-column blocks of its own and the caller's blocks are rebuilt from V and the taus (one
+		// batched Gram launch over V: one workgroup per block walks all rows -- 8192 x 64 with blocks of 48: 1.2 ms of rebuild against
+		// 0.44 ms for the whole classic factorization -- so only up to 3072 rows: tools/gpu_qr_shape_rule.py).
+		const bool bs_direct = bs > 0 && (bs % 64 == 0 || 64 % bs == 0);
+		if (size > 0 && bs > 0 && H.ncols == size && !ref_rejects_all && (bs_direct || m <= 3072) && tsqr_ok(A, bs_direct ? bs : 64)) {
 			Scratch taus((size_t) size * sizeof(T));
+			Scratch hown(bs_direct ? 256 : (size_t) 64 * (size_t) size * sizeof(T));
 			int reason = 0;
-			const idx_t done = tsqr_run(A, H, taus.as<T>(), &reason);
+			const idx_t done = tsqr_run(A, bs_direct ? H : MatV<T>{hown.as<T>(), 64, size, 1, 64}, taus.as<T>(), &reason);
 			g_qr_one_pass_columns = (long) done;
-			if (done == size)
+			if (done == size) {
+				if (!bs_direct) {
+					qr_t_blocks_from_taus<T>(A, H, size, taus.as<T>());
+					FH_HIP(hipStreamSynchronize(ctx().stream)); // scratch is released on return
+				}
 				return (long) size;
+			}
 			static const bool verbose = getenv("FAER_HIP_VERBOSE") != nullptr;
 			if (verbose)
 				fprintf(stderr, "faer_hip: qr: one-pass path stopped at column %ld (reason %d); classic path for the rest\n", (long) done, reason);

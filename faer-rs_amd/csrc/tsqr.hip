@@ -2644,9 +2644,20 @@ template <typename T> __global__ __launch_bounds__(256) void tq_range_rest_kerne
 	}
 }
 
+// shape rule of the whole-matrix one-pass path: at least g_tq_min_rows rows and g_tq_min_aspect rows per column
+// (rounds 3-6: 16384 rows, 8 per column.  The path beats the classic one -- with its one-pass panels -- by 1.4-3 x wherever its panels
+// stay tall: tools/gpu_qr_shape_rule.py, 1024 x 256 fp64 2.04 -> 0.60 ms, 3000 x 512 1.95 -> 1.36 ms; with 3 rows per column the last
+// panel still has 2 n + 64 rows)
+static std::atomic<long> g_tq_min_rows{1024}, g_tq_min_aspect{3};
+void tsqr_debug_shape_rule(long min_rows, long min_aspect)
+{
+	g_tq_min_rows.store(min_rows > 0 ? min_rows : 1024);
+	g_tq_min_aspect.store(min_aspect > 0 ? min_aspect : 3);
+}
+
 bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs)
 {
-	if (rs != 1 || cs < m || n < 1 || n > 512 || m < 16384 || m < 8 * n || m >= (1L << 30))
+	if (rs != 1 || cs < m || n < 1 || n > 512 || m < g_tq_min_rows.load() || m < g_tq_min_aspect.load() * n || m >= (1L << 30))
 		return false;
 	// T blocks are written per 64-column panel: a block of Q_coeff is either a whole number of panels or divides one
 	return bs % TQ_PW == 0 || TQ_PW % bs == 0;
@@ -3092,7 +3103,7 @@ bool tsqr_applicable64(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs, const voi
 {
 	if (g_tq_f64.load() == 0)
 		return false;
-	if (rs != 1 || cs < m || n < 1 || n > 512 || m < 16384 || m < 8 * n || m >= (1L << 30))
+	if (rs != 1 || cs < m || n < 1 || n > 512 || m < g_tq_min_rows.load() || m < g_tq_min_aspect.load() * n || m >= (1L << 30))
 		return false;
 	if (cs % 2 != 0 || (uintptr_t) p % 16 != 0) // 16-byte accesses down the columns (faer's Mat pads the column stride to 64 bytes)
 		return false;

@@ -499,12 +499,15 @@ FAER_HIP_API long faer_hip_debug_qr_one_pass_columns(void);
  * same without the raw copy of the panel (what matrices of more than 4.19 M rows run: V = P M as a launch of its own behind U2). */
 FAER_HIP_API void faer_hip_debug_qr_fused(int on);
 /* tests / A-B measurements: 0 = fp64 matrices never take the one-pass tall-skinny QR path (the classic path of rounds 1-6 runs), 1 (default) =
- * they take it under the same shape rule as fp32 (rows >= 16384, rows >= 8 cols, cols <= 512, unit row stride, even column stride). */
+ * they take it under the same shape rule as fp32 (rows >= 1024, rows >= 3 cols, cols <= 512, unit row stride; fp64 also: even column stride, 16-byte aligned columns). */
 FAER_HIP_API void faer_hip_debug_qr_one_pass_f64(int on);
 /* tests / A-B measurements: 0 = the classic QR path (square / wide matrices, rejected panels) factors its panels by the recursion down to
  * the 8-column cooperative leaf as in rounds 1-6, 1 (default) = a panel of up to 64 columns with at least 256 rows (and 4 rows per column) takes the one-pass
  * panel of csrc/tsqr.hip (and the recursion only if that refuses it). */
 FAER_HIP_API void faer_hip_debug_qr_panels_one_pass(int on);
+/* tests / A-B measurements: the shape rule of the whole-matrix one-pass QR path -- at least `min_rows` rows and `min_rows_per_column` rows per
+ * column (0, 0 = the defaults). */
+FAER_HIP_API void faer_hip_debug_qr_one_pass_shape_rule(long min_rows, long min_rows_per_column);
 /* Full-pivot LU: 1 = the in-place path (two launches per step) instead of the one-launch-per-step path between two scratch copies
  * (default 0; identical factors and permutations, tests/test_gpu_factor.py). */
 FAER_HIP_API void faer_hip_debug_fplu_inplace(int on);
