@@ -581,3 +581,34 @@ def test_qr_classic_path_one_pass_panels_rank_deficient(oracle, dtype):
     e = EPS[np.dtype(dtype)]
     q = q_from(F, dqr, dh, m, dtype).astype(np.float64)
     assert np.abs(q @ np.triu(to_host(dqr)).astype(np.float64) - a).max() <= 256 * np.sqrt(m) * e * np.abs(a).max()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("m,n,bs,cols", [(1024, 256, 32, 256), (1100, 100, 32, 100), (2048, 256, 48, 256), (3000, 512, 64, 512), (1536, 512, 48, 512),
+                                         (1024, 340, 40, 340), (4096, 256, 48, -1), (1023, 128, 64, -1), (1024, 342, 64, -1)])
+def test_qr_moderately_tall_one_pass_shape_rule(oracle, m, n, bs, cols, dtype):
+    """the whole-matrix one-pass path from 1024 rows and 3 rows per column (end of round 6; rounds 3-6: 16384 and 8), with blocks of Q_coeff
+    that fit its 64-column panels directly and blocks that do not (T rebuilt from V and the taus, up to 3072 rows); shapes just outside the
+    rule run the classic path.  Factors against the oracle at the classic path's tolerance."""
+    F = init_gpu()
+    rng = np.random.default_rng(m + 7 * n)
+    a = rnd(rng, m, n, dtype)
+    ref, rh = a.copy(order="F"), np.zeros((bs, n), dtype=dtype, order="F")
+    assert oracle.qr_in_place(ref, rh) == n
+    dqr, dh = to_dev(a), to_dev(np.zeros((bs, n), dtype=dtype))
+    assert F.qr_factor_in_place(dqr, dh) == n
+    F.lib().faer_hip_debug_qr_one_pass_columns.restype = C.c_long
+    assert F.lib().faer_hip_debug_qr_one_pass_columns() == cols
+    e = EPS[np.dtype(dtype)]
+    tol = 64 * max(m, n) * e * max(1.0, np.abs(a).max())
+    qr, h = to_host(dqr).astype(np.float64), to_host(dh).astype(np.float64)
+    assert np.abs(qr - ref).max() <= 8 * tol
+    up = np.zeros((bs, n), bool)
+    for j0 in range(0, n, bs):
+        w = min(bs, n - j0)
+        up[:w, j0:j0 + w] = np.triu(np.ones((w, w), bool))
+    assert np.isfinite(h).all()
+    assert np.abs(h - rh)[up].max() <= 8 * tol * max(1.0, np.abs(rh[up]).max())
+    q = q_from(F, dqr, dh, m, dtype).astype(np.float64)
+    assert np.abs(q @ np.triu(qr) - a).max() <= tol
+    assert np.abs(q.T @ q - np.eye(m)).max() <= tol
