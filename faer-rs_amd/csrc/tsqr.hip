@@ -35,6 +35,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "mfma.h"
 
 namespace fh {
 
@@ -2075,62 +2076,87 @@ template <typename T> __global__ __launch_bounds__(256) void tq_tx_general_kerne
 // T blocks) is the code above instantiated for double.  Schedule: the plain one (Gram, panel, y, update per panel on one stream).
 // ------------------------------------------------------------------------------------------------
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-constexpr int TQ_LP64 = 18; // LDS pitch (doubles) of one staged column of a 16-row chunk: 16-byte aligned; 16 lanes x 16 bytes hit 64 distinct banks
+constexpr int TQ_LP64 = 18; // LDS pitch (doubles) of one staged column of a 16-row chunk: 16-byte aligned (36 dwords: the 16 lanes of a b128 group hit distinct banks but for two pairs)
 
-struct TqGram64Args {
-	const double *P; // A[r0, c0]
-	const double *X; // A[r0, cx]
-	long ld;
-	int rows, w, t, tp; // rows from r0 down, panel width, trailing columns of this launch, t rounded up to 64 (32 NC)
-	int nsub, nchunks;  // 16-row sub-chunks per chunk (4 / 2 / 1 for <= 64 / <= 128 / more staged columns), chunks
-	int want_g, want_sq;
-	double *Gp; // [grid][64 * 64]
-	double *Cp; // [grid][64 * tp]
-	double *Sp; // [grid][256]
-	const int *stat;
-	int c0;
-	double *A1s; // want_g: the panel's top 64 x 64 block, column major
+// 16-byte vectors of the scalar type: RPV consecutive rows of a column per load / store
+template <typename T> struct TqVec;
+template <> struct TqVec<double> {
+	typedef f64x2 v;
+	static constexpr int RPV = 2;
+};
+template <> struct TqVec<float> {
+	typedef f32x4 v;
+	static constexpr int RPV = 4;
 };
 
-template <bool VEC> static __device__ __forceinline__ f64x2 tq_ld2(const double *p, int r, int rows)
+template <typename T> struct TqGramTArgs {
+	const T *P; // A[r0, c0]
+	const T *X; // A[r0, cx]
+	long ld;
+	int rows, w, t, tp; // rows from r0 down, panel width, trailing columns of this launch, t rounded up to 64 (32 NC)
+	int nsub, nchunks;  // sub-chunks (8 RPV rows each) per chunk (4 / 2 / 1 for <= 64 / <= 128 / more staged columns), chunks
+	int want_g, want_sq;
+	double *Gp; // [grid][64 * 64]
+	T *Cp;	    // [grid][64 * tp]
+	T *Sp;	    // [grid][256]
+	const int *stat;
+	int c0;
+	T *A1s; // want_g: the panel's top 64 x 64 block, column major
+};
+
+// bounds-checked 16-byte access (the partial chunk of a launch, views whose rows are not 16-byte aligned)
+template <typename T, bool VEC> static __device__ __forceinline__ typename TqVec<T>::v tq_ldv(const T *p, int r, int rows)
 {
-	f64x2 v = {0.0, 0.0};
-	if (VEC && r + 1 < rows) {
-		v = *reinterpret_cast<const f64x2 *>(p + r);
+	constexpr int RPV = TqVec<T>::RPV;
+	typename TqVec<T>::v v;
+#pragma unroll
+	for (int e = 0; e < RPV; ++e)
+		v[e] = (T) 0;
+	if (VEC && r + RPV - 1 < rows) {
+		v = *reinterpret_cast<const typename TqVec<T>::v *>(p + r);
 	} else {
-		if (r < rows)
-			v[0] = p[r];
-		if (r + 1 < rows)
-			v[1] = p[r + 1];
+#pragma unroll
+		for (int e = 0; e < RPV; ++e)
+			if (r + e < rows)
+				v[e] = p[r + e];
 	}
 	return v;
 }
-template <bool VEC> static __device__ __forceinline__ void tq_st2(double *p, int r, int rows, f64x2 v)
+template <typename T, bool VEC> static __device__ __forceinline__ void tq_stv(T *p, int r, int rows, typename TqVec<T>::v v)
 {
-	if (VEC && r + 1 < rows) {
-		*reinterpret_cast<f64x2 *>(p + r) = v;
+	constexpr int RPV = TqVec<T>::RPV;
+	if (VEC && r + RPV - 1 < rows) {
+		*reinterpret_cast<typename TqVec<T>::v *>(p + r) = v;
 	} else {
-		if (r < rows)
-			p[r] = v[0];
-		if (r + 1 < rows)
-			p[r + 1] = v[1];
+#pragma unroll
+		for (int e = 0; e < RPV; ++e)
+			if (r + e < rows)
+				p[r + e] = v[e];
 	}
 }
 
-// G = P^T P (lower 16 x 16 tiles) and C = P^T X, per-workgroup partial sums.  One persistent workgroup of 512 threads per CU.
-// A chunk is 32 KB of [P | X]: 16 rows of <= 256 columns, or -- narrow launches -- 32 / 64 rows of <= 128 / 64 columns as 2 / 4
-// sub-chunks side by side (a 16-row chunk of 64 columns is 8 KB: a memory round trip per 8 KB).  Thread (q = tid & 7,
-// cg = tid >> 3) loads rows 2 q, 2 q + 1 of the staged columns cg + 64 i: eight lanes cover the 128 bytes a column contributes to a
-// sub-chunk.  FOUR chunks per workgroup are in flight in registers (64 staging registers) and the LDS image is double buffered:
-// per chunk ONE barrier that leaves the global loads in flight; the first version (two 256-thread workgroups per CU, one chunk
-// ahead each) ran at 2.1-2.4 TB/s.  Wavefront (ia = wv & 3, hf = wv >> 2) owns the panel columns 16 ia .. + 15 (rows of G and C) and
-// every other column tile: its A operand is read once per sub-chunk, the B operand once per tile; lane (i = l & 15, g = l >> 4)
-// takes rows 4 g .. 4 g + 3 of its column as the four k-slices -- the order of the rows inside a Gram sum is free.
-// Balance at t = 192: 58 tiles x 4 MFMAs x 64 cycles per 32 KB chunk and four SIMDs = 4.5-4.8 TB/s chip-wide at the fp64 matrix-core
-// peak: the kernel is bound by both at once.
-template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(const TqGram64Args a)
+// G = P^T P (lower 16 x 16 tiles, fp64 matrix cores: for fp32 data the products are exact) and C = P^T X (matrix cores of the scalar
+// type), per-workgroup partial sums.  One persistent workgroup of 512 threads per CU.  A chunk is 32 KB of [P | X]: one sub-chunk
+// (8 RPV rows: 16 of fp64, 32 of fp32) of <= 256 columns, or -- narrow launches -- 2 / 4 sub-chunks of <= 128 / 64 columns side by
+// side (a single sub-chunk of 64 columns is 8 KB: a memory round trip per 8 KB).  Thread (q = tid & 7, cg = tid >> 3) loads rows
+// RPV q .. of the staged columns cg + 64 i: eight lanes cover the 128 bytes a column contributes to a sub-chunk.  FOUR chunks per
+// workgroup are in flight in registers (64 staging registers) and the LDS image is double buffered: per chunk ONE barrier that
+// leaves the global loads in flight; the first version (two 256-thread workgroups per CU, one chunk ahead each) ran at
+// 2.1-2.4 TB/s.  Wavefront (ia = wv & 3, hf = wv >> 2) owns the panel columns 16 ia .. + 15 (rows of G and C) and every other
+// column tile: its A operand is read once per sub-chunk, the B operand once per tile; lane (i = l & 15, g = l >> 4) takes the rows
+// KS g .. KS g + KS - 1 of its column (KS = 2 RPV) as k-slices -- the order of the rows inside a Gram sum is free.
+// Balance (fp64) at t = 192: 58 tiles x 4 MFMAs x 64 cycles per 32 KB chunk and four SIMDs = 4.5-4.8 TB/s chip-wide at the fp64
+// matrix-core peak: the kernel is bound by both at once.
+template <typename T, int NC> __global__ __launch_bounds__(512, 1) void tq_gramT_kernel(const TqGramTArgs<T> a)
 {
-	__shared__ double sm[2][256 * TQ_LP64];
+	typedef typename TqVec<T>::v vec_t;
+	typedef typename Mfma<T>::acc_t cacc_t;
+	constexpr int RPV = TqVec<T>::RPV;
+	constexpr int SR = 8 * RPV;   // rows of a sub-chunk
+	constexpr int KS = 2 * RPV;   // k-slices of a lane per sub-chunk (32 bytes: two vectors)
+	constexpr int LP = SR + RPV;  // LDS pitch of a staged column (18 doubles / 36 floats = 36 dwords: see TQ_LP64)
+	static_assert(LP * sizeof(T) == TQ_LP64 * 8, "pitch");
+	__shared__ T sm[2][256 * LP];
 	if (tq_skip(a.stat, a.c0))
 		return;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -2140,19 +2166,22 @@ template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(con
 	const int nslot = (ncol + 63) >> 6;	      // 64-column load slots per sub-chunk: 1 .. 4
 	const int nsub = a.nsub;		      // sub-chunks per chunk: 4 / nslot
 	const int ncolp = nslot * 64;		      // staged columns per sub-chunk
-	f64x4 gacc[2], cacc[NC > 0 ? NC : 1];
+	f64x4 gacc[2];
+	cacc_t cacc[NC > 0 ? NC : 1];
 #pragma unroll
 	for (int i = 0; i < 2; ++i)
 		gacc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
 	for (int i = 0; i < (NC > 0 ? NC : 1); ++i)
-		cacc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			cacc[i][r] = (T) 0;
 	double sq[4] = {0.0, 0.0, 0.0, 0.0};
 	// slot i of a thread: sub-chunk si, column ci of [P | X]; a slot without a column (a column beyond the launch's, the fourth slot of
 	// a 192-column chunk) loads from column 0 of the panel and stages zeros into a part of the image no product reads
 	int ldsoff[4], roff[4];
 	bool act[4];
-	const double *colp[4];
+	const T *colp[4];
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		const int si = i / nslot, ci = (i - si * nslot) * 64 + cg;
@@ -2160,10 +2189,10 @@ template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(con
 		const int cc = isp ? ci : ci - TQ_PW;
 		act[i] = si < nsub && (isp ? cc < a.w : cc < a.t);
 		colp[i] = act[i] ? (isp ? a.P : a.X) + (long) cc * a.ld : a.P;
-		roff[i] = act[i] ? 16 * si + 2 * q : 2 * q;
-		ldsoff[i] = (si * ncolp + ci) * TQ_LP64 + 2 * q; // (si * ncolp + ci < 256 always)
+		roff[i] = act[i] ? SR * si + RPV * q : RPV * q;
+		ldsoff[i] = (si * ncolp + ci) * LP + RPV * q; // (si * ncolp + ci < 256 always)
 	}
-	const int crows = 16 * nsub;
+	const int crows = SR * nsub;
 	// A workgroup owns a contiguous run of FULL chunks; the partial chunk at the end of the matrix (if any) is the last workgroup's
 	// epilogue.  The main loop is straight-line code: unconditional 16-byte loads, counted waits.  (Loads under per-lane branches --
 	// the bounds checks of the first version -- share their destination registers with the scalar loads of the other branch, the
@@ -2174,76 +2203,84 @@ template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(con
 	const int first = (int) blockIdx.x * cpw;
 	const int nmine = nfull - first < 0 ? 0 : (nfull - first < cpw ? nfull - first : cpw);
 	if (blockIdx.x == 0 && a.want_g) {
-		// the panel's top block for the panel kernel (64 rows: rows >= 8 n)
-		for (int e = tid; e < 64 * 32; e += 512) {
-			const int c = e >> 5, rp = e & 31;
-			f64x2 v = {0.0, 0.0};
+		// the panel's top block for the panel kernel (64 rows: rows >= 3 n)
+		for (int e = tid; e < 64 * (64 / RPV); e += 512) {
+			const int c = e / (64 / RPV), rp = e % (64 / RPV);
+			vec_t v;
+#pragma unroll
+			for (int x = 0; x < RPV; ++x)
+				v[x] = (T) 0;
 			if (c < a.w)
-				v = *reinterpret_cast<const f64x2 *>(a.P + (long) c * a.ld + 2 * rp);
-			*reinterpret_cast<f64x2 *>(a.A1s + c * 64 + 2 * rp) = v;
+				v = *reinterpret_cast<const vec_t *>(a.P + (long) c * a.ld + RPV * rp);
+			*reinterpret_cast<vec_t *>(a.A1s + c * 64 + RPV * rp) = v;
 		}
 	}
-	f64x2 s0[4], s1[4], s2[4], s3[4];
-	auto load_chunk = [&](int j, f64x2 (&st)[4]) { // chunk min(j, nmine - 1) of this workgroup
+	vec_t s0[4], s1[4], s2[4], s3[4];
+	auto load_chunk = [&](int j, vec_t (&st)[4]) { // chunk min(j, nmine - 1) of this workgroup
 		const int jj = j < nmine ? j : nmine - 1;
 		const long r0 = (long) (first + jj) * crows;
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
-			st[i] = *reinterpret_cast<const f64x2 *>(colp[i] + r0 + roff[i]);
+			st[i] = *reinterpret_cast<const vec_t *>(colp[i] + r0 + roff[i]);
 	};
-	auto stage = [&](int j, const f64x2 (&st)[4], double count) { // into LDS half j & 1
-		double *dst = sm[j & 1];
+	auto stage = [&](int j, const vec_t (&st)[4], double count) { // into LDS half j & 1
+		T *dst = sm[j & 1];
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			const f64x2 v = act[i] ? st[i] : f64x2{0.0, 0.0};
-			*reinterpret_cast<f64x2 *>(&dst[ldsoff[i]]) = v;
-			sq[i] += count * (v[0] * v[0] + v[1] * v[1]);
+			vec_t v = st[i];
+			double s = 0.0;
+#pragma unroll
+			for (int x = 0; x < RPV; ++x) {
+				v[x] = act[i] ? v[x] : (T) 0;
+				s += (double) v[x] * (double) v[x];
+			}
+			*reinterpret_cast<vec_t *>(&dst[ldsoff[i]]) = v;
+			sq[i] += count * s;
 		}
 	};
-	// NC column tiles of C per wavefront (a.tp == 32 NC): every B operand of a sub-chunk is requested before the first product,
-	// consecutive MFMAs go to different accumulators
+	// NC column tiles of C per wavefront (a.tp == 32 NC): the B operands of two tiles are requested together, consecutive MFMAs go to
+	// different accumulators
 	auto products = [&](int j) {
-		const double *src = sm[j & 1];
-		const int ro = 4 * (lane >> 4);
+		const T *src = sm[j & 1];
+		const int ro = KS * (lane >> 4);
 #pragma unroll 1
 		for (int sb = 0; sb < nsub; ++sb) {
-			const double *base = src + (long) sb * ncolp * TQ_LP64 + (lane & 15) * TQ_LP64 + ro;
-			const double *ap = base + 16 * ia * TQ_LP64;
-			const f64x2 a01 = *reinterpret_cast<const f64x2 *>(ap), a23 = *reinterpret_cast<const f64x2 *>(ap + 2);
-			// (groups of two tiles: their B operands are requested together, consecutive MFMAs go to different accumulators)
+			const T *base = src + (long) sb * ncolp * LP + (lane & 15) * LP + ro;
+			const T *ap = base + 16 * ia * LP;
+			const vec_t alo = *reinterpret_cast<const vec_t *>(ap), ahi = *reinterpret_cast<const vec_t *>(ap + RPV);
 #pragma unroll
 			for (int c0 = 0; c0 < NC; c0 += 2) {
-				f64x2 b01[2], b23[2];
+				vec_t blo[2], bhi[2];
 #pragma unroll
 				for (int c = 0; c < 2; ++c) {
-					const double *bp = base + (TQ_PW + 16 * (2 * (c0 + c) + hf)) * TQ_LP64;
-					b01[c] = *reinterpret_cast<const f64x2 *>(bp);
-					b23[c] = *reinterpret_cast<const f64x2 *>(bp + 2);
+					const T *bp = base + (TQ_PW + 16 * (2 * (c0 + c) + hf)) * LP;
+					blo[c] = *reinterpret_cast<const vec_t *>(bp);
+					bhi[c] = *reinterpret_cast<const vec_t *>(bp + RPV);
 				}
 #pragma unroll
-				for (int c = 0; c < 2; ++c)
-					cacc[c0 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b01[c][0], cacc[c0 + c], 0, 0, 0);
+				for (int x = 0; x < RPV; ++x)
 #pragma unroll
-				for (int c = 0; c < 2; ++c)
-					cacc[c0 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b01[c][1], cacc[c0 + c], 0, 0, 0);
+					for (int c = 0; c < 2; ++c)
+						cacc[c0 + c] = Mfma<T>::run(alo[x], blo[c][x], cacc[c0 + c]);
 #pragma unroll
-				for (int c = 0; c < 2; ++c)
-					cacc[c0 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b23[c][0], cacc[c0 + c], 0, 0, 0);
+				for (int x = 0; x < RPV; ++x)
 #pragma unroll
-				for (int c = 0; c < 2; ++c)
-					cacc[c0 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b23[c][1], cacc[c0 + c], 0, 0, 0);
+					for (int c = 0; c < 2; ++c)
+						cacc[c0 + c] = Mfma<T>::run(ahi[x], bhi[c][x], cacc[c0 + c]);
 			}
 			if (a.want_g) {
 #pragma unroll
 				for (int u = 0; u < 2; ++u) {
 					const int jb = 2 * hf + u;
 					if (jb <= ia) { // wave uniform
-						const double *bp = base + 16 * jb * TQ_LP64;
-						const f64x2 g01 = *reinterpret_cast<const f64x2 *>(bp), g23 = *reinterpret_cast<const f64x2 *>(bp + 2);
-						gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], g01[0], gacc[u], 0, 0, 0);
-						gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], g01[1], gacc[u], 0, 0, 0);
-						gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], g23[0], gacc[u], 0, 0, 0);
-						gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], g23[1], gacc[u], 0, 0, 0);
+						const T *bp = base + 16 * jb * LP;
+						const vec_t glo = *reinterpret_cast<const vec_t *>(bp), ghi = *reinterpret_cast<const vec_t *>(bp + RPV);
+#pragma unroll
+						for (int x = 0; x < RPV; ++x)
+							gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double) alo[x], (double) glo[x], gacc[u], 0, 0, 0);
+#pragma unroll
+						for (int x = 0; x < RPV; ++x)
+							gacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double) ahi[x], (double) ghi[x], gacc[u], 0, 0, 0);
 					}
 				}
 			}
@@ -2260,7 +2297,7 @@ template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(con
 		stage(0, s0, 1.0);
 		load_chunk(4, s0);
 		tq_lds_barrier();
-#define TQ_G64_STEP(J, SN)                                                                                                                  \
+#define TQ_GT_STEP(J, SN)                                                                                                                   \
 	{                                                                                                                                   \
 		stage((J) + 1, SN, (J) + 1 < nmine ? 1.0 : 0.0);                                                                            \
 		load_chunk((J) + 5, SN);                                                                                                    \
@@ -2270,35 +2307,37 @@ template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(con
 		int j = 0;
 #pragma unroll 1
 		for (; j + 3 < nmine; j += 4) {
-			TQ_G64_STEP(j, s1)
-			TQ_G64_STEP(j + 1, s2)
-			TQ_G64_STEP(j + 2, s3)
-			TQ_G64_STEP(j + 3, s0)
+			TQ_GT_STEP(j, s1)
+			TQ_GT_STEP(j + 1, s2)
+			TQ_GT_STEP(j + 2, s3)
+			TQ_GT_STEP(j + 3, s0)
 		}
 		// (the last 0 .. 3 chunks)
 		if (j < nmine)
-			TQ_G64_STEP(j, s1)
+			TQ_GT_STEP(j, s1)
 		if (j + 1 < nmine)
-			TQ_G64_STEP(j + 1, s2)
+			TQ_GT_STEP(j + 1, s2)
 		if (j + 2 < nmine)
-			TQ_G64_STEP(j + 2, s3)
-#undef TQ_G64_STEP
+			TQ_GT_STEP(j + 2, s3)
+#undef TQ_GT_STEP
 	}
 	if (blockIdx.x == gridDim.x - 1 && nfull * crows < a.rows) {
 		// the partial chunk: bounds-checked loads
 		const long r0 = (long) nfull * crows;
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			s0[i] = f64x2{0.0, 0.0};
+#pragma unroll
+			for (int x = 0; x < RPV; ++x)
+				s0[i][x] = (T) 0;
 			if (act[i])
-				s0[i] = tq_ld2<true>(colp[i] + r0, roff[i], a.rows - (int) r0);
+				s0[i] = tq_ldv<T, true>(colp[i] + r0, roff[i], a.rows - (int) r0);
 		}
 		__syncthreads();
 		stage(0, s0, 1.0);
 		__syncthreads();
 		products(0);
 	}
-	// f64 16x16x4 result map: col = lane & 15, row = (lane >> 4) + 4 * reg
+	// result map of the 16x16x4 forms: col = lane & 15, row = Mfma<.>::row(reg, lane >> 4)
 	const long blk = blockIdx.x;
 	if (a.want_g) {
 #pragma unroll
@@ -2307,7 +2346,7 @@ template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(con
 			if (jb <= ia) {
 #pragma unroll
 				for (int r = 0; r < 4; ++r)
-					a.Gp[blk * 4096 + (16 * ia + (lane >> 4) + 4 * r) * 64 + 16 * jb + (lane & 15)] = gacc[u][r];
+					a.Gp[blk * 4096 + (16 * ia + Mfma<double>::row(r, lane >> 4)) * 64 + 16 * jb + (lane & 15)] = gacc[u][r];
 			}
 		}
 	}
@@ -2316,7 +2355,7 @@ template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(con
 		const int cb = 2 * c + hf;
 #pragma unroll
 		for (int r = 0; r < 4; ++r)
-			a.Cp[blk * 64 * a.tp + (long) (16 * ia + (lane >> 4) + 4 * r) * a.tp + 16 * cb + (lane & 15)] = cacc[c][r];
+			a.Cp[blk * 64 * a.tp + (long) (16 * ia + Mfma<T>::row(r, lane >> 4)) * a.tp + 16 * cb + (lane & 15)] = cacc[c][r];
 	}
 	if (a.want_sq) {
 		// the slots of a thread that hold the same column (sub-chunks) are added in a fixed order
@@ -2333,7 +2372,7 @@ template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(con
 			v += __shfl_xor(v, 2);
 			v += __shfl_xor(v, 4);
 			if (q == 0 && i < nslot)
-				a.Sp[blk * 256 + i * 64 + cg] = v;
+				a.Sp[blk * 256 + i * 64 + cg] = (T) v;
 		}
 	}
 }
@@ -2341,31 +2380,35 @@ template <int NC> __global__ __launch_bounds__(512, 1) void tq_gram64_kernel(con
 // update: X <- X - P Y on a strip of <= 192 trailing columns and, if do_v, V = P M over the panel (at most 16 column tiles of 16
 // together: the whole trailing matrix of a 256-column factorization in ONE launch per panel).  The result tile is the TRANSPOSE of
 // the strip's tile: D[i][j] = X[row j][column i] (lanes along the rows), so the A operand is (-Y)^T / M^T -- kept in registers for
-// the whole launch, tiles wv and wv + 8 belong to wavefront wv of eight -- and the B operand the panel rows, staged per 32-row
-// chunk through LDS (16 KB).  A lane owns the row PAIR 2 j, 2 j + 1 of a chunk: 16-byte loads and stores, two tiles per column
-// tile.  The strip's tiles and the panel rows of the NEXT chunk are loaded before the products of this one (first version: the
-// strip's loads at the head of their own iteration, two 256-thread workgroups per CU covering for each other: 3.2-3.4 TB/s).
-// Chunks are visited from the last rows up: the Gram pass in front of this launch ended there, the one behind it starts at the top.
-// Balance: 2 x 64 x 16 x 32 flop per 8 KB read + written: at the fp64 matrix-core peak the strip would stream at 9-11 TB/s -- the
-// kernel is HBM bound.
-struct TqUpd64Args {
-	double *P; // A[r1, c0], r1 = first row below the top block
-	double *X; // A[r1, cx + coff]
+// the whole launch, tiles wv and wv + 8 belong to wavefront wv of eight -- and the B operand the panel rows, staged per chunk of
+// 16 RPV rows (32 of fp64, 64 of fp32) through LDS (16 KB).  A lane owns RPV consecutive rows of a chunk: 16-byte loads and stores,
+// RPV tiles per column tile.  The strip's tiles and the panel rows of the NEXT chunk are loaded before the products of this one
+// (first version: the strip's loads at the head of their own iteration, two 256-thread workgroups per CU covering for each other:
+// 3.2-3.4 TB/s).  Chunks are visited from the last rows up: the Gram pass in front of this launch ended there, the one behind it
+// starts at the top.  Balance (fp64): 2 x 64 x 16 x 32 flop per 8 KB read + written: at the fp64 matrix-core peak the strip would
+// stream at 9-11 TB/s -- the kernel is HBM bound.
+template <typename T> struct TqUpdTArgs {
+	T *P; // A[r1, c0], r1 = first row below the top block
+	T *X; // A[r1, cx + coff]
 	long ld;
 	int rows, w, ts; // rows from r1 down; strip width
-	const double *Yn; // -Y, row major 64 x typ
+	const T *Yn;	 // -Y, row major 64 x typ
 	int typ, coff;
-	const double *Mn; // M, row major 64 x 64
+	const T *Mn; // M, row major 64 x 64
 	int do_v;
-	int nchunks; // 32-row chunks
+	int nchunks; // chunks of 16 RPV rows
 	const int *stat;
 	int c0;
 };
-constexpr int TQ_LPP = 34; // LDS pitch (doubles) of a staged panel column of a 32-row chunk
 
-template <bool VEC> __global__ __launch_bounds__(512, 1) void tq_update64_kernel(const TqUpd64Args a)
+template <typename T, bool VEC> __global__ __launch_bounds__(512, 1) void tq_updateT_kernel(const TqUpdTArgs<T> a)
 {
-	__shared__ double Pl[64 * TQ_LPP];
+	typedef typename TqVec<T>::v vec_t;
+	typedef typename Mfma<T>::acc_t acc_t;
+	constexpr int RPV = TqVec<T>::RPV;
+	constexpr int CR = 16 * RPV;  // rows of a chunk
+	constexpr int LPP = CR + RPV; // LDS pitch of a staged panel column
+	__shared__ T Pl[64 * LPP];
 	if (tq_skip(a.stat, a.c0))
 		return;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -2373,100 +2416,115 @@ template <bool VEC> __global__ __launch_bounds__(512, 1) void tq_update64_kernel
 	const int nx = (a.ts + 15) >> 4;
 	const int nt = nx + (a.do_v ? 4 : 0);
 	// A operands: ya[u][ks] = A[i = li][k = 4 ks + g] of tile wv + 8 u
-	double ya[2][16];
+	T ya[2][16];
 #pragma unroll
 	for (int u = 0; u < 2; ++u) {
 		const int tl = wv + 8 * u;
 		const bool isx = tl < nx, isv = !isx && tl < nt;
 		const int col = isx ? 16 * tl + li : 16 * (tl - nx) + li;
 		const bool ok = isx ? col < a.ts : (isv && col < a.w);
-		const double *src = isx ? a.Yn + a.coff + col : a.Mn + col;
+		const T *src = isx ? a.Yn + a.coff + col : a.Mn + col;
 		const long step = isx ? (long) a.typ : 64L;
 #pragma unroll
 		for (int ks = 0; ks < 16; ++ks)
-			ya[u][ks] = ok && (4 * ks + g) < a.w ? src[(long) (4 * ks + g) * step] : 0.0;
+			ya[u][ks] = ok && (4 * ks + g) < a.w ? src[(long) (4 * ks + g) * step] : (T) 0;
 	}
-	const int pq = tid & 15, pc = tid >> 4; // staging: rows 2 pq, 2 pq + 1 of the panel columns pc, pc + 32
-	f64x2 pst[2];
-	f64x2 xv[2][4], xn[2][4];
-	// chunk ch of the launch is rows 32 (nchunks - 1 - ch) ..: chunk 0 is the one that may be partial
-	auto load_checked = [&](int ch, f64x2 (&x)[2][4]) {
+	const int pq = tid & 15, pc = tid >> 4; // staging: rows RPV pq .. of the panel columns pc, pc + 32
+	vec_t pst[2];
+	vec_t xv[2][4], xn[2][4];
+	// chunk ch of the launch is rows CR (nchunks - 1 - ch) ..: chunk 0 is the one that may be partial.  Register r of a result tile is
+	// the strip's column Mfma<T>::row(r, g) of the tile.
+	auto load_checked = [&](int ch, vec_t (&x)[2][4]) {
 		const int cr = a.nchunks - 1 - ch;
-		const int rb = cr * 32 + 2 * pq, rbase = cr * 32 + 2 * li;
+		const int rb = cr * CR + RPV * pq, rbase = cr * CR + RPV * li;
 #pragma unroll
 		for (int i = 0; i < 2; ++i) {
 			const int c = pc + 32 * i;
-			pst[i] = f64x2{0.0, 0.0};
+#pragma unroll
+			for (int e = 0; e < RPV; ++e)
+				pst[i][e] = (T) 0;
 			if (c < a.w)
-				pst[i] = tq_ld2<VEC>(a.P + (long) c * a.ld, rb, a.rows);
+				pst[i] = tq_ldv<T, VEC>(a.P + (long) c * a.ld, rb, a.rows);
 		}
 #pragma unroll
 		for (int u = 0; u < 2; ++u) {
 			const int tl = wv + 8 * u;
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
-				x[u][r] = f64x2{0.0, 0.0};
-				const int col = 16 * tl + g + 4 * r;
+#pragma unroll
+				for (int e = 0; e < RPV; ++e)
+					x[u][r][e] = (T) 0;
+				const int col = 16 * tl + Mfma<T>::row(r, g);
 				if (tl < nx && col < a.ts)
-					x[u][r] = tq_ld2<VEC>(a.X + (long) col * a.ld, rbase, a.rows);
+					x[u][r] = tq_ldv<T, VEC>(a.X + (long) col * a.ld, rbase, a.rows);
 			}
 		}
 	};
-	// a chunk inside the matrix: unconditional 16-byte loads (see tq_gram64_kernel) -- panel columns beyond w read column 0 and are
+	// a chunk inside the matrix: unconditional 16-byte loads (see tq_gramT_kernel) -- panel columns beyond w read column 0 and are
 	// zeroed when staged, tiles beyond the strip read a valid column and never use or store it
-	const double *pcol[2], *xcol[2][4];
+	const T *pcol[2], *xcol[2][4];
 #pragma unroll
 	for (int i = 0; i < 2; ++i)
-		pcol[i] = a.P + (long) (pc + 32 * i < a.w ? pc + 32 * i : 0) * a.ld + 2 * pq;
+		pcol[i] = a.P + (long) (pc + 32 * i < a.w ? pc + 32 * i : 0) * a.ld + RPV * pq;
 #pragma unroll
 	for (int u = 0; u < 2; ++u)
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
-			const int col = 16 * (wv + 8 * u) + g + 4 * r;
-			xcol[u][r] = (a.ts > 0 ? a.X + (long) (col < a.ts ? col : a.ts - 1) * a.ld : a.P) + 2 * li;
+			const int col = 16 * (wv + 8 * u) + Mfma<T>::row(r, g);
+			xcol[u][r] = (a.ts > 0 ? a.X + (long) (col < a.ts ? col : a.ts - 1) * a.ld : a.P) + RPV * li;
 		}
-	auto load_full = [&](int ch, f64x2 (&x)[2][4]) {
-		const long r0 = (long) (a.nchunks - 1 - ch) * 32;
+	auto load_full = [&](int ch, vec_t (&x)[2][4]) {
+		const long r0 = (long) (a.nchunks - 1 - ch) * CR;
 #pragma unroll
 		for (int i = 0; i < 2; ++i)
-			pst[i] = *reinterpret_cast<const f64x2 *>(pcol[i] + r0);
+			pst[i] = *reinterpret_cast<const vec_t *>(pcol[i] + r0);
 #pragma unroll
 		for (int u = 0; u < 2; ++u)
 #pragma unroll
 			for (int r = 0; r < 4; ++r)
-				x[u][r] = *reinterpret_cast<const f64x2 *>(xcol[u][r] + r0);
+				x[u][r] = *reinterpret_cast<const vec_t *>(xcol[u][r] + r0);
 	};
 	auto stage_panel = [&]() {
 #pragma unroll
-		for (int i = 0; i < 2; ++i)
-			*reinterpret_cast<f64x2 *>(&Pl[(pc + 32 * i) * TQ_LPP + 2 * pq]) = pc + 32 * i < a.w ? pst[i] : f64x2{0.0, 0.0};
+		for (int i = 0; i < 2; ++i) {
+			vec_t v = pst[i];
+#pragma unroll
+			for (int e = 0; e < RPV; ++e)
+				v[e] = pc + 32 * i < a.w ? v[e] : (T) 0;
+			*reinterpret_cast<vec_t *>(&Pl[(pc + 32 * i) * LPP + RPV * pq]) = v;
+		}
 	};
-	auto compute_store = [&](int ch, const f64x2 (&x)[2][4]) {
-		const int rbase = (a.nchunks - 1 - ch) * 32 + 2 * li;
+	auto compute_store = [&](int ch, const vec_t (&x)[2][4]) {
+		const int rbase = (a.nchunks - 1 - ch) * CR + RPV * li;
 #pragma unroll
 		for (int u = 0; u < 2; ++u) {
 			const int tl = wv + 8 * u;
 			if (tl < nt) { // wave uniform
 				const bool isx = tl < nx;
-				f64x4 acc0, acc1;
+				acc_t acc[RPV];
 #pragma unroll
-				for (int r = 0; r < 4; ++r) {
-					acc0[r] = isx ? x[u][r][0] : 0.0;
-					acc1[r] = isx ? x[u][r][1] : 0.0;
-				}
+				for (int e = 0; e < RPV; ++e)
+#pragma unroll
+					for (int r = 0; r < 4; ++r)
+						acc[e][r] = isx ? x[u][r][e] : (T) 0;
 #pragma unroll
 				for (int ks = 0; ks < 16; ++ks) {
-					const f64x2 b = *reinterpret_cast<const f64x2 *>(&Pl[(4 * ks + g) * TQ_LPP + 2 * li]);
-					acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][ks], b[0], acc0, 0, 0, 0);
-					acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][ks], b[1], acc1, 0, 0, 0);
+					const vec_t b = *reinterpret_cast<const vec_t *>(&Pl[(4 * ks + g) * LPP + RPV * li]);
+#pragma unroll
+					for (int e = 0; e < RPV; ++e)
+						acc[e] = Mfma<T>::run(ya[u][ks], b[e], acc[e]);
 				}
-				double *dst = isx ? a.X + (long) (16 * tl) * a.ld : a.P + (long) (16 * (tl - nx)) * a.ld;
+				T *dst = isx ? a.X + (long) (16 * tl) * a.ld : a.P + (long) (16 * (tl - nx)) * a.ld;
 				const int nvalid = isx ? a.ts - 16 * tl : a.w - 16 * (tl - nx);
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
-					const int cl = g + 4 * r;
+					const int cl = Mfma<T>::row(r, g);
+					vec_t o;
+#pragma unroll
+					for (int e = 0; e < RPV; ++e)
+						o[e] = acc[e][r];
 					if (cl < nvalid)
-						tq_st2<VEC>(dst + (long) cl * a.ld, rbase, a.rows, f64x2{acc0[r], acc1[r]});
+						tq_stv<T, VEC>(dst + (long) cl * a.ld, rbase, a.rows, o);
 				}
 			}
 		}
@@ -2475,7 +2533,7 @@ template <bool VEC> __global__ __launch_bounds__(512, 1) void tq_update64_kernel
 	const int cpw = (a.nchunks + (int) gridDim.x - 1) / (int) gridDim.x;
 	int ch = (int) blockIdx.x * cpw;
 	const int chend = ch + cpw < a.nchunks ? ch + cpw : a.nchunks;
-	const int nchecked = VEC ? ((a.rows & 31) != 0 ? 1 : 0) : a.nchunks; // chunks [0, nchecked) take the bounds-checked path
+	const int nchecked = VEC ? ((a.rows % CR) != 0 ? 1 : 0) : a.nchunks; // chunks [0, nchecked) take the bounds-checked path
 	for (; ch < chend && ch < nchecked; ++ch) {
 		load_checked(ch, xv);
 		__syncthreads();
@@ -2667,8 +2725,14 @@ bool tsqr_applicable(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs)
 // completed (a multiple of 64, or n); the state is then that of the reference algorithm after those columns: R and
 // V in place, the T blocks in H, taus[j] = T_jj, every reflector applied to all columns on the right.
 // `reason` reports why it stopped early (TQ_FAIL_*).
+template <typename T> static idx_t tsqr_factor_plain(MatV<T> A, MatV<T> H, T *taus, int *reason, idx_t rows_above);
+
 idx_t tsqr_factor(MatV<float> A, MatV<float> H, float *taus, int *reason, idx_t rows_above)
 {
+	// schedule 3 (faer_hip_debug_qr_fused): the plain schedule on the streaming kernels of the end of round 6 (tq_gramT_kernel /
+	// tq_updateT_kernel, written for fp64 data); needs 16-byte aligned columns
+	if (g_tq_fused.load() == 3 && A.cs % 4 == 0 && (uintptr_t) A.p % 16 == 0)
+		return tsqr_factor_plain<float>(A, H, taus, reason, rows_above);
 	const idx_t m = A.nrows, n = A.ncols, ld = A.cs, bs = H.nrows;
 	hipStream_t s = ctx().stream;
 	const bool vec = (ld % 4 == 0) && ((uintptr_t) A.p % 16 == 0);
@@ -3110,29 +3174,30 @@ bool tsqr_applicable64(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs, const voi
 	return bs % TQ_PW == 0 || TQ_PW % bs == 0;
 }
 
-idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, idx_t rows_above)
+template <typename T> static idx_t tsqr_factor_plain(MatV<T> A, MatV<T> H, T *taus, int *reason, idx_t rows_above)
 {
 	const idx_t m = A.nrows, n = A.ncols, ld = A.cs, bs = H.nrows;
 	hipStream_t s = ctx().stream;
 	const int npan = (int) ((n + TQ_PW - 1) / TQ_PW);
 	const int ldc = ((int) n + 63) & ~63;
 	const int typ = ldc, ldz = ldc;
-	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * 8), sp((size_t) TQ_NB * 256 * 8);
-	// workspace (all fp64): G (NG x 4096), N1, N3, Gf (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64), Td, Md (npan x 4096 each),
-	//                       Z, B (npan x 64 x ldz each), Mn (4096), top, A1s (4096 each), Yn (64 x typ); then the status words
+	constexpr int RPV = TqVec<T>::RPV;
+	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * sizeof(T)), sp((size_t) TQ_NB * 256 * sizeof(T));
+	// fp64 workspace: G (NG x 4096), N1, N3, Gf (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64), Td, Md (npan x 4096 each),
+	//                 Z, B (npan x 64 x ldz each); in the scalar type: Mn (4096), top, A1s (4096 each), Yn (64 x typ); then the status words
 	const size_t nd = (size_t) TQ_NG * 4096 + 3 * 4096 + (size_t) TQ_NG * 64 * ldc + (size_t) TQ_NG * 256 + (size_t) n + 64 + (size_t) 2 * npan * 4096 +
-			  (size_t) 2 * npan * 64 * ldz + 3 * 4096 + (size_t) 64 * typ;
-	Scratch small(nd * 8 + 2048);
+			  (size_t) 2 * npan * 64 * ldz;
+	Scratch small(nd * 8 + (3 * 4096 + (size_t) 64 * typ) * sizeof(T) + 2048);
 	double *G = small.as<double>();
 	double *N1 = G + (size_t) TQ_NG * 4096, *N3 = N1 + 4096, *Gf = N3 + 4096, *C = Gf + 4096;
 	double *S = C + (size_t) TQ_NG * 64 * ldc, *abv = S + (size_t) TQ_NG * 256;
 	double *Td = abv + n + 64, *Md = Td + (size_t) npan * 4096, *Z = Md + (size_t) npan * 4096, *Bx = Z + (size_t) npan * 64 * ldz;
-	double *Mn = Bx + (size_t) npan * 64 * ldz, *top = Mn + 4096, *A1s = top + 4096, *Yn = A1s + 4096;
+	T *Mn = reinterpret_cast<T *>(Bx + (size_t) npan * 64 * ldz), *top = Mn + 4096, *A1s = top + 4096, *Yn = A1s + 4096;
 	int *stat = reinterpret_cast<int *>(Yn + (size_t) 64 * typ);
 	FH_HIP(hipMemsetAsync(stat, 0, 2048, s));
 	FH_HIP(hipMemsetAsync(abv, 0, (size_t) (n + 64) * 8, s));
 	if (rows_above > 0)
-		hipLaunchKernelGGL(tq_above_kernel<double>, dim3((unsigned) n), dim3(256), 0, s, (const double *) A.p, (long) ld, (int) rows_above, abv);
+		hipLaunchKernelGGL(tq_above_kernel<T>, dim3((unsigned) n), dim3(256), 0, s, (const T *) A.p, (long) ld, (int) rows_above, abv);
 	const bool cross = bs > TQ_PW && npan > 1;
 	if (cross)
 		FH_HIP(hipMemsetAsync(Z, 0, (size_t) npan * 64 * ldz * 8, s));
@@ -3143,7 +3208,7 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, i
 		const int nstrip = t == 0 ? 1 : (t + TQ_TS - 1) / TQ_TS;
 		for (int st = 0; st < nstrip; ++st) {
 			const int off = st * TQ_TS;
-			TqGram64Args g;
+			TqGramTArgs<T> g;
 			g.P = A.p + (long) c0 * ld + c0;
 			g.X = A.p + (long) (cx + off) * ld + c0;
 			g.ld = ld;
@@ -3155,27 +3220,27 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, i
 				const int nslot = (TQ_PW + g.tp + 63) / 64;
 				g.nsub = 4 / nslot;
 			}
-			g.nchunks = (rows + 16 * g.nsub - 1) / (16 * g.nsub);
+			g.nchunks = (rows + 8 * RPV * g.nsub - 1) / (8 * RPV * g.nsub);
 			g.want_g = st == 0;
 			g.want_sq = first && st == 0; // (the range guard covers the first strip; tq_range_rest_kernel checks the others)
 			g.Gp = gp.as<double>();
-			g.Cp = cp.as<double>();
-			g.Sp = sp.as<double>();
+			g.Cp = cp.as<T>();
+			g.Sp = sp.as<T>();
 			g.stat = stat;
 			g.c0 = c0;
 			g.A1s = A1s;
 			const int nb = g.nchunks < ncu ? g.nchunks : ncu; // one persistent workgroup per CU (<= TQ_NB partial sums)
 			{
-				ProfScope prof(3, (double) rows * 8.0 * ((double) w + (double) g.t));
+				ProfScope prof(3, (double) rows * (double) sizeof(T) * ((double) w + (double) g.t));
 				switch (g.tp / 32) {
-				case 0: hipLaunchKernelGGL(tq_gram64_kernel<0>, dim3(nb), dim3(512), 0, s, g); break;
-				case 2: hipLaunchKernelGGL(tq_gram64_kernel<2>, dim3(nb), dim3(512), 0, s, g); break;
-				case 4: hipLaunchKernelGGL(tq_gram64_kernel<4>, dim3(nb), dim3(512), 0, s, g); break;
-				default: hipLaunchKernelGGL(tq_gram64_kernel<6>, dim3(nb), dim3(512), 0, s, g); break;
+				case 0: hipLaunchKernelGGL((tq_gramT_kernel<T, 0>), dim3(nb), dim3(512), 0, s, g); break;
+				case 2: hipLaunchKernelGGL((tq_gramT_kernel<T, 2>), dim3(nb), dim3(512), 0, s, g); break;
+				case 4: hipLaunchKernelGGL((tq_gramT_kernel<T, 4>), dim3(nb), dim3(512), 0, s, g); break;
+				default: hipLaunchKernelGGL((tq_gramT_kernel<T, 6>), dim3(nb), dim3(512), 0, s, g); break;
 				}
 			}
 			const int total = (g.want_g ? 4096 : 0) + 64 * g.tp + (g.want_sq ? 256 : 0);
-			hipLaunchKernelGGL(tq_reduce_kernel<double>, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, g.Gp, g.Cp, g.Sp, nb, g.tp, g.want_g, g.want_sq, G, C, ldc,
+			hipLaunchKernelGGL(tq_reduce_kernel<T>, dim3((total + 255) / 256, TQ_NG), dim3(256), 0, s, g.Gp, g.Cp, g.Sp, nb, g.tp, g.want_g, g.want_sq, G, C, ldc,
 					   cx + off - (c0 + w), S, stat, c0, Gf, stat + 128);
 			FH_HIP(hipGetLastError());
 		}
@@ -3184,7 +3249,7 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, i
 		const int c0 = k * TQ_PW;
 		const int w = (int) (n - c0 < TQ_PW ? n - c0 : TQ_PW);
 		const int t = (int) n - c0 - w;
-		TqPanelArgs<double> pa;
+		TqPanelArgs<T> pa;
 		pa.A = A.p;
 		pa.ld = ld;
 		pa.m = (int) m;
@@ -3212,14 +3277,14 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, i
 		pa.stat = stat;
 		pa.dbg = reinterpret_cast<long long *>(stat + 16);
 		ProfScope prof(4, 1.0);
-		hipLaunchKernelGGL(tq_panel_kernel<double>, dim3(1), dim3(TQ_PT), 0, s, pa);
+		hipLaunchKernelGGL(tq_panel_kernel<T>, dim3(1), dim3(TQ_PT), 0, s, pa);
 	};
 	if (n > TQ_PW + TQ_TS) {
-		hipLaunchKernelGGL(tq_range_rest_kernel<double>, dim3((unsigned) (n - (TQ_PW + TQ_TS))), dim3(256), 0, s, A.p, (long) ld, (int) m, TQ_PW + TQ_TS, stat);
+		hipLaunchKernelGGL(tq_range_rest_kernel<T>, dim3((unsigned) (n - (TQ_PW + TQ_TS))), dim3(256), 0, s, A.p, (long) ld, (int) m, TQ_PW + TQ_TS, stat);
 		FH_HIP(hipGetLastError());
 	}
 	auto tx_args = [&](int stage) {
-		TqTxArgs<double> ta;
+		TqTxArgs<T> ta;
 		ta.A = A.p;
 		ta.ld = ld;
 		ta.n = (int) n;
@@ -3247,12 +3312,12 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, i
 		if (two_stage && k == npan - 1) {
 			FH_HIP(hipEventRecord(side.xfork, s));
 			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
-			hipLaunchKernelGGL(tq_tx_kernel<double>, dim3(npan - 1), dim3(256), 0, side.tx, tx_args(1));
+			hipLaunchKernelGGL(tq_tx_kernel<T>, dim3(npan - 1), dim3(256), 0, side.tx, tx_args(1));
 		}
 		launch_gram(c0, w, c0 + w, t, k == 0);
 		launch_panel(k);
 		if (t > 0) {
-			TqYArgs<double> ya;
+			TqYArgs<T> ya;
 			ya.A = A.p;
 			ya.ld = ld;
 			ya.r0 = c0;
@@ -3275,32 +3340,32 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, i
 			ya.check_range = k == 0;
 			ya.range_cols = t < TQ_TS ? t : TQ_TS;
 			ya.mrows = (int) m;
-			hipLaunchKernelGGL(tq_y_kernel<double>, dim3((t + 15) / 16), dim3(256), 0, s, ya);
+			hipLaunchKernelGGL(tq_y_kernel<T>, dim3((t + 15) / 16), dim3(256), 0, s, ya);
 		} else {
-			hipLaunchKernelGGL(tq_top_kernel<double>, dim3(1), dim3(256), 0, s, A.p, (long) ld, c0, c0, w, (const double *) top, (const int *) stat);
+			hipLaunchKernelGGL(tq_top_kernel<T>, dim3(1), dim3(256), 0, s, A.p, (long) ld, c0, c0, w, (const T *) top, (const int *) stat);
 		}
 		if (two_stage && k == npan - 1) {
 			// stage 2 reads this panel's R block and M: beside the update below (which writes V below that block only)
 			FH_HIP(hipEventRecord(side.xfork, s));
 			FH_HIP(hipStreamWaitEvent(side.tx, side.xfork, 0));
-			hipLaunchKernelGGL(tq_tx_kernel<double>, dim3(npan - 1), dim3(256), 0, side.tx, tx_args(2));
+			hipLaunchKernelGGL(tq_tx_kernel<T>, dim3(npan - 1), dim3(256), 0, side.tx, tx_args(2));
 			FH_HIP(hipEventRecord(side.xdone, side.tx));
 		}
 		const int r1 = c0 + w;
 		const int rows = (int) (m - r1);
 		if (rows > 0) {
-			TqUpd64Args ua;
+			TqUpdTArgs<T> ua;
 			ua.P = A.p + (long) c0 * ld + r1;
 			ua.ld = ld;
 			ua.rows = rows;
 			ua.w = w;
 			ua.Yn = Yn;
 			ua.typ = typ;
-			ua.Mn = Md + (size_t) k * 4096;
-			ua.nchunks = (rows + 31) / 32;
+			ua.Mn = Mn;
+			ua.nchunks = (rows + 16 * RPV - 1) / (16 * RPV);
 			ua.stat = stat;
 			ua.c0 = c0;
-			const bool v2 = r1 % 2 == 0;
+			const bool v2 = r1 % RPV == 0;
 			const int nwg = ua.nchunks < ncu ? ua.nchunks : ncu; // one persistent 512-thread workgroup per CU
 			// strips of at most 192 columns; V = P M (it overwrites the panel) rides on the last one
 			int from = 0;
@@ -3313,11 +3378,11 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, i
 				ua.ts = ts;
 				ua.X = A.p + (long) (c0 + w + from) * ld + r1;
 				ua.do_v = last;
-				ProfScope prof(2, (double) rows * 8.0 * ((double) w + 2.0 * (double) ts + (last ? (double) w : 0.0)));
+				ProfScope prof(2, (double) rows * (double) sizeof(T) * ((double) w + 2.0 * (double) ts + (last ? (double) w : 0.0)));
 				if (v2)
-					hipLaunchKernelGGL(tq_update64_kernel<true>, dim3(nwg), dim3(512), 0, s, ua);
+					hipLaunchKernelGGL((tq_updateT_kernel<T, true>), dim3(nwg), dim3(512), 0, s, ua);
 				else
-					hipLaunchKernelGGL(tq_update64_kernel<false>, dim3(nwg), dim3(512), 0, s, ua);
+					hipLaunchKernelGGL((tq_updateT_kernel<T, false>), dim3(nwg), dim3(512), 0, s, ua);
 				from += ts;
 				if (last)
 					break;
@@ -3329,9 +3394,9 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, i
 		FH_HIP(hipStreamWaitEvent(s, side.xdone, 0));
 	} else if (cross) {
 		if (bs <= (TQ_TX_MAXL + 1) * TQ_PW)
-			hipLaunchKernelGGL(tq_tx_kernel<double>, dim3(npan - 1), dim3(256), 0, s, tx_args(0));
+			hipLaunchKernelGGL(tq_tx_kernel<T>, dim3(npan - 1), dim3(256), 0, s, tx_args(0));
 		else
-			hipLaunchKernelGGL(tq_tx_general_kernel<double>, dim3(npan - 1), dim3(256), 0, s, tx_args(0));
+			hipLaunchKernelGGL(tq_tx_general_kernel<T>, dim3(npan - 1), dim3(256), 0, s, tx_args(0));
 		FH_HIP(hipGetLastError());
 	}
 	int *st = ctx().pinned_ints();
@@ -3339,6 +3404,12 @@ idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, i
 	FH_HIP(hipStreamSynchronize(s));
 	*reason = st[0] ? st[2] : TQ_OK;
 	return st[0] ? (idx_t) st[1] : n;
+}
+
+
+idx_t tsqr_factor64(MatV<double> A, MatV<double> H, double *taus, int *reason, idx_t rows_above)
+{
+	return tsqr_factor_plain<double>(A, H, taus, reason, rows_above);
 }
 
 } // namespace fh

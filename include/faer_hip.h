@@ -496,7 +496,9 @@ FAER_HIP_API void faer_hip_debug_lu_plan(size_t nb2_from, size_t pipe_from, size
 FAER_HIP_API long faer_hip_debug_qr_one_pass_columns(void);
 /* tests / A-B measurements: 0 = the one-pass QR path applies a panel and forms the next panel's Gram products in separate launches (the
  * round 3-5 schedule), 1 (default) = in one pass per panel with the next panel's kernel beside its second half (csrc/tsqr.hip), 2 = the
- * same without the raw copy of the panel (what matrices of more than 4.19 M rows run: V = P M as a launch of its own behind U2). */
+ * same without the raw copy of the panel (what matrices of more than 4.19 M rows run: V = P M as a launch of its own behind U2), 3 = the
+ * plain schedule (Gram, panel, y, update per panel) on the streaming kernels of the fp64 instantiation, for fp32 data with 16-byte aligned
+ * columns (5e5 x 256: 1.80 ms against 1.68 fused -- its panel kernels are not hidden; ahead of the fused schedule below ~50000 rows). */
 FAER_HIP_API void faer_hip_debug_qr_fused(int on);
 /* tests / A-B measurements: 0 = fp64 matrices never take the one-pass tall-skinny QR path (the classic path of rounds 1-6 runs), 1 (default) =
  * they take it under the same shape rule as fp32 (rows >= 1024, rows >= 3 cols, cols <= 512, unit row stride; fp64 also: even column stride, 16-byte aligned columns). */

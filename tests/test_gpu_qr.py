@@ -512,12 +512,14 @@ def test_qr_norm_l2_scaling_cases(oracle, m, n, factor):
     assert np.abs(h - rh)[fin & tu].max(initial=0) <= 512 * max(m, n) * e * max(1.0, np.abs(rh[fin & tu]).max(initial=0))
 
 
-@pytest.mark.parametrize("mode", [0, 2])
-@pytest.mark.parametrize("m,n,bs", [(40000, 256, 256), (30001, 300, 64), (33000, 384, 128)])
+@pytest.mark.parametrize("mode", [0, 2, 3])
+@pytest.mark.parametrize("m,n,bs", [(40000, 256, 256), (30001, 300, 64), (33000, 384, 128), (20000, 70, 64)])
 def test_qr_tall_other_schedules_still_agree_with_the_oracle(oracle, m, n, bs, mode):
     """faer_hip_debug_qr_fused(0): the one-pass path with update and Gram products as separate launches (the schedule of rounds 3-5, kept
-    for A/B measurements); (2): the fused schedule without the raw copy of the panel (what matrices of more than 4.19 M rows run).  Both
-    must keep producing the reference's R / V / T -- the default schedule is what every other test runs."""
+    for A/B measurements); (2): the fused schedule without the raw copy of the panel (what matrices of more than 4.19 M rows run); (3): the
+    plain schedule on the streaming kernels written for fp64 data at the end of round 6, instantiated for fp32 (columns that are not 16-byte
+    aligned -- 30001 rows -- stay on the default schedule).  All must keep producing the reference's R / V / T -- the default schedule is
+    what every other test runs."""
     F = init_gpu()
     rng = np.random.default_rng(m + n)
     a = np.asfortranarray(rng.standard_normal((m, n)).astype(np.float32))
