@@ -614,3 +614,16 @@ def test_qr_moderately_tall_one_pass_shape_rule(oracle, m, n, bs, cols, dtype):
     q = q_from(F, dqr, dh, m, dtype).astype(np.float64)
     assert np.abs(q @ np.triu(qr) - a).max() <= tol
     assert np.abs(q.T @ q - np.eye(m)).max() <= tol
+
+
+def test_qr_dispatch_fuzz_vs_oracle():
+    """tools/gpu_qr_fuzz.py: random shapes, block sizes of Q_coeff, dtypes and views (row offsets, padded and odd column strides, a
+    dependent column now and then) over the QR dispatch -- whole-matrix one-pass path, one-pass panels inside the classic recursion,
+    rebuilt T blocks -- against the oracle; nothing outside a view may change"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_qr_fuzz.py"), "80", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "80 cases, 0 bad" in r.stdout
