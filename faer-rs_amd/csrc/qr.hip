@@ -560,13 +560,15 @@ template <typename T> static void qr_rec(MatV<T> P, MatV<T> Tb, idx_t row_abs, i
 	// instead of 8 cooperative leaves (one all-reduce per column) and the level-3 steps between them.  A panel it refuses (ill
 	// conditioned, a column failing the reference's rank test, ...) is untouched and goes down the recursion as before.
 	const bool onepass_tall = P.nrows >= 256;
-	if (w <= 64 && tsqr_panel_applicable(m, w, P.rs, P.cs, P.p, (int) sizeof(T))) {
+	bool first_done = false; // a 128-column node whose first panel the one-pass path completed (and applied to the second) before it stopped
+	if ((w <= 64 || w == 128) && tsqr_panel_applicable(m, w, P.rs, P.cs, P.p, (int) sizeof(T))) {
 		Scratch taus((size_t) w * sizeof(T));
 		int reason = 0;
 		// (rows above the panel in the parent count in the rank test: row_abs of them)
 		const idx_t done = tsqr_run(P, MatV<T>{Tb.p, w, w, Tb.rs, Tb.cs}, taus.as<T>(), &reason, row_abs);
 		if (done == w)
 			return;
+		first_done = w == 128 && done == 64; // T11 is complete (one panel), the second panel is untouched but updated
 	}
 	idx_t w1 = ((w / 2 + QR_PW - 1) / QR_PW) * QR_PW;
 	if (w1 >= w)
@@ -577,11 +579,15 @@ template <typename T> static void qr_rec(MatV<T> P, MatV<T> Tb, idx_t row_abs, i
 		if (w1 >= w)
 			w1 = w - 64;
 	}
+	if (first_done)
+		w1 = 64;
 	const idx_t w2 = w - w1;
 	MatV<T> V1 = P.sub(0, 0, m, w1), B = P.sub(0, w1, m, w2);
 	MatV<T> T11 = Tb.sub(0, 0, w1, w1), T12 = Tb.sub(0, w1, w1, w2), T22 = Tb.sub(w1, w1, w2, w2);
-	qr_rec<T>(V1, T11, row_abs, col_abs, wk);
-	apply_block_householder_dev<T>(V1.c(), T11.c(), B, true); // factor.rs:241-249
+	if (!first_done) {
+		qr_rec<T>(V1, T11, row_abs, col_abs, wk);
+		apply_block_householder_dev<T>(V1.c(), T11.c(), B, true); // factor.rs:241-249
+	}
 	if (m > w1) {
 		MatV<T> P2 = P.sub(w1, w1, m - w1, w2);
 		qr_rec<T>(P2, T22, row_abs + w1, col_abs + w1, wk);

@@ -3154,7 +3154,9 @@ bool tsqr_panel_applicable(idx_t m, idx_t w, idx_t rs, idx_t cs, const void *p, 
 	if (g_tq_panels.load() == 0 || (elem == 8 && g_tq_f64.load() == 0))
 		return false;
 	// (ONE panel: any width up to 64 -- the block-size rule of tsqr_applicable is about panels that share a block of Q_coeff)
-	if (rs != 1 || cs < m || w < 16 || w > TQ_PW || m < 256 || m < 4 * w || m >= (1L << 30))
+	// (... or a node of exactly two panels, 128 columns -- faer's block size of Q_coeff from N = 4096 on: one call, one read-back, the
+	// first panel applied to the second by the path's own update launch, T12 from its small matrices)
+	if (rs != 1 || cs < m || w < 16 || (w > TQ_PW && w != 2 * TQ_PW) || m < 256 || m < 4 * w || m >= (1L << 30))
 		return false;
 	if (elem == 8 && (cs % 2 != 0 || (uintptr_t) p % 16 != 0))
 		return false;

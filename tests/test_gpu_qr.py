@@ -567,19 +567,23 @@ def test_qr_classic_path_one_pass_panels_vs_oracle(oracle, m, n, bs, dtype):
     assert np.abs(out[0][0] - out[1][0]).max() <= 8 * tol
 
 
+@pytest.mark.parametrize("bs", [64, 128])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_qr_classic_path_one_pass_panels_rank_deficient(oracle, dtype):
+def test_qr_classic_path_one_pass_panels_rank_deficient(oracle, dtype, bs):
     """a rank-deficient matrix whose dependent columns sit in a LATER panel: the one-pass panel must refuse it (rank test with the rows
     above the panel counted, factor.rs:52-58) and the result is the oracle's rank and pattern of skipped reflectors"""
     F = init_gpu()
     rng = np.random.default_rng(21)
     m, n, r = 2048, 512, 200
     a = np.asfortranarray((rnd(rng, m, r) @ rnd(rng, r, n)).astype(dtype))
-    ref, rh = a.copy(order="F"), np.zeros((64, n), dtype=dtype, order="F")
+    # (blocks of 128: the node of two panels whose SECOND panel holds the first dependent column -- the one-pass path completes the first
+    # panel, applies it, stops; the recursion takes the second panel and T12)
+    ref, rh = a.copy(order="F"), np.zeros((bs, n), dtype=dtype, order="F")
     rk = oracle.qr_in_place(ref, rh)
-    dqr, dh = to_dev(a), to_dev(np.zeros((64, n), dtype=dtype))
+    dqr, dh = to_dev(a), to_dev(np.zeros((bs, n), dtype=dtype))
     assert F.qr_factor_in_place(dqr, dh) == rk
     assert r <= rk < n
+    assert np.array_equal(np.isinf(to_host(dh)), np.isinf(rh))
     e = EPS[np.dtype(dtype)]
     q = q_from(F, dqr, dh, m, dtype).astype(np.float64)
     assert np.abs(q @ np.triu(to_host(dqr)).astype(np.float64) - a).max() <= 256 * np.sqrt(m) * e * np.abs(a).max()
