@@ -325,6 +325,9 @@ template <typename T> struct GemmExtra {
 	// than helper_margin remain in an XCD's share.  The caller orders consumers of dst behind BOTH launches.
 	int *ticket = nullptr;
 	int helper_wgs = 0, helper_margin = 0;
+	// short-wide / tall-narrow FULL output with a deep K (the V^H A product of a QR block application, 128 x n with K = rows): 128 x 128
+	// tiles with more K slices instead of the 64 x 64 tiles the tile-count rule picks (square QR N = 8192: -3 %, tools/gpu_qr_square_gemm_ab.py)
+	bool prefer_big_tiles = false;
 };
 
 // dst(kind) <- [dst +] alpha * A * diag * B        (gemm.hip)

@@ -1325,7 +1325,7 @@ void gemm_dev(MatV<T> C, DstKind kind, bool add, MatV<const T> A, MatV<const T> 
 		big = false;
 	// variant 6 (A/B, tools/gpu_qr_square_gemm_ab.py): short-wide / tall-narrow FULL outputs with a deep K -- the V^H A products of the QR
 	// block applications, 128 x n with K = rows -- on 128 x 128 tiles with more K slices instead of 64 x 64 tiles
-	if (variant == 6 && !big && kind == DST_FULL && k >= 2048 && ((m >= 128 && n >= 1024) || (n >= 128 && m >= 1024)))
+	if ((variant == 6 || (variant == 0 && ex.prefer_big_tiles)) && !big && kind == DST_FULL && k >= 2048 && ((m >= 128 && n >= 1024) || (n >= 128 && m >= 1024)))
 		big = true;
 	// Eight wavefronts of 64 x 64 per workgroup (128 x 256 block tile, one workgroup per CU) for large plain FULL products
 	// with a deep K: the A tile is shared by four wavefront columns, the B tile by two rows -- 25 % fewer global loads and

@@ -45,8 +45,11 @@ template <typename T> static void apply_block_householder_dev(MatV<const T> V, M
 	MatV<T> Mtop = M.sub(0, 0, b, k), Mbot = M.sub(b, 0, m - b, k);
 	// tmp = V_top^H M_top + V_bot^H M_bot   (householder.rs:541-563)
 	matmul_triangular_dev<T>(tmp, 0, false, Vtop.t(), 6 /*unit upper*/, Mtop.c(), 0, (T) 1);
-	if (m > b)
-		gemm_dev<T>(tmp, DST_FULL, true, Vbot.t(), Mbot.c(), (T) 1);
+	if (m > b) {
+		GemmExtra<T> big;
+		big.prefer_big_tiles = true;
+		gemm_dev<T>(tmp, DST_FULL, true, Vbot.t(), Mbot.c(), (T) 1, &big);
+	}
 	// tmp <- T^-H tmp or T^-1 tmp          (householder.rs:564-578)
 	if (forward)
 		trsm_lower_dev<T>(Tf.t(), false, tmp);
