@@ -3184,6 +3184,9 @@ template <typename T> static idx_t tsqr_factor_plain(MatV<T> A, MatV<T> H, T *ta
 	const int ldc = ((int) n + 63) & ~63;
 	const int typ = ldc, ldz = ldc;
 	constexpr int RPV = TqVec<T>::RPV;
+	// (the streaming kernels load 16-byte vectors down the columns without bounds checks: tsqr_applicable64 / tsqr_panel_applicable /
+	// tsqr_factor's schedule 3 admit nothing else)
+	FH_CHECK(A.rs == 1 && ld % RPV == 0 && (uintptr_t) A.p % 16 == 0, "tsqr: the plain schedule needs 16-byte aligned columns");
 	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * sizeof(T)), sp((size_t) TQ_NB * 256 * sizeof(T));
 	// fp64 workspace: G (NG x 4096), N1, N3, Gf (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64), Td, Md (npan x 4096 each),
 	//                 Z, B (npan x 64 x ldz each); in the scalar type: Mn (4096), top, A1s (4096 each), Yn (64 x typ); then the status words
