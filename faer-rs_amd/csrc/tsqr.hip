@@ -1,5 +1,7 @@
 // One-pass tall-skinny Householder QR for gfx950 (fp32 data; fp64 data: the section "fp64 data" further down): faer's (V, T, R) -- qr/no_pivoting/factor.rs:137-256,
 // householder.rs:21-23,59-107,132-272 -- without a cross-workgroup reduction per column.
+// Callers (qr.hip): geqrf_dev for whole matrices of >= 1024 rows and >= 3 rows per column (tsqr_applicable / tsqr_applicable64), and the
+// classic path's recursion for single panels and two-panel nodes of any matrix (tsqr_panel_applicable, `rows_above`).
 //
 // The classic path (qr.hip) follows the reference's recursion: every column of a panel costs one device-wide
 // all-reduce and every level of the recursion a handful of dependent launches; a 5e5 x 256 matrix is streamed
