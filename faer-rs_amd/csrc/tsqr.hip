@@ -2149,7 +2149,7 @@ template <typename T, bool VEC> static __device__ __forceinline__ void tq_stv(T 
 // KS g .. KS g + KS - 1 of its column (KS = 2 RPV) as k-slices -- the order of the rows inside a Gram sum is free.
 // Balance (fp64) at t = 192: 58 tiles x 4 MFMAs x 64 cycles per 32 KB chunk and four SIMDs = 4.5-4.8 TB/s chip-wide at the fp64
 // matrix-core peak: the kernel is bound by both at once.
-template <typename T, int NC> __global__ __launch_bounds__(512, 1) void tq_gramT_kernel(const TqGramTArgs<T> a)
+template <typename T, int NC, bool VEC> __global__ __launch_bounds__(512, 1) void tq_gramT_kernel(const TqGramTArgs<T> a)
 {
 	typedef typename TqVec<T>::v vec_t;
 	typedef typename Mfma<T>::acc_t cacc_t;
@@ -2194,6 +2194,19 @@ template <typename T, int NC> __global__ __launch_bounds__(512, 1) void tq_gramT
 		roff[i] = act[i] ? SR * si + RPV * q : RPV * q;
 		ldsoff[i] = (si * ncolp + ci) * LP + RPV * q; // (si * ncolp + ci < 256 always)
 	}
+	// unconditional load of RPV consecutive rows: one 16-byte load, or -- columns that are not 16-byte aligned (a view that starts at an
+	// odd row, an odd column stride) -- RPV scalar loads, still without a branch
+	auto ldu = [](const T *p) {
+		vec_t v;
+		if (VEC) {
+			v = *reinterpret_cast<const vec_t *>(p);
+		} else {
+#pragma unroll
+			for (int x = 0; x < RPV; ++x)
+				v[x] = p[x];
+		}
+		return v;
+	};
 	const int crows = SR * nsub;
 	// A workgroup owns a contiguous run of FULL chunks; the partial chunk at the end of the matrix (if any) is the last workgroup's
 	// epilogue.  The main loop is straight-line code: unconditional 16-byte loads, counted waits.  (Loads under per-lane branches --
@@ -2213,7 +2226,7 @@ template <typename T, int NC> __global__ __launch_bounds__(512, 1) void tq_gramT
 			for (int x = 0; x < RPV; ++x)
 				v[x] = (T) 0;
 			if (c < a.w)
-				v = *reinterpret_cast<const vec_t *>(a.P + (long) c * a.ld + RPV * rp);
+				v = ldu(a.P + (long) c * a.ld + RPV * rp);
 			*reinterpret_cast<vec_t *>(a.A1s + c * 64 + RPV * rp) = v;
 		}
 	}
@@ -2223,7 +2236,7 @@ template <typename T, int NC> __global__ __launch_bounds__(512, 1) void tq_gramT
 		const long r0 = (long) (first + jj) * crows;
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
-			st[i] = *reinterpret_cast<const vec_t *>(colp[i] + r0 + roff[i]);
+			st[i] = ldu(colp[i] + r0 + roff[i]);
 	};
 	auto stage = [&](int j, const vec_t (&st)[4], double count) { // into LDS half j & 1
 		T *dst = sm[j & 1];
@@ -2332,7 +2345,7 @@ template <typename T, int NC> __global__ __launch_bounds__(512, 1) void tq_gramT
 			for (int x = 0; x < RPV; ++x)
 				s0[i][x] = (T) 0;
 			if (act[i])
-				s0[i] = tq_ldv<T, true>(colp[i] + r0, roff[i], a.rows - (int) r0);
+				s0[i] = tq_ldv<T, VEC>(colp[i] + r0, roff[i], a.rows - (int) r0);
 		}
 		__syncthreads();
 		stage(0, s0, 1.0);
@@ -3160,8 +3173,7 @@ bool tsqr_panel_applicable(idx_t m, idx_t w, idx_t rs, idx_t cs, const void *p, 
 	// first panel applied to the second by the path's own update launch, T12 from its small matrices)
 	if (rs != 1 || cs < m || w < 16 || (w > TQ_PW && w != 2 * TQ_PW) || m < 256 || m < 4 * w || m >= (1L << 30))
 		return false;
-	if (elem == 8 && (cs % 2 != 0 || (uintptr_t) p % 16 != 0))
-		return false;
+	(void) p;
 	if (elem == 4 && 16.0 * 1.1920928955078125e-07 * (double) m >= 1.0)
 		return false;
 	return true;
@@ -3173,8 +3185,7 @@ bool tsqr_applicable64(idx_t m, idx_t n, idx_t rs, idx_t cs, idx_t bs, const voi
 		return false;
 	if (rs != 1 || cs < m || n < 1 || n > 512 || m < g_tq_min_rows.load() || m < g_tq_min_aspect.load() * n || m >= (1L << 30))
 		return false;
-	if (cs % 2 != 0 || (uintptr_t) p % 16 != 0) // 16-byte accesses down the columns (faer's Mat pads the column stride to 64 bytes)
-		return false;
+	(void) p; // (columns that are not 16-byte aligned run the scalar-access variants of the streaming kernels)
 	return bs % TQ_PW == 0 || TQ_PW % bs == 0;
 }
 
@@ -3188,7 +3199,10 @@ template <typename T> static idx_t tsqr_factor_plain(MatV<T> A, MatV<T> H, T *ta
 	constexpr int RPV = TqVec<T>::RPV;
 	// (the streaming kernels load 16-byte vectors down the columns without bounds checks: tsqr_applicable64 / tsqr_panel_applicable /
 	// tsqr_factor's schedule 3 admit nothing else)
-	FH_CHECK(A.rs == 1 && ld % RPV == 0 && (uintptr_t) A.p % 16 == 0, "tsqr: the plain schedule needs 16-byte aligned columns");
+	FH_CHECK(A.rs == 1, "tsqr: unit row stride");
+	// 16-byte accesses down the columns where they are aligned (faer's Mat pads the column stride to 64 bytes; a view that starts at an odd
+	// row or has an odd column stride runs the same kernels with scalar accesses)
+	const bool vec = ld % RPV == 0 && (uintptr_t) A.p % 16 == 0;
 	Scratch gp((size_t) TQ_NB * 4096 * 8), cp((size_t) TQ_NB * 64 * TQ_TS * sizeof(T)), sp((size_t) TQ_NB * 256 * sizeof(T));
 	// fp64 workspace: G (NG x 4096), N1, N3, Gf (4096 each), C (NG x 64 x ldc), S (NG x 256), abv (n + 64), Td, Md (npan x 4096 each),
 	//                 Z, B (npan x 64 x ldz each); in the scalar type: Mn (4096), top, A1s (4096 each), Yn (64 x typ); then the status words
@@ -3240,10 +3254,22 @@ template <typename T> static idx_t tsqr_factor_plain(MatV<T> A, MatV<T> H, T *ta
 			{
 				ProfScope prof(3, (double) rows * (double) sizeof(T) * ((double) w + (double) g.t));
 				switch (g.tp / 32) {
-				case 0: hipLaunchKernelGGL((tq_gramT_kernel<T, 0>), dim3(nb), dim3(512), 0, s, g); break;
-				case 2: hipLaunchKernelGGL((tq_gramT_kernel<T, 2>), dim3(nb), dim3(512), 0, s, g); break;
-				case 4: hipLaunchKernelGGL((tq_gramT_kernel<T, 4>), dim3(nb), dim3(512), 0, s, g); break;
-				default: hipLaunchKernelGGL((tq_gramT_kernel<T, 6>), dim3(nb), dim3(512), 0, s, g); break;
+				case 0: if (vec)
+						hipLaunchKernelGGL((tq_gramT_kernel<T, 0, true>), dim3(nb), dim3(512), 0, s, g);
+					else
+						hipLaunchKernelGGL((tq_gramT_kernel<T, 0, false>), dim3(nb), dim3(512), 0, s, g); break;
+				case 2: if (vec)
+						hipLaunchKernelGGL((tq_gramT_kernel<T, 2, true>), dim3(nb), dim3(512), 0, s, g);
+					else
+						hipLaunchKernelGGL((tq_gramT_kernel<T, 2, false>), dim3(nb), dim3(512), 0, s, g); break;
+				case 4: if (vec)
+						hipLaunchKernelGGL((tq_gramT_kernel<T, 4, true>), dim3(nb), dim3(512), 0, s, g);
+					else
+						hipLaunchKernelGGL((tq_gramT_kernel<T, 4, false>), dim3(nb), dim3(512), 0, s, g); break;
+				default: if (vec)
+						hipLaunchKernelGGL((tq_gramT_kernel<T, 6, true>), dim3(nb), dim3(512), 0, s, g);
+					else
+						hipLaunchKernelGGL((tq_gramT_kernel<T, 6, false>), dim3(nb), dim3(512), 0, s, g); break;
 				}
 			}
 			const int total = (g.want_g ? 4096 : 0) + 64 * g.tp + (g.want_sq ? 256 : 0);
@@ -3372,7 +3398,7 @@ template <typename T> static idx_t tsqr_factor_plain(MatV<T> A, MatV<T> H, T *ta
 			ua.nchunks = (rows + 16 * RPV - 1) / (16 * RPV);
 			ua.stat = stat;
 			ua.c0 = c0;
-			const bool v2 = r1 % RPV == 0;
+			const bool v2 = vec && r1 % RPV == 0;
 			const int nwg = ua.nchunks < ncu ? ua.nchunks : ncu; // one persistent 512-thread workgroup per CU
 			// strips of at most 192 columns; V = P M (it overwrites the panel) rides on the last one
 			int from = 0;

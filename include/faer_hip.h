@@ -501,7 +501,7 @@ FAER_HIP_API long faer_hip_debug_qr_one_pass_columns(void);
  * columns (5e5 x 256: 1.80 ms against 1.68 fused -- its panel kernels are not hidden; ahead of the fused schedule below ~50000 rows). */
 FAER_HIP_API void faer_hip_debug_qr_fused(int on);
 /* tests / A-B measurements: 0 = fp64 matrices never take the one-pass tall-skinny QR path (the classic path of rounds 1-6 runs), 1 (default) =
- * they take it under the same shape rule as fp32 (rows >= 1024, rows >= 3 cols, cols <= 512, unit row stride; fp64 also: even column stride, 16-byte aligned columns). */
+ * they take it under the same shape rule as fp32 (rows >= 1024, rows >= 3 cols, cols <= 512, unit row stride; columns that are not 16-byte aligned run scalar-access variants of the kernels). */
 FAER_HIP_API void faer_hip_debug_qr_one_pass_f64(int on);
 /* tests / A-B measurements: 0 = the classic QR path (square / wide matrices, rejected panels) factors its panels by the recursion down to
  * the 8-column cooperative leaf as in rounds 1-6, 1 (default) = a panel of up to 64 columns with at least 256 rows (and 4 rows per column) takes the one-pass
